@@ -1,0 +1,423 @@
+#!/opt/conda/bin/python3.9
+"""Generate golden vectors from the REAL reference + REAL scikit-image.
+
+Run in the build container only (it needs ``/root/reference`` and the conda
+interpreter that has scikit-image 0.18.3)::
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+
+It makes a scratch, importable copy of ``/root/reference/magmap`` under ``/tmp``
+(two files need ``from __future__ import annotations`` to import on Python 3.9),
+imports the real ``magmap.cv.{detector,stack_detect,chunking}`` and the real
+``skimage.feature.blob_log``, runs them on small seeded inputs and stores
+**inputs and outputs only** (``.npz`` data) next to this script.  No reference
+source is copied into the repository.
+
+Fixtures (all ``np.savez_compressed``):
+
+* ``bloblog_<case>.npz``   -- volume, parameters, sigma ladder, ordered raw peaks
+  with their float64 LoG values, pruned ``(z,y,x,sigma)``, a LoG cube crop.
+* ``detect_<case>.npz``    -- ``magmap.cv.detector.detect_blobs`` 11-column table.
+* ``blocks.npz``           -- ``setup_blocks`` / ``stack_splitter`` parameter sweep.
+* ``stack_<case>.npz``     -- ``detect_blobs_blocks``: per-block tables, final table.
+* ``prune.npz``            -- ``remove_close_blobs`` / ``StackPruner.prune_blobs_mp``
+  on hand-made tables (multi-matches, half-even averages, >1000-row chunking).
+"""
+import io
+import os
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCRATCH = "/tmp/mmx_refcopy"
+
+
+def _bootstrap():
+    if os.path.isdir(SCRATCH):
+        shutil.rmtree(SCRATCH)
+    os.makedirs(SCRATCH)
+    shutil.copytree("/root/reference/magmap", os.path.join(SCRATCH, "magmap"))
+    for rel in ("magmap/io/np_io.py", "magmap/io/importer.py"):
+        path = os.path.join(SCRATCH, rel)
+        with open(path) as f:
+            src = f.read()
+        with open(path, "w") as f:
+            f.write("from __future__ import annotations\n" + src)
+    sys.path.insert(0, SCRATCH)
+
+
+_bootstrap()
+
+import contextlib  # noqa: E402
+import warnings  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+import skimage  # noqa: E402
+import scipy  # noqa: E402
+from skimage.feature import blob as ski_blob  # noqa: E402
+from skimage.feature import blob_log, peak_local_max  # noqa: E402
+from skimage.util import img_as_float  # noqa: E402
+from scipy.ndimage import gaussian_laplace  # noqa: E402
+
+from magmap.settings import config  # noqa: E402
+from magmap.io import cli, np_io  # noqa: E402
+from magmap.cv import chunking, detector, stack_detect  # noqa: E402
+
+VERSIONS = dict(skimage=skimage.__version__, scipy=scipy.__version__, numpy=np.__version__,
+                python=sys.version.split()[0])
+
+
+def make_volume(seed, shape, n_blobs, dtype=np.uint16, amp=40000.0, blob_sigma=3.0,
+                bg_mean=500.0, bg_sd=50.0, margin=6, centres=None):
+    """Seeded Gaussian-blob volume (SURVEY.md section 8d generator)."""
+    rng = np.random.default_rng(seed)
+    vol = rng.normal(bg_mean, bg_sd, shape)
+    if centres is None:
+        lo = np.full(3, margin, dtype=float)
+        hi = np.asarray(shape, dtype=float) - margin
+        centres = rng.uniform(lo, hi, (n_blobs, 3))
+    zz, yy, xx = np.meshgrid(*[np.arange(s, dtype=float) for s in shape], indexing="ij")
+    for c in centres:
+        d2 = (zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2
+        np.maximum(vol, amp * np.exp(-d2 / (2 * blob_sigma ** 2)), out=vol)
+    vol = np.clip(vol, 0, 65535)
+    if dtype == np.uint16:
+        return vol.astype(np.uint16)
+    if dtype == np.uint8:
+        return (vol / 257.0).astype(np.uint8)
+    if dtype in (np.float32, np.float64):
+        return (vol / 65535.0).astype(dtype)
+    raise ValueError(dtype)
+
+
+def make_twoscale_volume(seed, shape, n_pairs, small=(30000.0, 1.0), big=(20000.0, 5.0), off=2.5):
+    """Small bright blobs riding on large dim ones: two scale-space maxima per site, so that
+    the sphere-overlap prune (skimage blob.py:146-187) actually removes rows."""
+    rng = np.random.default_rng(seed)
+    vol = rng.normal(500, 50, shape)
+    zz, yy, xx = np.meshgrid(*[np.arange(s, dtype=float) for s in shape], indexing="ij")
+    for _ in range(n_pairs):
+        c = rng.uniform(9, np.asarray(shape, dtype=float) - 9)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        for centre, (amp, bs) in ((c, big), (c + d * off, small)):
+            d2 = (zz - centre[0]) ** 2 + (yy - centre[1]) ** 2 + (xx - centre[2]) ** 2
+            vol += amp * np.exp(-d2 / (2 * bs ** 2))
+    return np.clip(vol, 0, 65535).astype(np.uint16)
+
+
+def quiet(fn, *args, **kwargs):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        return fn(*args, **kwargs)
+
+
+def setup_profile(names=None, **over):
+    """Real profile set-up through the reference's own CLI helper."""
+    names = names or ["/root/reference/profiles/roi_blobs.yaml"]
+    quiet(cli.setup_roi_profiles, names)
+    for i, prof in enumerate(config.roi_profiles):
+        prof["denoise_size"] = None
+        for k, v in over.items():
+            if isinstance(v, dict) and "per_channel" in v:
+                prof[k] = v["per_channel"][i]
+            else:
+                prof[k] = v
+    return config.roi_profiles
+
+
+def skimage_stages(image, min_sigma, max_sigma, num_sigma, threshold):
+    """Raw (ordered) peaks and cube through scikit-image's own functions (blob.py:470-512)."""
+    image_f = img_as_float(image)
+    max_s = np.full(image_f.ndim, max_sigma, dtype=float)
+    min_s = np.full(image_f.ndim, min_sigma, dtype=float)
+    scale = np.linspace(0, 1, num_sigma)[:, np.newaxis]
+    sig = scale * (max_s - min_s) + min_s
+    gl = [-gaussian_laplace(image_f, s) * np.mean(s) ** 2 for s in sig]
+    cube = np.stack(gl, axis=-1)
+    lm = peak_local_max(cube, threshold_abs=threshold, footprint=np.ones((3,) * 4),
+                        threshold_rel=0.0, exclude_border=(0,) * 4)
+    return sig, cube, lm
+
+
+def bloblog_case(name, vol, min_sigma, max_sigma, num_sigma, threshold=0.1, overlap=0.5):
+    res = blob_log(vol, min_sigma=min_sigma, max_sigma=max_sigma, num_sigma=num_sigma,
+                   threshold=threshold, overlap=overlap)
+    sig, cube, lm = skimage_stages(vol, min_sigma, max_sigma, num_sigma, threshold)
+    vals = cube[tuple(lm.T)] if lm.size else np.empty(0)
+    crop = tuple(slice(s // 4, s // 4 + min(16, s)) for s in vol.shape)
+    out = dict(volume=vol, min_sigma=min_sigma, max_sigma=max_sigma, num_sigma=num_sigma,
+               threshold=threshold, overlap=overlap, sigmas=sig, peaks=lm, peak_values=vals,
+               pruned=res, cube_crop=cube[crop], cube_crop_origin=np.array([c.start for c in crop]),
+               cube_dtype=str(cube.dtype), versions=repr(VERSIONS))
+    np.savez_compressed(os.path.join(HERE, "bloblog_%s.npz" % name), **out)
+    print("bloblog_%s: %d raw peaks -> %d blobs, cube %s" % (name, len(lm), len(res), cube.dtype))
+
+
+def detect_case(name, roi, channel, exclude_border=None, resolutions=((1., 1., 1.),),
+                names=None, **over):
+    config.resolutions = np.array(resolutions)
+    setup_profile(names, **over)
+    table = quiet(detector.detect_blobs, roi, channel, exclude_border)
+    profs = [{k: config.get_roi_profile(i)[k] for k in (
+        "min_sigma_factor", "max_sigma_factor", "num_sigma", "detection_threshold", "overlap")}
+        for i in range(2)]
+    np.savez_compressed(
+        os.path.join(HERE, "detect_%s.npz" % name), roi=roi,
+        channel=np.array(-1 if channel is None else channel),
+        exclude_border=np.array(-1 if exclude_border is None else exclude_border),
+        resolutions=np.array(resolutions), profiles=repr(profs),
+        table=np.empty((0, 11)) if table is None else table, is_none=table is None,
+        versions=repr(VERSIONS))
+    print("detect_%s: %s" % (name, None if table is None else table.shape))
+
+
+def blocks_cases():
+    sweep = []
+    cases = [
+        # shape, resolutions, segment_size, exclude_border, prune_tol_factor, denoise_size
+        ((64, 96, 96), (1., 1., 1.), 40, None, (1, 1, 1), None),
+        ((51, 200, 200), (6.6, 1.1, 1.1), 150, (1, 0, 0), (1, 0.9, 0.9), 25),
+        ((1024, 2048, 2048), (1., 1., 1.), 256, None, (1, 1, 1), None),
+        ((1024, 2048, 2048), (1., 1., 1.), 500, None, (1, 1, 1), 25),
+        ((100, 100, 100), (2.0, 0.5, 0.5), 30, (8, 1, 1), (1.5, 1.3, 1.3), 2000),
+        ((7, 13, 300), (1., 1., 1.), 50, (0, 3, 4), (1, 1, 1), None),
+        ((33, 47, 59), (0.7, 0.33, 0.33), 12.5, None, (1, 0.9, 0.9), None),
+    ]
+    out = {}
+    for i, (shape, res, seg, excl, ptf, dn) in enumerate(cases):
+        config.resolutions = np.array([res])
+        settings = setup_profile()[0]
+        settings["segment_size"] = seg
+        settings["exclude_border"] = excl
+        settings["prune_tol_factor"] = ptf
+        settings["denoise_size"] = dn
+        bl = quiet(stack_detect.setup_blocks, settings, shape)
+        grid = bl.sub_roi_slices.shape
+        sl = np.array([[[s.start, s.stop] for s in bl.sub_roi_slices[c]]
+                       for c in np.ndindex(*grid)]).reshape(grid + (3, 2))
+        pre = "c%d_" % i
+        out[pre + "shape"] = np.array(shape)
+        out[pre + "resolutions"] = np.array(res)
+        out[pre + "segment_size"] = np.array(seg)
+        out[pre + "exclude_border"] = np.array(-1 if excl is None else excl)
+        out[pre + "prune_tol_factor"] = np.array(ptf)
+        out[pre + "denoise_size"] = np.array(-1 if dn is None else dn)
+        out[pre + "slices"] = sl
+        out[pre + "offsets"] = bl.sub_rois_offsets
+        out[pre + "denoise_max_shape"] = np.array(
+            -1 if bl.denoise_max_shape is None else bl.denoise_max_shape)
+        out[pre + "tol"] = bl.tol
+        out[pre + "overlap_base"] = bl.overlap_base
+        out[pre + "overlap"] = bl.overlap
+        out[pre + "overlap_padding"] = bl.overlap_padding
+        out[pre + "max_pixels"] = bl.max_pixels
+        sweep.append(i)
+    out["n_cases"] = np.array(len(sweep))
+    # stack_splitter alone, the reference's own unit-test geometry (test_chunking.py:47-66)
+    config.resolutions = [[6.6, 1.1, 1.1]]
+    ov = detector.calc_overlap(2)
+    out["calc_overlap_2"] = ov
+    for j, overlap in enumerate([np.array((0, 1, 1)), np.array((0, 1, 2)), np.array((1, 1, 2)), ov]):
+        sl, off = chunking.stack_splitter((5, 4, 4), [1, 3, 3], overlap)
+        grid = sl.shape
+        out["ss%d_overlap" % j] = overlap
+        out["ss%d_slices" % j] = np.array(
+            [[[s.start, s.stop] for s in sl[c]] for c in np.ndindex(*grid)]).reshape(grid + (3, 2))
+        out["ss%d_offsets" % j] = off
+    out["versions"] = repr(VERSIONS)
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **out)
+    print("blocks: %d cases" % len(sweep))
+
+
+def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, **over):
+    config.resolutions = np.array(resolutions)
+    config.filename = "golden"
+    config.cpus = cpus
+    setup_profile(**over)
+    quiet(chunking.set_mp_start_method)
+    img5d = np_io.Image5d(roi[None])
+    settings = config.get_roi_profile(0 if channels is None else channels[0])
+    # per-block tables before pruning, through the real StackDetector
+    chls = channels
+    if chls is None:
+        chls = list(range(roi.shape[3])) if roi.ndim > 3 else [0]
+    bl = quiet(stack_detect.setup_blocks, settings, roi.shape)
+    seg_rois = quiet(stack_detect.StackDetector.detect_blobs_sub_rois,
+                     img5d, roi, bl.sub_roi_slices, bl.sub_rois_offsets,
+                     bl.denoise_max_shape, bl.exclude_border, False, chls)
+    merged = chunking.merge_blobs(seg_rois)
+    pruned, df = quiet(stack_detect.StackPruner.prune_blobs_mp,
+                       roi, seg_rois, bl.overlap, bl.tol, bl.sub_roi_slices,
+                       bl.sub_rois_offsets, chls, bl.overlap_padding)
+    # and the public entry point end to end
+    _, _, blobs = quiet(stack_detect.detect_blobs_blocks, "golden", img5d, None, None,
+                        channels, False, False, True, False)
+    final = blobs.blobs
+    out = dict(roi=roi, channels=np.array(-1 if channels is None else channels),
+               resolutions=np.array(resolutions),
+               grid=np.array(seg_rois.shape),
+               merged=np.empty((0, 14)) if merged is None else merged,
+               pruned11=np.empty((0, 11)) if pruned is None else pruned,
+               final=np.empty((0, 8)) if final is None else final,
+               final_cols=np.array(blobs.cols if blobs.cols is not None else []),
+               ratios=np.empty((0, 3)) if df is None or df.empty else df.to_numpy(),
+               overrides=repr(over), versions=repr(VERSIONS))
+    for c in np.ndindex(*seg_rois.shape):
+        t = seg_rois[c]
+        out["block_%d_%d_%d" % c] = np.empty((0, 11)) if t is None else t
+    np.savez_compressed(os.path.join(HERE, "stack_%s.npz" % name), **out)
+    print("stack_%s: grid %s, %s merged -> %s final" % (
+        name, seg_rois.shape, None if merged is None else len(merged),
+        None if final is None else final.shape))
+
+
+def prune_cases():
+    rng = np.random.default_rng(77)
+    out = {}
+    quiet(chunking.set_mp_start_method)
+    # (1) remove_close_blobs directly: multi-matches, .5 averages, >1000 rows (chunking)
+    for k, (n_m, n_c, span, tol) in enumerate([
+            (12, 15, 12, (1, 2, 2)), (1500, 1200, 60, (2, 2, 2)), (300, 5, 200, (5, 5, 5)),
+            (40, 40, 300, (3, 1, 2))]):
+        def table(n):
+            t = np.ones((n, 14)) * -1
+            t[:, :3] = rng.integers(0, span, (n, 3))
+            t[:, 3] = 5.196
+            t[:, 6] = 0
+            t[:, 7:10] = t[:, :3] + rng.integers(0, 2, (n, 3))
+            t[:, 11:] = rng.integers(0, 3, (n, 3))
+            return t
+        master, check = table(n_m), table(n_c)
+        # force a few exact duplicates and odd-sum pairs
+        check[: min(4, n_c), :3] = master[: min(4, n_c), :3]
+        check[: min(4, n_c), 7:10] = master[: min(4, n_c), 7:10] + np.array([1, 0, 3])
+        detector.Blobs(np.ones((1, 11)) * -1).format_blobs()  # make sure 11-col indices are set
+        pruned, master_out = detector.remove_close_blobs(check.copy(), master.copy(), np.array(tol))
+        out["rc%d_master" % k] = master
+        out["rc%d_check" % k] = check
+        out["rc%d_tol" % k] = np.array(tol)
+        out["rc%d_pruned" % k] = pruned
+        out["rc%d_master_out" % k] = master_out
+    out["n_rc"] = np.array(4)
+
+    # (2) StackPruner.prune_blobs_mp on hand-made per-block tables
+    config.resolutions = np.array([[1., 1., 1.]])
+    config.cpus = 2
+    settings = setup_profile()[0]
+    settings["segment_size"] = 20
+    shape = (44, 50, 65)
+    bl = quiet(stack_detect.setup_blocks, settings, shape)
+    grid = bl.sub_roi_slices.shape
+    seg_rois = np.zeros(grid, dtype=object)
+    for c in np.ndindex(*grid):
+        sl = bl.sub_roi_slices[c]
+        lo = np.array([s.start for s in sl])
+        hi = np.array([s.stop for s in sl])
+        n = int(rng.integers(0, 14))
+        if n == 0:
+            seg_rois[c] = None
+            continue
+        t = np.ones((n, 11)) * -1
+        t[:, :3] = rng.integers(lo, hi, (n, 3))
+        t[:, 3] = 5.196
+        t[:, 6] = rng.integers(0, 2, n)
+        t[:, 7:10] = t[:, :3]
+        seg_rois[c] = t
+    # plant cross-block duplicates in the overlaps (same and +-1 shifted positions)
+    for c in np.ndindex(*grid):
+        for ax in range(3):
+            nb = list(c)
+            nb[ax] += 1
+            if nb[ax] >= grid[ax] or seg_rois[c] is None:
+                continue
+            nb = tuple(nb)
+            sl, sl_nb = bl.sub_roi_slices[c], bl.sub_roi_slices[nb]
+            pos = np.array([(max(a.start, b.start) + min(a.stop, b.stop)) // 2
+                            for a, b in zip(sl, sl_nb)], dtype=float)
+            for shift, chl in (((0, 0, 0), 0), ((1, 0, 1), 1), ((0, 1, 0), 0)):
+                row = np.ones(11) * -1
+                row[:3] = pos
+                row[3] = 5.196
+                row[6] = chl
+                row[7:10] = pos
+                row2 = row.copy()
+                row2[:3] += shift
+                row2[7:10] += shift
+                seg_rois[c] = np.vstack((seg_rois[c], row))
+                seg_rois[nb] = row2[None] if seg_rois[nb] is None else np.vstack((seg_rois[nb], row2))
+    dummy_img = np.zeros(shape, dtype=np.uint8)
+    pruned, df = quiet(stack_detect.StackPruner.prune_blobs_mp,
+                       dummy_img, seg_rois, bl.overlap, bl.tol, bl.sub_roi_slices,
+                       bl.sub_rois_offsets, [0, 1], bl.overlap_padding)
+    out["sp_shape"] = np.array(shape)
+    out["sp_grid"] = np.array(grid)
+    out["sp_segment_size"] = np.array(20)
+    for c in np.ndindex(*grid):
+        out["sp_block_%d_%d_%d" % c] = np.empty((0, 11)) if seg_rois[c] is None else seg_rois[c]
+    out["sp_pruned"] = pruned
+    out["sp_ratios"] = df.to_numpy()
+    out["sp_ratio_cols"] = np.array(list(df.columns))
+    out["versions"] = repr(VERSIONS)
+    np.savez_compressed(os.path.join(HERE, "prune.npz"), **out)
+    print("prune: remove_close x4; prune_blobs_mp %s blocks -> %d rows" % (grid, len(pruned)))
+
+
+def main():
+    print("versions:", VERSIONS)
+    # ---- blob_log arithmetic
+    bloblog_case("u16_1sigma", make_volume(11, (40, 56, 60), 22), 3, 3, 1)
+    bloblog_case("u16_5sigma", make_volume(12, (48, 64, 72), 30), 3, 5, 5)
+    dense = make_volume(13, (32, 48, 48), 0, centres=np.array(
+        [[10, 12, 12], [10, 12, 15.5], [12.5, 14, 13], [20, 30, 30], [20, 33, 30], [22, 31.5, 33],
+         [20, 30, 36.2], [9, 36, 10], [11.6, 37, 11], [25, 10, 38], [25.4, 13.2, 38]]))
+    bloblog_case("u16_dense10", dense, 3, 5, 10)
+    bloblog_case("u16_twoscale10", make_twoscale_volume(19, (36, 52, 52), 7), 1.0, 5.5, 10,
+                 threshold=0.05)
+    bloblog_case("u16_twoscale_b", make_twoscale_volume(20, (40, 48, 56), 9, small=(40000.0, 1.2),
+                                                        big=(15000.0, 5.5), off=1.5), 1.0, 5.5, 10,
+                 threshold=0.05, overlap=0.3)
+    bloblog_case("u8_3sigma", make_volume(14, (36, 40, 44), 14, dtype=np.uint8), 2.5, 3.5, 3)
+    bloblog_case("f32_2sigma", make_volume(15, (30, 44, 40), 12, dtype=np.float32), 3, 4, 2)
+    bloblog_case("f64_2sigma", make_volume(16, (30, 40, 44), 12, dtype=np.float64), 3, 4, 2)
+    bloblog_case("u16_empty", np.full((20, 24, 28), 700, dtype=np.uint16), 3, 5, 5)
+    bloblog_case("u16_thin", make_volume(17, (5, 40, 44), 6, margin=2), 3, 4, 3)
+    bloblog_case("u16_smallsig", make_volume(18, (24, 32, 32), 20, blob_sigma=1.2), 1.0, 2.0, 3,
+                 threshold=0.05)
+
+    # ---- magmap.cv.detector.detect_blobs
+    vol1 = make_volume(21, (40, 60, 64), 24)
+    detect_case("1ch", vol1, None, num_sigma=5)
+    detect_case("1ch_border", vol1, None, exclude_border=np.array([[2, 5, 5], [1, 6, 6]]), num_sigma=5)
+    vol2 = np.stack((make_volume(22, (36, 52, 56), 18), make_volume(23, (36, 52, 56), 14)), axis=-1)
+    detect_case("2ch", vol2, None, num_sigma=3)
+    detect_case("2ch_sel1", vol2, [1], num_sigma=3)
+    yaml = "/root/reference/profiles/roi_blobs.yaml"
+    detect_case("2ch_perchl", vol2, None, names=[yaml, yaml + ",4xnuc"], num_sigma=3,
+                detection_threshold={"per_channel": [0.1, 0.2]})
+    # the second profile is only used if one exists per channel
+    config.resolutions = np.array([[1., 1., 1.]])
+    detect_case("res_x2", vol1, None, resolutions=((2.0, 0.8, 0.8),), num_sigma=3)
+    detect_case("empty", np.full((24, 30, 30), 512, dtype=np.uint16), None, num_sigma=3)
+
+    # ---- block geometry
+    blocks_cases()
+
+    # ---- whole-stack detection, multi-block
+    stack_case("u16_2x3x3", make_volume(31, (64, 96, 96), 60), None, segment_size=40, num_sigma=5)
+    stack_case("u16_border", make_volume(32, (60, 80, 84), 45), None, segment_size=36, num_sigma=3,
+               exclude_border=(1, 0, 0), prune_tol_factor=(1, 0.9, 0.9))
+    vol2s = np.stack((make_volume(33, (50, 70, 70), 30), make_volume(34, (50, 70, 70), 26)), axis=-1)
+    stack_case("2ch", vol2s, None, segment_size=32, num_sigma=3)
+    stack_case("empty", np.full((40, 50, 50), 300, dtype=np.uint16), None, segment_size=30,
+               num_sigma=2)
+
+    # ---- table pruning
+    prune_cases()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+"""Pin the CPU oracle against golden vectors from the real reference + real scikit-image.
+
+CPU only.  The fixtures were produced by ``tests/golden/make_golden.py`` under
+``/opt/conda/bin/python3.9`` (scikit-image 0.18.3, SciPy 1.7.1); the oracle runs
+here on the image's Python 3.10 / SciPy 1.15.3 (the reference's pinned SciPy).
+LoG values agree to ~1 ulp between the two SciPy builds, peak sets and pruned
+blob sets must be identical.
+"""
+import ast
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, lexsorted, load_golden
+from oracle import blob_log_oracle as blo
+from oracle import magmap_oracle as mmo
+
+BLOBLOG_CASES = sorted(os.path.basename(p)[len("bloblog_"):-4]
+                       for p in glob.glob(os.path.join(GOLDEN, "bloblog_*.npz")))
+DETECT_CASES = sorted(os.path.basename(p)[len("detect_"):-4]
+                      for p in glob.glob(os.path.join(GOLDEN, "detect_*.npz")))
+STACK_CASES = sorted(os.path.basename(p)[len("stack_"):-4]
+                     for p in glob.glob(os.path.join(GOLDEN, "stack_*.npz")))
+
+
+def test_fixture_inventory():
+    assert len(BLOBLOG_CASES) >= 10 and len(DETECT_CASES) >= 6 and len(STACK_CASES) >= 4
+
+
+@pytest.mark.parametrize("case", BLOBLOG_CASES)
+def test_blob_log_matches_skimage(case):
+    g = load_golden("bloblog_%s.npz" % case)
+    res, st = blo.blob_log(g["volume"], float(g["min_sigma"]), float(g["max_sigma"]),
+                           int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]),
+                           return_stages=True)
+    # A1: sigma ladder, bit exact
+    np.testing.assert_array_equal(st["sigmas"], g["sigmas"])
+    # A0-A3: LoG cube crop; float64 cubes within a few ulp of the other SciPy build
+    o = g["cube_crop_origin"]
+    crop = st["cube"][tuple(slice(a, a + n) for a, n in zip(o, g["cube_crop"].shape[:3]))]
+    assert str(st["cube"].dtype) == str(g["cube_dtype"])
+    tol = 1e-6 if st["cube"].dtype == np.float32 else 1e-13
+    np.testing.assert_allclose(crop, g["cube_crop"], rtol=0, atol=tol)
+    # A4: raw peaks -- same set, same descending order (no exact ties in these cases)
+    np.testing.assert_array_equal(st["peaks"], g["peaks"].reshape(-1, 4))
+    np.testing.assert_allclose(st["peak_values"], g["peak_values"], rtol=0, atol=tol)
+    # A5: pruned blobs, bit exact as a set and in order
+    assert res.shape == g["pruned"].shape
+    np.testing.assert_array_equal(res, g["pruned"])
+
+
+def test_overlap_prune_removes_rows_and_is_order_invariant():
+    """The two-scale fixtures exercise A5; the outcome must not depend on pair order here."""
+    for case in ("u16_twoscale10", "u16_twoscale_b"):
+        g = load_golden("bloblog_%s.npz" % case)
+        peaks = g["peaks"]
+        assert len(g["pruned"]) < len(peaks)
+        lm = np.hstack([peaks[:, :3].astype(float), g["sigmas"][peaks[:, 3]][:, :1]])
+        base = blo.prune_blobs(lm, float(g["overlap"]))
+        np.testing.assert_array_equal(base, g["pruned"])
+        rng = np.random.default_rng(0)
+        from scipy import spatial
+        n_pairs = len(spatial.cKDTree(lm[:, :3]).query_pairs(2 * lm[:, 3].max() * np.sqrt(3)))
+        for _ in range(5):
+            perm = rng.permutation(n_pairs)
+            np.testing.assert_array_equal(
+                lexsorted(blo.prune_blobs(lm, float(g["overlap"]), pair_order=perm)),
+                lexsorted(base))
+
+
+def _profiles_from(g):
+    return ast.literal_eval(str(g["profiles"]))
+
+
+@pytest.mark.parametrize("case", DETECT_CASES)
+def test_detect_blobs_matches_reference(case):
+    g = load_golden("detect_%s.npz" % case)
+    profs = [dict(p, isotropic=None) for p in _profiles_from(g)]
+    channel = None if g["channel"].ndim == 0 else list(g["channel"])
+    excl = None if g["exclude_border"].ndim == 0 else g["exclude_border"]
+    table = mmo.detect_blobs(g["roi"], channel, profs, g["resolutions"], excl)
+    if bool(g["is_none"]):
+        assert table is None
+        return
+    assert table.dtype == np.float64 and table.shape[1] == 11
+    np.testing.assert_array_equal(table, g["table"])
+
+
+def test_setup_blocks_sweep():
+    g = load_golden("blocks.npz")
+    for i in range(int(g["n_cases"])):
+        pre = "c%d_" % i
+        excl = None if g[pre + "exclude_border"].ndim == 0 else tuple(g[pre + "exclude_border"])
+        dn = None if float(g[pre + "denoise_size"]) < 0 else g[pre + "denoise_size"].item()
+        prof = dict(segment_size=g[pre + "segment_size"].item(), exclude_border=excl,
+                    prune_tol_factor=tuple(g[pre + "prune_tol_factor"]), denoise_size=dn)
+        bl = mmo.setup_blocks(prof, tuple(g[pre + "shape"]), [g[pre + "resolutions"]])
+        grid = bl["sub_roi_slices"].shape
+        sl = np.array([[[s.start, s.stop] for s in bl["sub_roi_slices"][c]]
+                       for c in np.ndindex(*grid)]).reshape(grid + (3, 2))
+        np.testing.assert_array_equal(sl, g[pre + "slices"])
+        np.testing.assert_array_equal(bl["sub_rois_offsets"], g[pre + "offsets"])
+        for key in ("tol", "overlap_base", "overlap", "overlap_padding", "max_pixels"):
+            np.testing.assert_array_equal(bl[key], g[pre + key])
+            assert bl[key].dtype.kind == "i"
+        if g[pre + "denoise_max_shape"].ndim == 0:
+            assert bl["denoise_max_shape"] is None
+        else:
+            np.testing.assert_array_equal(bl["denoise_max_shape"], g[pre + "denoise_max_shape"])
+
+
+def test_stack_splitter_reference_unit_test_geometry():
+    """Same geometry as the reference's own test (magmap/tests/test_chunking.py:47-66)."""
+    g = load_golden("blocks.npz")
+    np.testing.assert_array_equal(mmo.calc_overlap([[6.6, 1.1, 1.1]], 2), g["calc_overlap_2"])
+    for j in range(4):
+        sl, off = mmo.stack_splitter((5, 4, 4), [1, 3, 3], g["ss%d_overlap" % j])
+        grid = sl.shape
+        got = np.array([[[s.start, s.stop] for s in sl[c]]
+                        for c in np.ndindex(*grid)]).reshape(grid + (3, 2))
+        np.testing.assert_array_equal(got, g["ss%d_slices" % j])
+        np.testing.assert_array_equal(off, g["ss%d_offsets" % j])
+
+
+def _stack_profiles(g):
+    over = ast.literal_eval(str(g["overrides"]))
+    prof = dict(min_sigma_factor=3, max_sigma_factor=5, num_sigma=10, detection_threshold=0.1,
+                overlap=0.5, exclude_border=None, segment_size=500, denoise_size=None,
+                prune_tol_factor=(1, 1, 1), isotropic=None)
+    prof.update(over)
+    return [prof]
+
+
+@pytest.mark.parametrize("case", STACK_CASES)
+def test_detect_blobs_blocks_matches_reference(case):
+    g = load_golden("stack_%s.npz" % case)
+    channels = None if g["channels"].ndim == 0 else list(g["channels"])
+    final, st = mmo.detect_blobs_blocks(g["roi"], channels, _stack_profiles(g), g["resolutions"])
+    grid = tuple(g["grid"])
+    assert st["seg_rois"].shape == grid
+    for c in np.ndindex(*grid):
+        want = g["block_%d_%d_%d" % c]
+        got = st["seg_rois"][c]
+        if want.shape[0] == 0:
+            assert got is None
+        else:
+            np.testing.assert_array_equal(got, want)
+    if g["final"].shape[0] == 0:
+        assert final is None
+        return
+    np.testing.assert_array_equal(st["merged"], g["merged"])
+    np.testing.assert_array_equal(st["pruned11"][:, 3:], g["pruned11"][:, 3:])
+    np.testing.assert_array_equal(final, g["final"])
+    assert list(g["final_cols"]) == ["z", "y", "x", "radius", "confirmed", "truth", "channel", "region"]
+    if g["ratios"].size:
+        got = np.array([st["ratios"][k] for k in ("blobs", "ratio_pruning", "ratio_adjacent")]).T
+        np.testing.assert_allclose(got, g["ratios"])
+
+
+def test_remove_close_blobs_matches_reference():
+    g = load_golden("prune.npz")
+    for k in range(int(g["n_rc"])):
+        pruned, master = mmo.remove_close_blobs(
+            g["rc%d_check" % k].copy(), g["rc%d_master" % k].copy(), g["rc%d_tol" % k])
+        np.testing.assert_array_equal(pruned, g["rc%d_pruned" % k])
+        np.testing.assert_array_equal(master, g["rc%d_master_out" % k])
+
+
+def test_prune_blobs_mp_matches_reference():
+    g = load_golden("prune.npz")
+    shape = tuple(g["sp_shape"])
+    prof = dict(segment_size=g["sp_segment_size"].item(), exclude_border=None,
+                prune_tol_factor=(1, 1, 1), denoise_size=None)
+    bl = mmo.setup_blocks(prof, shape, [[1., 1., 1.]])
+    grid = tuple(g["sp_grid"])
+    assert bl["sub_roi_slices"].shape == grid
+    seg = np.zeros(grid, dtype=object)
+    for c in np.ndindex(*grid):
+        t = g["sp_block_%d_%d_%d" % c]
+        seg[c] = None if t.shape[0] == 0 else t.copy()
+    pruned, ratios = mmo.prune_blobs_mp(shape, seg, bl["overlap"], bl["tol"], bl["sub_roi_slices"],
+                                        bl["sub_rois_offsets"], [0, 1], bl["overlap_padding"])
+    np.testing.assert_array_equal(pruned, g["sp_pruned"])
+    got = np.array([ratios[str(k)] for k in g["sp_ratio_cols"]]).T
+    np.testing.assert_allclose(got, g["sp_ratios"])
