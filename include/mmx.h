@@ -1,0 +1,169 @@
+/* mmx.h -- C ABI of the MI355X-native blob-detection hot path (libmmx_hip.so).
+ *
+ * Drop-in boundary for ONE path of MagellanMapper: whole-volume nuclei detection,
+ * i.e. what `magmap.cv.detector.detect_blobs` (reference magmap/cv/detector.py:874-957)
+ * gets from its single third-party call `skimage.feature.blob_log`
+ * (detector.py:931-933) plus the cross-block duplicate search of
+ * `detector.remove_close_blobs` (detector.py:1000-1085).  The reference has no
+ * FFI of its own (it is pure Python over SciPy's `_nd_image` C extension); the
+ * entry points below are what a ctypes binding on the reference side binds --
+ * see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - plain C, caller-owned buffers, no exceptions: every call returns an
+ *     `mmx_status` (0 = OK); `mmx_strerror` names it.
+ *   - pointers prefixed d_ are DEVICE pointers (HBM), h_ are HOST pointers.
+ *   - `stream` is a `hipStream_t` passed as `void*`; all device work is enqueued
+ *     on it and NOT synchronised -- the caller owns ordering.
+ *   - arrays are C-ordered (z, y, x), x contiguous ("z-major").
+ *   - a *block* is one sub-ROI of `chunking.stack_splitter`
+ *     (reference magmap/cv/chunking.py:214-256).  Every block is filtered on its
+ *     own extent with SciPy "reflect" boundaries -- exactly what each reference
+ *     worker sees (magmap/cv/stack_detect.py:79, 242).  A *batch* is a set of
+ *     blocks processed by one launch sequence; block i of a batch owns slot i of
+ *     every workspace array (`slot_elems` floats, dense [nz][ny][nx]).
+ */
+#ifndef MMX_H
+#define MMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMX_ABI_VERSION 1
+
+typedef enum {
+    MMX_OK = 0,
+    MMX_ERR_ARG = 1,        /* bad argument (null pointer, size, dtype, radius)        */
+    MMX_ERR_HIP = 2,        /* a HIP runtime call failed; see mmx_last_hip_error()      */
+    MMX_ERR_NO_DEVICE = 3,  /* no gfx950 device visible                                 */
+    MMX_ERR_WORKSPACE = 4,  /* workspace too small                                      */
+    MMX_ERR_UNSUPPORTED = 5 /* e.g. kernel radius above MMX_MAX_RADIUS_GENERIC          */
+} mmx_status;
+
+/* input voxel types (reference accepts any dtype through skimage.img_as_float,
+ * skimage/util/dtype.py:310-328) */
+typedef enum { MMX_U8 = 0, MMX_U16 = 1, MMX_F32 = 2, MMX_F64 = 3 } mmx_dtype;
+
+/* largest kernel radius with a register-resident (fully unrolled) column pass;
+ * larger radii take the generic path.  radius = int(4*sigma + 0.5)
+ * (scipy/ndimage/_filters.py:313-315). */
+#define MMX_MAX_RADIUS_FAST 24
+#define MMX_MAX_RADIUS_GENERIC 255
+
+/* One block of a batch (device array of these is passed to the kernels). */
+typedef struct {
+    int64_t src_off;   /* element offset of the block origin inside the source volume */
+    int32_t nz, ny, nx;/* block extent in voxels                                       */
+    int32_t slot;      /* workspace slot (0 .. n_blocks-1)                             */
+} mmx_block;
+
+/* Source volume view (one channel): element strides, x stride must be 1 for
+ * integer inputs laid out (z,y,x); a (z,y,x,c) image passes stride_x = n_channels. */
+typedef struct {
+    const void* d_data;
+    int32_t dtype;     /* mmx_dtype */
+    int32_t _pad;
+    int64_t stride_z, stride_y, stride_x; /* in elements */
+} mmx_volume;
+
+/* Scale-space candidate (A4).  48 bytes.  `flags` bit 0: contested -- within eps of
+ * a neighbour or of the threshold, the float64 value must decide. */
+typedef struct {
+    int32_t slot;      /* block slot in the batch          */
+    int32_t s;         /* sigma index                      */
+    int32_t z, y, x;   /* block-relative voxel             */
+    uint32_t flags;
+    float v;           /* float32 scale-normalised -LoG    */
+    float nbr_max;     /* float32 max over the 80 neighbours, 0-padded outside the cube */
+    double v64;        /* exact float64 value (filled by mmx_rescore_f64), NaN before   */
+    double _reserved;
+} mmx_cand;
+
+#define MMX_CAND_CONTESTED 1u
+
+/* ---- library / device ---------------------------------------------------- */
+int mmx_abi_version(void);
+const char* mmx_strerror(int status);
+const char* mmx_last_hip_error(void);
+/* number of visible devices whose arch is gfx950; <0 on HIP error */
+int mmx_device_count(void);
+
+/* ---- A0 + A2 + A3: scale-normalised -LoG of every block of a batch, one sigma
+ * replaces: skimage.feature.blob_log's
+ *     -gaussian_laplace(img_as_float(image), sigma) * sigma**2
+ * (skimage/feature/blob.py:470, 501-502 -> scipy/ndimage/_filters.py:644-707),
+ * computed in float32 (3 separable passes, shared order-0 passes).
+ *   h_w0, h_w2 : float64 half kernels, index k = 0..radius (k = distance from centre),
+ *                computed by the caller exactly as scipy's _gaussian_kernel1d does
+ *   norm       : mean(sigma)**2
+ *   d_log      : out, [n_blocks][slot_elems] float32
+ *   d_work     : scratch, 4 * n_blocks * slot_elems float32                       */
+int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
+                      int n_blocks, int64_t slot_elems,
+                      const double* h_w0, const double* h_w2, int radius, double norm,
+                      float* d_log, float* d_work, void* stream);
+
+/* Same contract, always through the generic (any radius <= MMX_MAX_RADIUS_GENERIC, any block
+ * extent) kernels.  mmx_log_batch_f32 picks per pass between the register-ring kernels and
+ * these; this entry exists so that tests can cross-check the two paths. */
+int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks,
+                              const mmx_block* h_blocks, int n_blocks, int64_t slot_elems,
+                              const double* h_w0, const double* h_w2, int radius, double norm,
+                              float* d_log, float* d_work, void* stream);
+
+/* ---- A4: 3x3x3x3 local maxima over (z,y,x,sigma) strictly above the threshold
+ * replaces: skimage.feature.peak_local_max(footprint=ones(3,3,3,3), mode='constant')
+ * (skimage/feature/peak.py:28-50, 114-319).
+ *   d_log        : [n_sigma][n_blocks][slot_elems] float32 (sigma-major)
+ *   eps          : candidates are emitted when v >= nbr_max - eps and v > thr - eps
+ *   d_cands/cap  : output table; *d_count keeps counting past cap (caller retries)  */
+int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
+                    const mmx_block* h_blocks, int n_blocks, int64_t slot_elems,
+                    float thr, float eps, mmx_cand* d_cands, uint32_t cap,
+                    uint32_t* d_count, void* stream);
+
+/* ---- exact float64 value of the cube at given points (bit-for-bit the reference's
+ * arithmetic: scipy NI_Correlate1D operation order, no FMA contraction)
+ * replaces: the float64 cube values that peak_local_max compares
+ *   d_pts[i].{slot,s,z,y,x} in, d_pts[i].v64 out; n points are taken from
+ *   *d_count (clamped to cap) when d_count != NULL, else n = cap.
+ *   d_w0/d_w2 : [n_sigma][MMX_MAX_RADIUS_GENERIC+1] float64 half kernels (device)
+ *   h_radius  : [n_sigma] kernel radii, h_norm: [n_sigma] mean(sigma)**2
+ *   store_f32 : 1 = the input is float32 and SciPy keeps float32 intermediates      */
+int mmx_rescore_f64(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
+                    mmx_cand* d_pts, uint32_t cap, const uint32_t* d_count,
+                    const double* d_w0, const double* d_w2, const int32_t* h_radius,
+                    const double* h_norm, int n_sigma, int store_f32, void* stream);
+
+/* ---- A5 support: all blob pairs of one block whose sphere-overlap fraction exceeds
+ * `overlap` (skimage/feature/blob.py:84-187: _blob_overlap / _prune_blobs)
+ *   d_blobs : [n][4] float64 (z, y, x, sigma), blocks delimited by d_offsets[n_blocks+1]
+ *   d_pairs : out [cap][2] int32 global row indices (i < j), *d_count total found
+ *   d_frac  : out [cap] float64 overlap fraction                                   */
+int mmx_overlap_pairs(const double* d_blobs, const int32_t* d_offsets, int n_blocks,
+                      double overlap, double band, int32_t* d_pairs, double* d_frac,
+                      uint32_t cap, uint32_t* d_count, void* stream);
+
+/* ---- A13 support: for every master row the LAST check row within `tol` on all
+ * three axes, and for every check row whether any master row matched
+ * (magmap/cv/detector.py:1000-1085: _find_close_blobs / remove_close_blobs)
+ *   d_master : [n_master][3] int32, d_check : [n_check][3] int32
+ *   d_last   : out [n_master] int32, -1 = no match
+ *   d_hit    : out [n_check] uint8                                               */
+int mmx_close_pairs(const int32_t* d_master, int n_master, const int32_t* d_check, int n_check,
+                    const int32_t tol[3], int32_t* d_last, uint8_t* d_hit, void* stream);
+
+/* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream */
+int mmx_event_create(void** ev);
+int mmx_event_destroy(void* ev);
+int mmx_event_record(void* ev, void* stream);
+int mmx_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMX_H */

@@ -1,0 +1,227 @@
+// extern "C" entry points of libmmx_hip.so (see include/mmx.h for the contract).
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+
+#include "mmx_common.h"
+
+int mmx_launch_generic_pass(int pass, const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
+                            int max_vox, int64_t slot_elems, const float* w0, const float* w2, int radius,
+                            const float* in1, const float* in2, float* out1, float* out2, hipStream_t s);
+int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, const mmx_block* d_blocks,
+                     int n_blocks, int max_vox, int64_t slot_elems, float thr, float eps,
+                     mmx_cand* d_cands, uint32_t cap, uint32_t* d_count, hipStream_t stream);
+
+namespace {
+thread_local char g_hip_err[256] = "";
+
+int hip_fail(hipError_t e, const char* what)
+{
+    snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+    return MMX_ERR_HIP;
+}
+
+// The register-ring column kernels prefetch kPrefetch (= 4) steps ahead and reflect once.
+constexpr int kColPrefetch = 4;
+}  // namespace
+
+extern "C" {
+
+int mmx_abi_version(void) { return MMX_ABI_VERSION; }
+
+const char* mmx_strerror(int status)
+{
+    switch (status) {
+        case MMX_OK: return "ok";
+        case MMX_ERR_ARG: return "bad argument";
+        case MMX_ERR_HIP: return "HIP runtime error";
+        case MMX_ERR_NO_DEVICE: return "no gfx950 device";
+        case MMX_ERR_WORKSPACE: return "workspace too small";
+        case MMX_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+const char* mmx_last_hip_error(void) { return g_hip_err; }
+
+int mmx_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { hip_fail(e, "hipGetDeviceCount"); return -1; }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
+                      int n_blocks, int64_t slot_elems,
+                      const double* h_w0, const double* h_w2, int radius, double norm,
+                      float* d_log, float* d_work, void* stream)
+{
+    if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
+        return MMX_ERR_ARG;
+    if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
+    if (radius > MMX_MAX_RADIUS_GENERIC) return MMX_ERR_UNSUPPORTED;
+    if (slot_elems >= (int64_t(1) << 29)) return MMX_ERR_UNSUPPORTED;  // 32-bit byte offsets in a slot
+    double in_scale = 1.0;
+    if (vol->dtype == MMX_U8) in_scale = 1.0 / 255.0;        // skimage img_as_float: x * (1/imax)
+    else if (vol->dtype == MMX_U16) in_scale = 1.0 / 65535.0;
+    else if (vol->dtype != MMX_F32) return MMX_ERR_UNSUPPORTED;  // float64 volumes: pass a float32 copy
+
+    int min_nz = 1 << 30, min_ny = 1 << 30, min_nx = 1 << 30;
+    int max_zcols = 0, max_ycols = 0, max_rows = 0, max_nx = 0, max_vox = 0;
+    int64_t max_lane_in = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_block& b = h_blocks[i];
+        if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
+        if ((int64_t)b.nz * b.ny * b.nx > slot_elems) return MMX_ERR_WORKSPACE;
+        if (b.nz < min_nz) min_nz = b.nz;
+        if (b.ny < min_ny) min_ny = b.ny;
+        if (b.nx < min_nx) min_nx = b.nx;
+        if (b.ny * b.nx > max_zcols) max_zcols = b.ny * b.nx;
+        if (b.nz * b.nx > max_ycols) max_ycols = b.nz * b.nx;
+        if (b.nz * b.ny > max_rows) max_rows = b.nz * b.ny;
+        if (b.nx > max_nx) max_nx = b.nx;
+        if (b.nz * b.ny * b.nx > max_vox) max_vox = b.nz * b.ny * b.nx;
+        const int64_t lane = (int64_t)(b.ny - 1) * vol->stride_y + (int64_t)(b.nx - 1) * vol->stride_x;
+        if (lane > max_lane_in) max_lane_in = lane;
+    }
+    const int64_t n_slots = n_blocks;
+    float* t0 = d_work;                          // Gz
+    float* t1 = d_work + n_slots * slot_elems;   // Gzz
+    float* t2 = t1 + n_slots * slot_elems;       // A
+    float* t3 = t2 + n_slots * slot_elems;       // BC
+    hipStream_t s = (hipStream_t)stream;
+
+    // weights per pass: input scale into the z pass, -norm into the x pass
+    float wz0[MMX_MAX_RADIUS_GENERIC + 1], wz2[MMX_MAX_RADIUS_GENERIC + 1];
+    float wy0[MMX_MAX_RADIUS_GENERIC + 1], wy2[MMX_MAX_RADIUS_GENERIC + 1];
+    float wx0[MMX_MAX_RADIUS_GENERIC + 1], wx2[MMX_MAX_RADIUS_GENERIC + 1];
+    for (int k = 0; k <= radius; ++k) {
+        wz0[k] = (float)(h_w0[k] * in_scale);
+        wz2[k] = (float)(h_w2[k] * in_scale);
+        wy0[k] = (float)h_w0[k];
+        wy2[k] = (float)h_w2[k];
+        wx0[k] = (float)(-norm * h_w0[k]);
+        wx2[k] = (float)(-norm * h_w2[k]);
+    }
+    const bool fast_r = radius >= 1 && radius <= MMX_MAX_RADIUS_FAST;
+    const bool lane_ok = max_lane_in * 8 < (int64_t(1) << 31);
+    const bool fast_z = fast_r && lane_ok && min_nz >= radius + kColPrefetch && vol->stride_y < (1 << 30);
+    const bool fast_y = fast_r && min_ny >= radius + kColPrefetch;
+    const bool fast_x = fast_r && min_nx >= radius;
+    auto taps = [&](const float* a, const float* b) {
+        mmx_taps_f32 t;
+        for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) {
+            t.w0[k] = k <= radius ? a[k] : 0.f;
+            t.w2[k] = k <= radius ? b[k] : 0.f;
+        }
+        return t;
+    };
+    int rc;
+    if (fast_z) rc = mmx_launch_zpass(vol, d_blocks, n_blocks, max_zcols, slot_elems, taps(wz0, wz2), radius, t0, t1, s);
+    else rc = mmx_launch_generic_pass(0, vol, d_blocks, n_blocks, max_vox, slot_elems, wz0, wz2, radius, nullptr, nullptr, t0, t1, s);
+    if (rc != MMX_OK) return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "z pass") : rc;
+    if (fast_y) rc = mmx_launch_ypass(d_blocks, n_blocks, max_ycols, slot_elems, taps(wy0, wy2), radius, t0, t1, t2, t3, s);
+    else rc = mmx_launch_generic_pass(1, vol, d_blocks, n_blocks, max_vox, slot_elems, wy0, wy2, radius, t0, t1, t2, t3, s);
+    if (rc != MMX_OK) return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "y pass") : rc;
+    if (fast_x) rc = mmx_launch_xpass(d_blocks, n_blocks, max_rows, max_nx, slot_elems, taps(wx0, wx2), radius, t2, t3, d_log, s);
+    else rc = mmx_launch_generic_pass(2, vol, d_blocks, n_blocks, max_vox, slot_elems, wx0, wx2, radius, t2, t3, d_log, nullptr, s);
+    if (rc != MMX_OK) return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "x pass") : rc;
+    return MMX_OK;
+}
+
+// Same as mmx_log_batch_f32 but always through the generic kernels (tests cross-check the
+// register-ring kernels against it; also what very large sigmas take).
+int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
+                              int n_blocks, int64_t slot_elems,
+                              const double* h_w0, const double* h_w2, int radius, double norm,
+                              float* d_log, float* d_work, void* stream)
+{
+    if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
+        return MMX_ERR_ARG;
+    if (n_blocks < 1 || radius < 0 || radius > MMX_MAX_RADIUS_GENERIC || slot_elems < 1) return MMX_ERR_ARG;
+    double in_scale = 1.0;
+    if (vol->dtype == MMX_U8) in_scale = 1.0 / 255.0;
+    else if (vol->dtype == MMX_U16) in_scale = 1.0 / 65535.0;
+    int max_vox = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_block& b = h_blocks[i];
+        if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
+        if ((int64_t)b.nz * b.ny * b.nx > slot_elems) return MMX_ERR_WORKSPACE;
+        if (b.nz * b.ny * b.nx > max_vox) max_vox = b.nz * b.ny * b.nx;
+    }
+    const int64_t n_slots = n_blocks;
+    float* t0 = d_work;
+    float* t1 = d_work + n_slots * slot_elems;
+    float* t2 = t1 + n_slots * slot_elems;
+    float* t3 = t2 + n_slots * slot_elems;
+    hipStream_t s = (hipStream_t)stream;
+    float a[MMX_MAX_RADIUS_GENERIC + 1], b[MMX_MAX_RADIUS_GENERIC + 1];
+    int rc;
+    for (int k = 0; k <= radius; ++k) { a[k] = (float)(h_w0[k] * in_scale); b[k] = (float)(h_w2[k] * in_scale); }
+    rc = mmx_launch_generic_pass(0, vol, d_blocks, n_blocks, max_vox, slot_elems, a, b, radius, nullptr, nullptr, t0, t1, s);
+    if (rc != MMX_OK) return rc;
+    for (int k = 0; k <= radius; ++k) { a[k] = (float)h_w0[k]; b[k] = (float)h_w2[k]; }
+    rc = mmx_launch_generic_pass(1, vol, d_blocks, n_blocks, max_vox, slot_elems, a, b, radius, t0, t1, t2, t3, s);
+    if (rc != MMX_OK) return rc;
+    for (int k = 0; k <= radius; ++k) { a[k] = (float)(-norm * h_w0[k]); b[k] = (float)(-norm * h_w2[k]); }
+    return mmx_launch_generic_pass(2, vol, d_blocks, n_blocks, max_vox, slot_elems, a, b, radius, t2, t3, d_log, nullptr, s);
+}
+
+int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
+                    const mmx_block* h_blocks, int n_blocks, int64_t slot_elems,
+                    float thr, float eps, mmx_cand* d_cands, uint32_t cap,
+                    uint32_t* d_count, void* stream)
+{
+    if (!d_log || !d_blocks || !h_blocks || !d_cands || !d_count) return MMX_ERR_ARG;
+    if (n_sigma < 1 || n_blocks < 1 || slot_elems < 1 || !(eps >= 0.f)) return MMX_ERR_ARG;
+    int max_vox = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_block& b = h_blocks[i];
+        if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
+        if ((int64_t)b.nz * b.ny * b.nx > slot_elems) return MMX_ERR_WORKSPACE;
+        if (b.nz * b.ny * b.nx > max_vox) max_vox = b.nz * b.ny * b.nx;
+    }
+    int rc = mmx_launch_peaks(d_log, n_sigma, (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox,
+                              slot_elems, thr, eps, d_cands, cap, d_count, (hipStream_t)stream);
+    return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "peaks") : rc;
+}
+
+int mmx_event_create(void** ev)
+{
+    if (!ev) return MMX_ERR_ARG;
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return hip_fail(r, "hipEventCreate");
+    *ev = (void*)e;
+    return MMX_OK;
+}
+
+int mmx_event_destroy(void* ev)
+{
+    hipError_t r = hipEventDestroy((hipEvent_t)ev);
+    return r == hipSuccess ? MMX_OK : hip_fail(r, "hipEventDestroy");
+}
+
+int mmx_event_record(void* ev, void* stream)
+{
+    hipError_t r = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+    return r == hipSuccess ? MMX_OK : hip_fail(r, "hipEventRecord");
+}
+
+int mmx_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    if (!ms) return MMX_ERR_ARG;
+    hipError_t r = hipEventSynchronize((hipEvent_t)stop);
+    if (r != hipSuccess) return hip_fail(r, "hipEventSynchronize");
+    r = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    return r == hipSuccess ? MMX_OK : hip_fail(r, "hipEventElapsedTime");
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// Shared declarations for the gfx950 kernels of libmmx_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmx.h"
+
+#define MMX_WG 256  // workgroup size used by the streaming kernels (4 waves of 64)
+
+// Half kernels (index k = distance from the centre tap) passed BY VALUE in the
+// kernarg segment, so that with a fully unrolled tap loop every weight is a scalar
+// (SGPR) operand of its v_fma.
+struct mmx_taps_f32 {
+    float w0[MMX_MAX_RADIUS_FAST + 1];  // order-0 Gaussian
+    float w2[MMX_MAX_RADIUS_FAST + 1];  // order-2 (second derivative) Gaussian
+};
+
+// scipy "reflect" (half-sample symmetric): d c b a | a b c d | d c b a.
+// Valid for any i (also |i| >> n), as scipy's NI_ExtendLine is.
+__host__ __device__ __forceinline__ int mmx_reflect(int i, int n)
+{
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+// internal launchers (defined one per translation unit, called by mmx_api.hip)
+int mmx_launch_zpass(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_cols,
+                     int64_t slot_elems, const mmx_taps_f32& taps, int radius,
+                     float* d_gz, float* d_gzz, hipStream_t stream);
+int mmx_launch_ypass(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
+                     const mmx_taps_f32& taps, int radius, const float* d_gz, const float* d_gzz,
+                     float* d_a, float* d_bc, hipStream_t stream);
+int mmx_launch_xpass(const mmx_block* d_blocks, int n_blocks, int max_rows, int max_nx,
+                     int64_t slot_elems, const mmx_taps_f32& taps, int radius,
+                     const float* d_a, const float* d_bc, float* d_log, hipStream_t stream);
