@@ -1,0 +1,113 @@
+"""ctypes binding of ``libmmx_hip.so`` (the C ABI declared in ``include/mmx.h``).
+
+There is NO CPU fallback: if the shared library is missing or a call fails the
+functions raise.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C magellanmapper_amd/csrc -j8``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_uint8, c_uint32, c_void_p)
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmx_hip.so")
+
+MMX_ABI_VERSION = 1
+MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
+MMX_MAX_RADIUS_FAST = 24
+MMX_MAX_RADIUS_GENERIC = 255
+MMX_CAND_CONTESTED = 1
+
+#: NumPy mirror of ``mmx_block`` (24 bytes).
+BLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("nz", "<i4"), ("ny", "<i4"), ("nx", "<i4"),
+                        ("slot", "<i4")], align=True)
+#: NumPy mirror of ``mmx_cand`` (48 bytes).
+CAND_DTYPE = np.dtype([("slot", "<i4"), ("s", "<i4"), ("z", "<i4"), ("y", "<i4"), ("x", "<i4"),
+                       ("flags", "<u4"), ("v", "<f4"), ("nbr_max", "<f4"), ("v64", "<f8"),
+                       ("_reserved", "<f8")], align=True)
+assert BLOCK_DTYPE.itemsize == 24 and CAND_DTYPE.itemsize == 48
+
+
+class Volume(Structure):
+    """``mmx_volume``."""
+    _fields_ = [("d_data", c_void_p), ("dtype", c_int32), ("_pad", c_int32),
+                ("stride_z", c_int64), ("stride_y", c_int64), ("stride_x", c_int64)]
+
+
+class MmxError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+_lib = None
+
+#: every symbol ``include/mmx.h`` declares
+SYMBOLS = (
+    "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
+    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_peaks_batch", "mmx_rescore_f64",
+    "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
+    "mmx_event_record", "mmx_event_elapsed_ms",
+)
+
+
+def lib() -> ctypes.CDLL:
+    """Load the library once; raise loudly when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmxError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run __graft_entry__.build() or make -C magellanmapper_amd/csrc). "
+            "There is no CPU fallback for this path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp = c_void_p
+    L.mmx_abi_version.restype = c_int
+    L.mmx_strerror.restype = c_char_p
+    L.mmx_strerror.argtypes = [c_int]
+    L.mmx_last_hip_error.restype = c_char_p
+    L.mmx_device_count.restype = c_int
+    log_args = [POINTER(Volume), vp, vp, c_int, c_int64, POINTER(c_double), POINTER(c_double),
+                c_int, c_double, vp, vp, vp]
+    L.mmx_log_batch_f32.argtypes = log_args
+    L.mmx_log_batch_f32_generic.argtypes = log_args
+    L.mmx_peaks_batch.argtypes = [vp, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
+                                  c_uint32, vp, vp]
+    L.mmx_rescore_f64.argtypes = [POINTER(Volume), vp, c_int, vp, c_uint32, vp, vp, vp,
+                                  POINTER(c_int32), POINTER(c_double), c_int, c_int, vp]
+    L.mmx_overlap_pairs.argtypes = [vp, vp, c_int, c_double, c_double, vp, vp, c_uint32, vp, vp]
+    L.mmx_close_pairs.argtypes = [vp, c_int, vp, c_int, POINTER(c_int32), vp, vp, vp]
+    L.mmx_event_create.argtypes = [POINTER(vp)]
+    L.mmx_event_destroy.argtypes = [vp]
+    L.mmx_event_record.argtypes = [vp, vp]
+    L.mmx_event_elapsed_ms.argtypes = [vp, vp, POINTER(c_float)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is None or name.startswith(("mmx_log", "mmx_peaks", "mmx_rescore",
+                                                  "mmx_overlap", "mmx_close", "mmx_event")):
+            fn.restype = c_int
+    if L.mmx_abi_version() != MMX_ABI_VERSION:
+        raise MmxError("libmmx_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        L = lib()
+        msg = L.mmx_strerror(status).decode()
+        hip = L.mmx_last_hip_error().decode()
+        raise MmxError(f"{what}: {msg}" + (f" ({hip})" if hip else ""))
+
+
+def as_double_ptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(POINTER(c_double))
+
+
+def as_int32_ptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(POINTER(c_int32))

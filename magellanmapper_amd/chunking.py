@@ -1,0 +1,68 @@
+"""Block geometry of a stack (mirror of the parts of ``magmap.cv.chunking`` on the path).
+
+* :func:`stack_splitter` -- reference magmap/cv/chunking.py:214-256 (with ``_num_units``
+  :170-185 and ``_bounds_side`` :188-211): the grid is ``ceil(shape / max_pixels)`` and
+  block ``k`` spans ``[k * mp, min(k * mp + mp + overlap, size))`` along each axis.
+* :func:`merge_blobs` -- :410-445: concatenate per-block tables, tagging each row with its
+  block's grid coordinate.
+* the multiprocessing helpers (:105-167) are kept as thin shims: blocks are dispatched to
+  GPUs, not to a process pool, but callers may still query / set the start method.
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import config
+
+
+def set_mp_start_method(val: Optional[str] = None) -> str:
+    if val is None:
+        val = config.roi_profile["mp_start"] if config.roi_profile else "fork"
+    avail = mp.get_all_start_methods()
+    if val not in avail:
+        val = avail[0]
+    try:
+        mp.set_start_method(val)
+    except RuntimeError:
+        pass
+    return val
+
+
+def is_fork() -> bool:
+    return mp.get_start_method(False) == "fork"
+
+
+def stack_splitter(shape: Sequence[int], max_pixels: Sequence[int],
+                   overlap: Optional[Sequence[int]] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """``(sub_roi_slices, sub_rois_offsets)``: an object array of slice triples indexed by
+    block (z, y, x) and a float array ``grid + (3,)`` of block origins."""
+    size = np.asarray(shape[:3])
+    mp_ = np.asarray(max_pixels)
+    grid = (-(-size // mp_)).astype(int)          # ceil division, per axis
+    ov = np.zeros(3, dtype=int) if overlap is None else np.asarray(overlap)
+    starts = [np.arange(g) * int(m) for g, m in zip(grid, mp_)]
+    stops = [np.minimum(st + int(m) + int(o), int(n))
+             for st, m, o, n in zip(starts, mp_, ov, size)]
+    slices = np.zeros(grid, dtype=object)
+    offsets = np.zeros(tuple(grid) + (3,))
+    for coord in np.ndindex(*grid):
+        slices[coord] = tuple(slice(int(starts[a][coord[a]]), int(stops[a][coord[a]]))
+                              for a in range(3))
+        offsets[coord] = [starts[a][coord[a]] for a in range(3)]
+    return slices, offsets
+
+
+def merge_blobs(blob_rois: np.ndarray) -> Optional[np.ndarray]:
+    """All block tables stacked, with the block's grid coordinate as 3 extra int columns."""
+    parts = []
+    for coord in np.ndindex(*blob_rois.shape):
+        tbl = blob_rois[coord]
+        if tbl is None or isinstance(tbl, (int, np.integer)):
+            continue
+        tag = np.empty((tbl.shape[0], 3), dtype=int)
+        tag[:] = coord
+        parts.append(np.concatenate((tbl, tag), axis=1))
+    return np.vstack(parts) if parts else None

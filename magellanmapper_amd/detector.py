@@ -1,0 +1,495 @@
+"""Per-ROI blob detection and the blob table (mirror of ``magmap.cv.detector``).
+
+Public surface kept from the reference (magmap/cv/detector.py):
+
+* :class:`Blobs` -- table + archive class: column registry shared at class level
+  (:116, :154-162), ``format_blobs`` to the 11 standard columns (:325-364), coordinate
+  shifting helpers (:603-709), ``blobs_in_channel`` (:747-772), npz archive version 5
+  (:68-86, :185-323).
+* :func:`calc_scaling_factor`, :func:`calc_overlap` (:810-841), ``OVERLAP_FACTOR`` (:41).
+* :func:`detect_blobs` (:874-957) -- the scikit-image ``blob_log`` call (:931-933) is
+  replaced by the device pipeline of :mod:`magellanmapper_amd.blob_log`.
+* :func:`remove_close_blobs` (:1000-1085) -- the all-pairs search runs on the device
+  (``mmx_close_pairs``); deletion, averaging (round-half-even) and last-write-wins are
+  applied on the host exactly as NumPy does in the reference.
+* :func:`get_blobs_in_roi`, :func:`get_blobs_interior` (:1210-1268),
+  :func:`meas_pruning_ratio` (:1126-1147), :func:`sort_blobs` (:985-997).
+"""
+from __future__ import annotations
+
+import math
+import os
+from enum import Enum
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import config
+
+#: blob confirmation flags
+CONFIRMATION: Dict[int, str] = {-1: "unverified", 0: "no", 1: "yes", 2: "maybe"}
+#: overlap between neighbouring blocks, in multiples of the pixel scaling
+OVERLAP_FACTOR: int = 5
+
+_logger = config.logger.getChild(__name__)
+
+
+class Blobs:
+    """Blob table ``[[z, y, x, radius, ...], ...]`` with named columns and an npz archive."""
+
+    #: archive version (5: column names no longer list the removed abs coords)
+    BLOBS_NP_VER: int = 5
+
+    class Keys(Enum):
+        VER = "ver"
+        BLOBS = "segments"
+        COLOCS = "colocs"
+        RESOLUTIONS = "resolutions"
+        BASENAME = "basename"
+        ROI_OFFSET = "offset"
+        ROI_SIZE = "roi_size"
+        COLS = "columns"
+
+    class Cols(Enum):
+        Z = "z"
+        Y = "y"
+        X = "x"
+        RADIUS = "radius"
+        CONFIRMED = "confirmed"
+        TRUTH = "truth"
+        CHANNEL = "channel"
+        ABS_Z = "abs_z"
+        ABS_Y = "abs_y"
+        ABS_X = "abs_x"
+        REGION = "region"
+
+    #: column -> index in the table; CLASS level and mutable, as in the reference: setting
+    #: ``cols`` on any instance re-targets every accessor (global state)
+    _col_inds: Dict["Blobs.Cols", Optional[int]] = {c: i for i, c in enumerate(Cols)}
+
+    def __init__(self, blobs=None, blob_matches=None, colocalizations=None, path=None, cols=None):
+        self._cols = None
+        self._blobs = None
+        self.cols = cols
+        self.blobs = blobs
+        self.blob_matches = blob_matches
+        self.colocalizations = colocalizations
+        self.path = path
+        self.ver = self.BLOBS_NP_VER
+        self.roi_offset = None
+        self.roi_size = None
+        self.resolutions = None
+        self.basename = None
+        self.scaling = np.ones(3)
+
+    # -- column registry ---------------------------------------------------------------
+    @property
+    def cols(self) -> Optional[Sequence[str]]:
+        return self._cols
+
+    @cols.setter
+    def cols(self, names: Optional[Sequence[str]]):
+        self._cols = names
+        if names is None:
+            return
+        index: Dict[Blobs.Cols, Optional[int]] = {c: None for c in self.Cols}
+        for i, name in enumerate(names):
+            try:
+                index[self.Cols(name)] = i
+            except ValueError:
+                _logger.warning("%s is not a valid Blobs column, skipping", name)
+        Blobs._col_inds = index
+
+    @property
+    def blobs(self) -> Optional[np.ndarray]:
+        return self._blobs
+
+    @blobs.setter
+    def blobs(self, table):
+        self._blobs = table
+        if table is not None and self.cols is None:
+            self.cols = [c.value for c in self.Cols][:table.shape[1]]
+
+    @classmethod
+    def _ind(cls, col):
+        if isinstance(col, cls.Cols):
+            return cls._col_inds[col]
+        if isinstance(col, (list, tuple)):
+            return [cls._ind(c) for c in col]
+        return col
+
+    @classmethod
+    def _get_rel_inds(cls) -> List[int]:
+        return [cls._col_inds[c] for c in (cls.Cols.Z, cls.Cols.Y, cls.Cols.X)]
+
+    @classmethod
+    def _get_abs_inds(cls) -> List[int]:
+        return [cls._col_inds[c] for c in (cls.Cols.ABS_Z, cls.Cols.ABS_Y, cls.Cols.ABS_X)]
+
+    # -- generic accessors -------------------------------------------------------------
+    @classmethod
+    def get_blob_col(cls, blob: np.ndarray, col):
+        many = blob.ndim > 1
+        if col is None:
+            return np.array([]) if many else None
+        col = cls._ind(col)
+        return blob[..., col] if many else blob[col]
+
+    @classmethod
+    def set_blob_col(cls, blob: np.ndarray, col, val, mask=np.s_[:], **kwargs) -> np.ndarray:
+        col = cls._ind(col)
+        if blob.ndim > 1:
+            blob[mask, ..., col] = val
+        else:
+            blob[col] = val
+        return blob
+
+    @classmethod
+    def get_blob_confirmed(cls, blob):
+        return cls.get_blob_col(blob, cls._col_inds[cls.Cols.CONFIRMED])
+
+    @classmethod
+    def set_blob_confirmed(cls, blob, *args, **kwargs):
+        return cls.set_blob_col(blob, cls._col_inds[cls.Cols.CONFIRMED], *args, **kwargs)
+
+    @classmethod
+    def get_blob_truth(cls, blob):
+        return cls.get_blob_col(blob, cls._col_inds[cls.Cols.TRUTH])
+
+    @classmethod
+    def set_blob_truth(cls, blob, *args, **kwargs):
+        return cls.set_blob_col(blob, cls._col_inds[cls.Cols.TRUTH], *args, **kwargs)
+
+    @classmethod
+    def get_blobs_channel(cls, blob):
+        return cls.get_blob_col(blob, cls._col_inds[cls.Cols.CHANNEL])
+
+    @classmethod
+    def set_blob_channel(cls, blob, *args, **kwargs):
+        return cls.set_blob_col(blob, cls._col_inds[cls.Cols.CHANNEL], *args, **kwargs)
+
+    @classmethod
+    def get_blob_abs_coords(cls, blobs):
+        return cls.get_blob_col(blobs, cls._get_abs_inds())
+
+    @classmethod
+    def set_blob_abs_coords(cls, blobs, coords, *args, **kwargs):
+        cls.set_blob_col(blobs, cls._get_abs_inds(), coords, *args, **kwargs)
+        return blobs
+
+    # -- table construction ------------------------------------------------------------
+    def format_blobs(self, channel=None) -> np.ndarray:
+        """Pad to all 11 columns with -1, mirror rel -> abs coordinates, set the channel."""
+        have = self.blobs.shape[1]
+        pad = -np.ones((self.blobs.shape[0], len(self.Cols) - have))
+        self.blobs = np.concatenate((self.blobs, pad), axis=1)
+        self.cols = [c.value for c in self.Cols]
+        self.blobs[:, self._get_abs_inds()] = self.blobs[:, self._get_rel_inds()]
+        if channel is not None:
+            self.set_blob_channel(self.blobs, channel)
+        return self.blobs
+
+    # -- coordinate helpers ------------------------------------------------------------
+    @classmethod
+    def shift_blobs(cls, blob, cols, fn, vals, to_int: bool = False):
+        if blob is None:
+            return blob
+        sub = fn(blob[cols] if blob.ndim == 1 else blob[..., cols], vals)
+        if to_int:
+            sub = sub.astype(int)
+        if blob.ndim == 1:
+            blob[cols] = sub
+        else:
+            blob[..., cols] = sub
+        return blob
+
+    @classmethod
+    def shift_blob_rel_coords(cls, blob, offset):
+        return cls.shift_blobs(blob, cls._get_rel_inds(), np.add, offset)
+
+    @classmethod
+    def shift_blob_abs_coords(cls, blob, offset):
+        return cls.shift_blobs(blob, cls._get_abs_inds(), np.add, offset)
+
+    @classmethod
+    def multiply_blob_rel_coords(cls, blob, factor):
+        return cls.shift_blobs(blob, cls._get_rel_inds(), np.multiply, factor, True)
+
+    @classmethod
+    def multiply_blob_abs_coords(cls, blob, factor):
+        return cls.shift_blobs(blob, cls._get_abs_inds(), np.multiply, factor, True)
+
+    def remove_abs_blob_coords(self, remove_extra: bool = False) -> np.ndarray:
+        """Drop the abs columns (and, with ``remove_extra``, any unnamed trailing columns)."""
+        candidates = Blobs._col_inds.values() if remove_extra else range(self.blobs.shape[1])
+        drop = set(Blobs._get_abs_inds())
+        keep = [i for i in candidates if i not in drop]
+        self.cols = [self.cols[i] for i in keep]
+        self.blobs = self.blobs[:, keep]
+        return self.blobs
+
+    @classmethod
+    def replace_rel_with_abs_blob_coords(cls, blobs: np.ndarray) -> np.ndarray:
+        blobs[:, cls._get_rel_inds()] = blobs[:, cls._get_abs_inds()]
+        return blobs
+
+    @classmethod
+    def blobs_in_channel(cls, blobs, channel, return_mask: bool = False):
+        mask = None
+        sel = blobs
+        if channel is not None:
+            mask = np.isin(cls.get_blobs_channel(blobs), channel)
+            sel = blobs[mask]
+        return (sel, mask) if return_mask else sel
+
+    @classmethod
+    def show_blobs_per_channel(cls, blobs):
+        for chl in np.unique(cls.get_blobs_channel(blobs)):
+            _logger.info("- blobs in channel %s: %s", int(chl), len(cls.blobs_in_channel(blobs, chl)))
+
+    @classmethod
+    def blob_for_db(cls, blob: np.ndarray) -> np.ndarray:
+        rest = [cls._col_inds[c] for c in (cls.Cols.RADIUS, cls.Cols.CONFIRMED, cls.Cols.TRUTH,
+                                            cls.Cols.CHANNEL)]
+        return np.array([*blob[cls._get_abs_inds()], *blob[rest]])
+
+    # -- archive -----------------------------------------------------------------------
+    def save_archive(self, to_add=None, update: bool = False):
+        """Write the uncompressed ``.npz`` archive (keys :class:`Keys`), backing up an
+        existing file first."""
+        if to_add is None:
+            present = sorted(((c, i) for c, i in self._col_inds.items() if i is not None),
+                             key=lambda e: e[1])
+            arc = {
+                self.Keys.VER.value: self.ver,
+                self.Keys.BLOBS.value: self.blobs,
+                self.Keys.RESOLUTIONS.value: self.resolutions,
+                self.Keys.BASENAME.value: self.basename,
+                self.Keys.ROI_OFFSET.value: self.roi_offset,
+                self.Keys.ROI_SIZE.value: self.roi_size,
+                self.Keys.COLOCS.value: self.colocalizations,
+                self.Keys.COLS.value: [c.value for c, _ in present],
+            }
+        else:
+            arc = to_add
+        if update:
+            with np.load(self.path, allow_pickle=True) as old:
+                arc = {k: old[k] for k in old.files}
+                arc.update(to_add)
+        _backup_file(self.path)
+        with open(self.path, "wb") as f:
+            np.savez(f, **arc)
+        _logger.info("Saved blobs archive to: %s", self.path)
+        return arc
+
+    def load_blobs(self, path: Optional[str] = None) -> "Blobs":
+        if path is not None:
+            self.path = path
+        with np.load(self.path, allow_pickle=True) as arc:
+            info = {}
+            for k in arc.files:
+                v = arc[k]
+                info[k] = v.item() if v.ndim == 0 else v   # 0-d arrays hold Python scalars / None
+        K = self.Keys
+        if K.VER.value in info:
+            self.ver = info[K.VER.value]
+        if K.COLS.value in info:
+            self.cols = list(info[K.COLS.value])
+        if K.BLOBS.value in info:
+            self.blobs = info[K.BLOBS.value]
+        self.colocalizations = info.get(K.COLOCS.value, self.colocalizations)
+        self.resolutions = info.get(K.RESOLUTIONS.value, self.resolutions)
+        self.basename = info.get(K.BASENAME.value, self.basename)
+        self.roi_offset = info.get(K.ROI_OFFSET.value, self.roi_offset)
+        self.roi_size = info.get(K.ROI_SIZE.value, self.roi_size)
+        if self.ver <= 4 and self.cols is not None:
+            self.cols = self.cols[:len(self.cols) - 3]
+        self.ver = self.BLOBS_NP_VER
+        return self
+
+
+def _backup_file(path: str) -> None:
+    """Move an existing file aside as ``name(1).ext``, ``name(2).ext``, ..."""
+    if not path or not os.path.exists(path):
+        return
+    stem, ext = os.path.splitext(path)
+    i = 1
+    while os.path.exists(f"{stem}({i}){ext}"):
+        i += 1
+    os.replace(path, f"{stem}({i}){ext}")
+
+
+# ------------------------------------------------------------------------------------
+def calc_scaling_factor() -> np.ndarray:
+    """Pixels per physical unit, ``1 / resolutions[0]``."""
+    if config.resolutions is None or len(config.resolutions) < 1:
+        raise AttributeError("Must load resolutions from file or set a resolution")
+    return np.divide(1.0, config.resolutions[0])
+
+
+def calc_overlap(factor: Optional[int] = None) -> np.ndarray:
+    """Block overlap in pixels per axis: ``ceil(scaling * factor)`` as ints."""
+    if factor is None:
+        factor = OVERLAP_FACTOR
+    return np.ceil(np.multiply(calc_scaling_factor(), factor)).astype(int)
+
+
+def _channels_of(roi_ndim: int, n_channels: int, channel, dim_channel: int = 3):
+    """``plot_3d.setup_channels`` (reference magmap/plot/plot_3d.py:24-52)."""
+    multichannel = roi_ndim > dim_channel
+    if not multichannel:
+        return False, [0]
+    return True, (range(n_channels) if channel is None else channel)
+
+
+def detect_blobs(roi, channel: Optional[Sequence[int]],
+                 exclude_border: Optional[Sequence[int]] = None) -> Optional[np.ndarray]:
+    """Detect blobs in one ROI -> ``(m, 11)`` float64 table, or ``None`` when nothing is found.
+
+    ``roi`` is a ``(z, y, x[, c])`` array (host) or a
+    :class:`magellanmapper_amd.blob_log.DeviceVolume`.  Reads ``config.resolutions`` and the
+    per-channel ROI profile at every call.  ``exclude_border`` is ``[pad_start, pad_end]`` in
+    z, y, x.
+    """
+    from . import blob_log as bl
+    dvol = roi if isinstance(roi, bl.DeviceVolume) else bl.DeviceVolume(roi)
+    tables = detect_blobs_blocks_device(dvol, channel, [(0, 0, 0)], [dvol.shape[:3]])
+    blobs_all = tables[0]
+    if blobs_all is None:
+        return None
+    if exclude_border is not None:
+        blobs_all = get_blobs_interior(blobs_all, dvol.shape[:3], *exclude_border)
+    return blobs_all
+
+
+def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None) -> List[Optional[np.ndarray]]:
+    """:func:`detect_blobs` for many blocks of one resident volume in one device pass.
+
+    Returns one 11-column table (block-relative coordinates) or ``None`` per block, rows
+    ordered as the reference orders them: channels in turn, within a channel the pruned
+    ``blob_log`` order.
+    """
+    from . import blob_log as bl
+    multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
+    first = config.get_roi_profile(list(channels)[0])
+    if first["isotropic"] is not None:
+        raise NotImplementedError(
+            "the 'isotropic' rescale (reference detector.py:893-897) is not built yet "
+            "(SURVEY.md section 8f row 4); use a profile with isotropic: None")
+    per_block: List[List[np.ndarray]] = [[] for _ in shapes]
+    for chl in channels:
+        settings = config.get_roi_profile(chl)
+        if getattr(settings, "spectral_unmixing", None) is not None:
+            raise NotImplementedError("spectral unmixing (reference detector.py:910-921) is "
+                                      "not built yet (SURVEY.md section 8f row 4)")
+        scaling_factor = calc_scaling_factor()[2]          # x scaling alone, as the reference
+        res = bl.blob_log_blocks(
+            dvol, chl if multichannel else 0, origins, shapes,
+            min_sigma=settings["min_sigma_factor"] * scaling_factor,
+            max_sigma=settings["max_sigma_factor"] * scaling_factor,
+            num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
+            overlap=settings["overlap"], stats=stats)
+        for i, blobs_log in enumerate(res):
+            if blobs_log.size < 1:
+                continue
+            blobs_log = blobs_log.copy()
+            blobs_log[:, 3] = blobs_log[:, 3] * math.sqrt(3)
+            per_block[i].append(Blobs(blobs_log).format_blobs(chl))
+    return [np.vstack(t) if t else None for t in per_block]
+
+
+# ------------------------------------------------------------------------------------
+def sort_blobs(blobs: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    order = np.lexsort(tuple(blobs[:, i] for i in range(2, -1, -1)))
+    return blobs[order], order
+
+
+def _smallest_signed_int(max_val) -> type:
+    """``libmag.dtype_within_range(0, max, True, True)`` (reference magmap/io/libmag.py:1116-1152)."""
+    for dt in (np.int8, np.int16, np.int32, np.int64):
+        if np.iinfo(dt).max >= max_val:
+            return dt
+    raise TypeError("unable to find an integer type for the coordinate range")
+
+
+def find_close_pairs(check_zyx: np.ndarray, master_zyx: np.ndarray, tol) -> Tuple[np.ndarray, np.ndarray]:
+    """Device all-pairs search: ``(last_check_per_master, check_hit)``.
+
+    For each master row the index of the LAST check row with ``|d| <= tol`` on all three
+    axes (-1 if none), and for each check row whether any master row matched.  This is
+    what the reference's chunked ``_find_close_blobs`` loop boils down to once NumPy's
+    duplicate fancy-index assignment (last write wins) and ``np.delete`` are applied
+    (reference detector.py:1049-1083).
+    """
+    import ctypes
+
+    import torch
+
+    from . import _native as nat
+    from .blob_log import _require_gpu, _stream_ptr
+    dev = _require_gpu()
+    L = nat.lib()
+    m = np.ascontiguousarray(master_zyx, dtype=np.int32)
+    c = np.ascontiguousarray(check_zyx, dtype=np.int32)
+    d_m = torch.from_numpy(m).to(dev)
+    d_c = torch.from_numpy(c).to(dev)
+    d_last = torch.empty(len(m), dtype=torch.int32, device=dev)
+    d_hit = torch.zeros(max(1, len(c)), dtype=torch.uint8, device=dev)
+    t = (ctypes.c_int32 * 3)(*[int(v) for v in np.broadcast_to(np.asarray(tol), (3,))])
+    nat.check(L.mmx_close_pairs(d_m.data_ptr(), len(m), d_c.data_ptr(), len(c), t,
+                                d_last.data_ptr(), d_hit.data_ptr(), _stream_ptr()), "mmx_close_pairs")
+    return d_last.cpu().numpy(), d_hit.cpu().numpy()[:len(c)].astype(bool)
+
+
+def remove_close_blobs(blobs: np.ndarray, blobs_master: np.ndarray, tol,
+                       chunk_size: int = 1000) -> Tuple[np.ndarray, np.ndarray]:
+    """Remove rows of ``blobs`` that lie within ``tol`` of a row of ``blobs_master``.
+
+    Returns ``(pruned, blobs_master)``; each matched master row's *abs* coordinates become
+    ``np.around((abs_master + abs_check) / 2)`` (round half to even) for its last matching
+    check row.  ``chunk_size`` is accepted for signature compatibility (the device search
+    needs no chunking).
+    """
+    if len(blobs) < 1 or len(blobs_master) < 1:
+        return blobs, blobs_master
+    # the reference compares coordinates cast to the smallest signed int type that holds
+    # them; integer-valued float coordinates survive the cast unchanged
+    dtype = _smallest_signed_int(np.amax((np.amax(blobs[:, :3]), np.amax(blobs_master[:, :3]))))
+    last, hit = find_close_pairs(blobs[:, :3].astype(dtype), blobs_master[:, :3].astype(dtype),
+                                 np.asarray(tol))
+    pruned = blobs[~hit]
+    matched = np.nonzero(last >= 0)[0]
+    Blobs(blobs)  # as the reference does: (re)binds the class-level column indices to this table
+    if len(matched):
+        abs_inds = Blobs._get_abs_inds()
+        between = np.around(np.divide(
+            np.add(blobs_master[matched][:, abs_inds], blobs[last[matched]][:, abs_inds]), 2))
+        blobs_master[np.ix_(matched, abs_inds)] = between
+    return pruned, blobs_master
+
+
+def meas_pruning_ratio(num_blobs_orig, num_blobs_after_pruning, num_blobs_next):
+    if num_blobs_next > 0 and num_blobs_orig > 0:
+        return (num_blobs_orig, num_blobs_after_pruning / num_blobs_orig,
+                num_blobs_after_pruning / num_blobs_next)
+    return None
+
+
+def get_blobs_in_roi(blobs: np.ndarray, offset, size, margin=(0, 0, 0), reverse: bool = True):
+    """Blobs inside ``[offset - margin, offset + size + margin)``; ``reverse`` takes the
+    arguments in x, y, z order (the reference's ROI convention)."""
+    if reverse:
+        offset, size, margin = offset[::-1], size[::-1], margin[::-1]
+    mask = np.ones(len(blobs), dtype=bool)
+    for ax in range(3):
+        mask &= blobs[:, ax] >= offset[ax] - margin[ax]
+        mask &= blobs[:, ax] < offset[ax] + size[ax] + margin[ax]
+    return blobs[mask], mask
+
+
+def get_blobs_interior(blobs: np.ndarray, shape, pad_start, pad_end) -> np.ndarray:
+    mask = np.ones(len(blobs), dtype=bool)
+    for ax in range(3):
+        mask &= blobs[:, ax] >= pad_start[ax]
+        mask &= blobs[:, ax] < shape[ax] - pad_end[ax]
+    return blobs[mask]

@@ -1,0 +1,434 @@
+"""Whole-volume blob detection in blocks (mirror of ``magmap.cv.stack_detect``).
+
+Same public surface as the reference (magmap/cv/stack_detect.py): :class:`StackTimes`
+(:27-31), :class:`StackDetector` (:34-257), :class:`Blocks` / :func:`setup_blocks`
+(:260-335), :func:`detect_blobs_blocks` (:338-517), :func:`detect_blobs_stack` (:520-615),
+:class:`StackPruner` (:618-861).
+
+What changes is *where blocks run*: the reference fans blocks out to a
+``multiprocessing.Pool`` (:222-257); here the volume is uploaded once and every block of
+this rank's share is filtered by the HIP kernels in a few batched launches
+(:mod:`magellanmapper_amd.blob_log`).  With ``torch.distributed`` initialised, blocks are
+sharded over ranks (one GPU each) and the per-block tables are all-gathered
+(:mod:`magellanmapper_amd.dist`); the overlap de-duplication then runs once.  Block geometry,
+table layout, pruning rules and all quirks (first-channel profile for block settings, rel <-
+abs replacement, dropped columns) are the reference's.
+"""
+from __future__ import annotations
+
+import os
+from enum import Enum
+from time import time
+from typing import NamedTuple, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import chunking, config, detector, roi_prof
+
+_logger = config.logger.getChild(__name__)
+
+
+class StackTimes(Enum):
+    DETECTION = "Detection"
+    PRUNING = "Pruning"
+    TOTAL = "Total_stack"
+
+
+class Image5d:
+    """Minimal stand-in for ``magmap.io.np_io.Image5d`` (reference np_io.py:33-70): the
+    ``(t, z, y, x[, c])`` array plus the attributes this path reads."""
+
+    def __init__(self, img=None, path_img=None, path_meta=None, img_io=None):
+        self.img = img
+        self.path_img = path_img
+        self.path_meta = path_meta
+        self.img_io = img_io
+        self.subimg_offset = None
+        self.subimg_size = None
+        self.meta = None
+        self.rgb = False
+        self.is_roi = False
+
+
+class StackDetector:
+    """Detects blobs block by block.  Class attributes mirror the reference's fork-shared
+    state (:51-57) but are only informational here."""
+    img5d = None
+    img = None
+    last_coord = None
+    denoise_max_shape = None
+    exclude_border = None
+    coloc = False
+    channel = None
+    #: counters of the last :meth:`detect_blobs_sub_rois` call (``blob_log.BatchStats``)
+    last_stats = None
+
+    @staticmethod
+    def _exclude_matrix(coord, last_coord, exclude_border):
+        """Border exclusion per block: none on faces that are outer faces of the ROI (:152-157)."""
+        if exclude_border is None:
+            return None
+        exclude = np.array([exclude_border, exclude_border])
+        exclude[0, np.equal(coord, 0)] = 0
+        exclude[1, np.equal(coord, last_coord)] = 0
+        return exclude
+
+    @classmethod
+    def _finish_block(cls, segments, shape, exclude, offset):
+        if segments is not None and exclude is not None:
+            segments = detector.get_blobs_interior(segments, shape, *exclude)
+        if segments is not None:
+            detector.Blobs.shift_blob_rel_coords(segments, offset)
+            detector.Blobs.shift_blob_abs_coords(segments, offset)
+        return segments
+
+    @classmethod
+    def detect_sub_roi_from_data(cls, coord, sub_roi_slices, offset):
+        return cls.detect_sub_roi(coord, offset, cls.last_coord, cls.denoise_max_shape,
+                                  cls.exclude_border, cls.img5d, cls.img[sub_roi_slices],
+                                  cls.channel, coloc=cls.coloc)
+
+    @classmethod
+    def detect_sub_roi(cls, coord, offset, last_coord, denoise_max_shape, exclude_border, img5d,
+                       sub_roi, channel, img_path=None, coloc=False):
+        """One block given as an array -> ``(coord, table | None)`` with coordinates shifted
+        to the full ROI (both the rel and the abs set, :164-170)."""
+        _check_unbuilt(denoise_max_shape, coloc)
+        exclude = cls._exclude_matrix(coord, last_coord, exclude_border)
+        segments = detector.detect_blobs(sub_roi, channel, exclude)
+        if segments is not None:
+            detector.Blobs.shift_blob_rel_coords(segments, offset)
+            detector.Blobs.shift_blob_abs_coords(segments, offset)
+        return coord, segments
+
+    @classmethod
+    def detect_blobs_sub_rois(cls, img5d, img, sub_roi_slices, sub_rois_offsets,
+                              denoise_max_shape, exclude_border, coloc, channel):
+        """All blocks -> object array (grid shaped) of per-block tables / ``None``.
+
+        ``img`` is the ``(z, y, x[, c])`` ROI: a host array (uploaded once) or an
+        already resident ``DeviceVolume``.
+        """
+        from . import blob_log as bl
+        from . import dist
+        _check_unbuilt(denoise_max_shape, coloc)
+        cls.img5d, cls.img, cls.channel, cls.coloc = img5d, img, channel, coloc
+        cls.denoise_max_shape, cls.exclude_border = denoise_max_shape, exclude_border
+        grid = sub_roi_slices.shape
+        last_coord = np.subtract(grid, 1)
+        cls.last_coord = last_coord
+        coords = list(np.ndindex(*grid))
+        mine = dist.my_share(len(coords))            # all of them without torch.distributed
+        shape3 = img.shape[:3]
+        origins, shapes = [], []
+        for i in mine:
+            slc = sub_roi_slices[coords[i]]
+            rng = [s.indices(n) for s, n in zip(slc, shape3)]
+            origins.append(tuple(r[0] for r in rng))
+            shapes.append(tuple(r[1] - r[0] for r in rng))
+        stats = bl.BatchStats()
+        tables = []
+        if mine:
+            dvol = img if isinstance(img, bl.DeviceVolume) else bl.DeviceVolume(img)
+            tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats)
+        cls.last_stats = stats
+        local = []
+        for i, tbl, shp in zip(mine, tables, shapes):
+            coord = coords[i]
+            exclude = cls._exclude_matrix(coord, last_coord, exclude_border)
+            local.append((i, cls._finish_block(tbl, shp, exclude, sub_rois_offsets[coord])))
+        seg_rois = np.zeros(grid, dtype=object)
+        for i, tbl in dist.gather_tables(local, len(coords)):
+            seg_rois[coords[i]] = tbl
+        return seg_rois
+
+
+def _check_unbuilt(denoise_max_shape, coloc):
+    if denoise_max_shape is not None:
+        raise NotImplementedError(
+            "per-block preprocessing (saturate_roi / denoise_roi, reference stack_detect.py:122-150) "
+            "is not built yet (SURVEY.md section 8f row 1); set the profile's denoise_size to None")
+    if coloc:
+        raise NotImplementedError(
+            "intensity co-localisation (reference colocalizer.py:340-441) is not built yet "
+            "(SURVEY.md section 8f row 2)")
+
+
+class Blocks(NamedTuple):
+    """Block processing parameters (same 9 fields as the reference, :260-279)."""
+    sub_roi_slices: np.ndarray
+    sub_rois_offsets: np.ndarray
+    denoise_max_shape: Optional[np.ndarray]
+    exclude_border: Optional[Sequence[int]]
+    tol: np.ndarray
+    overlap_base: np.ndarray
+    overlap: np.ndarray
+    overlap_padding: np.ndarray
+    max_pixels: np.ndarray
+
+
+def setup_blocks(settings, shape: Sequence[int]) -> Blocks:
+    """Block grid and pruning distances from a profile and ``config.resolutions``."""
+    scale = detector.calc_scaling_factor()
+    denoise_size = settings["denoise_size"]
+    denoise_max_shape = (np.ceil(np.multiply(scale, denoise_size)).astype(int)
+                         if denoise_size else None)
+    overlap_base = detector.calc_overlap()
+    tol = np.multiply(overlap_base, settings["prune_tol_factor"]).astype(int)
+    overlap_padding = tol.copy()
+    overlap = overlap_base.copy()
+    exclude_border = settings["exclude_border"]
+    if exclude_border is not None:
+        # overlap must exceed twice the excluded border so no plane is excluded from both
+        # neighbours; one more plane where a border is excluded, and no padding there
+        twice = np.multiply(2, exclude_border)
+        overlap = np.where(overlap < twice, twice, overlap)
+        has_border = np.greater(exclude_border, 0)
+        overlap[has_border] += 1
+        overlap_padding[has_border] = 0
+    max_pixels = np.ceil(np.multiply(scale, settings["segment_size"])).astype(int)
+    slices, offsets = chunking.stack_splitter(shape, max_pixels, overlap)
+    return Blocks(slices, offsets, denoise_max_shape, exclude_border, tol, overlap_base, overlap,
+                  overlap_padding, max_pixels)
+
+
+def _combine_paths(base: Optional[str], suffix: str) -> str:
+    """``libmag.combine_paths`` for the default arguments (reference libmag.py:331-380)."""
+    if not base:
+        return suffix
+    if not os.path.basename(base):
+        return os.path.join(base, suffix)
+    return os.path.splitext(base)[0] + "_" + suffix
+
+
+def _subimage_name(base: str, offset, shape) -> str:
+    """``naming.make_subimage_name`` (reference naming.py:9-38): x,y,z order in the name."""
+    site = "{}x{}".format(tuple(offset[::-1]), tuple(shape[::-1])).replace(" ", "")
+    stem, ext = os.path.splitext(base)
+    return f"{stem}_{site}{ext}"
+
+
+def _prepare_subimg(image5d, offset, size):
+    """``plot_3d.prepare_subimg`` (reference plot_3d.py:340-375): ``[t=0, z, y, x]`` slab."""
+    sl = tuple(slice(int(o), int(o) + int(s)) for o, s in zip(offset, size))
+    return image5d[0][sl]
+
+
+def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, channels=None,
+                        verify: bool = False, save_dfs: bool = True, full_roi: bool = False,
+                        coloc: bool = False):
+    """Detect blobs in a large image block by block -> ``(stats, fdbk, Blobs)``."""
+    time_start = time()
+    if img5d.img is None:
+        raise ValueError("Image data is None")
+    if verify:
+        raise NotImplementedError("truth-set verification is outside this path's scope")
+    image5d = img5d.img
+    subimg_path_base = filename_base
+    if size is None or offset is None:
+        size = image5d.shape[1:4]
+        offset = (0, 0, 0)
+    else:
+        subimg_path_base = _subimage_name(filename_base, offset, size)
+    filename_blobs = _combine_paths(subimg_path_base, config.SUFFIX_BLOBS)
+
+    roi = image5d[0] if full_roi else _prepare_subimg(image5d, offset, size)
+    num_chls_roi = 1 if len(roi.shape) < 4 else roi.shape[3]
+    if num_chls_roi < 2:
+        coloc = False
+
+    time_detection_start = time()
+    if channels is None:
+        channels = detector._channels_of(roi.ndim, num_chls_roi, None)[1]
+    settings = config.get_roi_profile(channels[0])       # first channel's block settings
+    blocks = setup_blocks(settings, roi.shape)
+    seg_rois = StackDetector.detect_blobs_sub_rois(
+        img5d, roi, blocks.sub_roi_slices, blocks.sub_rois_offsets, blocks.denoise_max_shape,
+        blocks.exclude_border, coloc, channels)
+    detection_time = time() - time_detection_start
+
+    time_pruning_start = time()
+    segments_all, df_pruning = StackPruner.prune_blobs_mp(
+        roi, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+        blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    pruning_time = time() - time_pruning_start
+
+    if df_pruning is not None and save_dfs and len(df_pruning):
+        _save_pruning_ratios(df_pruning)
+
+    blobs = detector.Blobs(segments_all, path=filename_blobs)
+    colocs = None
+    if segments_all is not None:
+        blobs.replace_rel_with_abs_blob_coords(segments_all)
+        blobs.blobs = segments_all
+        if coloc:
+            colocs = segments_all[:, 10:10 + num_chls_roi].astype(np.uint8)
+        segments_all = blobs.remove_abs_blob_coords(True)
+
+    blobs.blobs = segments_all
+    blobs.colocalizations = colocs
+    blobs.resolutions = config.resolutions
+    blobs.basename = os.path.basename(config.filename) if config.filename else None
+    blobs.roi_offset = offset
+    blobs.roi_size = size
+
+    times = {StackTimes.DETECTION: [detection_time], StackTimes.PRUNING: [pruning_time],
+             StackTimes.TOTAL: time() - time_start}
+    blobs.times = times
+    if save_dfs:
+        import pandas as pd
+        pd.DataFrame({k.value: v for k, v in times.items()}).to_csv(
+            "stack_detection_times.csv", index=False)
+    if segments_all is None:
+        _logger.info("No blobs detected")
+    else:
+        _logger.info("Total blobs found: %s", len(segments_all))
+    return None, None, blobs
+
+
+def _save_pruning_ratios(df):
+    """``blob_ratios.csv`` and the blob-count weighted means (reference :424-442)."""
+    df.to_csv("blob_ratios.csv", index=False)
+    cols = df.columns.tolist()
+    if "blobs" in cols:
+        weights = df["blobs"]
+        total = np.sum(weights)
+        means = {f"mean_{c}": [np.sum(np.multiply(df[c], weights)) / total] for c in cols[1:]}
+        import pandas as pd
+        pd.DataFrame(means).to_csv("blob_ratios_means.csv", index=False)
+
+
+def _combine_arrs(arrs):
+    arrs = [a for a in arrs if a is not None]
+    if not arrs:
+        return None
+    return arrs[0] if len(arrs) == 1 else np.concatenate(arrs)
+
+
+def detect_blobs_stack(filename_base: str, img5d, subimg_offset=None, subimg_size=None,
+                       coloc: bool = False):
+    """Detect blobs in a whole image; channels whose profiles agree on
+    ``ROIProfile.BLOCK_SIZES`` share one set of blocks, others get their own (:554-561).
+    Saves ``<base>_blobs.npz``."""
+    if img5d is None or img5d.img is None:
+        raise IOError("No image data available for blob detection")
+    n_chl = img5d.img.shape[4] if img5d.img.ndim > 4 else 1
+    channels = detector._channels_of(img5d.img.ndim, n_chl, config.channel, 4)[1]
+    channels = list(channels)
+    if roi_prof.ROIProfile.is_identical_settings(
+            [config.get_roi_profile(c) for c in channels], roi_prof.ROIProfile.BLOCK_SIZES):
+        channels = [channels]
+    outs = []
+    for chl in channels:
+        chl = list(chl) if isinstance(chl, (list, tuple, range)) else [chl]
+        outs.append(detect_blobs_blocks(
+            filename_base, img5d, subimg_offset, subimg_size, chl, False,
+            not config.grid_search_profile, getattr(img5d, "is_roi", False), coloc))
+    blobs_all = None
+    if outs:
+        blobs_all = outs[0][2]
+        blobs_all.blobs = _combine_arrs([o[2].blobs for o in outs])
+        blobs_all.colocalizations = _combine_arrs([o[2].colocalizations for o in outs])
+        if blobs_all.blobs is not None:
+            detector.Blobs.show_blobs_per_channel(blobs_all.blobs)
+        from . import dist
+        if dist.rank() == 0:
+            blobs_all.save_archive()
+    return None, "", blobs_all
+
+
+class StackPruner:
+    """Removes duplicates of blobs that were detected in two overlapping blocks."""
+    blobs_to_prune = None
+
+    @classmethod
+    def prune_overlap_by_index(cls, i):
+        return cls.prune_overlap(i, cls.blobs_to_prune[i])
+
+    @classmethod
+    def prune_overlap(cls, i, pruner):
+        """One overlap slab: rows tagged block ``i`` along ``axis`` are the master set,
+        rows tagged ``i + 1`` are checked against it (:643-677)."""
+        blobs, axis, tol, blobs_next = pruner
+        if blobs is None:
+            return None, None
+        tag_col = blobs.shape[1] - 3 + axis
+        n_orig = len(blobs)
+        master = blobs[blobs[:, tag_col] == i]
+        check = blobs[blobs[:, tag_col] == i + 1]
+        pruned, master = detector.remove_close_blobs(check, master, tol)
+        after = np.concatenate((master, pruned))
+        ratios = None
+        if blobs_next is not None:
+            ratios = detector.meas_pruning_ratio(n_orig, len(after), len(blobs_next))
+        return after, ratios
+
+    @classmethod
+    def prune_blobs_mp(cls, img, seg_rois, overlap, tol, sub_roi_slices, sub_rois_offsets,
+                       channels, overlap_padding=None):
+        """Prune duplicates in the overlap slabs, per channel, axis by axis (:679-861).
+
+        For every axis with more than one block, every block boundary ``j | j+1`` defines a
+        slab ``[end_j - (overlap + pad), end_j + pad)`` spanning the whole plane; blobs in it
+        are de-duplicated between the two block generations, everything else passes through,
+        and the recombined table goes on to the next axis.  Returns ``(table, DataFrame)``
+        or ``(None, None)``.
+        """
+        import pandas as pd
+        merged = chunking.merge_blobs(seg_rois)
+        if merged is None:
+            return None, None
+        if overlap_padding is None:
+            overlap_padding = tol
+        shape3 = img.shape[:3]
+        grid = sub_roi_slices.shape
+        coord_last = tuple(np.subtract(grid, 1))
+        ratio_cols = ("blobs", "ratio_pruning", "ratio_adjacent")
+        ratios_all = {}
+        per_channel = []
+        for chl in channels:
+            blobs = detector.Blobs.blobs_in_channel(merged, chl)
+            for axis in range(3):
+                n_sections = sub_rois_offsets.shape[axis]
+                if n_sections <= 1:
+                    continue
+                pos = blobs[:, axis]
+                shift = overlap[axis] + overlap_padding[axis]
+                passthrough = []
+                slabs = []
+                for j in range(n_sections):
+                    coord = [0, 0, 0]
+                    coord[axis] = j
+                    coord = tuple(coord)
+                    start = sub_rois_offsets[coord][axis]
+                    slc = sub_roi_slices[coord]
+                    extent = [len(range(*s.indices(n))) for s, n in zip(slc, shape3)]
+                    end = start + extent[axis]
+                    lo = start + (shift if j > 0 else 0)
+                    if j < n_sections - 1:
+                        slab_lo, slab_hi = end - shift, end + overlap_padding[axis]
+                        in_slab = blobs[(pos >= slab_lo) & (pos < slab_hi)]
+                        nxt_lo = end + tol[axis]
+                        nxt_hi = nxt_lo + overlap[axis] + 2 * overlap_padding[axis]
+                        roi_end = sub_rois_offsets[coord_last][axis] + extent[axis]
+                        in_next = None
+                        if nxt_lo < roi_end and nxt_hi < roi_end:
+                            in_next = blobs[(pos >= nxt_lo) & (pos < nxt_hi)]
+                        slabs.append((in_slab, axis, tol, in_next))
+                        passthrough.append(blobs[(pos < slab_lo) & (pos >= lo)])
+                    else:
+                        slabs.append((None, axis, tol, None))
+                        passthrough.append(blobs[(pos < end) & (pos >= lo)])
+                cls.blobs_to_prune = slabs
+                deduped = []
+                for j in range(len(slabs)):
+                    after, ratios = cls.prune_overlap(j, slabs[j])
+                    if after is not None:
+                        deduped.append(after)
+                    if ratios:
+                        for col, val in zip(ratio_cols, ratios):
+                            ratios_all.setdefault(col, []).append(val)
+                blobs = np.concatenate(passthrough + deduped)
+            per_channel.append(blobs)
+        out = np.vstack(per_channel)[:, :-3]
+        return out, pd.DataFrame(ratios_all)

@@ -1,0 +1,364 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no compute calls
+through the C ABI).  Modelled on the reference's own unit tests
+(magmap/tests/test_detector.py, test_chunking.py) plus the golden vectors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, lexsorted, load_golden
+from magellanmapper_amd import _native, chunking, config, detector, kernels1d, roi_prof, stack_detect
+
+
+# ---------------------------------------------------------------- C ABI (load + symbols)
+def test_library_loads_and_exports_every_declared_symbol():
+    assert os.path.exists(_native.LIB_PATH), "build libmmx_hip.so first (__graft_entry__.build())"
+    lib = _native.lib()
+    header = open(os.path.join(ROOT, "include", "mmx.h")).read()
+    declared = set(re.findall(r"\b(mmx_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mmx_status", "mmx_dtype"}
+    assert declared == set(_native.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mmx_abi_version() == _native.MMX_ABI_VERSION
+    assert lib.mmx_strerror(0) == b"ok" and lib.mmx_strerror(5) == b"unsupported configuration"
+
+
+def test_struct_layouts_match_header():
+    assert _native.BLOCK_DTYPE.itemsize == 24
+    assert _native.CAND_DTYPE.itemsize == 48
+    assert _native.CAND_DTYPE.fields["v64"][1] == 32
+    assert ctypes.sizeof(_native.Volume) == 40
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any device work."""
+    lib = _native.lib()
+    assert lib.mmx_peaks_batch(None, 1, None, None, 1, 1, 0.1, 1e-5, None, 1, None, None) == 1
+    vol = _native.Volume(0, 1, 0, 1, 1, 1)
+    w = np.ones(3)
+    assert lib.mmx_log_batch_f32(ctypes.byref(vol), None, None, 1, 8, _native.as_double_ptr(w),
+                                 _native.as_double_ptr(w), 2, 1.0, None, None, None) == 1
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "magellanmapper_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("oracle/ndfilters.c", ""), fn
+
+
+def test_no_gpu_means_loud_failure():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from magellanmapper_amd import blob_log as bl
+    with pytest.raises(_native.MmxError):
+        bl.blob_log(np.zeros((8, 8, 8), np.uint16), 1, 2, 2, 0.1, 0.5)
+
+
+# ---------------------------------------------------------------- filter parameters
+@pytest.mark.parametrize("sigma", [0.7, 1.0, 2.6, 2.8, 3.0, 3.5, 5.0, 14.0])
+def test_half_kernels_equal_scipy(sigma):
+    from scipy.ndimage import _filters as sf
+    R = kernels1d.kernel_radius(sigma)
+    for order in (0, 2):
+        full = sf._gaussian_kernel1d(sigma, order, R)[::-1]
+        np.testing.assert_array_equal(kernels1d.gaussian_half_kernel(sigma, order, R), full[R:])
+
+
+def test_sigma_ladder_equals_oracle():
+    from oracle import blob_log_oracle as blo
+    for lo, hi, n in ((3, 5, 10), (3, 3, 1), (2.6 / 1.1, 2.8 / 1.1, 10), (1.0, 5.5, 10)):
+        sig, norm = kernels1d.sigma_ladder(lo, hi, n)
+        want, scalar = blo.sigma_list(lo, hi, n)
+        assert scalar
+        np.testing.assert_array_equal(sig, want[:, 0])
+        np.testing.assert_array_equal(norm, [np.mean(r) ** 2 for r in want])
+
+
+def test_plan_batches():
+    from magellanmapper_amd.blob_log import plan_batches
+    shapes = [(10, 10, 10)] * 5 + [(20, 10, 10)] + [(10, 10, 10)] * 3
+    b = plan_batches(shapes, 5, budget_bytes=4 * 1000 * 36)
+    assert sum(b, []) == list(range(9))
+    for batch in b:
+        slot = max(int(np.prod(shapes[i])) for i in batch)
+        assert len(batch) == 1 or len(batch) * slot * 36 <= 4 * 1000 * 36
+    assert plan_batches(shapes, 5, 1 << 40) == [list(range(9))]
+
+
+# ---------------------------------------------------------------- Blobs (reference test_detector.py)
+def test_blob_columns_and_accessors():
+    rng = np.random.default_rng(0)
+    blobs = rng.random(20).reshape((5, 4))
+    blobs[:, :3] = np.multiply(blobs[:, :3], 100).astype(int)
+    blobs[:, 3] = blobs[:, 3] * 10
+    bl = detector.Blobs(blobs)
+    assert bl.cols == [c.value for c in bl.Cols][:4]
+    assert bl._col_inds[bl.Cols.RADIUS] == 3
+    assert bl._col_inds[bl.Cols.ABS_X] is None
+    bl.format_blobs()
+    assert bl.cols == [c.value for c in bl.Cols]
+    assert bl._col_inds[bl.Cols.RADIUS] == 3 and bl._col_inds[bl.Cols.ABS_X] == 9
+    assert bl.blobs.shape == (5, 11)
+    np.testing.assert_array_equal(bl.blobs[:, 7:10], bl.blobs[:, :3])
+    np.testing.assert_array_equal(bl.blobs[:, [4, 5, 6, 10]], -np.ones((5, 4)))
+
+    np.testing.assert_array_equal(bl.get_blob_confirmed(bl.blobs), bl.blobs[:, 4])
+    bl.set_blob_confirmed(bl.blobs, 1)
+    assert np.all(bl.get_blob_confirmed(bl.blobs) == 1)
+    np.testing.assert_array_equal(bl.get_blob_truth(bl.blobs), bl.blobs[:, 5])
+    bl.set_blob_truth(bl.blobs, 2)
+    assert np.all(bl.get_blob_truth(bl.blobs) == 2)
+    np.testing.assert_array_equal(bl.get_blobs_channel(bl.blobs), bl.blobs[:, 6])
+    bl.set_blob_channel(bl.blobs, 3)
+    assert np.all(bl.get_blobs_channel(bl.blobs) == 3)
+    np.testing.assert_array_equal(bl.get_blob_abs_coords(bl.blobs), bl.blobs[:, 7:10])
+    bl.set_blob_abs_coords(bl.blobs, (1, 2, 3))
+    assert all(np.all(bl.get_blob_abs_coords(bl.blobs) == (1, 2, 3), axis=1))
+
+    t = bl.blobs.copy()
+    detector.Blobs.shift_blob_rel_coords(t, (10, 20, 30))
+    np.testing.assert_array_equal(t[:, :3], bl.blobs[:, :3] + (10, 20, 30))
+    detector.Blobs.replace_rel_with_abs_blob_coords(t)
+    np.testing.assert_array_equal(t[:, :3], t[:, 7:10])
+    b2 = detector.Blobs(t)
+    out = b2.remove_abs_blob_coords(True)
+    assert out.shape[1] == 8
+    assert b2.cols == ["z", "y", "x", "radius", "confirmed", "truth", "channel", "region"]
+    detector.Blobs(np.ones((1, 4))).format_blobs()   # restore the 11-column registry
+
+
+def test_archive_roundtrip(tmp_path):
+    tbl = np.arange(24, dtype=float).reshape(3, 8)
+    b = detector.Blobs(tbl, path=str(tmp_path / "x_blobs.npz"),
+                       cols=["z", "y", "x", "radius", "confirmed", "truth", "channel", "region"])
+    b.resolutions = np.array([[1., 1., 1.]])
+    b.basename, b.roi_offset, b.roi_size = "x", (0, 0, 0), (3, 4, 5)
+    arc = b.save_archive()
+    assert set(arc) == {"ver", "segments", "resolutions", "basename", "offset", "roi_size", "colocs",
+                        "columns"}
+    b.save_archive()                                    # second save backs the first one up
+    assert os.path.exists(tmp_path / "x_blobs(1).npz")
+    back = detector.Blobs().load_blobs(b.path)
+    np.testing.assert_array_equal(back.blobs, tbl)
+    assert list(back.cols) == b.cols and back.basename == "x"
+    detector.Blobs(np.ones((1, 4))).format_blobs()
+
+
+def test_resolution_helpers():
+    config.resolutions = None
+    with pytest.raises(AttributeError):
+        detector.calc_scaling_factor()
+    config.resolutions = [[6.6, 1.1, 1.1]]
+    g = load_golden("blocks.npz")
+    np.testing.assert_array_equal(detector.calc_overlap(2), g["calc_overlap_2"])
+    np.testing.assert_allclose(detector.calc_scaling_factor(), 1 / np.array([6.6, 1.1, 1.1]))
+
+
+def test_interior_and_roi_filters():
+    rng = np.random.default_rng(1)
+    t = np.hstack((rng.integers(0, 30, (50, 3)).astype(float), np.ones((50, 8))))
+    inner = detector.get_blobs_interior(t, (30, 30, 30), (2, 3, 4), (1, 0, 5))
+    keep = ((t[:, 0] >= 2) & (t[:, 0] < 29) & (t[:, 1] >= 3) & (t[:, 1] < 30) & (t[:, 2] >= 4) &
+            (t[:, 2] < 25))
+    np.testing.assert_array_equal(inner, t[keep])
+    sub, mask = detector.get_blobs_in_roi(t, (5, 6, 7), (10, 10, 10))     # x, y, z order
+    want = ((t[:, 0] >= 7) & (t[:, 0] < 17) & (t[:, 1] >= 6) & (t[:, 1] < 16) & (t[:, 2] >= 5) &
+            (t[:, 2] < 15))
+    np.testing.assert_array_equal(mask, want)
+
+
+# ---------------------------------------------------------------- chunking (reference test_chunking.py)
+def _split_remerge(roi, max_pixels, overlap):
+    slices, _ = chunking.stack_splitter(roi.shape, max_pixels, overlap)
+    out = np.zeros_like(roi)
+    grid = slices.shape
+    for c in np.ndindex(*grid):
+        sub = roi[slices[c]]
+        keep = [sub.shape[a] if c[a] == grid[a] - 1 else min(sub.shape[a], max_pixels[a])
+                for a in range(3)]
+        o = [slices[c][a].start for a in range(3)]
+        out[o[0]:o[0] + keep[0], o[1]:o[1] + keep[1], o[2]:o[2] + keep[2]] = \
+            sub[:keep[0], :keep[1], :keep[2]]
+    return out
+
+
+def test_stack_splitter_reference_geometry():
+    roi = np.arange(5 * 4 * 4).reshape((5, 4, 4))
+    g = load_golden("blocks.npz")
+    config.resolutions = [[6.6, 1.1, 1.1]]
+    for j, ov in enumerate([np.array((0, 1, 1)), np.array((0, 1, 2)), np.array((1, 1, 2)),
+                            detector.calc_overlap(2)]):
+        sl, off = chunking.stack_splitter(roi.shape, [1, 3, 3], ov)
+        got = np.array([[[s.start, s.stop] for s in sl[c]] for c in np.ndindex(*sl.shape)]
+                       ).reshape(sl.shape + (3, 2))
+        np.testing.assert_array_equal(got, g["ss%d_slices" % j])
+        np.testing.assert_array_equal(off, g["ss%d_offsets" % j])
+        np.testing.assert_array_equal(_split_remerge(roi, [1, 3, 3], ov), roi)
+
+
+def test_setup_blocks_sweep_matches_reference():
+    g = load_golden("blocks.npz")
+    for i in range(int(g["n_cases"])):
+        pre = "c%d_" % i
+        excl = None if g[pre + "exclude_border"].ndim == 0 else tuple(g[pre + "exclude_border"])
+        dn = None if float(g[pre + "denoise_size"]) < 0 else g[pre + "denoise_size"].item()
+        config.resolutions = [g[pre + "resolutions"]]
+        prof = roi_prof.ROIProfile(segment_size=g[pre + "segment_size"].item(), exclude_border=excl,
+                                   prune_tol_factor=tuple(g[pre + "prune_tol_factor"]),
+                                   denoise_size=dn)
+        bl = stack_detect.setup_blocks(prof, tuple(g[pre + "shape"]))
+        grid = bl.sub_roi_slices.shape
+        sl = np.array([[[s.start, s.stop] for s in bl.sub_roi_slices[c]]
+                       for c in np.ndindex(*grid)]).reshape(grid + (3, 2))
+        np.testing.assert_array_equal(sl, g[pre + "slices"])
+        np.testing.assert_array_equal(bl.sub_rois_offsets, g[pre + "offsets"])
+        for key in ("tol", "overlap_base", "overlap", "overlap_padding", "max_pixels"):
+            np.testing.assert_array_equal(getattr(bl, key), g[pre + key])
+        if g[pre + "denoise_max_shape"].ndim == 0:
+            assert bl.denoise_max_shape is None
+        else:
+            np.testing.assert_array_equal(bl.denoise_max_shape, g[pre + "denoise_max_shape"])
+    # the benchmark grid: 4 x 8 x 8 blocks of at most 261^3
+    config.resolutions = [[1., 1., 1.]]
+    bl = stack_detect.setup_blocks(roi_prof.ROIProfile(segment_size=256, denoise_size=None),
+                                   (1024, 2048, 2048))
+    assert bl.sub_roi_slices.shape == (4, 8, 8)
+    assert bl.sub_roi_slices[0, 0, 0] == (slice(0, 261), slice(0, 261), slice(0, 261))
+    assert bl.sub_roi_slices[3, 7, 7] == (slice(768, 1024), slice(1792, 2048), slice(1792, 2048))
+
+
+def test_merge_blobs_tags_rows():
+    seg = np.zeros((1, 2, 2), dtype=object)
+    seg[0, 0, 0] = np.ones((2, 11))
+    seg[0, 0, 1] = None
+    seg[0, 1, 1] = np.full((3, 11), 2.0)
+    m = chunking.merge_blobs(seg)
+    assert m.shape == (5, 14)
+    np.testing.assert_array_equal(m[:2, 11:], [[0, 0, 0]] * 2)
+    np.testing.assert_array_equal(m[2:, 11:], [[0, 1, 1]] * 3)
+    assert chunking.merge_blobs(np.zeros((2, 1, 1), dtype=object)) is None
+
+
+# ---------------------------------------------------------------- profiles
+def test_profile_layering_and_yaml(tmp_path):
+    prof = roi_prof.ROIProfile()
+    assert prof["min_sigma_factor"] == 3 and prof["num_sigma"] == 10 and prof["denoise_size"] == 25
+    prof.add_profiles("lightsheet,4xnuc")
+    assert prof["settings_name"] == "default,lightsheet,4xnuc"
+    assert prof["max_sigma_factor"] == 4 and prof["overlap"] == 0.55        # later wins
+    assert prof["exclude_border"] == (1, 0, 0) and prof["isotropic"] == (0.96, 1, 1)
+    y = tmp_path / "roi_test.yaml"
+    y.write_text("---\nnum_sigma: 5\ndetection_threshold: 0.2\nexclude_border: null\n...\n")
+    prof.add_profiles(str(y))
+    assert prof["num_sigma"] == 5 and prof["exclude_border"] is None
+    assert not prof.check_file_changed()
+    os.utime(y, (os.path.getmtime(y) + 10,) * 2)
+    assert prof.check_file_changed()
+    prof.add_profiles("nonexistent")                                       # skipped, not an error
+    a, b = roi_prof.ROIProfile(), roi_prof.ROIProfile()
+    assert roi_prof.ROIProfile.is_identical_settings([a, b], roi_prof.ROIProfile.BLOCK_SIZES)
+    b.add_profiles("20x")
+    assert not roi_prof.ROIProfile.is_identical_settings([a, b], roi_prof.ROIProfile.BLOCK_SIZES)
+
+
+def test_per_channel_profiles():
+    config.setup_roi_profiles(["lightsheet", "4xnuc"])
+    assert config.get_roi_profile(0)["segment_size"] == 150
+    assert config.get_roi_profile(1)["max_sigma_factor"] == 4
+    assert config.get_roi_profile(7) is config.roi_profile      # beyond the list: the default one
+    config.setup_roi_profiles(None)
+
+
+# ---------------------------------------------------------------- overlap pruning (host rules)
+def _brute_close(check, master, tol):
+    d = np.abs(master[:, None, :].astype(np.int64) - check[None, :, :].astype(np.int64))
+    close = (d <= np.asarray(tol)).all(2)
+    last = np.where(close.any(1), close.shape[1] - 1 - np.argmax(close[:, ::-1], axis=1), -1)
+    return last.astype(np.int32), close.any(0)
+
+
+def test_remove_close_blobs_apply_rules(monkeypatch):
+    """Deletion, round-half-even averaging and last-write-wins vs the reference's outputs;
+    the device search is replaced by a brute-force matcher (the search itself is GPU-tested)."""
+    monkeypatch.setattr(detector, "find_close_pairs", _brute_close)
+    g = load_golden("prune.npz")
+    for k in range(int(g["n_rc"])):
+        detector.Blobs(np.ones((1, 4))).format_blobs()
+        pruned, master = detector.remove_close_blobs(
+            g["rc%d_check" % k].copy(), g["rc%d_master" % k].copy(), g["rc%d_tol" % k])
+        np.testing.assert_array_equal(pruned, g["rc%d_pruned" % k])
+        np.testing.assert_array_equal(master, g["rc%d_master_out" % k])
+    # explicit half-even case: (3 + 4) / 2 = 3.5 -> 4, (4 + 5) / 2 = 4.5 -> 4
+    m = -np.ones((1, 11)); m[0, :3] = (3, 4, 7); m[0, 7:10] = (3, 4, 7)
+    c = -np.ones((1, 11)); c[0, :3] = (4, 5, 7); c[0, 7:10] = (4, 5, 7)
+    _, m2 = detector.remove_close_blobs(c, m, (1, 1, 1))
+    np.testing.assert_array_equal(m2[0, 7:10], (4, 4, 7))
+
+
+def test_prune_blobs_mp_matches_reference(monkeypatch):
+    monkeypatch.setattr(detector, "find_close_pairs", _brute_close)
+    g = load_golden("prune.npz")
+    config.resolutions = [[1., 1., 1.]]
+    shape = tuple(g["sp_shape"])
+    bl = stack_detect.setup_blocks(roi_prof.ROIProfile(segment_size=20, denoise_size=None), shape)
+    grid = tuple(g["sp_grid"])
+    seg = np.zeros(grid, dtype=object)
+    for c in np.ndindex(*grid):
+        t = g["sp_block_%d_%d_%d" % c]
+        seg[c] = None if t.shape[0] == 0 else t.copy()
+    pruned, df = stack_detect.StackPruner.prune_blobs_mp(
+        np.zeros(shape, np.uint8), seg, bl.overlap, bl.tol, bl.sub_roi_slices, bl.sub_rois_offsets,
+        [0, 1], bl.overlap_padding)
+    np.testing.assert_array_equal(pruned, g["sp_pruned"])
+    np.testing.assert_allclose(df.to_numpy(), g["sp_ratios"])
+    assert list(df.columns) == list(g["sp_ratio_cols"])
+    empty = np.zeros(grid, dtype=object)
+    empty[:] = None
+    assert stack_detect.StackPruner.prune_blobs_mp(
+        np.zeros(shape, np.uint8), empty, bl.overlap, bl.tol, bl.sub_roi_slices,
+        bl.sub_rois_offsets, [0]) == (None, None)
+
+
+def test_stack_level_prune_from_golden_block_tables(monkeypatch):
+    """Feed the real reference's per-block tables through our pruner + epilogue."""
+    monkeypatch.setattr(detector, "find_close_pairs", _brute_close)
+    import ast
+    for case in ("u16_2x3x3", "u16_border", "2ch"):
+        g = load_golden("stack_%s.npz" % case)
+        over = ast.literal_eval(str(g["overrides"]))
+        config.resolutions = g["resolutions"]
+        prof = roi_prof.ROIProfile(denoise_size=None)
+        prof.update(over)
+        roi = g["roi"]
+        bl = stack_detect.setup_blocks(prof, roi.shape)
+        grid = tuple(g["grid"])
+        seg = np.zeros(grid, dtype=object)
+        for c in np.ndindex(*grid):
+            t = g["block_%d_%d_%d" % c]
+            seg[c] = None if t.shape[0] == 0 else t.copy()
+        chls = list(range(roi.shape[3])) if roi.ndim > 3 else [0]
+        pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
+            roi, seg, bl.overlap, bl.tol, bl.sub_roi_slices, bl.sub_rois_offsets, chls,
+            bl.overlap_padding)
+        np.testing.assert_array_equal(pruned[:, 3:], g["pruned11"][:, 3:])
+        b = detector.Blobs(pruned)
+        b.replace_rel_with_abs_blob_coords(pruned)
+        b.blobs = pruned
+        np.testing.assert_array_equal(b.remove_abs_blob_coords(True), g["final"])
+
+
+def test_unbuilt_rows_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        stack_detect.StackDetector.detect_blobs_sub_rois(
+            None, np.zeros((4, 4, 4), np.uint16), np.zeros((1, 1, 1), object), np.zeros((1, 1, 1, 3)),
+            np.array([5, 5, 5]), None, False, [0])
+    with pytest.raises(ValueError):
+        stack_detect.detect_blobs_blocks("x", stack_detect.Image5d(None))
+    with pytest.raises(IOError):
+        stack_detect.detect_blobs_stack("x", None)
