@@ -121,8 +121,8 @@ class DeviceVolume:
         else:
             code = _NP_TO_MMX[self.np_dtype]
         sz, sy, sx = self._strides(t)
-        ptr = t.data_ptr() + (channel if self.multichannel else 0) * t.element_size()
-        return nat.Volume(ptr, code, 0, sz, sy, sx)
+        ptr = int(t.data_ptr()) + (int(channel) if self.multichannel else 0) * t.element_size()
+        return nat.Volume(ptr, code, 0, int(sz), int(sy), int(sx))
 
 
 def _img_as_float_host(arr: np.ndarray) -> np.ndarray:
