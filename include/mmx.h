@@ -157,7 +157,16 @@ int mmx_overlap_pairs(const double* d_blobs, const int32_t* d_offsets, int n_blo
 int mmx_close_pairs(const int32_t* d_master, int n_master, const int32_t* d_check, int n_check,
                     const int32_t tol[3], int32_t* d_last, uint8_t* d_hit, void* stream);
 
-/* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream */
+/* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream.
+ * mmx_timing_enable(1) makes every kernel launch of this library record a HIP event
+ * before and after itself on its launch stream; mmx_timing_read() synchronises those
+ * events, returns summed milliseconds and launch counts per kernel family (index =
+ * MMX_K_*: 0 z pass, 1 y pass, 2 x pass, 3 generic passes, 4 peaks, 5 rescore,
+ * 6 overlap pairs, 7 close pairs) and starts a new window. */
+#define MMX_K_COUNT 8
+int mmx_timing_enable(int on);
+int mmx_timing_read(double* ms, int64_t* launches, int n);
+
 int mmx_event_create(void** ev);
 int mmx_event_destroy(void* ev);
 int mmx_event_record(void* ev, void* stream);

@@ -49,8 +49,10 @@ SYMBOLS = (
     "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
     "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
-    "mmx_event_record", "mmx_event_elapsed_ms",
+    "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
 )
+KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
+                "close_pairs")
 
 
 def lib() -> ctypes.CDLL:
@@ -84,10 +86,12 @@ def lib() -> ctypes.CDLL:
     L.mmx_event_destroy.argtypes = [vp]
     L.mmx_event_record.argtypes = [vp, vp]
     L.mmx_event_elapsed_ms.argtypes = [vp, vp, POINTER(c_float)]
+    L.mmx_timing_enable.argtypes = [c_int]
+    L.mmx_timing_read.argtypes = [POINTER(c_double), POINTER(c_int64), c_int]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is None or name.startswith(("mmx_log", "mmx_peaks", "mmx_rescore",
-                                                  "mmx_overlap", "mmx_close", "mmx_event")):
+                                                  "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing")):
             fn.restype = c_int
     if L.mmx_abi_version() != MMX_ABI_VERSION:
         raise MmxError("libmmx_hip.so ABI version mismatch")
@@ -111,3 +115,15 @@ def as_double_ptr(a: np.ndarray):
 def as_int32_ptr(a: np.ndarray):
     assert a.dtype == np.int32 and a.flags.c_contiguous
     return a.ctypes.data_as(POINTER(c_int32))
+
+
+def timing_enable(on: bool = True) -> None:
+    check(lib().mmx_timing_enable(1 if on else 0), "mmx_timing_enable")
+
+
+def timing_read() -> dict:
+    """``{kind: (milliseconds, launches)}`` since the last read (synchronises the events)."""
+    ms = (c_double * len(KERNEL_KINDS))()
+    n = (c_int64 * len(KERNEL_KINDS))()
+    check(lib().mmx_timing_read(ms, n, len(KERNEL_KINDS)), "mmx_timing_read")
+    return {k: (ms[i], n[i]) for i, k in enumerate(KERNEL_KINDS)}

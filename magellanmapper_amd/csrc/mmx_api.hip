@@ -13,8 +13,26 @@ int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, cons
                      int n_blocks, int max_vox, int64_t slot_elems, float thr, float eps,
                      mmx_cand* d_cands, uint32_t cap, uint32_t* d_count, hipStream_t stream);
 
+#include <mutex>
+#include <vector>
+
 namespace {
 thread_local char g_hip_err[256] = "";
+
+struct span { hipEvent_t a, b; int kind; };
+std::mutex g_tm;
+bool g_timing = false;
+std::vector<span> g_spans;          // recorded spans of the current window
+std::vector<hipEvent_t> g_pool;     // recycled events
+hipEvent_t g_open[MMX_K_COUNT];
+
+hipEvent_t take_event()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
 
 int hip_fail(hipError_t e, const char* what)
 {
@@ -26,7 +44,55 @@ int hip_fail(hipError_t e, const char* what)
 constexpr int kColPrefetch = 4;
 }  // namespace
 
+void mmx_time_begin(int kind, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_tm);
+    if (!g_timing) return;
+    g_open[kind] = take_event();
+    hipEventRecord(g_open[kind], s);
+}
+
+void mmx_time_end(int kind, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_tm);
+    if (!g_timing || !g_open[kind]) return;
+    hipEvent_t b = take_event();
+    hipEventRecord(b, s);
+    g_spans.push_back({g_open[kind], b, kind});
+    g_open[kind] = nullptr;
+}
+
 extern "C" {
+
+int mmx_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_tm);
+    for (auto& sp : g_spans) { g_pool.push_back(sp.a); g_pool.push_back(sp.b); }
+    g_spans.clear();
+    for (int k = 0; k < MMX_K_COUNT; ++k) g_open[k] = nullptr;
+    g_timing = on != 0;
+    return MMX_OK;
+}
+
+int mmx_timing_read(double* ms, int64_t* launches, int n)
+{
+    if (!ms || !launches || n < MMX_K_COUNT) return MMX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_tm);
+    for (int k = 0; k < n; ++k) { ms[k] = 0.0; launches[k] = 0; }
+    for (auto& sp : g_spans) {
+        hipError_t r = hipEventSynchronize(sp.b);
+        if (r != hipSuccess) return hip_fail(r, "hipEventSynchronize");
+        float t = 0.f;
+        r = hipEventElapsedTime(&t, sp.a, sp.b);
+        if (r != hipSuccess) return hip_fail(r, "hipEventElapsedTime");
+        ms[sp.kind] += t;
+        launches[sp.kind] += 1;
+        g_pool.push_back(sp.a);
+        g_pool.push_back(sp.b);
+    }
+    g_spans.clear();
+    return MMX_OK;
+}
 
 int mmx_abi_version(void) { return MMX_ABI_VERSION; }
 
@@ -124,14 +190,17 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         return t;
     };
     int rc;
+    { mmx_timed_scope ts(fast_z ? MMX_K_ZPASS : MMX_K_GENERIC, s);
     if (fast_z) rc = mmx_launch_zpass(vol, d_blocks, n_blocks, max_zcols, slot_elems, taps(wz0, wz2), radius, t0, t1, s);
-    else rc = mmx_launch_generic_pass(0, vol, d_blocks, n_blocks, max_vox, slot_elems, wz0, wz2, radius, nullptr, nullptr, t0, t1, s);
+    else rc = mmx_launch_generic_pass(0, vol, d_blocks, n_blocks, max_vox, slot_elems, wz0, wz2, radius, nullptr, nullptr, t0, t1, s); }
     if (rc != MMX_OK) return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "z pass") : rc;
+    { mmx_timed_scope ts(fast_y ? MMX_K_YPASS : MMX_K_GENERIC, s);
     if (fast_y) rc = mmx_launch_ypass(d_blocks, n_blocks, max_ycols, slot_elems, taps(wy0, wy2), radius, t0, t1, t2, t3, s);
-    else rc = mmx_launch_generic_pass(1, vol, d_blocks, n_blocks, max_vox, slot_elems, wy0, wy2, radius, t0, t1, t2, t3, s);
+    else rc = mmx_launch_generic_pass(1, vol, d_blocks, n_blocks, max_vox, slot_elems, wy0, wy2, radius, t0, t1, t2, t3, s); }
     if (rc != MMX_OK) return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "y pass") : rc;
+    { mmx_timed_scope ts(fast_x ? MMX_K_XPASS : MMX_K_GENERIC, s);
     if (fast_x) rc = mmx_launch_xpass(d_blocks, n_blocks, max_rows, max_nx, slot_elems, taps(wx0, wx2), radius, t2, t3, d_log, s);
-    else rc = mmx_launch_generic_pass(2, vol, d_blocks, n_blocks, max_vox, slot_elems, wx0, wx2, radius, t2, t3, d_log, nullptr, s);
+    else rc = mmx_launch_generic_pass(2, vol, d_blocks, n_blocks, max_vox, slot_elems, wx0, wx2, radius, t2, t3, d_log, nullptr, s); }
     if (rc != MMX_OK) return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "x pass") : rc;
     return MMX_OK;
 }
@@ -188,6 +257,7 @@ int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
         if ((int64_t)b.nz * b.ny * b.nx > slot_elems) return MMX_ERR_WORKSPACE;
         if (b.nz * b.ny * b.nx > max_vox) max_vox = b.nz * b.ny * b.nx;
     }
+    mmx_timed_scope ts(MMX_K_PEAKS, (hipStream_t)stream);
     int rc = mmx_launch_peaks(d_log, n_sigma, (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox,
                               slot_elems, thr, eps, d_cands, cap, d_count, (hipStream_t)stream);
     return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "peaks") : rc;

@@ -37,3 +37,17 @@ int mmx_launch_ypass(const mmx_block* d_blocks, int n_blocks, int max_cols, int6
 int mmx_launch_xpass(const mmx_block* d_blocks, int n_blocks, int max_rows, int max_nx,
                      int64_t slot_elems, const mmx_taps_f32& taps, int radius,
                      const float* d_a, const float* d_bc, float* d_log, hipStream_t stream);
+
+// ---- optional per-kernel-family timing with HIP events on the launch stream (bench.py) ----
+enum mmx_kernel_kind {
+    MMX_K_ZPASS = 0, MMX_K_YPASS, MMX_K_XPASS, MMX_K_GENERIC, MMX_K_PEAKS, MMX_K_RESCORE,
+    MMX_K_PAIRS, MMX_K_CLOSE, MMX_K_END
+};
+void mmx_time_begin(int kind, hipStream_t s);
+void mmx_time_end(int kind, hipStream_t s);
+static_assert(MMX_K_END == MMX_K_COUNT, "kernel kinds out of sync with mmx.h");
+struct mmx_timed_scope {
+    int kind; hipStream_t s;
+    mmx_timed_scope(int k, hipStream_t st) : kind(k), s(st) { mmx_time_begin(k, st); }
+    ~mmx_timed_scope() { mmx_time_end(kind, s); }
+};

@@ -163,6 +163,7 @@ extern "C" int mmx_rescore_f64(const mmx_volume* vol, const mmx_block* d_blocks,
     const size_t lds = (size_t)2 * N * strip * sizeof(double) + fixed;
     hipStream_t s = (hipStream_t)stream;
     const bool f32s = store_f32 != 0;
+    mmx_timed_scope ts(MMX_K_RESCORE, s);
     switch (vol->dtype) {
         case MMX_U8:  return launch<uint8_t, double>(vol, d_blocks, d_pts, cap, d_count, d_w0, d_w2, prm, lds, s);
         case MMX_U16: return launch<uint16_t, double>(vol, d_blocks, d_pts, cap, d_count, d_w0, d_w2, prm, lds, s);

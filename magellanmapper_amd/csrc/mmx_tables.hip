@@ -103,6 +103,7 @@ extern "C" int mmx_overlap_pairs(const double* d_blobs, const int32_t* d_offsets
 {
     if (!d_blobs || !d_offsets || !d_pairs || !d_frac || !d_count || n_blocks < 1) return MMX_ERR_ARG;
     dim3 grid(8, n_blocks);
+    mmx_timed_scope ts(MMX_K_PAIRS, (hipStream_t)stream);
     hipLaunchKernelGGL(overlap_pairs_kernel, grid, dim3(MMX_WG), 0, (hipStream_t)stream, d_blobs, d_offsets,
                        overlap, band, d_pairs, d_frac, cap, d_count);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
@@ -119,6 +120,7 @@ extern "C" int mmx_close_pairs(const int32_t* d_master, int n_master, const int3
         if (e != hipSuccess) return MMX_ERR_HIP;
     }
     dim3 grid((n_master + MMX_WG - 1) / MMX_WG);
+    mmx_timed_scope ts(MMX_K_CLOSE, s);
     hipLaunchKernelGGL(close_pairs_kernel, grid, dim3(MMX_WG), 0, s, d_master, n_master, d_check, n_check,
                        tol[0], tol[1], tol[2], d_last, d_hit);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
