@@ -21,7 +21,7 @@
  *     own extent with SciPy "reflect" boundaries -- exactly what each reference
  *     worker sees (magmap/cv/stack_detect.py:79, 242).  A *batch* is a set of
  *     blocks processed by one launch sequence; block i of a batch owns slot i of
- *     every workspace array (`slot_elems` floats, dense [nz][ny][nx]).
+ *     every workspace array (`slot_elems` floats, [nz][ny][px], px = row pitch).
  */
 #ifndef MMX_H
 #define MMX_H
@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 1
+#define MMX_ABI_VERSION 2
 
 typedef enum {
     MMX_OK = 0,
@@ -59,7 +59,12 @@ typedef struct {
     int64_t src_off;   /* element offset of the block origin inside the source volume */
     int32_t nz, ny, nx;/* block extent in voxels                                       */
     int32_t slot;      /* workspace slot (0 .. n_blocks-1)                             */
+    int32_t px;        /* row pitch of the block's workspace arrays, in floats:
+                          a multiple of MMX_ROW_ALIGN >= nx (128-byte aligned rows and
+                          planes: every wave-level store is whole cache lines)         */
+    int32_t _pad;
 } mmx_block;
+#define MMX_ROW_ALIGN 32
 
 /* Source volume view (one channel): element strides, x stride must be 1 for
  * integer inputs laid out (z,y,x); a (z,y,x,c) image passes stride_x = n_channels. */

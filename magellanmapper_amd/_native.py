@@ -14,22 +14,24 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmx_hip.so")
+#: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
+LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 1
+MMX_ABI_VERSION = 2
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
 MMX_CAND_CONTESTED = 1
 
-#: NumPy mirror of ``mmx_block`` (24 bytes).
+#: NumPy mirror of ``mmx_block`` (32 bytes).
 BLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("nz", "<i4"), ("ny", "<i4"), ("nx", "<i4"),
-                        ("slot", "<i4")], align=True)
+                        ("slot", "<i4"), ("px", "<i4"), ("_pad", "<i4")], align=True)
+MMX_ROW_ALIGN = 32
 #: NumPy mirror of ``mmx_cand`` (48 bytes).
 CAND_DTYPE = np.dtype([("slot", "<i4"), ("s", "<i4"), ("z", "<i4"), ("y", "<i4"), ("x", "<i4"),
                        ("flags", "<u4"), ("v", "<f4"), ("nbr_max", "<f4"), ("v64", "<f8"),
                        ("_reserved", "<f8")], align=True)
-assert BLOCK_DTYPE.itemsize == 24 and CAND_DTYPE.itemsize == 48
+assert BLOCK_DTYPE.itemsize == 32 and CAND_DTYPE.itemsize == 48
 
 
 class Volume(Structure):

@@ -206,7 +206,7 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     cur: List[int] = []
     cur_slot = 0
     for i, shp in enumerate(shapes):
-        vox = int(shp[0]) * int(shp[1]) * int(shp[2])
+        vox = int(shp[0]) * int(shp[1]) * (-(-int(shp[2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
         slot = max(cur_slot, vox)
         if cur and (len(cur) + 1) * slot * per_vox > budget_bytes:
             batches.append(cur)
@@ -266,8 +266,10 @@ def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: Sc
     logs = ws[4 * nb * slot:].view(ns, nb, slot).cpu().numpy()
     out = []
     for i, shp in enumerate(shapes):
-        n = int(np.prod(shp))
-        out.append(np.moveaxis(logs[:, i, :n].reshape((ns,) + tuple(shp)), 0, -1).copy())
+        px = int(blocks["px"][i])
+        n = int(shp[0]) * int(shp[1]) * px
+        cube = logs[:, i, :n].reshape((ns, shp[0], shp[1], px))[..., :shp[2]]
+        out.append(np.moveaxis(cube, 0, -1).copy())
     return out
 
 
@@ -280,8 +282,9 @@ def _make_blocks(dvol: DeviceVolume, channel: int, origins, shapes):
         for ax in range(3):
             if o[ax] < 0 or shp[ax] < 1 or o[ax] + shp[ax] > dvol.shape[ax]:
                 raise ValueError("block outside the volume")
-        blocks[i] = (int(o[0]) * sz + int(o[1]) * sy + int(o[2]) * sx, shp[0], shp[1], shp[2], i)
-        slot = max(slot, int(shp[0]) * int(shp[1]) * int(shp[2]))
+        px = -(-int(shp[2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN   # 128-B aligned rows
+        blocks[i] = (int(o[0]) * sz + int(o[1]) * sy + int(o[2]) * sx, shp[0], shp[1], shp[2], i, px, 0)
+        slot = max(slot, int(shp[0]) * int(shp[1]) * px)
     return blocks, slot
 
 

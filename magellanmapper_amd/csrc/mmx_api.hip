@@ -134,6 +134,7 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
     if (radius > MMX_MAX_RADIUS_GENERIC) return MMX_ERR_UNSUPPORTED;
     if (slot_elems >= (int64_t(1) << 29)) return MMX_ERR_UNSUPPORTED;  // 32-bit byte offsets in a slot
+    if (slot_elems % MMX_ROW_ALIGN) return MMX_ERR_ARG;
     double in_scale = 1.0;
     if (vol->dtype == MMX_U8) in_scale = 1.0 / 255.0;        // skimage img_as_float: x * (1/imax)
     else if (vol->dtype == MMX_U16) in_scale = 1.0 / 65535.0;
@@ -145,15 +146,16 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
         if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
-        if ((int64_t)b.nz * b.ny * b.nx > slot_elems) return MMX_ERR_WORKSPACE;
+        if (b.px < b.nx || b.px % MMX_ROW_ALIGN) return MMX_ERR_ARG;
+        if ((int64_t)b.nz * b.ny * b.px > slot_elems) return MMX_ERR_WORKSPACE;
         if (b.nz < min_nz) min_nz = b.nz;
         if (b.ny < min_ny) min_ny = b.ny;
         if (b.nx < min_nx) min_nx = b.nx;
-        if (b.ny * b.nx > max_zcols) max_zcols = b.ny * b.nx;
-        if (b.nz * b.nx > max_ycols) max_ycols = b.nz * b.nx;
+        if (b.ny * b.px > max_zcols) max_zcols = b.ny * b.px;
+        if (b.nz * b.px > max_ycols) max_ycols = b.nz * b.px;
         if (b.nz * b.ny > max_rows) max_rows = b.nz * b.ny;
         if (b.nx > max_nx) max_nx = b.nx;
-        if (b.nz * b.ny * b.nx > max_vox) max_vox = b.nz * b.ny * b.nx;
+        if (b.nz * b.ny * b.px > max_vox) max_vox = b.nz * b.ny * b.px;
         const int64_t lane = (int64_t)(b.ny - 1) * vol->stride_y + (int64_t)(b.nx - 1) * vol->stride_x;
         if (lane > max_lane_in) max_lane_in = lane;
     }
@@ -222,8 +224,9 @@ int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks, 
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
         if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
-        if ((int64_t)b.nz * b.ny * b.nx > slot_elems) return MMX_ERR_WORKSPACE;
-        if (b.nz * b.ny * b.nx > max_vox) max_vox = b.nz * b.ny * b.nx;
+        if (b.px < b.nx || b.px % MMX_ROW_ALIGN) return MMX_ERR_ARG;
+        if ((int64_t)b.nz * b.ny * b.px > slot_elems) return MMX_ERR_WORKSPACE;
+        if (b.nz * b.ny * b.px > max_vox) max_vox = b.nz * b.ny * b.px;
     }
     const int64_t n_slots = n_blocks;
     float* t0 = d_work;
@@ -254,8 +257,9 @@ int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
         if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
-        if ((int64_t)b.nz * b.ny * b.nx > slot_elems) return MMX_ERR_WORKSPACE;
-        if (b.nz * b.ny * b.nx > max_vox) max_vox = b.nz * b.ny * b.nx;
+        if (b.px < b.nx || b.px % MMX_ROW_ALIGN) return MMX_ERR_ARG;
+        if ((int64_t)b.nz * b.ny * b.px > slot_elems) return MMX_ERR_WORKSPACE;
+        if (b.nz * b.ny * b.px > max_vox) max_vox = b.nz * b.ny * b.px;
     }
     mmx_timed_scope ts(MMX_K_PEAKS, (hipStream_t)stream);
     int rc = mmx_launch_peaks(d_log, n_sigma, (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox,

@@ -25,15 +25,17 @@ __device__ __forceinline__ float load_any(const void* base, int dtype, int64_t i
     }
 }
 
-__device__ __forceinline__ bool locate(const mmx_block& bd, int idx, int& z, int& y, int& x)
+// idx runs over the pitched block [nz][ny][px]; returns 0 past the end, 1 for a voxel, 2 for a
+// pitch column (skipped)
+__device__ __forceinline__ int locate(const mmx_block& bd, int idx, int& z, int& y, int& x)
 {
-    const int plane = bd.ny * bd.nx;
-    if (idx >= bd.nz * plane) return false;
+    const int plane = bd.ny * bd.px;
+    if (idx >= bd.nz * plane) return 0;
     z = idx / plane;
     const int rem = idx - z * plane;
-    y = rem / bd.nx;
-    x = rem - y * bd.nx;
-    return true;
+    y = rem / bd.px;
+    x = rem - y * bd.px;
+    return x < bd.nx ? 1 : 2;
 }
 
 __global__ void __launch_bounds__(MMX_WG)
@@ -43,7 +45,9 @@ gen_z(mmx_volume vol, const mmx_block* __restrict__ blocks, int64_t slot_elems, 
     const mmx_block bd = blocks[blockIdx.y];
     for (int idx = blockIdx.x * MMX_WG + threadIdx.x;; idx += gridDim.x * MMX_WG) {
         int z, y, x;
-        if (!locate(bd, idx, z, y, x)) return;
+        const int where = locate(bd, idx, z, y, x);
+        if (where == 0) return;
+        if (where == 2) continue;
         const int64_t col = bd.src_off + (int64_t)y * vol.stride_y + (int64_t)x * vol.stride_x;
         const float c = load_any(vol.d_data, vol.dtype, col + (int64_t)z * vol.stride_z);
         float a0 = c * t.w0[0], a2 = c * t.w2[0];
@@ -67,14 +71,16 @@ gen_y(const mmx_block* __restrict__ blocks, int64_t slot_elems, int R,
     const mmx_block bd = blocks[blockIdx.y];
     for (int idx = blockIdx.x * MMX_WG + threadIdx.x;; idx += gridDim.x * MMX_WG) {
         int z, y, x;
-        if (!locate(bd, idx, z, y, x)) return;
-        const int64_t col = (int64_t)bd.slot * slot_elems + (int64_t)z * bd.ny * bd.nx + x;
-        const float c1 = gz[col + (int64_t)y * bd.nx], c2 = gzz[col + (int64_t)y * bd.nx];
+        const int where = locate(bd, idx, z, y, x);
+        if (where == 0) return;
+        if (where == 2) continue;
+        const int64_t col = (int64_t)bd.slot * slot_elems + (int64_t)z * bd.ny * bd.px + x;
+        const float c1 = gz[col + (int64_t)y * bd.px], c2 = gzz[col + (int64_t)y * bd.px];
         float a = c1 * t.w0[0];
         float bc = fmaf(c2, t.w0[0], c1 * t.w2[0]);
         for (int k = 1; k <= R; ++k) {
-            const int64_t lo = col + (int64_t)mmx_reflect(y - k, bd.ny) * bd.nx;
-            const int64_t hi = col + (int64_t)mmx_reflect(y + k, bd.ny) * bd.nx;
+            const int64_t lo = col + (int64_t)mmx_reflect(y - k, bd.ny) * bd.px;
+            const int64_t hi = col + (int64_t)mmx_reflect(y + k, bd.ny) * bd.px;
             const float p1 = gz[lo] + gz[hi];
             const float p2 = gzz[lo] + gzz[hi];
             a = fmaf(p1, t.w0[k], a);
@@ -95,8 +101,10 @@ gen_x(const mmx_block* __restrict__ blocks, int64_t slot_elems, int R,
     const mmx_block bd = blocks[blockIdx.y];
     for (int idx = blockIdx.x * MMX_WG + threadIdx.x;; idx += gridDim.x * MMX_WG) {
         int z, y, x;
-        if (!locate(bd, idx, z, y, x)) return;
-        const int64_t row = (int64_t)bd.slot * slot_elems + ((int64_t)z * bd.ny + y) * bd.nx;
+        const int where = locate(bd, idx, z, y, x);
+        if (where == 0) return;
+        if (where == 2) continue;
+        const int64_t row = (int64_t)bd.slot * slot_elems + ((int64_t)z * bd.ny + y) * bd.px;
         float acc = ga[row + x] * t.w2[0];
         for (int k = 1; k <= R; ++k)
             acc = fmaf(ga[row + mmx_reflect(x - k, bd.nx)] + ga[row + mmx_reflect(x + k, bd.nx)], t.w2[k], acc);

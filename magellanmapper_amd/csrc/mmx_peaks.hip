@@ -26,23 +26,24 @@ peaks_kernel(const float* __restrict__ log, int ns, int64_t sigma_stride,
              mmx_cand* __restrict__ out, uint32_t cap, uint32_t* __restrict__ count)
 {
     const mmx_block bd = blocks[blockIdx.y];
-    const int nz = bd.nz, ny = bd.ny, nx = bd.nx;
-    const int plane = ny * nx;
-    const int nvox = nz * plane;
+    const int nz = bd.nz, ny = bd.ny, nx = bd.nx, px = bd.px;
+    const int plane = ny * px;
+    const int nvox = nz * plane;          // pitch columns are skipped below
     const float* base = log + (int64_t)bd.slot * slot_elems;
     const float lo = thr - eps;
 
     for (int idx = blockIdx.x * MMX_WG + threadIdx.x; idx < nvox; idx += gridDim.x * MMX_WG) {
         bool located = false;
         int z = 0, y = 0, x = 0;
+        if (px != nx && (idx % px) >= nx) continue;
         for (int s = 0; s < ns; ++s) {
             const float v = base[(int64_t)s * sigma_stride + idx];
             if (!(v > lo)) continue;
             if (!located) {
                 z = idx / plane;
                 const int rem = idx - z * plane;
-                y = rem / nx;
-                x = rem - y * nx;
+                y = rem / px;
+                x = rem - y * px;
                 located = true;
             }
             const float reject = v + eps;  // a neighbour above this rules the voxel out
@@ -52,8 +53,8 @@ peaks_kernel(const float* __restrict__ log, int ns, int64_t sigma_stride,
             const float* ps = base + (int64_t)s * sigma_stride;
             if (x > 0) m = fmaxf(m, ps[idx - 1]); else border = true;
             if (x + 1 < nx) m = fmaxf(m, ps[idx + 1]); else border = true;
-            if (y > 0) m = fmaxf(m, ps[idx - nx]); else border = true;
-            if (y + 1 < ny) m = fmaxf(m, ps[idx + nx]); else border = true;
+            if (y > 0) m = fmaxf(m, ps[idx - px]); else border = true;
+            if (y + 1 < ny) m = fmaxf(m, ps[idx + px]); else border = true;
             if (z > 0) m = fmaxf(m, ps[idx - plane]); else border = true;
             if (z + 1 < nz) m = fmaxf(m, ps[idx + plane]); else border = true;
             if (m > reject) continue;
@@ -67,7 +68,7 @@ peaks_kernel(const float* __restrict__ log, int ns, int64_t sigma_stride,
                     for (int dy = -1; dy <= 1; ++dy) {
                         const int yy = y + dy;
                         if (yy < 0 || yy >= ny) continue;
-                        const int row = zz * plane + yy * nx;
+                        const int row = zz * plane + yy * px;
 #pragma unroll
                         for (int dx = -1; dx <= 1; ++dx) {
                             const int xx = x + dx;

@@ -50,7 +50,7 @@ xpass_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int rg_ma
         const int nr = min(RG, rows - row0);
         // ---- stage A and BC rows with the reflect halo
         for (int r = wave; r < nr; r += MMX_WG / 64) {
-            const int64_t gro = sbase + (int64_t)(row0 + r) * W;
+            const int64_t gro = sbase + (int64_t)(row0 + r) * bd.px;
             for (int xx = lane; xx < HW; xx += 64) {
                 int x = xx - R;
                 x = x < 0 ? -1 - x : x;
@@ -93,7 +93,7 @@ xpass_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int rg_ma
             }
             if (nr * CH > MMX_WG) {
                 // more work items than threads (very wide rows): store this item's outputs directly
-                const int64_t gro = sbase + (int64_t)(row0 + r) * W + c * kT;
+                const int64_t gro = sbase + (int64_t)(row0 + r) * bd.px + c * kT;
 #pragma unroll
                 for (int o = 0; o < kT; ++o)
                     if (c * kT + o < W) out[gro + o] = res[o];
@@ -108,8 +108,8 @@ xpass_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int rg_ma
             }
             __syncthreads();
             for (int r = wave; r < nr; r += MMX_WG / 64) {
-                const int64_t gro = sbase + (int64_t)(row0 + r) * W;
-                for (int x = lane; x < W; x += 64) out[gro + x] = la[r * PW + pad8(x)];
+                const int64_t gro = sbase + (int64_t)(row0 + r) * bd.px;
+                for (int x = lane; x < bd.px; x += 64) out[gro + x] = x < W ? la[r * PW + pad8(x)] : 0.f;
             }
         }
         __syncthreads();

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert _native.BLOCK_DTYPE.itemsize == 24
+    assert _native.BLOCK_DTYPE.itemsize == 32
     assert _native.CAND_DTYPE.itemsize == 48
     assert _native.CAND_DTYPE.fields["v64"][1] == 32
     assert ctypes.sizeof(_native.Volume) == 40
@@ -83,11 +83,11 @@ def test_sigma_ladder_equals_oracle():
 def test_plan_batches():
     from magellanmapper_amd.blob_log import plan_batches
     shapes = [(10, 10, 10)] * 5 + [(20, 10, 10)] + [(10, 10, 10)] * 3
-    b = plan_batches(shapes, 5, budget_bytes=4 * 1000 * 36)
+    b = plan_batches(shapes, 5, budget_bytes=4 * 3200 * 36)
     assert sum(b, []) == list(range(9))
     for batch in b:
-        slot = max(int(np.prod(shapes[i])) for i in batch)
-        assert len(batch) == 1 or len(batch) * slot * 36 <= 4 * 1000 * 36
+        slot = max(shapes[i][0] * shapes[i][1] * 32 for i in batch)     # rows are pitched to 32 floats
+        assert len(batch) == 1 or len(batch) * slot * 36 <= 4 * 3200 * 36
     assert plan_batches(shapes, 5, 1 << 40) == [list(range(9))]
 
 

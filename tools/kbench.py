@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark: HIP-event time of each kernel family on a batch of blocks.
+
+    python tools/kbench.py [--blocks 32] [--edge 261] [--sigmas 3 4 5] [--reps 3]
+"""
+import argparse, ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from magellanmapper_amd import _native as nat, blob_log as bl, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--blocks", type=int, default=32)
+ap.add_argument("--edge", type=int, default=261)
+ap.add_argument("--sigmas", type=float, nargs="+", default=[3.0, 4.0, 5.0])
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--generic", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+e = a.edge
+# a volume holding `blocks` blocks of edge e, overlapping by 5 like the real grid
+g = int(np.ceil(a.blocks ** (1 / 3)))
+step = e - 5
+shape = (step * g + 5,) * 3
+vol = synth.make_volume_device(shape, 3, dev)
+dvol = bl.DeviceVolume(vol)
+origins = [(z * step, y * step, x * step) for z in range(g) for y in range(g) for x in range(g)][:a.blocks]
+shapes = [(e, e, e)] * len(origins)
+L = nat.lib()
+blocks, slot = bl._make_blocks(dvol, 0, origins, shapes)
+nb = len(blocks)
+ns = len(a.sigmas)
+ws = torch.empty((4 + ns) * nb * slot, dtype=torch.float32, device=dev)
+d_blocks = bl._to_device_bytes(blocks, dev)
+v32 = dvol.view(0, True)
+stream = torch.cuda.current_stream().cuda_stream
+from magellanmapper_amd import kernels1d as k1
+nvox = nb * e ** 3   # algorithmic voxels (pitch columns not counted)
+res = {}
+fn = L.mmx_log_batch_f32_generic if a.generic else L.mmx_log_batch_f32
+log_base = ws.data_ptr() + 4 * nb * slot * 4
+for rep in range(a.reps + 1):
+    if rep == 1:
+        nat.timing_enable(True)
+    for i, s in enumerate(a.sigmas):
+        R = k1.kernel_radius(s)
+        w0 = k1.gaussian_half_kernel(s, 0, R); w2 = k1.gaussian_half_kernel(s, 2, R)
+        nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
+                     nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, s * s,
+                     log_base + i * nb * slot * 4, ws.data_ptr(), stream), "log")
+        if rep >= 1:
+            t = nat.timing_read()
+            for k, (ms, n) in t.items():
+                if n:
+                    res.setdefault((k, R), []).append(ms)
+    cap = 1 << 20
+    table = torch.empty(cap * 48, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    nat.check(L.mmx_peaks_batch(log_base, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, 0.1, 2e-5,
+                                table.data_ptr(), cap, count.data_ptr(), stream), "peaks")
+    if rep >= 1:
+        t = nat.timing_read()
+        res.setdefault(("peaks", ns), []).append(t["peaks"][0])
+torch.cuda.synchronize()
+alg = {"zpass": 10, "ypass": 16, "xpass": 12, "generic": 38 / 3}
+print(f"blocks {nb} x {e}^3 = {nvox/1e6:.0f} Mvox; candidates {int(count.item())}")
+for (k, R), v in sorted(res.items()):
+    ms = float(np.median(v))
+    if k == "peaks":
+        gbs = 4 * R * nvox / ms / 1e6
+    else:
+        gbs = alg.get(k, 0) * nvox / ms / 1e6
+    print(f"{k:8s} R={R:3d}  {ms:8.3f} ms  {gbs:8.1f} GB/s(alg)  {nvox/ms/1e6:7.2f} Gvox/s")
