@@ -253,6 +253,7 @@ int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
 {
     if (!d_log || !d_blocks || !h_blocks || !d_cands || !d_count) return MMX_ERR_ARG;
     if (n_sigma < 1 || n_blocks < 1 || slot_elems < 1 || !(eps >= 0.f)) return MMX_ERR_ARG;
+    if (slot_elems % MMX_ROW_ALIGN) return MMX_ERR_ARG;
     int max_vox = 0;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];

@@ -20,84 +20,149 @@
 
 namespace {
 
+constexpr int kSigmaChunk = 8;   // sigma planes whose loads are issued back to back
+
+struct peak_ctx {
+    const float* base;      // slot base of sigma 0
+    int64_t sigma_stride;
+    int ns, nz, ny, nx, px, plane, slot;
+    float thr, eps;
+    mmx_cand* out;
+    uint32_t cap;
+    uint32_t* count;
+};
+
+// Full 80-neighbour test of one voxel that passed `v > thr - eps` (rare: inside blobs only).
+__device__ __forceinline__ void check_voxel(const peak_ctx& c, int s, int idx, float v)
+{
+    const int z = idx / c.plane;
+    const int rem = idx - z * c.plane;
+    const int y = rem / c.px;
+    const int x = rem - y * c.px;
+    const int nz = c.nz, ny = c.ny, nx = c.nx, px = c.px, plane = c.plane;
+    const float reject = v + c.eps;  // a neighbour above this rules the voxel out
+    float m = -INFINITY;
+    bool border = false;
+    // same-sigma face neighbours first: they reject nearly every non-peak
+    const float* ps = c.base + (int64_t)s * c.sigma_stride;
+    if (x > 0) m = fmaxf(m, ps[idx - 1]); else border = true;
+    if (x + 1 < nx) m = fmaxf(m, ps[idx + 1]); else border = true;
+    if (y > 0) m = fmaxf(m, ps[idx - px]); else border = true;
+    if (y + 1 < ny) m = fmaxf(m, ps[idx + px]); else border = true;
+    if (z > 0) m = fmaxf(m, ps[idx - plane]); else border = true;
+    if (z + 1 < nz) m = fmaxf(m, ps[idx + plane]); else border = true;
+    if (m > reject) return;
+    for (int ds = -1; ds <= 1; ++ds) {
+        const int ss = s + ds;
+        if (ss < 0 || ss >= c.ns) { border = true; continue; }
+        const float* pss = c.base + (int64_t)ss * c.sigma_stride;
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int zz = z + dz;
+            if (zz < 0 || zz >= nz) continue;  // border already noted above
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= ny) continue;
+                const int row = zz * plane + yy * px;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= nx) continue;
+                    if ((ds | dz | dy | dx) == 0) continue;
+                    m = fmaxf(m, pss[row + xx]);
+                }
+            }
+            if (m > reject) return;
+        }
+    }
+    if (border) m = fmaxf(m, 0.0f);  // mode='constant', cval = 0
+    if (!(v >= m - c.eps)) return;
+    const bool contested = !(v > m + c.eps) || !(v > c.thr + c.eps);
+    const uint32_t pos = atomicAdd(c.count, 1u);
+    if (pos < c.cap) {
+        mmx_cand r;
+        r.slot = c.slot;
+        r.s = s;
+        r.z = z;
+        r.y = y;
+        r.x = x;
+        r.flags = contested ? MMX_CAND_CONTESTED : 0u;
+        r.v = v;
+        r.nbr_max = m;
+        r.v64 = __longlong_as_double(0x7ff8000000000000LL);
+        r._reserved = 0.0;
+        c.out[pos] = r;
+    }
+}
+
+// Thread = 4 consecutive x (one 16-byte load per sigma plane; rows are 128-B aligned), all
+// sigma loads of a chunk issued before any is tested.
 __global__ void __launch_bounds__(MMX_WG)
 peaks_kernel(const float* __restrict__ log, int ns, int64_t sigma_stride,
              const mmx_block* __restrict__ blocks, int64_t slot_elems, float thr, float eps,
              mmx_cand* __restrict__ out, uint32_t cap, uint32_t* __restrict__ count)
 {
     const mmx_block bd = blocks[blockIdx.y];
-    const int nz = bd.nz, ny = bd.ny, nx = bd.nx, px = bd.px;
-    const int plane = ny * px;
-    const int nvox = nz * plane;          // pitch columns are skipped below
-    const float* base = log + (int64_t)bd.slot * slot_elems;
+    peak_ctx c;
+    c.base = log + (int64_t)bd.slot * slot_elems;
+    c.sigma_stride = sigma_stride;
+    c.ns = ns; c.nz = bd.nz; c.ny = bd.ny; c.nx = bd.nx; c.px = bd.px;
+    c.plane = bd.ny * bd.px; c.slot = bd.slot;
+    c.thr = thr; c.eps = eps; c.out = out; c.cap = cap; c.count = count;
+    const int nquads = bd.nz * c.plane / 4;
     const float lo = thr - eps;
+    const int qrow = bd.px / 4;          // quads per row
 
-    for (int idx = blockIdx.x * MMX_WG + threadIdx.x; idx < nvox; idx += gridDim.x * MMX_WG) {
-        bool located = false;
-        int z = 0, y = 0, x = 0;
-        if (px != nx && (idx % px) >= nx) continue;
-        for (int s = 0; s < ns; ++s) {
-            const float v = base[(int64_t)s * sigma_stride + idx];
-            if (!(v > lo)) continue;
-            if (!located) {
-                z = idx / plane;
-                const int rem = idx - z * plane;
-                y = rem / px;
-                x = rem - y * px;
-                located = true;
-            }
-            const float reject = v + eps;  // a neighbour above this rules the voxel out
-            float m = -INFINITY;
-            bool border = false, dead = false;
-            // same-sigma face neighbours first: they reject nearly every non-peak
-            const float* ps = base + (int64_t)s * sigma_stride;
-            if (x > 0) m = fmaxf(m, ps[idx - 1]); else border = true;
-            if (x + 1 < nx) m = fmaxf(m, ps[idx + 1]); else border = true;
-            if (y > 0) m = fmaxf(m, ps[idx - px]); else border = true;
-            if (y + 1 < ny) m = fmaxf(m, ps[idx + px]); else border = true;
-            if (z > 0) m = fmaxf(m, ps[idx - plane]); else border = true;
-            if (z + 1 < nz) m = fmaxf(m, ps[idx + plane]); else border = true;
-            if (m > reject) continue;
-            for (int ds = -1; ds <= 1 && !dead; ++ds) {
-                const int ss = s + ds;
-                if (ss < 0 || ss >= ns) { border = true; continue; }
-                const float* pss = base + (int64_t)ss * sigma_stride;
-                for (int dz = -1; dz <= 1 && !dead; ++dz) {
-                    const int zz = z + dz;
-                    if (zz < 0 || zz >= nz) continue;  // border already noted above
-                    for (int dy = -1; dy <= 1; ++dy) {
-                        const int yy = y + dy;
-                        if (yy < 0 || yy >= ny) continue;
-                        const int row = zz * plane + yy * px;
+    for (int q = blockIdx.x * MMX_WG + threadIdx.x; q < nquads; q += gridDim.x * MMX_WG) {
+        const int x0 = (q % qrow) * 4;
+        if (x0 >= bd.nx) continue;       // pitch columns
+        const float4* p = reinterpret_cast<const float4*>(c.base) + q;
+        const int64_t sstride4 = sigma_stride / 4;
+        const int lane = threadIdx.x & 63;
+        const bool has_left = x0 > 0 && lane > 0;            // lane - 1 holds x0-4 .. x0-1 of this row
+        const bool has_right = x0 + 4 < bd.nx && lane < 63 && q + 1 < nquads;  // lane + 1: x0+4 .. x0+7
+        for (int s0 = 0; s0 < ns; s0 += kSigmaChunk) {
+            // v[k + 1] = sigma s0 + k; v[0] and v[kSigmaChunk + 1] are the neighbouring scales
+            float4 v[kSigmaChunk + 2];
+            const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int xx = x + dx;
-                            if (xx < 0 || xx >= nx) continue;
-                            if ((ds | dz | dy | dx) == 0) continue;
-                            m = fmaxf(m, pss[row + xx]);
-                        }
-                    }
-                    if (m > reject) dead = true;
+            for (int k = -1; k <= kSigmaChunk; ++k) {
+                const int s = s0 + k;
+                v[k + 1] = (s >= 0 && s < ns) ? p[(int64_t)s * sstride4] : ninf;
+                // pitch columns hold no data: they must never out-vote a real neighbour
+                if (x0 + 1 >= bd.nx) v[k + 1].y = -INFINITY;
+                if (x0 + 2 >= bd.nx) v[k + 1].z = -INFINITY;
+                if (x0 + 3 >= bd.nx) v[k + 1].w = -INFINITY;
+            }
+            // In-register pre-filter: a 4-D local maximum must beat its two x neighbours and the
+            // same voxel one scale up / down (all already in registers or one lane away).  Only
+            // survivors pay for the remaining 76 neighbour reads.
+            unsigned hits = 0;
+#pragma unroll
+            for (int k = 0; k < kSigmaChunk; ++k) {
+                if (s0 + k < ns) {
+                    const float4 a = v[k + 1], dn = v[k], up = v[k + 2];
+                    float lft = __shfl_up(a.w, 1);
+                    float rgt = __shfl_down(a.x, 1);
+                    lft = has_left ? lft : -INFINITY;
+                    rgt = has_right ? rgt : -INFINITY;
+                    const float n0 = fmaxf(fmaxf(lft, a.y), fmaxf(dn.x, up.x));
+                    const float n1 = fmaxf(fmaxf(a.x, a.z), fmaxf(dn.y, up.y));
+                    const float n2 = fmaxf(fmaxf(a.y, a.w), fmaxf(dn.z, up.z));
+                    const float n3 = fmaxf(fmaxf(a.z, rgt), fmaxf(dn.w, up.w));
+                    hits |= ((a.x > lo && !(n0 > a.x + eps)) ? 1u : 0u) << (4 * k);
+                    hits |= ((a.y > lo && !(n1 > a.y + eps)) ? 2u : 0u) << (4 * k);
+                    hits |= ((a.z > lo && !(n2 > a.z + eps)) ? 4u : 0u) << (4 * k);
+                    hits |= ((a.w > lo && !(n3 > a.w + eps)) ? 8u : 0u) << (4 * k);
                 }
             }
-            if (dead) continue;
-            if (border) m = fmaxf(m, 0.0f);  // mode='constant', cval = 0
-            if (!(v >= m - eps)) continue;
-            const bool contested = !(v > m + eps) || !(v > thr + eps);
-            const uint32_t pos = atomicAdd(count, 1u);
-            if (pos < cap) {
-                mmx_cand c;
-                c.slot = bd.slot;
-                c.s = s;
-                c.z = z;
-                c.y = y;
-                c.x = x;
-                c.flags = contested ? MMX_CAND_CONTESTED : 0u;
-                c.v = v;
-                c.nbr_max = m;
-                c.v64 = __longlong_as_double(0x7ff8000000000000LL);
-                c._reserved = 0.0;
-                out[pos] = c;
+            while (hits) {              // rare: only inside blobs
+                const int b = __ffs(hits) - 1;
+                hits &= hits - 1;
+                const int j = b & 3;
+                if (x0 + j >= bd.nx) continue;
+                const int s = s0 + (b >> 2);
+                const int idx = 4 * q + j;
+                check_voxel(c, s, idx, c.base[(int64_t)s * sigma_stride + idx]);
             }
         }
     }
@@ -109,8 +174,8 @@ int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, cons
                      int n_blocks, int max_vox, int64_t slot_elems, float thr, float eps,
                      mmx_cand* d_cands, uint32_t cap, uint32_t* d_count, hipStream_t stream)
 {
-    int gx = (max_vox + MMX_WG - 1) / MMX_WG;
-    if (gx > 4096) gx = 4096;
+    int gx = (max_vox / 4 + MMX_WG - 1) / MMX_WG;
+    if (gx > 8192) gx = 8192;
     if (gx < 1) gx = 1;
     dim3 grid(gx, n_blocks);
     hipLaunchKernelGGL(peaks_kernel, grid, dim3(MMX_WG), 0, stream, d_log, n_sigma, sigma_stride,

@@ -7,11 +7,13 @@
 //
 // Design (gfx950): along x the taps live in neighbouring lanes, so rows are staged in LDS.
 // A workgroup takes RG whole rows (block rows are at most a few hundred voxels, so the
-// scipy "reflect" halo is applied while staging and no inter-tile halo exists), each
-// thread then produces T = 8 consecutive outputs from a register window of T + 2R
-// staged values (fully unrolled, SGPR weights).  LDS rows are padded by one float every
-// eight so that lanes reading at a stride of eight floats hit distinct banks.  Results
-// go back through LDS so that global stores are whole coalesced row segments.
+// scipy "reflect" halo is applied while staging and no inter-tile halo exists).  Rows are
+// 128-byte aligned (pitch px), so a row group is one contiguous run read with 16-byte
+// loads; the NEXT group's loads are issued right after the barrier and stay in flight
+// while the current group is computed (software prefetch through registers).  Each thread
+// produces T = 8 consecutive outputs from a register window of T + 2R staged values (fully
+// unrolled, SGPR weights, ds_read_b64 on a 2-in-8 padded layout = conflict free).  Results
+// go back through LDS so that the global stores are whole aligned rows (16 B per lane).
 //
 // Algorithmic HBM bytes per voxel: read 8 (A, BC) + write 4.
 
@@ -19,9 +21,13 @@
 
 namespace {
 
-constexpr int kT = 8;  // outputs per thread
+constexpr int kT = 8;        // outputs per thread
+constexpr int kMaxQuads = 2; // 16-byte loads per thread, array and row group (host sizes RG to fit)
+constexpr int kMaxHalo = 2;  // halo loads per thread, array and row group
 
-__device__ __forceinline__ int pad8(int i) { return i + (i >> 3); }
+// LDS row layout: two pad floats after every eight, so that threads reading 8-float-strided
+// windows with ds_read_b64 hit 32 distinct bank pairs.
+__device__ __forceinline__ int pad2(int i) { return i + 2 * (i >> 3); }
 
 template <int R>
 __global__ void __launch_bounds__(MMX_WG)
@@ -29,90 +35,142 @@ xpass_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int rg_ma
              const float* __restrict__ ga, const float* __restrict__ gbc,
              float* __restrict__ out, mmx_taps_f32 taps)
 {
+    constexpr int LEAD = R & 1;                   // odd radius: window starts one float early (8-B aligned)
+    constexpr int S = (R + LEAD + 7) & ~7;        // staged position of x = 0
+    constexpr int WIN = kT + 2 * R + LEAD;        // floats read per thread and array (even)
     extern __shared__ float lds[];
     const mmx_block bd = blocks[blockIdx.y];
-    const int W = bd.nx;
+    const int W = bd.nx, px = bd.px;
     const int rows = bd.nz * bd.ny;
-    const int HW = W + 2 * R;          // staged row length (with halo)
-    const int PW = pad8(HW) + 1;       // padded LDS row pitch
-    const int CH = (W + kT - 1) / kT;  // chunks per row
-    int RG = MMX_WG / CH;              // rows per group
+    const int CH = (W + kT - 1) / kT;             // chunks per row
+    int RG = MMX_WG / CH;                         // rows per group
     if (RG < 1) RG = 1;
     if (RG > rg_max) RG = rg_max;
+    const int PW = (pad2(S + px + R + LEAD) + 3) & ~1;   // LDS row pitch (floats, even)
     float* la = lds;
-    float* lb = lds + RG * PW;
+    float* lb = la + rg_max * PW;
+    float* lc = lb + rg_max * PW;                 // results, plain [RG][px] (16-B aligned rows)
     const int64_t sbase = (int64_t)bd.slot * slot_elems;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_groups = (rows + RG - 1) / RG;
+    const int t = threadIdx.x;
 
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    float4 qa[kMaxQuads], qb[kMaxQuads];
+    float ha[kMaxHalo], hb[kMaxHalo];
+
+    auto prefetch = [&](int g) {
         const int row0 = g * RG;
         const int nr = min(RG, rows - row0);
-        // ---- stage A and BC rows with the reflect halo
-        for (int r = wave; r < nr; r += MMX_WG / 64) {
-            const int64_t gro = sbase + (int64_t)(row0 + r) * bd.px;
-            for (int xx = lane; xx < HW; xx += 64) {
-                int x = xx - R;
-                x = x < 0 ? -1 - x : x;
-                x = x >= W ? 2 * W - 1 - x : x;
-                x = min(max(x, 0), W - 1);  // rows thinner than R: routed to the generic path by the host
-                la[r * PW + pad8(xx)] = ga[gro + x];
-                lb[r * PW + pad8(xx)] = gbc[gro + x];
+        const float4* pa = reinterpret_cast<const float4*>(ga + sbase + (int64_t)row0 * px);
+        const float4* pb = reinterpret_cast<const float4*>(gbc + sbase + (int64_t)row0 * px);
+        const int nq = nr * (px / 4);
+#pragma unroll
+        for (int i = 0; i < kMaxQuads; ++i) {
+            const int f = t + i * MMX_WG;
+            if (f < nq) { qa[i] = pa[f]; qb[i] = pb[f]; }
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxHalo; ++i) {
+            const int h = t + i * MMX_WG;
+            if (h < nr * 2 * R) {
+                const int r = h / (2 * R), k = h - r * 2 * R;
+                const int x = k < R ? k : W - 1 - (k - R);             // scipy "reflect": x = -1-k -> k
+                ha[i] = ga[sbase + (int64_t)(row0 + r) * px + x];
+                hb[i] = gbc[sbase + (int64_t)(row0 + r) * px + x];
             }
         }
+    };
+    auto stage = [&](int g) {
+        const int row0 = g * RG;
+        const int nr = min(RG, rows - row0);
+        const int nq = nr * (px / 4);
+        const int qrow = px / 4;
+#pragma unroll
+        for (int i = 0; i < kMaxQuads; ++i) {
+            const int f = t + i * MMX_WG;
+            if (f < nq) {
+                const int r = f / qrow;
+                const int x = (f - r * qrow) * 4;
+                float* da = la + r * PW;
+                float* db = lb + r * PW;
+                const int p0 = S + x;            // multiple of 4: the quad stays inside one 8-group
+                const int q0 = pad2(p0);
+                // pitch columns (x >= W) are not staged: those positions belong to the halo
+                const float va[4] = {qa[i].x, qa[i].y, qa[i].z, qa[i].w};
+                const float vb[4] = {qb[i].x, qb[i].y, qb[i].z, qb[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x + j < W) { da[q0 + j] = va[j]; db[q0 + j] = vb[j]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxHalo; ++i) {
+            const int h = t + i * MMX_WG;
+            if (h < nr * 2 * R) {
+                const int r = h / (2 * R), k = h - r * 2 * R;
+                const int p = k < R ? S - 1 - k : S + W + (k - R);
+                la[r * PW + pad2(p)] = ha[i];
+                lb[r * PW + pad2(p)] = hb[i];
+            }
+        }
+    };
+
+    int g = blockIdx.x;
+    if (g < n_groups) prefetch(g);
+    for (; g < n_groups; g += gridDim.x) {
+        const int row0 = g * RG;
+        const int nr = min(RG, rows - row0);
+        stage(g);
         __syncthreads();
-        // ---- compute kT outputs per work item
-        float res[kT];
-        int my_r = -1, my_c = 0;
-        for (int item = threadIdx.x; item < nr * CH; item += MMX_WG) {
-            const int r = item / CH;
-            const int c = item - r * CH;
-            my_r = r;
-            my_c = c;
+        if (g + (int)gridDim.x < n_groups) prefetch(g + gridDim.x);   // in flight during the compute
+        const int r = t / CH;
+        const int c = t - r * CH;
+        if (r < nr) {
+            float res[kT];
+            float win[WIN];
+            const int base = S - R - LEAD + c * kT;                   // even
             const float* pa = la + r * PW;
+#pragma unroll
+            for (int i = 0; i < WIN; i += 2) {
+                const float2 v = *reinterpret_cast<const float2*>(pa + pad2(base + i));
+                win[i] = v.x;
+                win[i + 1] = v.y;
+            }
+#pragma unroll
+            for (int o = 0; o < kT; ++o) {
+                float acc = win[LEAD + o + R] * taps.w2[0];
+#pragma unroll
+                for (int k = 1; k <= R; ++k)
+                    acc = fmaf(win[LEAD + o + R - k] + win[LEAD + o + R + k], taps.w2[k], acc);
+                res[o] = acc;
+            }
             const float* pb = lb + r * PW;
-            float win[kT + 2 * R];
 #pragma unroll
-            for (int i = 0; i < kT + 2 * R; ++i) win[i] = pa[pad8(c * kT + i)];
+            for (int i = 0; i < WIN; i += 2) {
+                const float2 v = *reinterpret_cast<const float2*>(pb + pad2(base + i));
+                win[i] = v.x;
+                win[i + 1] = v.y;
+            }
 #pragma unroll
             for (int o = 0; o < kT; ++o) {
-                float acc = win[o + R] * taps.w2[0];
+                float acc = fmaf(win[LEAD + o + R], taps.w0[0], res[o]);
 #pragma unroll
-                for (int k = 1; k <= R; ++k) acc = fmaf(win[o + R - k] + win[o + R + k], taps.w2[k], acc);
+                for (int k = 1; k <= R; ++k)
+                    acc = fmaf(win[LEAD + o + R - k] + win[LEAD + o + R + k], taps.w0[k], acc);
                 res[o] = acc;
             }
-#pragma unroll
-            for (int i = 0; i < kT + 2 * R; ++i) win[i] = pb[pad8(c * kT + i)];
-#pragma unroll
-            for (int o = 0; o < kT; ++o) {
-                float acc = res[o];
-                acc = fmaf(win[o + R], taps.w0[0], acc);
-#pragma unroll
-                for (int k = 1; k <= R; ++k) acc = fmaf(win[o + R - k] + win[o + R + k], taps.w0[k], acc);
-                res[o] = acc;
-            }
-            if (nr * CH > MMX_WG) {
-                // more work items than threads (very wide rows): store this item's outputs directly
-                const int64_t gro = sbase + (int64_t)(row0 + r) * bd.px + c * kT;
-#pragma unroll
-                for (int o = 0; o < kT; ++o)
-                    if (c * kT + o < W) out[gro + o] = res[o];
-            }
-        }
-        if (nr * CH <= MMX_WG) {
-            // ---- results back through LDS (reusing the A tile) for coalesced row stores
-            __syncthreads();
-            if (my_r >= 0) {
-#pragma unroll
-                for (int o = 0; o < kT; ++o) la[my_r * PW + pad8(my_c * kT + o)] = res[o];
-            }
-            __syncthreads();
-            for (int r = wave; r < nr; r += MMX_WG / 64) {
-                const int64_t gro = sbase + (int64_t)(row0 + r) * bd.px;
-                for (int x = lane; x < bd.px; x += 64) out[gro + x] = x < W ? la[r * PW + pad8(x)] : 0.f;
-            }
+            float4* dst = reinterpret_cast<float4*>(lc + r * px + c * kT);
+            dst[0] = make_float4(res[0], res[1], res[2], res[3]);
+            dst[1] = make_float4(res[4], res[5], res[6], res[7]);
         }
         __syncthreads();
+        // whole, 128-byte aligned rows back to HBM (pitch columns get whatever the last chunk
+        // computed from the halo: never read as data)
+        {
+            float4* po = reinterpret_cast<float4*>(out + sbase + (int64_t)row0 * px);
+            const float4* src = reinterpret_cast<const float4*>(lc);
+            const int nq = nr * (px / 4);
+            for (int f = t; f < nq; f += MMX_WG) po[f] = src[f];
+        }
     }
 }
 
@@ -120,23 +178,26 @@ template <int R>
 int launch_x(const mmx_block* d_blocks, int n_blocks, int max_rows, int max_nx, int64_t slot_elems,
              const mmx_taps_f32& taps, const float* d_a, const float* d_bc, float* d_log, hipStream_t s)
 {
-    const int HW = max_nx + 2 * R;
-    const int PW = HW + (HW >> 3) + 1;
+    constexpr int LEAD = R & 1;
+    constexpr int S = (R + LEAD + 7) & ~7;
+    const int px = (max_nx + MMX_ROW_ALIGN - 1) / MMX_ROW_ALIGN * MMX_ROW_ALIGN;
+    const int span = S + px + R + LEAD;
+    const int PW = ((span + 2 * (span >> 3)) + 3) & ~1;
     const int CH = (max_nx + kT - 1) / kT;
-    int RG = MMX_WG / CH;
-    if (RG < 1) RG = 1;
-    // rows with fewer chunks (narrow edge blocks) would pack more rows per group: cap by LDS
-    const int lds_budget = 48 * 1024;
-    int rg_max = lds_budget / (2 * PW * (int)sizeof(float));
-    if (rg_max < 1) return MMX_ERR_UNSUPPORTED;
-    if (rg_max > MMX_WG) rg_max = MMX_WG;
-    const size_t lds_bytes = (size_t)2 * rg_max * PW * sizeof(float);
-    (void)RG;
-    int groups = (max_rows + 0) / 1;  // upper bound on row groups: at least one row per group
-    int gx = groups < 2048 ? groups : 2048;
+    // rows per group: as many as the threads cover, within the per-thread prefetch registers
+    int rg = MMX_WG / CH;
+    if (rg < 1) rg = 1;
+    while (rg > 1 && (rg * (px / 4) > kMaxQuads * MMX_WG || rg * 2 * R > kMaxHalo * MMX_WG)) --rg;
+    if (px / 4 > kMaxQuads * MMX_WG || 2 * R > kMaxHalo * MMX_WG) return MMX_ERR_UNSUPPORTED;
+    if (CH > MMX_WG) return MMX_ERR_UNSUPPORTED;   // rows wider than 2048 voxels: generic path
+    // narrower blocks of the same batch may pack more rows per group; keep them within rg
+    const size_t lds_bytes = ((size_t)2 * rg * PW + (size_t)rg * px) * sizeof(float);
+    if (lds_bytes > 64 * 1024) return MMX_ERR_UNSUPPORTED;
+    int gx = (max_rows + rg - 1) / rg;
+    if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     dim3 grid(gx, n_blocks);
-    hipLaunchKernelGGL(xpass_kernel<R>, grid, dim3(MMX_WG), lds_bytes, s, d_blocks, slot_elems, rg_max,
+    hipLaunchKernelGGL(xpass_kernel<R>, grid, dim3(MMX_WG), lds_bytes, s, d_blocks, slot_elems, rg,
                        d_a, d_bc, d_log, taps);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
