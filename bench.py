@@ -265,7 +265,7 @@ def main():
                 "achieved_GBps_wall": round(B_ALG_PER_SIGMA * ns * nvox / (elapsed / args.steps) / 1e9, 1),
                 "frac_wall": round(B_ALG_PER_SIGMA * ns * nvox / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4)},
             "kernels": per_kernel,
-            "detector_stats": {k: (round(v, 9) if isinstance(v, float) else v)
+            "detector_stats": {k: (round(float(v), 9) if isinstance(v, (float, np.floating)) else int(v))
                                for k, v in vars(stats).items()},
             "cpu_baseline": cpu, "parity_sample_identical": parity,
             "volume_gen_s": round(t_gen, 2),

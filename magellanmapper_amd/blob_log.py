@@ -219,13 +219,22 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
 
 
 class _Buffers:
-    """Device scratch that is reused across batches of one call."""
+    """Device scratch that is reused across the batches of one call.
+
+    ``main`` is the caller's stream: the float32 passes, the NMS and the bulk re-score of
+    batch k are enqueued there back to back.  ``side`` is a high-priority stream for the
+    small follow-up work of batch k-1 (copying its candidates out, re-scoring the neighbours
+    of contested candidates, the overlap-pair search), which therefore overlaps the heavy
+    kernels of batch k instead of queueing behind them.
+    """
 
     def __init__(self, dev):
         self.dev = dev
         self.ws = None
-        self.cands = None
-        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cands = [None, None]
+        self.counts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.host_counts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.side = torch.cuda.Stream(device=dev, priority=-1)
 
     def workspace(self, n_floats: int):
         if self.ws is None or self.ws.numel() < n_floats:
@@ -233,11 +242,12 @@ class _Buffers:
             self.ws = torch.empty(n_floats, dtype=torch.float32, device=self.dev)
         return self.ws
 
-    def cand_table(self, cap: int):
-        if self.cands is None or self.cands.numel() < cap * nat.CAND_DTYPE.itemsize:
-            self.cands = None
-            self.cands = torch.empty(cap * nat.CAND_DTYPE.itemsize, dtype=torch.uint8, device=self.dev)
-        return self.cands
+    def cand_table(self, which: int, cap: int):
+        need = cap * nat.CAND_DTYPE.itemsize
+        if self.cands[which] is None or self.cands[which].numel() < need:
+            self.cands[which] = None
+            self.cands[which] = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        return self.cands[which]
 
 
 def _to_device_bytes(arr: np.ndarray, dev) -> "torch.Tensor":
@@ -309,20 +319,32 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     peaks_out: List[Optional[Tuple[np.ndarray, np.ndarray]]] = [None] * len(shapes)
     bufs = _Buffers(dvol.tensor.device)
     eps = EPS_REL * dvol.value_scale()
-    for batch in plan_batches(shapes, len(space.sigmas), budget_bytes):
-        peaks = _detect_batch(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
-                              space, float(threshold), eps, bufs, stats)
-        pruned = _prune_batch(peaks, space, float(overlap), dvol.tensor.device, stats)
-        for i, pk, res in zip(batch, peaks, pruned):
-            results[i] = res
-            peaks_out[i] = pk
+    d_w0 = torch.from_numpy(space.w0_tab).to(dvol.tensor.device)
+    d_w2 = torch.from_numpy(space.w2_tab).to(dvol.tensor.device)
+    batches = plan_batches(shapes, len(space.sigmas), budget_bytes)
+    pending = None
+    for k in range(len(batches) + 1):
+        job = None
+        if k < len(batches):
+            batch = batches[k]
+            job = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
+                                  space, float(threshold), eps, bufs, k & 1, d_w0, d_w2)
+            job["batch"] = batch
+        if pending is not None:      # host + side-stream work of the previous batch, GPU busy with `job`
+            peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats)
+            with torch.cuda.stream(bufs.side):
+                pruned = _prune_batch(peaks, space, float(overlap), dvol.tensor.device, stats)
+            for i, pk, res in zip(pending["batch"], peaks, pruned):
+                results[i] = res
+                peaks_out[i] = pk
+        pending = job
     return (results, peaks_out) if return_peaks else results
 
 
 # --------------------------------------------------------------------------- A0-A4
-def _detect_batch(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
-                  bufs: _Buffers, stats: BatchStats):
-    """Ordered raw peaks ``(coords int64 (n, 4), values float64 (n,))`` per block."""
+def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
+                    bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None):
+    """Enqueue A0-A4 of one batch on the current stream; nothing here waits for the GPU."""
     L = nat.lib()
     dev = dvol.tensor.device
     blocks, slot = _make_blocks(dvol, channel, origins, shapes)
@@ -342,43 +364,63 @@ def _detect_batch(dvol, channel, origins, shapes, space: ScaleSpace, thr: float,
             float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(), stream),
             "mmx_log_batch_f32")
     n_vox = int(sum(int(np.prod(s)) for s in shapes))
-    d_w0 = torch.from_numpy(space.w0_tab).to(dev)
-    d_w2 = torch.from_numpy(space.w2_tab).to(dev)
     store_f32 = 1 if dvol.np_dtype == np.float32 else 0
-    cap = max(4096, min(n_vox * ns, n_vox // 2000 * ns + 65536))
-    while True:
-        table = bufs.cand_table(cap)
-        bufs.count.zero_()
-        nat.check(L.mmx_peaks_batch(log_base, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
-                                    thr, eps, table.data_ptr(), cap, bufs.count.data_ptr(), stream),
-                  "mmx_peaks_batch")
-        nat.check(L.mmx_rescore_f64(
-            ctypes.byref(vol_exact), d_blocks.data_ptr(), nb, table.data_ptr(), cap,
-            bufs.count.data_ptr(), d_w0.data_ptr(), d_w2.data_ptr(), nat.as_int32_ptr(space.radii),
-            nat.as_double_ptr(space.norms), ns, store_f32, stream), "mmx_rescore_f64")
-        count = int(bufs.count.item()) & 0xFFFFFFFF
-        if count <= cap:
-            break
-        if count >= n_vox * ns:
+    if cap is None:
+        cap = max(4096, min(n_vox * ns, n_vox // 2000 * ns + 65536))
+    table = bufs.cand_table(which, cap)
+    count = bufs.counts[which]
+    count.zero_()
+    nat.check(L.mmx_peaks_batch(log_base, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
+                                thr, eps, table.data_ptr(), cap, count.data_ptr(), stream),
+              "mmx_peaks_batch")
+    nat.check(L.mmx_rescore_f64(
+        ctypes.byref(vol_exact), d_blocks.data_ptr(), nb, table.data_ptr(), cap,
+        count.data_ptr(), d_w0.data_ptr(), d_w2.data_ptr(), nat.as_int32_ptr(space.radii),
+        nat.as_double_ptr(space.norms), ns, store_f32, stream), "mmx_rescore_f64")
+    bufs.host_counts[which].copy_(count, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
+                nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
+                vol_exact=vol_exact)
+
+
+def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
+                   stats: BatchStats):
+    """Wait for one batch's candidates and turn them into ordered raw peaks
+    ``(coords int64 (n, 4), values float64 (n,))`` per block."""
+    job["done"].synchronize()
+    which, cap, ns = job["which"], job["cap"], job["ns"]
+    count = int(bufs.host_counts[which].item()) & 0xFFFFFFFF
+    if count > cap:
+        if count >= job["n_vox"] * ns:
             # every voxel of every block "equals its maximum": only possible for constant
             # cubes, which scikit-image treats as having no peaks (peak.py:41-43)
             count = 0
-            break
-        cap = count + 1024
-    cands = (table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
-             if count else np.zeros(0, dtype=nat.CAND_DTYPE))
-    stats.n_blocks += nb
-    stats.n_voxels += n_vox
-    stats.n_candidates += count
-    if count:
-        err = float(np.max(np.abs(cands["v"].astype(np.float64) - cands["v64"])))
-        stats.max_f32_error = max(stats.max_f32_error, err)
-        if not err < 0.25 * eps:
-            raise nat.MmxError(
-                f"float32 LoG deviates from the exact value by {err:.3g} (band {eps:.3g}): "
-                "refusing to decide peaks on it")
-    return _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_w0, d_w2,
-                          space, store_f32, stats)
+        else:
+            # table overflow (rare): redo this batch with a table that fits; the pipeline
+            # already reused the workspace, so the passes run again
+            torch.cuda.current_stream().synchronize()
+            redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr,
+                                   eps, bufs, which, d_w0, d_w2, cap=count + 1024)
+            redo["batch"] = job.get("batch")
+            return _finish_detect(redo, dvol, space, thr, eps, bufs, d_w0, d_w2, stats)
+    with torch.cuda.stream(bufs.side):
+        table = bufs.cands[which]
+        cands = (table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
+                 if count else np.zeros(0, dtype=nat.CAND_DTYPE))
+        stats.n_blocks += job["nb"]
+        stats.n_voxels += job["n_vox"]
+        stats.n_candidates += count
+        if count:
+            err = float(np.max(np.abs(cands["v"].astype(np.float64) - cands["v64"])))
+            stats.max_f32_error = max(stats.max_f32_error, err)
+            if not err < 0.25 * eps:
+                raise nat.MmxError(
+                    f"float32 LoG deviates from the exact value by {err:.3g} (band {eps:.3g}): "
+                    "refusing to decide peaks on it")
+        return _resolve_peaks(cands, job["blocks"], job["shapes"], ns, thr, dvol, job["vol_exact"],
+                              job["d_blocks"], d_w0, d_w2, space, job["store_f32"], stats)
 
 
 def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_w0, d_w2,
@@ -428,20 +470,26 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
         keep[contested] = c["v64"] >= nbr_max
     keep &= cands["v64"] > thr
     cands = cands[keep]
+    # group by block; inside a block the C order of np.nonzero on the (z, y, x, sigma) cube
+    dims = np.asarray(shapes, dtype=np.int64)
+    slot = cands["slot"].astype(np.int64)
+    lin = ((cands["z"].astype(np.int64) * dims[slot, 1] + cands["y"]) * dims[slot, 2] + cands["x"]) * ns \
+        + cands["s"]
+    order = np.lexsort((lin, slot))
+    cands = cands[order]
+    bounds = np.searchsorted(cands["slot"], np.arange(len(shapes) + 1))
+    coords_all = np.stack([cands["z"], cands["y"], cands["x"], cands["s"]], axis=1).astype(np.int64)
+    vals_all = cands["v64"]
     out = []
-    for i, shp in enumerate(shapes):
-        mine = cands[cands["slot"] == i]
-        if len(mine) == 0:
+    for i in range(len(shapes)):
+        a, b = bounds[i], bounds[i + 1]
+        if a == b:
             out.append((np.zeros((0, 4), dtype=np.int64), np.zeros(0)))
             continue
-        # C order of np.nonzero on the (z, y, x, sigma) cube, then argsort(-values)
-        lin = ((mine["z"].astype(np.int64) * shp[1] + mine["y"]) * shp[2] + mine["x"]) * ns + mine["s"]
-        mine = mine[np.argsort(lin, kind="stable")]
-        vals = mine["v64"].copy()
-        order = np.argsort(-vals)
-        coords = np.stack([mine["z"], mine["y"], mine["x"], mine["s"]], axis=1).astype(np.int64)[order]
-        out.append((coords, vals[order]))
-        stats.n_peaks += len(order)
+        vals = vals_all[a:b].copy()
+        rank = np.argsort(-vals)          # the reference's call on the reference's array (peak.py:17)
+        out.append((coords_all[a:b][rank], vals[rank]))
+        stats.n_peaks += b - a
     return out
 
 
@@ -480,79 +528,77 @@ def _reference_pair_order(lm: np.ndarray) -> np.ndarray:
 
 
 def _prune_batch(peaks, space: ScaleSpace, overlap: float, dev, stats: BatchStats):
-    """Sphere-overlap prune of every block of the batch."""
+    """Sphere-overlap prune of every block of the batch (skimage blob.py:146-187).
+
+    The device returns every pair whose overlap fraction exceeds the limit.  The reference
+    visits pairs one by one and zeroes the smaller sigma (first of the pair on ties); a dead
+    blob never kills another.  The outcome is independent of the visiting order unless some
+    blob loses one over-limit pair and wins another (a chain): only blocks with such a blob
+    take the reference's own order from ``cKDTree.query_pairs``.
+    """
     L = nat.lib()
-    lms = []
-    for coords, _vals in peaks:
-        if len(coords) == 0:
-            lms.append(None)
-            continue
-        lm = coords.astype(np.float64)
-        lm[:, 3] = space.sigmas[coords[:, 3]]
-        lms.append(lm)
-    sizes = np.array([0 if lm is None else len(lm) for lm in lms], dtype=np.int32)
-    offsets = np.zeros(len(lms) + 1, dtype=np.int32)
+    sizes = np.array([len(c) for c, _ in peaks], dtype=np.int32)
+    offsets = np.zeros(len(peaks) + 1, dtype=np.int32)
     np.cumsum(sizes, out=offsets[1:])
     total = int(offsets[-1])
+    if total == 0:
+        return [np.empty((0, 3)) for _ in peaks]
+    coords = np.concatenate([c for c, _ in peaks if len(c)])
+    allb = coords.astype(np.float64)
+    allb[:, 3] = space.sigmas[coords[:, 3]]
+    d_blobs = torch.from_numpy(allb).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    cap = max(1024, 4 * total)
+    while True:
+        d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        d_frac = torch.empty(cap, dtype=torch.float64, device=dev)
+        d_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        nat.check(L.mmx_overlap_pairs(d_blobs.data_ptr(), d_off.data_ptr(), len(peaks), overlap,
+                                      OVERLAP_BAND, d_pairs.data_ptr(), d_frac.data_ptr(), cap,
+                                      d_count.data_ptr(), _stream_ptr()), "mmx_overlap_pairs")
+        n = int(d_count.item()) & 0xFFFFFFFF
+        if n <= cap:
+            break
+        cap = n + 64
+    sig = allb[:, 3].copy()
+    stats.n_overlap_pairs += n
+    if n:
+        pairs = d_pairs[:n].cpu().numpy().astype(np.int64)
+        frac = d_frac[:n].cpu().numpy()
+        for k in np.nonzero(np.abs(frac - overlap) <= OVERLAP_BAND)[0]:   # knife edge: exact libm
+            frac[k] = _exact_overlap(allb[pairs[k, 0]], allb[pairs[k, 1]])
+        act = pairs[frac > overlap]
+        if len(act):
+            # the device appends pairs in arbitrary order; (i, j) itself always has i < j
+            i, j = act[:, 0], act[:, 1]
+            first_bigger = sig[i] > sig[j]
+            loser = np.where(first_bigger, j, i)
+            winner = np.where(first_bigger, i, j)
+            chained = np.intersect1d(loser, winner)
+            block_of_pair = np.searchsorted(offsets, i, side="right") - 1
+            chain_blocks = np.unique(np.searchsorted(offsets, chained, side="right") - 1)
+            simple = ~np.isin(block_of_pair, chain_blocks)
+            sig[loser[simple]] = 0
+            for b in chain_blocks:
+                stats.n_order_fallbacks += 1
+                lo, hi = offsets[b], offsets[b + 1]
+                mine = block_of_pair == b
+                active = {(int(a_) - lo, int(b_) - lo) for a_, b_ in act[mine]}
+                bs = sig[lo:hi]
+                for a_, b_ in _reference_pair_order(allb[lo:hi]):
+                    a_, b_ = int(a_), int(b_)
+                    if (a_, b_) in active and bs[a_] > 0 and bs[b_] > 0:
+                        if bs[a_] > bs[b_]:
+                            bs[b_] = 0
+                        else:
+                            bs[a_] = 0
     results = []
-    pairs = np.zeros((0, 2), dtype=np.int32)
-    frac = np.zeros(0)
-    if total:
-        allb = np.concatenate([lm for lm in lms if lm is not None])
-        d_blobs = torch.from_numpy(allb).to(dev)
-        d_off = torch.from_numpy(offsets).to(dev)
-        cap = max(1024, 4 * total)
-        while True:
-            d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
-            d_frac = torch.empty(cap, dtype=torch.float64, device=dev)
-            d_count = torch.zeros(1, dtype=torch.int32, device=dev)
-            nat.check(L.mmx_overlap_pairs(d_blobs.data_ptr(), d_off.data_ptr(), len(lms), overlap,
-                                          OVERLAP_BAND, d_pairs.data_ptr(), d_frac.data_ptr(), cap,
-                                          d_count.data_ptr(), _stream_ptr()), "mmx_overlap_pairs")
-            n = int(d_count.item()) & 0xFFFFFFFF
-            if n <= cap:
-                break
-            cap = n + 64
-        if n:
-            pairs = d_pairs[:n].cpu().numpy()
-            frac = d_frac[:n].cpu().numpy()
-    stats.n_overlap_pairs += len(pairs)
-    owner = np.searchsorted(offsets, pairs[:, 0], side="right") - 1 if len(pairs) else np.zeros(0, int)
-    for b, lm in enumerate(lms):
-        if lm is None:
+    for b in range(len(peaks)):
+        lo, hi = offsets[b], offsets[b + 1]
+        if lo == hi:
             results.append(np.empty((0, 3)))
             continue
-        mine = owner == b
-        if not mine.any():
-            results.append(lm)
-            stats.n_blobs += len(lm)
-            continue
-        loc = pairs[mine] - offsets[b]
-        fr = frac[mine].copy()
-        edge = np.abs(fr - overlap) <= OVERLAP_BAND
-        for k in np.nonzero(edge)[0]:
-            fr[k] = _exact_overlap(lm[loc[k, 0]], lm[loc[k, 1]])
-        act = loc[fr > overlap]
-        sig = lm[:, 3].copy()
-        if len(act):
-            uses = np.bincount(act.ravel(), minlength=len(lm))
-            if uses.max() > 1:
-                # chains: the result depends on the visiting order -> take the reference's
-                stats.n_order_fallbacks += 1
-                active = {(int(i), int(j)) for i, j in act}
-                for i, j in _reference_pair_order(lm):
-                    i, j = int(i), int(j)
-                    if (i, j) in active and sig[i] > 0 and sig[j] > 0:
-                        if sig[i] > sig[j]:
-                            sig[j] = 0
-                        else:
-                            sig[i] = 0
-            else:
-                i, j = act[:, 0], act[:, 1]
-                first_bigger = sig[i] > sig[j]
-                sig[j[first_bigger]] = 0
-                sig[i[~first_bigger]] = 0
-        res = lm[sig > 0]
+        res = allb[lo:hi][sig[lo:hi] > 0]
         results.append(res)
         stats.n_blobs += len(res)
     return results

@@ -412,6 +412,10 @@ def _smallest_signed_int(max_val) -> type:
     raise TypeError("unable to find an integer type for the coordinate range")
 
 
+#: positions (in the ``blobs`` argument) of the rows kept by the last :func:`remove_close_blobs`
+last_survivors = None
+
+
 def find_close_pairs(check_zyx: np.ndarray, master_zyx: np.ndarray, tol) -> Tuple[np.ndarray, np.ndarray]:
     """Device all-pairs search: ``(last_check_per_master, check_hit)``.
 
@@ -457,7 +461,9 @@ def remove_close_blobs(blobs: np.ndarray, blobs_master: np.ndarray, tol,
     dtype = _smallest_signed_int(np.amax((np.amax(blobs[:, :3]), np.amax(blobs_master[:, :3]))))
     last, hit = find_close_pairs(blobs[:, :3].astype(dtype), blobs_master[:, :3].astype(dtype),
                                  np.asarray(tol))
-    pruned = blobs[~hit]
+    global last_survivors
+    last_survivors = np.nonzero(~hit)[0]     # positions in ``blobs`` that were kept
+    pruned = blobs[last_survivors]
     matched = np.nonzero(last >= 0)[0]
     Blobs(blobs)  # as the reference does: (re)binds the class-level column indices to this table
     if len(matched):

@@ -370,9 +370,12 @@ class StackPruner:
 
         For every axis with more than one block, every block boundary ``j | j+1`` defines a
         slab ``[end_j - (overlap + pad), end_j + pad)`` spanning the whole plane; blobs in it
-        are de-duplicated between the two block generations, everything else passes through,
-        and the recombined table goes on to the next axis.  Returns ``(table, DataFrame)``
-        or ``(None, None)``.
+        are de-duplicated between the two block generations (:meth:`prune_overlap`),
+        everything else passes through, and the recombined table goes on to the next axis.
+        Returns ``(table, DataFrame)`` or ``(None, None)``.
+
+        Same results and row order as the reference, but rows are tracked as indices into the
+        merged table (only the 3 abs columns ever change), so the big table is gathered once.
         """
         import pandas as pd
         merged = chunking.merge_blobs(seg_rois)
@@ -385,17 +388,22 @@ class StackPruner:
         coord_last = tuple(np.subtract(grid, 1))
         ratio_cols = ("blobs", "ratio_pruning", "ratio_adjacent")
         ratios_all = {}
-        per_channel = []
+        ncol = merged.shape[1]
+        detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
+        abs_inds = detector.Blobs._get_abs_inds()
+        chan = detector.Blobs.get_blobs_channel(merged)
+        pieces = []
         for chl in channels:
-            blobs = detector.Blobs.blobs_in_channel(merged, chl)
+            cur = np.nonzero(np.isin(chan, chl))[0]          # row ids, in table order
             for axis in range(3):
                 n_sections = sub_rois_offsets.shape[axis]
                 if n_sections <= 1:
                     continue
-                pos = blobs[:, axis]
+                pos = merged[cur, axis]
+                tag = merged[cur, ncol - 3 + axis]
                 shift = overlap[axis] + overlap_padding[axis]
                 passthrough = []
-                slabs = []
+                deduped = []
                 for j in range(n_sections):
                     coord = [0, 0, 0]
                     coord[axis] = j
@@ -405,30 +413,44 @@ class StackPruner:
                     extent = [len(range(*s.indices(n))) for s, n in zip(slc, shape3)]
                     end = start + extent[axis]
                     lo = start + (shift if j > 0 else 0)
-                    if j < n_sections - 1:
-                        slab_lo, slab_hi = end - shift, end + overlap_padding[axis]
-                        in_slab = blobs[(pos >= slab_lo) & (pos < slab_hi)]
-                        nxt_lo = end + tol[axis]
-                        nxt_hi = nxt_lo + overlap[axis] + 2 * overlap_padding[axis]
-                        roi_end = sub_rois_offsets[coord_last][axis] + extent[axis]
-                        in_next = None
-                        if nxt_lo < roi_end and nxt_hi < roi_end:
-                            in_next = blobs[(pos >= nxt_lo) & (pos < nxt_hi)]
-                        slabs.append((in_slab, axis, tol, in_next))
-                        passthrough.append(blobs[(pos < slab_lo) & (pos >= lo)])
-                    else:
-                        slabs.append((None, axis, tol, None))
-                        passthrough.append(blobs[(pos < end) & (pos >= lo)])
-                cls.blobs_to_prune = slabs
-                deduped = []
-                for j in range(len(slabs)):
-                    after, ratios = cls.prune_overlap(j, slabs[j])
-                    if after is not None:
-                        deduped.append(after)
-                    if ratios:
-                        for col, val in zip(ratio_cols, ratios):
-                            ratios_all.setdefault(col, []).append(val)
-                blobs = np.concatenate(passthrough + deduped)
-            per_channel.append(blobs)
-        out = np.vstack(per_channel)[:, :-3]
+                    if j == n_sections - 1:
+                        passthrough.append(cur[(pos < end) & (pos >= lo)])
+                        continue
+                    slab_lo, slab_hi = end - shift, end + overlap_padding[axis]
+                    passthrough.append(cur[(pos < slab_lo) & (pos >= lo)])
+                    in_slab = (pos >= slab_lo) & (pos < slab_hi)
+                    n_orig = int(np.count_nonzero(in_slab))
+                    master = cur[in_slab & (tag == j)]
+                    check = cur[in_slab & (tag == j + 1)]
+                    check = cls._dedup(merged, master, check, tol, abs_inds)
+                    after = np.concatenate((master, check))
+                    deduped.append(after)
+                    nxt_lo = end + tol[axis]
+                    nxt_hi = nxt_lo + overlap[axis] + 2 * overlap_padding[axis]
+                    roi_end = sub_rois_offsets[coord_last][axis] + extent[axis]
+                    if nxt_lo < roi_end and nxt_hi < roi_end:
+                        n_next = int(np.count_nonzero((pos >= nxt_lo) & (pos < nxt_hi)))
+                        ratios = detector.meas_pruning_ratio(n_orig, len(after), n_next)
+                        if ratios:
+                            for col, val in zip(ratio_cols, ratios):
+                                ratios_all.setdefault(col, []).append(val)
+                cur = np.concatenate(passthrough + deduped)
+            pieces.append(cur)
+        out = merged[np.concatenate(pieces)][:, :-3]
         return out, pd.DataFrame(ratios_all)
+
+    @staticmethod
+    def _dedup(merged, master, check, tol, abs_inds):
+        """:func:`detector.remove_close_blobs` on row ids: returns the surviving check ids and
+        updates the masters' abs coordinates inside ``merged``."""
+        if len(master) == 0 or len(check) == 0:
+            return check
+        m_rows, c_rows = merged[master], merged[check]
+        pruned, m_rows = detector.remove_close_blobs(c_rows, m_rows, tol)
+        merged[np.ix_(master, abs_inds)] = m_rows[:, abs_inds]
+        if len(pruned) == len(check):
+            return check
+        # remove_close_blobs keeps order: recover which rows survived
+        hit = np.ones(len(check), dtype=bool)
+        hit[detector.last_survivors] = False
+        return check[~hit]
