@@ -215,6 +215,14 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
         cur_slot = slot
     if cur:
         batches.append(cur)
+    # The host work of the LAST batch is not hidden behind any GPU work: taper the tail by
+    # splitting the final batch (1/2, 1/4, 1/4 ...) while it stays large.
+    while len(batches[-1]) > 24:
+        last = batches.pop()
+        cut = len(last) - max(12, len(last) // 4)
+        batches.extend([last[:cut], last[cut:]])
+        if len(batches[-1]) <= 24:
+            break
     return batches
 
 
@@ -302,13 +310,15 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                     shapes: Sequence[Sequence[int]], min_sigma: float, max_sigma: float,
                     num_sigma: int, threshold: float, overlap: float, *,
                     budget_bytes: int = 24 << 30, stats: Optional[BatchStats] = None,
-                    return_peaks: bool = False):
+                    return_peaks: bool = False, on_batch=None):
     """``blob_log`` of every block -> list of ``(n, 4)`` float64 ``[z, y, x, sigma]`` arrays.
 
     Each block is an independent image exactly as each reference worker's sub-ROI is
     (reference magmap/cv/stack_detect.py:79): reflect boundaries at the block faces,
     coordinates relative to the block.  Blocks without blobs give ``np.empty((0, 3))`` like
     scikit-image does (blob.py:516-517).  Row order equals the reference's.
+    ``on_batch(indices, results)`` is called as each batch finishes, while the GPU is busy
+    with the next one.
     """
     _require_gpu()
     space = ScaleSpace.make(min_sigma, max_sigma, num_sigma)
@@ -337,6 +347,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             for i, pk, res in zip(pending["batch"], peaks, pruned):
                 results[i] = res
                 peaks_out[i] = pk
+            if on_batch is not None:    # caller's per-block post-processing, still overlapped
+                on_batch(pending["batch"], pruned)
         pending = job
     return (results, peaks_out) if return_peaks else results
 
@@ -469,17 +481,19 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
         nbr_max[border] = np.maximum(nbr_max[border], 0.0)   # mode='constant', cval=0
         keep[contested] = c["v64"] >= nbr_max
     keep &= cands["v64"] > thr
-    cands = cands[keep]
+    sel = np.nonzero(keep)[0]
+    # plain contiguous columns from here on (record-array fancy indexing is slow)
+    slot = cands["slot"].astype(np.int64)[sel]
+    cs, cz, cy, cx = (cands[f].astype(np.int64)[sel] for f in ("s", "z", "y", "x"))
+    v64 = cands["v64"][sel]
     # group by block; inside a block the C order of np.nonzero on the (z, y, x, sigma) cube
     dims = np.asarray(shapes, dtype=np.int64)
-    slot = cands["slot"].astype(np.int64)
-    lin = ((cands["z"].astype(np.int64) * dims[slot, 1] + cands["y"]) * dims[slot, 2] + cands["x"]) * ns \
-        + cands["s"]
+    lin = ((cz * dims[slot, 1] + cy) * dims[slot, 2] + cx) * ns + cs
     order = np.lexsort((lin, slot))
-    cands = cands[order]
-    bounds = np.searchsorted(cands["slot"], np.arange(len(shapes) + 1))
-    coords_all = np.stack([cands["z"], cands["y"], cands["x"], cands["s"]], axis=1).astype(np.int64)
-    vals_all = cands["v64"]
+    slot = slot[order]
+    coords_all = np.stack([cz[order], cy[order], cx[order], cs[order]], axis=1)
+    vals_all = v64[order]
+    bounds = np.searchsorted(slot, np.arange(len(shapes) + 1))
     out = []
     for i in range(len(shapes)):
         a, b = bounds[i], bounds[i + 1]

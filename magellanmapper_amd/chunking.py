@@ -57,12 +57,33 @@ def stack_splitter(shape: Sequence[int], max_pixels: Sequence[int],
 
 def merge_blobs(blob_rois: np.ndarray) -> Optional[np.ndarray]:
     """All block tables stacked, with the block's grid coordinate as 3 extra int columns."""
-    parts = []
-    for coord in np.ndindex(*blob_rois.shape):
-        tbl = blob_rois[coord]
-        if tbl is None or isinstance(tbl, (int, np.integer)):
-            continue
-        tag = np.empty((tbl.shape[0], 3), dtype=int)
-        tag[:] = coord
-        parts.append(np.concatenate((tbl, tag), axis=1))
-    return np.vstack(parts) if parts else None
+    arena = getattr(blob_rois, "arena", None)
+    if arena is not None:
+        # tables were stored back to back (grid order) with their tags while the GPU was busy:
+        # the merged table already exists, provided the caller did not replace any block table
+        at = 0
+        intact = True
+        for coord in np.ndindex(*blob_rois.shape):
+            tbl = blob_rois[coord]
+            if tbl is None or isinstance(tbl, (int, np.integer)) or len(tbl) == 0:
+                continue
+            span = arena.spans.get(coord)
+            if span is None or span[0] != at or not np.shares_memory(tbl, arena.store):
+                intact = False
+                break
+            at = span[1]
+        if intact and at == arena.n:
+            return arena.store[:arena.n] if at else None
+    live = [(coord, blob_rois[coord]) for coord in np.ndindex(*blob_rois.shape)
+            if blob_rois[coord] is not None and not isinstance(blob_rois[coord], (int, np.integer))]
+    if not live:
+        return None
+    n_rows = sum(t.shape[0] for _, t in live)
+    n_cols = live[0][1].shape[1]
+    out = np.empty((n_rows, n_cols + 3), dtype=np.result_type(live[0][1].dtype, np.int64))
+    at = 0
+    for coord, tbl in live:                       # one allocation, filled block by block
+        out[at:at + tbl.shape[0], :n_cols] = tbl
+        out[at:at + tbl.shape[0], n_cols:] = coord
+        at += tbl.shape[0]
+    return out

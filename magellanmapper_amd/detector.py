@@ -362,12 +362,14 @@ def detect_blobs(roi, channel: Optional[Sequence[int]],
     return blobs_all
 
 
-def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None) -> List[Optional[np.ndarray]]:
+def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
+                               on_block=None) -> List[Optional[np.ndarray]]:
     """:func:`detect_blobs` for many blocks of one resident volume in one device pass.
 
     Returns one 11-column table (block-relative coordinates) or ``None`` per block, rows
     ordered as the reference orders them: channels in turn, within a channel the pruned
-    ``blob_log`` order.
+    ``blob_log`` order.  ``on_block(i, table)`` (optional) post-processes each finished block
+    table while the GPU is still busy with later batches; its return value replaces the table.
     """
     from . import blob_log as bl
     multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
@@ -377,25 +379,36 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None) -> Li
             "the 'isotropic' rescale (reference detector.py:893-897) is not built yet "
             "(SURVEY.md section 8f row 4); use a profile with isotropic: None")
     per_block: List[List[np.ndarray]] = [[] for _ in shapes]
+    done: List[Optional[np.ndarray]] = [None] * len(shapes)
+    channels = list(channels)
     for chl in channels:
         settings = config.get_roi_profile(chl)
         if getattr(settings, "spectral_unmixing", None) is not None:
             raise NotImplementedError("spectral unmixing (reference detector.py:910-921) is "
                                       "not built yet (SURVEY.md section 8f row 4)")
         scaling_factor = calc_scaling_factor()[2]          # x scaling alone, as the reference
-        res = bl.blob_log_blocks(
+        root3 = math.sqrt(3)
+
+        def to_tables(indices, results, chl=chl):
+            # radius = sigma * sqrt(3), then the 11 standard columns (reference :937-938)
+            for i, blobs_log in zip(indices, results):
+                if blobs_log.size < 1:
+                    continue
+                blobs_log = blobs_log.copy()
+                blobs_log[:, 3] = blobs_log[:, 3] * root3
+                per_block[i].append(Blobs(blobs_log).format_blobs(chl))
+            if chl == channels[-1]:            # the block tables of this batch are complete
+                for i in indices:
+                    tbl = np.vstack(per_block[i]) if per_block[i] else None
+                    done[i] = on_block(i, tbl) if on_block is not None else tbl
+
+        bl.blob_log_blocks(
             dvol, chl if multichannel else 0, origins, shapes,
             min_sigma=settings["min_sigma_factor"] * scaling_factor,
             max_sigma=settings["max_sigma_factor"] * scaling_factor,
             num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
-            overlap=settings["overlap"], stats=stats)
-        for i, blobs_log in enumerate(res):
-            if blobs_log.size < 1:
-                continue
-            blobs_log = blobs_log.copy()
-            blobs_log[:, 3] = blobs_log[:, 3] * math.sqrt(3)
-            per_block[i].append(Blobs(blobs_log).format_blobs(chl))
-    return [np.vstack(t) if t else None for t in per_block]
+            overlap=settings["overlap"], stats=stats, on_batch=to_tables)
+    return done
 
 
 # ------------------------------------------------------------------------------------

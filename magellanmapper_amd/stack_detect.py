@@ -50,6 +50,43 @@ class Image5d:
         self.is_roi = False
 
 
+class _TableArena:
+    """Per-block tables stored back to back in one ``(n, 14)`` array whose last three columns
+    already hold the block's grid coordinate: what ``chunking.merge_blobs`` would build, filled
+    while the GPU is still busy.  The per-block tables handed out are views of it."""
+
+    def __init__(self, n_cols: int = 11):
+        self.n_cols = n_cols
+        self.store = np.empty((4096, n_cols + 3))
+        self.n = 0
+        self.spans = {}
+
+    def add(self, coord, table: np.ndarray) -> np.ndarray:
+        rows = table.shape[0]
+        if self.n + rows > self.store.shape[0]:
+            grown = np.empty((max(2 * self.store.shape[0], self.n + rows), self.store.shape[1]))
+            grown[:self.n] = self.store[:self.n]
+            old = self.store
+            self.store = grown
+            # re-point the views handed out so far
+            self.stale = old
+        a = self.n
+        self.store[a:a + rows, :self.n_cols] = table
+        self.store[a:a + rows, self.n_cols:] = coord
+        self.n += rows
+        self.spans[tuple(coord)] = (a, a + rows)
+        return self.store[a:a + rows, :self.n_cols]
+
+    def view(self, coord):
+        a, b = self.spans[tuple(coord)]
+        return self.store[a:b, :self.n_cols]
+
+
+class _SegRois(np.ndarray):
+    """Object array of per-block tables that remembers the arena its tables live in."""
+    arena = None
+
+
 class StackDetector:
     """Detects blobs block by block.  Class attributes mirror the reference's fork-shared
     state (:51-57) but are only informational here."""
@@ -128,18 +165,30 @@ class StackDetector:
             shapes.append(tuple(r[1] - r[0] for r in rng))
         stats = bl.BatchStats()
         tables = []
+        arena = _TableArena() if dist.world_size() == 1 else None
+        pos = {i: k for k, i in enumerate(mine)}
+
+        def finish(k, tbl):
+            # border exclusion + shift to ROI coordinates, as soon as the block's batch is done
+            coord = coords[mine[k]]
+            exclude = cls._exclude_matrix(coord, last_coord, exclude_border)
+            tbl = cls._finish_block(tbl, shapes[k], exclude, sub_rois_offsets[coord])
+            if tbl is not None and arena is not None and len(tbl):
+                arena.add(coord, tbl)
+            return tbl
+
         if mine:
             dvol = img if isinstance(img, bl.DeviceVolume) else bl.DeviceVolume(img)
-            tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats)
+            tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish)
         cls.last_stats = stats
-        local = []
-        for i, tbl, shp in zip(mine, tables, shapes):
-            coord = coords[i]
-            exclude = cls._exclude_matrix(coord, last_coord, exclude_border)
-            local.append((i, cls._finish_block(tbl, shp, exclude, sub_rois_offsets[coord])))
-        seg_rois = np.zeros(grid, dtype=object)
+        local = [(i, tbl) for i, tbl in zip(mine, tables)]
+        seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
         for i, tbl in dist.gather_tables(local, len(coords)):
+            if arena is not None and tbl is not None and len(tbl):
+                tbl = arena.view(coords[i])         # the copy that lives in the arena
             seg_rois[coords[i]] = tbl
+        if arena is not None:
+            seg_rois.arena = arena
         return seg_rois
 
 
@@ -392,6 +441,10 @@ class StackPruner:
         detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
         abs_inds = detector.Blobs._get_abs_inds()
         chan = detector.Blobs.get_blobs_channel(merged)
+        zyx = merged[:, :3].astype(np.int64)                 # detection coordinates never change
+        tags = merged[:, ncol - 3:].astype(np.int64)
+        abs_cur = merged[:, abs_inds].copy()                 # the only values pruning changes
+        big = int(zyx.max(initial=0)) + int(np.max(tol)) + 2     # keeps sections apart in one search
         pieces = []
         for chl in channels:
             cur = np.nonzero(np.isin(chan, chl))[0]          # row ids, in table order
@@ -399,44 +452,83 @@ class StackPruner:
                 n_sections = sub_rois_offsets.shape[axis]
                 if n_sections <= 1:
                     continue
-                pos = merged[cur, axis]
-                tag = merged[cur, ncol - 3 + axis]
+                # The axis is tiled by [pass 0][slab 0][pass 1][slab 1] ... [pass last]; slab j
+                # = [end_j - (overlap + pad), end_j + pad) belongs to the boundary j | j + 1.
                 shift = overlap[axis] + overlap_padding[axis]
-                passthrough = []
-                deduped = []
+                bounds = []
+                ends = []
                 for j in range(n_sections):
                     coord = [0, 0, 0]
                     coord[axis] = j
                     coord = tuple(coord)
                     start = sub_rois_offsets[coord][axis]
                     slc = sub_roi_slices[coord]
-                    extent = [len(range(*s.indices(n))) for s, n in zip(slc, shape3)]
-                    end = start + extent[axis]
-                    lo = start + (shift if j > 0 else 0)
-                    if j == n_sections - 1:
-                        passthrough.append(cur[(pos < end) & (pos >= lo)])
-                        continue
-                    slab_lo, slab_hi = end - shift, end + overlap_padding[axis]
-                    passthrough.append(cur[(pos < slab_lo) & (pos >= lo)])
-                    in_slab = (pos >= slab_lo) & (pos < slab_hi)
-                    n_orig = int(np.count_nonzero(in_slab))
-                    master = cur[in_slab & (tag == j)]
-                    check = cur[in_slab & (tag == j + 1)]
-                    check = cls._dedup(merged, master, check, tol, abs_inds)
-                    after = np.concatenate((master, check))
-                    deduped.append(after)
+                    extent = len(range(*slc[axis].indices(shape3[axis])))
+                    end = start + extent
+                    ends.append((end, extent))
+                    bounds.append(start + (shift if j > 0 else 0))          # pass j begins
+                    if j < n_sections - 1:
+                        bounds.append(end - shift)                          # slab j begins
+                bounds = np.asarray(bounds, dtype=np.float64)
+                pos = merged[cur, axis]
+                tag = tags[cur, axis]
+                region = np.searchsorted(bounds, pos, side="right") - 1     # 2j = pass j, 2j+1 = slab j
+                last_end = ends[-1][0]
+                inside = (region >= 0) & (pos < last_end)
+                sec = region >> 1
+                in_slab = inside & ((region & 1) == 1)
+                is_master = in_slab & (tag == sec)
+                is_check = in_slab & (tag == sec + 1)
+                # one device search for all slabs of this axis: shifting section j by j * big
+                # along the axis keeps rows of different slabs from ever matching
+                m_ids, c_ids = cur[is_master], cur[is_check]
+                hit = np.zeros(len(c_ids), dtype=bool)
+                if len(m_ids) and len(c_ids):
+                    m_xyz, c_xyz = zyx[m_ids].copy(), zyx[c_ids].copy()
+                    m_xyz[:, axis] += sec[is_master] * big
+                    c_xyz[:, axis] += sec[is_check] * big
+                    last, hit = detector.find_close_pairs(c_xyz, m_xyz, np.asarray(tol))
+                    matched = np.nonzero(last >= 0)[0]
+                    if len(matched):
+                        # abs <- round-half-even mean with the LAST matching check row
+                        # (detector.remove_close_blobs; NumPy's duplicate-index assignment)
+                        mid = np.around(np.divide(np.add(
+                            abs_cur[m_ids[matched]], abs_cur[c_ids[last[matched]]]), 2))
+                        abs_cur[m_ids[matched]] = mid
+                # pruning-ratio statistics per slab (reference :673-676, :836-838)
+                n_slab = np.bincount(sec[in_slab], minlength=n_sections)
+                n_master = np.bincount(sec[is_master], minlength=n_sections)
+                n_kept = np.bincount(sec[is_check][~hit], minlength=n_sections)
+                for j in range(n_sections - 1):
+                    end, extent = ends[j]
                     nxt_lo = end + tol[axis]
                     nxt_hi = nxt_lo + overlap[axis] + 2 * overlap_padding[axis]
-                    roi_end = sub_rois_offsets[coord_last][axis] + extent[axis]
+                    roi_end = sub_rois_offsets[coord_last][axis] + extent
                     if nxt_lo < roi_end and nxt_hi < roi_end:
                         n_next = int(np.count_nonzero((pos >= nxt_lo) & (pos < nxt_hi)))
-                        ratios = detector.meas_pruning_ratio(n_orig, len(after), n_next)
+                        ratios = detector.meas_pruning_ratio(
+                            int(n_slab[j]), int(n_master[j] + n_kept[j]), n_next)
                         if ratios:
                             for col, val in zip(ratio_cols, ratios):
                                 ratios_all.setdefault(col, []).append(val)
-                cur = np.concatenate(passthrough + deduped)
+                # new row order: every pass section in turn, then per slab its masters followed
+                # by its surviving check rows; a stable sort on that key keeps table order inside
+                # each group.  Slab rows of any other block generation are dropped (reference
+                # prune_overlap keeps only generations j and j + 1).
+                key = np.full(len(cur), 255, dtype=np.int64)
+                is_pass = inside & ((region & 1) == 0)
+                key[is_pass] = sec[is_pass]
+                key[is_master] = n_sections + 2 * sec[is_master]
+                kept_check = is_check.copy()
+                kept_check[np.nonzero(is_check)[0][hit]] = False
+                key[kept_check] = n_sections + 2 * sec[kept_check] + 1
+                keep = key < 255
+                order = np.argsort(key[keep].astype(np.uint16), kind="stable")
+                cur = cur[keep][order]
             pieces.append(cur)
-        out = merged[np.concatenate(pieces)][:, :-3]
+        rows = np.concatenate(pieces)
+        out = np.take(merged, rows, axis=0)[:, :-3]          # (np.take: 10x fancy indexing)
+        out[:, abs_inds] = np.take(abs_cur, rows, axis=0)
         return out, pd.DataFrame(ratios_all)
 
     @staticmethod
