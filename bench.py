@@ -235,12 +235,22 @@ def main():
         stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
         dom = max(stream_k, key=lambda k: stream_k[k]["ms_per_step"]) if stream_k else None
         roof = None
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+        # command (profiles/, collected with rocprofv3 --pmc in separate passes and calibrated)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if tuple(shape) == SHAPE and world == 1 and dom in pmc["per_launch_GB"]:
+                traffic = round(pmc["per_launch_GB"][dom]["total_GB"] * 1e9)
+        except (OSError, KeyError, ValueError):
+            pass
         if dom:
             launches = ktimes[dom][1]
             roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),
-                    "traffic": None,
+                    "traffic": traffic,
                     "alg_bytes_per_launch": int(ALG_BYTES[dom] * my_vox * ns * args.steps / max(1, launches)),
                     "avg_launch_ms": round(ktimes[dom][0] / max(1, launches), 4)}
         gpu_ms = sum(ms for ms, n in ktimes.values()) / args.steps

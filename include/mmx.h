@@ -177,6 +177,10 @@ int mmx_event_destroy(void* ev);
 int mmx_event_record(void* ev, void* stream);
 int mmx_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
 
+/* PMC calibration (tools/pmc_calib.py): one streaming launch over n_elems elements with a known
+ * byte count.  kind 0: float copy, 4 B per lane; 1: float copy, 16 B per lane; 2: uint16 read. */
+int mmx_calib_stream(int kind, const void* d_in, void* d_out, int64_t n_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

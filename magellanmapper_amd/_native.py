@@ -52,6 +52,7 @@ SYMBOLS = (
     "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
+    "mmx_calib_stream",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs")
@@ -90,10 +91,11 @@ def lib() -> ctypes.CDLL:
     L.mmx_event_elapsed_ms.argtypes = [vp, vp, POINTER(c_float)]
     L.mmx_timing_enable.argtypes = [c_int]
     L.mmx_timing_read.argtypes = [POINTER(c_double), POINTER(c_int64), c_int]
+    L.mmx_calib_stream.argtypes = [c_int, vp, vp, c_int64, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is None or name.startswith(("mmx_log", "mmx_peaks", "mmx_rescore",
-                                                  "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing")):
+                                                  "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing", "mmx_calib")):
             fn.restype = c_int
     if L.mmx_abi_version() != MMX_ABI_VERSION:
         raise MmxError("libmmx_hip.so ABI version mismatch")

@@ -120,39 +120,43 @@ peaks_kernel(const float* __restrict__ log, int ns, int64_t sigma_stride,
         const int lane = threadIdx.x & 63;
         const bool has_left = x0 > 0 && lane > 0;            // lane - 1 holds x0-4 .. x0-1 of this row
         const bool has_right = x0 + 4 < bd.nx && lane < 63 && q + 1 < nquads;  // lane + 1: x0+4 .. x0+7
+        const bool ok1 = x0 + 1 < bd.nx, ok2 = x0 + 2 < bd.nx, ok3 = x0 + 3 < bd.nx;
         for (int s0 = 0; s0 < ns; s0 += kSigmaChunk) {
-            // v[k + 1] = sigma s0 + k; v[0] and v[kSigmaChunk + 1] are the neighbouring scales
-            float4 v[kSigmaChunk + 2];
-            const float4 ninf = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            // e?[k + 1] = element ? of sigma s0 + k; index 0 and kSigmaChunk + 1 are the neighbouring
+            // scales (-inf outside the ladder: zero padding can never out-vote a value > thr >= 0).
+            // Plain scalar arrays with compile-time indices only: they must stay in registers.
+            float e0[kSigmaChunk + 2], e1[kSigmaChunk + 2], e2[kSigmaChunk + 2], e3[kSigmaChunk + 2];
 #pragma unroll
-            for (int k = -1; k <= kSigmaChunk; ++k) {
-                const int s = s0 + k;
-                v[k + 1] = (s >= 0 && s < ns) ? p[(int64_t)s * sstride4] : ninf;
+            for (int k = 0; k < kSigmaChunk + 2; ++k) {
+                const int s = s0 + k - 1;
+                float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                if (s >= 0 && s < ns) v = p[(int64_t)s * sstride4];
                 // pitch columns hold no data: they must never out-vote a real neighbour
-                if (x0 + 1 >= bd.nx) v[k + 1].y = -INFINITY;
-                if (x0 + 2 >= bd.nx) v[k + 1].z = -INFINITY;
-                if (x0 + 3 >= bd.nx) v[k + 1].w = -INFINITY;
+                e0[k] = v.x;
+                e1[k] = ok1 ? v.y : -INFINITY;
+                e2[k] = ok2 ? v.z : -INFINITY;
+                e3[k] = ok3 ? v.w : -INFINITY;
             }
             // In-register pre-filter: a 4-D local maximum must beat its two x neighbours and the
             // same voxel one scale up / down (all already in registers or one lane away).  Only
             // survivors pay for the remaining 76 neighbour reads.
             unsigned hits = 0;
 #pragma unroll
-            for (int k = 0; k < kSigmaChunk; ++k) {
-                if (s0 + k < ns) {
-                    const float4 a = v[k + 1], dn = v[k], up = v[k + 2];
-                    float lft = __shfl_up(a.w, 1);
-                    float rgt = __shfl_down(a.x, 1);
+            for (int k = 1; k <= kSigmaChunk; ++k) {
+                if (s0 + k - 1 < ns) {
+                    float lft = __shfl_up(e3[k], 1);
+                    float rgt = __shfl_down(e0[k], 1);
                     lft = has_left ? lft : -INFINITY;
                     rgt = has_right ? rgt : -INFINITY;
-                    const float n0 = fmaxf(fmaxf(lft, a.y), fmaxf(dn.x, up.x));
-                    const float n1 = fmaxf(fmaxf(a.x, a.z), fmaxf(dn.y, up.y));
-                    const float n2 = fmaxf(fmaxf(a.y, a.w), fmaxf(dn.z, up.z));
-                    const float n3 = fmaxf(fmaxf(a.z, rgt), fmaxf(dn.w, up.w));
-                    hits |= ((a.x > lo && !(n0 > a.x + eps)) ? 1u : 0u) << (4 * k);
-                    hits |= ((a.y > lo && !(n1 > a.y + eps)) ? 2u : 0u) << (4 * k);
-                    hits |= ((a.z > lo && !(n2 > a.z + eps)) ? 4u : 0u) << (4 * k);
-                    hits |= ((a.w > lo && !(n3 > a.w + eps)) ? 8u : 0u) << (4 * k);
+                    const float n0 = fmaxf(fmaxf(lft, e1[k]), fmaxf(e0[k - 1], e0[k + 1]));
+                    const float n1 = fmaxf(fmaxf(e0[k], e2[k]), fmaxf(e1[k - 1], e1[k + 1]));
+                    const float n2 = fmaxf(fmaxf(e1[k], e3[k]), fmaxf(e2[k - 1], e2[k + 1]));
+                    const float n3 = fmaxf(fmaxf(e2[k], rgt), fmaxf(e3[k - 1], e3[k + 1]));
+                    const unsigned sh = 4 * (k - 1);
+                    hits |= ((e0[k] > lo && !(n0 > e0[k] + eps)) ? 1u : 0u) << sh;
+                    hits |= ((e1[k] > lo && !(n1 > e1[k] + eps)) ? 2u : 0u) << sh;
+                    hits |= ((e2[k] > lo && !(n2 > e2[k] + eps)) ? 4u : 0u) << sh;
+                    hits |= ((e3[k] > lo && !(n3 > e3[k] + eps)) ? 8u : 0u) << sh;
                 }
             }
             while (hits) {              // rare: only inside blobs

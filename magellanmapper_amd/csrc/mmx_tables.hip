@@ -125,3 +125,40 @@ extern "C" int mmx_close_pairs(const int32_t* d_master, int n_master, const int3
                        tol[0], tol[1], tol[2], d_last, d_hit);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
+
+// ---- PMC calibration kernels (tools/pmc_calib.py): streams of a known byte count with the
+// access shapes the LoG kernels use, to turn rocprofv3 FETCH_SIZE / WRITE_SIZE into bytes.
+namespace {
+__global__ void __launch_bounds__(MMX_WG) calib_copy_b32(const float* __restrict__ in, float* __restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * MMX_WG)
+        out[i] = in[i] + 1.0f;
+}
+__global__ void __launch_bounds__(MMX_WG) calib_copy_b128(const float4* __restrict__ in, float4* __restrict__ out, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n4; i += (int64_t)gridDim.x * MMX_WG) {
+        float4 v = in[i];
+        v.x += 1.0f;
+        out[i] = v;
+    }
+}
+__global__ void __launch_bounds__(MMX_WG) calib_read_u16(const uint16_t* __restrict__ in, float* __restrict__ out, int64_t n)
+{
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * MMX_WG)
+        acc += (float)in[i];
+    if (acc == 12345.678f) out[0] = acc;   // keep the loads alive, (almost) never store
+}
+}  // namespace
+
+extern "C" int mmx_calib_stream(int kind, const void* d_in, void* d_out, int64_t n_elems, void* stream)
+{
+    if (!d_in || !d_out || n_elems < 1) return MMX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(256 * 8);
+    if (kind == 0) hipLaunchKernelGGL(calib_copy_b32, grid, dim3(MMX_WG), 0, s, (const float*)d_in, (float*)d_out, n_elems);
+    else if (kind == 1) hipLaunchKernelGGL(calib_copy_b128, grid, dim3(MMX_WG), 0, s, (const float4*)d_in, (float4*)d_out, n_elems / 4);
+    else if (kind == 2) hipLaunchKernelGGL(calib_read_u16, grid, dim3(MMX_WG), 0, s, (const uint16_t*)d_in, (float*)d_out, n_elems);
+    else return MMX_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from rocprofv3 PMC passes, calibrated on known-byte streams.
+
+usage: pmc_summary.py <dir with trace/ pmc_fetch/ pmc_write/ cal_fetch/ cal_write/>
+MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE are in KiB-like units of the
+TCC request counters; on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide (16 B/lane) streams,
+WRITE_SIZE is exact for 16 B/lane stores; other widths must be calibrated -- done here with
+tools/pmc_calib.py (4 B/lane copy, 16 B/lane copy, u16 read of a known element count).
+"""
+import csv, glob, os, re, sys, json
+from collections import defaultdict
+
+def load_counter(d, counter):
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                rows.append((r["Kernel_Name"], float(r["Counter_Value"])))
+    return rows
+
+def short(name):
+    m = re.search(r"(zpass|ypass|xpass|peaks|rescore|overlap_pairs|close_pairs|gen_[xyz]|calib_[a-z0-9_]+)_?kernel|(calib_[a-z0-9_]+)", name)
+    if not m:
+        return None
+    return (m.group(1) or m.group(2))
+
+def per_kernel(rows):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for name, v in rows:
+        k = short(name)
+        if k:
+            tot[k] += v
+            cnt[k] += 1
+    return tot, cnt
+
+root = sys.argv[1]
+n = 1 << 30
+known = {  # bytes per launch of the calibration streams
+    "calib_copy_b32": (4 * n, 4 * n), "calib_copy_b128": (4 * n, 4 * n), "calib_read_u16": (2 * n, 0)}
+cf, ccf = per_kernel(load_counter(os.path.join(root, "cal_fetch"), "FETCH_SIZE"))
+cw, ccw = per_kernel(load_counter(os.path.join(root, "cal_write"), "WRITE_SIZE"))
+print("calibration (counter units per launch -> bytes per unit):")
+cal = {}
+for k, (rb, wb) in known.items():
+    fu = cf[k] / max(1, ccf[k]); wu = cw[k] / max(1, ccw[k])
+    cal[k] = (rb / fu if fu else float("nan"), wb / wu if wu else float("nan"))
+    print(f"  {k:16s} FETCH_SIZE {fu:14.1f} -> {cal[k][0]:8.1f} B/unit   WRITE_SIZE {wu:14.1f} -> {cal[k][1]:8.1f} B/unit")
+# access shape -> calibration stream
+read_cal = {"zpass": cal["calib_read_u16"][0], "ypass": cal["calib_copy_b32"][0],
+            "xpass": cal["calib_copy_b128"][0], "peaks": cal["calib_copy_b128"][0]}
+write_cal = {"zpass": cal["calib_copy_b32"][1], "ypass": cal["calib_copy_b32"][1],
+             "xpass": cal["calib_copy_b128"][1], "peaks": cal["calib_copy_b128"][1]}
+f, fc = per_kernel(load_counter(os.path.join(root, "pmc_fetch"), "FETCH_SIZE"))
+w, wc = per_kernel(load_counter(os.path.join(root, "pmc_write"), "WRITE_SIZE"))
+res = {}
+print("per-kernel HBM traffic per launch (calibrated):")
+for k in ("zpass", "ypass", "xpass", "peaks"):
+    if not fc[k]:
+        continue
+    rd = f[k] / fc[k] * read_cal[k]
+    wr = w[k] / max(1, wc[k]) * write_cal[k]
+    res[k] = dict(launches=fc[k], read_GB=rd / 1e9, write_GB=wr / 1e9, total_GB=(rd + wr) / 1e9)
+    print(f"  {k:6s} launches {fc[k]:4d}  read {rd/1e9:8.3f} GB  write {wr/1e9:8.3f} GB  total {(rd+wr)/1e9:8.3f} GB")
+print(json.dumps(res))
