@@ -112,6 +112,10 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
                       const double* h_w0, const double* h_w2, int radius, double norm,
                       float* d_log, float* d_work, void* stream);
 
+/* Select the experimental fused Z+X kernel for the following mmx_log_batch_f32 calls (default 0;
+ * env MMX_FUSE=1 sets the initial value).  Results are identical either way. */
+int mmx_set_fused(int on);
+
 /* Same contract, always through the generic (any radius <= MMX_MAX_RADIUS_GENERIC, any block
  * extent) kernels.  mmx_log_batch_f32 picks per pass between the register-ring kernels and
  * these; this entry exists so that tests can cross-check the two paths. */
@@ -167,8 +171,9 @@ int mmx_close_pairs(const int32_t* d_master, int n_master, const int32_t* d_chec
  * before and after itself on its launch stream; mmx_timing_read() synchronises those
  * events, returns summed milliseconds and launch counts per kernel family (index =
  * MMX_K_*: 0 z pass, 1 y pass, 2 x pass, 3 generic passes, 4 peaks, 5 rescore,
- * 6 overlap pairs, 7 close pairs) and starts a new window. */
-#define MMX_K_COUNT 8
+ * 6 overlap pairs, 7 close pairs, 8 fused z+x pass, 9 y pass of the fused path) and starts a new
+ * window. */
+#define MMX_K_COUNT 10
 int mmx_timing_enable(int on);
 int mmx_timing_read(double* ms, int64_t* launches, int n);
 

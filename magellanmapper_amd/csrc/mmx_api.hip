@@ -2,6 +2,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "mmx_common.h"
@@ -18,6 +19,8 @@ int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, cons
 
 namespace {
 thread_local char g_hip_err[256] = "";
+
+std::atomic<bool> g_fused{getenv("MMX_FUSE") && getenv("MMX_FUSE")[0] == '1'};
 
 struct span { hipEvent_t a, b; int kind; };
 std::mutex g_tm;
@@ -95,6 +98,12 @@ int mmx_timing_read(double* ms, int64_t* launches, int n)
 }
 
 int mmx_abi_version(void) { return MMX_ABI_VERSION; }
+
+int mmx_set_fused(int on)
+{
+    g_fused.store(on != 0);
+    return MMX_OK;
+}
 
 const char* mmx_strerror(int status)
 {
@@ -192,6 +201,28 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         return t;
     };
     int rc;
+    // Fused path (experimental, off by default: mmx_set_fused / MMX_FUSE=1): Z and X in one kernel
+    // (Gz / Gzz never touch HBM), then Y.  Same results; on MI355X it is currently slower than the
+    // three separate passes (register-limited occupancy of the fused kernel).
+    int max_ny = 0, max_px = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        if (h_blocks[i].ny > max_ny) max_ny = h_blocks[i].ny;
+        if (h_blocks[i].px > max_px) max_px = h_blocks[i].px;
+    }
+    const bool fused = g_fused.load() && fast_r && lane_ok && fast_y && min_nz >= radius + 1 && min_nx >= radius &&
+                       max_px <= 512 && vol->stride_y < (1 << 30);
+    if (fused) {
+        mmx_taps_f32 tzz = taps(wz0, wz2), txx = taps(wy0, wy2), tyy = taps(wx0, wx2);
+        { mmx_timed_scope ts(MMX_K_ZX, s);
+          rc = mmx_launch_zx(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
+        if (rc == MMX_OK) {
+            mmx_timed_scope ts(MMX_K_Y2, s);
+            rc = mmx_launch_y2(d_blocks, n_blocks, max_ycols, slot_elems, tyy, radius, t0, t1, d_log, s);
+        }
+        if (rc == MMX_ERR_HIP) return hip_fail(hipGetLastError(), "fused passes");
+        if (rc == MMX_OK) return MMX_OK;
+        if (rc != MMX_ERR_UNSUPPORTED) return rc;   // unsupported geometry: separate passes below
+    }
     { mmx_timed_scope ts(fast_z ? MMX_K_ZPASS : MMX_K_GENERIC, s);
     if (fast_z) rc = mmx_launch_zpass(vol, d_blocks, n_blocks, max_zcols, slot_elems, taps(wz0, wz2), radius, t0, t1, s);
     else rc = mmx_launch_generic_pass(0, vol, d_blocks, n_blocks, max_vox, slot_elems, wz0, wz2, radius, nullptr, nullptr, t0, t1, s); }

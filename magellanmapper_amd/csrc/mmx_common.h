@@ -38,10 +38,17 @@ int mmx_launch_xpass(const mmx_block* d_blocks, int n_blocks, int max_rows, int 
                      int64_t slot_elems, const mmx_taps_f32& taps, int radius,
                      const float* d_a, const float* d_bc, float* d_log, hipStream_t stream);
 
+int mmx_launch_zx(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_ny, int max_px,
+                  int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
+                  float* d_p, float* d_q, hipStream_t stream);
+int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
+                  const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
+                  float* d_log, hipStream_t stream);
+
 // ---- optional per-kernel-family timing with HIP events on the launch stream (bench.py) ----
 enum mmx_kernel_kind {
     MMX_K_ZPASS = 0, MMX_K_YPASS, MMX_K_XPASS, MMX_K_GENERIC, MMX_K_PEAKS, MMX_K_RESCORE,
-    MMX_K_PAIRS, MMX_K_CLOSE, MMX_K_END
+    MMX_K_PAIRS, MMX_K_CLOSE, MMX_K_ZX, MMX_K_Y2, MMX_K_END
 };
 void mmx_time_begin(int kind, hipStream_t s);
 void mmx_time_end(int kind, hipStream_t s);

@@ -67,6 +67,30 @@ def test_log_cube_within_tolerance(gpu, case):
     assert np.max(np.abs(fast[sl] - g["cube_crop"])) < LOG_TOL
 
 
+@pytest.mark.parametrize("case", ["u16_5sigma", "u8_3sigma", "f32_2sigma", "u16_twoscale10"])
+def test_fused_zx_path_gives_the_same_cube(gpu, case):
+    """The experimental fused Z+X kernel (mmx_set_fused) must reproduce the three-pass result."""
+    from magellanmapper_amd import _native as nat
+    from magellanmapper_amd import blob_log as bl
+    g = load_golden("bloblog_%s.npz" % case)
+    _, st = _oracle_stages(g)
+    dvol = bl.DeviceVolume(g["volume"])
+    space = bl.ScaleSpace.make(float(g["min_sigma"]), float(g["max_sigma"]), int(g["num_sigma"]))
+    shape = g["volume"].shape
+    sep = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
+    nat.lib().mmx_set_fused(1)
+    try:
+        nat.timing_enable(True)
+        fused = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
+        kinds = nat.timing_read()
+    finally:
+        nat.lib().mmx_set_fused(0)
+        nat.timing_enable(False)
+    assert kinds["zxpass"][1] > 0 and kinds["zpass"][1] == 0      # the fused kernels really ran
+    assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL
+    assert np.max(np.abs(fused - sep)) < 2e-6 * max(1.0, float(np.abs(sep).max()))
+
+
 @pytest.mark.parametrize("case", BLOBLOG_CASES)
 def test_blob_log_identical_to_reference(gpu, case):
     """A4 + A5: ordered raw peaks with bit-exact float64 values, and the pruned blobs."""

@@ -62,7 +62,7 @@ for rep in range(a.reps + 1):
         t = nat.timing_read()
         res.setdefault(("peaks", ns), []).append(t["peaks"][0])
 torch.cuda.synchronize()
-alg = {"zpass": 10, "ypass": 16, "xpass": 12, "generic": 38 / 3}
+alg = {"zpass": 10, "ypass": 16, "xpass": 12, "generic": 38 / 3, "zxpass": 10, "y2pass": 12}
 print(f"blocks {nb} x {e}^3 = {nvox/1e6:.0f} Mvox; candidates {int(count.item())}")
 for (k, R), v in sorted(res.items()):
     ms = float(np.median(v))
