@@ -182,6 +182,23 @@ int mmx_event_destroy(void* ev);
 int mmx_event_record(void* ev, void* stream);
 int mmx_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
 
+/* ---- A12/A13 on the host (no device work): one axis of the cross-block duplicate pruning of
+ * magmap/cv/stack_detect.py:679-861 (StackPruner.prune_blobs_mp) with the match/average/delete
+ * rules of magmap/cv/detector.py:1000-1085 (remove_close_blobs).
+ *   zyx, tag : int32 [n_table][3] detection coordinates / block grid coordinates
+ *   abs_zyx  : float64 [n_table][3], updated in place (round-half-even means)
+ *   cur      : current row ids in table order; bounds: the 2*n_sections-1 region starts along `axis`
+ *              (pass 0, slab 0, pass 1, ...); last_end: end of the last block
+ *   nxt_lo/hi: per slab the "adjacent region" range for the pruning-ratio statistic (NaN = none)
+ *   out_cur  : surviving row ids in the reference's new order, *out_n of them
+ *   n_slab, n_after, n_next : per slab row counts (before, after, adjacent region)          */
+int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
+                        const int64_t* cur, int64_t n_cur, int axis, int n_sections,
+                        const double* bounds, double last_end, const int32_t tol[3],
+                        const double* nxt_lo, const double* nxt_hi,
+                        int64_t* out_cur, int64_t* out_n,
+                        int64_t* n_slab, int64_t* n_after, int64_t* n_next);
+
 /* PMC calibration (tools/pmc_calib.py): one streaming launch over n_elems elements with a known
  * byte count.  kind 0: float copy, 4 B per lane; 1: float copy, 16 B per lane; 2: uint16 read. */
 int mmx_calib_stream(int kind, const void* d_in, void* d_out, int64_t n_elems, void* stream);

@@ -52,7 +52,7 @@ SYMBOLS = (
     "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_set_fused", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
-    "mmx_calib_stream",
+    "mmx_calib_stream", "mmx_host_prune_axis",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass")
@@ -94,10 +94,12 @@ def lib() -> ctypes.CDLL:
     L.mmx_timing_enable.argtypes = [c_int]
     L.mmx_timing_read.argtypes = [POINTER(c_double), POINTER(c_int64), c_int]
     L.mmx_calib_stream.argtypes = [c_int, vp, vp, c_int64, vp]
+    L.mmx_host_prune_axis.argtypes = [vp, vp, vp, vp, c_int64, c_int, c_int, vp, c_double,
+                                      POINTER(c_int32), vp, vp, vp, POINTER(c_int64), vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is None or name.startswith(("mmx_log", "mmx_peaks", "mmx_rescore",
-                                                  "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing", "mmx_calib")):
+                                                  "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing", "mmx_calib", "mmx_host")):
             fn.restype = c_int
     if L.mmx_abi_version() != MMX_ABI_VERSION:
         raise MmxError("libmmx_hip.so ABI version mismatch")

@@ -58,22 +58,9 @@ def stack_splitter(shape: Sequence[int], max_pixels: Sequence[int],
 def merge_blobs(blob_rois: np.ndarray) -> Optional[np.ndarray]:
     """All block tables stacked, with the block's grid coordinate as 3 extra int columns."""
     arena = getattr(blob_rois, "arena", None)
-    if arena is not None:
-        # tables were stored back to back (grid order) with their tags while the GPU was busy:
-        # the merged table already exists, provided the caller did not replace any block table
-        at = 0
-        intact = True
-        for coord in np.ndindex(*blob_rois.shape):
-            tbl = blob_rois[coord]
-            if tbl is None or isinstance(tbl, (int, np.integer)) or len(tbl) == 0:
-                continue
-            span = arena.spans.get(coord)
-            if span is None or span[0] != at or not np.shares_memory(tbl, arena.store):
-                intact = False
-                break
-            at = span[1]
-        if intact and at == arena.n:
-            return arena.store[:arena.n] if at else None
+    if arena is not None and arena.intact(blob_rois):
+        # the tables were stored back to back (grid order) with their tags while the GPU was busy
+        return arena.store[:arena.n] if arena.n else None
     live = [(coord, blob_rois[coord]) for coord in np.ndindex(*blob_rois.shape)
             if blob_rois[coord] is not None and not isinstance(blob_rois[coord], (int, np.integer))]
     if not live:

@@ -1,0 +1,119 @@
+// Host-side table code of libmmx_hip.so (plain C++, no device work).
+//
+// mmx_host_prune_axis -- one axis of the cross-block duplicate pruning that the reference does
+// with NumPy on the host (magmap/cv/stack_detect.py:679-861, StackPruner.prune_blobs_mp, with
+// detector.remove_close_blobs :1000-1085 inside).  north_star keeps this de-duplication on the
+// host; it is native here because at 3e5 blobs the NumPy formulation (a dozen full-table passes
+// per axis) was the longest serial piece after the last kernel.
+//
+// Semantics per axis (see the Python docstring of prune_blobs_mp for the derivation):
+//   the axis is tiled by regions  [pass 0][slab 0][pass 1][slab 1] ... [pass last];
+//   in slab j rows tagged block j are masters, rows tagged j+1 are checked against them
+//   (|d| <= tol on all three axes, integer compare), other generations are dropped;
+//   every matched check row is removed; a matched master's abs coordinates become
+//   rint((abs_master + abs_check) / 2) (round half to even) for its LAST matching check row
+//   in table order (NumPy duplicate fancy-index assignment: last write wins);
+//   new row order = pass sections in turn, then per slab its masters followed by the surviving
+//   check rows, each group in the current table order.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mmx.h"
+
+extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
+                                   const int64_t* cur, int64_t n_cur, int axis, int n_sections,
+                                   const double* bounds, double last_end, const int32_t tol[3],
+                                   const double* nxt_lo, const double* nxt_hi,
+                                   int64_t* out_cur, int64_t* out_n,
+                                   int64_t* n_slab, int64_t* n_after, int64_t* n_next)
+{
+    if (!zyx || !tag || !abs_zyx || (!cur && n_cur) || !bounds || !tol || !out_cur || !out_n ||
+        !n_slab || !n_after || !n_next || axis < 0 || axis > 2 || n_sections < 2 || n_cur < 0)
+        return MMX_ERR_ARG;
+    const int n_regions = 2 * n_sections - 1;
+    const int n_slabs = n_sections - 1;
+    // group ids: pass j -> j ; slab j master -> n_sections + 2j ; slab j kept check -> n_sections + 2j + 1
+    const int n_groups = n_sections + 2 * n_slabs;
+    std::vector<int32_t> group((size_t)n_cur, -1);
+    std::vector<std::vector<int64_t>> masters((size_t)n_slabs), checks((size_t)n_slabs);
+    for (int j = 0; j < n_slabs; ++j) { n_slab[j] = 0; n_after[j] = 0; n_next[j] = 0; }
+
+    for (int64_t i = 0; i < n_cur; ++i) {
+        const int64_t row = cur[i];
+        const double pos = (double)zyx[3 * row + axis];
+        for (int j = 0; j < n_slabs; ++j)
+            if (nxt_lo[j] == nxt_lo[j] && pos >= nxt_lo[j] && pos < nxt_hi[j]) ++n_next[j];
+        // region = (number of bounds <= pos) - 1   (np.searchsorted(bounds, pos, side="right") - 1)
+        const int region = (int)(std::upper_bound(bounds, bounds + n_regions, pos) - bounds) - 1;
+        if (region < 0 || !(pos < last_end)) continue;
+        const int sec = region >> 1;
+        if ((region & 1) == 0) { group[(size_t)i] = sec; continue; }
+        ++n_slab[sec];
+        const int32_t t = tag[3 * row + axis];
+        if (t == sec) { group[(size_t)i] = n_sections + 2 * sec; masters[(size_t)sec].push_back(i); }
+        else if (t == sec + 1) { group[(size_t)i] = n_sections + 2 * sec + 1; checks[(size_t)sec].push_back(i); }
+    }
+
+    // the axis to sort the check rows on: the longer of the two other axes is fine, any works
+    const int sa = axis == 0 ? 1 : 0;
+    std::vector<std::pair<int32_t, int64_t>> order;      // (coordinate on sa, position in checks[j])
+    std::vector<double> new_abs;
+    for (int j = 0; j < n_slabs; ++j) {
+        const auto& M = masters[(size_t)j];
+        const auto& C = checks[(size_t)j];
+        int64_t kept = (int64_t)C.size();
+        if (!M.empty() && !C.empty()) {
+            order.clear();
+            order.reserve(C.size());
+            for (size_t k = 0; k < C.size(); ++k) order.emplace_back(zyx[3 * cur[C[k]] + sa], (int64_t)k);
+            std::sort(order.begin(), order.end());
+            std::vector<char> hit(C.size(), 0);
+            new_abs.assign(M.size() * 3, 0.0);
+            std::vector<int64_t> last(M.size(), -1);
+            for (size_t m = 0; m < M.size(); ++m) {
+                const int32_t* mz = zyx + 3 * cur[M[m]];
+                const int32_t lo = mz[sa] - tol[sa], hi = mz[sa] + tol[sa];
+                auto it = std::lower_bound(order.begin(), order.end(), std::make_pair(lo, (int64_t)-1));
+                for (; it != order.end() && it->first <= hi; ++it) {
+                    const int32_t* cz = zyx + 3 * cur[C[(size_t)it->second]];
+                    if (std::abs(mz[0] - cz[0]) <= tol[0] && std::abs(mz[1] - cz[1]) <= tol[1] &&
+                        std::abs(mz[2] - cz[2]) <= tol[2]) {
+                        hit[(size_t)it->second] = 1;
+                        if (it->second > last[m]) last[m] = it->second;
+                    }
+                }
+            }
+            // averages from the values before any update of this stage
+            for (size_t m = 0; m < M.size(); ++m) {
+                if (last[m] < 0) continue;
+                const double* am = abs_zyx + 3 * cur[M[m]];
+                const double* ac = abs_zyx + 3 * cur[C[(size_t)last[m]]];
+                for (int a = 0; a < 3; ++a) new_abs[3 * m + a] = std::nearbyint((am[a] + ac[a]) / 2);
+            }
+            for (size_t m = 0; m < M.size(); ++m) {
+                if (last[m] < 0) continue;
+                double* am = abs_zyx + 3 * cur[M[m]];
+                for (int a = 0; a < 3; ++a) am[a] = new_abs[3 * m + a];
+            }
+            for (size_t k = 0; k < C.size(); ++k)
+                if (hit[k]) { group[(size_t)C[k]] = -1; --kept; }
+        }
+        n_after[j] = (int64_t)M.size() + kept;
+    }
+
+    // stable counting sort of the surviving rows by group
+    std::vector<int64_t> start((size_t)n_groups + 1, 0);
+    for (int64_t i = 0; i < n_cur; ++i)
+        if (group[(size_t)i] >= 0) ++start[(size_t)group[(size_t)i] + 1];
+    for (int g = 0; g < n_groups; ++g) start[(size_t)g + 1] += start[(size_t)g];
+    *out_n = start[(size_t)n_groups];
+    for (int64_t i = 0; i < n_cur; ++i) {
+        const int g = group[(size_t)i];
+        if (g >= 0) out_cur[start[(size_t)g]++] = cur[i];
+    }
+    return MMX_OK;
+}

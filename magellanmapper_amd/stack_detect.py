@@ -16,6 +16,7 @@ abs replacement, dropped columns) are the reference's.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from enum import Enum
 from time import time
@@ -23,6 +24,7 @@ from typing import NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import _native as nat
 from . import chunking, config, detector, roi_prof
 
 _logger = config.logger.getChild(__name__)
@@ -51,35 +53,57 @@ class Image5d:
 
 
 class _TableArena:
-    """Per-block tables stored back to back in one ``(n, 14)`` array whose last three columns
-    already hold the block's grid coordinate: what ``chunking.merge_blobs`` would build, filled
-    while the GPU is still busy.  The per-block tables handed out are views of it."""
+    """Per-block tables stored back to back, in block order, while the GPU is still busy:
+    the merged table ``chunking.merge_blobs`` would build (``store``: 11 columns + 3 block-tag
+    columns) plus the compact columns the pruning step works on.  The per-block tables handed
+    out are views of ``store``."""
 
     def __init__(self, n_cols: int = 11):
         self.n_cols = n_cols
-        self.store = np.empty((4096, n_cols + 3))
+        self.cap = 4096
+        self.store = np.empty((self.cap, n_cols + 3))
+        self.zyx = np.empty((self.cap, 3), dtype=np.int32)
+        self.tag = np.empty((self.cap, 3), dtype=np.int32)
         self.n = 0
         self.spans = {}
 
-    def add(self, coord, table: np.ndarray) -> np.ndarray:
+    def _grow(self, need: int):
+        cap = max(2 * self.cap, need)
+        for name in ("store", "zyx", "tag"):
+            old = getattr(self, name)
+            new = np.empty((cap,) + old.shape[1:], dtype=old.dtype)
+            new[:self.n] = old[:self.n]
+            setattr(self, name, new)
+        self.cap = cap
+
+    def add(self, coord, table: np.ndarray) -> None:
         rows = table.shape[0]
-        if self.n + rows > self.store.shape[0]:
-            grown = np.empty((max(2 * self.store.shape[0], self.n + rows), self.store.shape[1]))
-            grown[:self.n] = self.store[:self.n]
-            old = self.store
-            self.store = grown
-            # re-point the views handed out so far
-            self.stale = old
+        if self.n + rows > self.cap:
+            self._grow(self.n + rows)
         a = self.n
         self.store[a:a + rows, :self.n_cols] = table
         self.store[a:a + rows, self.n_cols:] = coord
+        self.zyx[a:a + rows] = table[:, :3]
+        self.tag[a:a + rows] = coord
         self.n += rows
         self.spans[tuple(coord)] = (a, a + rows)
-        return self.store[a:a + rows, :self.n_cols]
 
     def view(self, coord):
         a, b = self.spans[tuple(coord)]
         return self.store[a:b, :self.n_cols]
+
+    def intact(self, blob_rois) -> bool:
+        """True when ``blob_rois`` still holds exactly the arena's tables, in grid order."""
+        at = 0
+        for coord in np.ndindex(*blob_rois.shape):
+            tbl = blob_rois[coord]
+            if tbl is None or isinstance(tbl, (int, np.integer)) or len(tbl) == 0:
+                continue
+            span = self.spans.get(coord)
+            if span is None or span[0] != at or not np.shares_memory(tbl, self.store):
+                return False
+            at = span[1]
+        return at == self.n
 
 
 class _SegRois(np.ndarray):
@@ -424,10 +448,15 @@ class StackPruner:
         Returns ``(table, DataFrame)`` or ``(None, None)``.
 
         Same results and row order as the reference, but rows are tracked as indices into the
-        merged table (only the 3 abs columns ever change), so the big table is gathered once.
+        merged table (only the 3 abs columns ever change), so the big table is gathered once, and
+        the per-axis classify / match / reorder step is native host code
+        (``mmx_host_prune_axis``; the de-duplication stays on the host as in the reference).
         """
         import pandas as pd
-        merged = chunking.merge_blobs(seg_rois)
+        arena = getattr(seg_rois, "arena", None)
+        if arena is not None and not arena.intact(seg_rois):
+            arena = None
+        merged = arena.store[:arena.n] if arena is not None and arena.n else chunking.merge_blobs(seg_rois)
         if merged is None:
             return None, None
         if overlap_padding is None:
@@ -441,13 +470,18 @@ class StackPruner:
         detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
         abs_inds = detector.Blobs._get_abs_inds()
         chan = detector.Blobs.get_blobs_channel(merged)
-        zyx = merged[:, :3].astype(np.int64)                 # detection coordinates never change
-        tags = merged[:, ncol - 3:].astype(np.int64)
-        abs_cur = merged[:, abs_inds].copy()                 # the only values pruning changes
-        big = int(zyx.max(initial=0)) + int(np.max(tol)) + 2     # keeps sections apart in one search
+        # compact columns for the native per-axis step (libmmx_hip.so: mmx_host_prune_axis)
+        if arena is not None:                 # filled while the GPU was busy
+            zyx, tags = arena.zyx[:arena.n], arena.tag[:arena.n]
+        else:
+            zyx = np.ascontiguousarray(merged[:, :3], dtype=np.int32)  # detection coordinates never change
+            tags = np.ascontiguousarray(merged[:, ncol - 3:], dtype=np.int32)
+        abs_cur = np.ascontiguousarray(merged[:, abs_inds], dtype=np.float64)  # the only values pruning changes
+        tol3 = (ctypes.c_int32 * 3)(*[int(v) for v in np.broadcast_to(np.asarray(tol), (3,))])
+        lib = nat.lib()
         pieces = []
         for chl in channels:
-            cur = np.nonzero(np.isin(chan, chl))[0]          # row ids, in table order
+            cur = np.ascontiguousarray(np.nonzero(np.isin(chan, chl))[0], dtype=np.int64)  # row ids, table order
             for axis in range(3):
                 n_sections = sub_rois_offsets.shape[axis]
                 if n_sections <= 1:
@@ -455,8 +489,8 @@ class StackPruner:
                 # The axis is tiled by [pass 0][slab 0][pass 1][slab 1] ... [pass last]; slab j
                 # = [end_j - (overlap + pad), end_j + pad) belongs to the boundary j | j + 1.
                 shift = overlap[axis] + overlap_padding[axis]
-                bounds = []
-                ends = []
+                bounds, nxt_lo, nxt_hi = [], [], []
+                last_end = 0
                 for j in range(n_sections):
                     coord = [0, 0, 0]
                     coord[axis] = j
@@ -465,66 +499,37 @@ class StackPruner:
                     slc = sub_roi_slices[coord]
                     extent = len(range(*slc[axis].indices(shape3[axis])))
                     end = start + extent
-                    ends.append((end, extent))
+                    last_end = end
                     bounds.append(start + (shift if j > 0 else 0))          # pass j begins
                     if j < n_sections - 1:
                         bounds.append(end - shift)                          # slab j begins
+                        # "adjacent region" of the pruning-ratio statistic (reference :772-785)
+                        lo = end + tol[axis]
+                        hi = lo + overlap[axis] + 2 * overlap_padding[axis]
+                        roi_end = sub_rois_offsets[coord_last][axis] + extent
+                        ok = lo < roi_end and hi < roi_end
+                        nxt_lo.append(lo if ok else np.nan)
+                        nxt_hi.append(hi if ok else np.nan)
                 bounds = np.asarray(bounds, dtype=np.float64)
-                pos = merged[cur, axis]
-                tag = tags[cur, axis]
-                region = np.searchsorted(bounds, pos, side="right") - 1     # 2j = pass j, 2j+1 = slab j
-                last_end = ends[-1][0]
-                inside = (region >= 0) & (pos < last_end)
-                sec = region >> 1
-                in_slab = inside & ((region & 1) == 1)
-                is_master = in_slab & (tag == sec)
-                is_check = in_slab & (tag == sec + 1)
-                # one device search for all slabs of this axis: shifting section j by j * big
-                # along the axis keeps rows of different slabs from ever matching
-                m_ids, c_ids = cur[is_master], cur[is_check]
-                hit = np.zeros(len(c_ids), dtype=bool)
-                if len(m_ids) and len(c_ids):
-                    m_xyz, c_xyz = zyx[m_ids].copy(), zyx[c_ids].copy()
-                    m_xyz[:, axis] += sec[is_master] * big
-                    c_xyz[:, axis] += sec[is_check] * big
-                    last, hit = detector.find_close_pairs(c_xyz, m_xyz, np.asarray(tol))
-                    matched = np.nonzero(last >= 0)[0]
-                    if len(matched):
-                        # abs <- round-half-even mean with the LAST matching check row
-                        # (detector.remove_close_blobs; NumPy's duplicate-index assignment)
-                        mid = np.around(np.divide(np.add(
-                            abs_cur[m_ids[matched]], abs_cur[c_ids[last[matched]]]), 2))
-                        abs_cur[m_ids[matched]] = mid
-                # pruning-ratio statistics per slab (reference :673-676, :836-838)
-                n_slab = np.bincount(sec[in_slab], minlength=n_sections)
-                n_master = np.bincount(sec[is_master], minlength=n_sections)
-                n_kept = np.bincount(sec[is_check][~hit], minlength=n_sections)
+                nxt_lo = np.asarray(nxt_lo, dtype=np.float64)
+                nxt_hi = np.asarray(nxt_hi, dtype=np.float64)
+                out_cur = np.empty(len(cur), dtype=np.int64)
+                out_n = ctypes.c_int64(0)
+                n_slab = np.zeros(n_sections - 1, dtype=np.int64)
+                n_after = np.zeros_like(n_slab)
+                n_next = np.zeros_like(n_slab)
+                nat.check(lib.mmx_host_prune_axis(
+                    zyx.ctypes.data, tags.ctypes.data, abs_cur.ctypes.data, cur.ctypes.data, len(cur),
+                    axis, n_sections, bounds.ctypes.data, float(last_end), tol3, nxt_lo.ctypes.data,
+                    nxt_hi.ctypes.data, out_cur.ctypes.data, ctypes.byref(out_n), n_slab.ctypes.data,
+                    n_after.ctypes.data, n_next.ctypes.data), "mmx_host_prune_axis")
+                cur = out_cur[:out_n.value]
                 for j in range(n_sections - 1):
-                    end, extent = ends[j]
-                    nxt_lo = end + tol[axis]
-                    nxt_hi = nxt_lo + overlap[axis] + 2 * overlap_padding[axis]
-                    roi_end = sub_rois_offsets[coord_last][axis] + extent
-                    if nxt_lo < roi_end and nxt_hi < roi_end:
-                        n_next = int(np.count_nonzero((pos >= nxt_lo) & (pos < nxt_hi)))
-                        ratios = detector.meas_pruning_ratio(
-                            int(n_slab[j]), int(n_master[j] + n_kept[j]), n_next)
+                    if not np.isnan(nxt_lo[j]):
+                        ratios = detector.meas_pruning_ratio(int(n_slab[j]), int(n_after[j]), int(n_next[j]))
                         if ratios:
                             for col, val in zip(ratio_cols, ratios):
                                 ratios_all.setdefault(col, []).append(val)
-                # new row order: every pass section in turn, then per slab its masters followed
-                # by its surviving check rows; a stable sort on that key keeps table order inside
-                # each group.  Slab rows of any other block generation are dropped (reference
-                # prune_overlap keeps only generations j and j + 1).
-                key = np.full(len(cur), 255, dtype=np.int64)
-                is_pass = inside & ((region & 1) == 0)
-                key[is_pass] = sec[is_pass]
-                key[is_master] = n_sections + 2 * sec[is_master]
-                kept_check = is_check.copy()
-                kept_check[np.nonzero(is_check)[0][hit]] = False
-                key[kept_check] = n_sections + 2 * sec[kept_check] + 1
-                keep = key < 255
-                order = np.argsort(key[keep].astype(np.uint16), kind="stable")
-                cur = cur[keep][order]
             pieces.append(cur)
         rows = np.concatenate(pieces)
         out = np.take(merged, rows, axis=0)[:, :-3]          # (np.take: 10x fancy indexing)
