@@ -83,8 +83,8 @@ def canon(t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="z y x (default: the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--budget-gb", type=float, default=64.0, help="workspace budget per batch")
@@ -120,11 +120,17 @@ def main():
                          f"density, profile, segment_size as the GPU run), {n_jobs} blocks over a pool of "
                          f"{min(cores, n_jobs)} processes; detection {t_det:.1f}s of {t_tot:.1f}s total",
                "blobs": 0 if cpu_final is None else int(len(cpu_final))}
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; MMX_DIST_BACKEND=gloo + fewer GPUs than ranks is only for functional tests
+    backend = os.environ.get("MMX_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+    local_dev = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        tdist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            tdist.init_process_group("nccl", device_id=dev)
+        else:
+            tdist.init_process_group(backend)
 
     from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
@@ -217,7 +223,7 @@ def main():
     ktimes = nat.timing_read()
     nat.timing_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
 

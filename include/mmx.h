@@ -151,10 +151,11 @@ int mmx_rescore_f64(const mmx_volume* vol, const mmx_block* d_blocks, int n_bloc
 /* ---- A5 support: all blob pairs of one block whose sphere-overlap fraction exceeds
  * `overlap` (skimage/feature/blob.py:84-187: _blob_overlap / _prune_blobs)
  *   d_blobs : [n][4] float64 (z, y, x, sigma), blocks delimited by d_offsets[n_blocks+1]
+ *   max_sigma: largest sigma in the table (pairs farther apart than 2*sqrt(3)*max_sigma are skipped)
  *   d_pairs : out [cap][2] int32 global row indices (i < j), *d_count total found
  *   d_frac  : out [cap] float64 overlap fraction                                   */
 int mmx_overlap_pairs(const double* d_blobs, const int32_t* d_offsets, int n_blocks,
-                      double overlap, double band, int32_t* d_pairs, double* d_frac,
+                      double overlap, double band, double max_sigma, int32_t* d_pairs, double* d_frac,
                       uint32_t cap, uint32_t* d_count, void* stream);
 
 /* ---- A13 support: for every master row the LAST check row within `tol` on all

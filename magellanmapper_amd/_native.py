@@ -85,7 +85,7 @@ def lib() -> ctypes.CDLL:
                                   c_uint32, vp, vp]
     L.mmx_rescore_f64.argtypes = [POINTER(Volume), vp, c_int, vp, c_uint32, vp, vp, vp,
                                   POINTER(c_int32), POINTER(c_double), c_int, c_int, vp]
-    L.mmx_overlap_pairs.argtypes = [vp, vp, c_int, c_double, c_double, vp, vp, c_uint32, vp, vp]
+    L.mmx_overlap_pairs.argtypes = [vp, vp, c_int, c_double, c_double, c_double, vp, vp, c_uint32, vp, vp]
     L.mmx_close_pairs.argtypes = [vp, c_int, vp, c_int, POINTER(c_int32), vp, vp, vp]
     L.mmx_event_create.argtypes = [POINTER(vp)]
     L.mmx_event_destroy.argtypes = [vp]

@@ -500,6 +500,12 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
         if a == b:
             out.append((np.zeros((0, 4), dtype=np.int64), np.zeros(0)))
             continue
+        cube_size = int(shapes[i][0]) * int(shapes[i][1]) * int(shapes[i][2]) * ns
+        if b - a == cube_size and cube_size > 1:
+            # every voxel equals its 3^4 maximum (a constant cube): "no peak for a trivial image"
+            # (skimage peak.py:41-43)
+            out.append((np.zeros((0, 4), dtype=np.int64), np.zeros(0)))
+            continue
         vals = vals_all[a:b].copy()
         rank = np.argsort(-vals)          # the reference's call on the reference's array (peak.py:17)
         out.append((coords_all[a:b][rank], vals[rank]))
@@ -568,7 +574,8 @@ def _prune_batch(peaks, space: ScaleSpace, overlap: float, dev, stats: BatchStat
         d_frac = torch.empty(cap, dtype=torch.float64, device=dev)
         d_count = torch.zeros(1, dtype=torch.int32, device=dev)
         nat.check(L.mmx_overlap_pairs(d_blobs.data_ptr(), d_off.data_ptr(), len(peaks), overlap,
-                                      OVERLAP_BAND, d_pairs.data_ptr(), d_frac.data_ptr(), cap,
+                                      OVERLAP_BAND, float(space.sigmas.max()), d_pairs.data_ptr(),
+                                      d_frac.data_ptr(), cap,
                                       d_count.data_ptr(), _stream_ptr()), "mmx_overlap_pairs")
         n = int(d_count.item()) & 0xFFFFFFFF
         if n <= cap:

@@ -19,7 +19,7 @@ namespace {
 
 __global__ void __launch_bounds__(MMX_WG)
 overlap_pairs_kernel(const double* __restrict__ blobs, const int32_t* __restrict__ offsets,
-                     double overlap, double band, int32_t* __restrict__ pairs,
+                     double overlap, double band, double max_sigma, int32_t* __restrict__ pairs,
                      double* __restrict__ frac, uint32_t cap, uint32_t* __restrict__ count)
 {
     const int b0 = offsets[blockIdx.y], b1 = offsets[blockIdx.y + 1];
@@ -29,8 +29,14 @@ overlap_pairs_kernel(const double* __restrict__ blobs, const int32_t* __restrict
     for (int i = blockIdx.x * MMX_WG + threadIdx.x; i < n; i += gridDim.x * MMX_WG) {
         const double* bi = blobs + (int64_t)(b0 + i) * 4;
         const double zi = bi[0], yi = bi[1], xi = bi[2], si = bi[3];
+        // cheap cut first: no overlap beyond sqrt(3) (s_i + s_j) <= 2 sqrt(3) s_max on any one axis
+        const float cut = (float)(2.0 * root3 * max_sigma) + 1.0f;
+        const float fz = (float)zi, fy = (float)yi, fx = (float)xi;
         for (int j = i + 1; j < n; ++j) {
             const double* bj = blobs + (int64_t)(b0 + j) * 4;
+            if (fabsf((float)bj[0] - fz) > cut || fabsf((float)bj[1] - fy) > cut ||
+                fabsf((float)bj[2] - fx) > cut)
+                continue;
             const double sj = bj[3];
             if (si == 0.0 && sj == 0.0) continue;
             double r1, r2, ms;
@@ -98,14 +104,14 @@ close_pairs_kernel(const int32_t* __restrict__ master, int n_master,
 }  // namespace
 
 extern "C" int mmx_overlap_pairs(const double* d_blobs, const int32_t* d_offsets, int n_blocks,
-                                 double overlap, double band, int32_t* d_pairs, double* d_frac,
+                                 double overlap, double band, double max_sigma, int32_t* d_pairs, double* d_frac,
                                  uint32_t cap, uint32_t* d_count, void* stream)
 {
-    if (!d_blobs || !d_offsets || !d_pairs || !d_frac || !d_count || n_blocks < 1) return MMX_ERR_ARG;
+    if (!d_blobs || !d_offsets || !d_pairs || !d_frac || !d_count || n_blocks < 1 || !(max_sigma > 0)) return MMX_ERR_ARG;
     dim3 grid(8, n_blocks);
     mmx_timed_scope ts(MMX_K_PAIRS, (hipStream_t)stream);
     hipLaunchKernelGGL(overlap_pairs_kernel, grid, dim3(MMX_WG), 0, (hipStream_t)stream, d_blobs, d_offsets,
-                       overlap, band, d_pairs, d_frac, cap, d_count);
+                       overlap, band, max_sigma, d_pairs, d_frac, cap, d_count);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 

@@ -321,3 +321,103 @@ def test_subimage_offset_and_archive(gpu, tmp_path, monkeypatch):
     np.testing.assert_array_equal(loaded.blobs, all_blobs.blobs)
     assert list(loaded.cols) == ["z", "y", "x", "radius", "confirmed", "truth", "channel", "region"]
     assert int(loaded.ver) == 5
+
+
+def _oracle_final(vol, prof_over):
+    from magellanmapper_amd import config
+    from oracle import magmap_oracle as mmo
+    prof = dict(config.roi_profile)
+    return mmo.detect_blobs_blocks(vol, None, [prof], config.resolutions)[0]
+
+
+def test_many_blocks_several_batches_identical_to_oracle(gpu, tmp_path, monkeypatch):
+    """32 blocks through the pipelined batches (forced small workspace -> several batches, tapered
+    tail, side-stream follow-ups) and the native host prune; final table identical to the oracle."""
+    import functools
+    from magellanmapper_amd import blob_log as bl
+    from magellanmapper_amd import config, stack_detect, synth
+    monkeypatch.chdir(tmp_path)
+    vol = synth.make_volume(61, (96, 160, 168), 330)
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(denoise_size=None, num_sigma=4, segment_size=44)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "many"
+    monkeypatch.setattr(bl, "blob_log_blocks", functools.partial(bl.blob_log_blocks, budget_bytes=96 << 20))
+    img5d = stack_detect.Image5d(vol[None])
+    _, _, blobs = stack_detect.detect_blobs_blocks("many", img5d, None, None, None, False, False, True, False)
+    st = stack_detect.StackDetector.last_stats
+    assert st.n_blocks == 3 * 4 * 4
+    want = _oracle_final(vol, None)
+    assert len(want) > 200
+    np.testing.assert_array_equal(lexsorted(blobs.blobs), lexsorted(want))
+
+
+def test_candidate_table_overflow_is_retried(gpu, monkeypatch):
+    """A candidate table that is too small must be detected and the batch redone."""
+    from magellanmapper_amd import blob_log as bl
+    from oracle import blob_log_oracle as blo
+    g = load_golden("stack_u16_2x3x3.npz")
+    vol = g["roi"]
+    want = blo.blob_log(vol, 3, 5, 3, 0.1, 0.5)
+    real = bl._enqueue_detect
+    calls = []
+
+    def tiny_first(*args, **kwargs):
+        if not calls:                       # first attempt: room for 8 candidates only
+            kwargs["cap"] = 8
+        calls.append(kwargs.get("cap"))
+        return real(*args, **kwargs)
+
+    monkeypatch.setattr(bl, "_enqueue_detect", tiny_first)
+    got = bl.blob_log(vol, 3, 5, 3, 0.1, 0.5)
+    assert len(calls) == 2 and calls[0] == 8 and calls[1] > 8
+    np.testing.assert_array_equal(got, want)
+
+
+def test_constant_image_plateaus(gpu):
+    """Constant images: with one sigma every voxel equals its 3^4 maximum and scikit-image reports
+    no peaks at all (peak.py:41-43); with two sigmas the brighter scale is one big plateau of
+    peaks (all exact float64 ties) that the overlap prune then thins out -- both must match."""
+    from magellanmapper_amd import blob_log as bl
+    from oracle import blob_log_oracle as blo
+    vol = np.full((20, 24, 40), 0.5, dtype=np.float64)
+    want = blo.blob_log(vol, 2, 2, 1, -1.0, 0.5)
+    got = bl.blob_log(vol, 2, 2, 1, -1.0, 0.5)
+    assert want.shape == (0, 3) and got.shape == (0, 3)
+    small = np.full((9, 10, 12), 0.5, dtype=np.float64)
+    want, st = blo.blob_log(small, 2, 3, 2, -1.0, 0.5, return_stages=True)
+    stats = bl.BatchStats()
+    got, peaks = bl.blob_log_blocks(bl.DeviceVolume(small), 0, [(0, 0, 0)], [small.shape], 2, 3, 2, -1.0,
+                                    0.5, stats=stats, return_peaks=True)
+    assert len(st["peaks"]) == small.size and stats.n_contested == small.size
+    np.testing.assert_array_equal(lexsorted(peaks[0][0]), lexsorted(st["peaks"]))
+    np.testing.assert_array_equal(lexsorted(got[0]), lexsorted(want))
+
+
+def test_two_ranks_share_one_volume(gpu, tmp_path):
+    """bench.py's N > 1 path (block sharding, per-rank z-slab generation, table gather, rank-0 prune)
+    with two ranks on this one GPU over gloo must find exactly the blobs of the single-rank run."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MMX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    shape = ["96", "300", "300"]
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--shape", *shape]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *common],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", *common],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert two.returncode == 0, two.stderr[-2000:]
+    r1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert r1["n_gpus"] == 1 and r2["n_gpus"] == 2
+    assert r1["blobs"] == r2["blobs"] and r1["blobs"] > 100
+    assert r2["config"]["blocks_per_rank"] == 2          # 1 x 2 x 2 blocks over two ranks
