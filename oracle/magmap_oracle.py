@@ -166,8 +166,12 @@ def setup_blocks(profile: dict, shape, resolutions) -> Dict[str, object]:
 
 # ----------------------------------------------------------------------- A10
 def detect_sub_roi(coord, offset, last_coord, exclude_border, sub_roi, channel,
-                   profiles, resolutions) -> Optional[np.ndarray]:
-    """One block; magmap/cv/stack_detect.py:81-172 with ``denoise_max_shape=None``, ``coloc=False``."""
+                   profiles, resolutions, denoise_max_shape=None, near_max=(-1.0,)) -> Optional[np.ndarray]:
+    """One block; magmap/cv/stack_detect.py:81-172 with ``coloc=False``.  With
+    ``denoise_max_shape`` the block is preprocessed first (:122-150, ``preprocess_oracle``)."""
+    if denoise_max_shape is not None:
+        from . import preprocess_oracle as ppo
+        sub_roi = ppo.preprocess_block(sub_roi, denoise_max_shape, profiles, near_max)
     if exclude_border is None:
         exclude = None
     else:
@@ -181,7 +185,8 @@ def detect_sub_roi(coord, offset, last_coord, exclude_border, sub_roi, channel,
     return segments
 
 
-def detect_blobs_sub_rois(img, slices, offsets, exclude_border, channel, profiles, resolutions):
+def detect_blobs_sub_rois(img, slices, offsets, exclude_border, channel, profiles, resolutions,
+                          denoise_max_shape=None, near_max=(-1.0,)):
     """Serial version of the Pool fan-out, magmap/cv/stack_detect.py:174-257."""
     last_coord = np.subtract(slices.shape, 1)
     seg_rois = np.zeros(slices.shape, dtype=object)
@@ -191,7 +196,7 @@ def detect_blobs_sub_rois(img, slices, offsets, exclude_border, channel, profile
                 coord = (z, y, x)
                 seg_rois[coord] = detect_sub_roi(
                     coord, offsets[coord], last_coord, exclude_border,
-                    img[slices[coord]], channel, profiles, resolutions)
+                    img[slices[coord]], channel, profiles, resolutions, denoise_max_shape, near_max)
     return seg_rois
 
 
@@ -371,7 +376,7 @@ def _slice_shape(slc, img_shape):
 
 # ----------------------------------------------------------------------- A14
 def detect_blobs_blocks(roi: np.ndarray, channels: Optional[Sequence[int]],
-                        profiles: Sequence[dict], resolutions):
+                        profiles: Sequence[dict], resolutions, near_max=(-1.0,)):
     """Whole-ROI detection + pruning -> final ``(M, 8)`` table (or None) and stages.
 
     magmap/cv/stack_detect.py:338-517 for ``full_roi=True, coloc=False,
@@ -385,7 +390,7 @@ def detect_blobs_blocks(roi: np.ndarray, channels: Optional[Sequence[int]],
     blocks = setup_blocks(prof0, roi.shape, resolutions)
     seg_rois = detect_blobs_sub_rois(
         roi, blocks["sub_roi_slices"], blocks["sub_rois_offsets"],
-        blocks["exclude_border"], channels, profiles, resolutions)
+        blocks["exclude_border"], channels, profiles, resolutions, blocks["denoise_max_shape"], near_max)
     merged_before = merge_blobs(seg_rois)
     segments_all, ratios = prune_blobs_mp(
         roi.shape, seg_rois, blocks["overlap"], blocks["tol"], blocks["sub_roi_slices"],

@@ -22,6 +22,9 @@ Fixtures (all ``np.savez_compressed``):
 * ``stack_<case>.npz``     -- ``detect_blobs_blocks``: per-block tables, final table.
 * ``prune.npz``            -- ``remove_close_blobs`` / ``StackPruner.prune_blobs_mp``
   on hand-made tables (multi-matches, half-even averages, >1000-row chunking).
+* ``preproc.npz``          -- ``plot_3d.saturate_roi`` / ``plot_3d.denoise_roi`` on denoise
+  sub-blocks (sparse, dense/eroded, constant, ragged, x-size-3, uint8, near_max, 2 channels).
+* ``stack_denoise*.npz``   -- ``detect_blobs_blocks`` with the profile's ``denoise_size`` on.
 """
 import io
 import os
@@ -233,8 +236,10 @@ def blocks_cases():
     print("blocks: %d cases" % len(sweep))
 
 
-def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, **over):
+def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, near_max=(-1.0,),
+               **over):
     config.resolutions = np.array(resolutions)
+    config.near_max = list(near_max)
     config.filename = "golden"
     config.cpus = cpus
     setup_profile(**over)
@@ -265,7 +270,9 @@ def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, **
                final=np.empty((0, 8)) if final is None else final,
                final_cols=np.array(blobs.cols if blobs.cols is not None else []),
                ratios=np.empty((0, 3)) if df is None or df.empty else df.to_numpy(),
+               near_max=np.array(near_max, dtype=float),
                overrides=repr(over), versions=repr(VERSIONS))
+    config.near_max = [-1.0]
     for c in np.ndindex(*seg_rois.shape):
         t = seg_rois[c]
         out["block_%d_%d_%d" % c] = np.empty((0, 11)) if t is None else t
@@ -273,6 +280,65 @@ def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, **
     print("stack_%s: grid %s, %s merged -> %s final" % (
         name, seg_rois.shape, None if merged is None else len(merged),
         None if final is None else final.shape))
+
+
+def preproc_cases():
+    """saturate_roi / denoise_roi of the real reference on denoise-sized sub-blocks."""
+    from magmap.plot import plot_3d
+    out = {}
+    names = []
+
+    def case(name, roi, near_max=(-1.0,), names_=None, **over):
+        setup_profile(names_, **over)
+        config.near_max = list(near_max)
+        sat = quiet(plot_3d.saturate_roi, roi, channel=None)
+        den = quiet(plot_3d.denoise_roi, sat, channel=None)
+        out[name + "_roi"] = roi
+        out[name + "_near_max"] = np.array(near_max, dtype=float)
+        out[name + "_over"] = repr(over)
+        out[name + "_sat"] = sat
+        out[name + "_den"] = den
+        names.append(name)
+        print("preproc %-10s %s %s -> sat %s mean %.4f, den %s [%.4f, %.4f]" % (
+            name, roi.shape, roi.dtype, sat.dtype, float(np.mean(sat)), den.dtype,
+            float(den.min()), float(den.max())))
+
+    sparse = make_volume(41, (25, 25, 25), 3, margin=4)
+    case("sparse", sparse)
+    densev = make_volume(42, (25, 25, 25), 40, amp=6000.0, blob_sigma=3.5, bg_mean=3000.0,
+                         bg_sd=800.0, margin=0)
+    case("dense", densev)
+    case("const", np.full((25, 25, 25), 1234, dtype=np.uint16))
+    case("ragged", make_volume(43, (14, 25, 9), 2, margin=3))
+    case("x3", make_volume(44, (25, 25, 3), 2, margin=1))
+    case("x3dense", make_volume(45, (12, 20, 3), 6, amp=5000.0, bg_mean=3000.0, bg_sd=900.0,
+                                margin=0))
+    case("tiny", make_volume(46, (2, 1, 5), 0, margin=0))
+    case("u8", make_volume(47, (25, 25, 25), 4, dtype=np.uint8, margin=4))
+    case("nearmax", sparse, near_max=(90000.0,))
+    case("nearmax_lo", sparse, near_max=(3000.0,))
+    case("noero", densev, erosion_threshold=0.0)
+    case("nounsharp", densev, unsharp_strength=0.0)
+    case("clipvals", densev, clip_vmin=2, clip_vmax=90.5, clip_min=0.1, clip_max=0.8,
+         unsharp_strength=0.45, erosion_threshold=0.1)
+    # discrete data with many ties around the percentile ranks
+    rng = np.random.default_rng(48)
+    case("ties", (rng.integers(0, 6, (20, 25, 25)) * 100).astype(np.uint16))
+    big = make_volume(49, (32, 40, 36), 10, margin=4)   # larger than a stock sub-block, R=32 > every side
+    case("big", big)
+    two = np.stack((sparse, densev), axis=-1)
+    yaml = "/root/reference/profiles/roi_blobs.yaml"
+    case("2ch", two, near_max=(-1.0, 20000.0))
+    case("2ch_perchl", two, near_max=(-1.0, -1.0), names_=[yaml, yaml + ",4xnuc"],
+         unsharp_strength={"per_channel": [0.3, 0.6]})
+    config.near_max = [-1.0]
+    out["names"] = np.array(names)
+    out["versions"] = repr(VERSIONS)
+    # the sigma-8 kernel as THIS environment's SciPy/NumPy builds it: np.exp differs by an ulp between
+    # NumPy releases, so parity tests feed these weights to the restatement (data, not code)
+    from scipy.ndimage import filters as ndi_filters
+    out["gauss8_weights"] = ndi_filters._gaussian_kernel1d(8.0, 0, 32)
+    np.savez_compressed(os.path.join(HERE, "preproc.npz"), **out)
 
 
 def prune_cases():
@@ -368,6 +434,8 @@ def prune_cases():
 
 def main():
     print("versions:", VERSIONS)
+    if sys.argv[1:] == ["preproc"]:       # only the preprocessing fixtures (added later)
+        return main_preproc()
     # ---- blob_log arithmetic
     bloblog_case("u16_1sigma", make_volume(11, (40, 56, 60), 22), 3, 3, 1)
     bloblog_case("u16_5sigma", make_volume(12, (48, 64, 72), 30), 3, 5, 5)
@@ -417,6 +485,23 @@ def main():
 
     # ---- table pruning
     prune_cases()
+
+    main_preproc()
+
+
+def main_preproc():
+    # ---- per-block preprocessing (saturate + denoise) and whole-stack detection with it on
+    preproc_cases()
+    stack_case("denoise", make_volume(35, (64, 96, 96), 60), None, segment_size=40, num_sigma=5,
+               denoise_size=25)
+    bgvol = make_volume(36, (56, 84, 80), 50, amp=9000.0, bg_mean=2500.0, bg_sd=700.0)
+    stack_case("denoise_dense", bgvol, None, segment_size=36, num_sigma=3, denoise_size=20,
+               near_max=(30000.0,))
+    stack_case("denoise_aniso", make_volume(37, (40, 90, 93), 40), None,
+               resolutions=((2.0, 0.8, 0.8),), segment_size=60, num_sigma=3, denoise_size=30)
+    vol2d = np.stack((make_volume(38, (44, 60, 62), 24), make_volume(39, (44, 60, 62), 20)), axis=-1)
+    stack_case("denoise_2ch", vol2d, None, segment_size=32, num_sigma=3, denoise_size=25,
+               near_max=(-1.0, 25000.0))   # one near_max per channel or the reference raises IndexError
 
 
 if __name__ == "__main__":

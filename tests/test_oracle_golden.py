@@ -16,6 +16,7 @@ import pytest
 from conftest import GOLDEN, lexsorted, load_golden
 from oracle import blob_log_oracle as blo
 from oracle import magmap_oracle as mmo
+from oracle import preprocess_oracle as ppo
 
 BLOBLOG_CASES = sorted(os.path.basename(p)[len("bloblog_"):-4]
                        for p in glob.glob(os.path.join(GOLDEN, "bloblog_*.npz")))
@@ -126,18 +127,34 @@ def test_stack_splitter_reference_unit_test_geometry():
 
 def _stack_profiles(g):
     over = ast.literal_eval(str(g["overrides"]))
-    prof = dict(min_sigma_factor=3, max_sigma_factor=5, num_sigma=10, detection_threshold=0.1,
-                overlap=0.5, exclude_border=None, segment_size=500, denoise_size=None,
-                prune_tol_factor=(1, 1, 1), isotropic=None)
-    prof.update(over)
-    return [prof]
+    return _profiles(over, 1)
+
+
+#: the reference's default ROI profile + profiles/roi_blobs.yaml (what make_golden.py loads)
+BASE_PROFILE = dict(min_sigma_factor=3, max_sigma_factor=5, num_sigma=10, detection_threshold=0.1,
+                    overlap=0.5, exclude_border=None, segment_size=500, denoise_size=None,
+                    prune_tol_factor=(1, 1, 1), isotropic=None,
+                    clip_vmin=5, clip_vmax=99.5, clip_min=0.2, clip_max=1.0, max_thresh_factor=0.5,
+                    tot_var_denoise=None, unsharp_strength=0.3, erosion_threshold=0.2)
+
+
+def _profiles(over, n):
+    profs = []
+    for i in range(n):
+        prof = dict(BASE_PROFILE)
+        for k, v in over.items():
+            prof[k] = v["per_channel"][i] if isinstance(v, dict) and "per_channel" in v else v
+        profs.append(prof)
+    return profs
 
 
 @pytest.mark.parametrize("case", STACK_CASES)
-def test_detect_blobs_blocks_matches_reference(case):
+def test_detect_blobs_blocks_matches_reference(case, golden_gauss_weights):
     g = load_golden("stack_%s.npz" % case)
     channels = None if g["channels"].ndim == 0 else list(g["channels"])
-    final, st = mmo.detect_blobs_blocks(g["roi"], channels, _stack_profiles(g), g["resolutions"])
+    near_max = list(g["near_max"]) if "near_max" in g else [-1.0]
+    final, st = mmo.detect_blobs_blocks(g["roi"], channels, _stack_profiles(g), g["resolutions"],
+                                        near_max=near_max)
     grid = tuple(g["grid"])
     assert st["seg_rois"].shape == grid
     for c in np.ndindex(*grid):
@@ -157,6 +174,49 @@ def test_detect_blobs_blocks_matches_reference(case):
     if g["ratios"].size:
         got = np.array([st["ratios"][k] for k in ("blobs", "ratio_pruning", "ratio_adjacent")]).T
         np.testing.assert_allclose(got, g["ratios"])
+
+
+PREPROC = load_golden("preproc.npz")
+
+
+@pytest.fixture
+def golden_gauss_weights(monkeypatch):
+    """The sigma-8 kernel of the environment the fixtures were made in (np.exp is not bit-stable
+    across NumPy releases; everything downstream of the weights is)."""
+    monkeypatch.setattr(ppo, "GAUSS_WEIGHTS", PREPROC["gauss8_weights"])
+
+
+def test_gauss_weights_agree_with_this_scipy_to_an_ulp():
+    from scipy.ndimage import _filters
+    w = _filters._gaussian_kernel1d(8.0, 0, 32)
+    np.testing.assert_allclose(w, PREPROC["gauss8_weights"], rtol=4e-16, atol=0)
+
+
+@pytest.mark.parametrize("case", [str(n) for n in PREPROC["names"]])
+def test_preprocessing_matches_reference(case, golden_gauss_weights):
+    """saturate_roi + denoise_roi restated == the real reference (plot_3d.py:55-172), bit for bit."""
+    g = PREPROC
+    roi = g[case + "_roi"]
+    over = ast.literal_eval(str(g[case + "_over"]))
+    nprof = 2 if case == "2ch_perchl" else 1
+    profs = _profiles(over, nprof)
+    near_max = list(g[case + "_near_max"])
+    sat = ppo.saturate_roi(roi, profs, near_max)
+    assert sat.dtype == g[case + "_sat"].dtype
+    np.testing.assert_array_equal(sat, g[case + "_sat"])
+    den = ppo.denoise_roi(sat, profs)
+    assert den.dtype == np.float64
+    np.testing.assert_array_equal(den, g[case + "_den"])
+
+
+def test_preprocess_block_tiles_like_the_reference_loop():
+    g = load_golden("stack_denoise.npz")
+    roi = g["roi"][:40, :45, :52]
+    profs = _profiles({}, 1)
+    got = ppo.preprocess_block(roi, (25, 25, 25), profs, [-1.0])
+    for sl in [(slice(0, 25), slice(25, 45), slice(50, 52)), (slice(25, 40), slice(0, 25), slice(25, 50))]:
+        want = ppo.denoise_roi(ppo.saturate_roi(roi[sl], profs, [-1.0]), profs)
+        np.testing.assert_array_equal(got[sl], want)
 
 
 def test_remove_close_blobs_matches_reference():
