@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 2
+#define MMX_ABI_VERSION 3
 
 typedef enum {
     MMX_OK = 0,
@@ -167,14 +167,91 @@ int mmx_overlap_pairs(const double* d_blobs, const int32_t* d_offsets, int n_blo
 int mmx_close_pairs(const int32_t* d_master, int n_master, const int32_t* d_check, int n_check,
                     const int32_t tol[3], int32_t* d_last, uint8_t* d_hit, void* stream);
 
+/* ---- P1-P3: per-block preprocessing ahead of detection
+ * replaces: the sub-sub-block loop of StackDetector.detect_sub_roi (magmap/cv/stack_detect.py:122-150):
+ *     plot_3d.saturate_roi (magmap/plot/plot_3d.py:55-112) -- np.percentile contrast stretch
+ *     plot_3d.denoise_roi  (plot_3d.py:115-172) -- clip, unsharp mask with
+ *         skimage.filters.gaussian(sigma 8, 'nearest', truncate 4), erosion(octahedron(1)) when
+ *         the sub-block mean exceeds erosion_threshold
+ * for uint8 / uint16 voxels, in float64, bit for bit (same IEEE operations in NumPy's / SciPy's
+ * order).  One *sub-block* is one tile of chunking.stack_splitter(block.shape, denoise_max_shape)
+ * of one block and channel; it is processed as an independent image. */
+typedef struct {
+    int64_t src_off;      /* element offset of the sub-block origin inside the source volume        */
+    int64_t dst_off;      /* element offset of the sub-block origin inside d_out32 / d_out64        */
+    int64_t scratch_off;  /* generic entry only: offset (in doubles) of 2*nz*ny*nx doubles of scratch */
+    int32_t nz, ny, nx;   /* extent in voxels                                                       */
+    int32_t qclass;       /* row of the quantile-class table                                        */
+} mmx_subblock;           /* 40 bytes */
+
+/* What np.percentile(a, (clip_vmin, clip_vmax)) needs for an `a` of n values, computed by the caller
+ * exactly as NumPy does (numpy/lib/_function_base_impl.py: _quantile, method "linear"):
+ * virtual index (n-1)*q, its floor / floor+1 as 0-based ranks into sorted(a) (both n-1 when the
+ * index is >= n-1), gamma = virtual - floor. */
+typedef struct {
+    int32_t lo_prev, lo_next, hi_prev, hi_next;
+    double lo_gamma, hi_gamma;
+} mmx_quantile_class;     /* 32 bytes */
+
+typedef struct {
+    double clip_min, clip_max;   /* profile "clip_min"/"clip_max" (np.clip bounds after stretching)  */
+    double max_thresh;           /* config.near_max[channel] * profile "max_thresh_factor"           */
+    double unsharp_strength;     /* 0 = no unsharp mask (Python falsy)                               */
+    double erosion_threshold;    /* 0 = never erode (Python falsy)                                   */
+    int32_t radius;              /* Gaussian radius; must be 32 = int(4*8+0.5): sigma 8 is hard-coded
+                                    in the reference (plot_3d.py:151)                               */
+    int32_t rgb_guess;           /* 1 = scikit-image < 0.19: an array whose LAST axis has length 3 is
+                                    taken for RGB and not blurred along it (filters/_gaussian.py)   */
+} mmx_preproc_params;     /* 48 bytes */
+
+#define MMX_PP_IDENTITY 1    /* vmin == vmax: voxels pass through unstretched                        */
+#define MMX_PP_ERODED 2      /* mean > erosion_threshold                                             */
+#define MMX_PP_EXACT_MEAN 4  /* the mean was re-summed in NumPy's pairwise order (knife edge)         */
+typedef struct {
+    double vmin, vmax, mean;     /* percentiles (vmax after the near_max floor), np.mean(saturated)  */
+    int32_t flags;
+    int32_t _pad;
+} mmx_subblock_info;      /* 32 bytes */
+
+#define MMX_PP_RADIUS 32
+#define MMX_PP_MAX_SIDE 32          /* register-resident lines of the fast kernel                   */
+#define MMX_PP_MAX_LDS 163840       /* one workgroup may hold a whole sub-block in LDS              */
+
+/* LDS bytes the fast kernel needs for a sub-block, 0 if it does not qualify (a side above
+ * MMX_PP_MAX_SIDE or more than MMX_PP_MAX_LDS bytes). */
+int64_t mmx_preprocess_fast_lds(int nz, int ny, int nx);
+
+/* Fast entry: every sub-block must qualify (mmx_preprocess_fast_lds != 0), else MMX_ERR_UNSUPPORTED.
+ *   h_subs      : host copy of d_subs (validation, launch geometry)
+ *   h_weights   : float64 half kernel, index k = 0..radius, as scipy's _gaussian_kernel1d(8, 0, 32)
+ *   dst_sy/sz   : row / plane strides (elements) of the two outputs; x stride is 1
+ *   d_out32/64  : float32 copy (feeds mmx_log_batch_f32) and exact float64 result (feeds
+ *                 mmx_rescore_f64); only the voxels of the given sub-blocks are written
+ *   d_info      : optional [n_subs] diagnostics                                                    */
+int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx_subblock* h_subs,
+                         int n_subs, const mmx_quantile_class* d_qclasses, int n_qclasses,
+                         const mmx_preproc_params* params, const double* h_weights,
+                         int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
+                         mmx_subblock_info* d_info, void* stream);
+
+/* Same contract for any extent: data in d_scratch (each sub-block owns 2*nz*ny*nx doubles at its
+ * scratch_off), one output per lane and pass. */
+int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_subs,
+                                 const mmx_subblock* h_subs, int n_subs,
+                                 const mmx_quantile_class* d_qclasses, int n_qclasses,
+                                 const mmx_preproc_params* params, const double* h_weights,
+                                 int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
+                                 mmx_subblock_info* d_info, double* d_scratch, int64_t scratch_doubles,
+                                 void* stream);
+
 /* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream.
  * mmx_timing_enable(1) makes every kernel launch of this library record a HIP event
  * before and after itself on its launch stream; mmx_timing_read() synchronises those
  * events, returns summed milliseconds and launch counts per kernel family (index =
  * MMX_K_*: 0 z pass, 1 y pass, 2 x pass, 3 generic passes, 4 peaks, 5 rescore,
- * 6 overlap pairs, 7 close pairs, 8 fused z+x pass, 9 y pass of the fused path) and starts a new
- * window. */
-#define MMX_K_COUNT 10
+ * 6 overlap pairs, 7 close pairs, 8 fused z+x pass, 9 y pass of the fused path, 10 preprocessing)
+ * and starts a new window. */
+#define MMX_K_COUNT 11
 int mmx_timing_enable(int on);
 int mmx_timing_read(double* ms, int64_t* launches, int n);
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 2
+MMX_ABI_VERSION = 3
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -32,12 +32,28 @@ CAND_DTYPE = np.dtype([("slot", "<i4"), ("s", "<i4"), ("z", "<i4"), ("y", "<i4")
                        ("flags", "<u4"), ("v", "<f4"), ("nbr_max", "<f4"), ("v64", "<f8"),
                        ("_reserved", "<f8")], align=True)
 assert BLOCK_DTYPE.itemsize == 32 and CAND_DTYPE.itemsize == 48
+#: NumPy mirrors of ``mmx_subblock`` (40 bytes), ``mmx_quantile_class`` (32), ``mmx_subblock_info`` (32)
+SUBBLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("scratch_off", "<i8"),
+                           ("nz", "<i4"), ("ny", "<i4"), ("nx", "<i4"), ("qclass", "<i4")], align=True)
+QCLASS_DTYPE = np.dtype([("lo_prev", "<i4"), ("lo_next", "<i4"), ("hi_prev", "<i4"), ("hi_next", "<i4"),
+                         ("lo_gamma", "<f8"), ("hi_gamma", "<f8")], align=True)
+SUBINFO_DTYPE = np.dtype([("vmin", "<f8"), ("vmax", "<f8"), ("mean", "<f8"), ("flags", "<i4"),
+                          ("_pad", "<i4")], align=True)
+assert SUBBLOCK_DTYPE.itemsize == 40 and QCLASS_DTYPE.itemsize == 32 and SUBINFO_DTYPE.itemsize == 32
+MMX_PP_IDENTITY, MMX_PP_ERODED, MMX_PP_EXACT_MEAN = 1, 2, 4
 
 
 class Volume(Structure):
     """``mmx_volume``."""
     _fields_ = [("d_data", c_void_p), ("dtype", c_int32), ("_pad", c_int32),
                 ("stride_z", c_int64), ("stride_y", c_int64), ("stride_x", c_int64)]
+
+
+class PreprocParams(Structure):
+    """``mmx_preproc_params``."""
+    _fields_ = [("clip_min", c_double), ("clip_max", c_double), ("max_thresh", c_double),
+                ("unsharp_strength", c_double), ("erosion_threshold", c_double),
+                ("radius", c_int32), ("rgb_guess", c_int32)]
 
 
 class MmxError(RuntimeError):
@@ -53,9 +69,10 @@ SYMBOLS = (
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
+    "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
-                "close_pairs", "zxpass", "y2pass")
+                "close_pairs", "zxpass", "y2pass", "preproc")
 
 
 def lib() -> ctypes.CDLL:
@@ -96,8 +113,18 @@ def lib() -> ctypes.CDLL:
     L.mmx_calib_stream.argtypes = [c_int, vp, vp, c_int64, vp]
     L.mmx_host_prune_axis.argtypes = [vp, vp, vp, vp, c_int64, c_int, c_int, vp, c_double,
                                       POINTER(c_int32), vp, vp, vp, POINTER(c_int64), vp, vp, vp]
+    L.mmx_preprocess_fast_lds.argtypes = [c_int, c_int, c_int]
+    L.mmx_preprocess_fast_lds.restype = c_int64
+    pre_args = [POINTER(Volume), vp, vp, c_int, vp, c_int, POINTER(PreprocParams), POINTER(c_double),
+                c_int64, c_int64, vp, vp, vp]
+    L.mmx_preprocess_batch.argtypes = pre_args + [vp]
+    L.mmx_preprocess_batch_generic.argtypes = pre_args + [vp, c_int64, vp]
+    L.mmx_preprocess_batch.restype = c_int
+    L.mmx_preprocess_batch_generic.restype = c_int
     for name in SYMBOLS:
         fn = getattr(L, name)
+        if name == "mmx_preprocess_fast_lds":
+            continue
         if fn.restype is None or name.startswith(("mmx_log", "mmx_peaks", "mmx_rescore",
                                                   "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing", "mmx_calib", "mmx_host")):
             fn.restype = c_int

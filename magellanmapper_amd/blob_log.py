@@ -195,13 +195,14 @@ class BatchStats:
 
 
 def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
-                 budget_bytes: int) -> List[List[int]]:
+                 budget_bytes: int, extra_bytes_per_voxel: int = 0) -> List[List[int]]:
     """Group block indices into batches whose workspace fits ``budget_bytes``.
 
     Workspace = (4 + num_sigma) float32 arrays of ``n_blocks * slot`` voxels, slot = the
-    largest block of the batch.  Blocks keep their order (z-major grid order).
+    largest block of the batch (+ ``extra_bytes_per_voxel`` for the preprocessed copies).
+    Blocks keep their order (z-major grid order).
     """
-    per_vox = (4 + num_sigma) * 4
+    per_vox = (4 + num_sigma) * 4 + extra_bytes_per_voxel
     batches: List[List[int]] = []
     cur: List[int] = []
     cur_slot = 0
@@ -310,7 +311,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                     shapes: Sequence[Sequence[int]], min_sigma: float, max_sigma: float,
                     num_sigma: int, threshold: float, overlap: float, *,
                     budget_bytes: int = 24 << 30, stats: Optional[BatchStats] = None,
-                    return_peaks: bool = False, on_batch=None):
+                    return_peaks: bool = False, on_batch=None, pre=None):
     """``blob_log`` of every block -> list of ``(n, 4)`` float64 ``[z, y, x, sigma]`` arrays.
 
     Each block is an independent image exactly as each reference worker's sub-ROI is
@@ -318,7 +319,9 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     coordinates relative to the block.  Blocks without blobs give ``np.empty((0, 3))`` like
     scikit-image does (blob.py:516-517).  Row order equals the reference's.
     ``on_batch(indices, results)`` is called as each batch finishes, while the GPU is busy
-    with the next one.
+    with the next one.  ``pre`` (a ``preprocess.Preprocessor``) saturates + denoises every block
+    on the device first (reference stack_detect.py:122-150); detection then runs on the
+    float64 result exactly as the reference's ``blob_log`` does.
     """
     _require_gpu()
     space = ScaleSpace.make(min_sigma, max_sigma, num_sigma)
@@ -328,17 +331,18 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     results: List[Optional[np.ndarray]] = [None] * len(shapes)
     peaks_out: List[Optional[Tuple[np.ndarray, np.ndarray]]] = [None] * len(shapes)
     bufs = _Buffers(dvol.tensor.device)
-    eps = EPS_REL * dvol.value_scale()
+    eps = EPS_REL * (dvol.value_scale() if pre is None else pre.value_scale([channel]))
     d_w0 = torch.from_numpy(space.w0_tab).to(dvol.tensor.device)
     d_w2 = torch.from_numpy(space.w2_tab).to(dvol.tensor.device)
-    batches = plan_batches(shapes, len(space.sigmas), budget_bytes)
+    batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
+                           0 if pre is None else pre.bytes_per_voxel())
     pending = None
     for k in range(len(batches) + 1):
         job = None
         if k < len(batches):
             batch = batches[k]
             job = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
-                                  space, float(threshold), eps, bufs, k & 1, d_w0, d_w2)
+                                  space, float(threshold), eps, bufs, k & 1, d_w0, d_w2, pre=pre)
             job["batch"] = batch
         if pending is not None:      # host + side-stream work of the previous batch, GPU busy with `job`
             peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats)
@@ -355,18 +359,23 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
 
 # --------------------------------------------------------------------------- A0-A4
 def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
-                    bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None):
-    """Enqueue A0-A4 of one batch on the current stream; nothing here waits for the GPU."""
+                    bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None):
+    """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU."""
     L = nat.lib()
     dev = dvol.tensor.device
-    blocks, slot = _make_blocks(dvol, channel, origins, shapes)
+    if pre is None:
+        blocks, slot = _make_blocks(dvol, channel, origins, shapes)
+        vol32 = dvol.view(channel, True)
+        vol_exact = dvol.view(channel, False)
+        store_f32 = 1 if dvol.np_dtype == np.float32 else 0
+    else:
+        blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
+        store_f32 = 0
     nb, ns = len(blocks), len(space.sigmas)
     if slot >= (1 << 29):
         raise nat.MmxError("block too large for one workspace slot (>= 2^29 voxels)")
     ws = bufs.workspace((4 + ns) * nb * slot)
     d_blocks = _to_device_bytes(blocks, dev)
-    vol32 = dvol.view(channel, True)
-    vol_exact = dvol.view(channel, False)
     stream = _stream_ptr()
     log_base = ws.data_ptr() + 4 * nb * slot * 4
     for s in range(ns):
@@ -376,7 +385,6 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
             float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(), stream),
             "mmx_log_batch_f32")
     n_vox = int(sum(int(np.prod(s)) for s in shapes))
-    store_f32 = 1 if dvol.np_dtype == np.float32 else 0
     if cap is None:
         cap = max(4096, min(n_vox * ns, n_vox // 2000 * ns + 65536))
     table = bufs.cand_table(which, cap)
@@ -394,7 +402,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     done.record()
     return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
                 nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
-                vol_exact=vol_exact)
+                vol_exact=vol_exact, pre=pre)
 
 
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
@@ -414,7 +422,7 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
             # already reused the workspace, so the passes run again
             torch.cuda.current_stream().synchronize()
             redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr,
-                                   eps, bufs, which, d_w0, d_w2, cap=count + 1024)
+                                   eps, bufs, which, d_w0, d_w2, cap=count + 1024, pre=job.get("pre"))
             redo["batch"] = job.get("batch")
             return _finish_detect(redo, dvol, space, thr, eps, bufs, d_w0, d_w2, stats)
     with torch.cuda.stream(bufs.side):

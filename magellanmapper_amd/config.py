@@ -4,7 +4,7 @@ Only the handful of module-level globals that the reference's hot path consults 
 (reference magmap/settings/config.py): ``resolutions`` (:246), ``cpus`` (:79), ``channel``
 (:144), ``filename`` (:132), ``roi_profile`` / ``roi_profiles`` / :func:`get_roi_profile`
 (:882-901), ``SUFFIX_BLOBS`` (:126), ``save_subimg`` (:508), ``verbose`` (:108),
-``grid_search_profile`` (:905), ``truth_db_mode`` (:539).  They are read at every call --
+``grid_search_profile`` (:905), ``truth_db_mode`` (:539), ``near_max`` (:211).  They are read at every call --
 never cached -- because the reference's grid search mutates profiles between calls
 (magmap/stats/mlearn.py:31-).
 """
@@ -26,6 +26,9 @@ filename: Optional[str] = None
 channel: Optional[Sequence[int]] = None
 #: ``[[z, y, x], ...]`` physical voxel sizes; the first row is the one used
 resolutions = None
+#: per-channel near-maximum intensities from the image metadata; floors the stretch ceiling of
+#: ``saturate_roi`` (reference config.py:211, plot_3d.py:95-99)
+near_max = [-1.0]
 save_subimg: bool = False
 truth_db_mode = None
 grid_search_profile = None

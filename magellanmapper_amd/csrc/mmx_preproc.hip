@@ -1,0 +1,638 @@
+// Per-block preprocessing ahead of blob detection: contrast stretch + unsharp mask + erosion.
+//
+// What the reference does to every denoise sub-block of every detection block
+// (magmap/cv/stack_detect.py:122-150) before `blob_log` sees it:
+//   saturate_roi (magmap/plot/plot_3d.py:55-112)
+//       vmin, vmax = np.percentile(roi, (clip_vmin, clip_vmax))          # linear interpolation
+//       vmax = max(vmax, near_max * max_thresh_factor);  roi unchanged when vmin == vmax
+//       sat  = (np.clip(roi, vmin, vmax) - vmin) / (vmax - vmin)
+//   denoise_roi  (plot_3d.py:115-172)
+//       mean = np.mean(sat);  den = np.clip(sat, clip_min, clip_max)
+//       den  = den + (den - unsharp_strength * gaussian(den, sigma 8, 'nearest', truncate 4))
+//       den  = grey_erosion(den, octahedron(1))  if  mean > erosion_threshold
+// all in float64.  The result feeds an exact float64 re-score (mmx_rescore.hip), so it is
+// reproduced BIT FOR BIT: the same IEEE operations in the same order as NumPy / SciPy
+// (NI_Correlate1D symmetric branch: acc = in[c]*w0; for k = R..1: acc += (in[c-k]+in[c+k])*w[k]),
+// no FMA contraction (this file is built with -ffp-contract=off), correctly rounded division.
+// oracle/preprocess_oracle.py states the same on the CPU and is pinned to the real reference.
+//
+// Design (gfx950).  A stock sub-block is 25^3 voxels = 122 KiB of float64: it lives in LDS for
+// its whole life, ONE workgroup per sub-block (a CU's 160 KiB holds exactly one), HBM is
+// touched once for the 2-byte voxels and once for the 12 bytes of output per voxel.
+//   1. voxels -> LDS as doubles + 256-bin histogram of the high byte (LDS atomics)
+//   2. the 2x2 order statistics np.percentile needs: two-level radix select (wave scan over
+//      the bins), then NumPy's _lerp in double
+//   3. saturate, block-sum for the mean, clip -> LDS.  The mean only gates the erosion; it is
+//      summed in parallel and, if that lands within 1e-9 of the threshold, re-summed by one
+//      lane in NumPy's pairwise order (numpy/_core/src/umath/loops_utils.h.src) -- bit exact
+//   4. three in-place Gaussian passes: a lane owns a whole line (<= 32 voxels) in registers,
+//      'nearest' extension is the last register replicated, so all tap indices are
+//      compile-time; the 33 weights sit in SGPRs (kernarg).  ~97 float64 ops per voxel and
+//      axis: this stage is float64-ALU bound (about 30 us per sub-block and CU)
+//   5. unsharp in place, then the 7-point minimum (reflect == skip outside) if eroding,
+//      float64 + float32 copies out (the float32 copy feeds the LoG passes)
+// Sub-blocks with a side above 32 or more voxels than LDS holds take pp_generic_kernel:
+// same arithmetic, data in a global scratch, one output per lane and pass.
+
+#include "mmx_common.h"
+
+#define PP_R 32          // int(4 * 8 + 0.5): sigma 8 is hard-coded in plot_3d.py:151
+#define PP_MAXL 32       // longest line of the register-resident pass
+#define PP_WG 640        // 10 waves: 625 lines of a 25^3 sub-block in one round
+#define PP_WG_GENERIC 1024
+#define PP_HIST (5 * 256)
+
+struct pp_args {
+    double w[PP_R + 1];          // half kernel, w[k] = weight at distance k
+    double clip_min, clip_max, max_thresh, strength, ero_thr;
+    int64_t dst_sy, dst_sz;
+    int32_t do_unsharp, do_erosion, rgb_guess, _pad;
+};
+
+namespace {
+
+__device__ __forceinline__ double pp_clip(double x, double lo, double hi)
+{
+    // np.clip == minimum(maximum(x, lo), hi)
+    double t = x < lo ? lo : x;
+    return t > hi ? hi : t;
+}
+
+// numpy _lerp (numpy/lib/_function_base_impl.py): a + (b-a)*t, or b - (b-a)*(1-t) for t >= 0.5
+__device__ __forceinline__ double pp_lerp(int a, int b, double t)
+{
+    const double d = (double)(b - a);
+    double r = (double)a + d * t;
+    if (t >= 0.5) r = (double)b - d * (1.0 - t);
+    return r;
+}
+
+struct pp_sat {
+    double vmin, vmax, span;
+    int identity;
+    __device__ __forceinline__ double operator()(double raw) const
+    {
+        if (identity) return raw;
+        return (pp_clip(raw, vmin, vmax) - vmin) / span;
+    }
+};
+
+// Executed by one full wave: the bin of `h[0..255]` holding 0-based rank `rank`, and the rank
+// inside that bin.
+__device__ __forceinline__ void pp_select(const uint32_t* h, uint32_t rank, int& bin, uint32_t& res)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
+    const uint32_t s = c0 + c1 + c2 + c3;
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const uint32_t excl = incl - s;
+    const bool mine = rank >= excl && rank < incl;
+    const unsigned long long m = __ballot(mine);
+    const int src = m ? __ffsll((long long)m) - 1 : 63;
+    uint32_t r = rank - excl;
+    int b = 4 * lane;
+    if (r >= c0) { r -= c0; ++b; if (r >= c1) { r -= c1; ++b; if (r >= c2) { r -= c2; ++b; } } }
+    bin = __shfl(b, src);
+    res = __shfl(r, src);
+}
+
+__device__ __forceinline__ double pp_wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d);
+    return v;
+}
+
+// NumPy's pairwise summation of val(0..n-1) (DOUBLE_pairwise_sum), by ONE lane.  `stk` is
+// 4 x 40 ints/doubles of LDS for the explicit recursion stack.
+template <typename F>
+__device__ double pp_pairwise_leaf(F val, int lo, int n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; ++i) res += val(lo + i);
+        return res;
+    }
+    double r0 = val(lo), r1 = val(lo + 1), r2 = val(lo + 2), r3 = val(lo + 3);
+    double r4 = val(lo + 4), r5 = val(lo + 5), r6 = val(lo + 6), r7 = val(lo + 7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += val(lo + i); r1 += val(lo + i + 1); r2 += val(lo + i + 2); r3 += val(lo + i + 3);
+        r4 += val(lo + i + 4); r5 += val(lo + i + 5); r6 += val(lo + i + 6); r7 += val(lo + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += val(lo + i);
+    return res;
+}
+
+struct pp_stack { int lo[40]; int n[40]; int st[40]; double acc[40]; };
+
+template <typename F>
+__device__ double pp_pairwise(F val, int n, pp_stack* S)
+{
+    int sp = 0;
+    double ret = 0.;
+    S->lo[0] = 0; S->n[0] = n; S->st[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int t = sp - 1;
+        const int lo = S->lo[t], m = S->n[t];
+        if (m <= 128) { ret = pp_pairwise_leaf(val, lo, m); --sp; continue; }
+        int n2 = m / 2; n2 -= n2 % 8;
+        if (S->st[t] == 0) { S->st[t] = 1; S->lo[sp] = lo; S->n[sp] = n2; S->st[sp] = 0; ++sp; }
+        else if (S->st[t] == 1) {
+            S->acc[t] = ret; S->st[t] = 2;
+            S->lo[sp] = lo + n2; S->n[sp] = m - n2; S->st[sp] = 0; ++sp;
+        } else { ret = S->acc[t] + ret; --sp; }
+    }
+    return 0. + ret;   // the reduction starts from the identity (add.reduce)
+}
+
+// One in-place Gaussian pass over the lines of one axis, lines held in registers.
+// base/stride address the LDS tile; L <= PP_MAXL.
+__device__ __forceinline__ void pp_line_pass(double* __restrict__ tile, int base, int stride, int L,
+                                             const pp_args& A)
+{
+    double r[PP_MAXL];
+#pragma unroll
+    for (int i = 0; i < PP_MAXL; ++i) r[i] = tile[base + (i < L ? i : L - 1) * stride];
+#pragma unroll
+    for (int i = 0; i < PP_MAXL; ++i) {
+        if (i < L) {
+            double acc = r[i] * A.w[0];
+#pragma unroll
+            for (int k = PP_R; k >= 1; --k) {
+                const int a = i - k < 0 ? 0 : i - k;
+                const int b = i + k > PP_MAXL - 1 ? PP_MAXL - 1 : i + k;
+                acc += (r[a] + r[b]) * A.w[k];
+            }
+            tile[base + i * stride] = acc;
+        }
+    }
+}
+
+template <typename InT>
+__global__ void __launch_bounds__(PP_WG)
+pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
+               const mmx_subblock* __restrict__ subs, const mmx_quantile_class* __restrict__ qcs,
+               pp_args A, float* __restrict__ out32, double* __restrict__ out64,
+               mmx_subblock_info* __restrict__ info)
+{
+    extern __shared__ double tile[];
+    __shared__ int s_bin[4];
+    __shared__ uint32_t s_res[4];
+    __shared__ int s_val[4];
+    __shared__ double s_red[PP_WG / 64];
+    __shared__ double s_mean;
+    __shared__ int s_flags;
+    __shared__ pp_stack s_stack;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const mmx_subblock sb = subs[blockIdx.x];
+    const int nz = sb.nz, ny = sb.ny, nx = sb.nx, n = nz * ny * nx;
+    const int px = nx | 1;                        // odd row pitch: no LDS bank conflicts on x lines
+    uint32_t* hist = (uint32_t*)(tile + nz * ny * px);
+    const InT* src = vol + sb.src_off;
+    const float inv_nx = 1.0f / (float)nx, inv_ny = 1.0f / (float)ny;
+
+    for (int i = tid; i < PP_HIST; i += PP_WG) hist[i] = 0;
+    __syncthreads();
+
+    // 1. voxels -> LDS (as doubles), histogram of the high byte
+    for (int i = tid; i < n; i += PP_WG) {
+        const int t = (int)(((float)i + 0.5f) * inv_nx);
+        const int x = i - t * nx;
+        const int z = (int)(((float)t + 0.5f) * inv_ny);
+        const int y = t - z * ny;
+        const int v = (int)src[z * sz + y * sy + x * sx];
+        tile[(z * ny + y) * px + x] = (double)v;
+        atomicAdd(&hist[v >> 8], 1u);
+    }
+    __syncthreads();
+
+    // 2. order statistics: ranks lo_prev, lo_next, hi_prev, hi_next
+    const mmx_quantile_class qc = qcs[sb.qclass];
+    if (wave < 4) {
+        const uint32_t rank = wave == 0 ? qc.lo_prev : wave == 1 ? qc.lo_next : wave == 2 ? qc.hi_prev : qc.hi_next;
+        int b; uint32_t r;
+        pp_select(hist, rank, b, r);
+        if (lane == 0) { s_bin[wave] = b; s_res[wave] = r; }
+    }
+    __syncthreads();
+    {
+        const int b0 = s_bin[0], b1 = s_bin[1], b2 = s_bin[2], b3 = s_bin[3];
+        for (int i = tid; i < n; i += PP_WG) {
+            const int t = (int)(((float)i + 0.5f) * inv_nx);
+            const int x = i - t * nx;
+            const int v = (int)tile[t * px + x];
+            const int hi = v >> 8, lo = v & 255;
+            if (hi == b0) atomicAdd(&hist[256 + lo], 1u);
+            if (hi == b1) atomicAdd(&hist[512 + lo], 1u);
+            if (hi == b2) atomicAdd(&hist[768 + lo], 1u);
+            if (hi == b3) atomicAdd(&hist[1024 + lo], 1u);
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+        int b; uint32_t r;
+        pp_select(hist + 256 * (1 + wave), s_res[wave], b, r);
+        if (lane == 0) s_val[wave] = (s_bin[wave] << 8) | b;
+    }
+    __syncthreads();
+
+    pp_sat S;
+    {
+        const double vmin = pp_lerp(s_val[0], s_val[1], qc.lo_gamma);
+        double vmax = pp_lerp(s_val[2], s_val[3], qc.hi_gamma);
+        S.identity = vmin == vmax;
+        if (vmax < A.max_thresh) vmax = A.max_thresh;
+        S.vmin = vmin; S.vmax = vmax; S.span = vmax - vmin;
+    }
+
+    // 3. saturate, sum, clip
+    double part = 0.;
+    for (int i = tid; i < n; i += PP_WG) {
+        const int t = (int)(((float)i + 0.5f) * inv_nx);
+        const int x = i - t * nx;
+        const int pos = t * px + x;
+        const double s = S(tile[pos]);
+        part += s;
+        tile[pos] = pp_clip(s, A.clip_min, A.clip_max);
+    }
+    part = pp_wave_sum(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.;
+        for (int w = 0; w < PP_WG / 64; ++w) tot += s_red[w];
+        double mean = tot / (double)n;
+        int flags = S.identity ? MMX_PP_IDENTITY : 0;
+        if (A.do_erosion) {
+            const double tol = 1e-9 * (fabs(A.ero_thr) > 1. ? fabs(A.ero_thr) : 1.);
+            if (!S.identity && fabs(mean - A.ero_thr) <= tol) {
+                // knife edge: NumPy's own summation order decides
+                auto val = [&](int i) {
+                    const int t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
+                    return S((double)(int)src[z * sz + y * sy + x * sx]);
+                };
+                mean = pp_pairwise(val, n, &s_stack) / (double)n;
+                flags |= MMX_PP_EXACT_MEAN;
+            }
+            if (mean > A.ero_thr) flags |= MMX_PP_ERODED;
+        }
+        s_mean = mean;
+        s_flags = flags;
+    }
+    __syncthreads();
+    const int flags = s_flags;
+    if (info && tid == 0) {
+        mmx_subblock_info o;
+        o.vmin = S.vmin; o.vmax = S.vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
+        info[blockIdx.x] = o;
+    }
+
+    // 4. Gaussian blur, axis 0, 1, 2 in place (scipy gaussian_filter order)
+    if (A.do_unsharp) {
+#pragma unroll 1
+        for (int axis = 0; axis < 3; ++axis) {
+            const int L = axis == 0 ? nz : axis == 1 ? ny : nx;
+            if (axis == 2 && A.rgb_guess && nx == 3) break;
+            const int nlines = n / L;
+            for (int l = tid; l < nlines; l += PP_WG) {
+                int base, stride;
+                if (axis == 2) { base = l * px; stride = 1; }
+                else {
+                    const int t = (int)(((float)l + 0.5f) * inv_nx);
+                    const int x = l - t * nx;
+                    if (axis == 0) { base = t * px + x; stride = ny * px; }
+                    else { base = t * ny * px + x; stride = px; }
+                }
+                pp_line_pass(tile, base, stride, L, A);
+            }
+            __syncthreads();
+        }
+    }
+
+    // 5. unsharp mask (+ erosion), write out
+    const bool erode = flags & MMX_PP_ERODED;
+    for (int i = tid; i < n; i += PP_WG) {
+        const int t = (int)(((float)i + 0.5f) * inv_nx);
+        const int x = i - t * nx;
+        const int z = (int)(((float)t + 0.5f) * inv_ny);
+        const int y = t - z * ny;
+        const int pos = t * px + x;
+        double o;
+        if (A.do_unsharp) {
+            const double den = pp_clip(S((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
+            const double m = A.strength * tile[pos];
+            const double hp = den - m;
+            o = den + hp;
+        } else {
+            o = tile[pos];
+        }
+        if (erode) tile[pos] = o;
+        else {
+            const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
+            out64[d] = o;
+            out32[d] = (float)o;
+        }
+    }
+    if (!erode) return;
+    __syncthreads();
+    for (int i = tid; i < n; i += PP_WG) {
+        const int t = (int)(((float)i + 0.5f) * inv_nx);
+        const int x = i - t * nx;
+        const int z = (int)(((float)t + 0.5f) * inv_ny);
+        const int y = t - z * ny;
+        const int pos = t * px + x;
+        double o = tile[pos];
+        if (x > 0) o = fmin(o, tile[pos - 1]);
+        if (x < nx - 1) o = fmin(o, tile[pos + 1]);
+        if (y > 0) o = fmin(o, tile[pos - px]);
+        if (y < ny - 1) o = fmin(o, tile[pos + px]);
+        if (z > 0) o = fmin(o, tile[pos - ny * px]);
+        if (z < nz - 1) o = fmin(o, tile[pos + ny * px]);
+        const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
+        out64[d] = o;
+        out32[d] = (float)o;
+    }
+}
+
+// ---- any extent: data in a global scratch (2 * n doubles per sub-block), one output per lane and pass
+template <typename InT>
+__global__ void __launch_bounds__(PP_WG_GENERIC)
+pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
+                  const mmx_subblock* __restrict__ subs, const mmx_quantile_class* __restrict__ qcs,
+                  pp_args A, float* __restrict__ out32, double* __restrict__ out64,
+                  mmx_subblock_info* __restrict__ info, double* __restrict__ scratch)
+{
+    __shared__ uint32_t hist[PP_HIST];
+    __shared__ int s_bin[4];
+    __shared__ uint32_t s_res[4];
+    __shared__ int s_val[4];
+    __shared__ double s_red[PP_WG_GENERIC / 64];
+    __shared__ double s_mean;
+    __shared__ int s_flags;
+    __shared__ pp_stack s_stack;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const mmx_subblock sb = subs[blockIdx.x];
+    const int64_t nz = sb.nz, ny = sb.ny, nx = sb.nx, n = nz * ny * nx;
+    const InT* src = vol + sb.src_off;
+    double* bufA = scratch + sb.scratch_off;
+    double* bufB = bufA + n;
+    auto raw = [&](int64_t i) {
+        const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
+        return (int)src[z * sz + y * sy + x * sx];
+    };
+
+    for (int i = tid; i < PP_HIST; i += PP_WG_GENERIC) hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+        const int v = raw(i);
+        bufA[i] = (double)v;
+        atomicAdd(&hist[v >> 8], 1u);
+    }
+    __syncthreads();
+    const mmx_quantile_class qc = qcs[sb.qclass];
+    if (wave < 4) {
+        const uint32_t rank = wave == 0 ? qc.lo_prev : wave == 1 ? qc.lo_next : wave == 2 ? qc.hi_prev : qc.hi_next;
+        int b; uint32_t r;
+        pp_select(hist, rank, b, r);
+        if (lane == 0) { s_bin[wave] = b; s_res[wave] = r; }
+    }
+    __syncthreads();
+    {
+        const int b0 = s_bin[0], b1 = s_bin[1], b2 = s_bin[2], b3 = s_bin[3];
+        for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+            const int v = (int)bufA[i];
+            const int hi = v >> 8, lo = v & 255;
+            if (hi == b0) atomicAdd(&hist[256 + lo], 1u);
+            if (hi == b1) atomicAdd(&hist[512 + lo], 1u);
+            if (hi == b2) atomicAdd(&hist[768 + lo], 1u);
+            if (hi == b3) atomicAdd(&hist[1024 + lo], 1u);
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+        int b; uint32_t r;
+        pp_select(hist + 256 * (1 + wave), s_res[wave], b, r);
+        if (lane == 0) s_val[wave] = (s_bin[wave] << 8) | b;
+    }
+    __syncthreads();
+
+    pp_sat S;
+    {
+        const double vmin = pp_lerp(s_val[0], s_val[1], qc.lo_gamma);
+        double vmax = pp_lerp(s_val[2], s_val[3], qc.hi_gamma);
+        S.identity = vmin == vmax;
+        if (vmax < A.max_thresh) vmax = A.max_thresh;
+        S.vmin = vmin; S.vmax = vmax; S.span = vmax - vmin;
+    }
+
+    double part = 0.;
+    for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+        const double s = S(bufA[i]);
+        part += s;
+        bufA[i] = pp_clip(s, A.clip_min, A.clip_max);
+    }
+    part = pp_wave_sum(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.;
+        for (int w = 0; w < PP_WG_GENERIC / 64; ++w) tot += s_red[w];
+        double mean = tot / (double)n;
+        int flags = S.identity ? MMX_PP_IDENTITY : 0;
+        if (A.do_erosion) {
+            const double tol = 1e-9 * (fabs(A.ero_thr) > 1. ? fabs(A.ero_thr) : 1.);
+            if (!S.identity && fabs(mean - A.ero_thr) <= tol && n < (1ll << 31)) {
+                auto val = [&](int i) { return S((double)raw(i)); };
+                mean = pp_pairwise(val, (int)n, &s_stack) / (double)n;
+                flags |= MMX_PP_EXACT_MEAN;
+            }
+            if (mean > A.ero_thr) flags |= MMX_PP_ERODED;
+        }
+        s_mean = mean;
+        s_flags = flags;
+    }
+    __syncthreads();
+    const int flags = s_flags;
+    if (info && tid == 0) {
+        mmx_subblock_info o;
+        o.vmin = S.vmin; o.vmax = S.vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
+        info[blockIdx.x] = o;
+    }
+
+    double* cur = bufA;
+    double* oth = bufB;
+    if (A.do_unsharp) {
+#pragma unroll 1
+        for (int axis = 0; axis < 3; ++axis) {
+            if (axis == 2 && A.rgb_guess && nx == 3) break;
+            const int64_t L = axis == 0 ? nz : axis == 1 ? ny : nx;
+            const int64_t stride = axis == 0 ? ny * nx : axis == 1 ? nx : 1;
+            for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+                const int64_t c = (i / stride) % L;
+                const double* line = cur + (i - c * stride);
+                double acc = line[c * stride] * A.w[0];
+                for (int k = PP_R; k >= 1; --k) {
+                    const int64_t a = c - k < 0 ? 0 : c - k;
+                    const int64_t b = c + k > L - 1 ? L - 1 : c + k;
+                    acc += (line[a * stride] + line[b * stride]) * A.w[k];
+                }
+                oth[i] = acc;
+            }
+            __syncthreads();
+            double* t = cur; cur = oth; oth = t;
+        }
+    }
+
+    const bool erode = flags & MMX_PP_ERODED;
+    for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+        const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
+        double o;
+        if (A.do_unsharp) {
+            const double den = pp_clip(S((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
+            const double m = A.strength * cur[i];
+            const double hp = den - m;
+            o = den + hp;
+        } else {
+            o = cur[i];
+        }
+        if (erode) oth[i] = o;
+        else {
+            const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
+            out64[d] = o;
+            out32[d] = (float)o;
+        }
+    }
+    if (!erode) return;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+        const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
+        double o = oth[i];
+        if (x > 0) o = fmin(o, oth[i - 1]);
+        if (x < nx - 1) o = fmin(o, oth[i + 1]);
+        if (y > 0) o = fmin(o, oth[i - nx]);
+        if (y < ny - 1) o = fmin(o, oth[i + nx]);
+        if (z > 0) o = fmin(o, oth[i - ny * nx]);
+        if (z < nz - 1) o = fmin(o, oth[i + ny * nx]);
+        const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
+        out64[d] = o;
+        out32[d] = (float)o;
+    }
+}
+
+pp_args pp_make_args(const mmx_preproc_params* p, const double* h_w, int64_t dst_sy, int64_t dst_sz)
+{
+    pp_args A;
+    for (int k = 0; k <= PP_R; ++k) A.w[k] = h_w[k];
+    A.clip_min = p->clip_min; A.clip_max = p->clip_max; A.max_thresh = p->max_thresh;
+    A.strength = p->unsharp_strength; A.ero_thr = p->erosion_threshold;
+    A.dst_sy = dst_sy; A.dst_sz = dst_sz;
+    A.do_unsharp = p->unsharp_strength != 0.0;          // Python truthiness: `if unsharp_strength:`
+    A.do_erosion = p->erosion_threshold != 0.0;         // `if thresh_eros and ...`
+    A.rgb_guess = p->rgb_guess;
+    A._pad = 0;
+    return A;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mmx_preprocess_fast_lds(int nz, int ny, int nx)
+{
+    if (nz < 1 || ny < 1 || nx < 1 || nz > PP_MAXL || ny > PP_MAXL || nx > PP_MAXL) return 0;
+    const int64_t b = (int64_t)nz * ny * (nx | 1) * (int64_t)sizeof(double) + PP_HIST * (int64_t)sizeof(uint32_t);
+    return b <= MMX_PP_MAX_LDS - 2048 ? b : 0;     // 2 KiB of static LDS (selection, recursion stack)
+}
+
+static int pp_check(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx_subblock* h_subs, int n_subs,
+                    const mmx_quantile_class* d_qc, int n_qc, const mmx_preproc_params* p, const double* h_w,
+                    float* d_out32, double* d_out64)
+{
+    if (!vol || !vol->d_data || !d_subs || !h_subs || n_subs < 0 || !d_qc || n_qc < 1 || !p || !h_w ||
+        !d_out32 || !d_out64)
+        return MMX_ERR_ARG;
+    if (p->radius != PP_R) return MMX_ERR_UNSUPPORTED;
+    if (vol->dtype != MMX_U8 && vol->dtype != MMX_U16) return MMX_ERR_UNSUPPORTED;
+    for (int i = 0; i < n_subs; ++i) {
+        const mmx_subblock& b = h_subs[i];
+        if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.qclass < 0 || b.qclass >= n_qc || b.src_off < 0 || b.dst_off < 0)
+            return MMX_ERR_ARG;
+    }
+    return MMX_OK;
+}
+
+int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx_subblock* h_subs,
+                         int n_subs, const mmx_quantile_class* d_qclasses, int n_qclasses,
+                         const mmx_preproc_params* params, const double* h_weights,
+                         int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
+                         mmx_subblock_info* d_info, void* stream)
+{
+    const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, h_weights, d_out32, d_out64);
+    if (st != MMX_OK) return st;
+    if (n_subs == 0) return MMX_OK;
+    int64_t lds = 0;
+    for (int i = 0; i < n_subs; ++i) {
+        const int64_t b = mmx_preprocess_fast_lds(h_subs[i].nz, h_subs[i].ny, h_subs[i].nx);
+        if (!b) return MMX_ERR_UNSUPPORTED;
+        lds = b > lds ? b : lds;
+    }
+    const pp_args A = pp_make_args(params, h_weights, dst_sy, dst_sz);
+    hipStream_t s = (hipStream_t)stream;
+    mmx_timed_scope ts(MMX_K_PREPROC, s);
+    if (vol->dtype == MMX_U16) {
+        auto k = pp_fast_kernel<uint16_t>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MMX_ERR_HIP;
+        hipLaunchKernelGGL(k, dim3(n_subs), dim3(PP_WG), (size_t)lds, s, (const uint16_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, d_qclasses, A, d_out32, d_out64, d_info);
+    } else {
+        auto k = pp_fast_kernel<uint8_t>;
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return MMX_ERR_HIP;
+        hipLaunchKernelGGL(k, dim3(n_subs), dim3(PP_WG), (size_t)lds, s, (const uint8_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, d_qclasses, A, d_out32, d_out64, d_info);
+    }
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_subs,
+                                 const mmx_subblock* h_subs, int n_subs,
+                                 const mmx_quantile_class* d_qclasses, int n_qclasses,
+                                 const mmx_preproc_params* params, const double* h_weights,
+                                 int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
+                                 mmx_subblock_info* d_info, double* d_scratch, int64_t scratch_doubles,
+                                 void* stream)
+{
+    const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, h_weights, d_out32, d_out64);
+    if (st != MMX_OK) return st;
+    if (n_subs == 0) return MMX_OK;
+    if (!d_scratch) return MMX_ERR_ARG;
+    for (int i = 0; i < n_subs; ++i) {
+        const mmx_subblock& b = h_subs[i];
+        const int64_t n = (int64_t)b.nz * b.ny * b.nx;
+        if (b.scratch_off < 0 || b.scratch_off + 2 * n > scratch_doubles) return MMX_ERR_WORKSPACE;
+    }
+    const pp_args A = pp_make_args(params, h_weights, dst_sy, dst_sz);
+    hipStream_t s = (hipStream_t)stream;
+    mmx_timed_scope ts(MMX_K_PREPROC, s);
+    if (vol->dtype == MMX_U16)
+        hipLaunchKernelGGL(pp_generic_kernel<uint16_t>, dim3(n_subs), dim3(PP_WG_GENERIC), 0, s,
+                           (const uint16_t*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_subs,
+                           d_qclasses, A, d_out32, d_out64, d_info, d_scratch);
+    else
+        hipLaunchKernelGGL(pp_generic_kernel<uint8_t>, dim3(n_subs), dim3(PP_WG_GENERIC), 0, s,
+                           (const uint8_t*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_subs,
+                           d_qclasses, A, d_out32, d_out64, d_info, d_scratch);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+}  // extern "C"

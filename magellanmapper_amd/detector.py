@@ -363,15 +363,21 @@ def detect_blobs(roi, channel: Optional[Sequence[int]],
 
 
 def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
-                               on_block=None) -> List[Optional[np.ndarray]]:
+                               on_block=None, denoise_max_shape=None) -> List[Optional[np.ndarray]]:
     """:func:`detect_blobs` for many blocks of one resident volume in one device pass.
 
     Returns one 11-column table (block-relative coordinates) or ``None`` per block, rows
     ordered as the reference orders them: channels in turn, within a channel the pruned
     ``blob_log`` order.  ``on_block(i, table)`` (optional) post-processes each finished block
     table while the GPU is still busy with later batches; its return value replaces the table.
+    With ``denoise_max_shape`` every block is saturated + denoised tile by tile on the device
+    first (reference stack_detect.py:122-150; :mod:`preprocess`).
     """
     from . import blob_log as bl
+    pre = None
+    if denoise_max_shape is not None:
+        from . import preprocess
+        pre = preprocess.Preprocessor(denoise_max_shape)
     multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
     first = config.get_roi_profile(list(channels)[0])
     if first["isotropic"] is not None:
@@ -407,7 +413,7 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
             min_sigma=settings["min_sigma_factor"] * scaling_factor,
             max_sigma=settings["max_sigma_factor"] * scaling_factor,
             num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
-            overlap=settings["overlap"], stats=stats, on_batch=to_tables)
+            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=pre)
     return done
 
 

@@ -1,0 +1,293 @@
+"""Per-block preprocessing on the device: contrast stretch, unsharp mask, erosion.
+
+Mirror of the sub-sub-block loop of ``StackDetector.detect_sub_roi`` (reference
+magmap/cv/stack_detect.py:122-150): every detection block is cut into
+``denoise_max_shape`` tiles (``chunking.stack_splitter`` without overlap), each tile goes through
+``plot_3d.saturate_roi`` (magmap/plot/plot_3d.py:55-112) and ``plot_3d.denoise_roi`` (:115-172)
+on its own, and the float64 results are merged back into the block that ``detect_blobs`` sees.
+Here one HIP workgroup does all of that for one tile (``csrc/mmx_preproc.hip``), bit for bit.
+
+Host side of the exactness contract (the parts that are cheaper to state in NumPy than on the
+device, all O(number of distinct tile sizes)):
+
+* :func:`quantile_ranks` -- the index arithmetic of ``np.percentile(..., method="linear")``
+  (numpy/lib/_function_base_impl.py ``_quantile`` / ``_get_indexes`` / ``_get_gamma``);
+* the sigma-8 Gaussian weights, built like ``scipy.ndimage._filters._gaussian_kernel1d``
+  (:mod:`kernels1d`).
+
+Scope: uint8 / uint16 voxels (what microscopes write); ``tot_var_denoise`` profiles raise
+``NotImplementedError``.  scikit-image < 0.19 treats a 3-D array whose last axis has length 3
+as RGB inside ``filters.gaussian``; the reference pins 0.25 (no such guess), :data:`RGB_GUESS`
+switches the old behaviour on for the golden fixtures made with 0.18.3.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+try:
+    import torch
+except ImportError:  # pragma: no cover
+    torch = None
+
+from . import _native as nat
+from . import config, kernels1d
+
+GAUSS_SIGMA = 8.0                    # hard-coded in the reference (plot_3d.py:151)
+#: scikit-image < 0.19 ``filters.gaussian`` RGB guess for ``(M, N, 3)`` arrays
+RGB_GUESS = False
+#: test hook: half kernel ``w[0..32]`` to use instead of this NumPy's (``np.exp`` is not bit-stable
+#: across NumPy releases and the golden fixtures were made under NumPy 1.26)
+GAUSS_WEIGHTS_OVERRIDE: Optional[np.ndarray] = None
+#: test hook: send every tile through the generic (global-scratch) kernel
+FORCE_GENERIC = False
+
+
+def gauss_weights() -> np.ndarray:
+    if GAUSS_WEIGHTS_OVERRIDE is not None:
+        return np.ascontiguousarray(GAUSS_WEIGHTS_OVERRIDE, dtype=np.float64)
+    return kernels1d.gaussian_half_kernel(GAUSS_SIGMA, 0, kernels1d.kernel_radius(GAUSS_SIGMA))
+
+
+def quantile_ranks(n: int, pct) -> Tuple[int, int, float]:
+    """``(prev, next, gamma)`` of ``np.percentile(a, pct)`` for ``a.size == n`` (method "linear"):
+    the result is ``_lerp(sorted(a)[prev], sorted(a)[next], gamma)``."""
+    if not 0 <= pct <= 100:
+        raise ValueError("Percentiles must be in the range [0, 100]")
+    q = np.true_divide(np.asanyarray(pct, dtype=np.float64), 100)
+    virt = (n - 1) * q
+    prev = np.floor(virt)
+    nxt = prev + 1
+    if virt >= n - 1:
+        prev = nxt = -1.0
+    gamma = float(virt - prev)              # NumPy subtracts the *fixed* index (gamma is unused then)
+    prev_i, next_i = int(prev), int(nxt)
+    if prev_i < 0:
+        prev_i = next_i = n - 1
+    return prev_i, next_i, gamma
+
+
+def _tile_grid(shape: Sequence[int], dms: Sequence[int]):
+    """Tile origins and extents of one block, C order (chunking.stack_splitter, no overlap)."""
+    axes = []
+    for n, d in zip(shape, dms):
+        starts = np.arange(0, n, d, dtype=np.int64)
+        axes.append((starts, np.minimum(d, n - starts)))
+    oz, oy, ox = np.meshgrid(axes[0][0], axes[1][0], axes[2][0], indexing="ij")
+    ez, ey, ex = np.meshgrid(axes[0][1], axes[1][1], axes[2][1], indexing="ij")
+    return (np.stack([oz.ravel(), oy.ravel(), ox.ravel()], axis=1),
+            np.stack([ez.ravel(), ey.ravel(), ex.ravel()], axis=1))
+
+
+def channel_params(chl: int, near_max: Optional[Sequence[float]] = None) -> Tuple[nat.PreprocParams, float, float]:
+    """C-ABI parameters of one channel from its ROI profile + ``config.near_max``, read at call
+    time like the reference does (plot_3d.py:84-99, 141-163)."""
+    settings = config.get_roi_profile(chl)
+    if settings["tot_var_denoise"]:
+        raise NotImplementedError(
+            "total-variation denoising (profile 'tot_var_denoise', reference plot_3d.py:147-149) "
+            "is not built; stock nuclei profiles leave it off")
+    near = config.near_max if near_max is None else near_max
+    max_thresh = near[chl] * settings["max_thresh_factor"]       # IndexError like the reference
+    strength = settings["unsharp_strength"] or 0.0
+    ero = settings["erosion_threshold"] or 0.0
+    p = nat.PreprocParams(float(settings["clip_min"]), float(settings["clip_max"]), float(max_thresh),
+                          float(strength), float(ero), kernels1d.kernel_radius(GAUSS_SIGMA),
+                          1 if RGB_GUESS else 0)
+    return p, settings["clip_vmin"], settings["clip_vmax"]
+
+
+class Preprocessor:
+    """Preprocesses the blocks of a batch into uniform-stride float32 / float64 slots."""
+
+    def __init__(self, denoise_max_shape: Sequence[int], near_max: Optional[Sequence[float]] = None,
+                 want_info: bool = False):
+        dms = [int(v) for v in denoise_max_shape]
+        if len(dms) != 3 or min(dms) < 1:
+            raise ValueError("denoise_max_shape must be three positive sizes")
+        self.dms = dms
+        self.near_max = near_max
+        self.want_info = want_info
+        self._out64 = [None, None]
+        self._out32 = None
+        self._scratch = None
+        self._tiles: Dict[Tuple[int, int, int], Tuple[np.ndarray, np.ndarray]] = {}
+        self.last_info: Optional[np.ndarray] = None
+        self.last_subs: Optional[np.ndarray] = None
+
+    # ---- geometry
+    @staticmethod
+    def bytes_per_voxel() -> int:
+        """Extra HBM per block voxel: one float32 slot + two (double-buffered) float64 slots."""
+        return 4 + 2 * 8
+
+    def value_scale(self, channels: Sequence[int]) -> float:
+        """Bound on |preprocessed voxel|: den + (den - s*blur) with den, blur in [clip_min, clip_max]."""
+        m = 1.0
+        for chl in channels:
+            s = config.get_roi_profile(chl)
+            c = max(abs(float(s["clip_min"])), abs(float(s["clip_max"])))
+            m = max(m, 2 * c + abs(float(s["unsharp_strength"] or 0.0)) * c)
+        return m
+
+    def _grid(self, shape):
+        shape = tuple(int(v) for v in shape)
+        if shape not in self._tiles:
+            self._tiles[shape] = _tile_grid(shape, self.dms)
+        return self._tiles[shape]
+
+    def _buffer(self, name, which, n_elems, dtype, dev):
+        cur = getattr(self, name)
+        t = cur if which is None else cur[which]
+        if t is None or t.numel() < n_elems or t.device != dev:
+            t = torch.empty(int(n_elems), dtype=dtype, device=dev)
+            if which is None:
+                setattr(self, name, t)
+            else:
+                cur[which] = t
+        return t
+
+    def run(self, dvol, channel: int, origins, shapes, which: int = 0):
+        """Enqueue the preprocessing of the given blocks of channel ``channel`` on the current
+        stream.  Returns ``(blocks, slot_elems, vol32, vol64)``: the ``mmx_block`` table whose
+        ``src_off`` point into the preprocessed slots, the LoG workspace slot size and the two
+        ``mmx_volume`` views (float32 for the passes, float64 for the exact re-score)."""
+        L = nat.lib()
+        dev = dvol.tensor.device
+        if dvol.np_dtype not in (np.dtype(np.uint8), np.dtype(np.uint16)):
+            raise NotImplementedError(
+                f"device preprocessing reads uint8 / uint16 voxels, not {dvol.np_dtype}")
+        params, pct_lo, pct_hi = channel_params(int(channel), self.near_max)
+        nb = len(shapes)
+        shp = np.asarray(shapes, dtype=np.int64).reshape(nb, 3)
+        org = np.asarray(origins, dtype=np.int64).reshape(nb, 3)
+        for ax in range(3):
+            if (org[:, ax] < 0).any() or (shp[:, ax] < 1).any() or (org[:, ax] + shp[:, ax] > dvol.shape[ax]).any():
+                raise ValueError("block outside the volume")
+        # uniform slot geometry: rows 128-byte aligned like the LoG workspace
+        sx = int(-(-shp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
+        sy_rows = int(shp[:, 1].max())
+        dst_sy, dst_sz = sx, sx * sy_rows
+        slot_pre = dst_sz * int(shp[:, 0].max())
+        t = dvol.tensor
+        vsz, vsy, vsx = (int(v) for v in t.stride()[:3])
+        # sub-block table
+        subs_parts = []
+        for i in range(nb):
+            o, e = self._grid(shp[i])
+            part = np.zeros(len(o), dtype=nat.SUBBLOCK_DTYPE)
+            part["src_off"] = ((org[i, 0] + o[:, 0]) * vsz + (org[i, 1] + o[:, 1]) * vsy
+                               + (org[i, 2] + o[:, 2]) * vsx)
+            part["dst_off"] = i * slot_pre + o[:, 0] * dst_sz + o[:, 1] * dst_sy + o[:, 2]
+            part["nz"], part["ny"], part["nx"] = e[:, 0], e[:, 1], e[:, 2]
+            subs_parts.append(part)
+        subs = np.concatenate(subs_parts) if subs_parts else np.zeros(0, dtype=nat.SUBBLOCK_DTYPE)
+        nvox = subs["nz"].astype(np.int64) * subs["ny"] * subs["nx"]
+        sizes, inverse = np.unique(nvox, return_inverse=True)
+        qc = np.zeros(len(sizes), dtype=nat.QCLASS_DTYPE)
+        for j, n in enumerate(sizes):
+            lp, ln, lg = quantile_ranks(int(n), pct_lo)
+            hp, hn, hg = quantile_ranks(int(n), pct_hi)
+            qc[j] = (lp, ln, hp, hn, lg, hg)
+        subs["qclass"] = inverse.astype(np.int32)
+        dims = np.stack([subs["nz"], subs["ny"], subs["nx"]], axis=1)
+        uniq, inv = np.unique(dims, axis=0, return_inverse=True)
+        ok = np.array([L.mmx_preprocess_fast_lds(int(u[0]), int(u[1]), int(u[2])) != 0 for u in uniq],
+                      dtype=bool)
+        is_fast = ok[inv.reshape(-1)] if len(subs) else np.zeros(0, dtype=bool)
+        if FORCE_GENERIC:
+            is_fast[:] = False
+        order = np.concatenate([np.nonzero(is_fast)[0], np.nonzero(~is_fast)[0]])
+        subs = subs[order]
+        n_fast = int(is_fast.sum())
+        n_gen = len(subs) - n_fast
+        if n_gen:
+            gen_n = (subs["nz"][n_fast:].astype(np.int64) * subs["ny"][n_fast:] * subs["nx"][n_fast:])
+            offs = np.concatenate([[0], np.cumsum(2 * gen_n)])
+            subs["scratch_off"][n_fast:] = offs[:-1]
+            scratch = self._buffer("_scratch", None, int(offs[-1]), torch.float64, dev)
+        out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)
+        out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
+        d_subs = torch.from_numpy(subs.view(np.uint8).reshape(-1)).to(dev, non_blocking=False)
+        d_qc = torch.from_numpy(qc.view(np.uint8).reshape(-1)).to(dev)
+        d_info = None
+        if self.want_info:
+            d_info = torch.zeros(len(subs) * nat.SUBINFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        weights = gauss_weights()
+        if len(weights) != params.radius + 1:
+            raise nat.MmxError("Gaussian half kernel has the wrong length")
+        vol = dvol.view(channel, False)
+        stream = torch.cuda.current_stream().cuda_stream
+        item = nat.SUBBLOCK_DTYPE.itemsize
+        info_ptr = d_info.data_ptr() if d_info is not None else None
+        if n_fast:
+            nat.check(L.mmx_preprocess_batch(
+                ctypes.byref(vol), d_subs.data_ptr(), subs.ctypes.data, n_fast, d_qc.data_ptr(), len(qc),
+                ctypes.byref(params), nat.as_double_ptr(weights), dst_sy, dst_sz,
+                out32.data_ptr(), out64.data_ptr(), info_ptr, stream), "mmx_preprocess_batch")
+        if n_gen:
+            nat.check(L.mmx_preprocess_batch_generic(
+                ctypes.byref(vol), d_subs.data_ptr() + n_fast * item, subs.ctypes.data + n_fast * item,
+                n_gen, d_qc.data_ptr(), len(qc), ctypes.byref(params), nat.as_double_ptr(weights),
+                dst_sy, dst_sz, out32.data_ptr(), out64.data_ptr(),
+                (info_ptr + n_fast * nat.SUBINFO_DTYPE.itemsize) if info_ptr else None,
+                scratch.data_ptr(), int(scratch.numel()), stream), "mmx_preprocess_batch_generic")
+        self.last_subs = subs
+        self._keep = (d_subs, d_qc, d_info)
+        if d_info is not None:
+            self.last_info = d_info        # device bytes; see info()
+        # block table over the preprocessed slots
+        blocks = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
+        slot = 1
+        for i in range(nb):
+            px = -(-int(shp[i, 2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN
+            blocks[i] = (i * slot_pre, shp[i, 0], shp[i, 1], shp[i, 2], i, px, 0)
+            slot = max(slot, int(shp[i, 0]) * int(shp[i, 1]) * px)
+        vol32 = nat.Volume(out32.data_ptr(), nat.MMX_F32, 0, dst_sz, dst_sy, 1)
+        vol64 = nat.Volume(out64.data_ptr(), nat.MMX_F64, 0, dst_sz, dst_sy, 1)
+        self.last_geometry = (slot_pre, dst_sz, dst_sy, out64, out32)
+        return blocks, slot, vol32, vol64
+
+    def info(self) -> np.ndarray:
+        """Per-sub-block diagnostics of the last :meth:`run` (``want_info=True``), in ``last_subs`` order."""
+        if self.last_info is None:
+            raise ValueError("run() was not asked for diagnostics")
+        return self.last_info.cpu().numpy().view(nat.SUBINFO_DTYPE)
+
+    def fetch(self, shapes, which: int = 0) -> List[np.ndarray]:
+        """The float64 preprocessed blocks of the last :meth:`run` as host arrays."""
+        slot_pre, dst_sz, dst_sy, out64, _ = self.last_geometry
+        torch.cuda.current_stream().synchronize()
+        res = []
+        for i, s in enumerate(shapes):
+            nz, ny, nx = (int(v) for v in s)
+            flat = out64[i * slot_pre:(i + 1) * slot_pre]
+            view = torch.as_strided(flat, (nz, ny, nx), (dst_sz, dst_sy, 1))
+            res.append(view.cpu().numpy().copy())
+        return res
+
+
+def preprocess_roi(roi, denoise_max_shape, channel: Optional[Sequence[int]] = None,
+                   near_max: Optional[Sequence[float]] = None, return_info: bool = False):
+    """Saturate + denoise a ``(z, y, x[, c])`` block tile by tile -> float64 array of the same
+    shape: what ``detect_sub_roi`` hands to ``detect_blobs`` (stack_detect.py:122-150).
+    Channels not selected stay zero, as in the reference."""
+    from . import blob_log as bl
+    from .detector import _channels_of
+    dvol = roi if isinstance(roi, bl.DeviceVolume) else bl.DeviceVolume(roi)
+    multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
+    out = np.zeros(dvol.shape, dtype=np.float64)
+    infos = []
+    for chl in channels:
+        pre = Preprocessor(denoise_max_shape, near_max, want_info=return_info)
+        pre.run(dvol, chl if multichannel else 0, [(0, 0, 0)], [dvol.shape[:3]])
+        block = pre.fetch([dvol.shape[:3]])[0]
+        if multichannel:
+            out[..., chl] = block
+        else:
+            out = block
+        if return_info:
+            infos.append((pre.last_subs, pre.info()))
+    return (out, infos) if return_info else out

@@ -154,9 +154,18 @@ class StackDetector:
                        sub_roi, channel, img_path=None, coloc=False):
         """One block given as an array -> ``(coord, table | None)`` with coordinates shifted
         to the full ROI (both the rel and the abs set, :164-170)."""
-        _check_unbuilt(denoise_max_shape, coloc)
+        _check_unbuilt(coloc)
         exclude = cls._exclude_matrix(coord, last_coord, exclude_border)
-        segments = detector.detect_blobs(sub_roi, channel, exclude)
+        if denoise_max_shape is None:
+            segments = detector.detect_blobs(sub_roi, channel, exclude)
+        else:
+            # saturate + denoise tile by tile (:122-150), then detect on the float64 result
+            from . import blob_log as bl
+            dvol = sub_roi if isinstance(sub_roi, bl.DeviceVolume) else bl.DeviceVolume(sub_roi)
+            segments = detector.detect_blobs_blocks_device(
+                dvol, channel, [(0, 0, 0)], [dvol.shape[:3]], denoise_max_shape=denoise_max_shape)[0]
+            if segments is not None and exclude is not None:
+                segments = detector.get_blobs_interior(segments, dvol.shape[:3], *exclude)
         if segments is not None:
             detector.Blobs.shift_blob_rel_coords(segments, offset)
             detector.Blobs.shift_blob_abs_coords(segments, offset)
@@ -172,7 +181,7 @@ class StackDetector:
         """
         from . import blob_log as bl
         from . import dist
-        _check_unbuilt(denoise_max_shape, coloc)
+        _check_unbuilt(coloc)
         cls.img5d, cls.img, cls.channel, cls.coloc = img5d, img, channel, coloc
         cls.denoise_max_shape, cls.exclude_border = denoise_max_shape, exclude_border
         grid = sub_roi_slices.shape
@@ -203,7 +212,8 @@ class StackDetector:
 
         if mine:
             dvol = img if isinstance(img, bl.DeviceVolume) else bl.DeviceVolume(img)
-            tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish)
+            tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
+                                                         denoise_max_shape=denoise_max_shape)
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
         seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
@@ -216,11 +226,7 @@ class StackDetector:
         return seg_rois
 
 
-def _check_unbuilt(denoise_max_shape, coloc):
-    if denoise_max_shape is not None:
-        raise NotImplementedError(
-            "per-block preprocessing (saturate_roi / denoise_roi, reference stack_detect.py:122-150) "
-            "is not built yet (SURVEY.md section 8f row 1); set the profile's denoise_size to None")
+def _check_unbuilt(coloc):
     if coloc:
         raise NotImplementedError(
             "intensity co-localisation (reference colocalizer.py:340-441) is not built yet "

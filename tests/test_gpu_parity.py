@@ -240,17 +240,30 @@ def test_detect_blobs_matches_reference(gpu, case):
     np.testing.assert_array_equal(table, g["table"])
 
 
+@pytest.fixture
+def golden_preproc_env(monkeypatch):
+    """The environment the preprocessing fixtures were made in: scikit-image 0.18.3 (RGB guess in
+    filters.gaussian) and NumPy 1.26 (its np.exp gives the sigma-8 weights stored in preproc.npz)."""
+    from magellanmapper_amd import config, preprocess
+    w = load_golden("preproc.npz")["gauss8_weights"]
+    monkeypatch.setattr(preprocess, "RGB_GUESS", True)
+    monkeypatch.setattr(preprocess, "GAUSS_WEIGHTS_OVERRIDE", np.ascontiguousarray(w[32:]))
+    yield
+    config.near_max = [-1.0]
+
+
 @pytest.mark.parametrize("case", STACK_CASES)
-def test_detect_blobs_blocks_matches_reference(gpu, case, tmp_path, monkeypatch):
-    """A8-A14: per-block tables, merged table and final 8-column table identical to the
-    real reference's ``detect_blobs_blocks``."""
+def test_detect_blobs_blocks_matches_reference(gpu, case, tmp_path, monkeypatch, golden_preproc_env):
+    """A8-A14 (and P1-P3 for the ``denoise*`` cases): per-block tables, merged table and final
+    8-column table identical to the real reference's ``detect_blobs_blocks``."""
     from magellanmapper_amd import chunking, config, stack_detect
     monkeypatch.chdir(tmp_path)
     g = load_golden("stack_%s.npz" % case)
     over = ast.literal_eval(str(g["overrides"]))
     config.setup_roi_profiles(None)
-    config.roi_profile.update(over)
     config.roi_profile["denoise_size"] = None
+    config.roi_profile.update(over)
+    config.near_max = list(g["near_max"]) if "near_max" in g else [-1.0]
     config.resolutions = g["resolutions"]
     config.filename = "golden"
     channels = None if g["channels"].ndim == 0 else list(g["channels"])

@@ -1,0 +1,172 @@
+"""GPU parity tests of the per-block preprocessing: the HIP kernels
+(through the C ABI) against the golden vectors of the real reference's ``plot_3d.saturate_roi`` /
+``plot_3d.denoise_roi`` and against the CPU oracle.  Everything is float64 and compared BIT FOR BIT.
+"""
+import ast
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+PREPROC = load_golden("preproc.npz")
+CASES = [str(n) for n in PREPROC["names"]]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    from magellanmapper_amd import _native
+    assert _native.lib().mmx_device_count() >= 1
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture
+def env(monkeypatch):
+    """scikit-image 0.18.3 + NumPy 1.26 behaviour of the fixtures (see golden_preproc_env)."""
+    from magellanmapper_amd import config, preprocess
+    from oracle import preprocess_oracle as ppo
+    monkeypatch.setattr(preprocess, "RGB_GUESS", True)
+    monkeypatch.setattr(preprocess, "GAUSS_WEIGHTS_OVERRIDE",
+                        np.ascontiguousarray(PREPROC["gauss8_weights"][32:]))
+    monkeypatch.setattr(ppo, "GAUSS_WEIGHTS", PREPROC["gauss8_weights"])
+    yield
+    config.setup_roi_profiles(None)
+    config.near_max = [-1.0]
+
+
+def _set_profiles(over, n=1):
+    from magellanmapper_amd import config
+    config.setup_roi_profiles(["default"] * n)
+    for i, p in enumerate(config.roi_profiles):
+        for k, v in over.items():
+            p[k] = v["per_channel"][i] if isinstance(v, dict) and "per_channel" in v else v
+    return [dict(p) for p in config.roi_profiles]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tile_matches_reference(gpu, env, case):
+    """One tile == one call of saturate_roi + denoise_roi of the real reference."""
+    from magellanmapper_amd import _native as nat, preprocess
+    g = PREPROC
+    roi = g[case + "_roi"]
+    over = ast.literal_eval(str(g[case + "_over"]))
+    _set_profiles(over, 2 if case == "2ch_perchl" else 1)
+    near_max = list(g[case + "_near_max"])
+    got, infos = preprocess.preprocess_roi(roi, roi.shape[:3], near_max=near_max, return_info=True)
+    assert got.dtype == np.float64
+    np.testing.assert_array_equal(got, g[case + "_den"])
+    # the percentiles themselves, against this NumPy
+    for c, (subs, info) in enumerate(infos):
+        plane = roi[..., c] if roi.ndim == 4 else roi
+        prof = _set_profiles(over, 2 if case == "2ch_perchl" else 1)[c if case == "2ch_perchl" else 0]
+        vmin, vmax = np.percentile(plane, (prof["clip_vmin"], prof["clip_vmax"]))
+        assert len(info) == 1 and info["vmin"][0] == vmin
+        ident = bool(info["flags"][0] & nat.MMX_PP_IDENTITY)
+        assert ident == (vmin == vmax)
+        if not ident:
+            assert info["vmax"][0] == max(vmax, near_max[c] * prof["max_thresh_factor"])
+            sat = g[case + "_sat"][..., c] if roi.ndim == 4 else g[case + "_sat"]
+            assert abs(info["mean"][0] - np.mean(sat)) < 1e-12
+
+
+@pytest.mark.parametrize("dms", [(25, 25, 25), (13, 25, 30), (7, 40, 9), (64, 96, 96)])
+def test_tiled_block_matches_oracle(gpu, env, dms):
+    """A whole block, tiled like chunking.stack_splitter does: fast (LDS) and generic tiles mixed."""
+    from magellanmapper_amd import preprocess
+    from oracle import preprocess_oracle as ppo
+    roi = load_golden("stack_denoise_dense.npz")["roi"][:50, :70, :66]
+    profs = _set_profiles({})
+    want = ppo.preprocess_block(roi, dms, profs, [30000.0])
+    got = preprocess.preprocess_roi(roi, dms, near_max=[30000.0])
+    np.testing.assert_array_equal(got, want)
+
+
+def test_generic_kernel_equals_fast_kernel(gpu, env, monkeypatch):
+    from magellanmapper_amd import preprocess
+    roi = load_golden("stack_denoise.npz")["roi"][:40, :50, :52]
+    _set_profiles({})
+    fast = preprocess.preprocess_roi(roi, (25, 25, 25))
+    monkeypatch.setattr(preprocess, "FORCE_GENERIC", True)
+    slow = preprocess.preprocess_roi(roi, (25, 25, 25))
+    np.testing.assert_array_equal(fast, slow)
+
+
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_knife_edge_mean_uses_numpys_summation_order(gpu, env, monkeypatch, force_generic):
+    """erosion_threshold set exactly AT the tile mean (and one ulp below): the device must
+    reproduce np.mean bit for bit to take the reference's branch."""
+    from magellanmapper_amd import _native as nat, preprocess
+    from oracle import preprocess_oracle as ppo
+    monkeypatch.setattr(preprocess, "FORCE_GENERIC", force_generic)
+    roi = PREPROC["dense_roi"]
+    profs = _set_profiles({})
+    mean = float(np.mean(ppo.saturate_roi(roi, profs, [-1.0])))
+    for thr, eroded in ((mean, False), (np.nextafter(mean, 0.0), True), (np.nextafter(mean, 1.0), False)):
+        profs = _set_profiles({"erosion_threshold": thr})
+        want = ppo.denoise_roi(ppo.saturate_roi(roi, profs, [-1.0]), profs)
+        got, infos = preprocess.preprocess_roi(roi, roi.shape, return_info=True)
+        info = infos[0][1]
+        assert info["flags"][0] & nat.MMX_PP_EXACT_MEAN
+        assert bool(info["flags"][0] & nat.MMX_PP_ERODED) == eroded
+        assert info["mean"][0] == mean
+        np.testing.assert_array_equal(got, want)
+
+
+def test_exact_mean_on_awkward_sizes(gpu, env):
+    """NumPy's pairwise summation has three regimes (n < 8, n <= 128, recursive halving)."""
+    from magellanmapper_amd import _native as nat, preprocess
+    from oracle import preprocess_oracle as ppo
+    rng = np.random.default_rng(5)
+    for shape in ((1, 1, 5), (1, 7, 9), (3, 5, 9), (2, 8, 8), (5, 11, 13), (9, 17, 23), (25, 25, 25)):
+        roi = rng.integers(0, 4000, shape).astype(np.uint16)
+        profs = _set_profiles({})
+        sat = ppo.saturate_roi(roi, profs, [-1.0])
+        if sat.dtype != np.float64:
+            continue
+        mean = float(np.mean(sat))
+        _set_profiles({"erosion_threshold": mean})
+        _, infos = preprocess.preprocess_roi(roi, shape, return_info=True)
+        info = infos[0][1]
+        assert info["flags"][0] & nat.MMX_PP_EXACT_MEAN, shape
+        assert info["mean"][0] == mean, shape
+
+
+def test_unsupported_inputs_fail_loudly(gpu, env):
+    from magellanmapper_amd import preprocess
+    _set_profiles({})
+    with pytest.raises(NotImplementedError):
+        preprocess.preprocess_roi(np.zeros((4, 4, 4), np.float32), (4, 4, 4))
+    _set_profiles({"tot_var_denoise": 0.1})
+    with pytest.raises(NotImplementedError):
+        preprocess.preprocess_roi(np.zeros((4, 4, 4), np.uint16), (4, 4, 4))
+    _set_profiles({"clip_vmax": 101})
+    with pytest.raises(ValueError):
+        preprocess.preprocess_roi(np.zeros((4, 4, 4), np.uint16), (4, 4, 4))
+    _set_profiles({})
+    with pytest.raises(IndexError):                 # one near_max per channel, as in the reference
+        preprocess.preprocess_roi(np.zeros((4, 4, 4, 2), np.uint16), (4, 4, 4), near_max=[-1.0])
+
+
+def test_detect_sub_roi_with_denoise(gpu, env):
+    """The single-block entry (StackDetector.detect_sub_roi) with preprocessing on."""
+    from magellanmapper_amd import config, stack_detect
+    from oracle import magmap_oracle as mmo
+    g = load_golden("stack_denoise.npz")
+    roi = g["roi"][:44, :60, :62]
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(num_sigma=4)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    excl = np.array([1, 2, 2])
+    coord, got = stack_detect.StackDetector.detect_sub_roi(
+        (0, 1, 0), (0, 10, 0), (1, 1, 1), np.array([25, 25, 25]), excl, None, roi, None)
+    want = mmo.detect_sub_roi((0, 1, 0), (0, 10, 0), (1, 1, 1), excl, roi, None,
+                              [dict(config.roi_profile)], config.resolutions,
+                              denoise_max_shape=np.array([25, 25, 25]))
+    assert coord == (0, 1, 0) and want is not None
+    np.testing.assert_array_equal(got, want)

@@ -354,10 +354,17 @@ def test_stack_level_prune_from_golden_block_tables(monkeypatch):
 
 
 def test_unbuilt_rows_fail_loudly():
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):       # co-localisation
         stack_detect.StackDetector.detect_blobs_sub_rois(
             None, np.zeros((4, 4, 4), np.uint16), np.zeros((1, 1, 1), object), np.zeros((1, 1, 1, 3)),
-            np.array([5, 5, 5]), None, False, [0])
+            None, None, True, [0])
+    from magellanmapper_amd import preprocess
+    config.setup_roi_profiles(["minpreproc"])              # a profile with tot_var_denoise
+    try:
+        with pytest.raises(NotImplementedError):
+            preprocess.channel_params(0)
+    finally:
+        config.setup_roi_profiles()
     with pytest.raises(ValueError):
         stack_detect.detect_blobs_blocks("x", stack_detect.Image5d(None))
     with pytest.raises(IOError):
