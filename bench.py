@@ -36,7 +36,10 @@ SHAPE = (1024, 2048, 2048)          # z, y, x  ("2048 x 2048 x 1024" in x, y, z)
 SEED = 3
 PROFILE = dict(min_sigma_factor=3, max_sigma_factor=5, num_sigma=5, detection_threshold=0.1,
                overlap=0.5, exclude_border=None, segment_size=256, denoise_size=None,
-               prune_tol_factor=(1, 1, 1), isotropic=None)
+               prune_tol_factor=(1, 1, 1), isotropic=None,
+               # preprocessing keys (only read with --denoise): the reference's defaults
+               clip_vmin=5, clip_vmax=99.5, clip_min=0.2, clip_max=1.0, max_thresh_factor=0.5,
+               tot_var_denoise=None, unsharp_strength=0.3, erosion_threshold=0.2)
 RESOLUTIONS = np.array([[1.0, 1.0, 1.0]])
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s copy-measured)
 #: algorithmic HBM bytes per voxel per sigma of each kernel
@@ -47,10 +50,10 @@ B_ALG_PER_SIGMA = 50                # SURVEY.md section 8d contract figure
 # ------------------------------------------------------------------ CPU baseline (oracle)
 def _cpu_block(args):
     """One block through the oracle (runs in a spawned worker: NumPy/SciPy only)."""
-    coord, offset, last_coord, sub = args
+    coord, offset, last_coord, sub, profile, dms = args
     from oracle import magmap_oracle as mmo
-    return coord, mmo.detect_sub_roi(coord, offset, last_coord, None, sub, None, [PROFILE],
-                                     RESOLUTIONS)
+    return coord, mmo.detect_sub_roi(coord, offset, last_coord, None, sub, None, [profile],
+                                     RESOLUTIONS, denoise_max_shape=dms)
 
 
 def cpu_baseline(sample: np.ndarray, cores: int):
@@ -60,7 +63,8 @@ def cpu_baseline(sample: np.ndarray, cores: int):
     blocks = mmo.setup_blocks(PROFILE, sample.shape, RESOLUTIONS)
     sl, off = blocks["sub_roi_slices"], blocks["sub_rois_offsets"]
     last = np.subtract(sl.shape, 1)
-    jobs = [(c, off[c], last, sample[sl[c]]) for c in np.ndindex(*sl.shape)]
+    jobs = [(c, off[c], last, sample[sl[c]], PROFILE, blocks["denoise_max_shape"])
+            for c in np.ndindex(*sl.shape)]
     seg = np.zeros(sl.shape, dtype=object)
     with mp.get_context("spawn").Pool(processes=cores) as pool:
         for coord, tbl in pool.imap_unordered(_cpu_block, jobs):
@@ -88,7 +92,12 @@ def main():
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="z y x (default: the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--budget-gb", type=float, default=64.0, help="workspace budget per batch")
+    ap.add_argument("--denoise", type=int, default=0, metavar="SIZE",
+                    help="secondary workload: per-block preprocessing on (profile denoise_size, the "
+                         "reference's default is 25); the headline metric is quoted WITHOUT it")
     args = ap.parse_args()
+    if args.denoise:
+        PROFILE["denoise_size"] = args.denoise
     shape = tuple(args.shape) if args.shape else SHAPE
 
     import torch
@@ -171,7 +180,8 @@ def main():
 
     def one_step():
         seg = stack_detect.StackDetector.detect_blobs_sub_rois(
-            None, dvol, blocks.sub_roi_slices, blocks.sub_rois_offsets, None, None, False, [0])
+            None, dvol, blocks.sub_roi_slices, blocks.sub_rois_offsets, blocks.denoise_max_shape, None,
+            False, [0])
         st = stack_detect.StackDetector.last_stats
         final = None
         if rank == 0:
@@ -193,7 +203,8 @@ def main():
         sblocks = stack_detect.setup_blocks(config.roi_profile, sample.shape)
         sdvol = bl.DeviceVolume(sample)
         seg = stack_detect.StackDetector.detect_blobs_sub_rois(
-            None, sdvol, sblocks.sub_roi_slices, sblocks.sub_rois_offsets, None, None, False, [0])
+            None, sdvol, sblocks.sub_roi_slices, sblocks.sub_rois_offsets, sblocks.denoise_max_shape,
+            None, False, [0])
         pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
             sdvol, seg, sblocks.overlap, sblocks.tol, sblocks.sub_roi_slices, sblocks.sub_rois_offsets,
             [0], sblocks.overlap_padding)
@@ -268,7 +279,10 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{shape[2]}x{shape[1]}x{shape[0]} (x,y,z) uint16 Gaussian-blob volume, "
                                    f"seed {SEED}, {n_blocks} blocks (segment_size 256, overlap 5), sigma 3..5 x5, "
-                                   "threshold 0.1, overlap 0.5; detect + gather + prune",
+                                   "threshold 0.1, overlap 0.5; detect + gather + prune"
+                                   + (f"; PLUS per-block preprocessing (denoise_size {args.denoise}: saturate + "
+                                      "unsharp + erosion in float64) -- secondary workload, not the headline"
+                                      if args.denoise else ""),
                        "blocks_per_rank": hi - lo, "parallelism": f"blocks sharded over {world} GPU(s)"},
             "blobs": 0 if final is None else int(len(final)),
             "blobs_per_s": round((0 if final is None else len(final)) * args.steps / elapsed, 1),

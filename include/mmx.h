@@ -223,14 +223,14 @@ int64_t mmx_preprocess_fast_lds(int nz, int ny, int nx);
 
 /* Fast entry: every sub-block must qualify (mmx_preprocess_fast_lds != 0), else MMX_ERR_UNSUPPORTED.
  *   h_subs      : host copy of d_subs (validation, launch geometry)
- *   h_weights   : float64 half kernel, index k = 0..radius, as scipy's _gaussian_kernel1d(8, 0, 32)
+ *   d_weights   : DEVICE float64 half kernel, index k = 0..radius, as scipy's _gaussian_kernel1d(8, 0, 32)
  *   dst_sy/sz   : row / plane strides (elements) of the two outputs; x stride is 1
  *   d_out32/64  : float32 copy (feeds mmx_log_batch_f32) and exact float64 result (feeds
  *                 mmx_rescore_f64); only the voxels of the given sub-blocks are written
  *   d_info      : optional [n_subs] diagnostics                                                    */
 int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx_subblock* h_subs,
                          int n_subs, const mmx_quantile_class* d_qclasses, int n_qclasses,
-                         const mmx_preproc_params* params, const double* h_weights,
+                         const mmx_preproc_params* params, const double* d_weights,
                          int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
                          mmx_subblock_info* d_info, void* stream);
 
@@ -239,7 +239,7 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
 int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_subs,
                                  const mmx_subblock* h_subs, int n_subs,
                                  const mmx_quantile_class* d_qclasses, int n_qclasses,
-                                 const mmx_preproc_params* params, const double* h_weights,
+                                 const mmx_preproc_params* params, const double* d_weights,
                                  int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
                                  mmx_subblock_info* d_info, double* d_scratch, int64_t scratch_doubles,
                                  void* stream);

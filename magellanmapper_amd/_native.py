@@ -115,7 +115,7 @@ def lib() -> ctypes.CDLL:
                                       POINTER(c_int32), vp, vp, vp, POINTER(c_int64), vp, vp, vp]
     L.mmx_preprocess_fast_lds.argtypes = [c_int, c_int, c_int]
     L.mmx_preprocess_fast_lds.restype = c_int64
-    pre_args = [POINTER(Volume), vp, vp, c_int, vp, c_int, POINTER(PreprocParams), POINTER(c_double),
+    pre_args = [POINTER(Volume), vp, vp, c_int, vp, c_int, POINTER(PreprocParams), vp,
                 c_int64, c_int64, vp, vp, vp]
     L.mmx_preprocess_batch.argtypes = pre_args + [vp]
     L.mmx_preprocess_batch_generic.argtypes = pre_args + [vp, c_int64, vp]

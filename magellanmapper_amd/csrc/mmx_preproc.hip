@@ -41,9 +41,10 @@
 #define PP_WG 640        // 10 waves: 625 lines of a 25^3 sub-block in one round
 #define PP_WG_GENERIC 1024
 #define PP_HIST (5 * 256)
+#define PP_NB_LOAD 13     // global loads in flight per lane (25 rows = 13 + 12)
+#define PP_NB 9           // voxels in flight per lane in the arithmetic stages (25 rows = 9 + 9 + 7)
 
 struct pp_args {
-    double w[PP_R + 1];          // half kernel, w[k] = weight at distance k
     double clip_min, clip_max, max_thresh, strength, ero_thr;
     int64_t dst_sy, dst_sz;
     int32_t do_unsharp, do_erosion, rgb_guess, _pad;
@@ -53,9 +54,8 @@ namespace {
 
 __device__ __forceinline__ double pp_clip(double x, double lo, double hi)
 {
-    // np.clip == minimum(maximum(x, lo), hi)
-    double t = x < lo ? lo : x;
-    return t > hi ? hi : t;
+    // np.clip == minimum(maximum(x, lo), hi); no NaNs on this path, so v_max_f64 / v_min_f64 agree
+    return fmin(fmax(x, lo), hi);
 }
 
 // numpy _lerp (numpy/lib/_function_base_impl.py): a + (b-a)*t, or b - (b-a)*(1-t) for t >= 0.5
@@ -67,15 +67,51 @@ __device__ __forceinline__ double pp_lerp(int a, int b, double t)
     return r;
 }
 
+// saturate_roi's stretch (clip(x, vmin, vmax) - vmin) / span.  The division is IEEE-exact: it is the
+// compiler's own float64 expansion (v_div_scale / v_rcp + 2 Newton steps / q = n*r; e = fma(-d, q, n);
+// v_div_fmas; v_div_fixup) with the denominator-only part hoisted out of the voxel loop.  That is valid
+// while v_div_scale leaves both operands unscaled, i.e. for ordinary magnitudes: `fast` is set only
+// when 2^-200 < span < 2^200, and the numerator is 0 or in [2^-60, span] (a difference of a <= 16-bit
+// integer and an interpolated one).  Otherwise the plain `/` is used.
+// An *identity* tile (vmin == vmax: the reference leaves the voxels alone) runs the same formula with
+// vmin = 0, vmax = +inf, span = 1, which returns x exactly.
 struct pp_sat {
-    double vmin, vmax, span;
-    int identity;
-    __device__ __forceinline__ double operator()(double raw) const
+    double vmin, vmax, span, rcp;
+    int identity, fast;
+    __device__ __forceinline__ void finish()
     {
-        if (identity) return raw;
+        if (identity) { vmin = 0.; vmax = __builtin_inf(); span = 1.; }
+        fast = span > 0x1p-200 && span < 0x1p200;
+        double r = __builtin_amdgcn_rcp(span);
+        r = __builtin_fma(__builtin_fma(-span, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-span, r, 1.0), r, r);
+        rcp = r;
+    }
+    __device__ __forceinline__ double operator()(double raw) const      // requires `fast`
+    {
+        const double num = pp_clip(raw, vmin, vmax) - vmin;
+        const double q = num * rcp;
+        const double e = __builtin_fma(-span, q, num);
+        return __builtin_fma(e, rcp, q);
+    }
+    __device__ __forceinline__ double plain(double raw) const            // any magnitude
+    {
         return (pp_clip(raw, vmin, vmax) - vmin) / span;
     }
 };
+
+// histogram increment with the lanes that share the first active lane's bin folded into one LDS
+// atomic: a tile is mostly background, whose voxels all land in one or two bins
+__device__ __forceinline__ void pp_hist_add(uint32_t* hist, int bin, bool active)
+{
+    const unsigned long long act = __ballot(active);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const int lead_bin = __shfl(bin, leader);
+    const unsigned long long same = __ballot(active && bin == lead_bin);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lead_bin], (uint32_t)__popcll(same));
+    if (active && bin != lead_bin) atomicAdd(&hist[bin], 1u);
+}
 
 // Executed by one full wave: the bin of `h[0..255]` holding 0-based rank `rank`, and the rank
 // inside that bin.
@@ -154,8 +190,10 @@ __device__ double pp_pairwise(F val, int n, pp_stack* S)
 
 // One in-place Gaussian pass over the lines of one axis, lines held in registers.
 // base/stride address the LDS tile; L <= PP_MAXL.
+// The weights come through a `const __restrict__` kernel argument (scalar loads next to their use),
+// not by value: 66 SGPRs held from kernel entry made the compiler spill scalars in every other stage.
 __device__ __forceinline__ void pp_line_pass(double* __restrict__ tile, int base, int stride, int L,
-                                             const pp_args& A)
+                                             const double (&w)[PP_R + 1])
 {
     double r[PP_MAXL];
 #pragma unroll
@@ -163,22 +201,36 @@ __device__ __forceinline__ void pp_line_pass(double* __restrict__ tile, int base
 #pragma unroll
     for (int i = 0; i < PP_MAXL; ++i) {
         if (i < L) {
-            double acc = r[i] * A.w[0];
+            double acc = r[i] * w[0];
 #pragma unroll
             for (int k = PP_R; k >= 1; --k) {
                 const int a = i - k < 0 ? 0 : i - k;
                 const int b = i + k > PP_MAXL - 1 ? PP_MAXL - 1 : i + k;
-                acc += (r[a] + r[b]) * A.w[k];
+                acc += (r[a] + r[b]) * w[k];
             }
             tile[base + i * stride] = acc;
         }
     }
 }
 
+// (z, y, x) of the dense index i of an n-voxel tile: exact for i < 2^15 (float has 24 bits and
+// (i + 0.5) / nx is at least 0.5 / 32 away from an integer)
+struct pp_coord { int t, x, y, z; };
+__device__ __forceinline__ pp_coord pp_decode(int i, int nx, int ny, float inv_nx, float inv_ny)
+{
+    pp_coord c;
+    c.t = (int)(((float)i + 0.5f) * inv_nx);
+    c.x = i - c.t * nx;
+    c.z = (int)(((float)c.t + 0.5f) * inv_ny);
+    c.y = c.t - c.z * ny;
+    return c;
+}
+
 template <typename InT>
 __global__ void __launch_bounds__(PP_WG)
 pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
-               const mmx_subblock* __restrict__ subs, const mmx_quantile_class* __restrict__ qcs,
+               const mmx_subblock* __restrict__ subs, int n_subs,
+               const mmx_quantile_class* __restrict__ qcs, const double* __restrict__ wts,
                pp_args A, float* __restrict__ out32, double* __restrict__ out64,
                mmx_subblock_info* __restrict__ info)
 {
@@ -192,27 +244,59 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     __shared__ pp_stack s_stack;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const mmx_subblock sb = subs[blockIdx.x];
+    // Workgroups are dealt to the 8 XCDs round-robin; give each XCD a CONTIGUOUS run of tiles so
+    // that x-neighbouring tiles (which share 128-byte lines of the source rows and of both
+    // outputs) meet in one L2.
+    const int per = (n_subs + 7) >> 3;
+    const int sub_id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (sub_id >= n_subs) return;
+    const mmx_subblock sb = subs[sub_id];
     const int nz = sb.nz, ny = sb.ny, nx = sb.nx, n = nz * ny * nx;
     const int px = nx | 1;                        // odd row pitch: no LDS bank conflicts on x lines
     uint32_t* hist = (uint32_t*)(tile + nz * ny * px);
+    uint16_t* raw = (uint16_t*)(hist + PP_HIST);  // the voxels themselves, dense index
     const InT* src = vol + sb.src_off;
     const float inv_nx = 1.0f / (float)nx, inv_ny = 1.0f / (float)ny;
+#ifdef PP_PROFILE
+    long long stamp[8]; int ns_ = 0;
+#define PP_STAMP() do { __syncthreads(); stamp[ns_++] = wall_clock64(); } while (0)
+#else
+#define PP_STAMP() do {} while (0)
+#endif
+    PP_STAMP();
 
     for (int i = tid; i < PP_HIST; i += PP_WG) hist[i] = 0;
     __syncthreads();
 
-    // 1. voxels -> LDS (as doubles), histogram of the high byte
-    for (int i = tid; i < n; i += PP_WG) {
-        const int t = (int)(((float)i + 0.5f) * inv_nx);
-        const int x = i - t * nx;
-        const int z = (int)(((float)t + 0.5f) * inv_ny);
-        const int y = t - z * ny;
-        const int v = (int)src[z * sz + y * sy + x * sx];
-        tile[(z * ny + y) * px + x] = (double)v;
-        atomicAdd(&hist[v >> 8], 1u);
+    // Lane <-> voxel mapping of the element-wise stages: a lane keeps its x and walks rows
+    // (z*ny + y) in steps of `rpi`, so no per-voxel index decoding; rpi * nx <= PP_WG lanes work.
+    const int nrows = nz * ny;
+    const int rpi = PP_WG / nx;
+    const int r_first = (int)(((float)tid + 0.5f) * inv_nx);
+    const int x = tid - r_first * nx;
+    const int r0 = r_first < rpi ? r_first : nrows;          // idle lanes start past the end
+
+    // 1. voxels -> LDS, histogram of the high byte.  Loads are issued PP_NB at a time: with one
+    //    workgroup per CU nothing else hides their latency.
+    for (int rb0 = 0; rb0 < nrows; rb0 += PP_NB_LOAD * rpi) {     // same trip count in every lane (ballots)
+        const int rb = r0 + rb0;
+        int v[PP_NB_LOAD];
+#pragma unroll
+        for (int j = 0; j < PP_NB_LOAD; ++j) {
+            const int row = rb + j * rpi < nrows ? rb + j * rpi : 0;
+            const int z = (int)(((float)row + 0.5f) * inv_ny);
+            const int y = row - z * ny;
+            v[j] = (int)src[z * sz + y * sy + (r0 < nrows ? x : 0) * sx];
+        }
+#pragma unroll
+        for (int j = 0; j < PP_NB_LOAD; ++j) {
+            const int row = rb + j * rpi;
+            if (row < nrows) raw[row * nx + x] = (uint16_t)v[j];
+            pp_hist_add(hist, v[j] >> 8, row < nrows);
+        }
     }
     __syncthreads();
+    PP_STAMP();
 
     // 2. order statistics: ranks lo_prev, lo_next, hi_prev, hi_next
     const mmx_quantile_class qc = qcs[sb.qclass];
@@ -224,44 +308,66 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     }
     __syncthreads();
     {
+        // one low-byte histogram per DISTINCT high-byte bin (prev / next ranks usually share theirs)
         const int b0 = s_bin[0], b1 = s_bin[1], b2 = s_bin[2], b3 = s_bin[3];
+        const bool u1 = b1 != b0, u2 = b2 != b0 && b2 != b1, u3 = b3 != b0 && b3 != b1 && b3 != b2;
         for (int i = tid; i < n; i += PP_WG) {
-            const int t = (int)(((float)i + 0.5f) * inv_nx);
-            const int x = i - t * nx;
-            const int v = (int)tile[t * px + x];
+            const int v = raw[i];
             const int hi = v >> 8, lo = v & 255;
             if (hi == b0) atomicAdd(&hist[256 + lo], 1u);
-            if (hi == b1) atomicAdd(&hist[512 + lo], 1u);
-            if (hi == b2) atomicAdd(&hist[768 + lo], 1u);
-            if (hi == b3) atomicAdd(&hist[1024 + lo], 1u);
+            if (u1 && hi == b1) atomicAdd(&hist[512 + lo], 1u);
+            if (u2 && hi == b2) atomicAdd(&hist[768 + lo], 1u);
+            if (u3 && hi == b3) atomicAdd(&hist[1024 + lo], 1u);
         }
     }
     __syncthreads();
     if (wave < 4) {
+        int slot = wave;
+        for (int w = wave - 1; w >= 0; --w) if (s_bin[w] == s_bin[wave]) slot = w;
         int b; uint32_t r;
-        pp_select(hist + 256 * (1 + wave), s_res[wave], b, r);
+        pp_select(hist + 256 * (1 + slot), s_res[wave], b, r);
         if (lane == 0) s_val[wave] = (s_bin[wave] << 8) | b;
     }
     __syncthreads();
+    PP_STAMP();
 
     pp_sat S;
+    double info_vmin, info_vmax;
     {
         const double vmin = pp_lerp(s_val[0], s_val[1], qc.lo_gamma);
         double vmax = pp_lerp(s_val[2], s_val[3], qc.hi_gamma);
         S.identity = vmin == vmax;
         if (vmax < A.max_thresh) vmax = A.max_thresh;
         S.vmin = vmin; S.vmax = vmax; S.span = vmax - vmin;
+        info_vmin = vmin; info_vmax = vmax;
+        S.finish();
     }
 
-    // 3. saturate, sum, clip
+    // 3. saturate, sum, clip -> the float64 tile (PP_NB independent divisions in flight per lane)
     double part = 0.;
-    for (int i = tid; i < n; i += PP_WG) {
-        const int t = (int)(((float)i + 0.5f) * inv_nx);
-        const int x = i - t * nx;
-        const int pos = t * px + x;
-        const double s = S(tile[pos]);
-        part += s;
-        tile[pos] = pp_clip(s, A.clip_min, A.clip_max);
+    for (int rb = r0; rb < nrows; rb += PP_NB * rpi) {
+        double s[PP_NB];
+#pragma unroll
+        for (int j = 0; j < PP_NB; ++j) {
+            const int row = rb + j * rpi < nrows ? rb + j * rpi : rb;
+            s[j] = S((double)(int)raw[row * nx + x]);
+        }
+#pragma unroll
+        for (int j = 0; j < PP_NB; ++j) {
+            const int row = rb + j * rpi;
+            if (row < nrows) {
+                part += s[j];
+                tile[row * px + x] = pp_clip(s[j], A.clip_min, A.clip_max);
+            }
+        }
+    }
+    if (!S.fast) {                 // extreme span (never with integer voxels): plain division, same stores
+        part = 0.;
+        for (int row = r0; row < nrows; row += rpi) {
+            const double sv = S.plain((double)(int)raw[row * nx + x]);
+            part += sv;
+            tile[row * px + x] = pp_clip(sv, A.clip_min, A.clip_max);
+        }
     }
     part = pp_wave_sum(part);
     if (lane == 0) s_red[wave] = part;
@@ -275,10 +381,7 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
             const double tol = 1e-9 * (fabs(A.ero_thr) > 1. ? fabs(A.ero_thr) : 1.);
             if (!S.identity && fabs(mean - A.ero_thr) <= tol) {
                 // knife edge: NumPy's own summation order decides
-                auto val = [&](int i) {
-                    const int t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
-                    return S((double)(int)src[z * sz + y * sy + x * sx]);
-                };
+                auto val = [&](int i) { return S.plain((double)(int)raw[i]); };
                 mean = pp_pairwise(val, n, &s_stack) / (double)n;
                 flags |= MMX_PP_EXACT_MEAN;
             }
@@ -289,14 +392,20 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     }
     __syncthreads();
     const int flags = s_flags;
+#ifndef PP_PROFILE
     if (info && tid == 0) {
         mmx_subblock_info o;
-        o.vmin = S.vmin; o.vmax = S.vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
-        info[blockIdx.x] = o;
+        o.vmin = info_vmin; o.vmax = info_vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
+        info[sub_id] = o;
     }
+#endif
+    PP_STAMP();
 
     // 4. Gaussian blur, axis 0, 1, 2 in place (scipy gaussian_filter order)
     if (A.do_unsharp) {
+        double wl[PP_R + 1];
+#pragma unroll
+        for (int k = 0; k <= PP_R; ++k) wl[k] = wts[k];          // uniform: scalar loads, SGPR resident
 #pragma unroll 1
         for (int axis = 0; axis < 3; ++axis) {
             const int L = axis == 0 ? nz : axis == 1 ? ny : nx;
@@ -311,44 +420,69 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
                     if (axis == 0) { base = t * px + x; stride = ny * px; }
                     else { base = t * ny * px + x; stride = px; }
                 }
-                pp_line_pass(tile, base, stride, L, A);
+                pp_line_pass(tile, base, stride, L, wl);
             }
             __syncthreads();
         }
     }
+    PP_STAMP();
 
     // 5. unsharp mask (+ erosion), write out
     const bool erode = flags & MMX_PP_ERODED;
-    for (int i = tid; i < n; i += PP_WG) {
-        const int t = (int)(((float)i + 0.5f) * inv_nx);
-        const int x = i - t * nx;
-        const int z = (int)(((float)t + 0.5f) * inv_ny);
-        const int y = t - z * ny;
-        const int pos = t * px + x;
-        double o;
-        if (A.do_unsharp) {
-            const double den = pp_clip(S((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
-            const double m = A.strength * tile[pos];
-            const double hp = den - m;
-            o = den + hp;
-        } else {
-            o = tile[pos];
+    for (int rb = r0; rb < nrows; rb += PP_NB * rpi) {
+        double o[PP_NB];
+#pragma unroll
+        for (int j = 0; j < PP_NB; ++j) {
+            const int row = rb + j * rpi < nrows ? rb + j * rpi : rb;
+            const double blur = tile[row * px + x];
+            if (A.do_unsharp) {
+                const double den = pp_clip(S((double)(int)raw[row * nx + x]), A.clip_min, A.clip_max);
+                const double m = A.strength * blur;
+                const double hp = den - m;
+                o[j] = den + hp;
+            } else {
+                o[j] = blur;
+            }
         }
-        if (erode) tile[pos] = o;
-        else {
-            const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
-            out64[d] = o;
-            out32[d] = (float)o;
+        if (A.do_unsharp && !S.fast) {
+            for (int j = 0; j < PP_NB; ++j) {
+                const int row = rb + j * rpi < nrows ? rb + j * rpi : rb;
+                const double den = pp_clip(S.plain((double)(int)raw[row * nx + x]), A.clip_min, A.clip_max);
+                const double m = A.strength * tile[row * px + x];
+                const double hp = den - m;
+                o[j] = den + hp;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PP_NB; ++j) {
+            const int row = rb + j * rpi;
+            if (row >= nrows) continue;
+            if (erode) tile[row * px + x] = o[j];
+            else {
+                const int z = (int)(((float)row + 0.5f) * inv_ny);
+                const int y = row - z * ny;
+                const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
+                out64[d] = o[j];
+                out32[d] = (float)o[j];
+            }
         }
     }
+#ifdef PP_PROFILE
+    PP_STAMP();
+    if (info && tid == 0) {   // 100 MHz ticks per stage: load, select, saturate, blur, write
+        mmx_subblock_info o;
+        o.vmin = (double)(stamp[1] - stamp[0]) + 1e-6 * (double)(stamp[2] - stamp[1]);
+        o.vmax = (double)(stamp[3] - stamp[2]) + 1e-6 * (double)(stamp[4] - stamp[3]);
+        o.mean = (double)(stamp[5] - stamp[4]); o.flags = flags; o._pad = 0;
+        info[sub_id] = o;
+    }
+#endif
     if (!erode) return;
     __syncthreads();
-    for (int i = tid; i < n; i += PP_WG) {
-        const int t = (int)(((float)i + 0.5f) * inv_nx);
-        const int x = i - t * nx;
-        const int z = (int)(((float)t + 0.5f) * inv_ny);
-        const int y = t - z * ny;
-        const int pos = t * px + x;
+    for (int row = r0; row < nrows; row += rpi) {
+        const int z = (int)(((float)row + 0.5f) * inv_ny);
+        const int y = row - z * ny;
+        const int pos = row * px + x;
         double o = tile[pos];
         if (x > 0) o = fmin(o, tile[pos - 1]);
         if (x < nx - 1) o = fmin(o, tile[pos + 1]);
@@ -367,6 +501,7 @@ template <typename InT>
 __global__ void __launch_bounds__(PP_WG_GENERIC)
 pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
                   const mmx_subblock* __restrict__ subs, const mmx_quantile_class* __restrict__ qcs,
+                  const double* __restrict__ wts,
                   pp_args A, float* __restrict__ out32, double* __restrict__ out64,
                   mmx_subblock_info* __restrict__ info, double* __restrict__ scratch)
 {
@@ -426,17 +561,20 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
     __syncthreads();
 
     pp_sat S;
+    double info_vmin, info_vmax;
     {
         const double vmin = pp_lerp(s_val[0], s_val[1], qc.lo_gamma);
         double vmax = pp_lerp(s_val[2], s_val[3], qc.hi_gamma);
         S.identity = vmin == vmax;
         if (vmax < A.max_thresh) vmax = A.max_thresh;
         S.vmin = vmin; S.vmax = vmax; S.span = vmax - vmin;
+        info_vmin = vmin; info_vmax = vmax;
+        S.finish();
     }
 
     double part = 0.;
     for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
-        const double s = S(bufA[i]);
+        const double s = S.plain(bufA[i]);
         part += s;
         bufA[i] = pp_clip(s, A.clip_min, A.clip_max);
     }
@@ -451,7 +589,7 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
         if (A.do_erosion) {
             const double tol = 1e-9 * (fabs(A.ero_thr) > 1. ? fabs(A.ero_thr) : 1.);
             if (!S.identity && fabs(mean - A.ero_thr) <= tol && n < (1ll << 31)) {
-                auto val = [&](int i) { return S((double)raw(i)); };
+                auto val = [&](int i) { return S.plain((double)raw(i)); };
                 mean = pp_pairwise(val, (int)n, &s_stack) / (double)n;
                 flags |= MMX_PP_EXACT_MEAN;
             }
@@ -464,7 +602,7 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
     const int flags = s_flags;
     if (info && tid == 0) {
         mmx_subblock_info o;
-        o.vmin = S.vmin; o.vmax = S.vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
+        o.vmin = info_vmin; o.vmax = info_vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
         info[blockIdx.x] = o;
     }
 
@@ -479,11 +617,11 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
             for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
                 const int64_t c = (i / stride) % L;
                 const double* line = cur + (i - c * stride);
-                double acc = line[c * stride] * A.w[0];
+                double acc = line[c * stride] * wts[0];
                 for (int k = PP_R; k >= 1; --k) {
                     const int64_t a = c - k < 0 ? 0 : c - k;
                     const int64_t b = c + k > L - 1 ? L - 1 : c + k;
-                    acc += (line[a * stride] + line[b * stride]) * A.w[k];
+                    acc += (line[a * stride] + line[b * stride]) * wts[k];
                 }
                 oth[i] = acc;
             }
@@ -497,7 +635,7 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
         const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
         double o;
         if (A.do_unsharp) {
-            const double den = pp_clip(S((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
+            const double den = pp_clip(S.plain((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
             const double m = A.strength * cur[i];
             const double hp = den - m;
             o = den + hp;
@@ -528,10 +666,9 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
     }
 }
 
-pp_args pp_make_args(const mmx_preproc_params* p, const double* h_w, int64_t dst_sy, int64_t dst_sz)
+pp_args pp_make_args(const mmx_preproc_params* p, int64_t dst_sy, int64_t dst_sz)
 {
     pp_args A;
-    for (int k = 0; k <= PP_R; ++k) A.w[k] = h_w[k];
     A.clip_min = p->clip_min; A.clip_max = p->clip_max; A.max_thresh = p->max_thresh;
     A.strength = p->unsharp_strength; A.ero_thr = p->erosion_threshold;
     A.dst_sy = dst_sy; A.dst_sz = dst_sz;
@@ -549,8 +686,10 @@ extern "C" {
 int64_t mmx_preprocess_fast_lds(int nz, int ny, int nx)
 {
     if (nz < 1 || ny < 1 || nx < 1 || nz > PP_MAXL || ny > PP_MAXL || nx > PP_MAXL) return 0;
-    const int64_t b = (int64_t)nz * ny * (nx | 1) * (int64_t)sizeof(double) + PP_HIST * (int64_t)sizeof(uint32_t);
-    return b <= MMX_PP_MAX_LDS - 2048 ? b : 0;     // 2 KiB of static LDS (selection, recursion stack)
+    const int64_t n = (int64_t)nz * ny * nx;
+    const int64_t b = (int64_t)nz * ny * (nx | 1) * (int64_t)sizeof(double) + PP_HIST * (int64_t)sizeof(uint32_t)
+                      + ((n * 2 + 7) & ~7ll);      // float64 tile, histograms, the uint16 voxels
+    return b <= MMX_PP_MAX_LDS - 1024 ? b : 0;     // < 1 KiB of static LDS (selection, recursion stack)
 }
 
 static int pp_check(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx_subblock* h_subs, int n_subs,
@@ -572,11 +711,11 @@ static int pp_check(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx
 
 int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx_subblock* h_subs,
                          int n_subs, const mmx_quantile_class* d_qclasses, int n_qclasses,
-                         const mmx_preproc_params* params, const double* h_weights,
+                         const mmx_preproc_params* params, const double* d_weights,
                          int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
                          mmx_subblock_info* d_info, void* stream)
 {
-    const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, h_weights, d_out32, d_out64);
+    const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, d_weights, d_out32, d_out64);
     if (st != MMX_OK) return st;
     if (n_subs == 0) return MMX_OK;
     int64_t lds = 0;
@@ -585,21 +724,22 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
         if (!b) return MMX_ERR_UNSUPPORTED;
         lds = b > lds ? b : lds;
     }
-    const pp_args A = pp_make_args(params, h_weights, dst_sy, dst_sz);
+    const pp_args A = pp_make_args(params, dst_sy, dst_sz);
     hipStream_t s = (hipStream_t)stream;
+    const int grid = ((n_subs + 7) / 8) * 8;       // 8 XCD-contiguous runs of tiles
     mmx_timed_scope ts(MMX_K_PREPROC, s);
     if (vol->dtype == MMX_U16) {
         auto k = pp_fast_kernel<uint16_t>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MMX_ERR_HIP;
-        hipLaunchKernelGGL(k, dim3(n_subs), dim3(PP_WG), (size_t)lds, s, (const uint16_t*)vol->d_data,
-                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, d_qclasses, A, d_out32, d_out64, d_info);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PP_WG), (size_t)lds, s, (const uint16_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, n_subs, d_qclasses, d_weights, A, d_out32, d_out64, d_info);
     } else {
         auto k = pp_fast_kernel<uint8_t>;
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return MMX_ERR_HIP;
-        hipLaunchKernelGGL(k, dim3(n_subs), dim3(PP_WG), (size_t)lds, s, (const uint8_t*)vol->d_data,
-                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, d_qclasses, A, d_out32, d_out64, d_info);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PP_WG), (size_t)lds, s, (const uint8_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, n_subs, d_qclasses, d_weights, A, d_out32, d_out64, d_info);
     }
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
@@ -607,12 +747,12 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
 int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_subs,
                                  const mmx_subblock* h_subs, int n_subs,
                                  const mmx_quantile_class* d_qclasses, int n_qclasses,
-                                 const mmx_preproc_params* params, const double* h_weights,
+                                 const mmx_preproc_params* params, const double* d_weights,
                                  int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
                                  mmx_subblock_info* d_info, double* d_scratch, int64_t scratch_doubles,
                                  void* stream)
 {
-    const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, h_weights, d_out32, d_out64);
+    const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, d_weights, d_out32, d_out64);
     if (st != MMX_OK) return st;
     if (n_subs == 0) return MMX_OK;
     if (!d_scratch) return MMX_ERR_ARG;
@@ -621,17 +761,17 @@ int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_su
         const int64_t n = (int64_t)b.nz * b.ny * b.nx;
         if (b.scratch_off < 0 || b.scratch_off + 2 * n > scratch_doubles) return MMX_ERR_WORKSPACE;
     }
-    const pp_args A = pp_make_args(params, h_weights, dst_sy, dst_sz);
+    const pp_args A = pp_make_args(params, dst_sy, dst_sz);
     hipStream_t s = (hipStream_t)stream;
     mmx_timed_scope ts(MMX_K_PREPROC, s);
     if (vol->dtype == MMX_U16)
         hipLaunchKernelGGL(pp_generic_kernel<uint16_t>, dim3(n_subs), dim3(PP_WG_GENERIC), 0, s,
                            (const uint16_t*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_subs,
-                           d_qclasses, A, d_out32, d_out64, d_info, d_scratch);
+                           d_qclasses, d_weights, A, d_out32, d_out64, d_info, d_scratch);
     else
         hipLaunchKernelGGL(pp_generic_kernel<uint8_t>, dim3(n_subs), dim3(PP_WG_GENERIC), 0, s,
                            (const uint8_t*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_subs,
-                           d_qclasses, A, d_out32, d_out64, d_info, d_scratch);
+                           d_qclasses, d_weights, A, d_out32, d_out64, d_info, d_scratch);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 

@@ -113,6 +113,9 @@ class Preprocessor:
         self._out64 = [None, None]
         self._out32 = None
         self._scratch = None
+        self._weights = None
+        self._tmpl_key = None
+        self._tmpl, self._qc_rows, self._qc_index = {}, [], {}
         self._tiles: Dict[Tuple[int, int, int], Tuple[np.ndarray, np.ndarray]] = {}
         self.last_info: Optional[np.ndarray] = None
         self.last_subs: Optional[np.ndarray] = None
@@ -137,6 +140,37 @@ class Preprocessor:
         if shape not in self._tiles:
             self._tiles[shape] = _tile_grid(shape, self.dms)
         return self._tiles[shape]
+
+    def _template(self, shape, vstrides, dstrides, pct_lo, pct_hi):
+        """``(fast, generic)`` sub-block tables of one block shape with block-relative offsets."""
+        tkey = (shape, vstrides, dstrides)
+        hit = self._tmpl.get(tkey)
+        if hit is not None:
+            return hit
+        L = nat.lib()
+        o, e = self._grid(shape)
+        t = np.zeros(len(o), dtype=nat.SUBBLOCK_DTYPE)
+        t["src_off"] = o[:, 0] * vstrides[0] + o[:, 1] * vstrides[1] + o[:, 2] * vstrides[2]
+        t["dst_off"] = o[:, 0] * dstrides[0] + o[:, 1] * dstrides[1] + o[:, 2]
+        t["nz"], t["ny"], t["nx"] = e[:, 0], e[:, 1], e[:, 2]
+        uniq, inv = np.unique(e, axis=0, return_inverse=True)
+        inv = inv.reshape(-1)
+        cls = np.zeros(len(uniq), dtype=np.int32)
+        fast = np.zeros(len(uniq), dtype=bool)
+        for j, u in enumerate(uniq):
+            n = int(u[0]) * int(u[1]) * int(u[2])
+            if n not in self._qc_index:
+                lp, ln, lg = quantile_ranks(n, pct_lo)
+                hp, hn, hg = quantile_ranks(n, pct_hi)
+                self._qc_index[n] = len(self._qc_rows)
+                self._qc_rows.append((lp, ln, hp, hn, lg, hg))
+            cls[j] = self._qc_index[n]
+            fast[j] = (not FORCE_GENERIC) and L.mmx_preprocess_fast_lds(int(u[0]), int(u[1]), int(u[2])) != 0
+        t["qclass"] = cls[inv]
+        is_fast = fast[inv]
+        hit = (t[is_fast], t[~is_fast])
+        self._tmpl[tkey] = hit
+        return hit
 
     def _buffer(self, name, which, n_elems, dtype, dev):
         cur = getattr(self, name)
@@ -173,36 +207,27 @@ class Preprocessor:
         slot_pre = dst_sz * int(shp[:, 0].max())
         t = dvol.tensor
         vsz, vsy, vsx = (int(v) for v in t.stride()[:3])
-        # sub-block table
-        subs_parts = []
+        # sub-block table: per distinct block shape a cached template (tile extents, offsets relative
+        # to the block, quantile class, fast / generic split); a block only adds its two base offsets
+        key = (pct_lo, pct_hi, bool(FORCE_GENERIC))
+        if self._tmpl_key != key:
+            self._tmpl_key, self._tmpl, self._qc_rows, self._qc_index = key, {}, [], {}
+        fast_parts, gen_parts = [], []
         for i in range(nb):
-            o, e = self._grid(shp[i])
-            part = np.zeros(len(o), dtype=nat.SUBBLOCK_DTYPE)
-            part["src_off"] = ((org[i, 0] + o[:, 0]) * vsz + (org[i, 1] + o[:, 1]) * vsy
-                               + (org[i, 2] + o[:, 2]) * vsx)
-            part["dst_off"] = i * slot_pre + o[:, 0] * dst_sz + o[:, 1] * dst_sy + o[:, 2]
-            part["nz"], part["ny"], part["nx"] = e[:, 0], e[:, 1], e[:, 2]
-            subs_parts.append(part)
-        subs = np.concatenate(subs_parts) if subs_parts else np.zeros(0, dtype=nat.SUBBLOCK_DTYPE)
-        nvox = subs["nz"].astype(np.int64) * subs["ny"] * subs["nx"]
-        sizes, inverse = np.unique(nvox, return_inverse=True)
-        qc = np.zeros(len(sizes), dtype=nat.QCLASS_DTYPE)
-        for j, n in enumerate(sizes):
-            lp, ln, lg = quantile_ranks(int(n), pct_lo)
-            hp, hn, hg = quantile_ranks(int(n), pct_hi)
-            qc[j] = (lp, ln, hp, hn, lg, hg)
-        subs["qclass"] = inverse.astype(np.int32)
-        dims = np.stack([subs["nz"], subs["ny"], subs["nx"]], axis=1)
-        uniq, inv = np.unique(dims, axis=0, return_inverse=True)
-        ok = np.array([L.mmx_preprocess_fast_lds(int(u[0]), int(u[1]), int(u[2])) != 0 for u in uniq],
-                      dtype=bool)
-        is_fast = ok[inv.reshape(-1)] if len(subs) else np.zeros(0, dtype=bool)
-        if FORCE_GENERIC:
-            is_fast[:] = False
-        order = np.concatenate([np.nonzero(is_fast)[0], np.nonzero(~is_fast)[0]])
-        subs = subs[order]
-        n_fast = int(is_fast.sum())
-        n_gen = len(subs) - n_fast
+            tf, tg = self._template(tuple(int(v) for v in shp[i]), (vsz, vsy, vsx), (dst_sz, dst_sy),
+                                    pct_lo, pct_hi)
+            base_src = int(org[i, 0]) * vsz + int(org[i, 1]) * vsy + int(org[i, 2]) * vsx
+            for tmpl, parts in ((tf, fast_parts), (tg, gen_parts)):
+                if len(tmpl):
+                    part = tmpl.copy()
+                    part["src_off"] += base_src
+                    part["dst_off"] += i * slot_pre
+                    parts.append(part)
+        n_fast = sum(len(p) for p in fast_parts)
+        n_gen = sum(len(p) for p in gen_parts)
+        subs = (np.concatenate(fast_parts + gen_parts) if n_fast + n_gen
+                else np.zeros(0, dtype=nat.SUBBLOCK_DTYPE))
+        qc = np.array(self._qc_rows, dtype=nat.QCLASS_DTYPE)
         if n_gen:
             gen_n = (subs["nz"][n_fast:].astype(np.int64) * subs["ny"][n_fast:] * subs["nx"][n_fast:])
             offs = np.concatenate([[0], np.cumsum(2 * gen_n)])
@@ -218,6 +243,10 @@ class Preprocessor:
         weights = gauss_weights()
         if len(weights) != params.radius + 1:
             raise nat.MmxError("Gaussian half kernel has the wrong length")
+        wkey = weights.tobytes()
+        if self._weights is None or self._weights[0] != wkey or self._weights[1].device != dev:
+            self._weights = (wkey, torch.from_numpy(weights).to(dev))
+        d_w = self._weights[1]
         vol = dvol.view(channel, False)
         stream = torch.cuda.current_stream().cuda_stream
         item = nat.SUBBLOCK_DTYPE.itemsize
@@ -225,12 +254,12 @@ class Preprocessor:
         if n_fast:
             nat.check(L.mmx_preprocess_batch(
                 ctypes.byref(vol), d_subs.data_ptr(), subs.ctypes.data, n_fast, d_qc.data_ptr(), len(qc),
-                ctypes.byref(params), nat.as_double_ptr(weights), dst_sy, dst_sz,
+                ctypes.byref(params), d_w.data_ptr(), dst_sy, dst_sz,
                 out32.data_ptr(), out64.data_ptr(), info_ptr, stream), "mmx_preprocess_batch")
         if n_gen:
             nat.check(L.mmx_preprocess_batch_generic(
                 ctypes.byref(vol), d_subs.data_ptr() + n_fast * item, subs.ctypes.data + n_fast * item,
-                n_gen, d_qc.data_ptr(), len(qc), ctypes.byref(params), nat.as_double_ptr(weights),
+                n_gen, d_qc.data_ptr(), len(qc), ctypes.byref(params), d_w.data_ptr(),
                 dst_sy, dst_sz, out32.data_ptr(), out64.data_ptr(),
                 (info_ptr + n_fast * nat.SUBINFO_DTYPE.itemsize) if info_ptr else None,
                 scratch.data_ptr(), int(scratch.numel()), stream), "mmx_preprocess_batch_generic")
