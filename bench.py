@@ -249,6 +249,8 @@ def main():
                 if k in ALG_BYTES:
                     gbs = ALG_BYTES[k] * my_vox * ns * args.steps / (ms * 1e-3) / 1e9
                     per_kernel[k]["alg_GBps"] = round(gbs, 1)
+                elif k == "preproc":      # once per voxel (not per sigma): 2 B in, 8 + 4 B out; fp64-VALU bound
+                    per_kernel[k]["alg_GBps"] = round(14 * my_vox * args.steps / (ms * 1e-3) / 1e9, 1)
         stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
         dom = max(stream_k, key=lambda k: stream_k[k]["ms_per_step"]) if stream_k else None
         roof = None
@@ -256,7 +258,8 @@ def main():
         # command (profiles/, collected with rocprofv3 --pmc in separate passes and calibrated)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_denoise_pmc_traffic.json" if args.denoise
+                                   else "r01_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if tuple(shape) == SHAPE and world == 1 and dom in pmc["per_launch_GB"]:
                 traffic = round(pmc["per_launch_GB"][dom]["total_GB"] * 1e9)

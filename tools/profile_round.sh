@@ -4,10 +4,11 @@
 #   bench and for the known-byte calibration streams.  Outputs under gpurun_out/prof_<tag>/.
 set -u
 tag=${1:-r01}
+extra=${2:-}          # extra bench.py arguments, e.g. "--denoise 25"
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+B="bench.py --steps 2 --warmup 1 --no-cpu-baseline $extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $B > $out/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $B > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $B > $out/pmc_write.log 2>&1
