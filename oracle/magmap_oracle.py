@@ -166,9 +166,11 @@ def setup_blocks(profile: dict, shape, resolutions) -> Dict[str, object]:
 
 # ----------------------------------------------------------------------- A10
 def detect_sub_roi(coord, offset, last_coord, exclude_border, sub_roi, channel,
-                   profiles, resolutions, denoise_max_shape=None, near_max=(-1.0,)) -> Optional[np.ndarray]:
-    """One block; magmap/cv/stack_detect.py:81-172 with ``coloc=False``.  With
-    ``denoise_max_shape`` the block is preprocessed first (:122-150, ``preprocess_oracle``)."""
+                   profiles, resolutions, denoise_max_shape=None, near_max=(-1.0,),
+                   coloc=False) -> Optional[np.ndarray]:
+    """One block; magmap/cv/stack_detect.py:81-172.  With ``denoise_max_shape`` the block is
+    preprocessed first (:122-150, ``preprocess_oracle``); with ``coloc`` the intensity
+    co-localisation flags are appended as extra columns (:159-162, ``coloc_oracle``)."""
     if denoise_max_shape is not None:
         from . import preprocess_oracle as ppo
         sub_roi = ppo.preprocess_block(sub_roi, denoise_max_shape, profiles, near_max)
@@ -179,6 +181,12 @@ def detect_sub_roi(coord, offset, last_coord, exclude_border, sub_roi, channel,
         exclude[0, np.equal(coord, 0)] = 0
         exclude[1, np.equal(coord, last_coord)] = 0
     segments = detect_blobs(sub_roi, channel, profiles, resolutions, exclude)
+    if coloc and segments is not None:
+        from . import coloc_oracle
+        colocs = coloc_oracle.colocalize_blobs(sub_roi, segments)
+        if colocs is None:
+            raise ValueError("all the input arrays must have same number of dimensions")  # np.hstack
+        segments = np.hstack((segments, colocs))
     if segments is not None:
         segments[:, 0:3] = np.add(segments[:, 0:3], offset)
         segments[:, 7:10] = np.add(segments[:, 7:10], offset)
@@ -186,7 +194,7 @@ def detect_sub_roi(coord, offset, last_coord, exclude_border, sub_roi, channel,
 
 
 def detect_blobs_sub_rois(img, slices, offsets, exclude_border, channel, profiles, resolutions,
-                          denoise_max_shape=None, near_max=(-1.0,)):
+                          denoise_max_shape=None, near_max=(-1.0,), coloc=False):
     """Serial version of the Pool fan-out, magmap/cv/stack_detect.py:174-257."""
     last_coord = np.subtract(slices.shape, 1)
     seg_rois = np.zeros(slices.shape, dtype=object)
@@ -196,7 +204,8 @@ def detect_blobs_sub_rois(img, slices, offsets, exclude_border, channel, profile
                 coord = (z, y, x)
                 seg_rois[coord] = detect_sub_roi(
                     coord, offsets[coord], last_coord, exclude_border,
-                    img[slices[coord]], channel, profiles, resolutions, denoise_max_shape, near_max)
+                    img[slices[coord]], channel, profiles, resolutions, denoise_max_shape, near_max,
+                    coloc)
     return seg_rois
 
 
@@ -376,7 +385,7 @@ def _slice_shape(slc, img_shape):
 
 # ----------------------------------------------------------------------- A14
 def detect_blobs_blocks(roi: np.ndarray, channels: Optional[Sequence[int]],
-                        profiles: Sequence[dict], resolutions, near_max=(-1.0,)):
+                        profiles: Sequence[dict], resolutions, near_max=(-1.0,), coloc=False):
     """Whole-ROI detection + pruning -> final ``(M, 8)`` table (or None) and stages.
 
     magmap/cv/stack_detect.py:338-517 for ``full_roi=True, coloc=False,
@@ -390,14 +399,22 @@ def detect_blobs_blocks(roi: np.ndarray, channels: Optional[Sequence[int]],
     blocks = setup_blocks(prof0, roi.shape, resolutions)
     seg_rois = detect_blobs_sub_rois(
         roi, blocks["sub_roi_slices"], blocks["sub_rois_offsets"],
-        blocks["exclude_border"], channels, profiles, resolutions, blocks["denoise_max_shape"], near_max)
+        blocks["exclude_border"], channels, profiles, resolutions, blocks["denoise_max_shape"], near_max,
+        coloc)
     merged_before = merge_blobs(seg_rois)
     segments_all, ratios = prune_blobs_mp(
         roi.shape, seg_rois, blocks["overlap"], blocks["tol"], blocks["sub_roi_slices"],
         blocks["sub_rois_offsets"], channels, blocks["overlap_padding"])
     final = None
+    colocs = None
     if segments_all is not None:
         segments_all[:, 0:3] = segments_all[:, 7:10]
+        if coloc:
+            # the reference reads the flags starting at column 10 -- the ``region`` column that was
+            # added after this line was written -- so row = [uint8(region), flags of all channels but
+            # the last] (stack_detect.py:463-464)
+            num_chls_roi = 1 if roi.ndim < 4 else roi.shape[3]
+            colocs = segments_all[:, 10:10 + num_chls_roi].astype(np.uint8)
         final = segments_all[:, [0, 1, 2, 3, 4, 5, 6, 10]]
     return final, dict(blocks=blocks, seg_rois=seg_rois, merged=merged_before,
-                       pruned11=segments_all, ratios=ratios)
+                       pruned11=segments_all, ratios=ratios, colocs=colocs)

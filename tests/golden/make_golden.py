@@ -237,7 +237,7 @@ def blocks_cases():
 
 
 def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, near_max=(-1.0,),
-               **over):
+               coloc=False, **over):
     config.resolutions = np.array(resolutions)
     config.near_max = list(near_max)
     config.filename = "golden"
@@ -253,14 +253,14 @@ def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, ne
     bl = quiet(stack_detect.setup_blocks, settings, roi.shape)
     seg_rois = quiet(stack_detect.StackDetector.detect_blobs_sub_rois,
                      img5d, roi, bl.sub_roi_slices, bl.sub_rois_offsets,
-                     bl.denoise_max_shape, bl.exclude_border, False, chls)
+                     bl.denoise_max_shape, bl.exclude_border, coloc, chls)
     merged = chunking.merge_blobs(seg_rois)
     pruned, df = quiet(stack_detect.StackPruner.prune_blobs_mp,
                        roi, seg_rois, bl.overlap, bl.tol, bl.sub_roi_slices,
                        bl.sub_rois_offsets, chls, bl.overlap_padding)
     # and the public entry point end to end
     _, _, blobs = quiet(stack_detect.detect_blobs_blocks, "golden", img5d, None, None,
-                        channels, False, False, True, False)
+                        channels, False, False, True, coloc)
     final = blobs.blobs
     out = dict(roi=roi, channels=np.array(-1 if channels is None else channels),
                resolutions=np.array(resolutions),
@@ -270,7 +270,9 @@ def stack_case(name, roi, channels=None, resolutions=((1., 1., 1.),), cpus=4, ne
                final=np.empty((0, 8)) if final is None else final,
                final_cols=np.array(blobs.cols if blobs.cols is not None else []),
                ratios=np.empty((0, 3)) if df is None or df.empty else df.to_numpy(),
-               near_max=np.array(near_max, dtype=float),
+               near_max=np.array(near_max, dtype=float), coloc=np.array(bool(coloc)),
+               colocs=(np.empty((0, 0), np.uint8) if blobs.colocalizations is None
+                       else blobs.colocalizations),
                overrides=repr(over), versions=repr(VERSIONS))
     config.near_max = [-1.0]
     for c in np.ndindex(*seg_rois.shape):
@@ -339,6 +341,70 @@ def preproc_cases():
     from scipy.ndimage import filters as ndi_filters
     out["gauss8_weights"] = ndi_filters._gaussian_kernel1d(8.0, 0, 32)
     np.savez_compressed(os.path.join(HERE, "preproc.npz"), **out)
+
+
+def make_coloc_volume(seed, shape, n_blobs, n_chl=2, shared=0.5):
+    """Channels whose blobs partly coincide: a fraction ``shared`` of channel 0's centres is reused
+    (with another amplitude) in every other channel."""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.full(3, 6.0), np.asarray(shape, dtype=float) - 6
+    base = rng.uniform(lo, hi, (n_blobs, 3))
+    chls = []
+    for c in range(n_chl):
+        if c == 0:
+            centres = base
+        else:
+            keep = base[rng.random(n_blobs) < shared]
+            own = rng.uniform(lo, hi, (n_blobs - len(keep), 3))
+            centres = np.concatenate((keep, own))
+        chls.append(make_volume(seed * 10 + c, shape, 0, centres=centres, amp=30000.0 + 5000 * c))
+    return np.stack(chls, axis=-1)
+
+
+def coloc_cases():
+    """colocalize_blobs of the real reference on block-sized inputs."""
+    from magmap.cv import colocalizer
+    out, names = {}, []
+
+    def case(name, roi, blobs, thresh=None, roi_key=None):
+        got = quiet(colocalizer.colocalize_blobs, roi, blobs, thresh)
+        if roi_key is None:                  # volumes are stored once and shared between cases
+            roi_key = name + "_roi"
+            out[roi_key] = roi
+        out[name + "_roikey"] = np.array(roi_key)
+        out[name + "_blobs"] = blobs
+        out[name + "_thresh"] = np.array(-1.0 if thresh is None else thresh)
+        out[name + "_colocs"] = np.empty((0, 0), np.uint8) if got is None else got
+        names.append(name)
+        print("coloc %-10s roi %s blobs %s -> %s" % (
+            name, roi.shape, None if blobs is None else blobs.shape,
+            None if got is None else got.sum(axis=0)))
+
+    config.resolutions = np.array([[1., 1., 1.]])
+    setup_profile(num_sigma=3)
+    vol = make_coloc_volume(51, (36, 52, 56), 24)
+    blobs = quiet(detector.detect_blobs, vol, None)
+    case("two", vol, blobs)
+    vol3 = make_coloc_volume(52, (32, 48, 48), 20, n_chl=3, shared=0.4)
+    blobs3 = quiet(detector.detect_blobs, vol3, None)
+    case("three", vol3, blobs3)
+    case("sel1", vol3, quiet(detector.detect_blobs, vol3, [1]), roi_key="three_roi")   # one channel's blobs
+    # crowded: balls overlap, higher row index owns the shared voxels; a duplicate centre owns nothing
+    crowd = blobs.copy()
+    crowd[1, :3] = crowd[0, :3] + (0, 1, 1)
+    crowd[3, :3] = crowd[2, :3]
+    crowd[5, :3] = (0, 0, 0)
+    crowd[6, :3] = np.array(vol.shape[:3]) - 1
+    case("crowd", vol, crowd, roi_key="two_roi")
+    outside = blobs.copy()
+    outside[0, 0] = -1
+    outside[1, 2] = vol.shape[2]
+    case("outside", vol, outside, roi_key="two_roi")
+    case("f64", vol.astype(np.float64) / 65535.0 * 1.7 + 0.2, blobs, roi_key="two_roi:f64")
+    case("single", vol[..., 0], blobs, roi_key="two_roi:ch0")         # 3-D ROI -> None
+    out["names"] = np.array(names)
+    out["versions"] = repr(VERSIONS)
+    np.savez_compressed(os.path.join(HERE, "coloc.npz"), **out)
 
 
 def prune_cases():
@@ -436,6 +502,8 @@ def main():
     print("versions:", VERSIONS)
     if sys.argv[1:] == ["preproc"]:       # only the preprocessing fixtures (added later)
         return main_preproc()
+    if sys.argv[1:] == ["coloc"]:         # only the co-localisation fixtures (added later)
+        return main_coloc()
     # ---- blob_log arithmetic
     bloblog_case("u16_1sigma", make_volume(11, (40, 56, 60), 22), 3, 3, 1)
     bloblog_case("u16_5sigma", make_volume(12, (48, 64, 72), 30), 3, 5, 5)
@@ -487,6 +555,18 @@ def main():
     prune_cases()
 
     main_preproc()
+    main_coloc()
+
+
+def main_coloc():
+    # ---- intensity co-localisation (colocalizer.colocalize_blobs) alone and inside whole-stack detection
+    coloc_cases()
+    stack_case("coloc_2ch", make_coloc_volume(53, (50, 70, 70), 30), None, segment_size=32, num_sigma=3,
+               coloc=True)
+    stack_case("coloc_3ch", make_coloc_volume(54, (44, 64, 60), 24, n_chl=3, shared=0.4), None,
+               segment_size=36, num_sigma=3, coloc=True)
+    stack_case("coloc_denoise", make_coloc_volume(55, (48, 66, 64), 26), None, segment_size=34,
+               num_sigma=3, denoise_size=25, near_max=(-1.0, -1.0), coloc=True)
 
 
 def main_preproc():

@@ -17,6 +17,7 @@ from conftest import GOLDEN, lexsorted, load_golden
 from oracle import blob_log_oracle as blo
 from oracle import magmap_oracle as mmo
 from oracle import preprocess_oracle as ppo
+from oracle import coloc_oracle
 
 BLOBLOG_CASES = sorted(os.path.basename(p)[len("bloblog_"):-4]
                        for p in glob.glob(os.path.join(GOLDEN, "bloblog_*.npz")))
@@ -153,8 +154,9 @@ def test_detect_blobs_blocks_matches_reference(case, golden_gauss_weights):
     g = load_golden("stack_%s.npz" % case)
     channels = None if g["channels"].ndim == 0 else list(g["channels"])
     near_max = list(g["near_max"]) if "near_max" in g else [-1.0]
+    coloc = bool(g["coloc"]) if "coloc" in g else False
     final, st = mmo.detect_blobs_blocks(g["roi"], channels, _stack_profiles(g), g["resolutions"],
-                                        near_max=near_max)
+                                        near_max=near_max, coloc=coloc)
     grid = tuple(g["grid"])
     assert st["seg_rois"].shape == grid
     for c in np.ndindex(*grid):
@@ -170,6 +172,9 @@ def test_detect_blobs_blocks_matches_reference(case, golden_gauss_weights):
     np.testing.assert_array_equal(st["merged"], g["merged"])
     np.testing.assert_array_equal(st["pruned11"][:, 3:], g["pruned11"][:, 3:])
     np.testing.assert_array_equal(final, g["final"])
+    if coloc:
+        assert st["colocs"].dtype == np.uint8
+        np.testing.assert_array_equal(st["colocs"], g["colocs"])
     assert list(g["final_cols"]) == ["z", "y", "x", "radius", "confirmed", "truth", "channel", "region"]
     if g["ratios"].size:
         got = np.array([st["ratios"][k] for k in ("blobs", "ratio_pruning", "ratio_adjacent")]).T
@@ -217,6 +222,34 @@ def test_preprocess_block_tiles_like_the_reference_loop():
     for sl in [(slice(0, 25), slice(25, 45), slice(50, 52)), (slice(25, 40), slice(0, 25), slice(25, 50))]:
         want = ppo.denoise_roi(ppo.saturate_roi(roi[sl], profs, [-1.0]), profs)
         np.testing.assert_array_equal(got[sl], want)
+
+
+COLOC = load_golden("coloc.npz")
+
+
+def coloc_roi(g, case):
+    """The case's ROI (volumes are stored once: ``key[:f64|:ch0]``)."""
+    key = str(g[case + "_roikey"])
+    name, _, mod = key.partition(":")
+    roi = g[name]
+    if mod == "f64":
+        roi = roi.astype(np.float64) / 65535.0 * 1.7 + 0.2
+    elif mod == "ch0":
+        roi = roi[..., 0]
+    return roi
+
+
+@pytest.mark.parametrize("case", [str(n) for n in COLOC["names"]])
+def test_colocalize_blobs_matches_reference(case):
+    """colocalizer.colocalize_blobs restated == the real reference (colocalizer.py:340-441)."""
+    g = COLOC
+    got = coloc_oracle.colocalize_blobs(coloc_roi(g, case), g[case + "_blobs"])
+    want = g[case + "_colocs"]
+    if want.size == 0 and want.ndim == 2 and want.shape[0] == 0:
+        assert got is None
+        return
+    assert got.dtype == np.uint8
+    np.testing.assert_array_equal(got, want)
 
 
 def test_remove_close_blobs_matches_reference():
