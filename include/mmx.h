@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 3
+#define MMX_ABI_VERSION 4
 
 typedef enum {
     MMX_OK = 0,
@@ -244,14 +244,29 @@ int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_su
                                  mmx_subblock_info* d_info, double* d_scratch, int64_t scratch_doubles,
                                  void* stream);
 
+/* ---- C1: intensity co-localisation: for every blob the mean of ONE image
+ * channel over the voxels the blob owns
+ * replaces: the label-volume dilation + per-blob np.mean of colocalizer.colocalize_blobs
+ * (magmap/cv/colocalizer.py:372-421): ball(2) around every blob centre, contested voxels go to the
+ * higher row index among blobs of the same channel of the same block; float64 mean in NumPy's
+ * summation order (bit-equal), NaN when the blob owns no voxel.
+ *   vol      : the image channel to average (any mmx_dtype; raw voxels or a preprocessed slot buffer)
+ *   d_blocks : block geometry (src_off into vol, extent); blob coordinates are block-relative
+ *   d_blobs  : [n_blobs][5] int32 (block slot, z, y, x, channel of the blob), grouped by block in table
+ *              order; d_offsets[n_blocks+1] delimits the blocks
+ *   d_mean   : out [n_blobs] float64; d_count: out [n_blobs] owned voxels (0..33)                   */
+int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
+                    const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
+                    double* d_mean, int32_t* d_count, void* stream);
+
 /* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream.
  * mmx_timing_enable(1) makes every kernel launch of this library record a HIP event
  * before and after itself on its launch stream; mmx_timing_read() synchronises those
  * events, returns summed milliseconds and launch counts per kernel family (index =
  * MMX_K_*: 0 z pass, 1 y pass, 2 x pass, 3 generic passes, 4 peaks, 5 rescore,
- * 6 overlap pairs, 7 close pairs, 8 fused z+x pass, 9 y pass of the fused path, 10 preprocessing)
- * and starts a new window. */
-#define MMX_K_COUNT 11
+ * 6 overlap pairs, 7 close pairs, 8 fused z+x pass, 9 y pass of the fused path, 10 preprocessing,
+ * 11 co-localisation means) and starts a new window. */
+#define MMX_K_COUNT 12
 int mmx_timing_enable(int on);
 int mmx_timing_read(double* ms, int64_t* launches, int n);
 

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 3
+MMX_ABI_VERSION = 4
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -70,9 +70,10 @@ SYMBOLS = (
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
+    "mmx_coloc_means",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
-                "close_pairs", "zxpass", "y2pass", "preproc")
+                "close_pairs", "zxpass", "y2pass", "preproc", "coloc")
 
 
 def lib() -> ctypes.CDLL:
@@ -119,6 +120,8 @@ def lib() -> ctypes.CDLL:
                 c_int64, c_int64, vp, vp, vp]
     L.mmx_preprocess_batch.argtypes = pre_args + [vp]
     L.mmx_preprocess_batch_generic.argtypes = pre_args + [vp, c_int64, vp]
+    L.mmx_coloc_means.argtypes = [POINTER(Volume), vp, c_int, vp, vp, c_int, vp, vp, vp]
+    L.mmx_coloc_means.restype = c_int
     L.mmx_preprocess_batch.restype = c_int
     L.mmx_preprocess_batch_generic.restype = c_int
     for name in SYMBOLS:

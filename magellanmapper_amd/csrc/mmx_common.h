@@ -48,7 +48,7 @@ int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t
 // ---- optional per-kernel-family timing with HIP events on the launch stream (bench.py) ----
 enum mmx_kernel_kind {
     MMX_K_ZPASS = 0, MMX_K_YPASS, MMX_K_XPASS, MMX_K_GENERIC, MMX_K_PEAKS, MMX_K_RESCORE,
-    MMX_K_PAIRS, MMX_K_CLOSE, MMX_K_ZX, MMX_K_Y2, MMX_K_PREPROC, MMX_K_END
+    MMX_K_PAIRS, MMX_K_CLOSE, MMX_K_ZX, MMX_K_Y2, MMX_K_PREPROC, MMX_K_COLOC, MMX_K_END
 };
 void mmx_time_begin(int kind, hipStream_t s);
 void mmx_time_end(int kind, hipStream_t s);

@@ -132,6 +132,118 @@ extern "C" int mmx_close_pairs(const int32_t* d_master, int n_master, const int3
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
+// ---- intensity co-localisation: mean intensity of one image channel over the voxels each blob owns
+// (magmap/cv/colocalizer.py:340-441).  The reference labels a volume per blob channel (row index at
+// every blob centre, -1 elsewhere), grey-dilates it with ball(2) -- 33 voxels, so where two balls
+// meet the HIGHER row index owns the voxel -- and takes np.mean(roi[label == b, c]).  Here one wave
+// owns one blob: lanes 0..32 are the 33 offsets in C order (= the order boolean-mask indexing yields),
+// the block's later blobs of the same channel are scanned for takers, and lane 0 sums the owned
+// voxels in NumPy's pairwise order (n <= 33: eight accumulators over the first 8*floor(n/8), then the
+// tail) so the float64 mean is bit-equal.  A blob that owns nothing gets 0/0 = NaN, as NumPy gives.
+namespace {
+template <typename InT>
+__global__ void __launch_bounds__(64)
+coloc_means_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
+                   const mmx_block* __restrict__ blocks, const int32_t* __restrict__ blobs,
+                   const int32_t* __restrict__ offsets, int n_blobs, double* __restrict__ mean,
+                   int32_t* __restrict__ count)
+{
+    __shared__ double vals[33];
+    const int b = blockIdx.x;
+    if (b >= n_blobs) return;
+    const int lane = threadIdx.x;
+    const int32_t* me = blobs + 5 * (int64_t)b;
+    const int slot = me[0], pz = me[1], py = me[2], px = me[3], chl = me[4];
+    const mmx_block bd = blocks[slot];
+    // lane -> offset (dz, dy, dx) of ball(2) in lexicographic order
+    int dz = 0, dy = 0, dx = 0;
+    bool in_ball = false;
+    {
+        int k = 0;
+        for (int a = -2; a <= 2; ++a)
+            for (int c = -2; c <= 2; ++c)
+                for (int d = -2; d <= 2; ++d)
+                    if (a * a + c * c + d * d <= 4) {
+                        if (k == lane) { dz = a; dy = c; dx = d; in_ball = true; }
+                        ++k;
+                    }
+    }
+    const int vz = pz + dz, vy = py + dy, vx = px + dx;
+    bool owned = in_ball && vz >= 0 && vz < bd.nz && vy >= 0 && vy < bd.ny && vx >= 0 && vx < bd.nx &&
+                 pz >= 0 && pz < bd.nz && py >= 0 && py < bd.ny && px >= 0 && px < bd.nx;
+    // takers: later rows of the same block and channel whose ball reaches this voxel
+    const int end = offsets[slot + 1];
+    for (int t0 = b + 1; t0 < end; t0 += 64) {
+        const int t = t0 + lane;
+        bool near = false;
+        int tz = 0, ty = 0, tx = 0;
+        if (t < end) {
+            const int32_t* o = blobs + 5 * (int64_t)t;
+            tz = o[1]; ty = o[2]; tx = o[3];
+            near = o[4] == chl && abs(tz - pz) <= 4 && abs(ty - py) <= 4 && abs(tx - px) <= 4 &&
+                   tz >= 0 && tz < bd.nz && ty >= 0 && ty < bd.ny && tx >= 0 && tx < bd.nx;
+        }
+        unsigned long long m = __ballot(near);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int qz = __shfl(tz, src), qy = __shfl(ty, src), qx = __shfl(tx, src);
+            const int ez = vz - qz, ey = vy - qy, ex = vx - qx;
+            if (ez * ez + ey * ey + ex * ex <= 4) owned = false;
+        }
+    }
+    const unsigned long long om = __ballot(owned);
+    const int n = __popcll(om);
+    if (owned) {
+        const int rank = __popcll(om & ((1ull << lane) - 1ull));
+        vals[rank] = (double)vol[bd.src_off + vz * sz + vy * sy + vx * sx];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double res;
+        if (n < 8) {
+            res = 0.;
+            for (int i = 0; i < n; ++i) res += vals[i];
+        } else {
+            double r[8];
+            for (int j = 0; j < 8; ++j) r[j] = vals[j];
+            int i;
+            for (i = 8; i < n - (n % 8); i += 8)
+                for (int j = 0; j < 8; ++j) r[j] += vals[i + j];
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < n; ++i) res += vals[i];
+        }
+        mean[b] = (0. + res) / (double)n;       // n == 0 -> NaN, like np.mean of an empty selection
+        count[b] = n;
+    }
+}
+}  // namespace
+
+extern "C" int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
+                               const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
+                               double* d_mean, int32_t* d_count, void* stream)
+{
+    if (!vol || !vol->d_data || !d_blocks || n_blocks < 1 || !d_blobs || !d_offsets || n_blobs < 0 ||
+        !d_mean || !d_count)
+        return MMX_ERR_ARG;
+    if (n_blobs == 0) return MMX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    mmx_timed_scope ts(MMX_K_COLOC, s);
+#define MMX_COLOC_LAUNCH(T)                                                                              \
+    hipLaunchKernelGGL(coloc_means_kernel<T>, dim3(n_blobs), dim3(64), 0, s, (const T*)vol->d_data,        \
+                       vol->stride_z, vol->stride_y, vol->stride_x, d_blocks, d_blobs, d_offsets, n_blobs, \
+                       d_mean, d_count)
+    switch (vol->dtype) {
+        case MMX_U8: MMX_COLOC_LAUNCH(uint8_t); break;
+        case MMX_U16: MMX_COLOC_LAUNCH(uint16_t); break;
+        case MMX_F32: MMX_COLOC_LAUNCH(float); break;
+        case MMX_F64: MMX_COLOC_LAUNCH(double); break;
+        default: return MMX_ERR_UNSUPPORTED;
+    }
+#undef MMX_COLOC_LAUNCH
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
 // ---- PMC calibration kernels (tools/pmc_calib.py): streams of a known byte count with the
 // access shapes the LoG kernels use, to turn rocprofv3 FETCH_SIZE / WRITE_SIZE into bytes.
 namespace {

@@ -363,7 +363,8 @@ def detect_blobs(roi, channel: Optional[Sequence[int]],
 
 
 def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
-                               on_block=None, denoise_max_shape=None) -> List[Optional[np.ndarray]]:
+                               on_block=None, denoise_max_shape=None, exclude=None,
+                               coloc: bool = False) -> List[Optional[np.ndarray]]:
     """:func:`detect_blobs` for many blocks of one resident volume in one device pass.
 
     Returns one 11-column table (block-relative coordinates) or ``None`` per block, rows
@@ -371,7 +372,10 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
     ``blob_log`` order.  ``on_block(i, table)`` (optional) post-processes each finished block
     table while the GPU is still busy with later batches; its return value replaces the table.
     With ``denoise_max_shape`` every block is saturated + denoised tile by tile on the device
-    first (reference stack_detect.py:122-150; :mod:`preprocess`).
+    first (reference stack_detect.py:122-150; :mod:`preprocess`).  ``exclude(i)`` (optional) gives
+    block ``i``'s border-exclusion matrix, applied as ``detect_blobs`` applies it (:952-955); with
+    ``coloc`` the intensity co-localisation flags are then appended as extra columns
+    (stack_detect.py:159-162; :mod:`colocalizer`) -- both before ``on_block``.
     """
     from . import blob_log as bl
     pre = None
@@ -404,8 +408,17 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                 blobs_log[:, 3] = blobs_log[:, 3] * root3
                 per_block[i].append(Blobs(blobs_log).format_blobs(chl))
             if chl == channels[-1]:            # the block tables of this batch are complete
+                tbls = []
                 for i in indices:
                     tbl = np.vstack(per_block[i]) if per_block[i] else None
+                    ex = exclude(i) if exclude is not None else None
+                    if tbl is not None and ex is not None:
+                        tbl = get_blobs_interior(tbl, shapes[i], *ex)
+                    tbls.append(tbl)
+                if coloc:
+                    tbls = _append_colocs(dvol, channels, [origins[i] for i in indices],
+                                          [shapes[i] for i in indices], tbls, denoise_max_shape)
+                for i, tbl in zip(indices, tbls):
                     done[i] = on_block(i, tbl) if on_block is not None else tbl
 
         bl.blob_log_blocks(
@@ -415,6 +428,51 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
             num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
             overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=pre)
     return done
+
+
+def _append_colocs(dvol, channels, origins, shapes, tables, denoise_max_shape):
+    """``np.hstack((table, colocalize_blobs(block, table)))`` for the blocks of one batch
+    (reference stack_detect.py:159-162).  The image the reference hands to ``colocalize_blobs`` is
+    the block as detection saw it: preprocessed when ``denoise_max_shape`` is set."""
+    from . import blob_log as bl
+    from . import colocalizer
+    if not dvol.multichannel:
+        if any(t is not None for t in tables):       # np.hstack((segments, None)) in the reference
+            raise ValueError("all the input arrays must have same number of dimensions: a "
+                             "single-channel ROI cannot be co-localised")
+        return tables
+    dev = dvol.tensor.device
+    if not any(t is not None and len(t) for t in tables):
+        return [None if t is None else np.hstack((t, np.zeros((len(t), dvol.n_channels)))) for t in tables]
+    volumes = {}
+    if denoise_max_shape is None:
+        blocks, _ = bl._make_blocks(dvol, 0, origins, shapes)
+        d_blocks = bl._to_device_bytes(blocks, dev)
+        for c in channels:
+            volumes[c] = dvol.view(c, False)
+        flags = colocalizer.colocalize_blocks_device(volumes, blocks, d_blocks, shapes, tables,
+                                                     dvol.n_channels, dev)
+    else:
+        # one preprocessed channel at a time through a buffer set of its own
+        from . import preprocess
+        global _coloc_pre
+        if _coloc_pre is None or _coloc_pre.dms != [int(v) for v in denoise_max_shape]:
+            _coloc_pre = preprocess.Preprocessor(denoise_max_shape)
+        flags = None
+        for c in channels:
+            blocks, _, _, vol64 = _coloc_pre.run(dvol, c, origins, shapes, 0)
+            d_blocks = bl._to_device_bytes(blocks, dev)
+            part = colocalizer.colocalize_blocks_device({c: vol64}, blocks, d_blocks, shapes, tables,
+                                                        dvol.n_channels, dev, means_only=True)
+            flags = part if flags is None else [None if a is None else np.where(np.isnan(a), b, a)
+                                                for a, b in zip(flags, part)]
+        flags = [None if (t is None or m is None) else
+                 colocalizer._flags_from_means(t, m, shp, dvol.n_channels)
+                 for t, m, shp in zip(tables, flags, shapes)]
+    return [None if t is None else np.hstack((t, f)) for t, f in zip(tables, flags)]
+
+
+_coloc_pre = None
 
 
 # ------------------------------------------------------------------------------------

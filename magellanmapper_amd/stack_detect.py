@@ -154,18 +154,17 @@ class StackDetector:
                        sub_roi, channel, img_path=None, coloc=False):
         """One block given as an array -> ``(coord, table | None)`` with coordinates shifted
         to the full ROI (both the rel and the abs set, :164-170)."""
-        _check_unbuilt(coloc)
         exclude = cls._exclude_matrix(coord, last_coord, exclude_border)
-        if denoise_max_shape is None:
+        if denoise_max_shape is None and not coloc:
             segments = detector.detect_blobs(sub_roi, channel, exclude)
         else:
-            # saturate + denoise tile by tile (:122-150), then detect on the float64 result
+            # saturate + denoise tile by tile (:122-150), detect on the float64 result,
+            # co-localise on the same image (:159-162)
             from . import blob_log as bl
             dvol = sub_roi if isinstance(sub_roi, bl.DeviceVolume) else bl.DeviceVolume(sub_roi)
             segments = detector.detect_blobs_blocks_device(
-                dvol, channel, [(0, 0, 0)], [dvol.shape[:3]], denoise_max_shape=denoise_max_shape)[0]
-            if segments is not None and exclude is not None:
-                segments = detector.get_blobs_interior(segments, dvol.shape[:3], *exclude)
+                dvol, channel, [(0, 0, 0)], [dvol.shape[:3]], denoise_max_shape=denoise_max_shape,
+                exclude=lambda i: exclude, coloc=coloc)[0]
         if segments is not None:
             detector.Blobs.shift_blob_rel_coords(segments, offset)
             detector.Blobs.shift_blob_abs_coords(segments, offset)
@@ -181,7 +180,6 @@ class StackDetector:
         """
         from . import blob_log as bl
         from . import dist
-        _check_unbuilt(coloc)
         cls.img5d, cls.img, cls.channel, cls.coloc = img5d, img, channel, coloc
         cls.denoise_max_shape, cls.exclude_border = denoise_max_shape, exclude_border
         grid = sub_roi_slices.shape
@@ -198,14 +196,18 @@ class StackDetector:
             shapes.append(tuple(r[1] - r[0] for r in rng))
         stats = bl.BatchStats()
         tables = []
-        arena = _TableArena() if dist.world_size() == 1 else None
+        n_extra = (img.shape[3] if len(img.shape) > 3 else 0) if coloc else 0
+        arena = _TableArena(11 + n_extra) if dist.world_size() == 1 else None
         pos = {i: k for k, i in enumerate(mine)}
 
+        def exclude_of(k):
+            return cls._exclude_matrix(coords[mine[k]], last_coord, exclude_border)
+
         def finish(k, tbl):
-            # border exclusion + shift to ROI coordinates, as soon as the block's batch is done
+            # shift to ROI coordinates as soon as the block's batch is done (border exclusion and
+            # co-localisation have happened on the block-relative table, in the reference's order)
             coord = coords[mine[k]]
-            exclude = cls._exclude_matrix(coord, last_coord, exclude_border)
-            tbl = cls._finish_block(tbl, shapes[k], exclude, sub_rois_offsets[coord])
+            tbl = cls._finish_block(tbl, shapes[k], None, sub_rois_offsets[coord])
             if tbl is not None and arena is not None and len(tbl):
                 arena.add(coord, tbl)
             return tbl
@@ -213,7 +215,8 @@ class StackDetector:
         if mine:
             dvol = img if isinstance(img, bl.DeviceVolume) else bl.DeviceVolume(img)
             tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
-                                                         denoise_max_shape=denoise_max_shape)
+                                                         denoise_max_shape=denoise_max_shape,
+                                                         exclude=exclude_of, coloc=coloc)
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
         seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
@@ -224,13 +227,6 @@ class StackDetector:
         if arena is not None:
             seg_rois.arena = arena
         return seg_rois
-
-
-def _check_unbuilt(coloc):
-    if coloc:
-        raise NotImplementedError(
-            "intensity co-localisation (reference colocalizer.py:340-441) is not built yet "
-            "(SURVEY.md section 8f row 2)")
 
 
 class Blocks(NamedTuple):

@@ -1,0 +1,114 @@
+"""GPU parity tests of the intensity co-localisation: ``mmx_coloc_means``
+through the C ABI + the host thresholds against the golden vectors of the real reference's
+``colocalizer.colocalize_blobs`` and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_oracle_golden import COLOC, coloc_roi
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    from magellanmapper_amd import _native
+    assert _native.lib().mmx_device_count() >= 1
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("case", [str(n) for n in COLOC["names"]])
+def test_colocalize_blobs_matches_reference(gpu, case):
+    from magellanmapper_amd import colocalizer
+    got = colocalizer.colocalize_blobs(coloc_roi(COLOC, case), COLOC[case + "_blobs"])
+    want = COLOC[case + "_colocs"]
+    if want.shape[0] == 0:
+        assert got is None
+        return
+    assert got.dtype == np.uint8
+    np.testing.assert_array_equal(got, want)
+
+
+def test_means_are_bit_equal_to_numpy(gpu):
+    """The per-blob means themselves (float64 image: NumPy's pairwise order matters), including
+    crowded blobs whose balls overlap and blobs at the ROI corners."""
+    import ctypes
+    from magellanmapper_amd import _native as nat, blob_log as bl
+    from oracle import coloc_oracle
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(8)
+    roi = rng.random((20, 24, 28, 2)) * 3 - 1
+    n = 60
+    pts = np.stack([rng.integers(0, s, n) for s in roi.shape[:3]], axis=1)
+    pts[:6] = [[0, 0, 0], [19, 23, 27], [0, 1, 1], [5, 5, 5], [5, 6, 6], [5, 5, 5]]
+    chl = rng.integers(0, 2, n)
+    chl[3:6] = 0
+    dvol = bl.DeviceVolume(roi)
+    blocks, _ = bl._make_blocks(dvol, 0, [(0, 0, 0)], [roi.shape[:3]])
+    d_blocks = bl._to_device_bytes(blocks, gpu)
+    rows = np.zeros((n, 5), np.int32)
+    rows[:, 1:4] = pts
+    rows[:, 4] = chl
+    d_rows = torch.from_numpy(rows.reshape(-1)).to(gpu)
+    d_off = torch.tensor([0, n], dtype=torch.int32, device=gpu)
+    d_mean = torch.empty(n, dtype=torch.float64, device=gpu)
+    d_cnt = torch.empty(n, dtype=torch.int32, device=gpu)
+    for c in range(2):
+        vol = dvol.view(c, False)
+        nat.check(nat.lib().mmx_coloc_means(ctypes.byref(vol), d_blocks.data_ptr(), 1, d_rows.data_ptr(),
+                                            d_off.data_ptr(), n, d_mean.data_ptr(), d_cnt.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "coloc")
+        got, cnt = d_mean.cpu().numpy(), d_cnt.cpu().numpy()
+        for bc in range(2):                       # label volume of blob channel bc, as the reference builds it
+            sel = np.where(chl == bc)[0]
+            mask = -np.ones(roi.shape[:3], dtype=int)
+            mask[pts[sel, 0], pts[sel, 1], pts[sel, 2]] = sel
+            mask = ndi.grey_dilation(mask, footprint=coloc_oracle.ball(2))
+            for b in sel:
+                vox = roi[mask == b, c]
+                assert cnt[b] == vox.size
+                if vox.size:
+                    assert got[b] == np.mean(vox), (b, c)
+                else:
+                    assert np.isnan(got[b])
+
+
+def test_stack_coloc_many_batches_matches_oracle(gpu, monkeypatch, tmp_path):
+    """Several device batches (tiny workspace budget), co-localisation on, against the oracle."""
+    import functools
+    from magellanmapper_amd import blob_log as bl, config, stack_detect
+    from oracle import magmap_oracle as mmo
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("stack_coloc_2ch.npz")
+    roi = g["roi"]
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(num_sigma=3, segment_size=24, denoise_size=None)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "coloc"
+    monkeypatch.setattr(bl, "blob_log_blocks", functools.partial(bl.blob_log_blocks, budget_bytes=6 << 20))
+    _, _, blobs = stack_detect.detect_blobs_blocks("coloc", stack_detect.Image5d(roi[None]), None, None,
+                                                   None, False, False, True, True)
+    assert stack_detect.StackDetector.last_stats.n_blocks > 20
+    want, st = mmo.detect_blobs_blocks(roi, None, [dict(config.roi_profile)], config.resolutions, coloc=True)
+    np.testing.assert_array_equal(blobs.blobs, want)
+    np.testing.assert_array_equal(blobs.colocalizations, st["colocs"])
+    assert st["colocs"][:, 1].any()
+
+
+def test_single_channel_coloc_is_switched_off_like_the_reference(gpu, monkeypatch, tmp_path):
+    from magellanmapper_amd import config, stack_detect
+    monkeypatch.chdir(tmp_path)
+    roi = load_golden("stack_coloc_2ch.npz")["roi"][..., 0]
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(num_sigma=3, segment_size=40, denoise_size=None)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    _, _, blobs = stack_detect.detect_blobs_blocks("c1", stack_detect.Image5d(roi[None]), None, None,
+                                                   None, False, False, True, True)
+    assert blobs.colocalizations is None and blobs.blobs.shape[1] == 8
+    with pytest.raises(ValueError):        # np.hstack((segments, None)) in the reference's detect_sub_roi
+        stack_detect.StackDetector.detect_sub_roi((0, 0, 0), (0, 0, 0), (0, 0, 0), None, None, None,
+                                                  roi, None, coloc=True)

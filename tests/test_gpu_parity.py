@@ -269,10 +269,11 @@ def test_detect_blobs_blocks_matches_reference(gpu, case, tmp_path, monkeypatch,
     channels = None if g["channels"].ndim == 0 else list(g["channels"])
     roi = g["roi"]
     chls = channels if channels is not None else (list(range(roi.shape[3])) if roi.ndim > 3 else [0])
+    coloc = bool(g["coloc"]) if "coloc" in g else False
     bl = stack_detect.setup_blocks(config.roi_profile, roi.shape)
     seg = stack_detect.StackDetector.detect_blobs_sub_rois(
         None, roi, bl.sub_roi_slices, bl.sub_rois_offsets, bl.denoise_max_shape, bl.exclude_border,
-        False, chls)
+        coloc, chls)
     assert seg.shape == tuple(g["grid"])
     for c in np.ndindex(*seg.shape):
         want = g["block_%d_%d_%d" % c]
@@ -283,13 +284,18 @@ def test_detect_blobs_blocks_matches_reference(gpu, case, tmp_path, monkeypatch,
     merged = chunking.merge_blobs(seg)
     img5d = stack_detect.Image5d(roi[None])
     _, _, blobs = stack_detect.detect_blobs_blocks("golden", img5d, None, None, channels, False,
-                                                   False, True, False)
+                                                   False, True, coloc)
     if g["final"].shape[0] == 0:
         assert merged is None and blobs.blobs is None
         return
     np.testing.assert_array_equal(merged, g["merged"])
     np.testing.assert_array_equal(blobs.blobs, g["final"])
     assert list(blobs.cols) == list(g["final_cols"])
+    if coloc:         # C1 + the reference's column-offset quirk
+        assert blobs.colocalizations.dtype == np.uint8
+        np.testing.assert_array_equal(blobs.colocalizations, g["colocs"])
+    else:
+        assert blobs.colocalizations is None
 
 
 def test_remove_close_blobs_device(gpu):

@@ -354,10 +354,10 @@ def test_stack_level_prune_from_golden_block_tables(monkeypatch):
 
 
 def test_unbuilt_rows_fail_loudly():
-    with pytest.raises(NotImplementedError):       # co-localisation
-        stack_detect.StackDetector.detect_blobs_sub_rois(
-            None, np.zeros((4, 4, 4), np.uint16), np.zeros((1, 1, 1), object), np.zeros((1, 1, 1, 3)),
-            None, None, True, [0])
+    from magellanmapper_amd import colocalizer
+    with pytest.raises(NotImplementedError):       # percentile thresholds of the intensity co-localisation
+        colocalizer.colocalize_blobs(np.zeros((4, 4, 4, 2), np.uint16), np.zeros((1, 11)), thresh=50)
+    assert colocalizer.colocalize_blobs(np.zeros((4, 4, 4), np.uint16), np.zeros((1, 11))) is None
     from magellanmapper_amd import preprocess
     config.setup_roi_profiles(["minpreproc"])              # a profile with tot_var_denoise
     try:
@@ -369,3 +369,33 @@ def test_unbuilt_rows_fail_loudly():
         stack_detect.detect_blobs_blocks("x", stack_detect.Image5d(None))
     with pytest.raises(IOError):
         stack_detect.detect_blobs_stack("x", None)
+
+
+# ---------------------------------------------------------------- co-localisation host logic
+def test_coloc_flags_from_means_match_reference():
+    """Thresholds + flags (host NumPy) from a means matrix built the reference's way on the CPU:
+    equals the real reference's colocalize_blobs on every golden case, incl. the NaN-poisoned one."""
+    from scipy import ndimage as ndi
+    from magellanmapper_amd import colocalizer
+    from oracle import coloc_oracle
+    from test_oracle_golden import COLOC, coloc_roi
+    for case in [str(n) for n in COLOC["names"]]:
+        roi, blobs, want = coloc_roi(COLOC, case), COLOC[case + "_blobs"], COLOC[case + "_colocs"]
+        if roi.ndim < 4:
+            continue
+        n_chl = roi.shape[3]
+        shape3 = roi.shape[:3]
+        inside = np.all((blobs[:, :3] >= 0) & (blobs[:, :3] < shape3), axis=1)
+        means = np.full((len(blobs), n_chl), np.nan)
+        for bc in range(n_chl):
+            sel = np.where(inside & (blobs[:, 6] == bc))[0]
+            mask = -np.ones(shape3, dtype=int)
+            c = blobs[sel, :3].astype(int)
+            mask[c[:, 0], c[:, 1], c[:, 2]] = sel
+            mask = ndi.grey_dilation(mask, footprint=coloc_oracle.ball(2))
+            for b in sel:
+                vox = mask == b
+                for oc in range(n_chl):
+                    means[b, oc] = np.mean(roi[vox, oc]) if vox.any() else np.nan
+        got = colocalizer._flags_from_means(blobs, means, shape3, n_chl)
+        np.testing.assert_array_equal(got, want, err_msg=case)
