@@ -81,7 +81,15 @@ class DeviceVolume:
             if arr.dtype not in _NP_TO_MMX:
                 arr = _img_as_float_host(arr)
             np_dtype = arr.dtype
-            t = torch.from_numpy(np.ascontiguousarray(arr))
+            if np_dtype not in _NP_TO_MMX:
+                raise TypeError(f"unsupported voxel type {np_dtype}")
+            if arr.ndim not in (3, 4):
+                raise ValueError("image must be (z, y, x) or (z, y, x, c)")
+            mapped = isinstance(image, np.memmap) or not arr.flags.writeable   # (views of) mapped files
+            if mapped and arr.nbytes > _STREAM_MIN_BYTES:
+                t = _upload_streamed(arr, dev)
+            else:
+                t = torch.from_numpy(np.array(arr) if not arr.flags.writeable else np.ascontiguousarray(arr))
         if np_dtype not in _NP_TO_MMX:
             raise TypeError(f"unsupported voxel type {np_dtype}")
         if t.ndim not in (3, 4):
@@ -123,6 +131,35 @@ class DeviceVolume:
         sz, sy, sx = self._strides(t)
         ptr = int(t.data_ptr()) + (int(channel) if self.multichannel else 0) * t.element_size()
         return nat.Volume(ptr, code, 0, int(sz), int(sy), int(sx))
+
+
+#: memory-mapped images above this size go to the device plane block by plane block
+_STREAM_MIN_BYTES = 64 << 20
+_STREAM_CHUNK_BYTES = 256 << 20
+
+
+def _upload_streamed(arr: np.ndarray, dev) -> "torch.Tensor":
+    """Copy a (memory-mapped) ``(z, y, x[, c])`` image to the device through two pinned staging
+    buffers: the file is read once, the host never holds a second full copy, and reading chunk
+    k + 1 overlaps the DMA of chunk k."""
+    tdtype = getattr(torch, str(arr.dtype))
+    out = torch.empty(arr.shape, dtype=tdtype, device=dev)
+    plane = int(np.prod(arr.shape[1:])) * arr.dtype.itemsize
+    nz = max(1, min(arr.shape[0], _STREAM_CHUNK_BYTES // max(1, plane)))
+    stage = [torch.empty((nz,) + tuple(arr.shape[1:]), dtype=tdtype).pin_memory() for _ in range(2)]
+    done = [None, None]
+    for k, z0 in enumerate(range(0, arr.shape[0], nz)):
+        z1 = min(z0 + nz, arr.shape[0])
+        buf = stage[k & 1]
+        if done[k & 1] is not None:
+            done[k & 1].synchronize()              # the DMA that last used this buffer
+        np.copyto(buf[:z1 - z0].numpy(), arr[z0:z1])
+        out[z0:z1].copy_(buf[:z1 - z0], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        done[k & 1] = ev
+    torch.cuda.current_stream().synchronize()
+    return out
 
 
 def _img_as_float_host(arr: np.ndarray) -> np.ndarray:

@@ -29,6 +29,9 @@ resolutions = None
 #: per-channel near-maximum intensities from the image metadata; floors the stretch ceiling of
 #: ``saturate_roi`` (reference config.py:211, plot_3d.py:95-99)
 near_max = [-1.0]
+near_min = [0.0]
+magnification = 1.0
+zoom = 1.0
 save_subimg: bool = False
 truth_db_mode = None
 grid_search_profile = None

@@ -504,6 +504,8 @@ def main():
         return main_preproc()
     if sys.argv[1:] == ["coloc"]:         # only the co-localisation fixtures (added later)
         return main_coloc()
+    if sys.argv[1:] == ["image5d"]:       # only the on-disk image fixtures (added later)
+        return main_image5d()
     # ---- blob_log arithmetic
     bloblog_case("u16_1sigma", make_volume(11, (40, 56, 60), 22), 3, 3, 1)
     bloblog_case("u16_5sigma", make_volume(12, (48, 64, 72), 30), 3, 5, 5)
@@ -556,6 +558,39 @@ def main():
 
     main_preproc()
     main_coloc()
+    main_image5d()
+
+
+def main_image5d():
+    """A small image written the way the reference's importer writes it: ``sample_image5d.npy`` +
+    ``sample_meta.yml`` (importer.save_image_info), and what the real ``importer.read_file`` then
+    reports (shape, dtype, the config globals it sets)."""
+    from magmap.io import importer
+    vol = np.stack((make_volume(61, (20, 36, 40), 8), make_volume(62, (20, 36, 40), 6)), axis=-1)
+    image5d = vol[None]
+    base = os.path.join(HERE, "sample")
+    path_img, path_meta = quiet(importer.make_filenames, base + ".czi")
+    with open(path_img, "wb") as f:
+        np.save(f, image5d)
+    lows, highs = np.percentile(vol.reshape(-1, 2), (0.5, 99.5), axis=0)
+    quiet(importer.save_image_info, path_meta, ["sample.czi"], [image5d.shape], [[5.0, 1.2, 1.2]], 5.0, 1.0,
+          lows.tolist(), highs.tolist())
+    config.resolutions = None
+    config.near_max = [-1.0]
+    img5d = quiet(importer.read_file, base + ".czi", 0)
+    np.savez_compressed(os.path.join(HERE, "image5d_expect.npz"),
+                        path_img=np.array(os.path.basename(img5d.path_img)),
+                        path_meta=np.array(os.path.basename(img5d.path_meta)),
+                        shape=np.array(img5d.img.shape), dtype=np.array(str(img5d.img.dtype)),
+                        is_memmap=np.array(isinstance(img5d.img, np.memmap)),
+                        resolutions=np.array(config.resolutions), near_max=np.array(config.near_max),
+                        near_min=np.array(config.near_min), magnification=np.array(config.magnification),
+                        zoom=np.array(config.zoom), meta_keys=np.array(sorted(str(k) for k in img5d.meta
+                                                                              if isinstance(k, str))),
+                        versions=repr(VERSIONS))
+    config.near_max = [-1.0]
+    print("image5d: %s %s, resolutions %s, near_max %s" % (img5d.img.shape, img5d.img.dtype,
+                                                          config.resolutions, highs))
 
 
 def main_coloc():

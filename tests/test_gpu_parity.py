@@ -440,3 +440,35 @@ def test_two_ranks_share_one_volume(gpu, tmp_path):
     assert r1["n_gpus"] == 1 and r2["n_gpus"] == 2
     assert r1["blobs"] == r2["blobs"] and r1["blobs"] > 100
     assert r2["config"]["blocks_per_rank"] == 2          # 1 x 2 x 2 blocks over two ranks
+
+
+def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
+    """importer.read_file (memory-mapped image5d.npy + meta.yml written by the real reference) ->
+    detect_blobs_stack -> archive; equals detection on the in-memory array, and the metadata
+    (resolutions, near_max) reaches the detection and the preprocessing."""
+    import shutil
+    from magellanmapper_amd import blob_log as bl, config, detector, importer, stack_detect
+    from oracle import magmap_oracle as mmo
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 1 << 10)        # take the streamed-upload path
+    monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 40 << 10)     # ... in several chunks
+    for fn in ("sample_image5d.npy", "sample_meta.yml"):
+        shutil.copy(os.path.join(GOLDEN, fn), tmp_path / fn)
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(num_sigma=3, segment_size=30)      # denoise_size stays at the default 25
+    config.resolutions, config.near_max, config.channel = None, [-1.0], None
+    try:
+        img5d = importer.read_file(str(tmp_path / "sample.czi"))
+        config.filename = str(tmp_path / "sample.czi")
+        assert isinstance(img5d.img, np.memmap)
+        np.testing.assert_array_equal(config.resolutions, [[5.0, 1.2, 1.2]])
+        _, _, blobs = stack_detect.detect_blobs_stack(str(tmp_path / "sample"), img5d)
+        want, _ = mmo.detect_blobs_blocks(np.asarray(img5d.img[0]), None, [dict(config.roi_profile)],
+                                          config.resolutions, near_max=config.near_max)
+        np.testing.assert_array_equal(blobs.blobs, want)
+        back = detector.Blobs().load_blobs(str(tmp_path / "sample_blobs.npz"))
+        np.testing.assert_array_equal(back.blobs, want)
+        np.testing.assert_array_equal(back.resolutions, config.resolutions)
+    finally:
+        config.resolutions, config.near_max = None, [-1.0]
+        detector.Blobs(np.ones((1, 4))).format_blobs()
