@@ -292,6 +292,12 @@ int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
                         int64_t* out_cur, int64_t* out_n,
                         int64_t* n_slab, int64_t* n_after, int64_t* n_next);
 
+/* Output assembly of the same step: out[i] = table[rows[i]][:n_cols] with the three absolute-coordinate
+ * columns taken from the compact (n_table, 3) array the axis steps updated (the reference's
+ * `blobs_all[:, :-3]` after pruning, stack_detect.py:858-861).  table: float64, row pitch ld. */
+int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int64_t n,
+                       int64_t n_cols, const double* abs_zyx, const int32_t abs_cols[3], double* out);
+
 /* PMC calibration (tools/pmc_calib.py): one streaming launch over n_elems elements with a known
  * byte count.  kind 0: float copy, 4 B per lane; 1: float copy, 16 B per lane; 2: uint16 read. */
 int mmx_calib_stream(int kind, const void* d_in, void* d_out, int64_t n_elems, void* stream);

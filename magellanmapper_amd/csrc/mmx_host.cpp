@@ -20,9 +20,31 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/mmx.h"
+
+namespace {
+// run fn(t, n_threads) on a few host threads (the tables have ~3e5 rows: a handful is enough)
+template <typename F>
+void parallel(int n_threads, F fn)
+{
+    if (n_threads <= 1) { fn(0, 1); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)n_threads - 1);
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(fn, t, n_threads);
+    fn(0, n_threads);
+    for (auto& th : pool) th.join();
+}
+
+int host_threads(int64_t n_rows)
+{
+    if (n_rows < 20000) return 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+}
+}  // namespace
 
 extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
                                    const int64_t* cur, int64_t n_cur, int axis, int n_sections,
@@ -39,71 +61,94 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
     // group ids: pass j -> j ; slab j master -> n_sections + 2j ; slab j kept check -> n_sections + 2j + 1
     const int n_groups = n_sections + 2 * n_slabs;
     std::vector<int32_t> group((size_t)n_cur, -1);
-    std::vector<std::vector<int64_t>> masters((size_t)n_slabs), checks((size_t)n_slabs);
     for (int j = 0; j < n_slabs; ++j) { n_slab[j] = 0; n_after[j] = 0; n_next[j] = 0; }
 
-    for (int64_t i = 0; i < n_cur; ++i) {
-        const int64_t row = cur[i];
-        const double pos = (double)zyx[3 * row + axis];
-        for (int j = 0; j < n_slabs; ++j)
-            if (nxt_lo[j] == nxt_lo[j] && pos >= nxt_lo[j] && pos < nxt_hi[j]) ++n_next[j];
-        // region = (number of bounds <= pos) - 1   (np.searchsorted(bounds, pos, side="right") - 1)
-        const int region = (int)(std::upper_bound(bounds, bounds + n_regions, pos) - bounds) - 1;
-        if (region < 0 || !(pos < last_end)) continue;
-        const int sec = region >> 1;
-        if ((region & 1) == 0) { group[(size_t)i] = sec; continue; }
-        ++n_slab[sec];
-        const int32_t t = tag[3 * row + axis];
-        if (t == sec) { group[(size_t)i] = n_sections + 2 * sec; masters[(size_t)sec].push_back(i); }
-        else if (t == sec + 1) { group[(size_t)i] = n_sections + 2 * sec + 1; checks[(size_t)sec].push_back(i); }
-    }
+    // ---- classification, in contiguous chunks of the current order (one per thread)
+    const int T = host_threads(n_cur);
+    struct part { std::vector<std::vector<int64_t>> masters, checks; std::vector<int64_t> n_slab, n_next; };
+    std::vector<part> parts((size_t)T);
+    parallel(T, [&](int t, int nt) {
+        part& P = parts[(size_t)t];
+        P.masters.assign((size_t)n_slabs, {});
+        P.checks.assign((size_t)n_slabs, {});
+        P.n_slab.assign((size_t)n_slabs, 0);
+        P.n_next.assign((size_t)n_slabs, 0);
+        const int64_t lo = n_cur * t / nt, hi = n_cur * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t row = cur[i];
+            const double pos = (double)zyx[3 * row + axis];
+            for (int j = 0; j < n_slabs; ++j)
+                if (nxt_lo[j] == nxt_lo[j] && pos >= nxt_lo[j] && pos < nxt_hi[j]) ++P.n_next[(size_t)j];
+            // region = (number of bounds <= pos) - 1   (np.searchsorted(bounds, pos, side="right") - 1)
+            const int region = (int)(std::upper_bound(bounds, bounds + n_regions, pos) - bounds) - 1;
+            if (region < 0 || !(pos < last_end)) continue;
+            const int sec = region >> 1;
+            if ((region & 1) == 0) { group[(size_t)i] = sec; continue; }
+            ++P.n_slab[(size_t)sec];
+            const int32_t tg = tag[3 * row + axis];
+            if (tg == sec) { group[(size_t)i] = n_sections + 2 * sec; P.masters[(size_t)sec].push_back(i); }
+            else if (tg == sec + 1) { group[(size_t)i] = n_sections + 2 * sec + 1; P.checks[(size_t)sec].push_back(i); }
+        }
+    });
+    std::vector<std::vector<int64_t>> masters((size_t)n_slabs), checks((size_t)n_slabs);
+    for (int j = 0; j < n_slabs; ++j)
+        for (int t = 0; t < T; ++t) {           // chunk order == table order
+            const part& P = parts[(size_t)t];
+            masters[(size_t)j].insert(masters[(size_t)j].end(), P.masters[(size_t)j].begin(), P.masters[(size_t)j].end());
+            checks[(size_t)j].insert(checks[(size_t)j].end(), P.checks[(size_t)j].begin(), P.checks[(size_t)j].end());
+            n_slab[j] += P.n_slab[(size_t)j];
+            n_next[j] += P.n_next[(size_t)j];
+        }
 
-    // the axis to sort the check rows on: the longer of the two other axes is fine, any works
+    // ---- matching: the slabs are independent (disjoint rows), one at a time per thread
+    // the axis to sort the check rows on: any of the two other axes works
     const int sa = axis == 0 ? 1 : 0;
-    std::vector<std::pair<int32_t, int64_t>> order;      // (coordinate on sa, position in checks[j])
-    std::vector<double> new_abs;
-    for (int j = 0; j < n_slabs; ++j) {
-        const auto& M = masters[(size_t)j];
-        const auto& C = checks[(size_t)j];
-        int64_t kept = (int64_t)C.size();
-        if (!M.empty() && !C.empty()) {
-            order.clear();
-            order.reserve(C.size());
-            for (size_t k = 0; k < C.size(); ++k) order.emplace_back(zyx[3 * cur[C[k]] + sa], (int64_t)k);
-            std::sort(order.begin(), order.end());
-            std::vector<char> hit(C.size(), 0);
-            new_abs.assign(M.size() * 3, 0.0);
-            std::vector<int64_t> last(M.size(), -1);
-            for (size_t m = 0; m < M.size(); ++m) {
-                const int32_t* mz = zyx + 3 * cur[M[m]];
-                const int32_t lo = mz[sa] - tol[sa], hi = mz[sa] + tol[sa];
-                auto it = std::lower_bound(order.begin(), order.end(), std::make_pair(lo, (int64_t)-1));
-                for (; it != order.end() && it->first <= hi; ++it) {
-                    const int32_t* cz = zyx + 3 * cur[C[(size_t)it->second]];
-                    if (std::abs(mz[0] - cz[0]) <= tol[0] && std::abs(mz[1] - cz[1]) <= tol[1] &&
-                        std::abs(mz[2] - cz[2]) <= tol[2]) {
-                        hit[(size_t)it->second] = 1;
-                        if (it->second > last[m]) last[m] = it->second;
+    parallel(std::min(T, n_slabs), [&](int t, int nt) {
+        std::vector<std::pair<int32_t, int64_t>> order;      // (coordinate on sa, position in checks[j])
+        std::vector<double> new_abs;
+        for (int j = t; j < n_slabs; j += nt) {
+            const auto& M = masters[(size_t)j];
+            const auto& C = checks[(size_t)j];
+            int64_t kept = (int64_t)C.size();
+            if (!M.empty() && !C.empty()) {
+                order.clear();
+                order.reserve(C.size());
+                for (size_t k = 0; k < C.size(); ++k) order.emplace_back(zyx[3 * cur[C[k]] + sa], (int64_t)k);
+                std::sort(order.begin(), order.end());
+                std::vector<char> hit(C.size(), 0);
+                new_abs.assign(M.size() * 3, 0.0);
+                std::vector<int64_t> last(M.size(), -1);
+                for (size_t m = 0; m < M.size(); ++m) {
+                    const int32_t* mz = zyx + 3 * cur[M[m]];
+                    const int32_t lo = mz[sa] - tol[sa], hi = mz[sa] + tol[sa];
+                    auto it = std::lower_bound(order.begin(), order.end(), std::make_pair(lo, (int64_t)-1));
+                    for (; it != order.end() && it->first <= hi; ++it) {
+                        const int32_t* cz = zyx + 3 * cur[C[(size_t)it->second]];
+                        if (std::abs(mz[0] - cz[0]) <= tol[0] && std::abs(mz[1] - cz[1]) <= tol[1] &&
+                            std::abs(mz[2] - cz[2]) <= tol[2]) {
+                            hit[(size_t)it->second] = 1;
+                            if (it->second > last[m]) last[m] = it->second;
+                        }
                     }
                 }
+                // averages from the values before any update of this stage
+                for (size_t m = 0; m < M.size(); ++m) {
+                    if (last[m] < 0) continue;
+                    const double* am = abs_zyx + 3 * cur[M[m]];
+                    const double* ac = abs_zyx + 3 * cur[C[(size_t)last[m]]];
+                    for (int a = 0; a < 3; ++a) new_abs[3 * m + a] = std::nearbyint((am[a] + ac[a]) / 2);
+                }
+                for (size_t m = 0; m < M.size(); ++m) {
+                    if (last[m] < 0) continue;
+                    double* am = abs_zyx + 3 * cur[M[m]];
+                    for (int a = 0; a < 3; ++a) am[a] = new_abs[3 * m + a];
+                }
+                for (size_t k = 0; k < C.size(); ++k)
+                    if (hit[k]) { group[(size_t)C[k]] = -1; --kept; }
             }
-            // averages from the values before any update of this stage
-            for (size_t m = 0; m < M.size(); ++m) {
-                if (last[m] < 0) continue;
-                const double* am = abs_zyx + 3 * cur[M[m]];
-                const double* ac = abs_zyx + 3 * cur[C[(size_t)last[m]]];
-                for (int a = 0; a < 3; ++a) new_abs[3 * m + a] = std::nearbyint((am[a] + ac[a]) / 2);
-            }
-            for (size_t m = 0; m < M.size(); ++m) {
-                if (last[m] < 0) continue;
-                double* am = abs_zyx + 3 * cur[M[m]];
-                for (int a = 0; a < 3; ++a) am[a] = new_abs[3 * m + a];
-            }
-            for (size_t k = 0; k < C.size(); ++k)
-                if (hit[k]) { group[(size_t)C[k]] = -1; --kept; }
+            n_after[j] = (int64_t)M.size() + kept;
         }
-        n_after[j] = (int64_t)M.size() + kept;
-    }
+    });
 
     // stable counting sort of the surviving rows by group
     std::vector<int64_t> start((size_t)n_groups + 1, 0);
@@ -115,5 +160,28 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
         const int g = group[(size_t)i];
         if (g >= 0) out_cur[start[(size_t)g]++] = cur[i];
     }
+    return MMX_OK;
+}
+
+// Rows `rows[0..n)` of a float64 table (row pitch `ld`), first `n_cols` columns, with three of the
+// columns replaced from a compact (n_table, 3) array -- the output of prune_blobs_mp
+// (`merged[rows][:, :-3]` with the updated absolute coordinates put back).
+extern "C" int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int64_t n,
+                                  int64_t n_cols, const double* abs_zyx, const int32_t abs_cols[3],
+                                  double* out)
+{
+    if (!table || (!rows && n) || !out || n < 0 || n_cols < 1 || n_cols > ld || !abs_zyx || !abs_cols)
+        return MMX_ERR_ARG;
+    for (int a = 0; a < 3; ++a)
+        if (abs_cols[a] < 0 || abs_cols[a] >= n_cols) return MMX_ERR_ARG;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t r = rows[i];
+            double* o = out + i * n_cols;
+            std::memcpy(o, table + r * ld, (size_t)n_cols * sizeof(double));
+            for (int a = 0; a < 3; ++a) o[abs_cols[a]] = abs_zyx[3 * r + a];
+        }
+    });
     return MMX_OK;
 }

@@ -64,12 +64,13 @@ class _TableArena:
         self.store = np.empty((self.cap, n_cols + 3))
         self.zyx = np.empty((self.cap, 3), dtype=np.int32)
         self.tag = np.empty((self.cap, 3), dtype=np.int32)
+        self.abs = np.empty((self.cap, 3))
         self.n = 0
         self.spans = {}
 
     def _grow(self, need: int):
         cap = max(2 * self.cap, need)
-        for name in ("store", "zyx", "tag"):
+        for name in ("store", "zyx", "tag", "abs"):
             old = getattr(self, name)
             new = np.empty((cap,) + old.shape[1:], dtype=old.dtype)
             new[:self.n] = old[:self.n]
@@ -85,6 +86,7 @@ class _TableArena:
         self.store[a:a + rows, self.n_cols:] = coord
         self.zyx[a:a + rows] = table[:, :3]
         self.tag[a:a + rows] = coord
+        self.abs[a:a + rows] = table[:, 7:10]
         self.n += rows
         self.spans[tuple(coord)] = (a, a + rows)
 
@@ -478,7 +480,11 @@ class StackPruner:
         else:
             zyx = np.ascontiguousarray(merged[:, :3], dtype=np.int32)  # detection coordinates never change
             tags = np.ascontiguousarray(merged[:, ncol - 3:], dtype=np.int32)
-        abs_cur = np.ascontiguousarray(merged[:, abs_inds], dtype=np.float64)  # the only values pruning changes
+        # the only values pruning changes (a private copy: the per-block tables stay as detected)
+        if arena is not None and list(abs_inds) == [7, 8, 9]:
+            abs_cur = arena.abs[:arena.n].copy()
+        else:
+            abs_cur = np.ascontiguousarray(merged[:, abs_inds], dtype=np.float64)
         tol3 = (ctypes.c_int32 * 3)(*[int(v) for v in np.broadcast_to(np.asarray(tol), (3,))])
         lib = nat.lib()
         pieces = []
@@ -534,8 +540,16 @@ class StackPruner:
                                 ratios_all.setdefault(col, []).append(val)
             pieces.append(cur)
         rows = np.concatenate(pieces)
-        out = np.take(merged, rows, axis=0)[:, :-3]          # (np.take: 10x fancy indexing)
-        out[:, abs_inds] = np.take(abs_cur, rows, axis=0)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        if merged.dtype == np.float64 and merged.strides[1] == 8 and merged.strides[0] % 8 == 0:
+            out = np.empty((len(rows), ncol - 3))
+            cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
+            nat.check(lib.mmx_host_take_rows(
+                merged.ctypes.data, merged.strides[0] // 8, rows.ctypes.data, len(rows), ncol - 3,
+                abs_cur.ctypes.data, cols3, out.ctypes.data), "mmx_host_take_rows")
+        else:
+            out = np.take(merged, rows, axis=0)[:, :-3]
+            out[:, abs_inds] = np.take(abs_cur, rows, axis=0)
         return out, pd.DataFrame(ratios_all)
 
     @staticmethod
