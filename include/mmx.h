@@ -259,6 +259,19 @@ int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks, int n_bloc
                     const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
                     double* d_mean, int32_t* d_count, void* stream);
 
+/* ---- U1: spectral unmixing ahead of detection
+ * replaces: detector.detect_blobs' `roi_detect = np.subtract(roi_detect, fac * roi[..., k]);
+ * roi_detect[roi_detect < 0] = 0` for every (k, fac) of the profile's spectral_unmixing entry
+ * (magmap/cv/detector.py:910-921), float64, bit-equal.
+ *   vol, h_subs[k] : the detected channel and the channels to subtract (same dtype, same block table)
+ *   d_blocks       : block geometry (src_off into every source, extent, slot)
+ *   d_out32/64     : [n_blocks][dst_slot] with strides (dst_sz, dst_sy, 1): float32 for the LoG passes,
+ *                    float64 for the exact re-score                                               */
+int mmx_unmix_batch(const mmx_volume* vol, const mmx_volume* h_subs, const double* h_facs, int n_subs,
+                    const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                    int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                    float* d_out32, double* d_out64, void* stream);
+
 /* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream.
  * mmx_timing_enable(1) makes every kernel launch of this library record a HIP event
  * before and after itself on its launch stream; mmx_timing_read() synchronises those

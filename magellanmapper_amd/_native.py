@@ -70,7 +70,7 @@ SYMBOLS = (
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
-    "mmx_coloc_means", "mmx_host_take_rows",
+    "mmx_coloc_means", "mmx_host_take_rows", "mmx_unmix_batch",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass", "preproc", "coloc")
@@ -120,6 +120,9 @@ def lib() -> ctypes.CDLL:
                 c_int64, c_int64, vp, vp, vp]
     L.mmx_preprocess_batch.argtypes = pre_args + [vp]
     L.mmx_preprocess_batch_generic.argtypes = pre_args + [vp, c_int64, vp]
+    L.mmx_unmix_batch.argtypes = [POINTER(Volume), POINTER(Volume), POINTER(c_double), c_int, vp, vp, c_int,
+                                  c_int64, c_int64, c_int64, vp, vp, vp]
+    L.mmx_unmix_batch.restype = c_int
     L.mmx_host_take_rows.argtypes = [vp, c_int64, vp, c_int64, c_int64, vp, POINTER(c_int32), vp]
     L.mmx_coloc_means.argtypes = [POINTER(Volume), vp, c_int, vp, vp, c_int, vp, vp, vp]
     L.mmx_coloc_means.restype = c_int

@@ -13,6 +13,9 @@
 //   detector.py:1069).
 // Built with -ffp-contract=off so the float64 expressions round like the Python ones.
 
+#include <algorithm>
+#include <cstring>
+
 #include "mmx_common.h"
 
 namespace {
@@ -241,6 +244,83 @@ extern "C" int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks,
         default: return MMX_ERR_UNSUPPORTED;
     }
 #undef MMX_COLOC_LAUNCH
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+// ---- spectral unmixing ahead of detection (magmap/cv/detector.py:910-921): for the detected channel
+//     x = x - fac_k * roi[..., k]  ;  x[x < 0] = 0      for every (k, fac_k) in turn, in float64
+// (NumPy promotes `uint16 - float * uint16` to float64; one rounding for the product, one for the
+// difference: no FMA, this file is built with -ffp-contract=off).  Streaming kernel: 1 + K voxels in,
+// 8 + 4 bytes out per voxel, written in the uniform-stride slot layout the preprocessing uses.
+#define MMX_UNMIX_MAX 8
+struct unmix_args {
+    const void* sub[MMX_UNMIX_MAX];
+    double fac[MMX_UNMIX_MAX];
+    int64_t sub_sz[MMX_UNMIX_MAX], sub_sy[MMX_UNMIX_MAX], sub_sx[MMX_UNMIX_MAX];
+    int32_t n_subs, _pad;
+};
+namespace {
+template <typename InT>
+__global__ void __launch_bounds__(MMX_WG)
+unmix_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx, unmix_args U,
+             const mmx_block* __restrict__ blocks, int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+             float* __restrict__ out32, double* __restrict__ out64)
+{
+    const mmx_block bd = blocks[blockIdx.y];
+    const int64_t n = (int64_t)bd.nz * bd.ny * bd.nx;
+    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * MMX_WG) {
+        const int64_t t = i / bd.nx, x = i - t * bd.nx, z = t / bd.ny, y = t - z * bd.ny;
+        double v = (double)vol[bd.src_off + z * sz + y * sy + x * sx];
+        for (int k = 0; k < U.n_subs; ++k) {
+            const InT* sp = (const InT*)U.sub[k];
+            const double m = U.fac[k] * (double)sp[bd.src_off + z * U.sub_sz[k] + y * U.sub_sy[k] + x * U.sub_sx[k]];
+            v = v - m;
+            if (v < 0.) v = 0.;
+        }
+        const int64_t d = (int64_t)bd.slot * dst_slot + z * dst_sz + y * dst_sy + x;
+        out64[d] = v;
+        out32[d] = (float)v;
+    }
+}
+}  // namespace
+
+extern "C" int mmx_unmix_batch(const mmx_volume* vol, const mmx_volume* h_subs, const double* h_facs, int n_subs,
+                               const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                               int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                               float* d_out32, double* d_out64, void* stream)
+{
+    if (!vol || !vol->d_data || (n_subs && (!h_subs || !h_facs)) || n_subs < 0 || !d_blocks || !h_blocks ||
+        n_blocks < 1 || !d_out32 || !d_out64)
+        return MMX_ERR_ARG;
+    if (n_subs > MMX_UNMIX_MAX) return MMX_ERR_UNSUPPORTED;
+    unmix_args U;
+    memset(&U, 0, sizeof U);
+    U.n_subs = n_subs;
+    for (int k = 0; k < n_subs; ++k) {
+        if (!h_subs[k].d_data || h_subs[k].dtype != vol->dtype) return MMX_ERR_ARG;
+        U.sub[k] = h_subs[k].d_data;
+        U.fac[k] = h_facs[k];
+        U.sub_sz[k] = h_subs[k].stride_z; U.sub_sy[k] = h_subs[k].stride_y; U.sub_sx[k] = h_subs[k].stride_x;
+    }
+    int64_t max_vox = 1;
+    for (int i = 0; i < n_blocks; ++i) {
+        if (h_blocks[i].nz < 1 || h_blocks[i].ny < 1 || h_blocks[i].nx < 1) return MMX_ERR_ARG;
+        max_vox = std::max<int64_t>(max_vox, (int64_t)h_blocks[i].nz * h_blocks[i].ny * h_blocks[i].nx);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)std::min<int64_t>((max_vox + MMX_WG * 4 - 1) / (MMX_WG * 4), 65535), (unsigned)n_blocks);
+    mmx_timed_scope ts(MMX_K_GENERIC, s);
+#define MMX_UNMIX_LAUNCH(T)                                                                                 \
+    hipLaunchKernelGGL(unmix_kernel<T>, grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z,      \
+                       vol->stride_y, vol->stride_x, U, d_blocks, dst_slot, dst_sy, dst_sz, d_out32, d_out64)
+    switch (vol->dtype) {
+        case MMX_U8: MMX_UNMIX_LAUNCH(uint8_t); break;
+        case MMX_U16: MMX_UNMIX_LAUNCH(uint16_t); break;
+        case MMX_F32: MMX_UNMIX_LAUNCH(float); break;
+        case MMX_F64: MMX_UNMIX_LAUNCH(double); break;
+        default: return MMX_ERR_UNSUPPORTED;
+    }
+#undef MMX_UNMIX_LAUNCH
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 

@@ -393,9 +393,17 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
     channels = list(channels)
     for chl in channels:
         settings = config.get_roi_profile(chl)
-        if getattr(settings, "spectral_unmixing", None) is not None:
-            raise NotImplementedError("spectral unmixing (reference detector.py:910-921) is "
-                                      "not built yet (SURVEY.md section 8f row 4)")
+        source = pre
+        spectral_unmixing = getattr(settings, "spectral_unmixing", None)
+        if spectral_unmixing is not None:
+            # x -= fac * roi[..., k]; x[x < 0] = 0 for every entry of this channel (:910-921)
+            subtract = [(k, f) for spec_chl, spec in spectral_unmixing.items() if spec_chl == chl
+                        for k, f in spec.items()]
+            if subtract:
+                from . import preprocess
+                source = preprocess.Unmixer(subtract, denoise_max_shape)
+                source._raw_scale = (float(np.iinfo(dvol.np_dtype).max) if dvol.np_dtype.kind in "ui"
+                                     else dvol.value_scale())
         scaling_factor = calc_scaling_factor()[2]          # x scaling alone, as the reference
         root3 = math.sqrt(3)
 
@@ -426,7 +434,7 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
             min_sigma=settings["min_sigma_factor"] * scaling_factor,
             max_sigma=settings["max_sigma_factor"] * scaling_factor,
             num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
-            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=pre)
+            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=source)
     return done
 
 

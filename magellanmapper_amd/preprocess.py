@@ -298,6 +298,85 @@ class Preprocessor:
         return res
 
 
+class Unmixer:
+    """Spectral unmixing of one detected channel for the blocks of a batch (reference
+    magmap/cv/detector.py:910-921): ``x = x - fac * roi[..., k]; x[x < 0] = 0`` for every
+    ``(k, fac)`` in turn, in float64, on the block as detection sees it -- the raw voxels, or the
+    preprocessed channels when ``denoise_max_shape`` is set (the reference preprocesses the block in
+    ``detect_sub_roi`` before ``detect_blobs`` unmixes it).  Same ``run`` contract as
+    :class:`Preprocessor`, so ``blob_log_blocks`` takes either."""
+
+    def __init__(self, subtract: Sequence[Tuple[int, float]], denoise_max_shape=None, near_max=None):
+        self.subtract = [(int(k), float(f)) for k, f in subtract]
+        self.dms = None if denoise_max_shape is None else [int(v) for v in denoise_max_shape]
+        self.near_max = near_max
+        self._pres: Dict[int, Preprocessor] = {}
+        self._out64 = [None, None]
+        self._out32 = None
+
+    def bytes_per_voxel(self) -> int:
+        n_src = 1 + len({k for k, _ in self.subtract})
+        return 20 + (0 if self.dms is None else 20 * n_src)
+
+    def value_scale(self, channels: Sequence[int]) -> float:
+        if self.dms is not None:
+            involved = list(channels) + [k for k, _ in self.subtract]
+            return Preprocessor(self.dms).value_scale(involved)
+        return self._raw_scale
+
+    _buffer = Preprocessor._buffer
+
+    def run(self, dvol, channel: int, origins, shapes, which: int = 0):
+        from . import blob_log as bl
+        L = nat.lib()
+        dev = dvol.tensor.device
+        if not dvol.multichannel:
+            raise IndexError("spectral unmixing needs a (z, y, x, c) image")
+        for k, _ in self.subtract:
+            if not 0 <= k < dvol.n_channels:
+                raise IndexError(f"index {k} is out of bounds for axis 3 with size {dvol.n_channels}")
+        if self.dms is None:
+            blocks_src, _ = bl._make_blocks(dvol, 0, origins, shapes)
+            main = dvol.view(channel, False)
+            subs = [dvol.view(k, False) for k, _ in self.subtract]
+        else:
+            views = {}
+            for c in [channel] + [k for k, _ in self.subtract]:
+                if c not in views:
+                    pre = self._pres.setdefault(c, Preprocessor(self.dms, self.near_max))
+                    blocks_src, _, _, views[c] = pre.run(dvol, c, origins, shapes, 0)
+            main = views[channel]
+            subs = [views[k] for k, _ in self.subtract]
+        nb = len(shapes)
+        shp = np.asarray(shapes, dtype=np.int64).reshape(nb, 3)
+        sx = int(-(-shp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
+        dst_sy, dst_sz = sx, sx * int(shp[:, 1].max())
+        slot_pre = dst_sz * int(shp[:, 0].max())
+        out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)
+        out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
+        d_src = torch.from_numpy(blocks_src.view(np.uint8).reshape(-1)).to(dev)
+        sub_arr = (nat.Volume * max(1, len(subs)))(*subs)
+        facs = np.array([f for _, f in self.subtract], dtype=np.float64)
+        nat.check(L.mmx_unmix_batch(
+            ctypes.byref(main), sub_arr, nat.as_double_ptr(facs) if len(facs) else None, len(subs),
+            d_src.data_ptr(), blocks_src.ctypes.data, nb, slot_pre, dst_sy, dst_sz,
+            out32.data_ptr(), out64.data_ptr(), torch.cuda.current_stream().cuda_stream), "mmx_unmix_batch")
+        self._keep = d_src
+        blocks = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
+        slot = 1
+        for i in range(nb):
+            px = -(-int(shp[i, 2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN
+            blocks[i] = (i * slot_pre, shp[i, 0], shp[i, 1], shp[i, 2], i, px, 0)
+            slot = max(slot, int(shp[i, 0]) * int(shp[i, 1]) * px)
+        self._raw_scale = (float(np.iinfo(dvol.np_dtype).max) if dvol.np_dtype.kind in "ui"
+                           else dvol.value_scale())
+        self.last_geometry = (slot_pre, dst_sz, dst_sy, out64, out32)
+        return (blocks, slot, nat.Volume(out32.data_ptr(), nat.MMX_F32, 0, dst_sz, dst_sy, 1),
+                nat.Volume(out64.data_ptr(), nat.MMX_F64, 0, dst_sz, dst_sy, 1))
+
+    fetch = Preprocessor.fetch
+
+
 def preprocess_roi(roi, denoise_max_shape, channel: Optional[Sequence[int]] = None,
                    near_max: Optional[Sequence[float]] = None, return_info: bool = False):
     """Saturate + denoise a ``(z, y, x[, c])`` block tile by tile -> float64 array of the same

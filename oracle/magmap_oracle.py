@@ -71,8 +71,9 @@ def detect_blobs(roi: np.ndarray, channel: Optional[Sequence[int]], profiles: Se
     """Per-ROI detection -> ``(m, 11)`` float64 table or ``None``.
 
     magmap/cv/detector.py:874-957 without the optional isotropic rescale
-    (:893-897, :944-951) and spectral unmixing (:910-921) steps (both off in the
-    benchmark profiles).  ``profiles[i]`` is what
+    (:893-897, :944-951).  Spectral unmixing (:910-921) is
+    taken from the profile dict's ``"spectral_unmixing"`` entry (an attribute of the
+    reference's ``ROIProfile``): ``{channel: {channel_to_subtract: factor}}``.  ``profiles[i]`` is what
     ``config.get_roi_profile(i)`` returns (magmap/settings/config.py:887-901: the
     last/only profile serves every channel beyond the list).
     """
@@ -89,6 +90,15 @@ def detect_blobs(roi: np.ndarray, channel: Optional[Sequence[int]], profiles: Se
         prof = profiles[chl] if len(profiles) > chl else profiles[0]
         if prof.get("isotropic") is not None:
             raise NotImplementedError("isotropic rescale is outside the oracle's scope")
+        unmix = prof.get("spectral_unmixing")
+        if unmix is not None:
+            for spec_chl, spec_subtr in unmix.items():
+                if spec_chl != chl:
+                    continue
+                for subt_chl, subt_fac in spec_subtr.items():
+                    roi_subt = roi[..., subt_chl]
+                    roi_detect = np.subtract(roi_detect, subt_fac * roi_subt)
+                    roi_detect[roi_detect < 0] = 0
         res = blo.blob_log(
             roi_detect,
             min_sigma=prof["min_sigma_factor"] * scale_x,

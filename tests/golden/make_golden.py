@@ -161,10 +161,15 @@ def bloblog_case(name, vol, min_sigma, max_sigma, num_sigma, threshold=0.1, over
 
 
 def detect_case(name, roi, channel, exclude_border=None, resolutions=((1., 1., 1.),),
-                names=None, **over):
+                names=None, unmix=None, **over):
     config.resolutions = np.array(resolutions)
     setup_profile(names, **over)
+    if unmix is not None:            # ROIProfile attribute: {channel: {channel_to_subtract: factor}}
+        for prof in config.roi_profiles:
+            prof.spectral_unmixing = unmix
     table = quiet(detector.detect_blobs, roi, channel, exclude_border)
+    for prof in config.roi_profiles:
+        prof.spectral_unmixing = None
     profs = [{k: config.get_roi_profile(i)[k] for k in (
         "min_sigma_factor", "max_sigma_factor", "num_sigma", "detection_threshold", "overlap")}
         for i in range(2)]
@@ -172,7 +177,7 @@ def detect_case(name, roi, channel, exclude_border=None, resolutions=((1., 1., 1
         os.path.join(HERE, "detect_%s.npz" % name), roi=roi,
         channel=np.array(-1 if channel is None else channel),
         exclude_border=np.array(-1 if exclude_border is None else exclude_border),
-        resolutions=np.array(resolutions), profiles=repr(profs),
+        resolutions=np.array(resolutions), profiles=repr(profs), unmix=repr(unmix),
         table=np.empty((0, 11)) if table is None else table, is_none=table is None,
         versions=repr(VERSIONS))
     print("detect_%s: %s" % (name, None if table is None else table.shape))
@@ -506,6 +511,8 @@ def main():
         return main_coloc()
     if sys.argv[1:] == ["image5d"]:       # only the on-disk image fixtures (added later)
         return main_image5d()
+    if sys.argv[1:] == ["unmix"]:         # only the spectral-unmixing fixtures (added later)
+        return main_unmix()
     # ---- blob_log arithmetic
     bloblog_case("u16_1sigma", make_volume(11, (40, 56, 60), 22), 3, 3, 1)
     bloblog_case("u16_5sigma", make_volume(12, (48, 64, 72), 30), 3, 5, 5)
@@ -559,6 +566,16 @@ def main():
     main_preproc()
     main_coloc()
     main_image5d()
+    main_unmix()
+
+
+def main_unmix():
+    """detect_blobs with the profile's spectral_unmixing set: the detected channel becomes an UNSCALED
+    float64 image (so thresholds are in raw intensity units)."""
+    vol = make_coloc_volume(71, (32, 44, 48), 16, n_chl=3, shared=0.6)
+    detect_case("unmix_1sub", vol, [1], unmix={1: {0: 0.4}}, num_sigma=3, detection_threshold=900.0)
+    detect_case("unmix_2sub", vol, None, unmix={1: {0: 0.5, 2: 0.25}, 2: {0: 1.5}}, num_sigma=3,
+                detection_threshold=900.0)
 
 
 def main_image5d():

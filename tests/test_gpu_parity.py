@@ -229,6 +229,9 @@ def test_detect_blobs_matches_reference(gpu, case):
     from magellanmapper_amd import config, detector
     g = load_golden("detect_%s.npz" % case)
     _apply_profiles(_profiles_from(g))
+    unmix = ast.literal_eval(str(g["unmix"])) if "unmix" in g else None
+    for p in config.roi_profiles:          # U1: the ROIProfile attribute the reference reads (:911)
+        p.spectral_unmixing = unmix
     config.resolutions = g["resolutions"]
     channel = None if g["channel"].ndim == 0 else list(g["channel"])
     excl = None if g["exclude_border"].ndim == 0 else g["exclude_border"]

@@ -170,3 +170,28 @@ def test_detect_sub_roi_with_denoise(gpu, env):
                               denoise_max_shape=np.array([25, 25, 25]))
     assert coord == (0, 1, 0) and want is not None
     np.testing.assert_array_equal(got, want)
+
+
+def test_unmixing_on_preprocessed_blocks_matches_oracle(gpu, env, tmp_path, monkeypatch):
+    """Spectral unmixing (detector.py:910-921) after the per-block preprocessing, whole stack, 3 channels:
+    the detected channel is (preprocessed c1) - 0.5 * (preprocessed c0), clipped at 0."""
+    from magellanmapper_amd import config, stack_detect
+    from oracle import magmap_oracle as mmo
+    monkeypatch.chdir(tmp_path)
+    roi = load_golden("stack_coloc_3ch.npz")["roi"]
+    unmix = {1: {0: 0.5}, 2: {1: 0.25, 0: 0.25}}
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(num_sigma=3, segment_size=30, denoise_size=25)
+    config.roi_profile.spectral_unmixing = unmix
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.near_max = [-1.0, -1.0, -1.0]
+    config.filename = "unmix"
+    try:
+        _, _, blobs = stack_detect.detect_blobs_blocks("unmix", stack_detect.Image5d(roi[None]), None, None,
+                                                       None, False, False, True, False)
+        prof = dict(config.roi_profile, spectral_unmixing=unmix)
+        want, _ = mmo.detect_blobs_blocks(roi, None, [prof], config.resolutions, near_max=config.near_max)
+        assert want is not None and len(np.unique(want[:, 6])) == 3
+        np.testing.assert_array_equal(blobs.blobs, want)
+    finally:
+        config.roi_profile.spectral_unmixing = None

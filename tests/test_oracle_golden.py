@@ -79,7 +79,8 @@ def _profiles_from(g):
 @pytest.mark.parametrize("case", DETECT_CASES)
 def test_detect_blobs_matches_reference(case):
     g = load_golden("detect_%s.npz" % case)
-    profs = [dict(p, isotropic=None) for p in _profiles_from(g)]
+    unmix = ast.literal_eval(str(g["unmix"])) if "unmix" in g else None
+    profs = [dict(p, isotropic=None, spectral_unmixing=unmix) for p in _profiles_from(g)]
     channel = None if g["channel"].ndim == 0 else list(g["channel"])
     excl = None if g["exclude_border"].ndim == 0 else g["exclude_border"]
     table = mmo.detect_blobs(g["roi"], channel, profs, g["resolutions"], excl)
