@@ -222,7 +222,15 @@ class StackDetector:
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
         seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
-        for i, tbl in dist.gather_tables(local, len(coords)):
+        gathered = dist.gather_tables(local, len(coords))
+        if arena is None and dist.rank() == 0:
+            # several ranks: the pruning rank lays the gathered tables out back to back (grid order)
+            # so that merge_blobs and the native prune step take their fast path as on one GPU
+            arena = _TableArena(11 + n_extra)
+            for i, tbl in gathered:
+                if tbl is not None and len(tbl):
+                    arena.add(coords[i], tbl)
+        for i, tbl in gathered:
             if arena is not None and tbl is not None and len(tbl):
                 tbl = arena.view(coords[i])         # the copy that lives in the arena
             seg_rois[coords[i]] = tbl
