@@ -70,8 +70,8 @@ def detect_blobs(roi: np.ndarray, channel: Optional[Sequence[int]], profiles: Se
                  resolutions, exclude_border=None) -> Optional[np.ndarray]:
     """Per-ROI detection -> ``(m, 11)`` float64 table or ``None``.
 
-    magmap/cv/detector.py:874-957 without the optional isotropic rescale
-    (:893-897, :944-951).  Spectral unmixing (:910-921) is
+    magmap/cv/detector.py:874-957.  The isotropic rescale (:893-897, :944-951; first channel's
+    profile) goes through ``isotropic_oracle``.  Spectral unmixing (:910-921) is
     taken from the profile dict's ``"spectral_unmixing"`` entry (an attribute of the
     reference's ``ROIProfile``): ``{channel: {channel_to_subtract: factor}}``.  ``profiles[i]`` is what
     ``config.get_roi_profile(i)`` returns (magmap/settings/config.py:887-901: the
@@ -84,12 +84,15 @@ def detect_blobs(roi: np.ndarray, channel: Optional[Sequence[int]], profiles: Se
     else:
         channels = [0]
     scale_x = scaling_factor(resolutions)[2]          # detector.py:907-908
+    first = profiles[channels[0]] if len(profiles) > channels[0] else profiles[0]
+    isotropic = first.get("isotropic")
+    if isotropic is not None:
+        from . import isotropic_oracle
+        roi = isotropic_oracle.make_isotropic(roi, isotropic, np.asarray(resolutions)[0])
     tables = []
     for chl in channels:
         roi_detect = roi[..., chl] if multichannel else roi
         prof = profiles[chl] if len(profiles) > chl else profiles[0]
-        if prof.get("isotropic") is not None:
-            raise NotImplementedError("isotropic rescale is outside the oracle's scope")
         unmix = prof.get("spectral_unmixing")
         if unmix is not None:
             for spec_chl, spec_subtr in unmix.items():
@@ -112,6 +115,11 @@ def detect_blobs(roi: np.ndarray, channel: Optional[Sequence[int]], profiles: Se
     if not tables:
         return None
     out = np.vstack(tables)
+    if isotropic is not None:                         # back to the original grid (:944-951)
+        from . import isotropic_oracle
+        factor = isotropic_oracle.calc_isotropic_factor(isotropic, np.asarray(resolutions)[0])
+        out[:, 0:3] = np.multiply(out[:, 0:3], 1 / factor).astype(int)
+        out[:, 7:10] = np.multiply(out[:, 7:10], 1 / factor).astype(int)
     if exclude_border is not None:
         out = blobs_interior(out, shape, *exclude_border)   # detector.py:953-955
     return out

@@ -171,7 +171,7 @@ def detect_case(name, roi, channel, exclude_border=None, resolutions=((1., 1., 1
     for prof in config.roi_profiles:
         prof.spectral_unmixing = None
     profs = [{k: config.get_roi_profile(i)[k] for k in (
-        "min_sigma_factor", "max_sigma_factor", "num_sigma", "detection_threshold", "overlap")}
+        "min_sigma_factor", "max_sigma_factor", "num_sigma", "detection_threshold", "overlap", "isotropic")}
         for i in range(2)]
     np.savez_compressed(
         os.path.join(HERE, "detect_%s.npz" % name), roi=roi,
@@ -513,6 +513,8 @@ def main():
         return main_image5d()
     if sys.argv[1:] == ["unmix"]:         # only the spectral-unmixing fixtures (added later)
         return main_unmix()
+    if sys.argv[1:] == ["isotropic"]:     # only the isotropic-rescale fixtures (added later)
+        return main_isotropic()
     # ---- blob_log arithmetic
     bloblog_case("u16_1sigma", make_volume(11, (40, 56, 60), 22), 3, 3, 1)
     bloblog_case("u16_5sigma", make_volume(12, (48, 64, 72), 30), 3, 5, 5)
@@ -567,6 +569,45 @@ def main():
     main_coloc()
     main_image5d()
     main_unmix()
+    main_isotropic()
+
+
+def main_isotropic():
+    """cv_nd.make_isotropic itself and detect_blobs / detect_blobs_blocks with the profile's isotropic
+    set.  scikit-image 0.18.3 resizes a 3-D array whose LAST axis keeps its length with its 2-D warp
+    (x as channels), unlike the release the reference pins; every case here is multichannel or changes
+    all three axes, so that 0.18.3 and >= 0.19 run the same SciPy interpolation."""
+    from magmap.cv import cv_nd
+    out, names = {}, []
+
+    def iso_case(name, roi, scale, res):
+        got = quiet(cv_nd.make_isotropic, roi, scale, np.array(res))
+        out[name + "_roi"], out[name + "_scale"], out[name + "_res"] = roi, np.array(scale, float), np.array(res, float)
+        out[name + "_out"] = got
+        names.append(name)
+        print("isotropic %-8s %s %s -> %s %s" % (name, roi.shape, roi.dtype, got.shape, got.dtype))
+
+    v1 = make_volume(81, (14, 30, 33), 6)
+    iso_case("allaxes", v1, (0.96, 1.07, 1), (2.5, 1.0, 1.2))
+    iso_case("down", v1, (1, 1, 1), (1.0, 1.15, 1.21))                 # z kept, y/x up
+    v2 = np.stack((make_volume(82, (12, 26, 28), 5), make_volume(83, (12, 26, 28), 4)), axis=-1)
+    iso_case("2ch_z", v2, (0.96, 1, 1), (3.0, 1.0, 1.0))                # the stock lightsheet shape: z only
+    iso_case("2ch_f64", v2.astype(np.float64) / 40000.0 - 0.1, (1, 1, 1), (2.2, 1.0, 1.0))
+    iso_case("2ch_slight", v2, (0.96, 1, 1), (1.0, 1.0, 1.0))           # 4 % down-sampling: anti-aliasing is a no-op
+    out["names"] = np.array(names)
+    out["versions"] = repr(VERSIONS)
+    np.savez_compressed(os.path.join(HERE, "isotropic.npz"), **out)
+
+    vol2 = np.stack((make_volume(84, (16, 44, 48), 9), make_volume(85, (16, 44, 48), 7)), axis=-1)
+    detect_case("iso_2ch", vol2, None, resolutions=((3.0, 1.0, 1.0),), num_sigma=3, isotropic=(0.96, 1, 1))
+    detect_case("iso_allaxes", make_volume(86, (16, 40, 44), 8), None, resolutions=((2.2, 1.0, 1.1),),
+                num_sigma=3, isotropic=(1, 1.06, 1), exclude_border=np.array([[1, 3, 3], [1, 2, 2]]))
+    stack_case("iso_2ch", np.stack((make_volume(87, (20, 64, 66), 14), make_volume(88, (20, 64, 66), 11)), axis=-1),
+               None, resolutions=((3.0, 1.0, 1.0),), segment_size=28, num_sigma=3, isotropic=(0.96, 1, 1))
+    stack_case("iso_denoise", np.stack((make_volume(89, (18, 56, 60), 12), make_volume(90, (18, 56, 60), 9)),
+                                       axis=-1),
+               None, resolutions=((2.5, 1.0, 1.0),), segment_size=30, num_sigma=3, isotropic=(1, 1, 1),
+               denoise_size=20, near_max=(-1.0, -1.0))
 
 
 def main_unmix():

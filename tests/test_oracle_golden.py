@@ -18,6 +18,7 @@ from oracle import blob_log_oracle as blo
 from oracle import magmap_oracle as mmo
 from oracle import preprocess_oracle as ppo
 from oracle import coloc_oracle
+from oracle import isotropic_oracle
 
 BLOBLOG_CASES = sorted(os.path.basename(p)[len("bloblog_"):-4]
                        for p in glob.glob(os.path.join(GOLDEN, "bloblog_*.npz")))
@@ -80,7 +81,7 @@ def _profiles_from(g):
 def test_detect_blobs_matches_reference(case):
     g = load_golden("detect_%s.npz" % case)
     unmix = ast.literal_eval(str(g["unmix"])) if "unmix" in g else None
-    profs = [dict(p, isotropic=None, spectral_unmixing=unmix) for p in _profiles_from(g)]
+    profs = [dict({"isotropic": None}, **p, spectral_unmixing=unmix) for p in _profiles_from(g)]
     channel = None if g["channel"].ndim == 0 else list(g["channel"])
     excl = None if g["exclude_border"].ndim == 0 else g["exclude_border"]
     table = mmo.detect_blobs(g["roi"], channel, profs, g["resolutions"], excl)
@@ -223,6 +224,19 @@ def test_preprocess_block_tiles_like_the_reference_loop():
     for sl in [(slice(0, 25), slice(25, 45), slice(50, 52)), (slice(25, 40), slice(0, 25), slice(25, 50))]:
         want = ppo.denoise_roi(ppo.saturate_roi(roi[sl], profs, [-1.0]), profs)
         np.testing.assert_array_equal(got[sl], want)
+
+
+ISO = load_golden("isotropic.npz")
+
+
+@pytest.mark.parametrize("case", [str(n) for n in ISO["names"]])
+def test_make_isotropic_matches_reference(case):
+    """cv_nd.make_isotropic restated (scipy zoom, the pinned scikit-image's code path) == the real
+    reference under scikit-image 0.18.3, for the shapes where both releases interpolate alike."""
+    got = isotropic_oracle.make_isotropic(ISO[case + "_roi"], ISO[case + "_scale"], ISO[case + "_res"])
+    want = ISO[case + "_out"]
+    assert got.dtype == want.dtype and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
 
 
 COLOC = load_golden("coloc.npz")
