@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 4
+#define MMX_ABI_VERSION 5
 
 typedef enum {
     MMX_OK = 0,
@@ -271,6 +271,33 @@ int mmx_unmix_batch(const mmx_volume* vol, const mmx_volume* h_subs, const doubl
                     const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
                     int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
                     float* d_out32, double* d_out64, void* stream);
+
+/* ---- R1: isotropic rescale ahead of detection
+ * replaces: cv_nd.make_isotropic (magmap/cv/cv_nd.py:1070-1164) as detect_blobs calls it
+ * (magmap/cv/detector.py:893-897) = skimage.transform.resize(mode="reflect", preserve_range=True) =
+ * scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True), clipped to the input range, cast back to the
+ * input dtype -- per block and channel, bit-equal to SciPy's float64 arithmetic.
+ * mmx_minmax_batch folds min / max of one channel's blocks into d_minmax[n_blocks][2] (the caller presets
+ * +inf / -inf and calls it for every channel of the ROI: scikit-image clips to the range of the whole
+ * multichannel block).  mmx_resize_batch resamples one channel.
+ *   d_index/d_weight : per axis and output index the two border-mapped source indices and the two linear
+ *                      weights, as NI_ZoomShift precomputes them (tz/ty/tx: the block's table offsets)
+ *   d_out            : uint8 / uint16 / float64 like the input, [n_blocks][dst_slot], strides (dst_sz,
+ *                      dst_sy, 1); d_out32: float32 copy (float64 inputs only)                       */
+typedef struct {
+    int64_t src_off;                  /* element offset of the block origin in the source               */
+    int32_t in_nz, in_ny, in_nx;      /* source extent                                                   */
+    int32_t out_nz, out_ny, out_nx;   /* resized extent                                                  */
+    int32_t slot;                     /* output slot and row of d_minmax                                 */
+    int32_t tz, ty, tx;               /* offsets (in output indices) of the axis tables                  */
+} mmx_resize_block;                   /* 48 bytes */
+int mmx_minmax_batch(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
+                     int n_blocks, double* d_minmax, void* stream);
+int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d_blocks,
+                     const mmx_resize_block* h_blocks, int n_blocks,
+                     const int32_t* d_index, const double* d_weight, const double* d_minmax,
+                     int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                     void* d_out, float* d_out32, void* stream);
 
 /* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream.
  * mmx_timing_enable(1) makes every kernel launch of this library record a HIP event

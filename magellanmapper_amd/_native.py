@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 4
+MMX_ABI_VERSION = 5
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -41,6 +41,11 @@ SUBINFO_DTYPE = np.dtype([("vmin", "<f8"), ("vmax", "<f8"), ("mean", "<f8"), ("f
                           ("_pad", "<i4")], align=True)
 assert SUBBLOCK_DTYPE.itemsize == 40 and QCLASS_DTYPE.itemsize == 32 and SUBINFO_DTYPE.itemsize == 32
 MMX_PP_IDENTITY, MMX_PP_ERODED, MMX_PP_EXACT_MEAN = 1, 2, 4
+#: NumPy mirror of ``mmx_resize_block`` (48 bytes)
+RESIZE_DTYPE = np.dtype([("src_off", "<i8"), ("in_nz", "<i4"), ("in_ny", "<i4"), ("in_nx", "<i4"),
+                         ("out_nz", "<i4"), ("out_ny", "<i4"), ("out_nx", "<i4"), ("slot", "<i4"),
+                         ("tz", "<i4"), ("ty", "<i4"), ("tx", "<i4")], align=True)
+assert RESIZE_DTYPE.itemsize == 48
 
 
 class Volume(Structure):
@@ -70,7 +75,7 @@ SYMBOLS = (
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
-    "mmx_coloc_means", "mmx_host_take_rows", "mmx_unmix_batch",
+    "mmx_coloc_means", "mmx_host_take_rows", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass", "preproc", "coloc")
@@ -120,6 +125,11 @@ def lib() -> ctypes.CDLL:
                 c_int64, c_int64, vp, vp, vp]
     L.mmx_preprocess_batch.argtypes = pre_args + [vp]
     L.mmx_preprocess_batch_generic.argtypes = pre_args + [vp, c_int64, vp]
+    L.mmx_minmax_batch.argtypes = [POINTER(Volume), vp, vp, c_int, vp, vp]
+    L.mmx_minmax_batch.restype = c_int
+    L.mmx_resize_batch.argtypes = [POINTER(Volume), vp, vp, c_int, vp, vp, vp, c_int64, c_int64, c_int64,
+                                   vp, vp, vp]
+    L.mmx_resize_batch.restype = c_int
     L.mmx_unmix_batch.argtypes = [POINTER(Volume), POINTER(Volume), POINTER(c_double), c_int, vp, vp, c_int,
                                   c_int64, c_int64, c_int64, vp, vp, vp]
     L.mmx_unmix_batch.restype = c_int

@@ -189,9 +189,12 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     }
     const bool fast_r = radius >= 1 && radius <= MMX_MAX_RADIUS_FAST;
     const bool lane_ok = max_lane_in * 8 < (int64_t(1) << 31);
-    const bool fast_z = fast_r && lane_ok && min_nz >= radius + kColPrefetch && vol->stride_y < (1 << 30);
-    const bool fast_y = fast_r && min_ny >= radius + kColPrefetch;
-    const bool fast_x = fast_r && min_nx >= radius;
+    // MMX_DEBUG_GENERIC=zyx (any subset) sends those passes through the generic kernels (bisecting only)
+    static const char* dbg = getenv("MMX_DEBUG_GENERIC");
+    const bool gz = dbg && strchr(dbg, 'z'), gy = dbg && strchr(dbg, 'y'), gx = dbg && strchr(dbg, 'x');
+    const bool fast_z = !gz && fast_r && lane_ok && min_nz >= radius + kColPrefetch && vol->stride_y < (1 << 30);
+    const bool fast_y = !gy && fast_r && min_ny >= radius + kColPrefetch;
+    const bool fast_x = !gx && fast_r && min_nx >= radius;
     auto taps = [&](const float* a, const float* b) {
         mmx_taps_f32 t;
         for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) {

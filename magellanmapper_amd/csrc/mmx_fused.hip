@@ -63,7 +63,7 @@ template <> struct vox<float> {
 template <int R> struct xgeom {
     static constexpr int LEAD = R & 1;                 // odd radius: window starts one float early
     static constexpr int S = (R + LEAD + 7) & ~7;      // staged position of x = 0
-    static constexpr int WIN = kT + 2 * R + LEAD;      // floats read per thread and array (even)
+    static constexpr int WIN = kT + 2 * R + 2 * LEAD;  // floats read per thread and array (even: read in pairs)
     // LDS row pitch, a compile-time constant (sized for the widest supported row, px = 512) so that
     // every row offset folds into the ds_* immediate field instead of living in a VGPR
     static constexpr int SPAN = S + 512 + R + LEAD;

@@ -324,6 +324,160 @@ extern "C" int mmx_unmix_batch(const mmx_volume* vol, const mmx_volume* h_subs, 
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
+// ---- isotropic rescale ahead of detection (magmap/cv/cv_nd.py:1070-1164 -> skimage.transform.resize ->
+// scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True)).  SciPy precomputes, per axis and output
+// index, the two source indices (border-mapped) and the two linear weights (w0 = 1 - frac, w1 = 1 - w0);
+// the caller does the same on the host (bit-equal double arithmetic, preprocess.zoom_axis_table).  The
+// kernel reproduces NI_ZoomShift's accumulation exactly: t = 0; for dz, dy, dx (dx fastest):
+// t += ((v * wz) * wy) * wx; then scikit-image's clip to the input range and the cast back to the input
+// dtype (truncation for integers).  No FMA (this file is built with -ffp-contract=off).
+namespace {
+__device__ __forceinline__ void atomic_min_f64(double* addr, double v)
+{
+    unsigned long long* a = (unsigned long long*)addr;
+    unsigned long long old = *a;
+    while (v < __longlong_as_double((long long)old)) {
+        const unsigned long long prev = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+        if (prev == old) break;
+        old = prev;
+    }
+}
+__device__ __forceinline__ void atomic_max_f64(double* addr, double v)
+{
+    unsigned long long* a = (unsigned long long*)addr;
+    unsigned long long old = *a;
+    while (v > __longlong_as_double((long long)old)) {
+        const unsigned long long prev = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+        if (prev == old) break;
+        old = prev;
+    }
+}
+
+template <typename InT>
+__global__ void __launch_bounds__(MMX_WG)
+minmax_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
+              const mmx_block* __restrict__ blocks, double* __restrict__ mm)
+{
+    __shared__ double s_lo[MMX_WG / 64], s_hi[MMX_WG / 64];
+    const mmx_block bd = blocks[blockIdx.y];
+    const int64_t n = (int64_t)bd.nz * bd.ny * bd.nx;
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * MMX_WG) {
+        const int64_t t = i / bd.nx, x = i - t * bd.nx, z = t / bd.ny, y = t - z * bd.ny;
+        const double v = (double)vol[bd.src_off + z * sz + y * sy + x * sx];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+    for (int d = 32; d >= 1; d >>= 1) { lo = fmin(lo, __shfl_down(lo, d)); hi = fmax(hi, __shfl_down(hi, d)); }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < MMX_WG / 64; ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); }
+        atomic_min_f64(mm + 2 * (int64_t)bd.slot, lo);
+        atomic_max_f64(mm + 2 * (int64_t)bd.slot + 1, hi);
+    }
+}
+
+template <typename InT, typename OutT>
+__global__ void __launch_bounds__(MMX_WG)
+resize_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
+              const mmx_resize_block* __restrict__ blocks, const int32_t* __restrict__ idx,
+              const double* __restrict__ wts, const double* __restrict__ mm,
+              int64_t dst_slot, int64_t dst_sy, int64_t dst_sz, OutT* __restrict__ out, float* __restrict__ out32)
+{
+    const mmx_resize_block bd = blocks[blockIdx.y];
+    const int64_t n = (int64_t)bd.out_nz * bd.out_ny * bd.out_nx;
+    const double lo = mm[2 * (int64_t)bd.slot], hi = mm[2 * (int64_t)bd.slot + 1];
+    const InT* src = vol + bd.src_off;
+    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * MMX_WG) {
+        const int64_t t = i / bd.out_nx, x = i - t * bd.out_nx, z = t / bd.out_ny, y = t - z * bd.out_ny;
+        const int32_t* iz = idx + 2 * ((int64_t)bd.tz + z);
+        const int32_t* iy = idx + 2 * ((int64_t)bd.ty + y);
+        const int32_t* ix = idx + 2 * ((int64_t)bd.tx + x);
+        const double* wz = wts + 2 * ((int64_t)bd.tz + z);
+        const double* wy = wts + 2 * ((int64_t)bd.ty + y);
+        const double* wx = wts + 2 * ((int64_t)bd.tx + x);
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    double v = (double)src[iz[a] * sz + iy[b] * sy + ix[c] * sx];
+                    v = v * wz[a];
+                    v = v * wy[b];
+                    v = v * wx[c];
+                    acc += v;
+                }
+        acc = fmin(fmax(acc, lo), hi);                    // np.clip(out, image.min(), image.max())
+        const int64_t d = (int64_t)bd.slot * dst_slot + z * dst_sz + y * dst_sy + x;
+        out[d] = (OutT)acc;                               // .astype(dtype): truncation for integers
+        if (out32) out32[d] = (float)acc;
+    }
+}
+}  // namespace
+
+extern "C" int mmx_minmax_batch(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
+                                int n_blocks, double* d_minmax, void* stream)
+{
+    if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || !d_minmax) return MMX_ERR_ARG;
+    int64_t max_vox = 1;
+    for (int i = 0; i < n_blocks; ++i)
+        max_vox = std::max<int64_t>(max_vox, (int64_t)h_blocks[i].nz * h_blocks[i].ny * h_blocks[i].nx);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)std::min<int64_t>((max_vox + MMX_WG * 16 - 1) / (MMX_WG * 16), 4096), (unsigned)n_blocks);
+    mmx_timed_scope ts(MMX_K_GENERIC, s);
+#define MMX_MM_LAUNCH(T)                                                                                  \
+    hipLaunchKernelGGL(minmax_kernel<T>, grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z,   \
+                       vol->stride_y, vol->stride_x, d_blocks, d_minmax)
+    switch (vol->dtype) {
+        case MMX_U8: MMX_MM_LAUNCH(uint8_t); break;
+        case MMX_U16: MMX_MM_LAUNCH(uint16_t); break;
+        case MMX_F32: MMX_MM_LAUNCH(float); break;
+        case MMX_F64: MMX_MM_LAUNCH(double); break;
+        default: return MMX_ERR_UNSUPPORTED;
+    }
+#undef MMX_MM_LAUNCH
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+extern "C" int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d_blocks,
+                                const mmx_resize_block* h_blocks, int n_blocks,
+                                const int32_t* d_index, const double* d_weight, const double* d_minmax,
+                                int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                                void* d_out, float* d_out32, void* stream)
+{
+    if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || !d_index || !d_weight ||
+        !d_minmax || !d_out)
+        return MMX_ERR_ARG;
+    int64_t max_vox = 1;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_resize_block& b = h_blocks[i];
+        if (b.in_nz < 2 || b.in_ny < 2 || b.in_nx < 2 || b.out_nz < 1 || b.out_ny < 1 || b.out_nx < 1)
+            return MMX_ERR_UNSUPPORTED;        // unit-thick blocks use scikit-image's 'edge' mode: not built
+        max_vox = std::max<int64_t>(max_vox, (int64_t)b.out_nz * b.out_ny * b.out_nx);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)std::min<int64_t>((max_vox + MMX_WG * 4 - 1) / (MMX_WG * 4), 65535), (unsigned)n_blocks);
+    mmx_timed_scope ts(MMX_K_GENERIC, s);
+#define MMX_RS_LAUNCH(T, O, O32)                                                                            \
+    hipLaunchKernelGGL((resize_kernel<T, O>), grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z, \
+                       vol->stride_y, vol->stride_x, d_blocks, d_index, d_weight, d_minmax, dst_slot,        \
+                       dst_sy, dst_sz, (O*)d_out, O32)
+    switch (vol->dtype) {
+        case MMX_U8: MMX_RS_LAUNCH(uint8_t, uint8_t, (float*)nullptr); break;
+        case MMX_U16: MMX_RS_LAUNCH(uint16_t, uint16_t, (float*)nullptr); break;
+        case MMX_F64:
+            if (!d_out32) return MMX_ERR_ARG;
+            MMX_RS_LAUNCH(double, double, d_out32);
+            break;
+        default: return MMX_ERR_UNSUPPORTED;   // float32 images: SciPy interpolates into a float32 array
+    }
+#undef MMX_RS_LAUNCH
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
 // ---- PMC calibration kernels (tools/pmc_calib.py): streams of a known byte count with the
 // access shapes the LoG kernels use, to turn rocprofv3 FETCH_SIZE / WRITE_SIZE into bytes.
 namespace {

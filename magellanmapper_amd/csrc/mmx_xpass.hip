@@ -37,7 +37,7 @@ xpass_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int rg_ma
 {
     constexpr int LEAD = R & 1;                   // odd radius: window starts one float early (8-B aligned)
     constexpr int S = (R + LEAD + 7) & ~7;        // staged position of x = 0
-    constexpr int WIN = kT + 2 * R + LEAD;        // floats read per thread and array (even)
+    constexpr int WIN = kT + 2 * R + 2 * LEAD;    // floats read per thread and array (even: read in pairs)
     extern __shared__ float lds[];
     const mmx_block bd = blocks[blockIdx.y];
     const int W = bd.nx, px = bd.px;

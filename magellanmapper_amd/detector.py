@@ -378,19 +378,26 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
     (stack_detect.py:159-162; :mod:`colocalizer`) -- both before ``on_block``.
     """
     from . import blob_log as bl
+    multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
+    channels = list(channels)
+    first = config.get_roi_profile(channels[0])
+    isotropic = first["isotropic"]
+    iso_factor = None
     pre = None
     if denoise_max_shape is not None:
         from . import preprocess
         pre = preprocess.Preprocessor(denoise_max_shape)
-    multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
-    first = config.get_roi_profile(list(channels)[0])
-    if first["isotropic"] is not None:
-        raise NotImplementedError(
-            "the 'isotropic' rescale (reference detector.py:893-897) is not built yet "
-            "(SURVEY.md section 8f row 4); use a profile with isotropic: None")
+    log_shapes = shapes
+    if isotropic is not None:
+        # interpolate every block to (near) isotropy for the detection, first channel's profile
+        # (:893-897); blob coordinates go back to the original grid afterwards (:944-951)
+        from . import preprocess
+        iso_factor = preprocess.calc_isotropic_factor(isotropic)
+        log_shapes = [preprocess.isotropic_shape(s, iso_factor) for s in shapes]
+        pre = preprocess.Rescaler(iso_factor, channels, denoise_max_shape)
+        pre.set_blocks(origins, shapes, log_shapes)
     per_block: List[List[np.ndarray]] = [[] for _ in shapes]
     done: List[Optional[np.ndarray]] = [None] * len(shapes)
-    channels = list(channels)
     for chl in channels:
         settings = config.get_roi_profile(chl)
         source = pre
@@ -399,6 +406,8 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
             # x -= fac * roi[..., k]; x[x < 0] = 0 for every entry of this channel (:910-921)
             subtract = [(k, f) for spec_chl, spec in spectral_unmixing.items() if spec_chl == chl
                         for k, f in spec.items()]
+            if subtract and isotropic is not None:
+                raise NotImplementedError("spectral unmixing of isotropically rescaled blocks is not built")
             if subtract:
                 from . import preprocess
                 source = preprocess.Unmixer(subtract, denoise_max_shape)
@@ -419,6 +428,9 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                 tbls = []
                 for i in indices:
                     tbl = np.vstack(per_block[i]) if per_block[i] else None
+                    if tbl is not None and iso_factor is not None:
+                        Blobs.multiply_blob_rel_coords(tbl, 1 / iso_factor)
+                        Blobs.multiply_blob_abs_coords(tbl, 1 / iso_factor)
                     ex = exclude(i) if exclude is not None else None
                     if tbl is not None and ex is not None:
                         tbl = get_blobs_interior(tbl, shapes[i], *ex)
@@ -430,7 +442,7 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                     done[i] = on_block(i, tbl) if on_block is not None else tbl
 
         bl.blob_log_blocks(
-            dvol, chl if multichannel else 0, origins, shapes,
+            dvol, chl if multichannel else 0, origins, log_shapes,
             min_sigma=settings["min_sigma_factor"] * scaling_factor,
             max_sigma=settings["max_sigma_factor"] * scaling_factor,
             num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],

@@ -377,6 +377,215 @@ class Unmixer:
     fetch = Preprocessor.fetch
 
 
+def calc_isotropic_factor(scale, res=None) -> np.ndarray:
+    """``cv_nd.calc_isotropic_factor`` (reference cv_nd.py:1040-1067)."""
+    if res is None:
+        res = config.resolutions[0]
+    resize_factor = np.divide(res, np.amin(res))
+    resize_factor = resize_factor * scale
+    return resize_factor
+
+
+_AXIS_TABLES: Dict[Tuple[int, int], Tuple[np.ndarray, np.ndarray]] = {}
+
+
+def zoom_axis_table(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray]:
+    """``(index (n_out, 2) int32, weight (n_out, 2) float64)`` of one axis of
+    ``scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True)``: SciPy's NI_ZoomShift computes, per
+    output index k, ``cc = (k + 0.5) * (n_in / n_out) - 0.5``, mirrors it into the array ("whole-sample
+    symmetric": -c -> c, beyond the end 2(n-1) - c), takes ``floor(cc)`` and the next sample (border
+    indices mirrored again) with weights ``w0 = 1 - frac``, ``w1 = 1 - w0``.  Same double arithmetic here."""
+    key = (int(n_in), int(n_out))
+    hit = _AXIS_TABLES.get(key)
+    if hit is not None:
+        return hit
+    n_in, n_out = key
+    if n_in < 2:
+        raise NotImplementedError("unit-thick blocks are resized in scikit-image's 'edge' mode: not built")
+    zoom = np.divide(np.float64(n_in), np.float64(n_out))
+    sz2 = 2 * n_in - 2
+    idx = np.zeros((n_out, 2), dtype=np.int32)
+    wts = np.zeros((n_out, 2), dtype=np.float64)
+    for k in range(n_out):
+        cc = np.float64(k)
+        cc = cc + 0.5
+        cc = cc * zoom
+        cc = cc - 0.5
+        if cc < 0:
+            cc = sz2 * int(-cc / sz2) + cc
+            cc = cc + sz2 if cc <= 1 - n_in else -cc
+        elif cc > n_in - 1:
+            cc = cc - sz2 * int(cc / sz2)
+            if cc >= n_in:
+                cc = sz2 - cc
+        start = int(np.floor(cc))
+        for ll in range(2):
+            j = start + ll
+            if j < 0:
+                j = sz2 * int(-j / sz2) + j
+                j = j + sz2 if j <= 1 - n_in else -j
+            elif j >= n_in:
+                j -= sz2 * int(j / sz2)
+                if j >= n_in:
+                    j = sz2 - j
+            idx[k, ll] = j
+        frac = cc - np.floor(cc)
+        wts[k, 0] = 1.0 - frac
+        wts[k, 1] = 1.0 - wts[k, 0]
+    _AXIS_TABLES[key] = (idx, wts)
+    return idx, wts
+
+
+def isotropic_shape(shape3, factor) -> Tuple[int, int, int]:
+    """``(shape * factor).astype(int)`` (cv_nd.py:1091-1092)."""
+    out = (np.array(shape3, dtype=int) * np.asarray(factor)).astype(int)
+    if (out < 1).any():
+        raise ValueError(f"isotropic rescale of a {tuple(shape3)} block gives an empty array")
+    return tuple(int(v) for v in out)
+
+
+class Rescaler:
+    """The profile's ``isotropic`` rescale of the blocks of a batch (reference detector.py:893-897 ->
+    cv_nd.make_isotropic -> skimage.transform.resize), after the optional per-block preprocessing, as
+    a ``run`` source for ``blob_log_blocks``.  ``run`` is called with the RESIZED shapes (those are the
+    images the detection sees); :meth:`set_blocks` tells it the original extents.  scikit-image clips the
+    result to the value range of the whole multichannel block, so every channel of the ROI is scanned."""
+
+    def __init__(self, factor, channels: Sequence[int], denoise_max_shape=None, near_max=None):
+        self.factor = np.asarray(factor, dtype=np.float64)
+        self.channels = [int(c) for c in channels]
+        self.dms = None if denoise_max_shape is None else [int(v) for v in denoise_max_shape]
+        self.near_max = near_max
+        self._pres: Dict[int, Preprocessor] = {}
+        self._orig: Dict[Tuple[Tuple[int, ...], Tuple[int, ...]], Tuple[int, int, int]] = {}
+        self._out = [None, None]
+        self._out32 = None
+        self._scale = 1.0
+
+    def set_blocks(self, origins, shapes, new_shapes) -> None:
+        for o, s, n in zip(origins, shapes, new_shapes):
+            s, n = tuple(int(v) for v in s), tuple(int(v) for v in n)
+            for a in range(3):
+                if n[a] < s[a]:
+                    sigma = (s[a] / n[a] - 1) / 2
+                    if int(4.0 * sigma + 0.5) > 0:
+                        raise NotImplementedError(
+                            "down-sampling by more than 25 % switches scikit-image's anti-aliasing filter on: "
+                            "not built (isotropic factors < 0.8)")
+            self._orig[(tuple(int(v) for v in o), n)] = s
+
+    def bytes_per_voxel(self) -> int:
+        # resized copies (2 x float64 + float32, or 2 x uint16) + the preprocessed sources of all channels
+        return 20 + (0 if self.dms is None else 20 * len(self.channels))
+
+    def value_scale(self, channels: Sequence[int]) -> float:
+        if self.dms is not None:
+            return Preprocessor(self.dms).value_scale(self.channels)
+        return self._scale
+
+    _buffer = Preprocessor._buffer
+
+    def run(self, dvol, channel: int, origins, shapes, which: int = 0):
+        from . import blob_log as bl
+        L = nat.lib()
+        dev = dvol.tensor.device
+        stream = torch.cuda.current_stream().cuda_stream
+        nb = len(shapes)
+        new_shp = np.asarray(shapes, dtype=np.int64).reshape(nb, 3)
+        orig = [self._orig[(tuple(int(v) for v in o), tuple(int(v) for v in n))]
+                for o, n in zip(origins, new_shp)]
+        # ---- sources: the block as detect_blobs receives it, every channel (for the clip range)
+        if self.dms is None:
+            if dvol.np_dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float64)):
+                raise NotImplementedError(f"isotropic rescale of {dvol.np_dtype} images is not built")
+            blocks_src, _ = bl._make_blocks(dvol, 0, origins, orig)
+            views = {c: dvol.view(c, False) for c in range(dvol.n_channels)}
+            zero_channels = False
+            self._scale = dvol.value_scale()
+        else:
+            views = {}
+            for c in self.channels:
+                pre = self._pres.setdefault(c, Preprocessor(self.dms, self.near_max))
+                blocks_src, _, _, views[c] = pre.run(dvol, c, origins, orig, 0)
+            zero_channels = len(self.channels) < dvol.n_channels      # unselected channels stay 0
+        d_src = torch.from_numpy(blocks_src.view(np.uint8).reshape(-1)).to(dev)
+        mm = np.empty((nb, 2))
+        mm[:, 0], mm[:, 1] = (0.0, 0.0) if zero_channels else (np.inf, -np.inf)
+        d_mm = torch.from_numpy(mm).to(dev)
+        for c in sorted(views):
+            nat.check(L.mmx_minmax_batch(ctypes.byref(views[c]), d_src.data_ptr(), blocks_src.ctypes.data, nb,
+                                         d_mm.data_ptr(), stream), "mmx_minmax_batch")
+        # ---- axis tables + block descriptors
+        tabs_i, tabs_w, at, offs = [], [], 0, {}
+        rb = np.zeros(nb, dtype=nat.RESIZE_DTYPE)
+        for i in range(nb):
+            t3 = []
+            for a in range(3):
+                key = (int(orig[i][a]), int(new_shp[i, a]))
+                if key not in offs:
+                    ix, w = zoom_axis_table(*key)
+                    offs[key] = at
+                    tabs_i.append(ix)
+                    tabs_w.append(w)
+                    at += len(ix)
+                t3.append(offs[key])
+            rb[i] = (blocks_src["src_off"][i], orig[i][0], orig[i][1], orig[i][2],
+                     new_shp[i, 0], new_shp[i, 1], new_shp[i, 2], i, t3[0], t3[1], t3[2])
+        d_idx = torch.from_numpy(np.concatenate(tabs_i).reshape(-1)).to(dev)
+        d_wts = torch.from_numpy(np.concatenate(tabs_w).reshape(-1)).to(dev)
+        d_rb = torch.from_numpy(rb.view(np.uint8).reshape(-1)).to(dev)
+        # ---- output slots (uniform strides, 128-byte rows)
+        sx = int(-(-new_shp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
+        dst_sy, dst_sz = sx, sx * int(new_shp[:, 1].max())
+        slot_pre = dst_sz * int(new_shp[:, 0].max())
+        src = views[channel]
+        if src.dtype == nat.MMX_F64:
+            out = self._buffer("_out", which, nb * slot_pre, torch.float64, dev)
+            out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)
+            vol32 = nat.Volume(out32.data_ptr(), nat.MMX_F32, 0, dst_sz, dst_sy, 1)
+            vol_exact = nat.Volume(out.data_ptr(), nat.MMX_F64, 0, dst_sz, dst_sy, 1)
+            o32 = out32.data_ptr()
+        else:
+            tdt = torch.uint8 if src.dtype == nat.MMX_U8 else torch.uint16
+            out = self._buffer("_out", which, nb * slot_pre, tdt, dev)
+            if out.dtype != tdt:
+                self._out[which] = out = torch.empty(nb * slot_pre, dtype=tdt, device=dev)
+            vol32 = vol_exact = nat.Volume(out.data_ptr(), src.dtype, 0, dst_sz, dst_sy, 1)
+            o32 = None
+        nat.check(L.mmx_resize_batch(ctypes.byref(src), d_rb.data_ptr(), rb.ctypes.data, nb, d_idx.data_ptr(),
+                                     d_wts.data_ptr(), d_mm.data_ptr(), slot_pre, dst_sy, dst_sz,
+                                     out.data_ptr(), o32, stream), "mmx_resize_batch")
+        self._keep = (d_src, d_mm, d_idx, d_wts, d_rb)
+        blocks = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
+        slot = 1
+        for i in range(nb):
+            px = -(-int(new_shp[i, 2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN
+            blocks[i] = (i * slot_pre, new_shp[i, 0], new_shp[i, 1], new_shp[i, 2], i, px, 0)
+            slot = max(slot, int(new_shp[i, 0]) * int(new_shp[i, 1]) * px)
+        self.last_geometry = (slot_pre, dst_sz, dst_sy, out, None)
+        self.store_f32 = 0
+        return blocks, slot, vol32, vol_exact
+
+    fetch = Preprocessor.fetch
+
+
+def make_isotropic(roi, scale, res=None, denoise_max_shape=None) -> np.ndarray:
+    """``cv_nd.make_isotropic`` of a whole ``(z, y, x[, c])`` ROI through the device path (every channel)."""
+    from . import blob_log as bl
+    dvol = roi if isinstance(roi, bl.DeviceVolume) else bl.DeviceVolume(roi)
+    factor = calc_isotropic_factor(scale, res)
+    shape3 = tuple(dvol.shape[:3])
+    new = isotropic_shape(shape3, factor)
+    chans = list(range(dvol.n_channels))
+    rs = Rescaler(factor, chans, denoise_max_shape)
+    rs.set_blocks([(0, 0, 0)], [shape3], [new])
+    outs = []
+    for c in chans:
+        rs.run(dvol, c, [(0, 0, 0)], [new], 0)
+        outs.append(rs.fetch([new])[0])
+    return np.stack(outs, axis=-1) if dvol.multichannel else outs[0]
+
+
 def preprocess_roi(roi, denoise_max_shape, channel: Optional[Sequence[int]] = None,
                    near_max: Optional[Sequence[float]] = None, return_info: bool = False):
     """Saturate + denoise a ``(z, y, x[, c])`` block tile by tile -> float64 array of the same

@@ -218,9 +218,9 @@ def _apply_profiles(profs):
     from magellanmapper_amd import config
     config.setup_roi_profiles(["default"] * len(profs))
     for p, over in zip(config.roi_profiles, profs):
+        p["isotropic"] = None
         p.update(over)
         p["denoise_size"] = None
-        p["isotropic"] = None
 
 
 @pytest.mark.parametrize("case", DETECT_CASES)
@@ -475,3 +475,26 @@ def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
     finally:
         config.resolutions, config.near_max = None, [-1.0]
         detector.Blobs(np.ones((1, 4))).format_blobs()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_every_kernel_radius_matches_oracle(gpu, fused):
+    """Each compiled radius (1..24 register-resident, 25 generic) of the separable passes against the
+    float64 oracle cube.  Regression: the X pass read its register window in pairs but sized it odd for
+    odd radii (undefined behaviour that showed as NaNs for R = 3..11)."""
+    from magellanmapper_amd import _native as nat, blob_log as bl, synth
+    from oracle import blob_log_oracle as blo
+    vol = synth.make_volume(3, (35, 42, 48), 12)
+    dvol = bl.DeviceVolume(vol)
+    img = blo.img_as_float(vol)
+    nat.lib().mmx_set_fused(1 if fused else 0)
+    try:
+        for R in range(1, 26):
+            sigma = (R + 0.2) / 4.0
+            space = bl.ScaleSpace.make(sigma, sigma, 1)
+            assert space.radii[0] == R
+            got = np.squeeze(bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [vol.shape], space)[0])
+            want = blo.log_cube(img, np.array([[sigma] * 3]))[..., 0]
+            assert np.abs(got - want).max() < LOG_TOL * 1e-2, R
+    finally:
+        nat.lib().mmx_set_fused(0)

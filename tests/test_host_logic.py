@@ -450,3 +450,36 @@ def test_filename_helpers():
     assert importer.make_filenames("/d/brain.nii.gz")[0] == "/d/brain_image5d.npy"
     assert importer.make_filenames("/d/brain.v2.tif", keep_ext=True)[0] == "/d/brain.v2.tif_image5d.npy"
     assert importer.combine_paths("/d/", "x.npy") == "/d/x.npy" and importer.combine_paths(None, "x") == "x"
+
+
+# ---------------------------------------------------------------- isotropic rescale: host tables
+def test_zoom_axis_tables_reproduce_scipy_zoom():
+    """index / weight tables (host) + NI_ZoomShift's accumulation order == scipy.ndimage.zoom(order=1,
+    mode='mirror', grid_mode=True), bit for bit, on random shapes (up- and down-sampling)."""
+    from scipy import ndimage as ndi
+    from magellanmapper_amd import preprocess
+    rng = np.random.default_rng(4)
+    for trial in range(40):
+        shp = tuple(int(v) for v in rng.integers(2, 11, 3))
+        out = tuple(max(1, int(s * f)) for s, f in zip(shp, rng.uniform(0.6, 3.3, 3)))
+        img = rng.random(shp) * 3 - 1 if trial % 2 else rng.integers(0, 60000, shp).astype(np.float64)
+        want = ndi.zoom(img, [o / i for o, i in zip(out, shp)], order=1, mode="mirror", grid_mode=True)
+        if want.shape != out:
+            continue
+        (iz, wz), (iy, wy), (ix, wx) = (preprocess.zoom_axis_table(i, o) for i, o in zip(shp, out))
+        acc = np.zeros(out)
+        for a in range(2):
+            for b in range(2):
+                for c in range(2):
+                    v = img[iz[:, a]][:, iy[:, b]][:, :, ix[:, c]]
+                    acc = acc + ((v * wz[:, a, None, None]) * wy[None, :, b, None]) * wx[None, None, :, c]
+        np.testing.assert_array_equal(acc, want)
+    with pytest.raises(NotImplementedError):
+        preprocess.zoom_axis_table(1, 3)
+    config.resolutions = [[3.0, 1.0, 1.0]]
+    np.testing.assert_array_equal(preprocess.calc_isotropic_factor((0.96, 1, 1)), [2.88, 1.0, 1.0])
+    assert preprocess.isotropic_shape((12, 26, 28), preprocess.calc_isotropic_factor((0.96, 1, 1))) == (34, 26, 28)
+    rs = preprocess.Rescaler([0.7, 1, 1], [0])
+    with pytest.raises(NotImplementedError):          # anti-aliasing would be active
+        rs.set_blocks([(0, 0, 0)], [(20, 8, 8)], [(14, 8, 8)])
+    config.resolutions = None
