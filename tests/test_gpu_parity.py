@@ -498,3 +498,58 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
             assert np.abs(got - want).max() < LOG_TOL * 1e-2, R
     finally:
         nat.lib().mmx_set_fused(0)
+
+
+def test_block_shape_and_dtype_sweep_matches_oracle(gpu):
+    """Ragged extents (row lengths around the 8-float chunk, the 32-float pitch and the 64-lane wave),
+    blocks thinner than the kernel radius (generic fallback per pass), every input dtype; several
+    differently shaped blocks in ONE batch."""
+    from magellanmapper_amd import blob_log as bl, synth
+    from oracle import blob_log_oracle as blo
+    rng = np.random.default_rng(21)
+    shapes = [(9, 23, 17), (30, 31, 33), (12, 40, 63), (25, 26, 65), (40, 9, 100), (7, 50, 31),
+              (33, 33, 129), (5, 6, 7), (20, 70, 257)]
+    full = (max(s[0] for s in shapes), max(s[1] for s in shapes), max(s[2] for s in shapes))
+    for dtype in (np.uint16, np.uint8, np.float32, np.float64):
+        vol = synth.make_volume(int(rng.integers(1 << 30)), full, 30)
+        if dtype == np.uint8:
+            vol = (vol >> 8).astype(np.uint8)
+        elif dtype != np.uint16:
+            vol = (vol / 65535.0).astype(dtype)
+        dvol = bl.DeviceVolume(vol)
+        origins = [tuple(int(rng.integers(0, f - s + 1)) for f, s in zip(full, shp)) for shp in shapes]
+        for sigmas in ((2.3, 2.3), (3.0, 4.75)):
+            space = bl.ScaleSpace.make(sigmas[0], sigmas[1], 2)
+            cubes = bl.log_cube_blocks(dvol, 0, origins, shapes, space)
+            for o, shp, got in zip(origins, shapes, cubes):
+                sub = vol[o[0]:o[0] + shp[0], o[1]:o[1] + shp[1], o[2]:o[2] + shp[2]]
+                want = blo.log_cube(blo.img_as_float(sub), np.stack([space.sigmas] * 3, axis=1))
+                err = np.abs(got - want).max()
+                assert got.shape == want.shape and err < 5e-6, (dtype, shp, sigmas, err)
+
+
+def test_blob_log_randomised_parameters_match_oracle(gpu):
+    """blob_log end to end on seeded random volumes over the parameter space the profiles span (sigma
+    ranges giving odd and even radii, one to many scales, thresholds, overlap limits, blob sizes and
+    crowding): the same rows in the same order as the oracle."""
+    from magellanmapper_amd import blob_log as bl, synth
+    from oracle import blob_log_oracle as blo
+    rng = np.random.default_rng(2024)
+    total = 0
+    for trial in range(14):
+        shape = tuple(int(v) for v in rng.integers(18, 56, 3))
+        n_blobs = int(rng.integers(3, 40))
+        bs = float(rng.uniform(1.0, 4.0))
+        vol = synth.make_volume(int(rng.integers(1 << 30)), shape, n_blobs, blob_sigma=bs,
+                                amp=float(rng.uniform(8000, 50000)))
+        lo = float(rng.uniform(0.8, 3.2))
+        hi = lo + float(rng.uniform(0.0, 3.0))
+        ns = int(rng.integers(1, 8))
+        thr = float(rng.choice([0.02, 0.05, 0.1, 0.2]))
+        ov = float(rng.choice([0.0, 0.3, 0.5, 0.9]))
+        got = bl.blob_log(vol, lo, hi, ns, thr, ov)
+        want = blo.blob_log(vol, lo, hi, ns, thr, ov)
+        assert got.shape == want.shape, (trial, shape, lo, hi, ns, thr, ov)
+        np.testing.assert_array_equal(got, want, err_msg=str((trial, shape, lo, hi, ns, thr, ov)))
+        total += len(want)
+    assert total > 100
