@@ -192,20 +192,21 @@ __device__ double pp_pairwise(F val, int n, pp_stack* S)
 // base/stride address the LDS tile; L <= PP_MAXL.
 // The weights come through a `const __restrict__` kernel argument (scalar loads next to their use),
 // not by value: 66 SGPRs held from kernel entry made the compiler spill scalars in every other stage.
-__device__ __forceinline__ void pp_line_pass(double* __restrict__ tile, int base, int stride, int L,
+template <int MAXL = PP_MAXL>
+__device__ __forceinline__ void pp_line_pass(double* __restrict__ tile, int64_t base, int64_t stride, int L,
                                              const double (&w)[PP_R + 1])
 {
-    double r[PP_MAXL];
+    double r[MAXL];
 #pragma unroll
-    for (int i = 0; i < PP_MAXL; ++i) r[i] = tile[base + (i < L ? i : L - 1) * stride];
+    for (int i = 0; i < MAXL; ++i) r[i] = tile[base + (i < L ? i : L - 1) * stride];
 #pragma unroll
-    for (int i = 0; i < PP_MAXL; ++i) {
+    for (int i = 0; i < MAXL; ++i) {
         if (i < L) {
             double acc = r[i] * w[0];
 #pragma unroll
             for (int k = PP_R; k >= 1; --k) {
                 const int a = i - k < 0 ? 0 : i - k;
-                const int b = i + k > PP_MAXL - 1 ? PP_MAXL - 1 : i + k;
+                const int b = i + k > MAXL - 1 ? MAXL - 1 : i + k;
                 acc += (r[a] + r[b]) * w[k];
             }
             tile[base + i * stride] = acc;
@@ -496,6 +497,257 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     }
 }
 
+// ---- tiles with every side <= 64 that do not fit LDS (finer-than-0.8-um voxels make the stock
+// denoise_size 25 um a 33..64-voxel tile): the float64 working copy lives in a global scratch (L2),
+// one 256-lane workgroup per tile.  Same register-resident line pass as the LDS kernel (64-register
+// lines): z and y lines are read straight from the scratch (lanes along x: coalesced), x lines go
+// through an LDS transpose in chunks of PP_MID_ROWS rows.
+#define PP_MIDL 64
+#define PP_WG_MID 256
+#define PP_MID_ROWS 128
+
+template <typename InT>
+__global__ void __launch_bounds__(PP_WG_MID)
+pp_mid_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
+              const mmx_subblock* __restrict__ subs, const mmx_quantile_class* __restrict__ qcs,
+              const double* __restrict__ wts,
+              pp_args A, float* __restrict__ out32, double* __restrict__ out64,
+              mmx_subblock_info* __restrict__ info, double* __restrict__ scratch)
+{
+    extern __shared__ double xrows[];              // [PP_MID_ROWS][nx | 1] for the x pass
+    __shared__ uint32_t hist[PP_HIST];
+    __shared__ int s_bin[4];
+    __shared__ uint32_t s_res[4];
+    __shared__ int s_val[4];
+    __shared__ double s_red[PP_WG_MID / 64];
+    __shared__ double s_mean;
+    __shared__ int s_flags;
+    __shared__ pp_stack s_stack;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const mmx_subblock sb = subs[blockIdx.x];
+    const int nz = sb.nz, ny = sb.ny, nx = sb.nx;
+    const int n = nz * ny * nx;
+    const int nrows = nz * ny;
+    const InT* src = vol + sb.src_off;
+    double* buf = scratch + sb.scratch_off;
+    auto raw = [&](int i) {                 // (rare paths only: two integer divisions)
+        const int t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
+        return (int)src[z * sz + y * sy + x * sx];
+    };
+    // element-wise stages: a lane keeps its x and walks rows (z*ny + y) in steps of rpi, no per-voxel
+    // index arithmetic; rows < 4096, so the float reciprocal gives row / ny exactly
+    const float inv_nx = 1.0f / (float)nx, inv_ny = 1.0f / (float)ny;
+    const int rpi = PP_WG_MID / nx;
+    const int r_first = (int)(((float)tid + 0.5f) * inv_nx);
+    const int x = tid - r_first * nx;
+    const bool lane_on = r_first < rpi;
+    auto raw_at = [&](int row) {
+        const int z = (int)(((float)row + 0.5f) * inv_ny);
+        const int y = row - z * ny;
+        return (int)src[z * sz + y * sy + x * sx];
+    };
+
+    for (int i = tid; i < PP_HIST; i += PP_WG_MID) hist[i] = 0;
+    __syncthreads();
+    // (8 rows per lane in flight: with 8 waves per CU nothing else hides the load latency)
+    for (int rb = 0; rb < nrows; rb += 8 * rpi) {          // same trip count in every lane (ballots)
+        int v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = rb + j * rpi + r_first;
+            v[j] = (lane_on && row < nrows) ? raw_at(row) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = rb + j * rpi + r_first;
+            pp_hist_add(hist, v[j] >> 8, lane_on && row < nrows);
+        }
+    }
+    __syncthreads();
+    const mmx_quantile_class qc = qcs[sb.qclass];
+    {
+        const uint32_t rank = wave == 0 ? qc.lo_prev : wave == 1 ? qc.lo_next : wave == 2 ? qc.hi_prev : qc.hi_next;
+        int b; uint32_t r;
+        pp_select(hist, rank, b, r);
+        if (lane == 0) { s_bin[wave] = b; s_res[wave] = r; }
+    }
+    __syncthreads();
+    {
+        const int b0 = s_bin[0], b1 = s_bin[1], b2 = s_bin[2], b3 = s_bin[3];
+        const bool u1 = b1 != b0, u2 = b2 != b0 && b2 != b1, u3 = b3 != b0 && b3 != b1 && b3 != b2;
+        for (int rb = lane_on ? r_first : nrows; rb < nrows; rb += 8 * rpi) {
+            int vv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vv[j] = rb + j * rpi < nrows ? raw_at(rb + j * rpi) : -1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (vv[j] < 0) continue;
+                const int hi = vv[j] >> 8, lo = vv[j] & 255;
+                if (hi == b0) atomicAdd(&hist[256 + lo], 1u);
+                if (u1 && hi == b1) atomicAdd(&hist[512 + lo], 1u);
+                if (u2 && hi == b2) atomicAdd(&hist[768 + lo], 1u);
+                if (u3 && hi == b3) atomicAdd(&hist[1024 + lo], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        int slot = wave;
+        for (int w = wave - 1; w >= 0; --w) if (s_bin[w] == s_bin[wave]) slot = w;
+        int b; uint32_t r;
+        pp_select(hist + 256 * (1 + slot), s_res[wave], b, r);
+        if (lane == 0) s_val[wave] = (s_bin[wave] << 8) | b;
+    }
+    __syncthreads();
+
+    pp_sat S;
+    double info_vmin, info_vmax;
+    {
+        const double vmin = pp_lerp(s_val[0], s_val[1], qc.lo_gamma);
+        double vmax = pp_lerp(s_val[2], s_val[3], qc.hi_gamma);
+        S.identity = vmin == vmax;
+        if (vmax < A.max_thresh) vmax = A.max_thresh;
+        S.vmin = vmin; S.vmax = vmax; S.span = vmax - vmin;
+        info_vmin = vmin; info_vmax = vmax;
+        S.finish();
+    }
+
+    double part = 0.;
+    for (int rb = lane_on ? r_first : nrows; rb < nrows; rb += 8 * rpi) {
+        int vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = rb + j * rpi < nrows ? raw_at(rb + j * rpi) : -1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (vv[j] < 0) continue;
+            const double rv = (double)vv[j];
+            const double s = S.fast ? S(rv) : S.plain(rv);
+            part += s;
+            buf[(rb + j * rpi) * nx + x] = pp_clip(s, A.clip_min, A.clip_max);
+        }
+    }
+    part = pp_wave_sum(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.;
+        for (int w = 0; w < PP_WG_MID / 64; ++w) tot += s_red[w];
+        double mean = tot / (double)n;
+        int flags = S.identity ? MMX_PP_IDENTITY : 0;
+        if (A.do_erosion) {
+            const double tol = 1e-9 * (fabs(A.ero_thr) > 1. ? fabs(A.ero_thr) : 1.);
+            if (!S.identity && fabs(mean - A.ero_thr) <= tol) {
+                auto val = [&](int i) { return S.plain((double)raw(i)); };
+                mean = pp_pairwise(val, n, &s_stack) / (double)n;
+                flags |= MMX_PP_EXACT_MEAN;
+            }
+            if (mean > A.ero_thr) flags |= MMX_PP_ERODED;
+        }
+        s_mean = mean;
+        s_flags = flags;
+    }
+    __syncthreads();          // also orders the scratch writes above before the passes below
+    const int flags = s_flags;
+    if (info && tid == 0) {
+        mmx_subblock_info o;
+        o.vmin = info_vmin; o.vmax = info_vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
+        info[blockIdx.x] = o;
+    }
+
+    if (A.do_unsharp) {
+        double wl[PP_R + 1];
+#pragma unroll
+        for (int k = 0; k <= PP_R; ++k) wl[k] = wts[k];
+        // z lines, then y lines: lane <-> (row of the other axis, x), x fastest
+#pragma unroll 1
+        for (int axis = 0; axis < 2; ++axis) {
+            const int L = axis == 0 ? nz : ny;
+            const int nlines = n / L;
+            for (int l = tid; l < nlines; l += PP_WG_MID) {
+                int64_t base, stride;
+                if (axis == 0) { base = l; stride = (int64_t)ny * nx; }
+                else { const int z = l / nx, x = l - z * nx; base = (int64_t)z * ny * nx + x; stride = nx; }
+                pp_line_pass<PP_MIDL>(buf, base, stride, L, wl);
+            }
+            __syncthreads();
+        }
+        // x lines through LDS: PP_MID_ROWS rows at a time, odd row pitch
+        if (!(A.rgb_guess && nx == 3)) {
+            const int pxl = nx | 1;
+            for (int row0 = 0; row0 < nrows; row0 += PP_MID_ROWS) {
+                const int nr = min(PP_MID_ROWS, nrows - row0);
+                for (int i = tid; i < nr * nx; i += PP_WG_MID) {
+                    const int r = i / nx, x = i - r * nx;
+                    xrows[r * pxl + x] = buf[(int64_t)row0 * nx + i];
+                }
+                __syncthreads();
+                if (tid < nr) pp_line_pass<PP_MIDL>(xrows, (int64_t)tid * pxl, 1, nx, wl);
+                __syncthreads();
+                for (int i = tid; i < nr * nx; i += PP_WG_MID) {
+                    const int r = i / nx, x = i - r * nx;
+                    buf[(int64_t)row0 * nx + i] = xrows[r * pxl + x];
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    const bool erode = flags & MMX_PP_ERODED;
+    for (int rb = lane_on ? r_first : nrows; rb < nrows; rb += 8 * rpi) {
+      int vv[8];
+      double bl8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+          const int row = rb + j * rpi;
+          vv[j] = row < nrows ? (A.do_unsharp ? raw_at(row) : 0) : -1;
+          bl8[j] = row < nrows ? buf[row * nx + x] : 0.;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (vv[j] < 0) continue;
+        const int row = rb + j * rpi;
+        const int z = (int)(((float)row + 0.5f) * inv_ny);
+        const int y = row - z * ny;
+        const int i = row * nx + x;
+        double o;
+        if (A.do_unsharp) {
+            const double rv = (double)vv[j];
+            const double sv = S.fast ? S(rv) : S.plain(rv);
+            const double den = pp_clip(sv, A.clip_min, A.clip_max);
+            const double m = A.strength * bl8[j];
+            const double hp = den - m;
+            o = den + hp;
+        } else {
+            o = bl8[j];
+        }
+        if (erode) buf[i] = o;
+        else {
+            const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
+            out64[d] = o;
+            out32[d] = (float)o;
+        }
+      }
+    }
+    if (!erode) return;
+    __syncthreads();
+    for (int row = lane_on ? r_first : nrows; row < nrows; row += rpi) {
+        const int z = (int)(((float)row + 0.5f) * inv_ny);
+        const int y = row - z * ny;
+        const int i = row * nx + x;
+        double o = buf[i];
+        if (x > 0) o = fmin(o, buf[i - 1]);
+        if (x < nx - 1) o = fmin(o, buf[i + 1]);
+        if (y > 0) o = fmin(o, buf[i - nx]);
+        if (y < ny - 1) o = fmin(o, buf[i + nx]);
+        if (z > 0) o = fmin(o, buf[i - ny * nx]);
+        if (z < nz - 1) o = fmin(o, buf[i + ny * nx]);
+        const int64_t d = sb.dst_off + z * A.dst_sz + y * A.dst_sy + x;
+        out64[d] = o;
+        out32[d] = (float)o;
+    }
+}
+
 // ---- any extent: data in a global scratch (2 * n doubles per sub-block), one output per lane and pass
 template <typename InT>
 __global__ void __launch_bounds__(PP_WG_GENERIC)
@@ -764,6 +1016,33 @@ int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_su
     const pp_args A = pp_make_args(params, dst_sy, dst_sz);
     hipStream_t s = (hipStream_t)stream;
     mmx_timed_scope ts(MMX_K_PREPROC, s);
+    // every side <= 64: register-resident lines over the scratch (pp_mid_kernel); else one output per lane
+    bool mid = true;
+    int max_nx = 1;
+    for (int i = 0; i < n_subs; ++i) {
+        const mmx_subblock& b = h_subs[i];
+        if (b.nz > PP_MIDL || b.ny > PP_MIDL || b.nx > PP_MIDL || (int64_t)b.nz * b.ny * b.nx >= (1ll << 30)) mid = false;
+        max_nx = b.nx > max_nx ? b.nx : max_nx;
+    }
+    if (mid) {
+        const size_t lds = (size_t)PP_MID_ROWS * (max_nx | 1) * sizeof(double);
+        if (vol->dtype == MMX_U16) {
+            auto k = pp_mid_kernel<uint16_t>;
+            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return MMX_ERR_HIP;
+            hipLaunchKernelGGL(k, dim3(n_subs), dim3(PP_WG_MID), lds, s, (const uint16_t*)vol->d_data,
+                               vol->stride_z, vol->stride_y, vol->stride_x, d_subs, d_qclasses, d_weights, A,
+                               d_out32, d_out64, d_info, d_scratch);
+        } else {
+            auto k = pp_mid_kernel<uint8_t>;
+            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return MMX_ERR_HIP;
+            hipLaunchKernelGGL(k, dim3(n_subs), dim3(PP_WG_MID), lds, s, (const uint8_t*)vol->d_data,
+                               vol->stride_z, vol->stride_y, vol->stride_x, d_subs, d_qclasses, d_weights, A,
+                               d_out32, d_out64, d_info, d_scratch);
+        }
+        return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+    }
     if (vol->dtype == MMX_U16)
         hipLaunchKernelGGL(pp_generic_kernel<uint16_t>, dim3(n_subs), dim3(PP_WG_GENERIC), 0, s,
                            (const uint16_t*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_subs,

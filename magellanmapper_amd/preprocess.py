@@ -41,7 +41,8 @@ RGB_GUESS = False
 #: test hook: half kernel ``w[0..32]`` to use instead of this NumPy's (``np.exp`` is not bit-stable
 #: across NumPy releases and the golden fixtures were made under NumPy 1.26)
 GAUSS_WEIGHTS_OVERRIDE: Optional[np.ndarray] = None
-#: test hook: send every tile through the generic (global-scratch) kernel
+#: test hook: send every tile through the global-scratch kernels (sides <= 64: register-line kernel,
+#: larger: one output per lane) instead of the LDS kernel; "big" forces the one-output-per-lane kernel
 FORCE_GENERIC = False
 
 
@@ -142,7 +143,7 @@ class Preprocessor:
         return self._tiles[shape]
 
     def _template(self, shape, vstrides, dstrides, pct_lo, pct_hi):
-        """``(fast, generic)`` sub-block tables of one block shape with block-relative offsets."""
+        """``(fast, mid, big)`` sub-block tables of one block shape with block-relative offsets."""
         tkey = (shape, vstrides, dstrides)
         hit = self._tmpl.get(tkey)
         if hit is not None:
@@ -168,7 +169,10 @@ class Preprocessor:
             fast[j] = (not FORCE_GENERIC) and L.mmx_preprocess_fast_lds(int(u[0]), int(u[1]), int(u[2])) != 0
         t["qclass"] = cls[inv]
         is_fast = fast[inv]
-        hit = (t[is_fast], t[~is_fast])
+        # tiles that do not fit LDS: every side <= 64 -> register-line kernel over a global scratch,
+        # anything larger -> one output per lane (both behind mmx_preprocess_batch_generic)
+        is_mid = ~is_fast & (e.max(axis=1) <= 64) & (FORCE_GENERIC != "big")
+        hit = (t[is_fast], t[is_mid], t[~is_fast & ~is_mid])
         self._tmpl[tkey] = hit
         return hit
 
@@ -209,23 +213,24 @@ class Preprocessor:
         vsz, vsy, vsx = (int(v) for v in t.stride()[:3])
         # sub-block table: per distinct block shape a cached template (tile extents, offsets relative
         # to the block, quantile class, fast / generic split); a block only adds its two base offsets
-        key = (pct_lo, pct_hi, bool(FORCE_GENERIC))
+        key = (pct_lo, pct_hi, FORCE_GENERIC)
         if self._tmpl_key != key:
             self._tmpl_key, self._tmpl, self._qc_rows, self._qc_index = key, {}, [], {}
-        fast_parts, gen_parts = [], []
+        fast_parts, mid_parts, big_parts = [], [], []
         for i in range(nb):
-            tf, tg = self._template(tuple(int(v) for v in shp[i]), (vsz, vsy, vsx), (dst_sz, dst_sy),
-                                    pct_lo, pct_hi)
+            tmpls = self._template(tuple(int(v) for v in shp[i]), (vsz, vsy, vsx), (dst_sz, dst_sy),
+                                   pct_lo, pct_hi)
             base_src = int(org[i, 0]) * vsz + int(org[i, 1]) * vsy + int(org[i, 2]) * vsx
-            for tmpl, parts in ((tf, fast_parts), (tg, gen_parts)):
+            for tmpl, parts in zip(tmpls, (fast_parts, mid_parts, big_parts)):
                 if len(tmpl):
                     part = tmpl.copy()
                     part["src_off"] += base_src
                     part["dst_off"] += i * slot_pre
                     parts.append(part)
         n_fast = sum(len(p) for p in fast_parts)
-        n_gen = sum(len(p) for p in gen_parts)
-        subs = (np.concatenate(fast_parts + gen_parts) if n_fast + n_gen
+        n_mid = sum(len(p) for p in mid_parts)
+        n_gen = n_mid + sum(len(p) for p in big_parts)
+        subs = (np.concatenate(fast_parts + mid_parts + big_parts) if n_fast + n_gen
                 else np.zeros(0, dtype=nat.SUBBLOCK_DTYPE))
         qc = np.array(self._qc_rows, dtype=nat.QCLASS_DTYPE)
         if n_gen:
@@ -256,13 +261,14 @@ class Preprocessor:
                 ctypes.byref(vol), d_subs.data_ptr(), subs.ctypes.data, n_fast, d_qc.data_ptr(), len(qc),
                 ctypes.byref(params), d_w.data_ptr(), dst_sy, dst_sz,
                 out32.data_ptr(), out64.data_ptr(), info_ptr, stream), "mmx_preprocess_batch")
-        if n_gen:
-            nat.check(L.mmx_preprocess_batch_generic(
-                ctypes.byref(vol), d_subs.data_ptr() + n_fast * item, subs.ctypes.data + n_fast * item,
-                n_gen, d_qc.data_ptr(), len(qc), ctypes.byref(params), d_w.data_ptr(),
-                dst_sy, dst_sz, out32.data_ptr(), out64.data_ptr(),
-                (info_ptr + n_fast * nat.SUBINFO_DTYPE.itemsize) if info_ptr else None,
-                scratch.data_ptr(), int(scratch.numel()), stream), "mmx_preprocess_batch_generic")
+        for first, count in ((n_fast, n_mid), (n_fast + n_mid, n_gen - n_mid)):
+            if count:      # one call per kernel class: the entry point picks the kernel from the extents
+                nat.check(L.mmx_preprocess_batch_generic(
+                    ctypes.byref(vol), d_subs.data_ptr() + first * item, subs.ctypes.data + first * item,
+                    count, d_qc.data_ptr(), len(qc), ctypes.byref(params), d_w.data_ptr(),
+                    dst_sy, dst_sz, out32.data_ptr(), out64.data_ptr(),
+                    (info_ptr + first * nat.SUBINFO_DTYPE.itemsize) if info_ptr else None,
+                    scratch.data_ptr(), int(scratch.numel()), stream), "mmx_preprocess_batch_generic")
         self.last_subs = subs
         self._keep = (d_subs, d_qc, d_info)
         if d_info is not None:

@@ -559,19 +559,3 @@ class StackPruner:
             out = np.take(merged, rows, axis=0)[:, :-3]
             out[:, abs_inds] = np.take(abs_cur, rows, axis=0)
         return out, pd.DataFrame(ratios_all)
-
-    @staticmethod
-    def _dedup(merged, master, check, tol, abs_inds):
-        """:func:`detector.remove_close_blobs` on row ids: returns the surviving check ids and
-        updates the masters' abs coordinates inside ``merged``."""
-        if len(master) == 0 or len(check) == 0:
-            return check
-        m_rows, c_rows = merged[master], merged[check]
-        pruned, m_rows = detector.remove_close_blobs(c_rows, m_rows, tol)
-        merged[np.ix_(master, abs_inds)] = m_rows[:, abs_inds]
-        if len(pruned) == len(check):
-            return check
-        # remove_close_blobs keeps order: recover which rows survived
-        hit = np.ones(len(check), dtype=bool)
-        hit[detector.last_survivors] = False
-        return check[~hit]

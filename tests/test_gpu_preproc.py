@@ -75,7 +75,7 @@ def test_tile_matches_reference(gpu, env, case):
             assert abs(info["mean"][0] - np.mean(sat)) < 1e-12
 
 
-@pytest.mark.parametrize("dms", [(25, 25, 25), (13, 25, 30), (7, 40, 9), (64, 96, 96)])
+@pytest.mark.parametrize("dms", [(25, 25, 25), (13, 25, 30), (7, 40, 9), (50, 64, 33), (64, 96, 96)])
 def test_tiled_block_matches_oracle(gpu, env, dms):
     """A whole block, tiled like chunking.stack_splitter does: fast (LDS) and generic tiles mixed."""
     from magellanmapper_amd import preprocess
@@ -92,12 +92,13 @@ def test_generic_kernel_equals_fast_kernel(gpu, env, monkeypatch):
     roi = load_golden("stack_denoise.npz")["roi"][:40, :50, :52]
     _set_profiles({})
     fast = preprocess.preprocess_roi(roi, (25, 25, 25))
-    monkeypatch.setattr(preprocess, "FORCE_GENERIC", True)
-    slow = preprocess.preprocess_roi(roi, (25, 25, 25))
-    np.testing.assert_array_equal(fast, slow)
+    for mode in (True, "big"):           # register-line kernel over a global scratch / one output per lane
+        monkeypatch.setattr(preprocess, "FORCE_GENERIC", mode)
+        slow = preprocess.preprocess_roi(roi, (25, 25, 25))
+        np.testing.assert_array_equal(fast, slow)
 
 
-@pytest.mark.parametrize("force_generic", [False, True])
+@pytest.mark.parametrize("force_generic", [False, True, "big"])
 def test_knife_edge_mean_uses_numpys_summation_order(gpu, env, monkeypatch, force_generic):
     """erosion_threshold set exactly AT the tile mean (and one ulp below): the device must
     reproduce np.mean bit for bit to take the reference's branch."""
