@@ -34,6 +34,8 @@
 // Sub-blocks with a side above 32 or more voxels than LDS holds take pp_generic_kernel:
 // same arithmetic, data in a global scratch, one output per lane and pass.
 
+#include <algorithm>
+
 #include "mmx_common.h"
 
 #define PP_R 32          // int(4 * 8 + 0.5): sigma 8 is hard-coded in plot_3d.py:151
@@ -227,8 +229,8 @@ __device__ __forceinline__ pp_coord pp_decode(int i, int nx, int ny, float inv_n
     return c;
 }
 
-template <typename InT>
-__global__ void __launch_bounds__(PP_WG)
+template <typename InT, int WG>
+__global__ void __launch_bounds__(WG)
 pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
                const mmx_subblock* __restrict__ subs, int n_subs,
                const mmx_quantile_class* __restrict__ qcs, const double* __restrict__ wts,
@@ -239,7 +241,7 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     __shared__ int s_bin[4];
     __shared__ uint32_t s_res[4];
     __shared__ int s_val[4];
-    __shared__ double s_red[PP_WG / 64];
+    __shared__ double s_red[WG / 64];
     __shared__ double s_mean;
     __shared__ int s_flags;
     __shared__ pp_stack s_stack;
@@ -266,13 +268,13 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
 #endif
     PP_STAMP();
 
-    for (int i = tid; i < PP_HIST; i += PP_WG) hist[i] = 0;
+    for (int i = tid; i < PP_HIST; i += WG) hist[i] = 0;
     __syncthreads();
 
     // Lane <-> voxel mapping of the element-wise stages: a lane keeps its x and walks rows
-    // (z*ny + y) in steps of `rpi`, so no per-voxel index decoding; rpi * nx <= PP_WG lanes work.
+    // (z*ny + y) in steps of `rpi`, so no per-voxel index decoding; rpi * nx <= WG lanes work.
     const int nrows = nz * ny;
-    const int rpi = PP_WG / nx;
+    const int rpi = WG / nx;
     const int r_first = (int)(((float)tid + 0.5f) * inv_nx);
     const int x = tid - r_first * nx;
     const int r0 = r_first < rpi ? r_first : nrows;          // idle lanes start past the end
@@ -312,7 +314,7 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
         // one low-byte histogram per DISTINCT high-byte bin (prev / next ranks usually share theirs)
         const int b0 = s_bin[0], b1 = s_bin[1], b2 = s_bin[2], b3 = s_bin[3];
         const bool u1 = b1 != b0, u2 = b2 != b0 && b2 != b1, u3 = b3 != b0 && b3 != b1 && b3 != b2;
-        for (int i = tid; i < n; i += PP_WG) {
+        for (int i = tid; i < n; i += WG) {
             const int v = raw[i];
             const int hi = v >> 8, lo = v & 255;
             if (hi == b0) atomicAdd(&hist[256 + lo], 1u);
@@ -375,7 +377,7 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     __syncthreads();
     if (tid == 0) {
         double tot = 0.;
-        for (int w = 0; w < PP_WG / 64; ++w) tot += s_red[w];
+        for (int w = 0; w < WG / 64; ++w) tot += s_red[w];
         double mean = tot / (double)n;
         int flags = S.identity ? MMX_PP_IDENTITY : 0;
         if (A.do_erosion) {
@@ -412,7 +414,7 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
             const int L = axis == 0 ? nz : axis == 1 ? ny : nx;
             if (axis == 2 && A.rgb_guess && nx == 3) break;
             const int nlines = n / L;
-            for (int l = tid; l < nlines; l += PP_WG) {
+            for (int l = tid; l < nlines; l += WG) {
                 int base, stride;
                 if (axis == 2) { base = l * px; stride = 1; }
                 else {
@@ -979,20 +981,25 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
     const pp_args A = pp_make_args(params, dst_sy, dst_sz);
     hipStream_t s = (hipStream_t)stream;
     const int grid = ((n_subs + 7) / 8) * 8;       // 8 XCD-contiguous runs of tiles
+    // small tiles (anisotropic voxels: 25 um is 4 x 23 x 23 voxels at 6.6 x 1.1 x 1.1 um): 256-lane
+    // workgroups, so that LDS (not the 32-wave limit) decides how many tiles a CU works on at once
+    int64_t max_vox = 0;
+    for (int i = 0; i < n_subs; ++i)
+        max_vox = std::max<int64_t>(max_vox, (int64_t)h_subs[i].nz * h_subs[i].ny * h_subs[i].nx);
+    const bool small = max_vox <= 4096;
     mmx_timed_scope ts(MMX_K_PREPROC, s);
-    if (vol->dtype == MMX_U16) {
-        auto k = pp_fast_kernel<uint16_t>;
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MMX_ERR_HIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PP_WG), (size_t)lds, s, (const uint16_t*)vol->d_data,
-                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, n_subs, d_qclasses, d_weights, A, d_out32, d_out64, d_info);
-    } else {
-        auto k = pp_fast_kernel<uint8_t>;
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return MMX_ERR_HIP;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PP_WG), (size_t)lds, s, (const uint8_t*)vol->d_data,
-                           vol->stride_z, vol->stride_y, vol->stride_x, d_subs, n_subs, d_qclasses, d_weights, A, d_out32, d_out64, d_info);
-    }
+#define PP_FAST_LAUNCH(T, W)                                                                              \
+    do {                                                                                                  \
+        auto k = pp_fast_kernel<T, W>;                                                                    \
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return MMX_ERR_HIP;                                                                           \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(W), (size_t)lds, s, (const T*)vol->d_data, vol->stride_z,  \
+                           vol->stride_y, vol->stride_x, d_subs, n_subs, d_qclasses, d_weights, A,        \
+                           d_out32, d_out64, d_info);                                                     \
+    } while (0)
+    if (vol->dtype == MMX_U16) { if (small) PP_FAST_LAUNCH(uint16_t, 256); else PP_FAST_LAUNCH(uint16_t, PP_WG); }
+    else { if (small) PP_FAST_LAUNCH(uint8_t, 256); else PP_FAST_LAUNCH(uint8_t, PP_WG); }
+#undef PP_FAST_LAUNCH
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
