@@ -225,3 +225,25 @@ def test_isotropic_z_only_single_channel_matches_scipy_zoom(gpu):
     f = rng.random((9, 21, 19)) * 2.5 - 0.4
     np.testing.assert_array_equal(preprocess.make_isotropic(f, (1, 1, 1), np.array((3.3, 1.0, 1.0))),
                                   isotropic_oracle.make_isotropic(f, (1, 1, 1), np.array((3.3, 1.0, 1.0))))
+
+
+def test_stock_anisotropic_lightsheet_geometry_matches_oracle(gpu, env, tmp_path, monkeypatch):
+    """The geometry real light-sheet data gives the default profile: 6.6 x 1.1 x 1.1 um voxels (the
+    reference's own test resolution) -> 4 x 23 x 23-voxel denoise tiles (256-lane small-tile kernel),
+    sigma 2.7..4.5 (kernel radii 11..18, odd ones included), overlap (1, 5, 5); whole stack vs the oracle."""
+    from magellanmapper_amd import config, stack_detect, synth
+    from oracle import magmap_oracle as mmo
+    monkeypatch.chdir(tmp_path)
+    vol = synth.make_volume(77, (22, 150, 160), 60, blob_sigma=2.6)
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(num_sigma=5, segment_size=70)          # denoise_size 25 as shipped
+    config.resolutions = np.array([[6.6, 1.1, 1.1]])
+    config.near_max = [-1.0]
+    config.filename = "aniso"
+    blocks = stack_detect.setup_blocks(config.roi_profile, vol.shape)
+    assert list(blocks.denoise_max_shape) == [4, 23, 23] and list(blocks.overlap) == [1, 5, 5]
+    _, _, blobs = stack_detect.detect_blobs_blocks("aniso", stack_detect.Image5d(vol[None]), None, None,
+                                                   None, False, False, True, False)
+    want, st = mmo.detect_blobs_blocks(vol, None, [dict(config.roi_profile)], config.resolutions)
+    assert st["seg_rois"].size >= 8 and len(want) > 20
+    np.testing.assert_array_equal(blobs.blobs, want)
