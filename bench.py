@@ -43,7 +43,9 @@ PROFILE = dict(min_sigma_factor=3, max_sigma_factor=5, num_sigma=5, detection_th
 RESOLUTIONS = np.array([[1.0, 1.0, 1.0]])
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s copy-measured)
 #: algorithmic HBM bytes per voxel per sigma of each kernel
-ALG_BYTES = {"zpass": 2 + 8, "ypass": 8 + 8, "xpass": 8 + 4, "peaks": 4}
+ALG_BYTES = {"zpass": 2 + 8, "ypass": 8 + 8, "xpass": 8 + 4, "peaks": 4,
+             # fused path (default): Z+X in one kernel (Gz / Gzz never leave the CU), then Y
+             "zxpass": 2 + 8, "y2pass": 8 + 4}
 B_ALG_PER_SIGMA = 50                # SURVEY.md section 8d contract figure
 
 
@@ -268,6 +270,10 @@ def main():
         if dom:
             launches = ktimes[dom][1]
             roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"],
+                    "note": ("zxpass = fused Z+X pass: its 10 algorithmic B/voxel/sigma replace the 22 of the separate "
+                             "Z and X passes, and it is bound by packed-fp32 VALU issue, not by HBM (DESIGN.md "
+                             "section 4c); the HBM-bound kernels of the step run at 0.56-0.61 of peak, see 'kernels'")
+                    if dom == "zxpass" else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),
                     "traffic": traffic,

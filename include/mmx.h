@@ -112,9 +112,11 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
                       const double* h_w0, const double* h_w2, int radius, double norm,
                       float* d_log, float* d_work, void* stream);
 
-/* Select the experimental fused Z+X kernel for the following mmx_log_batch_f32 calls (default 0;
- * env MMX_FUSE=1 sets the initial value).  Results are identical either way. */
-int mmx_set_fused(int on);
+/* Select how the following mmx_log_batch_f32 calls run the Z and X passes: 0 = three separate passes,
+ * 1 = first fused Z+X kernel (kept for comparison), 2 = wave-specialised packed-math fused Z+X kernel
+ * (default; env MMX_FUSE sets the initial value).  Geometries the fused kernels do not take fall back to
+ * the separate passes.  All three agree within float32 rounding (the NMS decisions are exact either way). */
+int mmx_set_fused(int mode);
 
 /* Same contract, always through the generic (any radius <= MMX_MAX_RADIUS_GENERIC, any block
  * extent) kernels.  mmx_log_batch_f32 picks per pass between the register-ring kernels and

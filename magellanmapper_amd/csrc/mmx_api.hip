@@ -20,7 +20,9 @@ int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, cons
 namespace {
 thread_local char g_hip_err[256] = "";
 
-std::atomic<bool> g_fused{getenv("MMX_FUSE") && getenv("MMX_FUSE")[0] == '1'};
+// 0 = three separate passes, 1 = first fused Z+X kernel (kept for comparison), 2 = wave-specialised
+// packed-math fused Z+X kernel (default: fastest; geometries it does not take use the separate passes)
+std::atomic<int> g_fused{getenv("MMX_FUSE") ? atoi(getenv("MMX_FUSE")) : 2};
 
 struct span { hipEvent_t a, b; int kind; };
 std::mutex g_tm;
@@ -101,7 +103,7 @@ int mmx_abi_version(void) { return MMX_ABI_VERSION; }
 
 int mmx_set_fused(int on)
 {
-    g_fused.store(on != 0);
+    g_fused.store(on);
     return MMX_OK;
 }
 
@@ -212,12 +214,14 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         if (h_blocks[i].ny > max_ny) max_ny = h_blocks[i].ny;
         if (h_blocks[i].px > max_px) max_px = h_blocks[i].px;
     }
-    const bool fused = g_fused.load() && fast_r && lane_ok && fast_y && min_nz >= radius + 1 && min_nx >= radius &&
+    const int fuse_mode = g_fused.load();
+    const bool fused = fuse_mode != 0 && fast_r && lane_ok && fast_y && min_nz >= radius + 1 && min_nx >= radius &&
                        max_px <= 512 && vol->stride_y < (1 << 30);
     if (fused) {
         mmx_taps_f32 tzz = taps(wz0, wz2), txx = taps(wy0, wy2), tyy = taps(wx0, wx2);
         { mmx_timed_scope ts(MMX_K_ZX, s);
-          rc = mmx_launch_zx(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
+          if (fuse_mode == 2) rc = mmx_launch_zx2(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);
+          else rc = mmx_launch_zx(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
         if (rc == MMX_OK) {
             mmx_timed_scope ts(MMX_K_Y2, s);
             rc = mmx_launch_y2(d_blocks, n_blocks, max_ycols, slot_elems, tyy, radius, t0, t1, d_log, s);

@@ -41,6 +41,9 @@ int mmx_launch_xpass(const mmx_block* d_blocks, int n_blocks, int max_rows, int 
 int mmx_launch_zx(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_ny, int max_px,
                   int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
                   float* d_p, float* d_q, hipStream_t stream);
+int mmx_launch_zx2(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_ny, int max_px,
+                   int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
+                   float* d_p, float* d_q, hipStream_t s);
 int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
                   float* d_log, hipStream_t stream);

@@ -69,7 +69,8 @@ def test_log_cube_within_tolerance(gpu, case):
 
 @pytest.mark.parametrize("case", ["u16_5sigma", "u8_3sigma", "f32_2sigma", "u16_twoscale10"])
 def test_fused_zx_path_gives_the_same_cube(gpu, case):
-    """The experimental fused Z+X kernel (mmx_set_fused) must reproduce the three-pass result."""
+    """The fused Z+X kernels (mmx_set_fused 1: first design, 2: wave-specialised packed math, the default)
+    must reproduce the three-pass result (mode 0)."""
     from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
     g = load_golden("bloblog_%s.npz" % case)
@@ -77,18 +78,23 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
     dvol = bl.DeviceVolume(g["volume"])
     space = bl.ScaleSpace.make(float(g["min_sigma"]), float(g["max_sigma"]), int(g["num_sigma"]))
     shape = g["volume"].shape
-    sep = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
-    nat.lib().mmx_set_fused(1)
     try:
-        nat.timing_enable(True)
-        fused = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
-        kinds = nat.timing_read()
-    finally:
         nat.lib().mmx_set_fused(0)
+        nat.timing_enable(True)
+        sep = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
+        kinds = nat.timing_read()
+        assert kinds["zxpass"][1] == 0 and (kinds["zpass"][1] > 0 or kinds["generic"][1] > 0)
+        for mode in (1, 2):
+            nat.lib().mmx_set_fused(mode)
+            fused = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
+            kinds = nat.timing_read()
+            # the fused kernels really ran (wherever the geometry lets any register-resident pass run)
+            assert kinds["zxpass"][1] > 0 or kinds["generic"][1] > 0 or kinds["zpass"][1] > 0
+            assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL
+            assert np.max(np.abs(fused - sep)) < 2e-6 * max(1.0, float(np.abs(sep).max()))
+    finally:
+        nat.lib().mmx_set_fused(2)
         nat.timing_enable(False)
-    assert kinds["zxpass"][1] > 0 and kinds["zpass"][1] == 0      # the fused kernels really ran
-    assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL
-    assert np.max(np.abs(fused - sep)) < 2e-6 * max(1.0, float(np.abs(sep).max()))
 
 
 @pytest.mark.parametrize("case", BLOBLOG_CASES)
@@ -477,7 +483,7 @@ def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
         detector.Blobs(np.ones((1, 4))).format_blobs()
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 def test_every_kernel_radius_matches_oracle(gpu, fused):
     """Each compiled radius (1..24 register-resident, 25 generic) of the separable passes against the
     float64 oracle cube.  Regression: the X pass read its register window in pairs but sized it odd for
@@ -487,7 +493,7 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
     vol = synth.make_volume(3, (35, 42, 48), 12)
     dvol = bl.DeviceVolume(vol)
     img = blo.img_as_float(vol)
-    nat.lib().mmx_set_fused(1 if fused else 0)
+    nat.lib().mmx_set_fused(int(fused))
     try:
         for R in range(1, 26):
             sigma = (R + 0.2) / 4.0
@@ -497,7 +503,7 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
             want = blo.log_cube(img, np.array([[sigma] * 3]))[..., 0]
             assert np.abs(got - want).max() < LOG_TOL * 1e-2, R
     finally:
-        nat.lib().mmx_set_fused(0)
+        nat.lib().mmx_set_fused(2)
 
 
 def test_block_shape_and_dtype_sweep_matches_oracle(gpu):

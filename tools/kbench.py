@@ -71,3 +71,16 @@ for (k, R), v in sorted(res.items()):
     else:
         gbs = alg.get(k, 0) * nvox / ms / 1e6
     print(f"{k:8s} R={R:3d}  {ms:8.3f} ms  {gbs:8.1f} GB/s(alg)  {nvox/ms/1e6:7.2f} Gvox/s")
+
+if os.environ.get("ZX2_PROFILE"):
+    # per (block, y) row: [producer busy, first consumer wave busy, total, last consumer wave busy] in 100 MHz ticks
+    R = k1.kernel_radius(a.sigmas[-1])
+    w0 = k1.gaussian_half_kernel(a.sigmas[-1], 0, R); w2 = k1.gaussian_half_kernel(a.sigmas[-1], 2, R)
+    nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, nat.as_double_ptr(w0),
+                 nat.as_double_ptr(w2), R, 1.0, log_base, ws.data_ptr(), stream), "log")
+    torch.cuda.synchronize()
+    P = ws[:nb * slot].view(nb, slot).cpu().numpy()
+    px = int(blocks["px"][0])
+    rows = P[:, :e * px].reshape(nb, e, px)[:, :, :4].reshape(-1, 4)
+    print("R=%d ticks per row-WG (100 MHz): producer busy %.0f, consumer busy %.0f / %.0f, total %.0f" % (
+        R, rows[:, 0].mean(), rows[:, 1].mean(), rows[:, 3].mean(), rows[:, 2].mean()))
