@@ -104,6 +104,12 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
     const int64_t sbase = (int64_t)bd.slot * slot_elems + (int64_t)y * px;
     const int64_t plane = (int64_t)bd.ny * px;
 
+#ifdef ZX2_PROFILE
+    if ((t & 63) == 0) {   // which SIMD hosts this wave (HW_ID bits 5:4)
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        gp[sbase + 8 + (t >> 6)] = (float)((hw >> 4) & 3);
+    }
+#endif
     if (t < np) {
         // ------------------------------------------------------------------ producers: z march
         const bool lane_on = t < px;

@@ -81,6 +81,9 @@ if os.environ.get("ZX2_PROFILE"):
     torch.cuda.synchronize()
     P = ws[:nb * slot].view(nb, slot).cpu().numpy()
     px = int(blocks["px"][0])
+    simd = P[:, :e * px].reshape(nb, e, px)[:, :, 8:24].reshape(-1, 16)
+    import collections
+    print("wave -> SIMD maps seen:", collections.Counter(tuple(int(v) for v in r[:14]) for r in simd).most_common(4))
     rows = P[:, :e * px].reshape(nb, e, px)[:, :, :4].reshape(-1, 4)
     print("R=%d ticks per row-WG (100 MHz): producer busy %.0f, consumer busy %.0f / %.0f, total %.0f" % (
         R, rows[:, 0].mean(), rows[:, 1].mean(), rows[:, 3].mean(), rows[:, 2].mean()))
