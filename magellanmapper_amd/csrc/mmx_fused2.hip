@@ -117,6 +117,9 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
         const InT* in = vol + bd.src_off + (int64_t)y * stride_y;
         const unsigned voff = (unsigned)(xl * stride_x) * (unsigned)sizeof(InT);
         const unsigned zstride_b = (unsigned)(stride_z * (int64_t)sizeof(InT));    // < 4 GiB (checked by the launcher)
+        const int qmain = pad2(t < W ? xg::S + t : xg::S + R + t);     // tile position of this lane's column
+        const int qleft = pad2(xg::S - 1 - t);
+        const int qright = pad2(xg::S + W + (W - 1 - t));
         // active window: inputs z0-R .. z0+R+G-1 of the current group; pf[u]: the 8 planes that enter the
         // window after group g (g % kPF == u), loaded kPF groups ahead.  With one workgroup per CU nothing
         // else hides HBM latency, and a load must never be moved while in flight -- hence a ring of
@@ -150,6 +153,7 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
                 if (g < ngroups && lane_on) {
                     v2f* rows = tile + (g & 1) * (kG * PW);
                     const int z0 = g * kG;
+                    v2f av[kG];
 #pragma unroll
                     for (int s = 0; s < kG; ++s) {
                         const float c = w[R + s];
@@ -161,13 +165,18 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
                             a = __builtin_elementwise_fma((v2f){p, p}, T.zw[k], a);
                         }
 #endif
-                        if (t < W) {
-                            v2f* row = rows + s * PW;
-                            row[pad2(xg::S + t)] = a;
-                            if (t < R) row[pad2(xg::S - 1 - t)] = a;                       // left halo:  x = -1-t <- x = t
-                            if (t >= W - R) row[pad2(xg::S + W + (W - 1 - t))] = a;        // right halo: x = W+j  <- x = W-1-j
-                        }
+                        rows[s * PW + qmain] = a;        // (pitch lanes write past the right halo: no branch)
+                        av[s] = a;
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // reflect halos of the 8 rows, once per group: x = -1-t <- x = t ; x = W+j <- x = W-1-j
+                    if (t < R) {
+#pragma unroll
+                        for (int s = 0; s < kG; ++s) rows[s * PW + qleft] = av[s];
+                    }
+                    if (t >= W - R && t < W) {
+#pragma unroll
+                        for (int s = 0; s < kG; ++s) rows[s * PW + qright] = av[s];
                     }
                     // shift the active window by 8 (ascending, in place), take the planes loaded kPF groups
                     // ago and reload their registers for group g + kPF
