@@ -514,8 +514,9 @@ def test_block_shape_and_dtype_sweep_matches_oracle(gpu):
     from oracle import blob_log_oracle as blo
     rng = np.random.default_rng(21)
     shapes = [(9, 23, 17), (30, 31, 33), (12, 40, 63), (25, 26, 65), (40, 9, 100), (7, 50, 31),
-              (33, 33, 129), (5, 6, 7), (20, 70, 257)]
-    full = (max(s[0] for s in shapes), max(s[1] for s in shapes), max(s[2] for s in shapes))
+              (33, 33, 129), (5, 6, 7), (20, 70, 257), (27, 11, 300), (26, 10, 330)]   # row pitch 320 / above it
+    full = (max(s[0] for s in shapes), max(max(s[1] for s in shapes), 31), max(s[2] for s in shapes))
+    all_shapes = shapes
     for dtype in (np.uint16, np.uint8, np.float32, np.float64):
         vol = synth.make_volume(int(rng.integers(1 << 30)), full, 30)
         if dtype == np.uint8:
@@ -524,7 +525,11 @@ def test_block_shape_and_dtype_sweep_matches_oracle(gpu):
             vol = (vol / 65535.0).astype(dtype)
         dvol = bl.DeviceVolume(vol)
         origins = [tuple(int(rng.integers(0, f - s + 1)) for f, s in zip(full, shp)) for shp in shapes]
-        for sigmas in ((2.3, 2.3), (3.0, 4.75)):
+        # (the 330-wide block sends its whole batch through the separate passes; without it the fused
+        # kernel takes the batch, pitch-320 row included)
+        roomy = [(30, 31, 33), (40, 26, 100), (33, 33, 129), (27, 30, 257), (27, 27, 300)]   # every pass register-resident
+        for sigmas, shapes in (((2.3, 2.3), all_shapes), ((3.0, 4.75), all_shapes[:-1]), ((2.4, 4.75), roomy)):
+            origins = [tuple(int(rng.integers(0, f - s + 1)) for f, s in zip(full, shp)) for shp in shapes]
             space = bl.ScaleSpace.make(sigmas[0], sigmas[1], 2)
             cubes = bl.log_cube_blocks(dvol, 0, origins, shapes, space)
             for o, shp, got in zip(origins, shapes, cubes):
