@@ -30,7 +30,7 @@ from __future__ import annotations
 import ctypes
 import math
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -296,6 +296,23 @@ class _Buffers:
         return self.cands[which]
 
 
+_BUFFERS: Dict[str, _Buffers] = {}
+
+
+def _buffers_for(dev) -> _Buffers:
+    """The per-device scratch, created once: the side stream, the pinned count words and the workspace
+    cost ~25 ms to set up (pinned allocations, stream creation), a tenth of a whole benchmark volume."""
+    key = str(dev)
+    if key not in _BUFFERS:
+        _BUFFERS[key] = _Buffers(dev)
+    return _BUFFERS[key]
+
+
+def release_buffers() -> None:
+    """Drop the cached device scratch (workspace, candidate tables) of every device."""
+    _BUFFERS.clear()
+
+
 def _to_device_bytes(arr: np.ndarray, dev) -> "torch.Tensor":
     return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(dev)
 
@@ -367,7 +384,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     stats = stats if stats is not None else BatchStats()
     results: List[Optional[np.ndarray]] = [None] * len(shapes)
     peaks_out: List[Optional[Tuple[np.ndarray, np.ndarray]]] = [None] * len(shapes)
-    bufs = _Buffers(dvol.tensor.device)
+    bufs = _buffers_for(dvol.tensor.device)
     eps = EPS_REL * (dvol.value_scale() if pre is None else pre.value_scale([channel]))
     d_w0 = torch.from_numpy(space.w0_tab).to(dvol.tensor.device)
     d_w2 = torch.from_numpy(space.w2_tab).to(dvol.tensor.device)
