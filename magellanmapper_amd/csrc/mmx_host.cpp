@@ -20,29 +20,93 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
 #include "../../include/mmx.h"
 
 namespace {
-// run fn(t, n_threads) on a few host threads (the tables have ~3e5 rows: a handful is enough)
+// A small persistent pool: the tables have ~3e5 rows, so one parallel section is a fraction of a
+// millisecond of work and creating threads per section would cost as much as the work itself.
+class pool {
+public:
+    static pool& get() { static pool p; return p; }
+    int size() const { return (int)workers_.size() + 1; }
+    // run fn(t, n) for t = 0..n-1, n <= size(); the caller is thread 0
+    void run(int n, const std::function<void(int, int)>& fn)
+    {
+        if (n <= 1) { fn(0, 1); return; }
+        std::unique_lock<std::mutex> serial(serial_);          // one section at a time
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn; n_ = n; pending_ = n - 1; ++epoch_;
+        }
+        cv_.notify_all();
+        fn(0, n);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    pool()
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int n = (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+        for (int t = 1; t < n; ++t) workers_.emplace_back([this, t] { loop(t); });
+    }
+    ~pool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    void loop(int t)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int, int)>* fn = nullptr;
+            int n = 0;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (stop_) return;
+                if (t < n_) { fn = fn_; n = n_; }
+            }
+            if (fn) {
+                (*fn)(t, n);
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, serial_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int, int)>* fn_ = nullptr;
+    int n_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
 template <typename F>
 void parallel(int n_threads, F fn)
 {
-    if (n_threads <= 1) { fn(0, 1); return; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)n_threads - 1);
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(fn, t, n_threads);
-    fn(0, n_threads);
-    for (auto& th : pool) th.join();
+    pool& p = pool::get();
+    const std::function<void(int, int)> f = fn;
+    p.run(std::min(n_threads, p.size()), f);
 }
 
 int host_threads(int64_t n_rows)
 {
     if (n_rows < 20000) return 1;
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(8u, hw ? hw : 1u));
+    return pool::get().size();
 }
 }  // namespace
 
@@ -56,6 +120,9 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
     if (!zyx || !tag || !abs_zyx || (!cur && n_cur) || !bounds || !tol || !out_cur || !out_n ||
         !n_slab || !n_after || !n_next || axis < 0 || axis > 2 || n_sections < 2 || n_cur < 0)
         return MMX_ERR_ARG;
+    static const bool prof = getenv("MMX_PRUNE_PROF") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = tnow();
     const int n_regions = 2 * n_sections - 1;
     const int n_slabs = n_sections - 1;
     // group ids: pass j -> j ; slab j master -> n_sections + 2j ; slab j kept check -> n_sections + 2j + 1
@@ -90,6 +157,7 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
             else if (tg == sec + 1) { group[(size_t)i] = n_sections + 2 * sec + 1; P.checks[(size_t)sec].push_back(i); }
         }
     });
+    auto t1 = tnow();
     std::vector<std::vector<int64_t>> masters((size_t)n_slabs), checks((size_t)n_slabs);
     for (int j = 0; j < n_slabs; ++j)
         for (int t = 0; t < T; ++t) {           // chunk order == table order
@@ -100,38 +168,70 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
             n_next[j] += P.n_next[(size_t)j];
         }
 
+    auto t2 = tnow();
     // ---- matching: the slabs are independent (disjoint rows), one at a time per thread
     // the axis to sort the check rows on: any of the two other axes works
     const int sa = axis == 0 ? 1 : 0;
+    // (a) per slab: check rows sorted on `sa` (slabs in parallel); (b) every master of every slab looks its
+    // window up (masters in parallel: each writes only its own `last`, `hit` bytes are set, never cleared);
+    // (c) per slab: averages from the values before any update of this stage, then the removals.
+    std::vector<std::vector<std::pair<int32_t, int64_t>>> orders((size_t)n_slabs);   // (coordinate on sa, position in checks[j])
+    std::vector<std::vector<char>> hits((size_t)n_slabs);
+    std::vector<std::vector<int64_t>> lasts((size_t)n_slabs);
+    std::vector<int64_t> m_start((size_t)n_slabs + 1, 0);
+    for (int j = 0; j < n_slabs; ++j) {
+        const bool live = !masters[(size_t)j].empty() && !checks[(size_t)j].empty();
+        m_start[(size_t)j + 1] = m_start[(size_t)j] + (live ? (int64_t)masters[(size_t)j].size() : 0);
+    }
     parallel(std::min(T, n_slabs), [&](int t, int nt) {
-        std::vector<std::pair<int32_t, int64_t>> order;      // (coordinate on sa, position in checks[j])
+        for (int j = t; j < n_slabs; j += nt) {
+            const auto& M = masters[(size_t)j];
+            const auto& C = checks[(size_t)j];
+            if (M.empty() || C.empty()) continue;
+            auto& order = orders[(size_t)j];
+            order.reserve(C.size());
+            for (size_t k = 0; k < C.size(); ++k) order.emplace_back(zyx[3 * cur[C[k]] + sa], (int64_t)k);
+            std::sort(order.begin(), order.end());
+            hits[(size_t)j].assign(C.size(), 0);
+            lasts[(size_t)j].assign(M.size(), -1);
+        }
+    });
+    const int64_t n_masters = m_start[(size_t)n_slabs];
+    parallel(n_masters > 2000 ? T : 1, [&](int t, int nt) {
+        const int64_t lo_m = n_masters * t / nt, hi_m = n_masters * (t + 1) / nt;
+        int j = 0;
+        for (int64_t g = lo_m; g < hi_m; ++g) {
+            while (g >= m_start[(size_t)j + 1]) ++j;
+            const size_t m = (size_t)(g - m_start[(size_t)j]);
+            const auto& M = masters[(size_t)j];
+            const auto& C = checks[(size_t)j];
+            const auto& order = orders[(size_t)j];
+            char* hit = hits[(size_t)j].data();
+            const int32_t* mz = zyx + 3 * cur[M[m]];
+            const int32_t lo = mz[sa] - tol[sa], hi = mz[sa] + tol[sa];
+            int64_t last = -1;
+            auto it = std::lower_bound(order.begin(), order.end(), std::make_pair(lo, (int64_t)-1));
+            for (; it != order.end() && it->first <= hi; ++it) {
+                const int32_t* cz = zyx + 3 * cur[C[(size_t)it->second]];
+                if (std::abs(mz[0] - cz[0]) <= tol[0] && std::abs(mz[1] - cz[1]) <= tol[1] &&
+                    std::abs(mz[2] - cz[2]) <= tol[2]) {
+                    hit[(size_t)it->second] = 1;
+                    if (it->second > last) last = it->second;
+                }
+            }
+            lasts[(size_t)j][m] = last;
+        }
+    });
+    parallel(std::min(T, n_slabs), [&](int t, int nt) {
         std::vector<double> new_abs;
         for (int j = t; j < n_slabs; j += nt) {
             const auto& M = masters[(size_t)j];
             const auto& C = checks[(size_t)j];
             int64_t kept = (int64_t)C.size();
             if (!M.empty() && !C.empty()) {
-                order.clear();
-                order.reserve(C.size());
-                for (size_t k = 0; k < C.size(); ++k) order.emplace_back(zyx[3 * cur[C[k]] + sa], (int64_t)k);
-                std::sort(order.begin(), order.end());
-                std::vector<char> hit(C.size(), 0);
+                const auto& last = lasts[(size_t)j];
+                const auto& hit = hits[(size_t)j];
                 new_abs.assign(M.size() * 3, 0.0);
-                std::vector<int64_t> last(M.size(), -1);
-                for (size_t m = 0; m < M.size(); ++m) {
-                    const int32_t* mz = zyx + 3 * cur[M[m]];
-                    const int32_t lo = mz[sa] - tol[sa], hi = mz[sa] + tol[sa];
-                    auto it = std::lower_bound(order.begin(), order.end(), std::make_pair(lo, (int64_t)-1));
-                    for (; it != order.end() && it->first <= hi; ++it) {
-                        const int32_t* cz = zyx + 3 * cur[C[(size_t)it->second]];
-                        if (std::abs(mz[0] - cz[0]) <= tol[0] && std::abs(mz[1] - cz[1]) <= tol[1] &&
-                            std::abs(mz[2] - cz[2]) <= tol[2]) {
-                            hit[(size_t)it->second] = 1;
-                            if (it->second > last[m]) last[m] = it->second;
-                        }
-                    }
-                }
-                // averages from the values before any update of this stage
                 for (size_t m = 0; m < M.size(); ++m) {
                     if (last[m] < 0) continue;
                     const double* am = abs_zyx + 3 * cur[M[m]];
@@ -150,15 +250,37 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
         }
     });
 
-    // stable counting sort of the surviving rows by group
-    std::vector<int64_t> start((size_t)n_groups + 1, 0);
-    for (int64_t i = 0; i < n_cur; ++i)
-        if (group[(size_t)i] >= 0) ++start[(size_t)group[(size_t)i] + 1];
-    for (int g = 0; g < n_groups; ++g) start[(size_t)g + 1] += start[(size_t)g];
-    *out_n = start[(size_t)n_groups];
-    for (int64_t i = 0; i < n_cur; ++i) {
-        const int g = group[(size_t)i];
-        if (g >= 0) out_cur[start[(size_t)g]++] = cur[i];
+    auto t3 = tnow();
+    // stable counting sort of the surviving rows by group: per-chunk histograms, one prefix over
+    // (group, chunk), then every chunk scatters its own rows
+    std::vector<std::vector<int64_t>> hist((size_t)T, std::vector<int64_t>((size_t)n_groups, 0));
+    parallel(T, [&](int t, int nt) {
+        auto& h = hist[(size_t)t];
+        const int64_t lo = n_cur * t / nt, hi = n_cur * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i)
+            if (group[(size_t)i] >= 0) ++h[(size_t)group[(size_t)i]];
+    });
+    int64_t total = 0;
+    for (int g = 0; g < n_groups; ++g)
+        for (int t = 0; t < T; ++t) {
+            const int64_t c = hist[(size_t)t][(size_t)g];
+            hist[(size_t)t][(size_t)g] = total;
+            total += c;
+        }
+    *out_n = total;
+    parallel(T, [&](int t, int nt) {
+        auto& h = hist[(size_t)t];
+        const int64_t lo = n_cur * t / nt, hi = n_cur * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int g = group[(size_t)i];
+            if (g >= 0) out_cur[h[(size_t)g]++] = cur[i];
+        }
+    });
+    if (prof) {
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        auto t4 = tnow();
+        fprintf(stderr, "prune axis %d: n %ld classify %ld us, merge %ld, match %ld, sort %ld\n", axis, (long)n_cur,
+                us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
     }
     return MMX_OK;
 }
