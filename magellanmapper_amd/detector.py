@@ -398,6 +398,7 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
         pre.set_blocks(origins, shapes, log_shapes)
     per_block: List[List[np.ndarray]] = [[] for _ in shapes]
     done: List[Optional[np.ndarray]] = [None] * len(shapes)
+    Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry to the 11 columns
     for chl in channels:
         settings = config.get_roi_profile(chl)
         source = pre
@@ -417,17 +418,33 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
         root3 = math.sqrt(3)
 
         def to_tables(indices, results, chl=chl):
-            # radius = sigma * sqrt(3), then the 11 standard columns (reference :937-938)
-            for i, blobs_log in zip(indices, results):
-                if blobs_log.size < 1:
-                    continue
-                blobs_log = blobs_log.copy()
-                blobs_log[:, 3] = blobs_log[:, 3] * root3
-                per_block[i].append(Blobs(blobs_log).format_blobs(chl))
+            # radius = sigma * sqrt(3), then the 11 standard columns (reference :937-938:
+            # Blobs(blobs_log).format_blobs(chl)) -- for all blocks of the batch in one table, the
+            # per-block tables are row ranges of it
+            lens = [r.shape[0] if r.size >= 1 else 0 for r in results]
+            total = sum(lens)
+            if total:
+                big = np.empty((total, 11))
+                at = 0
+                for r, n in zip(results, lens):
+                    if n:
+                        big[at:at + n, :4] = r
+                        at += n
+                big[:, 3] = big[:, 3] * root3
+                big[:, 4:6] = -1                       # confirmed, truth
+                big[:, 6] = chl
+                big[:, 7:10] = big[:, 0:3]             # abs <- rel
+                big[:, 10] = -1                        # region
+                at = 0
+                for i, n in zip(indices, lens):
+                    if n:
+                        per_block[i].append(big[at:at + n])
+                        at += n
             if chl == channels[-1]:            # the block tables of this batch are complete
                 tbls = []
                 for i in indices:
-                    tbl = np.vstack(per_block[i]) if per_block[i] else None
+                    parts = per_block[i]
+                    tbl = (parts[0] if len(parts) == 1 else np.vstack(parts)) if parts else None
                     if tbl is not None and iso_factor is not None:
                         Blobs.multiply_blob_rel_coords(tbl, 1 / iso_factor)
                         Blobs.multiply_blob_abs_coords(tbl, 1 / iso_factor)
