@@ -40,7 +40,10 @@ constexpr int kG = 8;        // z steps (rows) per tile
 constexpr int kT = 4;        // X outputs per consumer item
 constexpr int kCons = 576;   // consumer lanes (9 waves): one round of (row, chunk) items for px = 288
 constexpr int kMaxPx = 320;  // 5 producer waves
-constexpr int kPF = 3;       // groups of z planes in flight per producer lane
+#ifndef ZX2_PF
+#define ZX2_PF 2
+#endif
+constexpr int kPF = ZX2_PF;  // groups of z planes in flight per producer lane
 
 __device__ __forceinline__ int reflect_once(int i, int n)
 {
