@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 5
+#define MMX_ABI_VERSION 6
 
 typedef enum {
     MMX_OK = 0,
@@ -106,11 +106,18 @@ int mmx_device_count(void);
  *                computed by the caller exactly as scipy's _gaussian_kernel1d does
  *   norm       : mean(sigma)**2
  *   d_log      : out, [n_blocks][slot_elems] float32
- *   d_work     : scratch, 4 * n_blocks * slot_elems float32                       */
+ *   d_work     : scratch, 4 * n_blocks * slot_elems float32
+ *   d_nms_mask : optional out, (n_blocks * slot_elems) >> 5 uint64: one bit per voxel (block in slot b
+ *                starts at word (b * slot_elems) >> 5; its row y holds ceil(nz*px/64) words, bit z*px + x) set where the response exceeds nms_lo and no
+ *                y / x neighbour exceeds it by more than nms_eps -- a superset of the local maxima that
+ *                mmx_peaks_batch can visit instead of reading the whole cube.  Only the fused path
+ *                produces it, and only when every block's rows fit its share (tiny blocks do not):
+ *                *h_mask_written (host) says whether this call did.                    */
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                       int n_blocks, int64_t slot_elems,
                       const double* h_w0, const double* h_w2, int radius, double norm,
-                      float* d_log, float* d_work, void* stream);
+                      float* d_log, float* d_work, uint64_t* d_nms_mask, float nms_lo, float nms_eps,
+                      int* h_mask_written, void* stream);
 
 /* Select how the following mmx_log_batch_f32 calls run the Z and X passes: 0 = three separate passes,
  * 1 = first fused Z+X kernel (kept for comparison), 2 = wave-specialised packed-math fused Z+X kernel
@@ -130,9 +137,11 @@ int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks,
  * replaces: skimage.feature.peak_local_max(footprint=ones(3,3,3,3), mode='constant')
  * (skimage/feature/peak.py:28-50, 114-319).
  *   d_log        : [n_sigma][n_blocks][slot_elems] float32 (sigma-major)
+ *   d_nms_mask   : optional [n_sigma][(n_blocks * slot_elems) >> 5] uint64 written by mmx_log_batch_f32 with
+ *                  nms_lo = thr - eps and nms_eps = eps for EVERY sigma (NULL = read every voxel)
  *   eps          : candidates are emitted when v >= nbr_max - eps and v > thr - eps
  *   d_cands/cap  : output table; *d_count keeps counting past cap (caller retries)  */
-int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
+int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int n_sigma, const mmx_block* d_blocks,
                     const mmx_block* h_blocks, int n_blocks, int64_t slot_elems,
                     float thr, float eps, mmx_cand* d_cands, uint32_t cap,
                     uint32_t* d_count, void* stream);

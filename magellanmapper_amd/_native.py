@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 5
+MMX_ABI_VERSION = 6
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -99,12 +99,12 @@ def lib() -> ctypes.CDLL:
     L.mmx_last_hip_error.restype = c_char_p
     L.mmx_device_count.restype = c_int
     log_args = [POINTER(Volume), vp, vp, c_int, c_int64, POINTER(c_double), POINTER(c_double),
-                c_int, c_double, vp, vp, vp]
-    L.mmx_log_batch_f32.argtypes = log_args
-    L.mmx_log_batch_f32_generic.argtypes = log_args
+                c_int, c_double, vp, vp]
+    L.mmx_log_batch_f32.argtypes = log_args + [vp, c_float, c_float, POINTER(c_int), vp]
+    L.mmx_log_batch_f32_generic.argtypes = log_args + [vp]
     L.mmx_set_fused.argtypes = [c_int]
     L.mmx_set_fused.restype = c_int
-    L.mmx_peaks_batch.argtypes = [vp, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
+    L.mmx_peaks_batch.argtypes = [vp, vp, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
                                   c_uint32, vp, vp]
     L.mmx_rescore_f64.argtypes = [POINTER(Volume), vp, c_int, vp, c_uint32, vp, vp, vp,
                                   POINTER(c_int32), POINTER(c_double), c_int, c_int, vp]

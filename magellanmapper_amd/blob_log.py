@@ -239,7 +239,7 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     largest block of the batch (+ ``extra_bytes_per_voxel`` for the preprocessed copies).
     Blocks keep their order (z-major grid order).
     """
-    per_vox = (4 + num_sigma) * 4 + extra_bytes_per_voxel
+    per_vox = (4 + num_sigma) * 4 + (num_sigma + 3) // 4 + extra_bytes_per_voxel     # + the NMS bit masks
     batches: List[List[int]] = []
     cur: List[int] = []
     cur_slot = 0
@@ -334,7 +334,8 @@ def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: Sc
         nat.check(fn(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                      nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
                      int(space.radii[s]), float(space.norms[s]),
-                     log_base + s * nb * slot * 4, ws.data_ptr(), _stream_ptr()), "mmx_log_batch_f32")
+                     log_base + s * nb * slot * 4, ws.data_ptr(), *(() if generic else (None, 0.0, 0.0, None)),
+                     _stream_ptr()), "mmx_log_batch_f32")
     torch.cuda.synchronize()
     logs = ws[4 * nb * slot:].view(ns, nb, slot).cpu().numpy()
     out = []
@@ -428,24 +429,33 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     nb, ns = len(blocks), len(space.sigmas)
     if slot >= (1 << 29):
         raise nat.MmxError("block too large for one workspace slot (>= 2^29 voxels)")
-    ws = bufs.workspace((4 + ns) * nb * slot)
+    mask_words = (nb * slot) >> 5            # uint64 words per sigma (include/mmx.h: d_nms_mask)
+    ws = bufs.workspace((4 + ns) * nb * slot + 2 + ns * mask_words * 2)
     d_blocks = _to_device_bytes(blocks, dev)
     stream = _stream_ptr()
     log_base = ws.data_ptr() + 4 * nb * slot * 4
+    # NMS pre-filter masks, [ns][nb][slot / 32] uint64: written by the Y pass of the fused path
+    mask_base = (log_base + ns * nb * slot * 4 + 7) & ~7
+    mask_ok = True
+    written = ctypes.c_int(0)
     for s in range(ns):
         nat.check(L.mmx_log_batch_f32(
             ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
             nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]), int(space.radii[s]),
-            float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(), stream),
+            float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(),
+            (mask_base + s * mask_words * 8) if mask_ok else None, thr - eps, eps,
+            ctypes.byref(written), stream),
             "mmx_log_batch_f32")
+        mask_ok = mask_ok and written.value == 1
     n_vox = int(sum(int(np.prod(s)) for s in shapes))
     if cap is None:
         cap = max(4096, min(n_vox * ns, n_vox // 2000 * ns + 65536))
     table = bufs.cand_table(which, cap)
     count = bufs.counts[which]
     count.zero_()
-    nat.check(L.mmx_peaks_batch(log_base, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
-                                thr, eps, table.data_ptr(), cap, count.data_ptr(), stream),
+    nat.check(L.mmx_peaks_batch(log_base, mask_base if mask_ok else None, ns, d_blocks.data_ptr(),
+                                blocks.ctypes.data, nb, slot, thr, eps, table.data_ptr(), cap,
+                                count.data_ptr(), stream),
               "mmx_peaks_batch")
     nat.check(L.mmx_rescore_f64(
         ctypes.byref(vol_exact), d_blocks.data_ptr(), nb, table.data_ptr(), cap,

@@ -13,6 +13,10 @@ int mmx_launch_generic_pass(int pass, const mmx_volume* vol, const mmx_block* d_
 int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, const mmx_block* d_blocks,
                      int n_blocks, int max_vox, int64_t slot_elems, float thr, float eps,
                      mmx_cand* d_cands, uint32_t cap, uint32_t* d_count, hipStream_t stream);
+int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask, int n_sigma,
+                            int64_t sigma_stride, const mmx_block* d_blocks, int n_blocks, int max_vox,
+                            int64_t slot_elems, float thr, float eps, mmx_cand* d_cands, uint32_t cap,
+                            uint32_t* d_count, hipStream_t stream);
 
 #include <mutex>
 #include <vector>
@@ -138,8 +142,10 @@ int mmx_device_count(void)
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                       int n_blocks, int64_t slot_elems,
                       const double* h_w0, const double* h_w2, int radius, double norm,
-                      float* d_log, float* d_work, void* stream)
+                      float* d_log, float* d_work, uint64_t* d_nms_mask, float nms_lo, float nms_eps,
+                      int* h_mask_written, void* stream)
 {
+    if (h_mask_written) *h_mask_written = 0;
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
         return MMX_ERR_ARG;
     if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
@@ -224,7 +230,15 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
           else rc = mmx_launch_zx(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
         if (rc == MMX_OK) {
             mmx_timed_scope ts(MMX_K_Y2, s);
-            rc = mmx_launch_y2(d_blocks, n_blocks, max_ycols, slot_elems, tyy, radius, t0, t1, d_log, s);
+            // the mask rows of a block (ny rows of ceil(nz * px / 64) words) must fit its slot / 32 words
+            bool want_mask = d_nms_mask != nullptr && h_mask_written != nullptr;
+            for (int b = 0; want_mask && b < n_blocks; ++b) {
+                const int64_t need = (int64_t)h_blocks[b].ny * (((int64_t)h_blocks[b].nz * h_blocks[b].px + 63) >> 6);
+                if (need > (slot_elems >> 5) - 1) want_mask = false;
+            }
+            rc = mmx_launch_y2(d_blocks, n_blocks, max_ycols, slot_elems, tyy, radius, t0, t1, d_log,
+                               want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s);
+            if (rc == MMX_OK && want_mask) *h_mask_written = 1;
         }
         if (rc == MMX_ERR_HIP) return hip_fail(hipGetLastError(), "fused passes");
         if (rc == MMX_OK) return MMX_OK;
@@ -284,7 +298,7 @@ int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks, 
     return mmx_launch_generic_pass(2, vol, d_blocks, n_blocks, max_vox, slot_elems, a, b, radius, t2, t3, d_log, nullptr, s);
 }
 
-int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
+int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int n_sigma, const mmx_block* d_blocks,
                     const mmx_block* h_blocks, int n_blocks, int64_t slot_elems,
                     float thr, float eps, mmx_cand* d_cands, uint32_t cap,
                     uint32_t* d_count, void* stream)
@@ -301,7 +315,13 @@ int mmx_peaks_batch(const float* d_log, int n_sigma, const mmx_block* d_blocks,
         if (b.nz * b.ny * b.px > max_vox) max_vox = b.nz * b.ny * b.px;
     }
     mmx_timed_scope ts(MMX_K_PEAKS, (hipStream_t)stream);
-    int rc = mmx_launch_peaks(d_log, n_sigma, (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox,
+    int rc;
+    if (d_nms_mask)
+        rc = mmx_launch_peaks_sparse(d_log, (const unsigned long long*)d_nms_mask, n_sigma,
+                                     (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox, slot_elems,
+                                     thr, eps, d_cands, cap, d_count, (hipStream_t)stream);
+    else
+        rc = mmx_launch_peaks(d_log, n_sigma, (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox,
                               slot_elems, thr, eps, d_cands, cap, d_count, (hipStream_t)stream);
     return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "peaks") : rc;
 }

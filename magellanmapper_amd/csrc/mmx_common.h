@@ -46,7 +46,7 @@ int mmx_launch_zx2(const mmx_volume* vol, const mmx_block* d_blocks, int n_block
                    float* d_p, float* d_q, hipStream_t s);
 int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
-                  float* d_log, hipStream_t stream);
+                  float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);
 
 // ---- optional per-kernel-family timing with HIP events on the launch stream (bench.py) ----
 enum mmx_kernel_kind {

@@ -241,7 +241,8 @@ template <int R>
 __global__ void __launch_bounds__(MMX_WG)
 y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
           const float* __restrict__ gp, const float* __restrict__ gq,
-          float* __restrict__ out, mmx_taps_f32 taps)
+          float* __restrict__ out, mmx_taps_f32 taps,
+          unsigned long long* __restrict__ mask, float nms_lo, float nms_eps)
 {
     using io = vox<float>;
     constexpr int N = 2 * R + 1;
@@ -259,6 +260,17 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
     const float* i1 = gp + sbase;
     const float* i2 = gq + sbase;
     const float* w1 = out + sbase;
+
+    // NMS pre-filter (optional): one bit per voxel = "above thr - eps and not beaten by more than eps
+    // by its y and (same wave) x neighbours" -- a superset of the local maxima, decided on the very
+    // float32 values stored below.  The NMS kernel then only visits the set bits (mmx_peaks.hip).
+    const int lane = threadIdx.x & 63;
+    const int nwords = (ncol + 63) >> 6;
+    unsigned long long* mrow = mask ? mask + ((int64_t)bd.slot * slot_elems >> 5) + (col >> 6) : nullptr;
+    const bool real = x < bd.nx;
+    const bool has_l = lane > 0 && x > 0, has_r = lane < 63 && x + 1 < bd.nx && col + 1 < ncol;
+    float prev1 = -INFINITY, prev2 = -INFINITY, nbx_prev = -INFINITY;
+    int ydone = 0;       // outputs produced so far
 
     float r1[M];  // P window
     float r2[M];  // Q window
@@ -292,6 +304,23 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
         w1 += nx;
         r1[(s + R + kPrefetch) % M] = n1;
         r2[(s + R + kPrefetch) % M] = n2;
+        if (mask) {
+            // x neighbours by DPP wavefront shifts (no LDS crossbar traffic); lanes shifted in from
+            // outside the wave keep `acc`, which has_l / has_r discard
+            const float l = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
+                (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+            const float r = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
+                (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+            const float nbx = fmaxf(has_l ? l : -INFINITY, has_r ? r : -INFINITY);
+            if (ydone > 0) {      // decide row ydone - 1, now that its successor is known
+                const bool cand = real && prev1 > nms_lo &&
+                                  !(fmaxf(fmaxf(prev2, acc), nbx_prev) > prev1 + nms_eps);
+                const unsigned long long m = __ballot(cand);
+                if (lane == 0) mrow[(int64_t)(ydone - 1) * nwords] = m;
+            }
+            prev2 = prev1; prev1 = acc; nbx_prev = nbx;
+            ++ydone;
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     int y0 = 0;
@@ -307,6 +336,11 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
             if (y0 + s >= n) break;
             step(s, std::true_type{}, y0 + s);
         }
+    }
+    if (mask) {               // the last row has no successor
+        const bool cand = real && prev1 > nms_lo && !(fmaxf(prev2, nbx_prev) > prev1 + nms_eps);
+        const unsigned long long m = __ballot(cand);
+        if (lane == 0) mrow[(int64_t)(n - 1) * nwords] = m;
     }
 }
 
@@ -337,10 +371,12 @@ int launch_zx(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, in
 
 template <int R>
 int launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
-              const mmx_taps_f32& taps, const float* d_p, const float* d_q, float* d_log, hipStream_t s)
+              const mmx_taps_f32& taps, const float* d_p, const float* d_q, float* d_log,
+              unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t s)
 {
     dim3 grid((max_cols + MMX_WG - 1) / MMX_WG, n_blocks);
-    hipLaunchKernelGGL(y2_kernel<R>, grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, d_p, d_q, d_log, taps);
+    hipLaunchKernelGGL(y2_kernel<R>, grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, d_p, d_q, d_log, taps,
+                       d_mask, nms_lo, nms_eps);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
@@ -364,10 +400,10 @@ int mmx_launch_zx(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks
 
 int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
-                  float* d_log, hipStream_t stream)
+                  float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream)
 {
     switch (radius) {
-#define X(R) case R: return launch_y2<R>(d_blocks, n_blocks, max_cols, slot_elems, taps, d_p, d_q, d_log, stream);
+#define X(R) case R: return launch_y2<R>(d_blocks, n_blocks, max_cols, slot_elems, taps, d_p, d_q, d_log, d_mask, nms_lo, nms_eps, stream);
         MMX_FOR_EACH_RADIUS(X)
 #undef X
         default: return MMX_ERR_UNSUPPORTED;

@@ -172,7 +172,65 @@ peaks_kernel(const float* __restrict__ log, int ns, int64_t sigma_stride,
     }
 }
 
+// Sparse variant: the Y pass of the fused path has already marked, one bit per voxel, the voxels that
+// pass the threshold and are not beaten by their y / x neighbours (y2_kernel).  One lane per 64-voxel
+// word and sigma: nearly all words are zero; set bits get the full 80-neighbour test.  Reads
+// 1/8 byte per voxel and sigma instead of 4.
+__global__ void __launch_bounds__(MMX_WG)
+peaks_sparse_kernel(const float* __restrict__ log, const unsigned long long* __restrict__ mask,
+                    int ns, int64_t sigma_stride, const mmx_block* __restrict__ blocks, int64_t slot_elems,
+                    float thr, float eps, mmx_cand* __restrict__ out, uint32_t cap,
+                    uint32_t* __restrict__ count)
+{
+    const mmx_block bd = blocks[blockIdx.y];
+    peak_ctx c;
+    c.base = log + (int64_t)bd.slot * slot_elems;
+    c.sigma_stride = sigma_stride;
+    c.ns = ns; c.nz = bd.nz; c.ny = bd.ny; c.nx = bd.nx; c.px = bd.px;
+    c.plane = bd.ny * bd.px; c.slot = bd.slot;
+    c.thr = thr; c.eps = eps; c.out = out; c.cap = cap; c.count = count;
+    const int ncol = bd.nz * bd.px;
+    const int nwords = (ncol + 63) >> 6;
+    const int64_t per_sigma = (int64_t)bd.ny * nwords;
+    const int64_t total = per_sigma * ns;
+    const unsigned long long* mb = mask + ((int64_t)bd.slot * slot_elems >> 5);
+    const int64_t mask_sigma_stride = sigma_stride >> 5;
+    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < total; i += (int64_t)gridDim.x * MMX_WG) {
+        const int s = (int)(i / per_sigma);
+        const int64_t r = i - (int64_t)s * per_sigma;
+        unsigned long long m = mb[(int64_t)s * mask_sigma_stride + r];
+        if (!m) continue;
+        const int y = (int)(r / nwords);
+        const int w = (int)(r - (int64_t)y * nwords);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int col = (w << 6) + b;
+            const int z = col / bd.px;
+            const int x = col - z * bd.px;
+            if (x >= bd.nx || z >= bd.nz) continue;
+            const int idx = z * c.plane + y * bd.px + x;
+            check_voxel(c, s, idx, c.base[(int64_t)s * sigma_stride + idx]);
+        }
+    }
+}
+
 }  // namespace
+
+int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask, int n_sigma,
+                            int64_t sigma_stride, const mmx_block* d_blocks, int n_blocks, int max_vox,
+                            int64_t slot_elems, float thr, float eps, mmx_cand* d_cands, uint32_t cap,
+                            uint32_t* d_count, hipStream_t stream)
+{
+    int64_t words = ((int64_t)max_vox / 64 + 1024) * n_sigma;
+    int gx = (int)((words + MMX_WG - 1) / MMX_WG);
+    if (gx > 8192) gx = 8192;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, n_blocks);
+    hipLaunchKernelGGL(peaks_sparse_kernel, grid, dim3(MMX_WG), 0, stream, d_log, d_mask, n_sigma, sigma_stride,
+                       d_blocks, slot_elems, thr, eps, d_cands, cap, d_count);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
 
 int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, const mmx_block* d_blocks,
                      int n_blocks, int max_vox, int64_t slot_elems, float thr, float eps,

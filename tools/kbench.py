@@ -15,6 +15,7 @@ ap.add_argument("--edge", type=int, default=261)
 ap.add_argument("--sigmas", type=float, nargs="+", default=[3.0, 4.0, 5.0])
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--generic", action="store_true")
+ap.add_argument("--mask", action="store_true", help="Y pass writes the NMS pre-filter masks; sparse NMS kernel")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 e = a.edge
@@ -39,6 +40,9 @@ nvox = nb * e ** 3   # algorithmic voxels (pitch columns not counted)
 res = {}
 fn = L.mmx_log_batch_f32_generic if a.generic else L.mmx_log_batch_f32
 log_base = ws.data_ptr() + 4 * nb * slot * 4
+mask_words = (nb * slot) >> 5
+masks = torch.zeros(ns * mask_words, dtype=torch.int64, device=dev)
+written = ctypes.c_int(0)
 for rep in range(a.reps + 1):
     if rep == 1:
         nat.timing_enable(True)
@@ -47,7 +51,9 @@ for rep in range(a.reps + 1):
         w0 = k1.gaussian_half_kernel(s, 0, R); w2 = k1.gaussian_half_kernel(s, 2, R)
         nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                      nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, s * s,
-                     log_base + i * nb * slot * 4, ws.data_ptr(), stream), "log")
+                     log_base + i * nb * slot * 4, ws.data_ptr(), *(() if a.generic else ((masks.data_ptr() + i * mask_words * 8) if a.mask else None, 0.1 - 2e-5, 2e-5,
+                                                    ctypes.byref(written))), stream), "log")
+        assert not a.mask or written.value == 1
         if rep >= 1:
             t = nat.timing_read()
             for k, (ms, n) in t.items():
@@ -56,7 +62,7 @@ for rep in range(a.reps + 1):
     cap = 1 << 20
     table = torch.empty(cap * 48, dtype=torch.uint8, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
-    nat.check(L.mmx_peaks_batch(log_base, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, 0.1, 2e-5,
+    nat.check(L.mmx_peaks_batch(log_base, masks.data_ptr() if a.mask else None, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, 0.1, 2e-5,
                                 table.data_ptr(), cap, count.data_ptr(), stream), "peaks")
     if rep >= 1:
         t = nat.timing_read()
@@ -77,7 +83,7 @@ if os.environ.get("ZX2_PROFILE"):
     R = k1.kernel_radius(a.sigmas[-1])
     w0 = k1.gaussian_half_kernel(a.sigmas[-1], 0, R); w2 = k1.gaussian_half_kernel(a.sigmas[-1], 2, R)
     nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, nat.as_double_ptr(w0),
-                 nat.as_double_ptr(w2), R, 1.0, log_base, ws.data_ptr(), stream), "log")
+                 nat.as_double_ptr(w2), R, 1.0, log_base, ws.data_ptr(), None, 0.0, 0.0, None, stream), "log")
     torch.cuda.synchronize()
     P = ws[:nb * slot].view(nb, slot).cpu().numpy()
     px = int(blocks["px"][0])
