@@ -236,12 +236,18 @@ zx_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int strid
 
 // ---------------------------------------------------------------- Y pass on (P, Q)
 constexpr int kPrefetch = 4;
+typedef float v2f __attribute__((ext_vector_type(2)));
+// (G''(y), G(y)) weights as pairs: the ring holds (P, Q) pairs, so one v_pk_add_f32 forms both pair sums of
+// a tap and one v_pk_fma_f32 accumulates (G''(y) P, G(y) Q); the two halves are added once per output.
+struct y2_taps {
+    v2f w[MMX_MAX_RADIUS_FAST + 1];
+};
 
 template <int R>
 __global__ void __launch_bounds__(MMX_WG)
 y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
           const float* __restrict__ gp, const float* __restrict__ gq,
-          float* __restrict__ out, mmx_taps_f32 taps,
+          float* __restrict__ out, y2_taps taps,
           unsigned long long* __restrict__ mask, float nms_lo, float nms_eps)
 {
     using io = vox<float>;
@@ -272,13 +278,11 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
     float prev1 = -INFINITY, prev2 = -INFINITY, nbx_prev = -INFINITY;
     int ydone = 0;       // outputs produced so far
 
-    float r1[M];  // P window
-    float r2[M];  // Q window
+    v2f r[M];     // (P, Q) window
 #pragma unroll
     for (int j = -R; j < R + kPrefetch; ++j) {
         const int row = reflect_once(j, n) * nx;
-        r1[(j + M) % M] = io::load(make_rsrc(i1 + row), voff);
-        r2[(j + M) % M] = io::load(make_rsrc(i2 + row), voff);
+        r[(j + M) % M] = (v2f){io::load(make_rsrc(i1 + row), voff), io::load(make_rsrc(i2 + row), voff)};
     }
     const float* q1 = i1 + (int64_t)(R + kPrefetch) * nx;
     const float* q2 = i2 + (int64_t)(R + kPrefetch) * nx;
@@ -294,16 +298,23 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
         }
         q1 += nx;
         q2 += nx;
-        float acc = fmaf(r2[s], taps.w0[0], r1[s] * taps.w2[0]);
+        // two accumulator chains: a dependent v_pk_add -> v_pk_fma pair back to back costs a wait state
+        v2f a2 = r[s] * taps.w[0];
+        v2f b2 = (r[(s - 1 + M) % M] + r[(s + 1) % M]) * taps.w[1];
 #pragma unroll
-        for (int k = 1; k <= R; ++k) {
-            acc = fmaf(r1[(s - k + M) % M] + r1[(s + k) % M], taps.w2[k], acc);
-            acc = fmaf(r2[(s - k + M) % M] + r2[(s + k) % M], taps.w0[k], acc);
+        for (int k = 2; k <= R; k += 2) {
+            const v2f sa = r[(s - k + M) % M] + r[(s + k) % M];
+            a2 = __builtin_elementwise_fma(sa, taps.w[k], a2);
+            if (k + 1 <= R) {
+                const v2f sb = r[(s - k - 1 + M) % M] + r[(s + k + 1) % M];
+                b2 = __builtin_elementwise_fma(sb, taps.w[k + 1], b2);
+            }
         }
+        a2 += b2;
+        const float acc = a2.x + a2.y;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), make_rsrc(w1), voff, 0, 0);
         w1 += nx;
-        r1[(s + R + kPrefetch) % M] = n1;
-        r2[(s + R + kPrefetch) % M] = n2;
+        r[(s + R + kPrefetch) % M] = (v2f){n1, n2};
         if (mask) {
             // x neighbours by DPP wavefront shifts (no LDS crossbar traffic); lanes shifted in from
             // outside the wave keep `acc`, which has_l / has_r discard
@@ -375,7 +386,9 @@ int launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slo
               unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t s)
 {
     dim3 grid((max_cols + MMX_WG - 1) / MMX_WG, n_blocks);
-    hipLaunchKernelGGL(y2_kernel<R>, grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, d_p, d_q, d_log, taps,
+    y2_taps pk;
+    for (int k = 0; k <= R; ++k) pk.w[k] = (v2f){taps.w2[k], taps.w0[k]};
+    hipLaunchKernelGGL(y2_kernel<R>, grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, d_p, d_q, d_log, pk,
                        d_mask, nms_lo, nms_eps);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }

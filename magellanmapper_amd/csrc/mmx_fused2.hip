@@ -86,26 +86,187 @@ template <int R> struct xgeom2 {
     static constexpr int PITCH = ((SPAN + 2 * (SPAN >> 2)) + 3) & ~1;   // compile-time row pitch (pairs)
 };
 
+// Producer wave.  TAIL = false: lane = one column x, marching along z (8 outputs per group).
+// TAIL = true (block widths just past a multiple of 64, e.g. 261 = 256 + the 5 overlap columns): the
+// wave takes the last <= 8 columns with lane = (plane of the group, column): the same register window and
+// prefetch ring, shifted along z by (plane - 7) per lane, and ONE output per lane and group (window index 7)
+// -- about a quarter of a marching wave's instructions instead of a whole wave for 5 useful lanes.
+template <int R, typename InT, bool TAIL>
+__device__ __forceinline__ void zx2_producer(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stride_x,
+                                             const mmx_block& bd, int y, int xlane, v2f* tile, const mmx_taps_zx2& T,
+                                             float* __restrict__ gp, int64_t sbase)
+{
+    using io = vox<InT>;
+    using xg = xgeom2<R>;
+    constexpr int NA = 2 * R + kG;       // register window: inputs z0-R .. z0+R+G-1 (+ zs)
+    constexpr int PW = xg::PITCH;
+    constexpr int S0 = TAIL ? kG - 1 : 0;            // first output index of the window this wave computes
+    constexpr int NS = TAIL ? 1 : kG;                // outputs per lane and group
+    constexpr int I0 = TAIL ? kG - 1 : 0;            // first window entry in use
+    const int W = bd.nx, px = bd.px, nz = bd.nz;
+    const int ngroups = (nz + kG - 1) / kG;
+    const int lane = threadIdx.x & 63;
+    const int x = TAIL ? (W & ~63) + (lane & 7) : xlane;             // column of this lane
+    const int row0 = TAIL ? (lane >> 3) : 0;                         // tile row of output S0
+    const int zs = TAIL ? row0 - (kG - 1) : 0;                       // z shift of this lane's window
+    const bool lane_on = TAIL ? true : x < px;
+    const bool col_real = x < W;
+    const int xl = col_real ? x : W - 1;    // pitch lanes re-read the last column
+    const InT* in = vol + bd.src_off + (int64_t)y * stride_y;
+    const unsigned zstride_b = (unsigned)(stride_z * (int64_t)sizeof(InT));    // < 4 GiB / 8 (checked by the launcher)
+    // interior prefetches address plane (zf + zs + j) as descriptor(zf - S0) + voff + j * zstride_b
+    const unsigned voff0 = (unsigned)(xl * stride_x) * (unsigned)sizeof(InT);
+    const unsigned voff = voff0 + (unsigned)(zs + S0) * zstride_b;
+    const int qmain = pad2(col_real ? xg::S + x : xg::S + R + x);     // tile position of this lane's column
+    const int qleft = pad2(xg::S - 1 - x);
+    const int qright = pad2(xg::S + W + (W - 1 - x));
+    // active window: inputs z0-R .. z0+R+G-1 of the current group; pf[u]: the 8 planes that enter the
+    // window after group g (g % kPF == u), loaded kPF groups ahead.  With one workgroup per CU nothing
+    // else hides HBM latency, and a load must never be moved while in flight -- hence a ring of
+    // register groups with static indices (the group loop is unrolled by kPF) instead of a longer
+    // shifted tail.
+    float w[NA];
+    float pf[kPF][kG];
+    // a load of one (possibly reflected) plane.  Marching waves: the plane is wave-uniform and goes into the
+    // descriptor.  Tail wave: it differs per lane, and a per-lane descriptor would cost a waterfall loop per
+    // load -- so the descriptor sits at a uniform plane `pb` at most 64 planes below and the rest is offset.
+    auto load_plane = [&](int plane, int pb) __attribute__((always_inline)) {
+        if constexpr (TAIL)
+            return io::load(make_rsrc(in + (int64_t)pb * stride_z), voff0 + (unsigned)(plane - pb) * zstride_b);
+        else
+            return io::load(make_rsrc(in + (int64_t)plane * stride_z), voff0);
+    };
+    const int pb_end = nz > 64 ? nz - 64 : 0;       // base plane for the loads near the far face
+    if (lane_on) {
+#pragma unroll
+        for (int i = I0; i < NA; ++i)
+            w[i] = io::act(load_plane(reflect_clamped(i - R + zs, nz), 0));
+#pragma unroll
+        for (int u = 0; u < kPF; ++u)
+#pragma unroll
+            for (int j = 0; j < kG; ++j)
+                pf[u][j] = load_plane(reflect_clamped(u * kG + R + kG + j + zs, nz), 0);
+    }
+#ifdef ZX2_PROFILE
+    long long tw = 0, t_start = wall_clock64(), tb;
+#endif
+#pragma unroll 1
+    for (int g0 = 0; g0 <= ngroups; g0 += kPF) {
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+            const int g = g0 + u;
+            if (g > ngroups) break;
+#ifdef ZX2_PROFILE
+            tb = wall_clock64();
+#endif
+            if (g < ngroups && lane_on) {
+                v2f* rows = tile + (g & 1) * (kG * PW) + row0 * PW;
+                const int z0 = g * kG;
+                v2f av[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const float c = w[R + S0 + s];
+                    v2f a = (v2f){c, c} * T.zw[0];
+#ifndef ZX2_SKIP_PROD
+#pragma unroll
+                    for (int k = 1; k <= R; ++k) {
+                        const float p = w[R + S0 + s - k] + w[R + S0 + s + k];
+                        a = __builtin_elementwise_fma((v2f){p, p}, T.zw[k], a);
+                    }
+#endif
+                    if (!TAIL || col_real) rows[s * PW + qmain] = a;   // (pitch lanes write past the right halo: no branch)
+                    av[s] = a;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // reflect halos of the rows, once per group: x = -1-t <- x = t ; x = W+j <- x = W-1-j
+                if (x < R) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) rows[s * PW + qleft] = av[s];
+                }
+                if (x >= W - R && col_real) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) rows[s * PW + qright] = av[s];
+                }
+                // shift the active window by 8 (ascending, in place), take the planes loaded kPF groups
+                // ago and reload their registers for group g + kPF
+#pragma unroll
+                for (int i = I0; i < 2 * R; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(w[i]) : "v"(w[i + kG]));
+                const int zf = z0 + (kPF + 1) * kG + R;      // first plane of the group being prefetched
+                if (zf + kG <= nz) {
+                    // interior: one descriptor per group, the plane inside the group is a scalar offset
+                    const rsrc_t rs = make_rsrc(in + (int64_t)(zf - S0) * stride_z);
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) {
+                        w[2 * R + j] = io::act(pf[u][j]);
+                        pf[u][j] = io::load(rs, voff, (unsigned)j * zstride_b);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < kG; ++j) {
+                        w[2 * R + j] = io::act(pf[u][j]);
+                        pf[u][j] = load_plane(reflect_clamped(zf + j + zs, nz), pb_end);
+                    }
+                }
+            }
+#ifdef ZX2_PROFILE
+            tw += wall_clock64() - tb;
+#endif
+            __syncthreads();
+        }
+    }
+#ifdef ZX2_PROFILE
+    if (!TAIL && xlane == 0) { gp[sbase + 0] = (float)tw; gp[sbase + 2] = (float)(wall_clock64() - t_start); }
+    if (TAIL && lane == 0) gp[sbase + 4] = (float)tw;
+#endif
+}
+
+// Wave roles.  A workgroup is one block row: ceil(px / 64) producer waves and 9 consumer waves.  The
+// hardware deals the waves of a workgroup to the 4 SIMDs of the CU round-robin (wave i -> SIMD i % 4) and
+// the kernel is bound by VALU issue on the most loaded SIMD, so in the common geometry (14 waves, tail
+// producer: 4 marching P at ~420 instructions per group, 1 tail T at ~100, 9 consumers C at ~300) the roles
+// are dealt so that the SIMDs get  P T C C | C C C C | P P C | P C C  (1120 / 1200 / 1140 / 1020)
+// instead of  P T C C | P C C C | P C C | P C C  (1120 / 1320 / 1020 / 1020).
+constexpr unsigned long long kRole14 = 0xAAA8908ull;            // 2 bits per wave: 0 = P, 1 = T, 2 = C
+constexpr unsigned long long kOrd14 = 0x87654323102100ull;     // 4 bits per wave: ordinal within the role
+
 template <int R, typename InT>
 __global__ void __launch_bounds__(kMaxPx + kCons)
 zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stride_x,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
            float* __restrict__ gp, float* __restrict__ gq, mmx_taps_zx2 T)
 {
-    using io = vox<InT>;
     using xg = xgeom2<R>;
-    constexpr int NA = 2 * R + kG;       // producer register window: inputs z0-R .. z0+R+G-1
     constexpr int PW = xg::PITCH;
     extern __shared__ v2f tile[];        // [2][kG][PW]
     const mmx_block bd = blocks[blockIdx.y];
     const int y = blockIdx.x;
     if (y >= bd.ny) return;              // whole workgroup
     const int W = bd.nx, px = bd.px, nz = bd.nz;
-    const int np = (px + 63) & ~63;      // producer lanes (whole waves)
+    const int npw = (px + 63) >> 6;      // producer waves
     const int t = threadIdx.x;
+    const int wv = t >> 6;
+    const int nwaves = (int)blockDim.x >> 6;
     const int ngroups = (nz + kG - 1) / kG;
     const int64_t sbase = (int64_t)bd.slot * slot_elems + (int64_t)y * px;
     const int64_t plane = (int64_t)bd.ny * px;
+    // tail producer: the last producer wave would hold <= 8 real columns
+#ifdef ZX2_NO_TAIL
+    const bool tailmode = false;
+#else
+    const bool tailmode = (W & 63) != 0 && (W & 63) <= 8 && ((W + 63) >> 6) == npw;
+#endif
+    int role, ord;
+#ifdef ZX2_NO_ROLEMAP
+    if (false) {
+#else
+    if (tailmode && npw == 5 && nwaves == 14) {
+#endif
+        role = (int)((kRole14 >> (2 * wv)) & 3);
+        ord = (int)((kOrd14 >> (4 * wv)) & 15);
+    } else {
+        role = wv < npw ? (tailmode && wv == npw - 1 ? 1 : 0) : 2;
+        ord = wv < npw ? wv : wv - npw;
+    }
 
 #ifdef ZX2_PROFILE
     if ((t & 63) == 0) {   // which SIMD hosts this wave (HW_ID bits 5:4)
@@ -113,108 +274,13 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
         gp[sbase + 8 + (t >> 6)] = (float)((hw >> 4) & 3);
     }
 #endif
-    if (t < np) {
-        // ------------------------------------------------------------------ producers: z march
-        const bool lane_on = t < px;
-        const int xl = t < W ? t : W - 1;    // pitch lanes re-read the last column
-        const InT* in = vol + bd.src_off + (int64_t)y * stride_y;
-        const unsigned voff = (unsigned)(xl * stride_x) * (unsigned)sizeof(InT);
-        const unsigned zstride_b = (unsigned)(stride_z * (int64_t)sizeof(InT));    // < 4 GiB (checked by the launcher)
-        const int qmain = pad2(t < W ? xg::S + t : xg::S + R + t);     // tile position of this lane's column
-        const int qleft = pad2(xg::S - 1 - t);
-        const int qright = pad2(xg::S + W + (W - 1 - t));
-        // active window: inputs z0-R .. z0+R+G-1 of the current group; pf[u]: the 8 planes that enter the
-        // window after group g (g % kPF == u), loaded kPF groups ahead.  With one workgroup per CU nothing
-        // else hides HBM latency, and a load must never be moved while in flight -- hence a ring of
-        // register groups with static indices (the group loop is unrolled by kPF) instead of a longer
-        // shifted tail.
-        float w[NA];
-        float pf[kPF][kG];
-        if (lane_on) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-                w[i] = io::act(io::load(make_rsrc(in + (int64_t)reflect_clamped(i - R, nz) * stride_z), voff));
-#pragma unroll
-            for (int u = 0; u < kPF; ++u)
-#pragma unroll
-                for (int j = 0; j < kG; ++j)
-                    pf[u][j] = io::load(
-                        make_rsrc(in + (int64_t)reflect_clamped(u * kG + R + kG + j, nz) * stride_z), voff);
-        }
-#ifdef ZX2_PROFILE
-        long long tw = 0, t_start = wall_clock64(), tb;
-#endif
-#pragma unroll 1
-        for (int g0 = 0; g0 <= ngroups; g0 += kPF) {
-#pragma unroll
-            for (int u = 0; u < kPF; ++u) {
-                const int g = g0 + u;
-                if (g > ngroups) break;
-#ifdef ZX2_PROFILE
-                tb = wall_clock64();
-#endif
-                if (g < ngroups && lane_on) {
-                    v2f* rows = tile + (g & 1) * (kG * PW);
-                    const int z0 = g * kG;
-                    v2f av[kG];
-#pragma unroll
-                    for (int s = 0; s < kG; ++s) {
-                        const float c = w[R + s];
-                        v2f a = (v2f){c, c} * T.zw[0];
-#ifndef ZX2_SKIP_PROD
-#pragma unroll
-                        for (int k = 1; k <= R; ++k) {
-                            const float p = w[R + s - k] + w[R + s + k];
-                            a = __builtin_elementwise_fma((v2f){p, p}, T.zw[k], a);
-                        }
-#endif
-                        rows[s * PW + qmain] = a;        // (pitch lanes write past the right halo: no branch)
-                        av[s] = a;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    // reflect halos of the 8 rows, once per group: x = -1-t <- x = t ; x = W+j <- x = W-1-j
-                    if (t < R) {
-#pragma unroll
-                        for (int s = 0; s < kG; ++s) rows[s * PW + qleft] = av[s];
-                    }
-                    if (t >= W - R && t < W) {
-#pragma unroll
-                        for (int s = 0; s < kG; ++s) rows[s * PW + qright] = av[s];
-                    }
-                    // shift the active window by 8 (ascending, in place), take the planes loaded kPF groups
-                    // ago and reload their registers for group g + kPF
-#pragma unroll
-                    for (int i = 0; i < 2 * R; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(w[i]) : "v"(w[i + kG]));
-                    const int zf = z0 + (kPF + 1) * kG + R;      // first plane of the group being prefetched
-                    if (zf + kG <= nz) {
-                        // interior: one descriptor per group, the plane inside the group is a scalar offset
-                        const rsrc_t rs = make_rsrc(in + (int64_t)zf * stride_z);
-#pragma unroll
-                        for (int j = 0; j < kG; ++j) {
-                            w[2 * R + j] = io::act(pf[u][j]);
-                            pf[u][j] = io::load(rs, voff, (unsigned)j * zstride_b);
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < kG; ++j) {
-                            w[2 * R + j] = io::act(pf[u][j]);
-                            pf[u][j] = io::load(make_rsrc(in + (int64_t)reflect_clamped(zf + j, nz) * stride_z), voff);
-                        }
-                    }
-                }
-#ifdef ZX2_PROFILE
-                tw += wall_clock64() - tb;
-#endif
-                __syncthreads();
-            }
-        }
-#ifdef ZX2_PROFILE
-        if (t == 0) { gp[sbase + 0] = (float)tw; gp[sbase + 2] = (float)(wall_clock64() - t_start); }
-#endif
+    if (role == 0) {
+        zx2_producer<R, InT, false>(vol, stride_z, stride_y, stride_x, bd, y, ord * 64 + (t & 63), tile, T, gp, sbase);
+    } else if (role == 1) {
+        zx2_producer<R, InT, true>(vol, stride_z, stride_y, stride_x, bd, y, 0, tile, T, gp, sbase);
     } else {
         // ------------------------------------------------------------------ consumers: x pass on the tile
-        const int ct = t - np;
-        const int nct = (int)blockDim.x - np;
+        const int nct = (nwaves - npw) * 64;
         const int CH = px / kT;              // chunks per row
         const int nitems = kG * CH;
         const float inv_ch = 1.0f / (float)CH;
@@ -230,7 +296,7 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
             if (g >= 1) {
                 const v2f* rows = tile + ((g - 1) & 1) * (kG * PW);
                 const int z0 = (g - 1) * kG;
-                for (int first = (ct & ~63); first < nitems; first += nct) {     // one round per wave for px = 288
+                for (int first = ord * 64; first < nitems; first += nct) {     // one round per wave for px = 288
                     const int item = first + lane;
                     const int r = (int)(((float)item + 0.5f) * inv_ch);     // item < 2^12: exact
                     const int c = item - r * CH;
@@ -273,8 +339,8 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
             __syncthreads();
         }
 #ifdef ZX2_PROFILE
-        if (ct == 0) gp[sbase + 1] = (float)tw;
-        if (ct == nct - 64) gp[sbase + 3] = (float)tw;
+        if (ord == 0 && lane == 0) gp[sbase + 1] = (float)tw;
+        if (ord == nwaves - npw - 1 && lane == 0) gp[sbase + 3] = (float)tw;
 #endif
     }
 }

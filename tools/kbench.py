@@ -90,6 +90,6 @@ if os.environ.get("ZX2_PROFILE"):
     simd = P[:, :e * px].reshape(nb, e, px)[:, :, 8:24].reshape(-1, 16)
     import collections
     print("wave -> SIMD maps seen:", collections.Counter(tuple(int(v) for v in r[:14]) for r in simd).most_common(4))
-    rows = P[:, :e * px].reshape(nb, e, px)[:, :, :4].reshape(-1, 4)
-    print("R=%d ticks per row-WG (100 MHz): producer busy %.0f, consumer busy %.0f / %.0f, total %.0f" % (
-        R, rows[:, 0].mean(), rows[:, 1].mean(), rows[:, 3].mean(), rows[:, 2].mean()))
+    rows = P[:, :e * px].reshape(nb, e, px)[:, :, :5].reshape(-1, 5)
+    print("R=%d ticks per row-WG (100 MHz): producer busy %.0f, tail producer busy %.0f, consumer busy %.0f / %.0f, total %.0f" % (
+        R, rows[:, 0].mean(), rows[:, 4].mean(), rows[:, 1].mean(), rows[:, 3].mean(), rows[:, 2].mean()))
