@@ -145,7 +145,7 @@ def main():
 
     from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
-    from magellanmapper_amd import config, dist, stack_detect, synth
+    from magellanmapper_amd import config, detector, dist, stack_detect, synth
 
     config.resolutions = RESOLUTIONS
     config.filename = "bench"
@@ -190,9 +190,10 @@ def main():
             pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
                 dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices, blocks.sub_rois_offsets,
                 [0], blocks.overlap_padding)
-            if pruned is not None:
-                pruned[:, 0:3] = pruned[:, 7:10]
-                final = pruned[:, [0, 1, 2, 3, 4, 5, 6, 10]]
+            if pruned is not None:      # the table's final form (reference stack_detect.py:458-467)
+                bb = detector.Blobs(pruned)
+                bb.replace_rel_with_abs_blob_coords(pruned)
+                final = bb.remove_abs_blob_coords(True)
         return final, st
 
     # monkey: budget for the workspace
@@ -210,8 +211,9 @@ def main():
         pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
             sdvol, seg, sblocks.overlap, sblocks.tol, sblocks.sub_roi_slices, sblocks.sub_rois_offsets,
             [0], sblocks.overlap_padding)
-        pruned[:, 0:3] = pruned[:, 7:10]
-        gpu_final = pruned[:, [0, 1, 2, 3, 4, 5, 6, 10]]
+        bb = detector.Blobs(pruned)
+        bb.replace_rel_with_abs_blob_coords(pruned)
+        gpu_final = bb.remove_abs_blob_coords(True)
         parity = bool(cpu_final is not None and gpu_final.shape == cpu_final.shape and
                       np.array_equal(canon(gpu_final), canon(cpu_final)))
         del sdvol

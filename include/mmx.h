@@ -349,6 +349,12 @@ int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
 int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int64_t n,
                        int64_t n_cols, const double* abs_zyx, const int32_t abs_cols[3], double* out);
 
+/* out[i][dst_col0 + j] = table[i][src_cols[j]], i < n, j < n_map (<= 64), threaded.  The column shuffles that
+ * end a stack detection (reference magmap/cv/stack_detect.py:461-467 -> detector.py
+ * replace_rel_with_abs_blob_coords / remove_abs_blob_coords).  `out` may alias `table`. */
+int mmx_host_map_columns(const double* table, int64_t ld, int64_t n, const int32_t* src_cols,
+                         int32_t n_map, double* out, int64_t out_ld, int32_t dst_col0);
+
 /* PMC calibration (tools/pmc_calib.py): one streaming launch over n_elems elements with a known
  * byte count.  kind 0: float copy, 4 B per lane; 1: float copy, 16 B per lane; 2: uint16 read. */
 int mmx_calib_stream(int kind, const void* d_in, void* d_out, int64_t n_elems, void* stream);

@@ -285,6 +285,29 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
     return MMX_OK;
 }
 
+// out[i][dst_col0 + j] = table[i][src_cols[j]] for every row: the column shuffles that end a stack
+// detection (Blobs.replace_rel_with_abs_blob_coords: out = table, columns 7..9 -> 0..2;
+// Blobs.remove_abs_blob_coords: the kept columns into a new table).  `out` may be `table` itself (a row is
+// read completely before it is written).
+extern "C" int mmx_host_map_columns(const double* table, int64_t ld, int64_t n, const int32_t* src_cols,
+                                    int32_t n_map, double* out, int64_t out_ld, int32_t dst_col0)
+{
+    if (!table || !out || !src_cols || n < 0 || n_map < 1 || n_map > 64 || dst_col0 < 0 || dst_col0 + n_map > out_ld)
+        return MMX_ERR_ARG;
+    for (int j = 0; j < n_map; ++j)
+        if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        double tmp[64];
+        for (int64_t i = lo; i < hi; ++i) {
+            const double* r = table + i * ld;
+            for (int j = 0; j < n_map; ++j) tmp[j] = r[src_cols[j]];
+            std::memcpy(out + i * out_ld + dst_col0, tmp, (size_t)n_map * sizeof(double));
+        }
+    });
+    return MMX_OK;
+}
+
 // Rows `rows[0..n)` of a float64 table (row pitch `ld`), first `n_cols` columns, with three of the
 // columns replaced from a compact (n_table, 3) array -- the output of prune_blobs_mp
 // (`merged[rows][:, :-3]` with the updated absolute coordinates put back).

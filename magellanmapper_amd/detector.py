@@ -17,6 +17,7 @@ Public surface kept from the reference (magmap/cv/detector.py):
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 from enum import Enum
@@ -32,6 +33,31 @@ CONFIRMATION: Dict[int, str] = {-1: "unverified", 0: "no", 1: "yes", 2: "maybe"}
 OVERLAP_FACTOR: int = 5
 
 _logger = config.logger.getChild(__name__)
+
+
+def _map_columns(table: np.ndarray, src_cols, out: Optional[np.ndarray] = None, dst0: int = 0) -> np.ndarray:
+    """``out[:, dst0:dst0 + len(src_cols)] = table[:, src_cols]`` (``out`` = a new table by default).
+
+    Large float64 tables (the whole-stack table: 10^5..10^6 rows) go through the threaded native copy
+    (``mmx_host_map_columns``); anything else through NumPy.
+    """
+    src = [int(c) for c in src_cols]
+
+    def plain(a):
+        return (isinstance(a, np.ndarray) and a.ndim == 2 and a.dtype == np.float64 and a.strides[1] == 8
+                and a.strides[0] % 8 == 0 and a.strides[0] >= 8 * a.shape[1])
+    if out is None:
+        out = np.empty((len(table), len(src)), dtype=table.dtype)
+        dst0 = 0
+    if len(table) >= 4096 and plain(table) and plain(out) and 1 <= len(src) <= 64:
+        from . import _native as nat
+        lib = nat.lib()
+        cols = (ctypes.c_int32 * len(src))(*src)
+        nat.check(lib.mmx_host_map_columns(table.ctypes.data, table.strides[0] // 8, len(table), cols, len(src),
+                                           out.ctypes.data, out.strides[0] // 8, int(dst0)), "mmx_host_map_columns")
+    else:
+        out[:, dst0:dst0 + len(src)] = table[:, src]
+    return out
 
 
 class Blobs:
@@ -225,12 +251,16 @@ class Blobs:
         drop = set(Blobs._get_abs_inds())
         keep = [i for i in candidates if i not in drop]
         self.cols = [self.cols[i] for i in keep]
-        self.blobs = self.blobs[:, keep]
+        self.blobs = _map_columns(self.blobs, keep)
         return self.blobs
 
     @classmethod
     def replace_rel_with_abs_blob_coords(cls, blobs: np.ndarray) -> np.ndarray:
-        blobs[:, cls._get_rel_inds()] = blobs[:, cls._get_abs_inds()]
+        rel, ab = list(cls._get_rel_inds()), list(cls._get_abs_inds())
+        if rel == list(range(rel[0], rel[0] + len(rel))):
+            _map_columns(blobs, ab, out=blobs, dst0=rel[0])
+        else:
+            blobs[:, rel] = blobs[:, ab]
         return blobs
 
     @classmethod

@@ -564,3 +564,31 @@ def test_blob_log_randomised_parameters_match_oracle(gpu):
         np.testing.assert_array_equal(got, want, err_msg=str((trial, shape, lo, hi, ns, thr, ov)))
         total += len(want)
     assert total > 100
+
+
+def test_tail_column_widths_match_oracle(gpu):
+    """Block widths just past a multiple of 64 (256 + the 5 overlap columns of the stock block size and
+    its neighbours): the fused Z+X kernel gives the last <= 8 columns to its tail wave, and with 257..264
+    columns deals the wave roles over the SIMDs (mmx_fused2.hip).  End to end through the NMS bit masks of
+    the Y pass and the sparse NMS kernel: the same rows in the same order as the oracle."""
+    from magellanmapper_amd import blob_log as bl, synth
+    from oracle import blob_log_oracle as blo
+    rng = np.random.default_rng(77)
+    total = 0
+    for width in (257, 261, 264, 265, 256, 65, 72, 129, 193, 200):
+        shape = (int(rng.integers(26, 40)), int(rng.integers(26, 44)), width)
+        vol = synth.make_volume(int(rng.integers(1 << 30)), shape, 60, blob_sigma=float(rng.uniform(1.5, 3.5)))
+        if width % 2:
+            vol = (vol >> 8).astype(np.uint8)
+        lo = float(rng.uniform(1.0, 3.0))
+        hi = lo + float(rng.uniform(0.5, 2.5))
+        ns = int(rng.integers(2, 6))
+        got = bl.blob_log(vol, lo, hi, ns, 0.05, 0.5)
+        want = blo.blob_log(vol, lo, hi, ns, 0.05, 0.5)
+        np.testing.assert_array_equal(got, want, err_msg=str((shape, lo, hi, ns)))
+        total += len(want)
+        space = bl.ScaleSpace.make(lo, hi, ns)
+        cube = bl.log_cube_blocks(bl.DeviceVolume(vol), 0, [(0, 0, 0)], [shape], space)[0]
+        ref = blo.log_cube(blo.img_as_float(vol), np.stack([space.sigmas] * 3, axis=1))
+        assert np.abs(cube - ref).max() < 5e-6, (shape, lo, hi)
+    assert total > 200

@@ -483,3 +483,24 @@ def test_zoom_axis_tables_reproduce_scipy_zoom():
     with pytest.raises(NotImplementedError):          # anti-aliasing would be active
         rs.set_blocks([(0, 0, 0)], [(20, 8, 8)], [(14, 8, 8)])
     config.resolutions = None
+
+
+def test_map_columns_native_matches_numpy():
+    """Blobs.replace_rel_with_abs_blob_coords / remove_abs_blob_coords on a whole-stack-sized table
+    (threaded native column copy, include/mmx.h: mmx_host_map_columns) against the plain NumPy form."""
+    from magellanmapper_amd import detector
+    rng = np.random.default_rng(5)
+    for rows, width in ((20000, 11), (9000, 13), (100, 11)):
+        a = rng.random((rows, width + 2))[:, :width] if width == 13 else rng.random((rows, width))
+        b = a.copy()
+        bb = detector.Blobs(a)
+        bb.replace_rel_with_abs_blob_coords(a)
+        out = bb.remove_abs_blob_coords(True)
+        b[:, 0:3] = b[:, 7:10]
+        assert np.array_equal(a, b)
+        assert np.array_equal(out, b[:, [0, 1, 2, 3, 4, 5, 6, 10]])
+        assert bb.cols == ["z", "y", "x", "radius", "confirmed", "truth", "channel", "region"]
+    lib = _native.lib()
+    cols = (ctypes.c_int32 * 2)(0, 99)
+    t = np.zeros((4, 4))
+    assert lib.mmx_host_map_columns(t.ctypes.data, 4, 4, cols, 2, t.ctypes.data, 4, 0) == 1     # bad column

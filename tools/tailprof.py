@@ -28,6 +28,12 @@ for rep in range(3):
     t1 = time.perf_counter(); torch.cuda.synchronize(); t1s = time.perf_counter()
     out = stack_detect.StackPruner.prune_blobs_mp(dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices, blocks.sub_rois_offsets, [0], blocks.overlap_padding)
     t2 = time.perf_counter()
+    pruned = out[0]
+    pruned[:, 0:3] = pruned[:, 7:10]
+    t3 = time.perf_counter()
+    final = pruned[:, [0, 1, 2, 3, 4, 5, 6, 10]]
+    t4 = time.perf_counter()
+print("final formatting (bench.py one_step): rel<-abs %.2f ms, column selection %.2f ms" % ((t3 - t2) * 1e3, (t4 - t3) * 1e3))
 print("detect %.1f ms (gpu idle wait %.2f) prune %.1f ms total %.1f" % ((t1 - t0) * 1e3, (t1s - t1) * 1e3, (t2 - t1s) * 1e3, (t2 - t0) * 1e3))
 for n, a, b in marks:
     print("  %-12s start %7.1f  dur %6.1f" % (n, (a - t0) * 1e3, (b - a) * 1e3))
