@@ -25,6 +25,8 @@ def short(name):
         return "zxpass"
     if "y2_kernel" in name:
         return "y2pass"
+    if "peaks_sparse_kernel" in name:
+        return "peaks"
     m = re.search(r"(zpass|ypass|xpass|peaks|rescore|overlap_pairs|close_pairs|gen_[xyz]|calib_[a-z0-9_]+)_?kernel|(calib_[a-z0-9_]+)", name)
     if not m:
         return None
