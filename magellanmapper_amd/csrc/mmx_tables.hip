@@ -360,13 +360,26 @@ minmax_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
 {
     __shared__ double s_lo[MMX_WG / 64], s_hi[MMX_WG / 64];
     const mmx_block bd = blocks[blockIdx.y];
-    const int64_t n = (int64_t)bd.nz * bd.ny * bd.nx;
+    const int rows = bd.nz * bd.ny;
     double lo = __builtin_inf(), hi = -__builtin_inf();
-    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * MMX_WG) {
-        const int64_t t = i / bd.nx, x = i - t * bd.nx, z = t / bd.ny, y = t - z * bd.ny;
-        const double v = (double)vol[bd.src_off + z * sz + y * sy + x * sx];
-        lo = fmin(lo, v);
-        hi = fmax(hi, v);
+    // one wave per (z, y) row, lanes along x, two rows in flight: no per-voxel index arithmetic
+    const int lane = threadIdx.x & 63;
+    constexpr int WPG = MMX_WG / 64;
+    const int stride = (int)gridDim.x * WPG;
+    for (int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPG + ((int)threadIdx.x >> 6)); row < rows;
+         row += 2 * stride) {
+        const int row2 = row + stride < rows ? row + stride : row;
+        const int z = row / bd.ny, y = row - z * bd.ny;
+        const int z2 = row2 / bd.ny, y2 = row2 - z2 * bd.ny;
+        const InT* p = vol + bd.src_off + z * sz + y * sy;
+        const InT* p2 = vol + bd.src_off + z2 * sz + y2 * sy;
+        for (int x = lane; x < bd.nx; x += 128) {
+            const int xb = x + 64 < bd.nx ? x + 64 : x;
+            const double a = (double)p[x * sx], b = (double)p[xb * sx];
+            const double c = (double)p2[x * sx], d = (double)p2[xb * sx];
+            lo = fmin(fmin(lo, fmin(a, b)), fmin(c, d));
+            hi = fmax(fmax(hi, fmax(a, b)), fmax(c, d));
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) { lo = fmin(lo, __shfl_down(lo, d)); hi = fmax(hi, __shfl_down(hi, d)); }
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
@@ -378,6 +391,9 @@ minmax_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     }
 }
 
+// One wave per output row (z, y), lanes along x: the z / y table entries are wave-uniform (scalar loads),
+// the x entries one 8-byte + one 16-byte load per lane, the eight samples four coalesced row reads -- no
+// per-voxel index arithmetic.  The accumulation order is SciPy's (NI_ZoomShift: z outermost, x fastest).
 template <typename InT, typename OutT>
 __global__ void __launch_bounds__(MMX_WG)
 resize_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
@@ -386,34 +402,98 @@ resize_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
               int64_t dst_slot, int64_t dst_sy, int64_t dst_sz, OutT* __restrict__ out, float* __restrict__ out32)
 {
     const mmx_resize_block bd = blocks[blockIdx.y];
-    const int64_t n = (int64_t)bd.out_nz * bd.out_ny * bd.out_nx;
+    const int rows = bd.out_nz * bd.out_ny;
     const double lo = mm[2 * (int64_t)bd.slot], hi = mm[2 * (int64_t)bd.slot + 1];
     const InT* src = vol + bd.src_off;
-    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * MMX_WG) {
-        const int64_t t = i / bd.out_nx, x = i - t * bd.out_nx, z = t / bd.out_ny, y = t - z * bd.out_ny;
-        const int32_t* iz = idx + 2 * ((int64_t)bd.tz + z);
-        const int32_t* iy = idx + 2 * ((int64_t)bd.ty + y);
-        const int32_t* ix = idx + 2 * ((int64_t)bd.tx + x);
-        const double* wz = wts + 2 * ((int64_t)bd.tz + z);
-        const double* wy = wts + 2 * ((int64_t)bd.ty + y);
-        const double* wx = wts + 2 * ((int64_t)bd.tx + x);
+    const int lane = threadIdx.x & 63;
+    constexpr int WPG = MMX_WG / 64;
+    const int2* ixt = reinterpret_cast<const int2*>(idx) + bd.tx;
+    const double2* wxt = reinterpret_cast<const double2*>(wts) + bd.tx;
+    // the x table entries of this lane's columns stay in registers across the rows of the wave (rows up to
+    // kXC * 64 voxels wide; wider ones reload them per row)
+    constexpr int kXC = 6;
+    const int nxc = (bd.out_nx + 63) >> 6;
+    int2 ixr[kXC];
+    double2 wxr[kXC];
+#pragma unroll
+    for (int c = 0; c < kXC; ++c) {
+        const int x = lane + 64 * c;
+        const int xc = x < bd.out_nx ? x : bd.out_nx - 1;
+        ixr[c] = ixt[xc];
+        wxr[c] = wxt[xc];
+    }
+    // A sample whose weight is exactly 0 (an axis that keeps its length: frac = 0 everywhere) adds +-0 to a sum
+    // that starts at +0: skipping it leaves every bit of the result unchanged for finite voxels, and an
+    // unchanged axis is the common case (light-sheet stacks are rescaled along z only).  z2 / y2 / x2: the
+    // second sample of that axis takes part (wave-uniform).
+    bool x2 = false;
+#pragma unroll
+    for (int c = 0; c < kXC; ++c) x2 = x2 || wxr[c].y != 0.0;
+    x2 = __any(x2) || nxc > kXC;
+    auto one = [&](const InT* p00, const InT* p01, const InT* p10, const InT* p11, double2 wz, double2 wy,
+                   bool z2, bool y2, int2 ix, double2 wx) __attribute__((always_inline)) {
+        const int64_t o0 = ix.x * sx, o1 = ix.y * sx;
         double acc = 0.0;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double v = (double)src[iz[a] * sz + iy[b] * sy + ix[c] * sx];
-                    v = v * wz[a];
-                    v = v * wy[b];
-                    v = v * wx[c];
-                    acc += v;
+        auto plane = [&](const InT* pa, const InT* pb, double w) __attribute__((always_inline)) {
+            const double va0 = (double)pa[o0];
+            if (x2) {
+                const double va1 = (double)pa[o1];
+                acc += ((va0 * w) * wy.x) * wx.x;
+                acc += ((va1 * w) * wy.x) * wx.y;
+            } else {
+                acc += ((va0 * w) * wy.x) * wx.x;
+            }
+            if (y2) {
+                const double vb0 = (double)pb[o0];
+                if (x2) {
+                    const double vb1 = (double)pb[o1];
+                    acc += ((vb0 * w) * wy.y) * wx.x;
+                    acc += ((vb1 * w) * wy.y) * wx.y;
+                } else {
+                    acc += ((vb0 * w) * wy.y) * wx.x;
                 }
-        acc = fmin(fmax(acc, lo), hi);                    // np.clip(out, image.min(), image.max())
-        const int64_t d = (int64_t)bd.slot * dst_slot + z * dst_sz + y * dst_sy + x;
-        out[d] = (OutT)acc;                               // .astype(dtype): truncation for integers
-        if (out32) out32[d] = (float)acc;
+            }
+        };
+        plane(p00, p01, wz.x);
+        if (z2) plane(p10, p11, wz.y);
+        return fmin(fmax(acc, lo), hi);                       // np.clip(out, image.min(), image.max())
+    };
+    for (int row = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WPG + ((int)threadIdx.x >> 6)); row < rows;
+         row += (int)gridDim.x * WPG) {
+        const int z = row / bd.out_ny, y = row - z * bd.out_ny;
+        const int2 iz = reinterpret_cast<const int2*>(idx)[bd.tz + z];
+        const int2 iy = reinterpret_cast<const int2*>(idx)[bd.ty + y];
+        const double2 wz = reinterpret_cast<const double2*>(wts)[bd.tz + z];
+        const double2 wy = reinterpret_cast<const double2*>(wts)[bd.ty + y];
+        const InT* p00 = src + iz.x * sz + iy.x * sy;
+        const InT* p01 = src + iz.x * sz + iy.y * sy;
+        const InT* p10 = src + iz.y * sz + iy.x * sy;
+        const InT* p11 = src + iz.y * sz + iy.y * sy;
+        const int64_t drow = (int64_t)bd.slot * dst_slot + (int64_t)z * dst_sz + (int64_t)y * dst_sy;
+        const bool z2 = wz.y != 0.0, y2 = wy.y != 0.0;
+        if (nxc <= kXC) {
+#pragma unroll
+            for (int c = 0; c < kXC; c += 2) {
+                if (c >= nxc) break;                          // uniform
+                const int xa = lane + 64 * c, xb = xa + 64;
+                const double ra = one(p00, p01, p10, p11, wz, wy, z2, y2, ixr[c], wxr[c]);
+                const double rb = one(p00, p01, p10, p11, wz, wy, z2, y2, ixr[c + 1], wxr[c + 1]);
+                if (xa < bd.out_nx) {
+                    out[drow + xa] = (OutT)ra;                // .astype(dtype): truncation for integers
+                    if (out32) out32[drow + xa] = (float)ra;
+                }
+                if (xb < bd.out_nx) {
+                    out[drow + xb] = (OutT)rb;
+                    if (out32) out32[drow + xb] = (float)rb;
+                }
+            }
+        } else {
+            for (int x = lane; x < bd.out_nx; x += 64) {
+                const double r = one(p00, p01, p10, p11, wz, wy, z2, y2, ixt[x], wxt[x]);
+                out[drow + x] = (OutT)r;
+                if (out32) out32[drow + x] = (float)r;
+            }
+        }
     }
 }
 }  // namespace
@@ -422,11 +502,13 @@ extern "C" int mmx_minmax_batch(const mmx_volume* vol, const mmx_block* d_blocks
                                 int n_blocks, double* d_minmax, void* stream)
 {
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || !d_minmax) return MMX_ERR_ARG;
-    int64_t max_vox = 1;
+    int64_t max_rows = 1;
     for (int i = 0; i < n_blocks; ++i)
-        max_vox = std::max<int64_t>(max_vox, (int64_t)h_blocks[i].nz * h_blocks[i].ny * h_blocks[i].nx);
+        max_rows = std::max<int64_t>(max_rows, (int64_t)h_blocks[i].nz * h_blocks[i].ny);
+    if (max_rows >= (int64_t(1) << 30)) return MMX_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)std::min<int64_t>((max_vox + MMX_WG * 16 - 1) / (MMX_WG * 16), 4096), (unsigned)n_blocks);
+    // 16 rows per wave: few enough atomics, enough workgroups (4 waves each) to fill the chip
+    dim3 grid((unsigned)std::min<int64_t>((max_rows + 63) / 64, 4096), (unsigned)n_blocks);
     mmx_timed_scope ts(MMX_K_GENERIC, s);
 #define MMX_MM_LAUNCH(T)                                                                                  \
     hipLaunchKernelGGL(minmax_kernel<T>, grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z,   \
@@ -451,15 +533,17 @@ extern "C" int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || !d_index || !d_weight ||
         !d_minmax || !d_out)
         return MMX_ERR_ARG;
-    int64_t max_vox = 1;
+    int64_t max_rows = 1;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_resize_block& b = h_blocks[i];
         if (b.in_nz < 2 || b.in_ny < 2 || b.in_nx < 2 || b.out_nz < 1 || b.out_ny < 1 || b.out_nx < 1)
             return MMX_ERR_UNSUPPORTED;        // unit-thick blocks use scikit-image's 'edge' mode: not built
-        max_vox = std::max<int64_t>(max_vox, (int64_t)b.out_nz * b.out_ny * b.out_nx);
+        if ((int64_t)b.out_nz * b.out_ny >= (int64_t(1) << 31)) return MMX_ERR_UNSUPPORTED;
+        max_rows = std::max<int64_t>(max_rows, (int64_t)b.out_nz * b.out_ny);
     }
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)std::min<int64_t>((max_vox + MMX_WG * 4 - 1) / (MMX_WG * 4), 65535), (unsigned)n_blocks);
+    // 16 rows per wave: the per-wave set-up (block record, x tables) is three dependent memory round trips
+    dim3 grid((unsigned)std::min<int64_t>((max_rows + 16 * (MMX_WG / 64) - 1) / (16 * (MMX_WG / 64)), 65535), (unsigned)n_blocks);
     mmx_timed_scope ts(MMX_K_GENERIC, s);
 #define MMX_RS_LAUNCH(T, O, O32)                                                                            \
     hipLaunchKernelGGL((resize_kernel<T, O>), grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z, \
