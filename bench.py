@@ -277,7 +277,9 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"],
                     "note": ("zxpass = fused Z+X pass: its 10 algorithmic B/voxel/sigma replace the 22 of the separate "
                              "Z and X passes, and it is bound by packed-fp32 VALU issue, not by HBM (DESIGN.md "
-                             "section 4b); the HBM-bound kernels of the step run at 0.56-0.61 of peak, see 'kernels'")
+                             "section 4b); the HBM-bound Y pass of the step runs at "
+                             f"{stream_k.get('y2pass', {}).get('alg_GBps', 0) / HBM_PEAK_GBS:.2f} of peak on its "
+                             "algorithmic bytes, see 'kernels' and 'pipeline_roofline' for the whole step")
                     if dom == "zxpass" else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),

@@ -235,7 +235,10 @@ zx_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int strid
 }
 
 // ---------------------------------------------------------------- Y pass on (P, Q)
-constexpr int kPrefetch = 4;
+#ifndef Y2_PF
+#define Y2_PF 4
+#endif
+constexpr int kPrefetch = Y2_PF;
 typedef float v2f __attribute__((ext_vector_type(2)));
 // (G''(y), G(y)) weights as pairs: the ring holds (P, Q) pairs, so one v_pk_add_f32 forms both pair sums of
 // a tap and one v_pk_fma_f32 accumulates (G''(y) P, G(y) Q); the two halves are added once per output.
