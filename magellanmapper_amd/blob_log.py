@@ -18,11 +18,13 @@ A5     ``_prune_blobs`` (blob.py:146-187)           ``mmx_overlap_pairs`` (HIP) 
 =====  ==========================================  ================================
 
 Exactness.  The float32 passes only *nominate* candidates (within ``eps`` of being a
-maximum / of the threshold).  Every candidate gets its float64 cube value recomputed on
-the device with SciPy's exact operation order; contested candidates also get their 80
-neighbours' exact values.  Peak membership, the descending-response order and therefore
-the integer blob coordinates are decided on float64 values that equal the reference's bit
-for bit.  Nothing here falls back to a CPU implementation: without the HIP library and a
+maximum / of the threshold).  Wherever a decision of the reference could depend on more
+than float32 resolves -- a candidate within ``eps`` of the threshold or of a neighbour, two
+candidates of a block within ``eps`` of each other (their order) -- the float64 cube values
+are recomputed on the device with SciPy's exact operation order (contested candidates also
+get their 80 neighbours' exact values); by default every candidate is re-scored.  Peak
+membership, the descending-response order and therefore the integer blob coordinates are
+decided as the reference's float64 values decide them.  Nothing here falls back to a CPU implementation: without the HIP library and a
 GPU the calls raise.
 """
 from __future__ import annotations
@@ -224,6 +226,7 @@ class BatchStats:
     n_candidates: int = 0
     n_contested: int = 0
     n_probes: int = 0
+    n_rescored: int = 0         # candidates re-scored in float64 because a decision needed it
     n_peaks: int = 0
     n_blobs: int = 0
     n_overlap_pairs: int = 0
@@ -366,8 +369,15 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                     shapes: Sequence[Sequence[int]], min_sigma: float, max_sigma: float,
                     num_sigma: int, threshold: float, overlap: float, *,
                     budget_bytes: int = 24 << 30, stats: Optional[BatchStats] = None,
-                    return_peaks: bool = False, on_batch=None, pre=None):
+                    return_peaks: bool = False, on_batch=None, pre=None,
+                    exact_values: Optional[bool] = None):
     """``blob_log`` of every block -> list of ``(n, 4)`` float64 ``[z, y, x, sigma]`` arrays.
+
+    ``exact_values`` (default True): re-score EVERY candidate in float64 in the batch's own kernel queue, so
+    that the peak values are the reference's bit for bit.  ``False`` re-scores only the candidates whose
+    decision needs it (see ``_resolve_peaks``) -- fewer points, but as a second, host-synchronous launch
+    per batch: on the benchmark volume, whose blobs are all alike, 68 % of the candidates have a block mate
+    within eps and the step is slower (243 vs 227 ms); it pays on images with a wide intensity range.
 
     Each block is an independent image exactly as each reference worker's sub-ROI is
     (reference magmap/cv/stack_detect.py:79): reflect boundaries at the block faces,
@@ -397,7 +407,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         if k < len(batches):
             batch = batches[k]
             job = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
-                                  space, float(threshold), eps, bufs, k & 1, d_w0, d_w2, pre=pre)
+                                  space, float(threshold), eps, bufs, k & 1, d_w0, d_w2, pre=pre,
+                                  exact=bool(True if exact_values is None else exact_values))
             job["batch"] = batch
         if pending is not None:      # host + side-stream work of the previous batch, GPU busy with `job`
             peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats)
@@ -414,8 +425,11 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
 
 # --------------------------------------------------------------------------- A0-A4
 def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
-                    bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None):
-    """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU."""
+                    bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None,
+                    exact: bool = False):
+    """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU.
+    ``exact``: also re-score every candidate in float64 (otherwise ``_resolve_peaks`` re-scores the few
+    whose decision depends on it)."""
     L = nat.lib()
     dev = dvol.tensor.device
     if pre is None:
@@ -457,16 +471,17 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                                 blocks.ctypes.data, nb, slot, thr, eps, table.data_ptr(), cap,
                                 count.data_ptr(), stream),
               "mmx_peaks_batch")
-    nat.check(L.mmx_rescore_f64(
-        ctypes.byref(vol_exact), d_blocks.data_ptr(), nb, table.data_ptr(), cap,
-        count.data_ptr(), d_w0.data_ptr(), d_w2.data_ptr(), nat.as_int32_ptr(space.radii),
-        nat.as_double_ptr(space.norms), ns, store_f32, stream), "mmx_rescore_f64")
+    if exact:
+        nat.check(L.mmx_rescore_f64(
+            ctypes.byref(vol_exact), d_blocks.data_ptr(), nb, table.data_ptr(), cap,
+            count.data_ptr(), d_w0.data_ptr(), d_w2.data_ptr(), nat.as_int32_ptr(space.radii),
+            nat.as_double_ptr(space.norms), ns, store_f32, stream), "mmx_rescore_f64")
     bufs.host_counts[which].copy_(count, non_blocking=True)
     done = torch.cuda.Event()
     done.record()
     return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
                 nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
-                vol_exact=vol_exact, pre=pre)
+                vol_exact=vol_exact, pre=pre, exact=exact)
 
 
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
@@ -486,7 +501,8 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
             # already reused the workspace, so the passes run again
             torch.cuda.current_stream().synchronize()
             redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr,
-                                   eps, bufs, which, d_w0, d_w2, cap=count + 1024, pre=job.get("pre"))
+                                   eps, bufs, which, d_w0, d_w2, cap=count + 1024, pre=job.get("pre"),
+                                   exact=job.get("exact", False))
             redo["batch"] = job.get("batch")
             return _finish_detect(redo, dvol, space, thr, eps, bufs, d_w0, d_w2, stats)
     with torch.cuda.stream(bufs.side):
@@ -496,33 +512,63 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
         stats.n_blocks += job["nb"]
         stats.n_voxels += job["n_vox"]
         stats.n_candidates += count
-        if count:
-            err = float(np.max(np.abs(cands["v"].astype(np.float64) - cands["v64"])))
-            stats.max_f32_error = max(stats.max_f32_error, err)
-            if not err < 0.25 * eps:
-                raise nat.MmxError(
-                    f"float32 LoG deviates from the exact value by {err:.3g} (band {eps:.3g}): "
-                    "refusing to decide peaks on it")
         return _resolve_peaks(cands, job["blocks"], job["shapes"], ns, thr, dvol, job["vol_exact"],
-                              job["d_blocks"], d_w0, d_w2, space, job["store_f32"], stats)
+                              job["d_blocks"], d_w0, d_w2, space, job["store_f32"], stats, eps,
+                              job.get("exact", False))
+
+
+def _check_f32_error(v32, v64, eps, stats):
+    if len(v32):
+        err = float(np.max(np.abs(v32.astype(np.float64) - v64)))
+        stats.max_f32_error = max(stats.max_f32_error, err)
+        if not err < 0.25 * eps:
+            raise nat.MmxError(
+                f"float32 LoG deviates from the exact value by {err:.3g} (band {eps:.3g}): "
+                "refusing to decide peaks on it")
 
 
 def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_w0, d_w2,
-                   space, store_f32, stats):
-    """Exact peak membership + the reference's ordering, per block."""
+                   space, store_f32, stats, eps, exact):
+    """Exact peak membership + the reference's ordering, per block.
+
+    What the reference's float64 values decide: (i) whether a candidate within ``eps`` of the threshold or of
+    a neighbour is a peak -- the NMS kernel flags those CONTESTED; (ii) the order of the peaks of a block
+    (``argsort(-value)``, peak.py:17), which only two candidates whose float32 values lie within ``eps`` of
+    each other can swap.  Those candidates (and the neighbours of the contested ones) are re-scored in
+    float64 here; every other candidate keeps its float32 value as a stand-in, which leaves every comparison
+    the reference makes unchanged (|float32 - float64| < eps / 4 is checked on all re-scored values).
+    ``exact``: all candidates were re-scored by ``_enqueue_detect`` already.
+    """
     L = nat.lib()
     dev = dvol.tensor.device
     nb = len(blocks)
     keep = np.ones(len(cands), dtype=bool)
     contested = np.nonzero(cands["flags"] & nat.MMX_CAND_CONTESTED)[0]
     stats.n_contested += len(contested)
-    if len(contested):
+    v32 = cands["v"].astype(np.float64)
+    if exact:
+        _check_f32_error(cands["v"], cands["v64"], eps, stats)
+        selves = np.zeros(0, dtype=np.int64)
+    else:
+        # candidates of one block whose float32 values are within eps of each other: their order is open
+        cslot = cands["slot"].astype(np.int64)
+        o = np.lexsort((-v32, cslot))
+        close = (cslot[o][1:] == cslot[o][:-1]) & ((v32[o][:-1] - v32[o][1:]) < eps)
+        need = np.zeros(len(cands), dtype=bool)
+        need[o[1:][close]] = True
+        need[o[:-1][close]] = True
+        need[contested] = True
+        selves = np.nonzero(need)[0]
+        stats.n_rescored += len(selves)
+        cands = cands.copy() if not cands.flags.writeable else cands
+        cands["v64"] = v32                      # stand-ins; the re-scored ones are overwritten below
+    if len(contested) or len(selves):
         # exact values of the (up to) 80 neighbours of every contested candidate
         offs = np.array([(ds, dz, dy, dx) for ds in (-1, 0, 1) for dz in (-1, 0, 1)
                          for dy in (-1, 0, 1) for dx in (-1, 0, 1)
                          if (ds, dz, dy, dx) != (0, 0, 0, 0)], dtype=np.int32)
         c = cands[contested]
-        dims = np.array([shapes[i] for i in c["slot"]], dtype=np.int32)      # (m, 3)
+        dims = np.array([shapes[i] for i in c["slot"]], dtype=np.int32).reshape(-1, 3)      # (m, 3)
         ss = c["s"][:, None] + offs[None, :, 0]
         zz = c["z"][:, None] + offs[None, :, 1]
         yy = c["y"][:, None] + offs[None, :, 2]
@@ -530,14 +576,17 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
         inside = ((ss >= 0) & (ss < ns) & (zz >= 0) & (zz < dims[:, 0:1]) &
                   (yy >= 0) & (yy < dims[:, 1:2]) & (xx >= 0) & (xx < dims[:, 2:3]))
         owner, which = np.nonzero(inside)
-        probes = np.zeros(len(owner), dtype=nat.CAND_DTYPE)
-        probes["slot"] = c["slot"][owner]
-        probes["s"] = ss[owner, which]
-        probes["z"] = zz[owner, which]
-        probes["y"] = yy[owner, which]
-        probes["x"] = xx[owner, which]
+        n_nb = len(owner)
+        probes = np.zeros(n_nb + len(selves), dtype=nat.CAND_DTYPE)
+        probes["slot"][:n_nb] = c["slot"][owner]
+        probes["s"][:n_nb] = ss[owner, which]
+        probes["z"][:n_nb] = zz[owner, which]
+        probes["y"][:n_nb] = yy[owner, which]
+        probes["x"][:n_nb] = xx[owner, which]
+        for f in ("slot", "s", "z", "y", "x"):
+            probes[f][n_nb:] = cands[f][selves]
         probes["v64"] = np.nan
-        stats.n_probes += len(probes)
+        stats.n_probes += n_nb
         if len(probes):
             d_probes = _to_device_bytes(probes, dev)
             nat.check(L.mmx_rescore_f64(
@@ -547,11 +596,15 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
             vals = d_probes.cpu().numpy().view(nat.CAND_DTYPE)["v64"]
         else:
             vals = np.zeros(0)
+        if len(selves):
+            _check_f32_error(cands["v"][selves], vals[n_nb:], eps, stats)
+            cands["v64"][selves] = vals[n_nb:]
+            vals = vals[:n_nb]
         nbr_max = np.full(len(contested), -np.inf)
         np.maximum.at(nbr_max, owner, vals)
         border = ~inside.all(axis=1)
         nbr_max[border] = np.maximum(nbr_max[border], 0.0)   # mode='constant', cval=0
-        keep[contested] = c["v64"] >= nbr_max
+        keep[contested] = cands["v64"][contested] >= nbr_max
     keep &= cands["v64"] > thr
     sel = np.nonzero(keep)[0]
     # plain contiguous columns from here on (record-array fancy indexing is slow)

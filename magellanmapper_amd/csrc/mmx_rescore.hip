@@ -89,7 +89,25 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
             const double c = in_scale<InT>::get(col[(int64_t)zr[R] * sz]);
             double a0 = c * w0[0];
             double a2 = c * w2[0];
-            for (int k = R; k >= 1; --k) {
+            // the taps in SciPy's order (k = R .. 1); the loads of 8 taps are issued before the first is
+            // used -- a tap-by-tap loop exposes the full memory latency 2R times per column, and that
+            // latency, not the arithmetic, was this kernel's time
+            int k = R;
+            for (; k >= 8; k -= 8) {
+                InT lo[8], hi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    lo[j] = col[(int64_t)zr[R - (k - j)] * sz];
+                    hi[j] = col[(int64_t)zr[R + (k - j)] * sz];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double p = in_scale<InT>::get(lo[j]) + in_scale<InT>::get(hi[j]);
+                    a0 += p * w0[k - j];
+                    a2 += p * w2[k - j];
+                }
+            }
+            for (; k >= 1; --k) {
                 const double p = in_scale<InT>::get(col[(int64_t)zr[R - k] * sz]) +
                                  in_scale<InT>::get(col[(int64_t)zr[R + k] * sz]);
                 a0 += p * w0[k];
@@ -109,10 +127,13 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
         __syncthreads();
     }
     // ---- axis 2 (x) and the sum of the three terms, in SciPy's order
+    if (threadIdx.x < 3)      // the three terms side by side (each a serial chain of R dependent LDS reads)
+        zp0[threadIdx.x] = corr_at<StoreT>(yp + threadIdx.x * N, 1, R, threadIdx.x == 2 ? w2 : w0);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const StoreT t0 = (StoreT)corr_at<StoreT>(yp + 0 * N, 1, R, w0);
-        const StoreT t1 = (StoreT)corr_at<StoreT>(yp + 1 * N, 1, R, w0);
-        const StoreT t2 = (StoreT)corr_at<StoreT>(yp + 2 * N, 1, R, w2);
+        const StoreT t0 = (StoreT)zp0[0];
+        const StoreT t1 = (StoreT)zp0[1];
+        const StoreT t2 = (StoreT)zp0[2];
         StoreT sum = t0;
         sum += t1;
         sum += t2;
