@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line with the contract fields plus
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import multiprocessing as mp
 import os
@@ -301,6 +302,10 @@ def main():
                                       if args.denoise else ""),
                        "blocks_per_rank": hi - lo, "parallelism": f"blocks sharded over {world} GPU(s)"},
             "blobs": 0 if final is None else int(len(final)),
+            # digest of the final 8-column table of the last step (computed after the timed region): the same
+            # for every path / batch size / rank count that is correct (tests/test_gpu_parity.py compares small
+            # volumes with the oracle row by row; this is the full-size cross-check)
+            "table_sha1": None if final is None else hashlib.sha1(np.ascontiguousarray(final).tobytes()).hexdigest(),
             "blobs_per_s": round((0 if final is None else len(final)) * args.steps / elapsed, 1),
             "roofline": roof,
             "pipeline_roofline": {
