@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 6
+#define MMX_ABI_VERSION 7
 
 typedef enum {
     MMX_OK = 0,
@@ -107,12 +107,15 @@ int mmx_device_count(void);
  *   norm       : mean(sigma)**2
  *   d_log      : out, [n_blocks][slot_elems] float32
  *   d_work     : scratch, 4 * n_blocks * slot_elems float32
- *   d_nms_mask : optional out, (n_blocks * slot_elems) >> 5 uint64: one bit per voxel (block in slot b
- *                starts at word (b * slot_elems) >> 5; its row y holds ceil(nz*px/64) words, bit z*px + x) set where the response exceeds nms_lo and no
- *                y / x neighbour exceeds it by more than nms_eps -- a superset of the local maxima that
- *                mmx_peaks_batch can visit instead of reading the whole cube.  Only the fused path
- *                produces it, and only when every block's rows fit its share (tiny blocks do not):
- *                *h_mask_written (host) says whether this call did.                    */
+ *   d_nms_mask : optional out, (n_blocks * slot_elems) >> 5 entries of two uint64 (16-byte aligned): the block
+ *                in slot b starts at entry (b * slot_elems) >> 5; entry (c >> 6) + y * ceil(nz*px/64), bit
+ *                c & 63, c = z*px + x.  Word 0: the response exceeds nms_lo and no y / x neighbour exceeds it by
+ *                more than nms_eps -- a superset of the local maxima, the only voxels mmx_peaks_batch visits.
+ *                Word 1: the response exceeds nms_lo.  WITH A MASK, 64-VOXEL SEGMENTS WHOSE WORD 1 IS ZERO ARE
+ *                NOT WRITTEN TO d_log (a response below the threshold can neither be a peak nor out-vote
+ *                one): d_log is then only meaningful together with the entries.  Only the fused path produces
+ *                the entries, and only when every block's rows fit its share (tiny blocks do not):
+ *                *h_mask_written (host) says whether this call did (if not, d_log is complete).          */
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                       int n_blocks, int64_t slot_elems,
                       const double* h_w0, const double* h_w2, int radius, double norm,
@@ -137,7 +140,7 @@ int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks,
  * replaces: skimage.feature.peak_local_max(footprint=ones(3,3,3,3), mode='constant')
  * (skimage/feature/peak.py:28-50, 114-319).
  *   d_log        : [n_sigma][n_blocks][slot_elems] float32 (sigma-major)
- *   d_nms_mask   : optional [n_sigma][(n_blocks * slot_elems) >> 5] uint64 written by mmx_log_batch_f32 with
+ *   d_nms_mask   : optional [n_sigma][(n_blocks * slot_elems) >> 5] 16-byte entries written by mmx_log_batch_f32 with
  *                  nms_lo = thr - eps and nms_eps = eps for EVERY sigma (NULL = read every voxel)
  *   eps          : candidates are emitted when v >= nbr_max - eps and v > thr - eps
  *   d_cands/cap  : output table; *d_count keeps counting past cap (caller retries)  */

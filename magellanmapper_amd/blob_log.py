@@ -242,7 +242,7 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     largest block of the batch (+ ``extra_bytes_per_voxel`` for the preprocessed copies).
     Blocks keep their order (z-major grid order).
     """
-    per_vox = (4 + num_sigma) * 4 + (num_sigma + 3) // 4 + extra_bytes_per_voxel     # + the NMS bit masks
+    per_vox = (4 + num_sigma) * 4 + (num_sigma + 1) // 2 + extra_bytes_per_voxel     # + the NMS bit masks
     batches: List[List[int]] = []
     cur: List[int] = []
     cur_slot = 0
@@ -443,24 +443,35 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     nb, ns = len(blocks), len(space.sigmas)
     if slot >= (1 << 29):
         raise nat.MmxError("block too large for one workspace slot (>= 2^29 voxels)")
-    mask_words = (nb * slot) >> 5            # uint64 words per sigma (include/mmx.h: d_nms_mask)
-    ws = bufs.workspace((4 + ns) * nb * slot + 2 + ns * mask_words * 2)
+    mask_words = (nb * slot) >> 5            # 16-byte entries per sigma (include/mmx.h: d_nms_mask)
+    ws = bufs.workspace((4 + ns) * nb * slot + 4 + ns * mask_words * 4)
     d_blocks = _to_device_bytes(blocks, dev)
     stream = _stream_ptr()
     log_base = ws.data_ptr() + 4 * nb * slot * 4
     # NMS pre-filter masks, [ns][nb][slot / 32] uint64: written by the Y pass of the fused path
-    mask_base = (log_base + ns * nb * slot * 4 + 7) & ~7
-    mask_ok = True
+    mask_base = (log_base + ns * nb * slot * 4 + 15) & ~15
     written = ctypes.c_int(0)
-    for s in range(ns):
-        nat.check(L.mmx_log_batch_f32(
-            ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
-            nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]), int(space.radii[s]),
-            float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(),
-            (mask_base + s * mask_words * 8) if mask_ok else None, thr - eps, eps,
-            ctypes.byref(written), stream),
-            "mmx_log_batch_f32")
-        mask_ok = mask_ok and written.value == 1
+
+    def passes(with_mask: bool):
+        all_written, any_written = with_mask, False
+        for s in range(ns):
+            nat.check(L.mmx_log_batch_f32(
+                ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
+                nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]), int(space.radii[s]),
+                float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(),
+                (mask_base + s * mask_words * 16) if with_mask else None, thr - eps, eps,
+                ctypes.byref(written), stream),
+                "mmx_log_batch_f32")
+            all_written = all_written and written.value == 1
+            any_written = any_written or written.value == 1
+        return all_written, any_written
+
+    # With the entries the Y pass leaves whole segments of the cube unwritten, so it is all scales or none:
+    # if one scale cannot produce them (a radius outside the fused kernels, tiny blocks) every scale is
+    # computed again in full.
+    mask_ok, some = passes(True)
+    if some and not mask_ok:
+        passes(False)
     n_vox = int(sum(int(np.prod(s)) for s in shapes))
     if cap is None:
         cap = max(4096, min(n_vox * ns, n_vox // 2000 * ns + 65536))

@@ -270,12 +270,18 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
     const float* i2 = gq + sbase;
     const float* w1 = out + sbase;
 
-    // NMS pre-filter (optional): one bit per voxel = "above thr - eps and not beaten by more than eps
-    // by its y and (same wave) x neighbours" -- a superset of the local maxima, decided on the very
-    // float32 values stored below.  The NMS kernel then only visits the set bits (mmx_peaks.hip).
+    // NMS pre-filter (optional): per 64 columns of a row one entry of two 64-bit words,
+    //   .x  one bit per voxel = "above thr - eps and not beaten by more than eps by its y and (same wave) x
+    //       neighbours" -- a superset of the local maxima, decided on the very float32 values computed here:
+    //       the NMS kernel only visits these bits (mmx_peaks.hip);
+    //   .y  one bit per voxel = "above thr - eps".  A 64-voxel segment without such a voxel (three quarters
+    //       of them on the benchmark volume) is NOT STORED: a value below the threshold can neither be a peak
+    //       nor out-vote a candidate, so the NMS kernel reads a neighbour only where .y != 0.
     const int lane = threadIdx.x & 63;
     const int nwords = (ncol + 63) >> 6;
-    unsigned long long* mrow = mask ? mask + ((int64_t)bd.slot * slot_elems >> 5) + (col >> 6) : nullptr;
+    ulonglong2* mrow = mask ? reinterpret_cast<ulonglong2*>(mask) + ((int64_t)bd.slot * slot_elems >> 5) + (col >> 6)
+                            : nullptr;
+    unsigned long long ab_prev = 0;
     const bool real = x < bd.nx;
     const bool has_l = lane > 0 && x > 0, has_r = lane < 63 && x + 1 < bd.nx && col + 1 < ncol;
     float prev1 = -INFINITY, prev2 = -INFINITY, nbx_prev = -INFINITY;
@@ -315,7 +321,8 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
         }
         a2 += b2;
         const float acc = a2.x + a2.y;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), make_rsrc(w1), voff, 0, 0);
+        const unsigned long long ab = mask ? __ballot(real && acc > nms_lo) : ~0ull;
+        if (ab) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), make_rsrc(w1), voff, 0, 0);
         w1 += nx;
         r[(s + R + kPrefetch) % M] = (v2f){n1, n2};
         if (mask) {
@@ -330,9 +337,10 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
                 const bool cand = real && prev1 > nms_lo &&
                                   !(fmaxf(fmaxf(prev2, acc), nbx_prev) > prev1 + nms_eps);
                 const unsigned long long m = __ballot(cand);
-                if (lane == 0) mrow[(int64_t)(ydone - 1) * nwords] = m;
+                if (lane == 0) mrow[(int64_t)(ydone - 1) * nwords] = make_ulonglong2(m, ab_prev);
             }
             prev2 = prev1; prev1 = acc; nbx_prev = nbx;
+            ab_prev = ab;
             ++ydone;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -354,7 +362,7 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
     if (mask) {               // the last row has no successor
         const bool cand = real && prev1 > nms_lo && !(fmaxf(prev2, nbx_prev) > prev1 + nms_eps);
         const unsigned long long m = __ballot(cand);
-        if (lane == 0) mrow[(int64_t)(n - 1) * nwords] = m;
+        if (lane == 0) mrow[(int64_t)(n - 1) * nwords] = make_ulonglong2(m, ab_prev);
     }
 }
 

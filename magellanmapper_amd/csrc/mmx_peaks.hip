@@ -172,58 +172,176 @@ peaks_kernel(const float* __restrict__ log, int ns, int64_t sigma_stride,
     }
 }
 
-// Sparse variant: the Y pass of the fused path has already marked, one bit per voxel, the voxels that
-// pass the threshold and are not beaten by their y / x neighbours (y2_kernel).  One lane per 64-voxel
-// word and sigma: nearly all words are zero; set bits get the full 80-neighbour test.  Reads
-// 1/8 byte per voxel and sigma instead of 4.
+// ---- sparse variant: works from the entries the Y pass of the fused path leaves per 64 columns of a row
+// (y2_kernel): .x = candidate bits (above thr - eps, not beaten by the y / x neighbours), .y = "above
+// thr - eps" bits.  Segments with .y == 0 were not stored: their voxels count as -inf (they can neither
+// be peaks nor out-vote a candidate, which is above thr - eps itself).
+struct sparse_ctx {
+    peak_ctx c;
+    const ulonglong2* ent;      // entries of this block, sigma 0
+    int64_t ent_sigma_stride;   // entries per sigma
+    int nwords;                 // entries per row
+};
+
+__device__ __forceinline__ float sparse_at(const sparse_ctx& k, int s, int z, int y, int x)
+{
+    const int col = z * k.c.px + x;
+    const unsigned long long above = k.ent[(int64_t)s * k.ent_sigma_stride + (int64_t)y * k.nwords + (col >> 6)].y;
+    if (!above) return -INFINITY;
+    return k.c.base[(int64_t)s * k.c.sigma_stride + (int64_t)z * k.c.plane + y * k.c.px + x];
+}
+
+// check_voxel on the sparse cube (same decisions: a neighbour that is not stored is below thr - eps < v)
+__device__ __forceinline__ void check_voxel_sparse(const sparse_ctx& k, int s, int z, int y, int x, float v)
+{
+    const peak_ctx& c = k.c;
+    const int nz = c.nz, ny = c.ny, nx = c.nx;
+    const float reject = v + c.eps;
+    float m = -INFINITY;
+    bool border = false;
+    for (int ds = -1; ds <= 1; ++ds) {
+        const int ss = s + ds;
+        if (ss < 0 || ss >= c.ns) { border = true; continue; }
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int zz = z + dz;
+            if (zz < 0 || zz >= nz) { border = true; continue; }
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= ny) { border = true; continue; }
+                // the three x neighbours share (at most two) entries and one row
+                const int col0 = zz * c.px + x;
+                const ulonglong2* er = k.ent + (int64_t)ss * k.ent_sigma_stride + (int64_t)yy * k.nwords;
+                const float* row = c.base + (int64_t)ss * c.sigma_stride + (int64_t)zz * c.plane + yy * c.px;
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= nx) { border = true; continue; }
+                    if ((ds | dz | dy | dx) == 0) continue;
+                    if (er[(col0 + dx) >> 6].y) m = fmaxf(m, row[xx]);
+                }
+            }
+            if (m > reject) return;
+        }
+    }
+    if (border) m = fmaxf(m, 0.0f);  // mode='constant', cval = 0
+    if (!(v >= m - c.eps)) return;
+    const bool contested = !(v > m + c.eps) || !(v > c.thr + c.eps);
+    const uint32_t pos = atomicAdd(c.count, 1u);
+    if (pos < c.cap) {
+        mmx_cand r;
+        r.slot = c.slot;
+        r.s = s;
+        r.z = z;
+        r.y = y;
+        r.x = x;
+        r.flags = contested ? MMX_CAND_CONTESTED : 0u;
+        r.v = v;
+        r.nbr_max = m;
+        r.v64 = __longlong_as_double(0x7ff8000000000000LL);
+        r._reserved = 0.0;
+        c.out[pos] = r;
+    }
+}
+
+// One lane per entry and sigma: nearly all candidate words are zero; set bits are tested against z +- 1,
+// then sigma +- 1 (most of them are the in-plane maxima of the z-slices and scales of a blob and fall there),
+// survivors get the full 80-neighbour test.
 __global__ void __launch_bounds__(MMX_WG)
-peaks_sparse_kernel(const float* __restrict__ log, const unsigned long long* __restrict__ mask,
+peaks_sparse_kernel(const float* __restrict__ log, const ulonglong2* __restrict__ entries,
                     int ns, int64_t sigma_stride, const mmx_block* __restrict__ blocks, int64_t slot_elems,
                     float thr, float eps, mmx_cand* __restrict__ out, uint32_t cap,
                     uint32_t* __restrict__ count)
 {
     const mmx_block bd = blocks[blockIdx.y];
-    peak_ctx c;
+    sparse_ctx k;
+    peak_ctx& c = k.c;
     c.base = log + (int64_t)bd.slot * slot_elems;
     c.sigma_stride = sigma_stride;
     c.ns = ns; c.nz = bd.nz; c.ny = bd.ny; c.nx = bd.nx; c.px = bd.px;
     c.plane = bd.ny * bd.px; c.slot = bd.slot;
     c.thr = thr; c.eps = eps; c.out = out; c.cap = cap; c.count = count;
     const int ncol = bd.nz * bd.px;
-    const int nwords = (ncol + 63) >> 6;
-    const int64_t per_sigma = (int64_t)bd.ny * nwords;
+    k.nwords = (ncol + 63) >> 6;
+    k.ent = entries + ((int64_t)bd.slot * slot_elems >> 5);
+    k.ent_sigma_stride = sigma_stride >> 5;
+    const int64_t per_sigma = (int64_t)bd.ny * k.nwords;
     const int64_t total = per_sigma * ns;
-    const unsigned long long* mb = mask + ((int64_t)bd.slot * slot_elems >> 5);
-    const int64_t mask_sigma_stride = sigma_stride >> 5;
-    for (int64_t i = (int64_t)blockIdx.x * MMX_WG + threadIdx.x; i < total; i += (int64_t)gridDim.x * MMX_WG) {
+    // Set bits are rare (a few per cent of the words hold one) and each costs a chain of dependent loads:
+    // a lane that walked the bits of its own word would leave the other 63 waiting.  So the workgroup first
+    // queues the set bits of 256 words in LDS, then every lane takes one queued bit.
+    constexpr int kQ = 1024;
+    __shared__ unsigned long long q[kQ];
+    __shared__ int qn;
+    auto test_bit = [&](int64_t i, int b) __attribute__((always_inline)) {
         const int s = (int)(i / per_sigma);
         const int64_t r = i - (int64_t)s * per_sigma;
-        unsigned long long m = mb[(int64_t)s * mask_sigma_stride + r];
-        if (!m) continue;
-        const int y = (int)(r / nwords);
-        const int w = (int)(r - (int64_t)y * nwords);
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int col = (w << 6) + b;
-            const int z = col / bd.px;
-            const int x = col - z * bd.px;
-            if (x >= bd.nx || z >= bd.nz) continue;
-            const int idx = z * c.plane + y * bd.px + x;
-            // the y and x neighbours were tested when the bit was set: most set bits are the in-plane maxima
-            // of the z-slices of a blob and fall to their z (then sigma) neighbours -- two cache lines each
-            // instead of the four of the face test in check_voxel
-            const float* ps = c.base + (int64_t)s * sigma_stride + idx;
-            const float v = ps[0];
-            float nb = -INFINITY;
-            if (z > 0) nb = fmaxf(nb, ps[-c.plane]);
-            if (z + 1 < bd.nz) nb = fmaxf(nb, ps[c.plane]);
-            if (nb > v + eps) continue;
-            if (s > 0) nb = fmaxf(nb, ps[-sigma_stride]);
-            if (s + 1 < ns) nb = fmaxf(nb, ps[sigma_stride]);
-            if (nb > v + eps) continue;
-            check_voxel(c, s, idx, v);
+        const int y = (int)(r / k.nwords);
+        const int w = (int)(r - (int64_t)y * k.nwords);
+        const int col = (w << 6) + b;
+        const int z = col / bd.px;
+        const int x = col - z * bd.px;
+        if (x >= bd.nx || z >= bd.nz) return;
+        const float v = c.base[(int64_t)s * sigma_stride + (int64_t)z * c.plane + y * bd.px + x];
+        // (the y and x neighbours were tested when the bit was set: most set bits are the in-plane maxima of
+        // the z-slices and scales of a blob and fall to z +- 1 or sigma +- 1)
+        const float n0 = z > 0 ? sparse_at(k, s, z - 1, y, x) : -INFINITY;
+        const float n1 = z + 1 < bd.nz ? sparse_at(k, s, z + 1, y, x) : -INFINITY;
+        const float n2 = s > 0 ? sparse_at(k, s - 1, z, y, x) : -INFINITY;
+        const float n3 = s + 1 < ns ? sparse_at(k, s + 1, z, y, x) : -INFINITY;
+        if (fmaxf(fmaxf(n0, n1), fmaxf(n2, n3)) > v + eps) return;
+        check_voxel_sparse(k, s, z, y, x, v);
+    };
+    if (threadIdx.x == 0) qn = 0;
+    for (int j = threadIdx.x; j < kQ; j += MMX_WG) q[j] = ~0ull;     // "no item"
+    __syncthreads();
+    constexpr int kW = 8;                          // words per lane and round
+    const int64_t stride = (int64_t)gridDim.x * MMX_WG * kW;
+    const int64_t rounds = (total + stride - 1) / stride;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t i0 = rd * stride + (int64_t)blockIdx.x * MMX_WG * kW + threadIdx.x;
+        unsigned long long mw[kW];
+#pragma unroll
+        for (int u = 0; u < kW; ++u) {
+            const int64_t i = i0 + (int64_t)u * MMX_WG;
+            mw[u] = 0;
+            if (i < total) {
+                const int s = (int)(i / per_sigma);
+                mw[u] = k.ent[(int64_t)s * k.ent_sigma_stride + (i - (int64_t)s * per_sigma)].x;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < kW; ++u) {
+            unsigned long long m = mw[u];
+            if (!m) continue;
+            const int64_t i = i0 + (int64_t)u * MMX_WG;
+            const int cnt = __popcll(m);
+            const int at = atomicAdd(&qn, cnt);
+            if (at + cnt <= kQ) {
+                int j = at;
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    q[j++] = ((unsigned long long)i << 6) | (unsigned long long)b;
+                }
+            } else {                              // queue full (a dense patch): this lane walks its own bits
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    test_bit(i, b);
+                }
+            }
+        }
+        __syncthreads();
+        const int nq = qn < kQ ? qn : kQ;     // entries beyond kQ were never queued (handled inline above)
+        // (an `at` below kQ with at + cnt above it queued nothing either: its slots stay unused)
+        for (int j = threadIdx.x; j < nq; j += MMX_WG) {
+            const unsigned long long e = q[j];
+            if (e != ~0ull) test_bit((int64_t)(e >> 6), (int)(e & 63));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) qn = 0;
+        for (int j = threadIdx.x; j < nq; j += MMX_WG) q[j] = ~0ull;
+        __syncthreads();
     }
 }
 
@@ -235,11 +353,12 @@ int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask
                             uint32_t* d_count, hipStream_t stream)
 {
     int64_t words = ((int64_t)max_vox / 64 + 1024) * n_sigma;
-    int gx = (int)((words + MMX_WG - 1) / MMX_WG);
+    int gx = (int)((words + MMX_WG * 8 - 1) / (MMX_WG * 8));      // 8 words per lane and round
     if (gx > 8192) gx = 8192;
     if (gx < 1) gx = 1;
     dim3 grid(gx, n_blocks);
-    hipLaunchKernelGGL(peaks_sparse_kernel, grid, dim3(MMX_WG), 0, stream, d_log, d_mask, n_sigma, sigma_stride,
+    hipLaunchKernelGGL(peaks_sparse_kernel, grid, dim3(MMX_WG), 0, stream, d_log,
+                       reinterpret_cast<const ulonglong2*>(d_mask), n_sigma, sigma_stride,
                        d_blocks, slot_elems, thr, eps, d_cands, cap, d_count);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }

@@ -41,7 +41,7 @@ res = {}
 fn = L.mmx_log_batch_f32_generic if a.generic else L.mmx_log_batch_f32
 log_base = ws.data_ptr() + 4 * nb * slot * 4
 mask_words = (nb * slot) >> 5
-masks = torch.zeros(ns * mask_words, dtype=torch.int64, device=dev)
+masks = torch.zeros(ns * mask_words * 2, dtype=torch.int64, device=dev)
 written = ctypes.c_int(0)
 for rep in range(a.reps + 1):
     if rep == 1:
@@ -51,7 +51,7 @@ for rep in range(a.reps + 1):
         w0 = k1.gaussian_half_kernel(s, 0, R); w2 = k1.gaussian_half_kernel(s, 2, R)
         nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                      nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, s * s,
-                     log_base + i * nb * slot * 4, ws.data_ptr(), *(() if a.generic else ((masks.data_ptr() + i * mask_words * 8) if a.mask else None, 0.1 - 2e-5, 2e-5,
+                     log_base + i * nb * slot * 4, ws.data_ptr(), *(() if a.generic else ((masks.data_ptr() + i * mask_words * 16) if a.mask else None, 0.1 - 2e-5, 2e-5,
                                                     ctypes.byref(written))), stream), "log")
         assert not a.mask or written.value == 1
         if rep >= 1:
