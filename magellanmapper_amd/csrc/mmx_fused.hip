@@ -246,7 +246,7 @@ struct y2_taps {
     v2f w[MMX_MAX_RADIUS_FAST + 1];
 };
 
-template <int R>
+template <int R, bool MASK>
 __global__ void __launch_bounds__(MMX_WG)
 y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
           const float* __restrict__ gp, const float* __restrict__ gq,
@@ -279,8 +279,8 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
     //       nor out-vote a candidate, so the NMS kernel reads a neighbour only where .y != 0.
     const int lane = threadIdx.x & 63;
     const int nwords = (ncol + 63) >> 6;
-    ulonglong2* mrow = mask ? reinterpret_cast<ulonglong2*>(mask) + ((int64_t)bd.slot * slot_elems >> 5) + (col >> 6)
-                            : nullptr;
+    ulonglong2* mrow = MASK ? reinterpret_cast<ulonglong2*>(mask) + ((int64_t)bd.slot * slot_elems >> 5) + (col >> 6)
+                            : nullptr;      // entry of the row being decided (advanced by nwords per row)
     unsigned long long ab_prev = 0;
     const bool real = x < bd.nx;
     const bool has_l = lane > 0 && x > 0, has_r = lane < 63 && x + 1 < bd.nx && col + 1 < ncol;
@@ -293,20 +293,23 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
         const int row = reflect_once(j, n) * nx;
         r[(j + M) % M] = (v2f){io::load(make_rsrc(i1 + row), voff), io::load(make_rsrc(i2 + row), voff)};
     }
-    const float* q1 = i1 + (int64_t)(R + kPrefetch) * nx;
-    const float* q2 = i2 + (int64_t)(R + kPrefetch) * nx;
+    // one descriptor per array for the whole march; the row is a scalar byte offset (one s_add per step and
+    // array instead of rebuilding a descriptor: at R >= 18 the kernel is bound by instruction issue)
+    const rsrc_t rs1 = make_rsrc(i1), rs2 = make_rsrc(i2), rsw = make_rsrc(w1);
+    const unsigned row_b = (unsigned)nx * 4u;
+    unsigned qoff = (unsigned)(R + kPrefetch) * row_b;      // next row to load (bytes)
+    unsigned woff = 0;                                      // row being written
     auto step = [&](int s, auto reflecting, int y) __attribute__((always_inline)) {
         float n1, n2;
         if constexpr (decltype(reflecting)::value) {
-            const int rnext = reflect_once(y + R + kPrefetch, n) * nx;
-            n1 = io::load(make_rsrc(i1 + rnext), voff);
-            n2 = io::load(make_rsrc(i2 + rnext), voff);
+            const unsigned rnext = (unsigned)reflect_once(y + R + kPrefetch, n) * row_b;
+            n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, rnext, 0));
+            n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, rnext, 0));
         } else {
-            n1 = io::load(make_rsrc(q1), voff);
-            n2 = io::load(make_rsrc(q2), voff);
+            n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, qoff, 0));
+            n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, qoff, 0));
         }
-        q1 += nx;
-        q2 += nx;
+        qoff += row_b;
         // two accumulator chains: a dependent v_pk_add -> v_pk_fma pair back to back costs a wait state
         v2f a2 = r[s] * taps.w[0];
         v2f b2 = (r[(s - 1 + M) % M] + r[(s + 1) % M]) * taps.w[1];
@@ -321,11 +324,11 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
         }
         a2 += b2;
         const float acc = a2.x + a2.y;
-        const unsigned long long ab = mask ? __ballot(real && acc > nms_lo) : ~0ull;
-        if (ab) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), make_rsrc(w1), voff, 0, 0);
-        w1 += nx;
+        const unsigned long long ab = MASK ? __ballot(real & (acc > nms_lo)) : ~0ull;
+        if (ab) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rsw, voff, woff, 0);
+        woff += row_b;
         r[(s + R + kPrefetch) % M] = (v2f){n1, n2};
-        if (mask) {
+        if constexpr (MASK) {
             // x neighbours by DPP wavefront shifts (no LDS crossbar traffic); lanes shifted in from
             // outside the wave keep `acc`, which has_l / has_r discard
             const float l = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
@@ -334,10 +337,11 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
                 (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
             const float nbx = fmaxf(has_l ? l : -INFINITY, has_r ? r : -INFINITY);
             if (ydone > 0) {      // decide row ydone - 1, now that its successor is known
-                const bool cand = real && prev1 > nms_lo &&
+                const bool cand = real & (prev1 > nms_lo) &
                                   !(fmaxf(fmaxf(prev2, acc), nbx_prev) > prev1 + nms_eps);
                 const unsigned long long m = __ballot(cand);
-                if (lane == 0) mrow[(int64_t)(ydone - 1) * nwords] = make_ulonglong2(m, ab_prev);
+                if (lane == 0) *mrow = make_ulonglong2(m, ab_prev);
+                mrow += nwords;
             }
             prev2 = prev1; prev1 = acc; nbx_prev = nbx;
             ab_prev = ab;
@@ -359,10 +363,10 @@ y2_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems,
             step(s, std::true_type{}, y0 + s);
         }
     }
-    if (mask) {               // the last row has no successor
-        const bool cand = real && prev1 > nms_lo && !(fmaxf(prev2, nbx_prev) > prev1 + nms_eps);
+    if constexpr (MASK) {     // the last row has no successor
+        const bool cand = real & (prev1 > nms_lo) & !(fmaxf(prev2, nbx_prev) > prev1 + nms_eps);
         const unsigned long long m = __ballot(cand);
-        if (lane == 0) mrow[(int64_t)(n - 1) * nwords] = make_ulonglong2(m, ab_prev);
+        if (lane == 0) *mrow = make_ulonglong2(m, ab_prev);
     }
 }
 
@@ -399,8 +403,12 @@ int launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slo
     dim3 grid((max_cols + MMX_WG - 1) / MMX_WG, n_blocks);
     y2_taps pk;
     for (int k = 0; k <= R; ++k) pk.w[k] = (v2f){taps.w2[k], taps.w0[k]};
-    hipLaunchKernelGGL(y2_kernel<R>, grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, d_p, d_q, d_log, pk,
-                       d_mask, nms_lo, nms_eps);
+    if (d_mask)
+        hipLaunchKernelGGL((y2_kernel<R, true>), grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, d_p, d_q, d_log, pk,
+                           d_mask, nms_lo, nms_eps);
+    else
+        hipLaunchKernelGGL((y2_kernel<R, false>), grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, d_p, d_q, d_log, pk,
+                           d_mask, nms_lo, nms_eps);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
