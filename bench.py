@@ -255,8 +255,9 @@ def main():
                     gbs = ALG_BYTES[k] * my_vox * ns * args.steps / (ms * 1e-3) / 1e9
                     per_kernel[k]["alg_GBps"] = round(gbs, 1)
                     if k == "peaks" and gbs > HBM_PEAK_GBS:
-                        per_kernel[k]["note"] = ("sparse NMS over the bit masks the Y pass leaves (1/8 B per voxel and "
-                                                 "sigma actually read); alg_GBps is quoted on the 4 B contract figure")
+                        per_kernel[k]["note"] = ("sparse NMS over the entries the Y pass leaves (16 B per 64 voxels and "
+                                                 "sigma, plus the lines of the set bits); alg_GBps is quoted on the "
+                                                 "4 B contract figure")
                 elif k == "preproc":      # once per voxel (not per sigma): 2 B in, 8 + 4 B out; fp64-VALU bound
                     per_kernel[k]["alg_GBps"] = round(14 * my_vox * args.steps / (ms * 1e-3) / 1e9, 1)
         stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
