@@ -536,8 +536,8 @@ extern "C" int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d
     int64_t max_rows = 1;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_resize_block& b = h_blocks[i];
-        if (b.in_nz < 2 || b.in_ny < 2 || b.in_nx < 2 || b.out_nz < 1 || b.out_ny < 1 || b.out_nx < 1)
-            return MMX_ERR_UNSUPPORTED;        // unit-thick blocks use scikit-image's 'edge' mode: not built
+        if (b.in_nz < 1 || b.in_ny < 1 || b.in_nx < 1 || b.out_nz < 1 || b.out_ny < 1 || b.out_nx < 1)
+            return MMX_ERR_ARG;                // (unit-thick axes: the caller's tables are 'nearest' mode)
         if ((int64_t)b.out_nz * b.out_ny >= (int64_t(1) << 31)) return MMX_ERR_UNSUPPORTED;
         max_rows = std::max<int64_t>(max_rows, (int64_t)b.out_nz * b.out_ny);
     }

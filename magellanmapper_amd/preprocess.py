@@ -417,19 +417,25 @@ def calc_isotropic_factor(scale, res=None) -> np.ndarray:
 _AXIS_TABLES: Dict[Tuple[int, int], Tuple[np.ndarray, np.ndarray]] = {}
 
 
-def zoom_axis_table(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray]:
+def zoom_axis_table(n_in: int, n_out: int, mode: str = "mirror") -> Tuple[np.ndarray, np.ndarray]:
     """``(index (n_out, 2) int32, weight (n_out, 2) float64)`` of one axis of
-    ``scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True)``: SciPy's NI_ZoomShift computes, per
-    output index k, ``cc = (k + 0.5) * (n_in / n_out) - 0.5``, mirrors it into the array ("whole-sample
-    symmetric": -c -> c, beyond the end 2(n-1) - c), takes ``floor(cc)`` and the next sample (border
-    indices mirrored again) with weights ``w0 = 1 - frac``, ``w1 = 1 - w0``.  Same double arithmetic here."""
-    key = (int(n_in), int(n_out))
+    ``scipy.ndimage.zoom(order=1, mode=mode, grid_mode=True)``: SciPy's NI_ZoomShift computes, per
+    output index k, ``cc = (k + 0.5) * (n_in / n_out) - 0.5``, extends it into the array -- ``mirror``
+    ("whole-sample symmetric": -c -> c, beyond the end 2(n-1) - c) or ``nearest`` (what scikit-image's
+    ``mode='edge'`` becomes, used by the reference for blocks one voxel thick, cv_nd.py:1096-1101: the
+    coordinate stays as it is, only the sample indices are clamped to [0, n-1], so an outside point is
+    ``v * w0 + v * w1`` of the edge sample, not ``v``) -- takes ``floor(cc)`` and the next sample (border
+    indices extended the same way) with weights ``w0 = 1 - frac``, ``w1 = 1 - w0``.  Same double arithmetic
+    here (checked against SciPy bit for bit, tests/test_host_logic.py)."""
+    key = (int(n_in), int(n_out), mode)
     hit = _AXIS_TABLES.get(key)
     if hit is not None:
         return hit
-    n_in, n_out = key
-    if n_in < 2:
-        raise NotImplementedError("unit-thick blocks are resized in scikit-image's 'edge' mode: not built")
+    n_in, n_out, _ = key
+    if mode not in ("mirror", "nearest"):
+        raise ValueError(mode)
+    if n_in < 2 and mode == "mirror":
+        raise ValueError("SciPy's mirror extension needs at least two samples")
     zoom = np.divide(np.float64(n_in), np.float64(n_out))
     sz2 = 2 * n_in - 2
     idx = np.zeros((n_out, 2), dtype=np.int32)
@@ -439,7 +445,9 @@ def zoom_axis_table(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray]:
         cc = cc + 0.5
         cc = cc * zoom
         cc = cc - 0.5
-        if cc < 0:
+        if mode == "nearest":
+            pass            # SciPy leaves the coordinate alone and clamps the two sample indices below
+        elif cc < 0:
             cc = sz2 * int(-cc / sz2) + cc
             cc = cc + sz2 if cc <= 1 - n_in else -cc
         elif cc > n_in - 1:
@@ -449,7 +457,9 @@ def zoom_axis_table(n_in: int, n_out: int) -> Tuple[np.ndarray, np.ndarray]:
         start = int(np.floor(cc))
         for ll in range(2):
             j = start + ll
-            if j < 0:
+            if mode == "nearest":
+                j = 0 if j < 0 else (n_in - 1 if j >= n_in else j)
+            elif j < 0:
                 j = sz2 * int(-j / sz2) + j
                 j = j + sz2 if j <= 1 - n_in else -j
             elif j >= n_in:
@@ -548,8 +558,10 @@ class Rescaler:
         rb = np.zeros(nb, dtype=nat.RESIZE_DTYPE)
         for i in range(nb):
             t3 = []
+            # a block with an axis of length 1 (channels included) is resized in 'edge' mode (cv_nd.py:1096-1101)
+            edge = min(orig[i]) == 1 or (dvol.multichannel and dvol.n_channels == 1)
             for a in range(3):
-                key = (int(orig[i][a]), int(new_shp[i, a]))
+                key = (int(orig[i][a]), int(new_shp[i, a]), "nearest" if edge else "mirror")
                 if key not in offs:
                     ix, w = zoom_axis_table(*key)
                     offs[key] = at

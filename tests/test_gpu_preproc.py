@@ -247,3 +247,24 @@ def test_stock_anisotropic_lightsheet_geometry_matches_oracle(gpu, env, tmp_path
     want, st = mmo.detect_blobs_blocks(vol, None, [dict(config.roi_profile)], config.resolutions)
     assert st["seg_rois"].size >= 8 and len(want) > 20
     np.testing.assert_array_equal(blobs.blobs, want)
+
+
+def test_isotropic_unit_thick_blocks_use_edge_mode(gpu):
+    """A block with an axis of length 1 (the remainder block of a stack, a one-plane ROI) is resized in
+    scikit-image's 'edge' mode by the reference (cv_nd.py:1096-1101) = SciPy's 'nearest': the coordinate
+    is left alone and the sample indices are clamped.  Against the oracle's SciPy call (no fixture from the
+    real reference exists for this shape: scikit-image 0.18.3 takes its 2-D warp there)."""
+    from magellanmapper_amd import preprocess
+    from oracle import isotropic_oracle
+    rng = np.random.default_rng(12)
+    for shape, scale, res in (((1, 30, 33), (0.96, 1, 1), (3.0, 1.0, 1.0)),
+                              ((1, 17, 40), (1, 1, 1), (2.5, 1.2, 1.0)),
+                              ((12, 1, 28), (1, 1, 1), (2.0, 1.0, 1.5)),
+                              ((1, 1, 9), (1, 1, 1), (2.0, 3.0, 1.0))):
+        for dtype in (np.uint16, np.float64):
+            roi = (rng.integers(0, 65535, shape).astype(np.uint16) if dtype == np.uint16
+                   else rng.random(shape) * 3 - 0.5)
+            got = preprocess.make_isotropic(roi, scale, np.array(res))
+            want = isotropic_oracle.make_isotropic(roi, scale, np.array(res))
+            assert got.shape == want.shape and got.dtype == want.dtype
+            np.testing.assert_array_equal(got, want, err_msg=str((shape, scale, res, dtype)))
