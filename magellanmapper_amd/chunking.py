@@ -58,9 +58,11 @@ def stack_splitter(shape: Sequence[int], max_pixels: Sequence[int],
 def merge_blobs(blob_rois: np.ndarray) -> Optional[np.ndarray]:
     """All block tables stacked, with the block's grid coordinate as 3 extra int columns."""
     arena = getattr(blob_rois, "arena", None)
-    if arena is not None and arena.intact(blob_rois):
+    if arena is not None and arena.n and arena.intact(blob_rois):
         # the tables were stored back to back (grid order) with their tags while the GPU was busy
-        return arena.store[:arena.n] if arena.n else None
+        return arena.store[:arena.n]
+    # (no rows at all: blocks whose blobs were all excluded hold EMPTY tables, not None, and the reference
+    # then merges to an empty table rather than None -- the loop below does the same)
     live = [(coord, blob_rois[coord]) for coord in np.ndindex(*blob_rois.shape)
             if blob_rois[coord] is not None and not isinstance(blob_rois[coord], (int, np.integer))]
     if not live:

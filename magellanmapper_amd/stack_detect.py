@@ -448,6 +448,78 @@ class StackPruner:
             ratios = detector.meas_pruning_ratio(n_orig, len(after), len(blobs_next))
         return after, ratios
 
+    @staticmethod
+    def _axis_geometry(axis, shape3, overlap, overlap_padding, sub_roi_slices, sub_rois_offsets):
+        """``(start_j, end_j)`` of the blocks along ``axis`` and whether the reference's regions tile it:
+        pass 0 | slab 0 | pass 1 | ... with slab j = [end_j - shift, end_j + pad) ending exactly where pass
+        j + 1 = [start_{j+1} + shift, ...) begins, and no region of negative length."""
+        n_sections = sub_rois_offsets.shape[axis]
+        shift = overlap[axis] + overlap_padding[axis]
+        spans = []
+        for j in range(n_sections):
+            coord = [0, 0, 0]
+            coord[axis] = j
+            start = int(sub_rois_offsets[tuple(coord)][axis])
+            spans.append((start, start + len(range(*sub_roi_slices[tuple(coord)][axis].indices(shape3[axis])))))
+        regular = True
+        for j, (start, end) in enumerate(spans):
+            pass_lo = start + (shift if j > 0 else 0)
+            if j < n_sections - 1:
+                regular &= pass_lo <= end - shift                                   # pass j, then slab j
+                regular &= end + overlap_padding[axis] == spans[j + 1][0] + shift   # slab j meets pass j + 1
+            else:
+                regular &= pass_lo <= end
+        return spans, bool(regular)
+
+    @classmethod
+    def _prune_blobs_general(cls, merged, shape3, overlap, tol, sub_roi_slices, sub_rois_offsets, channels,
+                             overlap_padding):
+        """The reference's region arithmetic as it stands (stack_detect.py:679-861), on materialised tables:
+        used when the regions do not tile an axis -- blocks not much larger than their overlap, where a
+        truncated block at the far face or an overlap beyond the block stride makes slabs overlap each
+        other and passes empty.  The reference then lists a blob once per region it falls into and drops
+        those tagged for neither block of a slab; the index-based fast path cannot express that."""
+        coord_last = tuple(np.subtract(sub_roi_slices.shape, 1))
+        ratio_cols = ("blobs", "ratio_pruning", "ratio_adjacent")
+        ratios_all, blobs_all = {}, []
+        for chl in channels:
+            blobs = detector.Blobs.blobs_in_channel(merged, chl)
+            for axis in range(3):
+                n_sections = sub_rois_offsets.shape[axis]
+                if n_sections <= 1:
+                    continue
+                spans, _ = cls._axis_geometry(axis, shape3, overlap, overlap_padding, sub_roi_slices,
+                                              sub_rois_offsets)
+                shift = overlap[axis] + overlap_padding[axis]
+                pos = blobs[:, axis]
+                passes, pruners = [], []
+                for j, (start, end) in enumerate(spans):
+                    lo = start + (shift if j > 0 else 0)
+                    if j < n_sections - 1:
+                        slab = blobs[(pos >= end - shift) & (pos < end + overlap_padding[axis])]
+                        nxt_lo = end + tol[axis]
+                        nxt_hi = nxt_lo + overlap[axis] + 2 * overlap_padding[axis]
+                        roi_end = sub_rois_offsets[coord_last][axis] + (end - start)
+                        nxt = None
+                        if nxt_lo < roi_end and nxt_hi < roi_end:
+                            nxt = blobs[(pos >= nxt_lo) & (pos < nxt_hi)]
+                        passes.append(blobs[(pos < end - shift) & (pos >= lo)])
+                        pruners.append((slab, axis, tol, nxt))
+                    else:
+                        passes.append(blobs[(pos < end) & (pos >= lo)])
+                        pruners.append((None, axis, tol, None))
+                kept = []
+                for j, pruner in enumerate(pruners):
+                    after, ratios = cls.prune_overlap(j, pruner)
+                    if after is not None:
+                        kept.append(after)
+                    if ratios:
+                        for col, val in zip(ratio_cols, ratios):
+                            ratios_all.setdefault(col, []).append(val)
+                blobs = np.concatenate(passes + kept)
+            blobs_all.append(blobs)
+        return np.vstack(blobs_all)[:, :-3], ratios_all
+
     @classmethod
     def prune_blobs_mp(cls, img, seg_rois, overlap, tol, sub_roi_slices, sub_rois_offsets,
                        channels, overlap_padding=None):
@@ -478,6 +550,11 @@ class StackPruner:
         coord_last = tuple(np.subtract(grid, 1))
         ratio_cols = ("blobs", "ratio_pruning", "ratio_adjacent")
         ratios_all = {}
+        if not all(cls._axis_geometry(a, shape3, overlap, overlap_padding, sub_roi_slices, sub_rois_offsets)[1]
+                   for a in range(3) if sub_rois_offsets.shape[a] > 1):
+            out, ratios_all = cls._prune_blobs_general(merged, shape3, overlap, tol, sub_roi_slices,
+                                                       sub_rois_offsets, channels, overlap_padding)
+            return out, pd.DataFrame(ratios_all)
         ncol = merged.shape[1]
         detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
         abs_inds = detector.Blobs._get_abs_inds()

@@ -624,3 +624,43 @@ def test_selective_rescore_gives_the_exact_order(gpu):
         n_sel += st_b.n_rescored
         n_all += st_b.n_candidates
     assert 0 < n_sel < n_all
+
+
+@pytest.mark.parametrize("geometry", ["overlap_beyond_stride", "truncated_far_block", "all_excluded"])
+def test_irregular_block_geometry_matches_oracle(gpu, tmp_path, monkeypatch, geometry):
+    """Blocks not much larger than their overlap (small ``segment_size``, anisotropic voxels, a large
+    ``exclude_border``): the reference's pruning regions then stop tiling the axis -- slabs overlap each other,
+    passes are empty, a blob is listed once per region it falls into -- and blocks whose blobs were all
+    excluded hold EMPTY tables.  Found by tools/soak_stack.py; the final table must equal the oracle's,
+    duplicates included."""
+    from magellanmapper_amd import config, stack_detect, synth
+    from oracle import magmap_oracle as mmo
+    monkeypatch.chdir(tmp_path)
+    shape, res, over = {
+        "overlap_beyond_stride": ((47, 110, 81), 3.0, dict(segment_size=30, num_sigma=4, detection_threshold=0.05,
+                                                          overlap=0.8, exclude_border=(5, 0, 5))),
+        "truncated_far_block": ((65, 69, 141), 3.0, dict(segment_size=44, num_sigma=2, detection_threshold=0.2,
+                                                        overlap=0.3, exclude_border=(5, 3, 0),
+                                                        prune_tol_factor=(0.5, 1.0, 1.5))),
+        "all_excluded": ((40, 64, 60), 2.0, dict(segment_size=30, num_sigma=3, detection_threshold=0.5,
+                                                 exclude_border=(0, 2, 1))),
+    }[geometry]
+    vol = synth.make_volume(7, shape, 160 if geometry != "all_excluded" else 2, blob_sigma=2.5)
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(denoise_size=None, **over)
+    config.resolutions = np.array([[res, 1.0, 1.0]])
+    config.filename = "irregular"
+    blocks = stack_detect.setup_blocks(config.roi_profile, shape)
+    regular = all(stack_detect.StackPruner._axis_geometry(a, shape, blocks.overlap, blocks.overlap_padding,
+                                                          blocks.sub_roi_slices, blocks.sub_rois_offsets)[1]
+                  for a in range(3))
+    if geometry != "all_excluded":
+        assert not regular
+    want, _ = mmo.detect_blobs_blocks(vol, None, [dict(config.roi_profile)], config.resolutions)
+    img5d = stack_detect.Image5d(vol[None])
+    _, _, blobs = stack_detect.detect_blobs_blocks("irregular", img5d, None, None, None, False, False, True, False)
+    if want is None:
+        assert blobs.blobs is None
+    else:
+        assert blobs.blobs is not None and blobs.blobs.shape == want.shape
+        np.testing.assert_array_equal(lexsorted(blobs.blobs), lexsorted(want))

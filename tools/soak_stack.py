@@ -38,10 +38,13 @@ for trial in range(a.trials):
     denoise = None if rng.random() < 0.5 else int(rng.choice([15, 25, 40]))
     iso = (0.96, 1, 1) if (res[0, 0] > 1 and rng.random() < 0.6) else None
     coloc = bool(nch == 2 and rng.random() < 0.6)
+    # spectral unmixing of channel 1 by channel 0 (not built together with the isotropic rescale)
+    unmix = {1: {0: float(rng.choice([0.1, 0.3, 0.6]))}} if (nch == 2 and iso is None and rng.random() < 0.5) else None
+    excl = None if rng.random() < 0.6 else tuple(int(v) for v in rng.integers(0, 6, 3))
     over = dict(segment_size=int(rng.choice([30, 44, 60, 90])), num_sigma=int(rng.integers(2, 6)),
                 min_sigma_factor=float(rng.uniform(2.0, 3.0)), max_sigma_factor=float(rng.uniform(3.0, 5.0)),
                 detection_threshold=float(rng.choice([0.05, 0.1, 0.2])), overlap=float(rng.choice([0.3, 0.5, 0.8])),
-                denoise_size=denoise, isotropic=iso,
+                denoise_size=denoise, isotropic=iso, exclude_border=excl,
                 prune_tol_factor=tuple(float(v) for v in rng.choice([0.5, 1.0, 1.5], 3)))
     config.setup_roi_profiles(["default"] * nch)
     for p in config.roi_profiles:
@@ -50,7 +53,10 @@ for trial in range(a.trials):
     config.resolutions = res
     config.filename = "soak"
     config.near_max = [-1.0] * nch
-    profs = [dict(p) for p in config.roi_profiles]
+    for p in config.roi_profiles:
+        p.spectral_unmixing = unmix
+    config.roi_profile.spectral_unmixing = unmix
+    profs = [dict(p, spectral_unmixing=unmix) for p in config.roi_profiles]
     try:
         want, st = mmo.detect_blobs_blocks(vol, None, profs, res, near_max=config.near_max, coloc=coloc)
         img5d = stack_detect.Image5d(vol[None])
@@ -66,7 +72,7 @@ for trial in range(a.trials):
     rows += 0 if want is None else len(want)
     if not ok:
         bad += 1
-        print("MISMATCH trial", trial, shape, nch, res.tolist(), over, coloc,
+        print("MISMATCH trial", trial, shape, nch, res.tolist(), over, coloc, unmix,
               None if got is None else got.shape, None if want is None else want.shape, flush=True)
 print(f"stack soak seed {a.seed}: {a.trials} trials, {rows} final blob rows compared, {bad} mismatching stacks, "
       f"{time.time() - t0:.0f} s")
