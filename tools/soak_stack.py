@@ -49,6 +49,11 @@ for trial in range(a.trials):
     config.setup_roi_profiles(["default"] * nch)
     for p in config.roi_profiles:
         p.update(over)
+    if nch == 2 and rng.random() < 0.5:      # the second channel detects with its own profile (get_roi_profile(chl))
+        config.roi_profiles[1].update(num_sigma=int(rng.integers(2, 6)), min_sigma_factor=float(rng.uniform(2.0, 3.0)),
+                                      max_sigma_factor=float(rng.uniform(3.0, 5.0)),
+                                      detection_threshold=float(rng.choice([0.05, 0.1, 0.2])),
+                                      overlap=float(rng.choice([0.3, 0.5, 0.8])))
     config.roi_profile.update(over)
     config.resolutions = res
     config.filename = "soak"
