@@ -448,6 +448,7 @@ def test_two_ranks_share_one_volume(gpu, tmp_path):
     r2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     assert r1["n_gpus"] == 1 and r2["n_gpus"] == 2
     assert r1["blobs"] == r2["blobs"] and r1["blobs"] > 100
+    assert r1["table_sha1"] == r2["table_sha1"]          # the same final table, row for row
     assert r2["config"]["blocks_per_rank"] == 2          # 1 x 2 x 2 blocks over two ranks
 
 
