@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised parity soak of detector.detect_blobs (one ROI: channel selection, per-channel profiles,
+spectral unmixing, isotropic rescale, border exclusion) against the oracle, same rows in the same order.
+
+    python tools/soak_detect.py [--trials N] [--seed S]
+"""
+import argparse, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from magellanmapper_amd import config, detector, synth
+from oracle import magmap_oracle as mmo
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--trials", type=int, default=30)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+bad = rows = skipped = 0
+t0 = time.time()
+for trial in range(a.trials):
+    nch = int(rng.choice([1, 2, 3]))
+    four_d = nch > 1 or rng.random() < 0.2           # (z, y, x, 1) ROIs too
+    shape = (int(rng.integers(12, 50)), int(rng.integers(24, 90)), int(rng.integers(24, 90)))
+    chans = [synth.make_volume(int(rng.integers(1 << 30)), shape, int(rng.integers(5, 80)),
+                               blob_sigma=float(rng.uniform(1.5, 3.5)), amp=float(rng.uniform(8000, 50000)))
+             for _ in range(nch)]
+    roi = np.stack(chans, axis=-1) if four_d else chans[0]
+    if rng.random() < 0.2:
+        roi = (roi >> 8).astype(np.uint8)
+    res = np.array([[float(rng.choice([1.0, 2.0, 3.5])), float(rng.choice([1.0, 1.0, 1.3])), 1.0]])
+    channel = None
+    if four_d and rng.random() < 0.5:
+        k = int(rng.integers(1, nch + 1))
+        channel = sorted(int(v) for v in rng.choice(nch, k, replace=False))
+    iso = (0.96, 1, 1) if rng.random() < 0.35 else None
+    config.setup_roi_profiles(["default"] * nch)
+    for p in config.roi_profiles:
+        p.update(num_sigma=int(rng.integers(1, 6)), min_sigma_factor=float(rng.uniform(2.0, 3.0)),
+                 max_sigma_factor=float(rng.uniform(3.0, 5.0)),
+                 detection_threshold=float(rng.choice([0.05, 0.1, 0.2])),
+                 overlap=float(rng.choice([0.3, 0.5, 0.8])), isotropic=iso, denoise_size=None)
+        p.spectral_unmixing = None
+    unmix = None
+    if nch >= 2 and iso is None and rng.random() < 0.5:
+        tgt = int(rng.integers(0, nch))
+        unmix = {tgt: {int(c): float(rng.choice([0.1, 0.4])) for c in range(nch) if c != tgt and rng.random() < 0.7}}
+        for p in config.roi_profiles:
+            p.spectral_unmixing = unmix
+    config.resolutions = res
+    excl = None
+    if rng.random() < 0.4:
+        excl = np.array([rng.integers(0, 5, 3), rng.integers(0, 5, 3)])
+    profs = [dict(p, spectral_unmixing=unmix) for p in config.roi_profiles]
+    try:
+        want = mmo.detect_blobs(roi, channel, profs, res, excl)
+        got = detector.detect_blobs(roi, channel, excl)
+    except NotImplementedError as e:
+        skipped += 1
+        continue
+    ok = (want is None and got is None) or (want is not None and got is not None and got.shape == want.shape
+                                            and np.array_equal(got, want))
+    rows += 0 if want is None else len(want)
+    if not ok:
+        bad += 1
+        print("MISMATCH trial", trial, roi.shape, roi.dtype, res.tolist(), channel, iso, unmix,
+              None if excl is None else excl.tolist(), None if got is None else got.shape,
+              None if want is None else want.shape, flush=True)
+print(f"detect soak seed {a.seed}: {a.trials} trials ({skipped} skipped: not built), {rows} rows compared, "
+      f"{bad} mismatching ROIs, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
