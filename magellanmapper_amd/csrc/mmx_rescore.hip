@@ -20,6 +20,8 @@
 // just streamed by the float32 passes); the work is ~1e5 float64 operations per point and
 // there are ~1e3 points per block, so this costs a few per cent of the float32 passes.
 
+#include <type_traits>
+
 #include "mmx_common.h"
 
 #define MMX_MAX_SIGMAS 64
@@ -47,6 +49,11 @@ __device__ __forceinline__ double corr_at(const double* vals, int st, int R, con
     for (int k = R; k >= 1; --k) acc += (vals[(R - k) * st] + vals[(R + k) * st]) * w[k];
     return (double)(StoreT)acc;
 }
+
+#ifndef MMX_RESCORE_BATCH
+#define MMX_RESCORE_BATCH 8
+#endif
+constexpr int kB = MMX_RESCORE_BATCH;    // taps whose loads are in flight together
 
 template <typename InT, typename StoreT>
 __global__ void __launch_bounds__(MMX_WG)
@@ -89,30 +96,31 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
             const double c = in_scale<InT>::get(col[(int64_t)zr[R] * sz]);
             double a0 = c * w0[0];
             double a2 = c * w2[0];
-            // the taps in SciPy's order (k = R .. 1); the loads of 8 taps are issued before the first is
+            // the taps in SciPy's order (k = R .. 1); the loads of kB taps are issued before the first is
             // used -- a tap-by-tap loop exposes the full memory latency 2R times per column, and that
             // latency, not the arithmetic, was this kernel's time
             int k = R;
-            for (; k >= 8; k -= 8) {
-                InT lo[8], hi[8];
+            auto batch = [&](auto nb) __attribute__((always_inline)) {
+                constexpr int B = decltype(nb)::value;
+                for (; k >= B; k -= B) {
+                    InT lo[B], hi[B];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    lo[j] = col[(int64_t)zr[R - (k - j)] * sz];
-                    hi[j] = col[(int64_t)zr[R + (k - j)] * sz];
-                }
+                    for (int j = 0; j < B; ++j) {
+                        lo[j] = col[(int64_t)zr[R - (k - j)] * sz];
+                        hi[j] = col[(int64_t)zr[R + (k - j)] * sz];
+                    }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double p = in_scale<InT>::get(lo[j]) + in_scale<InT>::get(hi[j]);
-                    a0 += p * w0[k - j];
-                    a2 += p * w2[k - j];
+                    for (int j = 0; j < B; ++j) {
+                        const double p = in_scale<InT>::get(lo[j]) + in_scale<InT>::get(hi[j]);
+                        a0 += p * w0[k - j];
+                        a2 += p * w2[k - j];
+                    }
                 }
-            }
-            for (; k >= 1; --k) {
-                const double p = in_scale<InT>::get(col[(int64_t)zr[R - k] * sz]) +
-                                 in_scale<InT>::get(col[(int64_t)zr[R + k] * sz]);
-                a0 += p * w0[k];
-                a2 += p * w2[k];
-            }
+            };
+            batch(std::integral_constant<int, kB>{});      // then the remainder in halves: no tap-by-tap tail
+            batch(std::integral_constant<int, 4>{});
+            batch(std::integral_constant<int, 2>{});
+            batch(std::integral_constant<int, 1>{});
             zp0[dyi * SW + dxi] = (double)(StoreT)a0;
             zp2[dyi * SW + dxi] = (double)(StoreT)a2;
         }
