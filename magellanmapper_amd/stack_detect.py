@@ -58,8 +58,9 @@ class _TableArena:
     columns) plus the compact columns the pruning step works on.  The per-block tables handed
     out are views of ``store``."""
 
-    def __init__(self, n_cols: int = 11):
+    def __init__(self, n_cols: int = 11, n_expected: int = 0):
         self.n_cols = n_cols
+        self.n_expected = int(n_expected)      # blocks that will be added (0: unknown), for the growth estimate
         self.cap = 4096
         self.store = np.empty((self.cap, n_cols + 3))
         self.zyx = np.empty((self.cap, 3), dtype=np.int32)
@@ -70,6 +71,10 @@ class _TableArena:
 
     def _grow(self, need: int):
         cap = max(2 * self.cap, need)
+        if self.n_expected > len(self.spans) > 0:
+            # blocks hold similar numbers of blobs: size for all of them at once (the last doublings would
+            # otherwise copy a few hundred thousand rows while the GPU has nothing left to hide them)
+            cap = max(cap, int(need * 1.15 * self.n_expected / (len(self.spans) + 1)) + 1024)
         for name in ("store", "zyx", "tag", "abs"):
             old = getattr(self, name)
             new = np.empty((cap,) + old.shape[1:], dtype=old.dtype)
@@ -199,7 +204,7 @@ class StackDetector:
         stats = bl.BatchStats()
         tables = []
         n_extra = (img.shape[3] if len(img.shape) > 3 else 0) if coloc else 0
-        arena = _TableArena(11 + n_extra) if dist.world_size() == 1 else None
+        arena = _TableArena(11 + n_extra, len(mine)) if dist.world_size() == 1 else None
         pos = {i: k for k, i in enumerate(mine)}
 
         def exclude_of(k):
@@ -226,7 +231,7 @@ class StackDetector:
         if arena is None and dist.rank() == 0:
             # several ranks: the pruning rank lays the gathered tables out back to back (grid order)
             # so that merge_blobs and the native prune step take their fast path as on one GPU
-            arena = _TableArena(11 + n_extra)
+            arena = _TableArena(11 + n_extra, len(gathered))
             for i, tbl in gathered:
                 if tbl is not None and len(tbl):
                     arena.add(coords[i], tbl)

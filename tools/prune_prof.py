@@ -2,6 +2,7 @@
 """Line-ish profile of StackPruner.prune_blobs_mp on a realistic table (needs a GPU for the search)."""
 import sys, os, time, inspect, textwrap, re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)) + '/..')
 import numpy as np
 from magellanmapper_amd import config, stack_detect, detector, roi_prof, chunking
 config.resolutions = [[1., 1., 1.]]
@@ -15,6 +16,14 @@ for c in np.ndindex(*grid):
     n = 1290; t = -np.ones((n, 11)); t[:, :3] = rng.integers(lo, hi, (n, 3)); t[:, 3] = 5.2; t[:, 6] = 0; t[:, 7:10] = t[:, :3]; seg[c] = t
 class Img: pass
 Img.shape = shape
+if "--real" in sys.argv:          # tables (and their arena) from a real detection on the benchmark volume
+    import torch
+    from magellanmapper_amd import blob_log as _bl, synth as _synth
+    import bench as _bench
+    config.setup_roi_profiles(None); config.roi_profile.update(_bench.PROFILE)
+    bl = stack_detect.setup_blocks(config.roi_profile, shape)
+    _dv = _bl.DeviceVolume(_synth.make_volume_device(shape, 3, torch.device("cuda", 0)))
+    seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, _dv, bl.sub_roi_slices, bl.sub_rois_offsets, None, None, False, [0])
 src = inspect.getsource(stack_detect.StackPruner.prune_blobs_mp.__func__)
 src = textwrap.dedent(src).replace("@classmethod\n", "")
 # insert a timer call after every statement line at the loop-body indentation levels
