@@ -68,13 +68,27 @@ def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: in
     rows = [np.concatenate((np.full((len(t), 1), i, dtype=np.float64), t), axis=1)
             for i, t in local if t is not None and len(t)]
     mine = np.concatenate(rows) if rows else np.zeros((0, 0))
-    meta = torch.tensor([mine.shape[0], mine.shape[1]], dtype=torch.int64, device=dev)
-    metas = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(n_ranks)]
+    # meta: [rows, wire columns, table columns, one flag per block of the share: 0 = None, 1 = EMPTY table
+    # (a block whose blobs were all excluded: the reference keeps it, and a stack of nothing but such blocks
+    # merges to an empty table, not to None), 2 = rows follow]
+    max_share = -(-n_items // n_ranks)
+    lo = share_bounds(n_items, rank(), n_ranks)[0]
+    tcols = max([t.shape[1] for _, t in local if t is not None] or [0])
+    meta_np = np.zeros(3 + max_share, dtype=np.int64)
+    meta_np[:3] = (mine.shape[0], mine.shape[1], tcols)
+    for i, t in local:
+        meta_np[3 + i - lo] = 0 if t is None else (2 if len(t) else 1)
+    meta = torch.from_numpy(meta_np).to(dev)
+    metas = [torch.zeros_like(meta) for _ in range(n_ranks)]
     tdist.all_gather(metas, meta)
     metas = [m.cpu().numpy() for m in metas]
     max_rows = int(max(m[0] for m in metas))
     n_cols = int(max(m[1] for m in metas))
     out: List[Tuple[int, Optional[np.ndarray]]] = []
+    for r, m in enumerate(metas):
+        lo_r = share_bounds(n_items, r, n_ranks)[0]
+        for pos in np.nonzero(m[3:] == 1)[0]:
+            out.append((lo_r + int(pos), np.zeros((0, int(m[2])))))
     if max_rows and n_cols:
         padded = np.zeros((max_rows, n_cols))
         padded[:mine.shape[0], :mine.shape[1]] = mine

@@ -29,6 +29,8 @@ def test_share_bounds_cover_everything():
 def _tables_for(i):
     rng = np.random.default_rng(100 + i)
     n = int(rng.integers(0, 5))
+    if i % 5 == 3:
+        return np.zeros((0, 11))       # a block whose blobs were all excluded: EMPTY, not None
     return None if n == 0 else rng.integers(0, 50, (n, 11)).astype(np.float64) + 0.25 * i
 
 
@@ -48,6 +50,7 @@ def _worker(rank, world, port, n_items, out_dir):
             if want is None:
                 assert t is None
             else:
+                assert t is not None and t.shape == want.shape      # (0, 11) tables survive the gather
                 np.testing.assert_array_equal(t, want)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(len(mine)))
     finally:
