@@ -122,7 +122,7 @@ def main():
         cores = max(1, min(os.cpu_count() or 1, 16))
         by = max(1, min(shape[1] // 256, int(np.sqrt(cores))))
         bx = max(1, min(shape[2] // 256, cores // by))
-        sz = min(128, shape[0])
+        sz = min(320, shape[0])       # two z-layers of blocks: the sample prunes seams along all three axes
         sample = _synth.make_volume_device((sz, 256 * by, 256 * bx), SEED, torch.device("cpu"))
         sample = sample.to(torch.int32).numpy().astype(np.uint16)
         cpu_final, t_det, t_tot, n_jobs = cpu_baseline(sample, cores)
