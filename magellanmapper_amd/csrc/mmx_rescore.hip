@@ -79,9 +79,11 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     double* zp0 = smem;                 // [N][SW]  axis-0 sums, order-0 kernel
     double* zp2 = zp0 + (size_t)N * SW; // [N][SW]  axis-0 sums, order-2 kernel
     double* yp = zp2 + (size_t)N * SW;  // [3][N]   axis-1 sums of the three terms
-    int* zr = (int*)(yp + 3 * (size_t)N);  // [N] reflected z indices
+    // [N] element offsets of the reflected z planes (as 64-bit products once per point: a 64-bit integer
+    // multiply per load would cost as much issue time as the float64 arithmetic of the tap)
+    int64_t* zr = (int64_t*)(yp + 3 * (size_t)N);
 
-    for (int k = threadIdx.x; k < N; k += MMX_WG) zr[k] = mmx_reflect(pt.z + k - R, bd.nz);
+    for (int k = threadIdx.x; k < N; k += MMX_WG) zr[k] = (int64_t)mmx_reflect(pt.z + k - R, bd.nz) * sz;
     __syncthreads();
 
     for (int dx0 = 0; dx0 < N; dx0 += SW) {
@@ -93,7 +95,7 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
             const int yy = mmx_reflect(pt.y + dyi - R, bd.ny);
             const int xx = mmx_reflect(pt.x + dx0 + dxi - R, bd.nx);
             const InT* col = in + (int64_t)yy * sy + (int64_t)xx * sx;
-            const double c = in_scale<InT>::get(col[(int64_t)zr[R] * sz]);
+            const double c = in_scale<InT>::get(col[zr[R]]);
             double a0 = c * w0[0];
             double a2 = c * w2[0];
             // the taps in SciPy's order (k = R .. 1); the loads of kB taps are issued before the first is
@@ -106,8 +108,8 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
                     InT lo[B], hi[B];
 #pragma unroll
                     for (int j = 0; j < B; ++j) {
-                        lo[j] = col[(int64_t)zr[R - (k - j)] * sz];
-                        hi[j] = col[(int64_t)zr[R + (k - j)] * sz];
+                        lo[j] = col[zr[R - (k - j)]];
+                        hi[j] = col[zr[R + (k - j)]];
                     }
 #pragma unroll
                     for (int j = 0; j < B; ++j) {
@@ -184,7 +186,7 @@ extern "C" int mmx_rescore_f64(const mmx_volume* vol, const mmx_block* d_blocks,
     prm.n_blocks = n_blocks;
     const int N = 2 * rmax + 1;
     const size_t budget = 60 * 1024;
-    const size_t fixed = (size_t)3 * N * sizeof(double) + (size_t)N * sizeof(int) + 16;
+    const size_t fixed = (size_t)3 * N * sizeof(double) + (size_t)N * sizeof(int64_t) + 16;
     int strip = (int)((budget - fixed) / ((size_t)2 * N * sizeof(double)));
     if (strip < 1) return MMX_ERR_UNSUPPORTED;
     if (strip > N) strip = N;
