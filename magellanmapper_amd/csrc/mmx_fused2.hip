@@ -288,7 +288,16 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
 #ifdef ZX2_PROFILE
         long long tw = 0, tb;
 #endif
-#pragma unroll 1
+        // this lane's item of the first round is the same in every group: its row, tile offset and output
+        // offset are computed once (one round per wave is the common case: 576 items, 9 waves) -- the 64-bit
+        // address products are quarter-rate instructions
+        const int item0 = ord * 64 + lane;
+        const int r0 = (int)(((float)item0 + 0.5f) * inv_ch);        // item < 2^12: exact
+        const int c0 = item0 - r0 * CH;
+        const int lds0 = r0 * PW + pad2(xg::S - R - xg::LEAD + c0 * kT);
+        int64_t o0 = sbase + (int64_t)r0 * plane + c0 * kT;           // + z0 * plane, advanced per group
+        constexpr int kB0 = (xg::S - R - xg::LEAD) & 3;              // chunks start at multiples of 4 columns:
+#pragma unroll 1                                                     // pad2(base + i) - pad2(base) is a constant
         for (int g = 0; g <= ngroups; ++g) {
 #ifdef ZX2_PROFILE
             tb = wall_clock64();
@@ -298,40 +307,45 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
                 const int z0 = (g - 1) * kG;
                 for (int first = ord * 64; first < nitems; first += nct) {     // one round per wave for px = 288
                     const int item = first + lane;
-                    const int r = (int)(((float)item + 0.5f) * inv_ch);     // item < 2^12: exact
-                    const int c = item - r * CH;
+                    int r = r0, lds_at = lds0;
+                    int64_t o = o0;
+                    if (first != ord * 64) {                    // further rounds (rows wider than 288 floats)
+                        r = (int)(((float)item + 0.5f) * inv_ch);
+                        const int c = item - r * CH;
+                        lds_at = r * PW + pad2(xg::S - R - xg::LEAD + c * kT);
+                        o = sbase + (int64_t)(z0 + r) * plane + c * kT;
+                    }
                     if (item < nitems && z0 + r < nz) {       // (no `continue`: all lanes meet again at the loop top)
                     v2f win[xg::WIN];
-                    const int base = xg::S - R - xg::LEAD + c * kT;      // even
-                    const v2f* pr = rows + r * PW;
+                    const v2f* pr = rows + lds_at;
 #pragma unroll
                     for (int i = 0; i < xg::WIN; i += 2) {
-                        const float4 v = *reinterpret_cast<const float4*>(pr + pad2(base + i));
+                        const float4 v = *reinterpret_cast<const float4*>(pr + (pad2(kB0 + i) - pad2(kB0)));
                         win[i] = (v2f){v.x, v.y};
                         win[i + 1] = (v2f){v.z, v.w};
                     }
                     float P[kT], Q[kT];
 #pragma unroll
-                    for (int o = 0; o < kT; ++o) {
-                        const v2f cc = win[xg::LEAD + o + R];
+                    for (int oo = 0; oo < kT; ++oo) {
+                        const v2f cc = win[xg::LEAD + oo + R];
                         v2f ps = cc * T.xw0[0];                 // (G(x) Gz, G(x) Gzz)
                         float q = cc.x * T.xw2[0];              // G''(x) Gz
 #ifndef ZX2_SKIP_CONS
 #pragma unroll
                         for (int k = 1; k <= R; ++k) {
-                            const v2f sm = win[xg::LEAD + o + R - k] + win[xg::LEAD + o + R + k];
+                            const v2f sm = win[xg::LEAD + oo + R - k] + win[xg::LEAD + oo + R + k];
                             ps = __builtin_elementwise_fma(sm, T.xw0[k], ps);
                             q = fmaf(sm.x, T.xw2[k], q);
                         }
 #endif
-                        P[o] = ps.x;
-                        Q[o] = ps.y + q;
+                        P[oo] = ps.x;
+                        Q[oo] = ps.y + q;
                     }
-                    const int64_t o = sbase + (int64_t)(z0 + r) * plane + c * kT;
                     *reinterpret_cast<float4*>(gp + o) = make_float4(P[0], P[1], P[2], P[3]);
                     *reinterpret_cast<float4*>(gq + o) = make_float4(Q[0], Q[1], Q[2], Q[3]);
                     }
                 }
+                o0 += (int64_t)kG * plane;
             }
 #ifdef ZX2_PROFILE
             tw += wall_clock64() - tb;
