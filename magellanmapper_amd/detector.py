@@ -437,11 +437,13 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
             # x -= fac * roi[..., k]; x[x < 0] = 0 for every entry of this channel (:910-921)
             subtract = [(k, f) for spec_chl, spec in spectral_unmixing.items() if spec_chl == chl
                         for k, f in spec.items()]
-            if subtract and isotropic is not None:
-                raise NotImplementedError("spectral unmixing of isotropically rescaled blocks is not built")
             if subtract:
                 from . import preprocess
-                source = preprocess.Unmixer(subtract, denoise_max_shape)
+                if isotropic is not None:       # resize every channel first, then unmix the resized ones
+                    source = preprocess.Unmixer(subtract, denoise_max_shape, rescale=(iso_factor, channels))
+                    source.set_blocks(origins, shapes, log_shapes)
+                else:
+                    source = preprocess.Unmixer(subtract, denoise_max_shape)
                 source._raw_scale = (float(np.iinfo(dvol.np_dtype).max) if dvol.np_dtype.kind in "ui"
                                      else dvol.value_scale())
         scaling_factor = calc_scaling_factor()[2]          # x scaling alone, as the reference

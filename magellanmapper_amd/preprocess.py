@@ -334,16 +334,28 @@ class Unmixer:
     ``detect_sub_roi`` before ``detect_blobs`` unmixes it).  Same ``run`` contract as
     :class:`Preprocessor`, so ``blob_log_blocks`` takes either."""
 
-    def __init__(self, subtract: Sequence[Tuple[int, float]], denoise_max_shape=None, near_max=None):
+    def __init__(self, subtract: Sequence[Tuple[int, float]], denoise_max_shape=None, near_max=None,
+                 rescale=None):
+        """``rescale = (isotropic factor, channels of the detection)``: the profile's isotropic rescale comes
+        first (the reference resizes the whole multichannel block, then unmixes the resized channels:
+        detector.py:893-921), so every channel involved goes through its own :class:`Rescaler`."""
         self.subtract = [(int(k), float(f)) for k, f in subtract]
         self.dms = None if denoise_max_shape is None else [int(v) for v in denoise_max_shape]
         self.near_max = near_max
+        self.rescale = rescale
+        self._rs: Dict[int, "Rescaler"] = {}
+        self._blocks_args = None
         self._pres: Dict[int, Preprocessor] = {}
         self._out64 = [None, None]
         self._out32 = None
 
+    def set_blocks(self, origins, shapes, new_shapes) -> None:
+        self._blocks_args = (origins, shapes, new_shapes)
+
     def bytes_per_voxel(self) -> int:
         n_src = 1 + len({k for k, _ in self.subtract})
+        if self.rescale is not None:
+            return 20 + n_src * (20 + (0 if self.dms is None else 20 * len(self.rescale[1])))
         return 20 + (0 if self.dms is None else 20 * n_src)
 
     def value_scale(self, channels: Sequence[int]) -> float:
@@ -363,7 +375,18 @@ class Unmixer:
         for k, _ in self.subtract:
             if not 0 <= k < dvol.n_channels:
                 raise IndexError(f"index {k} is out of bounds for axis 3 with size {dvol.n_channels}")
-        if self.dms is None:
+        if self.rescale is not None:
+            views = {}
+            for c in [channel] + [k for k, _ in self.subtract]:
+                if c not in views:
+                    rs = self._rs.get(c)
+                    if rs is None:
+                        rs = self._rs[c] = Rescaler(self.rescale[0], self.rescale[1], self.dms, self.near_max)
+                    rs.set_blocks(*self._blocks_args)
+                    blocks_src, _, _, views[c] = rs.run(dvol, c, origins, shapes, 0)
+            main = views[channel]
+            subs = [views[k] for k, _ in self.subtract]
+        elif self.dms is None:
             blocks_src, _ = bl._make_blocks(dvol, 0, origins, shapes)
             main = dvol.view(channel, False)
             subs = [dvol.view(k, False) for k, _ in self.subtract]

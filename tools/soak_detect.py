@@ -41,7 +41,7 @@ for trial in range(a.trials):
                  overlap=float(rng.choice([0.3, 0.5, 0.8])), isotropic=iso, denoise_size=None)
         p.spectral_unmixing = None
     unmix = None
-    if nch >= 2 and iso is None and rng.random() < 0.5:
+    if nch >= 2 and rng.random() < 0.5:
         tgt = int(rng.integers(0, nch))
         unmix = {tgt: {int(c): float(rng.choice([0.1, 0.4])) for c in range(nch) if c != tgt and rng.random() < 0.7}}
         for p in config.roi_profiles:

@@ -38,8 +38,8 @@ for trial in range(a.trials):
     denoise = None if rng.random() < 0.5 else int(rng.choice([15, 25, 40]))
     iso = (0.96, 1, 1) if (res[0, 0] > 1 and rng.random() < 0.6) else None
     coloc = bool(nch == 2 and rng.random() < 0.6)
-    # spectral unmixing of channel 1 by channel 0 (not built together with the isotropic rescale)
-    unmix = {1: {0: float(rng.choice([0.1, 0.3, 0.6]))}} if (nch == 2 and iso is None and rng.random() < 0.5) else None
+    # spectral unmixing of channel 1 by channel 0 (also on isotropically rescaled blocks)
+    unmix = {1: {0: float(rng.choice([0.1, 0.3, 0.6]))}} if (nch == 2 and rng.random() < 0.5) else None
     excl = None if rng.random() < 0.6 else tuple(int(v) for v in rng.integers(0, 6, 3))
     over = dict(segment_size=int(rng.choice([30, 44, 60, 90])), num_sigma=int(rng.integers(2, 6)),
                 min_sigma_factor=float(rng.uniform(2.0, 3.0)), max_sigma_factor=float(rng.uniform(3.0, 5.0)),
