@@ -439,7 +439,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
         store_f32 = 1 if dvol.np_dtype == np.float32 else 0
     else:
         blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
-        store_f32 = 0
+        store_f32 = int(getattr(pre, "store_f32", 0))
     nb, ns = len(blocks), len(space.sigmas)
     if slot >= (1 << 29):
         raise nat.MmxError("block too large for one workspace slot (>= 2^29 voxels)")

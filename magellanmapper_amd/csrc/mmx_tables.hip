@@ -556,7 +556,8 @@ extern "C" int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d
             if (!d_out32) return MMX_ERR_ARG;
             MMX_RS_LAUNCH(double, double, d_out32);
             break;
-        default: return MMX_ERR_UNSUPPORTED;   // float32 images: SciPy interpolates into a float32 array
+        case MMX_F32: MMX_RS_LAUNCH(float, float, (float*)nullptr); break;    // SciPy's float32 output array
+        default: return MMX_ERR_UNSUPPORTED;
     }
 #undef MMX_RS_LAUNCH
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;

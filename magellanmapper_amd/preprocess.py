@@ -557,7 +557,8 @@ class Rescaler:
                 for o, n in zip(origins, new_shp)]
         # ---- sources: the block as detect_blobs receives it, every channel (for the clip range)
         if self.dms is None:
-            if dvol.np_dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float64)):
+            if dvol.np_dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float32),
+                                     np.dtype(np.float64)):
                 raise NotImplementedError(f"isotropic rescale of {dvol.np_dtype} images is not built")
             blocks_src, _ = bl._make_blocks(dvol, 0, origins, orig)
             views = {c: dvol.view(c, False) for c in range(dvol.n_channels)}
@@ -609,7 +610,9 @@ class Rescaler:
             vol_exact = nat.Volume(out.data_ptr(), nat.MMX_F64, 0, dst_sz, dst_sy, 1)
             o32 = out32.data_ptr()
         else:
-            tdt = torch.uint8 if src.dtype == nat.MMX_U8 else torch.uint16
+            # integer images come back in their own type; float32 images as float32 (SciPy interpolates in
+            # double and stores into a float32 array; detection then runs in float32 like the reference's)
+            tdt = {nat.MMX_U8: torch.uint8, nat.MMX_U16: torch.uint16, nat.MMX_F32: torch.float32}[src.dtype]
             out = self._buffer("_out", which, nb * slot_pre, tdt, dev)
             if out.dtype != tdt:
                 self._out[which] = out = torch.empty(nb * slot_pre, dtype=tdt, device=dev)
@@ -626,7 +629,7 @@ class Rescaler:
             blocks[i] = (i * slot_pre, new_shp[i, 0], new_shp[i, 1], new_shp[i, 2], i, px, 0)
             slot = max(slot, int(new_shp[i, 0]) * int(new_shp[i, 1]) * px)
         self.last_geometry = (slot_pre, dst_sz, dst_sy, out, None)
-        self.store_f32 = 0
+        self.store_f32 = 1 if src.dtype == nat.MMX_F32 else 0      # the cube of a float32 image is float32
         return blocks, slot, vol32, vol_exact
 
     fetch = Preprocessor.fetch

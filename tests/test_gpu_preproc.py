@@ -301,3 +301,27 @@ def test_unmixing_of_isotropically_rescaled_blocks(gpu, env, denoise):
         p.spectral_unmixing = None
     assert want is not None and len(want) > 20
     np.testing.assert_array_equal(got, want)
+
+
+def test_isotropic_rescale_of_float32_images(gpu):
+    """A float32 image is interpolated in double and stored into a float32 array (SciPy), clipped to its own
+    range, and detected in float32 like the reference's float32 cube: rescale and detection vs the oracle."""
+    from magellanmapper_amd import config, detector, preprocess, synth
+    from oracle import isotropic_oracle, magmap_oracle as mmo
+    rng = np.random.default_rng(8)
+    roi = (synth.make_volume(5, (18, 50, 47), 30, blob_sigma=2.0) / 65535.0).astype(np.float32)
+    for scale, res in (((0.96, 1, 1), (3.0, 1.0, 1.0)), ((1, 1, 1), (2.0, 1.5, 1.0))):
+        got = preprocess.make_isotropic(roi, scale, np.array(res))
+        want = isotropic_oracle.make_isotropic(roi, scale, np.array(res))
+        assert got.dtype == np.float32 and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(isotropic=(0.96, 1, 1), denoise_size=None, num_sigma=3)
+    config.resolutions = np.array([[2.5, 1.0, 1.0]])
+    want = mmo.detect_blobs(roi, None, [dict(config.roi_profile)], config.resolutions)
+    got = detector.detect_blobs(roi, None)
+    assert want is not None and len(want) > 10
+    np.testing.assert_array_equal(got, want)
+    roi2 = np.stack([roi, (roi * rng.random(roi.shape)).astype(np.float32)], axis=-1)
+    want = mmo.detect_blobs(roi2, None, [dict(config.roi_profile)], config.resolutions)
+    np.testing.assert_array_equal(detector.detect_blobs(roi2, None), want)

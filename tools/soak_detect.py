@@ -25,8 +25,11 @@ for trial in range(a.trials):
                                blob_sigma=float(rng.uniform(1.5, 3.5)), amp=float(rng.uniform(8000, 50000)))
              for _ in range(nch)]
     roi = np.stack(chans, axis=-1) if four_d else chans[0]
-    if rng.random() < 0.2:
+    kind = rng.random()
+    if kind < 0.2:
         roi = (roi >> 8).astype(np.uint8)
+    elif kind < 0.4:
+        roi = (roi / 65535.0).astype(np.float32)
     res = np.array([[float(rng.choice([1.0, 2.0, 3.5])), float(rng.choice([1.0, 1.0, 1.3])), 1.0]])
     channel = None
     if four_d and rng.random() < 0.5:
