@@ -68,6 +68,7 @@ class _TableArena:
         self.abs = np.empty((self.cap, 3))
         self.n = 0
         self.spans = {}
+        self.chan_lo, self.chan_hi = np.inf, -np.inf       # range of the channel column over all rows
 
     def _grow(self, need: int):
         cap = max(2 * self.cap, need)
@@ -92,6 +93,9 @@ class _TableArena:
         self.zyx[a:a + rows] = table[:, :3]
         self.tag[a:a + rows] = coord
         self.abs[a:a + rows] = table[:, 7:10]
+        if rows:
+            self.chan_lo = min(self.chan_lo, table[:, 6].min())
+            self.chan_hi = max(self.chan_hi, table[:, 6].max())
         self.n += rows
         self.spans[tuple(coord)] = (a, a + rows)
 
@@ -579,7 +583,10 @@ class StackPruner:
         lib = nat.lib()
         pieces = []
         for chl in channels:
-            cur = np.ascontiguousarray(np.nonzero(np.isin(chan, chl))[0], dtype=np.int64)  # row ids, table order
+            if arena is not None and arena.chan_lo == arena.chan_hi == chl:      # one channel: every row
+                cur = np.arange(len(chan), dtype=np.int64)
+            else:
+                cur = np.ascontiguousarray(np.nonzero(np.isin(chan, chl))[0], dtype=np.int64)  # row ids, table order
             for axis in range(3):
                 n_sections = sub_rois_offsets.shape[axis]
                 if n_sections <= 1:
