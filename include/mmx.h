@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 7
+#define MMX_ABI_VERSION 8
 
 typedef enum {
     MMX_OK = 0,
@@ -312,6 +312,24 @@ int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d_blocks,
                      const int32_t* d_index, const double* d_weight, const double* d_minmax,
                      int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
                      void* d_out, float* d_out32, void* stream);
+
+/* The same with the result's voxel type given explicitly (MMX_U8 / MMX_U16 from a float64 source: the
+ * anti-aliased path below; otherwise out_dtype must equal vol->dtype). */
+int mmx_resize_batch_as(const mmx_volume* vol, const mmx_resize_block* d_blocks,
+                        const mmx_resize_block* h_blocks, int n_blocks,
+                        const int32_t* d_index, const double* d_weight, const double* d_minmax,
+                        int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                        int out_dtype, void* d_out, float* d_out32, void* stream);
+
+/* Anti-aliasing ahead of a down-sampling resize (skimage.transform.resize, anti_aliasing=True ->
+ * scipy.ndimage.gaussian_filter(image.astype(float), (factor - 1) / 2, mode='mirror' | 'nearest')): ONE exact
+ * float64 correlate1d pass along `axis` for every block; block b uses d_weights[b * w_pitch + 0..d_radius[b]]
+ * (half kernel, weight at distance k) -- a truncated block has its own zoom factor.  vol: uint8 / uint16 /
+ * float64 at any strides (d_blocks[b].src_off); d_out: float64 [n_blocks][dst_slot], strides (dst_sz, dst_sy, 1). */
+int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
+                         int n_blocks, int axis, const double* d_weights, const int32_t* d_radius,
+                         int w_pitch, int nearest, int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                         double* d_out, void* stream);
 
 /* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream.
  * mmx_timing_enable(1) makes every kernel launch of this library record a HIP event

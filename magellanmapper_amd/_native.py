@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 7
+MMX_ABI_VERSION = 8
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -75,7 +75,7 @@ SYMBOLS = (
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
-    "mmx_coloc_means", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
+    "mmx_coloc_means", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass", "preproc", "coloc")
@@ -130,6 +130,12 @@ def lib() -> ctypes.CDLL:
     L.mmx_resize_batch.argtypes = [POINTER(Volume), vp, vp, c_int, vp, vp, vp, c_int64, c_int64, c_int64,
                                    vp, vp, vp]
     L.mmx_resize_batch.restype = c_int
+    L.mmx_resize_batch_as.argtypes = [POINTER(Volume), vp, vp, c_int, vp, vp, vp, c_int64, c_int64, c_int64,
+                                      c_int, vp, vp, vp]
+    L.mmx_resize_batch_as.restype = c_int
+    L.mmx_gauss_axis_batch.argtypes = [POINTER(Volume), vp, vp, c_int, c_int, vp, vp, c_int, c_int,
+                                       c_int64, c_int64, c_int64, vp, vp]
+    L.mmx_gauss_axis_batch.restype = c_int
     L.mmx_unmix_batch.argtypes = [POINTER(Volume), POINTER(Volume), POINTER(c_double), c_int, vp, vp, c_int,
                                   c_int64, c_int64, c_int64, vp, vp, vp]
     L.mmx_unmix_batch.restype = c_int

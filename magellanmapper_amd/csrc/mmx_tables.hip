@@ -524,11 +524,103 @@ extern "C" int mmx_minmax_batch(const mmx_volume* vol, const mmx_block* d_blocks
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
+// ---- anti-aliasing ahead of a down-sampling resize: one exact float64 correlate1d pass along one axis,
+// SciPy's symmetric branch (acc = in[c] w[0]; k = R .. 1: acc += (in[c-k] + in[c+k]) w[k]; no FMA), 'mirror'
+// (d c b | a b c d | c b a) or 'nearest' extension, weights and radius per block (a truncated block has its
+// own zoom factor).  Source: any supported voxel type at the volume's strides; output: float64 block slots.
+namespace {
+template <typename InT>
+__global__ void __launch_bounds__(MMX_WG)
+gauss_axis_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
+                  const mmx_block* __restrict__ blocks, int axis, const double* __restrict__ weights,
+                  const int32_t* __restrict__ radius, int w_pitch, int nearest,
+                  int64_t dst_slot, int64_t dst_sy, int64_t dst_sz, double* __restrict__ out)
+{
+    const mmx_block bd = blocks[blockIdx.y];
+    const int rows = bd.nz * bd.ny;
+    const InT* src = vol + bd.src_off;
+    const double* w = weights + (int64_t)blockIdx.y * w_pitch;
+    const int R = radius[blockIdx.y];
+    const int n = axis == 0 ? bd.nz : (axis == 1 ? bd.ny : bd.nx);
+    const int64_t st = axis == 0 ? sz : (axis == 1 ? sy : sx);
+    const int period = 2 * n - 2;
+    auto ext = [&](int i) {
+        if (n == 1) return 0;
+        if (nearest) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+        int m = i % period;
+        if (m < 0) m += period;
+        return m >= n ? period - m : m;
+    };
+    const int lane = threadIdx.x & 63;
+    constexpr int WPG = MMX_WG / 64;
+    for (int row = (int)blockIdx.x * WPG + ((int)threadIdx.x >> 6); row < rows; row += (int)gridDim.x * WPG) {
+        const int z = row / bd.ny, y = row - z * bd.ny;
+        for (int x = lane; x < bd.nx; x += 64) {
+            const int c = axis == 0 ? z : (axis == 1 ? y : x);
+            const InT* line = src + (int64_t)z * sz + (int64_t)y * sy + (int64_t)x * sx - (int64_t)c * st;
+            double acc = (double)line[(int64_t)c * st] * w[0];
+            for (int k = R; k >= 1; --k) {
+                const double p = (double)line[(int64_t)ext(c - k) * st] + (double)line[(int64_t)ext(c + k) * st];
+                acc += p * w[k];
+            }
+            out[(int64_t)bd.slot * dst_slot + (int64_t)z * dst_sz + (int64_t)y * dst_sy + x] = acc;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
+                                    int n_blocks, int axis, const double* d_weights, const int32_t* d_radius,
+                                    int w_pitch, int nearest, int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                                    double* d_out, void* stream)
+{
+    if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || axis < 0 || axis > 2 || !d_weights ||
+        !d_radius || w_pitch < 1 || !d_out)
+        return MMX_ERR_ARG;
+    int64_t max_rows = 1;
+    for (int i = 0; i < n_blocks; ++i)
+        max_rows = std::max<int64_t>(max_rows, (int64_t)h_blocks[i].nz * h_blocks[i].ny);
+    if (max_rows >= (int64_t(1) << 30)) return MMX_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)std::min<int64_t>((max_rows + 15) / 16, 65535), (unsigned)n_blocks);
+    mmx_timed_scope ts(MMX_K_GENERIC, s);
+#define MMX_GA_LAUNCH(T)                                                                                    \
+    hipLaunchKernelGGL(gauss_axis_kernel<T>, grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z, \
+                       vol->stride_y, vol->stride_x, d_blocks, axis, d_weights, d_radius, w_pitch, nearest, \
+                       dst_slot, dst_sy, dst_sz, d_out)
+    switch (vol->dtype) {
+        case MMX_U8: MMX_GA_LAUNCH(uint8_t); break;
+        case MMX_U16: MMX_GA_LAUNCH(uint16_t); break;
+        case MMX_F64: MMX_GA_LAUNCH(double); break;
+        default: return MMX_ERR_UNSUPPORTED;   // float32 images: SciPy filters in float32 (not built)
+    }
+#undef MMX_GA_LAUNCH
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+extern "C" int mmx_resize_batch_as(const mmx_volume* vol, const mmx_resize_block* d_blocks,
+                                   const mmx_resize_block* h_blocks, int n_blocks,
+                                   const int32_t* d_index, const double* d_weight, const double* d_minmax,
+                                   int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                                   int out_dtype, void* d_out, float* d_out32, void* stream);
+
 extern "C" int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d_blocks,
                                 const mmx_resize_block* h_blocks, int n_blocks,
                                 const int32_t* d_index, const double* d_weight, const double* d_minmax,
                                 int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
                                 void* d_out, float* d_out32, void* stream)
+{
+    return mmx_resize_batch_as(vol, d_blocks, h_blocks, n_blocks, d_index, d_weight, d_minmax, dst_slot, dst_sy,
+                               dst_sz, vol ? vol->dtype : -1, d_out, d_out32, stream);
+}
+
+// out_dtype: the voxel type of the result (.astype(dtype) of the reference: truncation for integers).  It is
+// the source's type, except after the anti-aliasing filter, whose float64 output stands in for an integer image.
+extern "C" int mmx_resize_batch_as(const mmx_volume* vol, const mmx_resize_block* d_blocks,
+                                   const mmx_resize_block* h_blocks, int n_blocks,
+                                   const int32_t* d_index, const double* d_weight, const double* d_minmax,
+                                   int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
+                                   int out_dtype, void* d_out, float* d_out32, void* stream)
 {
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || !d_index || !d_weight ||
         !d_minmax || !d_out)
@@ -549,7 +641,10 @@ extern "C" int mmx_resize_batch(const mmx_volume* vol, const mmx_resize_block* d
     hipLaunchKernelGGL((resize_kernel<T, O>), grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z, \
                        vol->stride_y, vol->stride_x, d_blocks, d_index, d_weight, d_minmax, dst_slot,        \
                        dst_sy, dst_sz, (O*)d_out, O32)
-    switch (vol->dtype) {
+    if (vol->dtype == MMX_F64 && out_dtype == MMX_U8) { MMX_RS_LAUNCH(double, uint8_t, (float*)nullptr); }
+    else if (vol->dtype == MMX_F64 && out_dtype == MMX_U16) { MMX_RS_LAUNCH(double, uint16_t, (float*)nullptr); }
+    else if (out_dtype != vol->dtype) return MMX_ERR_UNSUPPORTED;
+    else switch (vol->dtype) {
         case MMX_U8: MMX_RS_LAUNCH(uint8_t, uint8_t, (float*)nullptr); break;
         case MMX_U16: MMX_RS_LAUNCH(uint16_t, uint16_t, (float*)nullptr); break;
         case MMX_F64:

@@ -521,19 +521,20 @@ class Rescaler:
         self._orig: Dict[Tuple[Tuple[int, ...], Tuple[int, ...]], Tuple[int, int, int]] = {}
         self._out = [None, None]
         self._out32 = None
+        self._aa0 = self._aa1 = None          # ping-pong buffers of the anti-aliasing passes
         self._scale = 1.0
 
     def set_blocks(self, origins, shapes, new_shapes) -> None:
         for o, s, n in zip(origins, shapes, new_shapes):
             s, n = tuple(int(v) for v in s), tuple(int(v) for v in n)
-            for a in range(3):
-                if n[a] < s[a]:
-                    sigma = (s[a] / n[a] - 1) / 2
-                    if int(4.0 * sigma + 0.5) > 0:
-                        raise NotImplementedError(
-                            "down-sampling by more than 25 % switches scikit-image's anti-aliasing filter on: "
-                            "not built (isotropic factors < 0.8)")
             self._orig[(tuple(int(v) for v in o), n)] = s
+
+    @staticmethod
+    def aa_radius(n_in: int, n_out: int) -> Tuple[float, int]:
+        """``(sigma, radius)`` of scikit-image's anti-aliasing Gaussian along one axis (``resize`` with the default
+        ``anti_aliasing``: sigma = max(0, (n_in / n_out - 1) / 2), SciPy's ``truncate=4``)."""
+        sigma = max(0.0, (n_in / n_out - 1) / 2)
+        return sigma, int(4.0 * sigma + 0.5)
 
     def bytes_per_voxel(self) -> int:
         # resized copies (2 x float64 + float32, or 2 x uint16) + the preprocessed sources of all channels
@@ -577,6 +578,52 @@ class Rescaler:
         for c in sorted(views):
             nat.check(L.mmx_minmax_batch(ctypes.byref(views[c]), d_src.data_ptr(), blocks_src.ctypes.data, nb,
                                          d_mm.data_ptr(), stream), "mmx_minmax_batch")
+        # ---- anti-aliasing: a block that shrinks along any axis is first smoothed along its shrinking axes
+        # (skimage.transform.resize -> ndi.gaussian_filter(image.astype(float), (factor - 1) / 2, mode=...)),
+        # axis by axis in SciPy's order, exact float64; the resize below then reads the smoothed copy
+        src = views[channel]
+        out_code = src.dtype
+        aa = [[self.aa_radius(orig[i][a], int(new_shp[i, a])) if any(int(new_shp[i, b]) < orig[i][b] for b in range(3))
+               else (0.0, 0) for a in range(3)] for i in range(nb)]
+        if any(r > 0 for blk in aa for _, r in blk):
+            if src.dtype == nat.MMX_F32:
+                raise NotImplementedError("anti-aliased down-sampling of float32 images is not built")
+            from . import kernels1d as k1
+            oshp = np.asarray(orig, dtype=np.int64).reshape(nb, 3)
+            asx = int(-(-oshp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
+            a_sy, a_sz = asx, asx * int(oshp[:, 1].max())
+            a_slot = a_sz * int(oshp[:, 0].max())
+            cur_vol, cur_blocks, cur_dblocks = src, blocks_src, d_src
+            keep = []
+            for a in range(3):
+                radii = np.array([aa[i][a][1] for i in range(nb)], dtype=np.int32)
+                if not radii.any():
+                    continue
+                pitch = int(radii.max()) + 1
+                wts = np.zeros((nb, pitch))
+                for i in range(nb):
+                    # (radius 0: SciPy's one-tap kernel is exactly [1.0]: the pass copies)
+                    wts[i, :radii[i] + 1] = (k1.gaussian_half_kernel(aa[i][a][0], 0, int(radii[i])) if radii[i]
+                                             else [1.0])
+                edge = np.array([min(orig[i]) == 1 or (dvol.multichannel and dvol.n_channels == 1)
+                                 for i in range(nb)])
+                if edge.any() and not edge.all():
+                    raise NotImplementedError("anti-aliasing of a batch mixing unit-thick and regular blocks")
+                buf = self._buffer("_aa%d" % (len(keep) & 1), None, nb * a_slot, torch.float64, dev)
+                d_w = torch.from_numpy(wts.reshape(-1)).to(dev)
+                d_r = torch.from_numpy(radii).to(dev)
+                nat.check(L.mmx_gauss_axis_batch(ctypes.byref(cur_vol), cur_dblocks.data_ptr(), cur_blocks.ctypes.data,
+                                                 nb, a, d_w.data_ptr(), d_r.data_ptr(), pitch, int(edge.all()),
+                                                 a_slot, a_sy, a_sz, buf.data_ptr(), stream), "mmx_gauss_axis_batch")
+                nxt = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
+                for i in range(nb):
+                    nxt[i] = (i * a_slot, oshp[i, 0], oshp[i, 1], oshp[i, 2], i, asx, 0)
+                cur_vol = nat.Volume(buf.data_ptr(), nat.MMX_F64, 0, a_sz, a_sy, 1)
+                cur_blocks = nxt
+                cur_dblocks = torch.from_numpy(nxt.view(np.uint8).reshape(-1)).to(dev)
+                keep.append((buf, d_w, d_r, cur_dblocks))
+            src, blocks_src = cur_vol, cur_blocks
+            self._keep_aa = keep
         # ---- axis tables + block descriptors
         tabs_i, tabs_w, at, offs = [], [], 0, {}
         rb = np.zeros(nb, dtype=nat.RESIZE_DTYPE)
@@ -602,8 +649,7 @@ class Rescaler:
         sx = int(-(-new_shp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
         dst_sy, dst_sz = sx, sx * int(new_shp[:, 1].max())
         slot_pre = dst_sz * int(new_shp[:, 0].max())
-        src = views[channel]
-        if src.dtype == nat.MMX_F64:
+        if out_code == nat.MMX_F64:
             out = self._buffer("_out", which, nb * slot_pre, torch.float64, dev)
             out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)
             vol32 = nat.Volume(out32.data_ptr(), nat.MMX_F32, 0, dst_sz, dst_sy, 1)
@@ -612,15 +658,15 @@ class Rescaler:
         else:
             # integer images come back in their own type; float32 images as float32 (SciPy interpolates in
             # double and stores into a float32 array; detection then runs in float32 like the reference's)
-            tdt = {nat.MMX_U8: torch.uint8, nat.MMX_U16: torch.uint16, nat.MMX_F32: torch.float32}[src.dtype]
+            tdt = {nat.MMX_U8: torch.uint8, nat.MMX_U16: torch.uint16, nat.MMX_F32: torch.float32}[out_code]
             out = self._buffer("_out", which, nb * slot_pre, tdt, dev)
             if out.dtype != tdt:
                 self._out[which] = out = torch.empty(nb * slot_pre, dtype=tdt, device=dev)
-            vol32 = vol_exact = nat.Volume(out.data_ptr(), src.dtype, 0, dst_sz, dst_sy, 1)
+            vol32 = vol_exact = nat.Volume(out.data_ptr(), out_code, 0, dst_sz, dst_sy, 1)
             o32 = None
-        nat.check(L.mmx_resize_batch(ctypes.byref(src), d_rb.data_ptr(), rb.ctypes.data, nb, d_idx.data_ptr(),
-                                     d_wts.data_ptr(), d_mm.data_ptr(), slot_pre, dst_sy, dst_sz,
-                                     out.data_ptr(), o32, stream), "mmx_resize_batch")
+        nat.check(L.mmx_resize_batch_as(ctypes.byref(src), d_rb.data_ptr(), rb.ctypes.data, nb, d_idx.data_ptr(),
+                                        d_wts.data_ptr(), d_mm.data_ptr(), slot_pre, dst_sy, dst_sz, int(out_code),
+                                        out.data_ptr(), o32, stream), "mmx_resize_batch_as")
         self._keep = (d_src, d_mm, d_idx, d_wts, d_rb)
         blocks = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
         slot = 1
@@ -629,7 +675,7 @@ class Rescaler:
             blocks[i] = (i * slot_pre, new_shp[i, 0], new_shp[i, 1], new_shp[i, 2], i, px, 0)
             slot = max(slot, int(new_shp[i, 0]) * int(new_shp[i, 1]) * px)
         self.last_geometry = (slot_pre, dst_sz, dst_sy, out, None)
-        self.store_f32 = 1 if src.dtype == nat.MMX_F32 else 0      # the cube of a float32 image is float32
+        self.store_f32 = 1 if out_code == nat.MMX_F32 else 0       # the cube of a float32 image is float32
         return blocks, slot, vol32, vol_exact
 
     fetch = Preprocessor.fetch

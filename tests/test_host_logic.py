@@ -483,9 +483,10 @@ def test_zoom_axis_tables_reproduce_scipy_zoom():
     config.resolutions = [[3.0, 1.0, 1.0]]
     np.testing.assert_array_equal(preprocess.calc_isotropic_factor((0.96, 1, 1)), [2.88, 1.0, 1.0])
     assert preprocess.isotropic_shape((12, 26, 28), preprocess.calc_isotropic_factor((0.96, 1, 1))) == (34, 26, 28)
-    rs = preprocess.Rescaler([0.7, 1, 1], [0])
-    with pytest.raises(NotImplementedError):          # anti-aliasing would be active
-        rs.set_blocks([(0, 0, 0)], [(20, 8, 8)], [(14, 8, 8)])
+    # scikit-image's anti-aliasing Gaussian: sigma = (factor - 1) / 2, radius = int(4 sigma + 0.5)
+    assert preprocess.Rescaler.aa_radius(20, 14) == ((20 / 14 - 1) / 2, 1)
+    assert preprocess.Rescaler.aa_radius(20, 10) == (0.5, 2)
+    assert preprocess.Rescaler.aa_radius(20, 19)[1] == 0 and preprocess.Rescaler.aa_radius(10, 30) == (0.0, 0)
     config.resolutions = None
 
 

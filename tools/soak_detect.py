@@ -35,7 +35,9 @@ for trial in range(a.trials):
     if four_d and rng.random() < 0.5:
         k = int(rng.integers(1, nch + 1))
         channel = sorted(int(v) for v in rng.choice(nch, k, replace=False))
-    iso = (0.96, 1, 1) if rng.random() < 0.35 else None
+    iso = None
+    if rng.random() < 0.45:       # incl. shrinking axes: scikit-image's anti-aliasing Gaussian comes first
+        iso = [(0.96, 1, 1), (0.5, 1, 1), (0.7, 0.6, 1), (1, 0.45, 0.8)][int(rng.integers(0, 4))]
     config.setup_roi_profiles(["default"] * nch)
     for p in config.roi_profiles:
         p.update(num_sigma=int(rng.integers(1, 6)), min_sigma_factor=float(rng.uniform(2.0, 3.0)),

@@ -36,7 +36,9 @@ for trial in range(a.trials):
     vol = chans[0] if nch == 1 else np.stack(chans, axis=-1)
     res = np.array([[float(rng.choice([1.0, 1.0, 2.0, 3.0])), 1.0, 1.0]])
     denoise = None if rng.random() < 0.5 else int(rng.choice([15, 25, 40]))
-    iso = (0.96, 1, 1) if (res[0, 0] > 1 and rng.random() < 0.6) else None
+    iso = None
+    if res[0, 0] > 1 and rng.random() < 0.6:
+        iso = (0.96, 1, 1) if rng.random() < 0.7 else (0.3, 0.8, 1)      # the second shrinks z and y: anti-aliasing
     coloc = bool(nch == 2 and rng.random() < 0.6)
     # spectral unmixing of channel 1 by channel 0 (also on isotropically rescaled blocks)
     unmix = {1: {0: float(rng.choice([0.1, 0.3, 0.6]))}} if (nch == 2 and rng.random() < 0.5) else None
