@@ -325,11 +325,12 @@ int mmx_resize_batch_as(const mmx_volume* vol, const mmx_resize_block* d_blocks,
  * scipy.ndimage.gaussian_filter(image.astype(float), (factor - 1) / 2, mode='mirror' | 'nearest')): ONE exact
  * float64 correlate1d pass along `axis` for every block; block b uses d_weights[b * w_pitch + 0..d_radius[b]]
  * (half kernel, weight at distance k) -- a truncated block has its own zoom factor.  vol: uint8 / uint16 /
- * float64 at any strides (d_blocks[b].src_off); d_out: float64 [n_blocks][dst_slot], strides (dst_sz, dst_sy, 1). */
+ * float64 at any strides (d_blocks[b].src_off) -> d_out float64 [n_blocks][dst_slot], strides (dst_sz, dst_sy,
+ * 1); a float32 volume -> float32 d_out (SciPy rounds every pass of a float32 image to float32). */
 int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                          int n_blocks, int axis, const double* d_weights, const int32_t* d_radius,
                          int w_pitch, int nearest, int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
-                         double* d_out, void* stream);
+                         void* d_out, void* stream);
 
 /* ---- measurement helpers (bench.py): HIP-event timing on the caller's stream.
  * mmx_timing_enable(1) makes every kernel launch of this library record a HIP event

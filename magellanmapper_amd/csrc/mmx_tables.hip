@@ -529,12 +529,12 @@ extern "C" int mmx_minmax_batch(const mmx_volume* vol, const mmx_block* d_blocks
 // (d c b | a b c d | c b a) or 'nearest' extension, weights and radius per block (a truncated block has its
 // own zoom factor).  Source: any supported voxel type at the volume's strides; output: float64 block slots.
 namespace {
-template <typename InT>
+template <typename InT, typename OutT>
 __global__ void __launch_bounds__(MMX_WG)
 gauss_axis_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
                   const mmx_block* __restrict__ blocks, int axis, const double* __restrict__ weights,
                   const int32_t* __restrict__ radius, int w_pitch, int nearest,
-                  int64_t dst_slot, int64_t dst_sy, int64_t dst_sz, double* __restrict__ out)
+                  int64_t dst_slot, int64_t dst_sy, int64_t dst_sz, OutT* __restrict__ out)
 {
     const mmx_block bd = blocks[blockIdx.y];
     const int rows = bd.nz * bd.ny;
@@ -563,7 +563,7 @@ gauss_axis_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
                 const double p = (double)line[(int64_t)ext(c - k) * st] + (double)line[(int64_t)ext(c + k) * st];
                 acc += p * w[k];
             }
-            out[(int64_t)bd.slot * dst_slot + (int64_t)z * dst_sz + (int64_t)y * dst_sy + x] = acc;
+            out[(int64_t)bd.slot * dst_slot + (int64_t)z * dst_sz + (int64_t)y * dst_sy + x] = (OutT)acc;
         }
     }
 }
@@ -572,7 +572,7 @@ gauss_axis_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
 extern "C" int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                                     int n_blocks, int axis, const double* d_weights, const int32_t* d_radius,
                                     int w_pitch, int nearest, int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,
-                                    double* d_out, void* stream)
+                                    void* d_out, void* stream)
 {
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || axis < 0 || axis > 2 || !d_weights ||
         !d_radius || w_pitch < 1 || !d_out)
@@ -584,15 +584,16 @@ extern "C" int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_bl
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)std::min<int64_t>((max_rows + 15) / 16, 65535), (unsigned)n_blocks);
     mmx_timed_scope ts(MMX_K_GENERIC, s);
-#define MMX_GA_LAUNCH(T)                                                                                    \
-    hipLaunchKernelGGL(gauss_axis_kernel<T>, grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z, \
+#define MMX_GA_LAUNCH(T, O)                                                                                  \
+    hipLaunchKernelGGL((gauss_axis_kernel<T, O>), grid, dim3(MMX_WG), 0, s, (const T*)vol->d_data, vol->stride_z, \
                        vol->stride_y, vol->stride_x, d_blocks, axis, d_weights, d_radius, w_pitch, nearest, \
-                       dst_slot, dst_sy, dst_sz, d_out)
+                       dst_slot, dst_sy, dst_sz, (O*)d_out)
     switch (vol->dtype) {
-        case MMX_U8: MMX_GA_LAUNCH(uint8_t); break;
-        case MMX_U16: MMX_GA_LAUNCH(uint16_t); break;
-        case MMX_F64: MMX_GA_LAUNCH(double); break;
-        default: return MMX_ERR_UNSUPPORTED;   // float32 images: SciPy filters in float32 (not built)
+        case MMX_U8: MMX_GA_LAUNCH(uint8_t, double); break;
+        case MMX_U16: MMX_GA_LAUNCH(uint16_t, double); break;
+        case MMX_F64: MMX_GA_LAUNCH(double, double); break;
+        case MMX_F32: MMX_GA_LAUNCH(float, float); break;    // SciPy filters a float32 image into float32 arrays
+        default: return MMX_ERR_UNSUPPORTED;
     }
 #undef MMX_GA_LAUNCH
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;

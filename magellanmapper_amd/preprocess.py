@@ -586,9 +586,8 @@ class Rescaler:
         aa = [[self.aa_radius(orig[i][a], int(new_shp[i, a])) if any(int(new_shp[i, b]) < orig[i][b] for b in range(3))
                else (0.0, 0) for a in range(3)] for i in range(nb)]
         if any(r > 0 for blk in aa for _, r in blk):
-            if src.dtype == nat.MMX_F32:
-                raise NotImplementedError("anti-aliased down-sampling of float32 images is not built")
             from . import kernels1d as k1
+            f32 = src.dtype == nat.MMX_F32        # SciPy filters a float32 image into float32 arrays
             oshp = np.asarray(orig, dtype=np.int64).reshape(nb, 3)
             asx = int(-(-oshp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
             a_sy, a_sz = asx, asx * int(oshp[:, 1].max())
@@ -609,7 +608,11 @@ class Rescaler:
                                  for i in range(nb)])
                 if edge.any() and not edge.all():
                     raise NotImplementedError("anti-aliasing of a batch mixing unit-thick and regular blocks")
-                buf = self._buffer("_aa%d" % (len(keep) & 1), None, nb * a_slot, torch.float64, dev)
+                buf = self._buffer("_aa%d" % (len(keep) & 1), None, nb * a_slot,
+                                   torch.float32 if f32 else torch.float64, dev)
+                if buf.dtype != (torch.float32 if f32 else torch.float64):
+                    buf = torch.empty(nb * a_slot, dtype=torch.float32 if f32 else torch.float64, device=dev)
+                    setattr(self, "_aa%d" % (len(keep) & 1), buf)
                 d_w = torch.from_numpy(wts.reshape(-1)).to(dev)
                 d_r = torch.from_numpy(radii).to(dev)
                 nat.check(L.mmx_gauss_axis_batch(ctypes.byref(cur_vol), cur_dblocks.data_ptr(), cur_blocks.ctypes.data,
@@ -618,7 +621,7 @@ class Rescaler:
                 nxt = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
                 for i in range(nb):
                     nxt[i] = (i * a_slot, oshp[i, 0], oshp[i, 1], oshp[i, 2], i, asx, 0)
-                cur_vol = nat.Volume(buf.data_ptr(), nat.MMX_F64, 0, a_sz, a_sy, 1)
+                cur_vol = nat.Volume(buf.data_ptr(), nat.MMX_F32 if f32 else nat.MMX_F64, 0, a_sz, a_sy, 1)
                 cur_blocks = nxt
                 cur_dblocks = torch.from_numpy(nxt.view(np.uint8).reshape(-1)).to(dev)
                 keep.append((buf, d_w, d_r, cur_dblocks))

@@ -340,9 +340,11 @@ def test_isotropic_anti_aliased_down_sampling(gpu):
              ((16, 50, 20), (1, 0.3, 1), (1.0, 1.0, 1.0)),        # strong: sigma 1.17, radius 5
              ((21, 22, 23), (0.9, 0.95, 0.85), (1.0, 1.0, 1.0))]  # mild: radius 0 or 1
     for shape, scale, res in cases:
-        for kind in ("u16", "f64", "u16x2"):
+        for kind in ("u16", "f64", "u16x2", "f32"):
             if kind == "u16":
                 roi = rng.integers(0, 65535, shape).astype(np.uint16)
+            elif kind == "f32":
+                roi = (rng.random(shape) * 3 - 0.5).astype(np.float32)
             elif kind == "f64":
                 roi = rng.random(shape) * 3 - 0.5
             else:
