@@ -66,6 +66,17 @@ for trial in range(a.trials):
     profs = [dict(p, spectral_unmixing=unmix) for p in config.roi_profiles]
     try:
         want, st = mmo.detect_blobs_blocks(vol, None, profs, res, near_max=config.near_max, coloc=coloc)
+    except (OverflowError, ValueError, ZeroDivisionError) as e:
+        # the reference itself fails here (e.g. a thin remainder block rescaled to zero planes): so must we
+        try:
+            stack_detect.detect_blobs_blocks("soak", stack_detect.Image5d(vol[None]), None, None, None, False,
+                                             False, True, coloc)
+            bad += 1
+            print("MISMATCH trial", trial, "the reference raises", repr(e), "but the device path returned", flush=True)
+        except Exception:
+            pass
+        continue
+    try:
         img5d = stack_detect.Image5d(vol[None])
         _, _, blobs = stack_detect.detect_blobs_blocks("soak", img5d, None, None, None, False, False, True, coloc)
     except NotImplementedError as e:      # a combination this build states it does not cover
