@@ -127,6 +127,9 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
  * (default; env MMX_FUSE sets the initial value).  Geometries the fused kernels do not take fall back to
  * the separate passes.  All three agree within float32 rounding (the NMS decisions are exact either way). */
 int mmx_set_fused(int mode);
+/* Diagnostic: which Z+X kernel the calling thread's last mmx_log_batch_f32 ran (0 = separate passes,
+ * 1-4 = fused designs) -- tests use it to prove that a result came from the kernel they mean to check. */
+int mmx_last_zx_path(void);
 
 /* Same contract, always through the generic (any radius <= MMX_MAX_RADIUS_GENERIC, any block
  * extent) kernels.  mmx_log_batch_f32 picks per pass between the register-ring kernels and

@@ -70,7 +70,7 @@ _lib = None
 #: every symbol ``include/mmx.h`` declares
 SYMBOLS = (
     "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
-    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_set_fused", "mmx_peaks_batch", "mmx_rescore_f64",
+    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_set_fused", "mmx_last_zx_path", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
@@ -104,6 +104,7 @@ def lib() -> ctypes.CDLL:
     L.mmx_log_batch_f32_generic.argtypes = log_args + [vp]
     L.mmx_set_fused.argtypes = [c_int]
     L.mmx_set_fused.restype = c_int
+    L.mmx_last_zx_path.restype = c_int
     L.mmx_peaks_batch.argtypes = [vp, vp, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
                                   c_uint32, vp, vp]
     L.mmx_rescore_f64.argtypes = [POINTER(Volume), vp, c_int, vp, c_uint32, vp, vp, vp,

@@ -23,6 +23,7 @@ int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask
 
 namespace {
 thread_local char g_hip_err[256] = "";
+thread_local int g_last_zx = 0;   // which Z+X kernel the last mmx_log_batch_f32 of this thread ran (0 = separate passes)
 
 // 0 = three separate passes, 1 = first fused Z+X kernel (kept for comparison), 2 = wave-specialised
 // packed-math fused Z+X kernel (default: fastest; geometries it does not take use the separate passes)
@@ -126,6 +127,8 @@ const char* mmx_strerror(int status)
 
 const char* mmx_last_hip_error(void) { return g_hip_err; }
 
+int mmx_last_zx_path(void) { return g_last_zx; }
+
 int mmx_device_count(void)
 {
     int n = 0;
@@ -226,8 +229,14 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     if (fused) {
         mmx_taps_f32 tzz = taps(wz0, wz2), txx = taps(wy0, wy2), tyy = taps(wx0, wx2);
         { mmx_timed_scope ts(MMX_K_ZX, s);
-          if (fuse_mode == 2) rc = mmx_launch_zx2(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);
-          else rc = mmx_launch_zx(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
+          rc = MMX_ERR_UNSUPPORTED;
+          if (fuse_mode == 4)     // X + Z on the matrix cores (integer voxels); geometries it does not take: zx2
+              rc = mmx_launch_zx4(vol, d_blocks, h_blocks, n_blocks, slot_elems, txx, radius, t0, t1, t2,
+                                  (size_t)(2 * n_slots * slot_elems) * sizeof(float), s);
+          if (rc != MMX_ERR_UNSUPPORTED) g_last_zx = 4;
+          else if (fuse_mode == 3) { g_last_zx = 3; rc = mmx_launch_zx3(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
+          else if (fuse_mode == 2 || fuse_mode == 4) { g_last_zx = 2; rc = mmx_launch_zx2(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
+          else { g_last_zx = 1; rc = mmx_launch_zx(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); } }
         if (rc == MMX_OK) {
             mmx_timed_scope ts(MMX_K_Y2, s);
             // the mask rows of a block (ny rows of ceil(nz * px / 64) words) must fit its slot / 32 words
@@ -244,6 +253,7 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         if (rc == MMX_OK) return MMX_OK;
         if (rc != MMX_ERR_UNSUPPORTED) return rc;   // unsupported geometry: separate passes below
     }
+    g_last_zx = 0;
     { mmx_timed_scope ts(fast_z ? MMX_K_ZPASS : MMX_K_GENERIC, s);
     if (fast_z) rc = mmx_launch_zpass(vol, d_blocks, n_blocks, max_zcols, slot_elems, taps(wz0, wz2), radius, t0, t1, s);
     else rc = mmx_launch_generic_pass(0, vol, d_blocks, n_blocks, max_vox, slot_elems, wz0, wz2, radius, nullptr, nullptr, t0, t1, s); }

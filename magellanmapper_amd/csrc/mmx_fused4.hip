@@ -1,0 +1,575 @@
+// Fused X+Z pass on the matrix cores with split-float16 operands (gfx950), the default Z+X path for integer
+// voxels.
+//
+//   zx4_kernel :  I (u8 / u16, read once, x contiguous)  ->  P = G(z) G(x) I
+//                                                            Q = G(z) G''(x) I + G''(z) G(x) I
+// feeding y2_kernel (mmx_fused.hip) exactly as zx2_kernel (mmx_fused2.hip) does.
+//
+// Why.  zx2_kernel needs 5R packed VALU instructions per voxel and a workgroup-wide LDS hand-off per 8 planes;
+// measured, neither its arithmetic nor its skeleton (loads, LDS, barriers: 3.5 of its 5.4 ms per 64 blocks at
+// R = 16) gets near the 1.8 ms its 10 B/voxel cost at HBM speed.  A 1-D convolution of
+// 16 rows is a product with a banded Toeplitz matrix, and v_mfma_f32_16x16x32_f16 multiplies 16 x the flops
+// per clock of the float32 pipes.  Float16 carries 11 significant bits, so every float32 factor is split into
+// two float16 pieces, x = xh + xl / 2048 (xh = half(x), xl = half((x - xh) * 2048)), and a product is three
+// MFMAs (xh wh -> acc0; xh wl + xl wh -> acc1; result acc0 + acc1 / 2048; the dropped xl wl term is 2^-22 of
+// the product).  uint16 voxels split EXACTLY into two float16 pieces (high byte / 256 and low byte / 65536, the
+// latter float16 subnormals), so the X pass, taken first and straight from global memory, has no data error at
+// all.  Measured against the exact float64 values the result is as close as the float32 FMA chains were
+// (bench.py: max_f32_error), far inside the eps / 4 the exactness machinery allows.
+//
+// Layout: no LDS, no barriers.  A WAVE owns one 16-column output tile of one block row (y) and marches along z
+// in tiles of 16 planes:
+//   X pass   D1[z][x_out] = sum_k In[z][x_in(k)] Wx[x_in(k)][x_out].  A operand = voxels: lane l loads 8
+//            consecutive x of plane z0 + (l & 15) with ONE 16-byte load per k-step (k = 8 (l >> 4) + j) and
+//            unpacks them into the two exact float16 pieces with byte permutes; B operand = the Toeplitz
+//            fragments of this column (constant registers).  The accumulators come out with x_out on
+//            lane & 15 and four consecutive z in the four registers --
+//   Z pass   D2[x][z_out] = sum_k D1[z_in(k)][x] Wz[z_in(k)][z_out] -- which is exactly the A-operand layout
+//            of the next product once two z tiles are put side by side (k = 8 (l >> 4) + j <-> tile j >> 2,
+//            plane 4 (l >> 4) + (j & 3): the MFMA does not care in which order k runs as long as both
+//            operands agree).  So the X results never leave the registers: they are split into float16 pieces
+//            and kept in a sliding window of 2 LA + 2 z tiles; the Z Toeplitz fragments follow the same k order.
+//            The result has z_out on lane & 15 and four consecutive x in the registers: one 16-byte store per
+//            lane for P and for Q.
+// SciPy's "reflect" boundaries are folded into the Toeplitz fragments (the weight of a mirrored tap is added
+// to the tap it mirrors), so no halo is ever materialised and no load leaves the block: chunks and planes that
+// would are clamped into it and get zero weights.  The fragments are built on the device by a small setup
+// kernel per launch (zx4_setup: one table per distinct block width / depth of the batch, in the part of the
+// workspace the fused path does not use) and live in registers in the main kernel, except the Z fragments of
+// the first and last z tiles, which are reloaded when the march reaches them.
+
+#include <type_traits>
+
+#include "mmx_common.h"
+
+typedef _Float16 h2_4 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8_4 __attribute__((ext_vector_type(8)));
+typedef float f2_4 __attribute__((ext_vector_type(2)));
+typedef float f4_4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4_4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2_4 __attribute__((ext_vector_type(2)));
+
+#define MMX_ZX4_MAXCLS 8
+// cache policy bits of the streaming accesses (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef ZX4_ST_AUX
+#define ZX4_ST_AUX 0
+#endif
+#ifndef ZX4_LD_AUX
+#define ZX4_LD_AUX 0
+#endif
+
+struct mmx_zx4_cfg {
+    float w0[MMX_MAX_RADIUS_FAST + 1];     // order-0 half kernel (plain)
+    float w2[MMX_MAX_RADIUS_FAST + 1];     // order-2 half kernel (plain)
+    float xscale;                          // 65536 / 65535 (u16) or 256 / 255 (u8): the pieces carry v / 2^16
+    int radius;
+    int ncw, ncz;                          // distinct block widths / depths of the batch
+    int wcls[MMX_ZX4_MAXCLS];              // widths (nx)
+    int zcls[MMX_ZX4_MAXCLS];              // depths (nz)
+    int maxcol, maxu;                      // table extents: columns per width class, z tiles per depth class
+};
+
+namespace {
+
+#ifndef ZX4_PF
+#define ZX4_PF 3
+#endif
+constexpr int kPF4 = ZX4_PF;       // z tiles of voxels in flight per wave
+constexpr float kLoScale = 2048.f;
+constexpr float kLoInv = 1.f / 2048.f;
+
+using rsrc4_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc4_t make_rsrc4(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int R> struct geom4 {
+    static constexpr int R8 = (R + 7) & ~7;                       // x halo rounded to the 8-voxel chunks
+    static constexpr int NKX = (16 + 2 * R8 + 31) / 32;           // k-steps of the X pass
+    static constexpr int LA = (R + 15) / 16;                      // z tiles of look-ahead / look-back
+    static constexpr int NKZ = LA + 1;                            // k-steps of the Z pass (pairs of z tiles)
+    static constexpr int NT = 2 * NKZ;                            // window tiles: U - LA .. U + LA + 1
+};
+// geometry classes actually compiled: (NKX, LA) = (1, 1) for R <= 8, (2, 1) for R <= 16, (2, 2) for R <= 24
+template <int NKX, int LA> struct cls4 {
+    static constexpr int R8 = NKX == 1 ? 8 : (LA == 1 ? 16 : 24);
+    // first input column of output column tile c: 16 c - R8, moved down to a multiple of 32 voxels where the
+    // k-steps still reach the last input (16 c + 15 + R8) -- whole 64-byte pieces per plane for uint16
+    static __host__ __device__ constexpr int xstart(int c)
+    {
+        const int lo = 16 * c - R8;
+        const int al = lo & ~31;
+        return (al + 32 * NKX >= 16 * c + 16 + R8) ? al : lo;
+    }
+    static constexpr int NKZ = LA + 1;
+    static constexpr int NT = 2 * NKZ;
+};
+
+__device__ __forceinline__ unsigned pack_h2(float a, float b)
+{
+    const f2_4 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_4));
+}
+
+// ------------------------------------------------------------------------------------ setup: Toeplitz fragments
+// weight of input position p for output o on an axis of n voxels with SciPy "reflect" folded in
+__device__ __forceinline__ float folded_tap(const float* w, int R, int p, int o, int n)
+{
+    float s = 0.f;
+    int d = p - o; d = d < 0 ? -d : d;
+    if (d <= R) s += w[d];
+    d = (-1 - p) - o; d = d < 0 ? -d : d;            // left mirror image of p
+    if (d <= R) s += w[d];
+    d = (2 * n - 1 - p) - o; d = d < 0 ? -d : d;     // right mirror image of p
+    if (d <= R) s += w[d];
+    return s;
+}
+
+// One thread per (table entry, lane): 8 float16 weights (one MFMA operand register quad) as hi and lo pieces.
+//   X table [class][column][m][kernel][piece][lane], Z table [class][U][ks][kernel][piece][lane]
+template <int NKX, int LA>
+__global__ void __launch_bounds__(256)
+zx4_setup(mmx_zx4_cfg cfg, u4_4* __restrict__ xtab, u4_4* __restrict__ ztab)
+{
+    using cg = cls4<NKX, LA>;
+    const int R = cfg.radius;
+    const int lane = threadIdx.x & 63;
+    const int kq = lane >> 4, col = lane & 15;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);           // entry index over both tables: (.., kernel)
+    const int nx_entries = cfg.ncw * cfg.maxcol * NKX * 2;
+    const int nz_entries = cfg.ncz * cfg.maxu * cg::NKZ * 2;
+    float wt[8];
+    u4_4* dst;
+    if (e < nx_entries) {
+        const int kern = e & 1;
+        const int m = (e >> 1) % NKX;
+        const int c = ((e >> 1) / NKX) % cfg.maxcol;
+        const int cl = ((e >> 1) / NKX) / cfg.maxcol;
+        const int W = cfg.wcls[cl];
+        const float* w = kern ? cfg.w2 : cfg.w0;
+        const int xo = 16 * c + col;
+        const int xc = cg::xstart(c) + 32 * m + 8 * kq;             // natural start of this lane's chunk
+        int xl = xc < 0 ? 0 : xc;
+        xl = xl > W - 8 ? W - 8 : xl;                               // where the kernel loads it from
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = xl + j;
+            const bool ok = p >= xc && p < xc + 8 && p >= 0 && p < W && xo < W;
+            wt[j] = ok ? folded_tap(w, R, p, xo, W) * cfg.xscale : 0.f;
+        }
+        dst = xtab + (size_t)e * 2 * 64;
+    } else if (e < nx_entries + nz_entries) {
+        const int ez = e - nx_entries;
+        const int kern = ez & 1;
+        const int ks = (ez >> 1) % cg::NKZ;
+        const int U = ((ez >> 1) / cg::NKZ) % cfg.maxu;
+        const int cl = ((ez >> 1) / cg::NKZ) / cfg.maxu;
+        const int nz = cfg.zcls[cl];
+        const float* w = kern ? cfg.w2 : cfg.w0;
+        const int zo = 16 * U + col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = 2 * ks + (j >> 2);                        // window tile of this k
+            const int zi = 16 * (U - LA + i) + 4 * kq + (j & 3);
+            const bool ok = i < cg::NT - 1 && zi >= 0 && zi < nz && zo < nz;
+            wt[j] = ok ? folded_tap(w, R, zi, zo, nz) : 0.f;
+        }
+        dst = ztab + (size_t)ez * 2 * 64;
+    } else {
+        return;
+    }
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f2_4 v = {wt[j], wt[j + 1]};
+        const h2_4 h = __builtin_convertvector(v, h2_4);
+        const f2_4 r = {(wt[j] - (float)h.x) * kLoScale, (wt[j + 1] - (float)h.y) * kLoScale};
+        hi[j >> 1] = __builtin_bit_cast(unsigned, h);
+        lo[j >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2_4));
+    }
+    dst[lane] = (u4_4){hi[0], hi[1], hi[2], hi[3]};
+    dst[64 + lane] = (u4_4){lo[0], lo[1], lo[2], lo[3]};
+}
+
+// ------------------------------------------------------------------------------------------------ main kernel
+template <typename InT> struct pieces4;
+// 8 consecutive uint16 voxels (4 dwords) -> high bytes / 256 and low bytes / 65536 as packed float16:
+//   0x4400 | b  =  4 + b / 256      (float16, exponent 2^2, ulp 2^-8)
+//   0x2400 | b  =  2^-6 + b / 65536 (exponent 2^-6, ulp 2^-16)
+template <> struct pieces4<uint16_t> {
+    static constexpr int NP = 2;
+    using raw_t = u4_4;
+    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off)
+    {
+#ifdef ZX4_NO_LOAD
+        return (u4_4){off, off * 3u, off * 5u, off * 7u};
+#endif
+        return __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, ZX4_LD_AUX));
+    }
+    static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo)
+    {
+        const h2_4 four = {(_Float16)4.0f, (_Float16)4.0f};
+        const h2_4 sixty4th = {(_Float16)0.015625f, (_Float16)0.015625f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // v_perm_b32: bytes of {S0 = constant, S1 = data}; selector bytes 0-3 pick from S1, 4-7 from S0
+            const unsigned th = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07030501u);   // [44 b3 44 b1]
+            const unsigned tl = __builtin_amdgcn_perm(0x24002400u, d[i], 0x07020500u);   // [24 b2 24 b0]
+            hi[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2_4, th) - four);
+            lo[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2_4, tl) - sixty4th);
+        }
+    }
+};
+// 8 consecutive uint8 voxels (2 dwords) -> one exact piece: b / 256
+template <> struct pieces4<uint8_t> {
+    static constexpr int NP = 1;
+    using raw_t = u2_4;
+    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off)
+    {
+        return __builtin_bit_cast(u2_4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    }
+    static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo)
+    {
+        const h2_4 four = {(_Float16)4.0f, (_Float16)4.0f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned t0 = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07010500u);   // [44 b1 44 b0]
+            const unsigned t1 = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07030502u);   // [44 b3 44 b2]
+            hi[2 * i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2_4, t0) - four);
+            hi[2 * i + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2_4, t1) - four);
+        }
+        lo = hi;
+    }
+};
+
+__device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4& c)
+{
+#ifdef ZX4_NO_MFMA
+    f4_4 r = c; r[0] += __uint_as_float(a[0] ^ b[1]); r[3] += __uint_as_float(a[3] ^ b[2]); return r;
+#endif
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_4, a), __builtin_bit_cast(h8_4, b), c, 0, 0, 0);
+}
+
+template <int NKX, int LA, typename InT>
+__global__ void __launch_bounds__(256, 2)
+zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
+           const mmx_block* __restrict__ blocks, int64_t slot_elems,
+           float* __restrict__ gp, float* __restrict__ gq,
+           const u4_4* __restrict__ xtab, const u4_4* __restrict__ ztab, mmx_zx4_cfg cfg)
+{
+    using cg = cls4<NKX, LA>;
+    using pc = pieces4<InT>;
+    constexpr int NKZ = cg::NKZ, NT = cg::NT;
+    const mmx_block bd = blocks[blockIdx.y];
+    const int W = bd.nx, nz = bd.nz, px = bd.px;
+    const int ntx = (W + 15) >> 4;
+    // (readfirstlane: the wave index is uniform, but only this tells the compiler -- otherwise every buffer
+    //  descriptor below is built per lane and each load becomes a waterfall loop)
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of this block: (y, column)
+    const int y = gw / ntx;
+    if (y >= bd.ny) return;                                   // whole wave (no barriers in this kernel)
+    const int c = gw - y * ntx;
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 15, kq = lane >> 4;
+    int cw = 0, cz = 0;
+    for (int i = 1; i < cfg.ncw; ++i) cw = cfg.wcls[i] == W ? i : cw;
+    for (int i = 1; i < cfg.ncz; ++i) cz = cfg.zcls[i] == nz ? i : cz;
+    const int ntz = (nz + 15) >> 4;
+
+    // X fragments of this column: [m][kernel][piece]
+    u4_4 xw[NKX][2][2];
+    {
+        const u4_4* xt = xtab + ((size_t)(cw * cfg.maxcol + c) * NKX * 2) * 128 + lane;
+#pragma unroll
+        for (int m = 0; m < NKX; ++m)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                xw[m][k][0] = xt[(m * 2 + k) * 128];
+                xw[m][k][1] = xt[(m * 2 + k) * 128 + 64];
+            }
+    }
+    // Z fragments: [ks][kernel][piece], of the z tile being produced (reloaded when its class changes)
+    u4_4 zw[NKZ][2][2];
+    const u4_4* zt = ztab + ((size_t)cz * cfg.maxu * NKZ * 2) * 128 + lane;
+    // interior z tiles share one set: the first tile whose taps all fall inside the block
+    const int R = cfg.radius;
+    const int u_lo = (R + 15) >> 4;                             // first U with 16 U - R >= 0
+    const int u_hi = (nz - 16 - R) >> 4;                        // last U with 16 U + 15 + R <= nz - 1 (may be < u_lo)
+    int zset = -1;
+
+    // voxel rows: plane z0 + li, chunk of 8 x at xl[m] (clamped into the block; the fragments know)
+    const InT* in = vol + bd.src_off + (int64_t)y * stride_y;
+    unsigned xoff[NKX];
+#pragma unroll
+    for (int m = 0; m < NKX; ++m) {
+        int xl = cg::xstart(c) + 32 * m + 8 * kq;
+        xl = xl < 0 ? 0 : xl;
+        xl = xl > W - 8 ? W - 8 : xl;
+        xoff[m] = (unsigned)xl * (unsigned)sizeof(InT);
+    }
+    const unsigned zstride_b = (unsigned)(stride_z * (int64_t)sizeof(InT));
+    auto load_tile = [&](int t, typename pc::raw_t (&raw)[NKX]) __attribute__((always_inline)) {
+        const rsrc4_t rs = make_rsrc4(in + (int64_t)(16 * t) * stride_z);
+        int zr = nz - 1 - 16 * t;                                // last real plane relative to the tile
+        zr = li < zr ? li : zr;
+        const unsigned zo = (unsigned)zr * zstride_b;
+#pragma unroll
+        for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rs, zo + xoff[m]);
+    };
+
+    // window of X results as float16 pieces: [array: A hi, A lo, B hi, B lo][tile][2 dwords]
+    unsigned win[4][NT][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { win[a][i][0] = 0u; win[a][i][1] = 0u; }
+
+    const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
+    const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
+    const unsigned row_b = (unsigned)px * 4u;
+    const unsigned plane_b = (unsigned)bd.ny * row_b;
+    unsigned obase = (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
+
+    // voxels of the next ZX4_PF z tiles, in flight.  vmcnt counts loads and stores together and in issue order:
+    // a tile loaded only one step ahead could not be used before the stores of the step in between have been
+    // acknowledged by L2 -- measured, that wait and not the arithmetic set the step time (5.3 ms against 2.1 ms
+    // without the stores).  With PF steps of distance the stores older than the tile being consumed have had
+    // PF - 1 whole steps to complete.
+    typename pc::raw_t raw[kPF4][NKX];
+#pragma unroll
+    for (int u = 0; u < kPF4; ++u) load_tile(u < ntz ? u : ntz - 1, raw[u]);
+
+    // One march step: X pass of z tile t into the window, Z pass of z tile t - LA out of it.  STEADY = the
+    // branch-free form for the tiles in the middle of the block (every tile real, interior Z fragments already
+    // in registers, every output plane real): with no control flow between the memory instructions the
+    // compiler's s_waitcnt vmcnt(N) are exact counts and only ever wait for the tile being consumed.
+    // Results on their way to memory: a store reads its data registers asynchronously, so the compiler makes the
+    // next writer of those registers wait (vmcnt) until the store has completed.  Each ring slot therefore has
+    // its own result registers, kept allocated (an empty asm "use") until the slot comes round again.
+    f4_4 outP[kPF4], outQ[kPF4];
+#pragma unroll
+    for (int u = 0; u < kPF4; ++u) { outP[u] = (f4_4){0.f, 0.f, 0.f, 0.f}; outQ[u] = outP[u]; }
+    auto step = [&](int t, auto steady_tag, typename pc::raw_t (&rw)[NKX], f4_4& P, f4_4& Q) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        // shift the window by one z tile
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 2 * LA; ++i) { win[a][i][0] = win[a][i + 1][0]; win[a][i][1] = win[a][i + 1][1]; }
+        if (STEADY || t < ntz) {
+            // ---- X pass of z tile t
+            u4_4 dh[NKX], dl[NKX];
+#pragma unroll
+            for (int m = 0; m < NKX; ++m) pc::split(rw[m], dh[m], dl[m]);
+            // (past the last tile the ring re-reads it: loads without a branch, never used)
+            // the scheduler must not sink these loads to the end of the unrolled ring (it does, given the chance:
+            // all of a ring's loads then sit right in front of their first use)
+            __builtin_amdgcn_sched_barrier(0);
+            if (STEADY) load_tile(t + kPF4 < ntz ? t + kPF4 : ntz - 1, rw);
+            else if (t + kPF4 < ntz) load_tile(t + kPF4, rw);
+            __builtin_amdgcn_sched_barrier(0);
+            f4_4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+            for (int m = 0; m < NKX; ++m) {
+                a0 = mfma16(dh[m], xw[m][0][0], a0);
+                b0 = mfma16(dh[m], xw[m][1][0], b0);
+                a1 = mfma16(dh[m], xw[m][0][1], a1);
+                b1 = mfma16(dh[m], xw[m][1][1], b1);
+                if constexpr (pc::NP == 2) {
+                    a0 = mfma16(dl[m], xw[m][0][0], a0);
+                    b0 = mfma16(dl[m], xw[m][1][0], b0);
+                    a1 = mfma16(dl[m], xw[m][0][1], a1);
+                    b1 = mfma16(dl[m], xw[m][1][1], b1);
+                }
+            }
+            // combine the two accumulators and split into float16 pieces: v = acc0 + acc1 / 2048
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const float av0 = __builtin_fmaf(a1[r], kLoInv, a0[r]), av1 = __builtin_fmaf(a1[r + 1], kLoInv, a0[r + 1]);
+                const float bv0 = __builtin_fmaf(b1[r], kLoInv, b0[r]), bv1 = __builtin_fmaf(b1[r + 1], kLoInv, b0[r + 1]);
+                const f2_4 av = {av0, av1}, bv = {bv0, bv1};
+                const h2_4 ah = __builtin_convertvector(av, h2_4), bh = __builtin_convertvector(bv, h2_4);
+                const f2_4 ar = {__builtin_fmaf((float)ah.x, -kLoScale, av0 * kLoScale), __builtin_fmaf((float)ah.y, -kLoScale, av1 * kLoScale)};
+                const f2_4 br = {__builtin_fmaf((float)bh.x, -kLoScale, bv0 * kLoScale), __builtin_fmaf((float)bh.y, -kLoScale, bv1 * kLoScale)};
+                win[0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
+                win[1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
+                win[2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
+                win[3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { win[a][2 * LA][0] = 0u; win[a][2 * LA][1] = 0u; }
+        }
+        const int U = t - LA;
+        if (STEADY || U >= 0) {
+            // ---- Z pass of z tile U
+            if constexpr (!STEADY) {
+                const int want = (U >= u_lo && U <= u_hi) ? u_lo : U;
+                if (want != zset) {
+                    zset = want;
+#pragma unroll
+                    for (int ks = 0; ks < NKZ; ++ks)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            zw[ks][k][0] = zt[((size_t)(want * NKZ + ks) * 2 + k) * 128];
+                            zw[ks][k][1] = zt[((size_t)(want * NKZ + ks) * 2 + k) * 128 + 64];
+                        }
+                }
+            }
+            f4_4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, q0 = p0, q1 = p0;
+#pragma unroll
+            for (int ks = 0; ks < NKZ; ++ks) {
+                const u4_4 ah = {win[0][2 * ks][0], win[0][2 * ks][1], win[0][2 * ks + 1][0], win[0][2 * ks + 1][1]};
+                const u4_4 al = {win[1][2 * ks][0], win[1][2 * ks][1], win[1][2 * ks + 1][0], win[1][2 * ks + 1][1]};
+                const u4_4 bh = {win[2][2 * ks][0], win[2][2 * ks][1], win[2][2 * ks + 1][0], win[2][2 * ks + 1][1]};
+                const u4_4 bl = {win[3][2 * ks][0], win[3][2 * ks][1], win[3][2 * ks + 1][0], win[3][2 * ks + 1][1]};
+                p0 = mfma16(ah, zw[ks][0][0], p0);
+                q0 = mfma16(bh, zw[ks][0][0], q0);
+                p1 = mfma16(ah, zw[ks][0][1], p1);
+                q1 = mfma16(bh, zw[ks][0][1], q1);
+                p1 = mfma16(al, zw[ks][0][0], p1);
+                q1 = mfma16(bl, zw[ks][0][0], q1);
+                q0 = mfma16(ah, zw[ks][1][0], q0);
+                q1 = mfma16(ah, zw[ks][1][1], q1);
+                q1 = mfma16(al, zw[ks][1][0], q1);
+            }
+#ifdef ZX4_NO_STORE
+            asm volatile("" ::"v"(p0), "v"(p1), "v"(q0), "v"(q1));
+            if (false) {
+#else
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"v"(P), "v"(Q));       // the slot's previous results stayed in these registers until now
+            if (STEADY || 16 * U + li < nz) {
+#endif
+                // the results reach the slot's registers through opaque moves: the stores then read registers
+                // that nothing else may be allocated to before the slot comes round again
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_fmaf(p1[r], kLoInv, p0[r]);
+                    const float qv = __builtin_fmaf(q1[r], kLoInv, q0[r]);
+                    float pr, qr;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(pr) : "v"(pv));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(qr) : "v"(qv));
+                    P[r] = pr;
+                    Q[r] = qr;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P), rp, obase, 0, ZX4_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, Q), rq, obase, 0, ZX4_ST_AUX);
+            }
+            obase += 16u * plane_b;
+        }
+#ifdef ZX4_LOCKSTEP
+        __syncthreads();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // tiles [0, tA): generic steps up to the first interior output tile (U = t - LA >= u_lo), rounded up to a
+    // multiple of the ring; [tA, tB): steady steps (U in [u_lo, u_hi], t < ntz), whole rings; the rest generic.
+    const int t_end = ntz + LA;
+    int tA = ((u_lo + LA + kPF4 - 1) / kPF4) * kPF4;
+    int nB = (u_hi + LA + 1 < ntz ? u_hi + LA + 1 : ntz) - tA;       // steady steps available
+    nB = nB > 0 ? (nB / kPF4) * kPF4 : 0;
+    if (tA > t_end) tA = ((t_end + kPF4 - 1) / kPF4) * kPF4;
+    const int tB = tA + nB;
+#pragma unroll 1
+    for (int t0 = 0; t0 < tA; t0 += kPF4) {
+#pragma unroll
+        for (int u = 0; u < kPF4; ++u)
+            if (t0 + u < t_end) step(t0 + u, std::false_type{}, raw[u], outP[u], outQ[u]);
+    }
+    if (nB > 0) {
+        // interior Z fragments (the generic steps may have left an edge set in the registers)
+        if (zset != u_lo) {
+            zset = u_lo;
+#pragma unroll
+            for (int ks = 0; ks < NKZ; ++ks)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    zw[ks][k][0] = zt[((size_t)(u_lo * NKZ + ks) * 2 + k) * 128];
+                    zw[ks][k][1] = zt[((size_t)(u_lo * NKZ + ks) * 2 + k) * 128 + 64];
+                }
+        }
+        // nothing may be pending at the loop head: a wait for the fragment loads above, placed inside the loop
+        // at their first use, would be a static vmcnt(N) that in steady state waits for the previous step's stores
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+#pragma unroll 1
+        for (int t0 = tA; t0 < tB; t0 += kPF4) {
+#pragma unroll
+            for (int u = 0; u < kPF4; ++u) step(t0 + u, std::true_type{}, raw[u], outP[u], outQ[u]);
+        }
+    }
+#pragma unroll 1
+    for (int t0 = tB; t0 < t_end; t0 += kPF4) {
+#pragma unroll
+        for (int u = 0; u < kPF4; ++u)
+            if (t0 + u < t_end) step(t0 + u, std::false_type{}, raw[u], outP[u], outQ[u]);
+    }
+}
+
+template <int NKX, int LA>
+int launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+               int64_t slot_elems, const mmx_taps_f32& tx, int radius, float* d_p, float* d_q,
+               void* d_scratch, size_t scratch_bytes, hipStream_t s)
+{
+    using cg = cls4<NKX, LA>;
+    mmx_zx4_cfg cfg;
+    for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) { cfg.w0[k] = tx.w0[k]; cfg.w2[k] = tx.w2[k]; }
+    cfg.radius = radius;
+    cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(256.0 / 255.0);
+    cfg.ncw = cfg.ncz = 0;
+    cfg.maxcol = cfg.maxu = 0;
+    int max_waves = 0;
+    const int64_t esz = vol->dtype == MMX_U16 ? 2 : 1;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_block& b = h_blocks[i];
+        if (b.nx < 8 || b.nx < radius || b.nz < radius) return MMX_ERR_UNSUPPORTED;   // single reflection, 8-voxel chunks
+        if ((b.src_off * esz) % 16) return MMX_ERR_UNSUPPORTED;                        // 16-byte chunk loads
+        int j;
+        for (j = 0; j < cfg.ncw && cfg.wcls[j] != b.nx; ++j) {}
+        if (j == cfg.ncw) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; cfg.wcls[cfg.ncw++] = b.nx; }
+        for (j = 0; j < cfg.ncz && cfg.zcls[j] != b.nz; ++j) {}
+        if (j == cfg.ncz) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; cfg.zcls[cfg.ncz++] = b.nz; }
+        const int ntx = (b.nx + 15) / 16, ntz = (b.nz + 15) / 16;
+        if (ntx > cfg.maxcol) cfg.maxcol = ntx;
+        if (ntz > cfg.maxu) cfg.maxu = ntz;
+        if (b.ny * ntx > max_waves) max_waves = b.ny * ntx;
+    }
+    for (int j = cfg.ncw; j < MMX_ZX4_MAXCLS; ++j) cfg.wcls[j] = -1;
+    for (int j = cfg.ncz; j < MMX_ZX4_MAXCLS; ++j) cfg.zcls[j] = -1;
+    if ((vol->stride_y * esz) % 16 || (vol->stride_z * esz) % 16) return MMX_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(vol->d_data)) % 16) return MMX_ERR_UNSUPPORTED;
+    if (vol->stride_z * esz * 16 >= (int64_t(1) << 31)) return MMX_ERR_UNSUPPORTED;   // 32-bit row offsets in a tile
+    const int nx_entries = cfg.ncw * cfg.maxcol * NKX * 2;
+    const int nz_entries = cfg.ncz * cfg.maxu * cg::NKZ * 2;
+    const size_t xbytes = (size_t)nx_entries * 2 * 64 * sizeof(u4_4);
+    const size_t zbytes = (size_t)nz_entries * 2 * 64 * sizeof(u4_4);
+    if (xbytes + zbytes > scratch_bytes) return MMX_ERR_UNSUPPORTED;
+    u4_4* xtab = reinterpret_cast<u4_4*>(d_scratch);
+    u4_4* ztab = reinterpret_cast<u4_4*>(reinterpret_cast<char*>(d_scratch) + xbytes);
+    hipLaunchKernelGGL((zx4_setup<NKX, LA>), dim3((nx_entries + nz_entries + 3) / 4), dim3(256), 0, s, cfg, xtab, ztab);
+    dim3 grid((max_waves + 3) / 4, n_blocks);
+    if (vol->dtype == MMX_U16)
+        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, d_blocks, slot_elems, d_p, d_q, xtab, ztab, cfg);
+    else
+        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, d_blocks, slot_elems, d_p, d_q, xtab, ztab, cfg);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+}  // namespace
+
+// tx: the PLAIN half kernels (no input scale, no norm); d_scratch: device memory the fused path does not
+// otherwise use (the fragment tables: a few hundred KB)
+int mmx_launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                   int64_t slot_elems, const mmx_taps_f32& tx, int radius, float* d_p, float* d_q,
+                   void* d_scratch, size_t scratch_bytes, hipStream_t stream)
+{
+    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8) return MMX_ERR_UNSUPPORTED;
+    if (vol->stride_x != 1) return MMX_ERR_UNSUPPORTED;
+    if (radius < 1 || radius > MMX_MAX_RADIUS_FAST) return MMX_ERR_UNSUPPORTED;
+    if (radius <= 8) return launch_zx4<1, 1>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, stream);
+    if (radius <= 16) return launch_zx4<2, 1>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, stream);
+    return launch_zx4<2, 2>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, stream);
+}

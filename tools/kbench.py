@@ -22,7 +22,7 @@ e = a.edge
 # a volume holding `blocks` blocks of edge e, overlapping by 5 like the real grid
 g = int(np.ceil(a.blocks ** (1 / 3)))
 step = e - 5
-shape = (step * g + 5,) * 3
+shape = (step * g + 5, step * g + 5, -(-(step * g + 5) // 64) * 64)   # rows of whole 128-byte lines
 vol = synth.make_volume_device(shape, 3, dev)
 dvol = bl.DeviceVolume(vol)
 origins = [(z * step, y * step, x * step) for z in range(g) for y in range(g) for x in range(g)][:a.blocks]
@@ -69,7 +69,7 @@ for rep in range(a.reps + 1):
         res.setdefault(("peaks", ns), []).append(t["peaks"][0])
 torch.cuda.synchronize()
 alg = {"zpass": 10, "ypass": 16, "xpass": 12, "generic": 38 / 3, "zxpass": 10, "y2pass": 12}
-print(f"blocks {nb} x {e}^3 = {nvox/1e6:.0f} Mvox; candidates {int(count.item())}")
+print(f"blocks {nb} x {e}^3 = {nvox/1e6:.0f} Mvox; candidates {int(count.item())}; zx path {L.mmx_last_zx_path()}")
 for (k, R), v in sorted(res.items()):
     ms = float(np.median(v))
     if k == "peaks":

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Float32 LoG cubes of the matrix-core X+Z kernel (mmx_set_fused(4)) against SciPy's float64
+``gaussian_laplace`` and against the packed-VALU kernel (mode 2), over radii, widths, depths and dtypes,
+mixed-geometry batches included.  Prints the largest deviations; exits non-zero above the tolerance.
+
+    python tools/zx4_check.py
+"""
+import os
+import sys
+
+import numpy as np
+from scipy import ndimage as ndi
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from magellanmapper_amd import _native as nat, blob_log as bl  # noqa: E402
+
+TOL = 2e-6      # of the image value scale (eps / 4 of the exactness machinery is 5e-6)
+rng = np.random.default_rng(7)
+L = nat.lib()
+worst = 0.0
+fails = 0
+
+
+def run(vol, origins, shapes, sigma, label):
+    global worst, fails
+    dv = bl.DeviceVolume(vol)
+    space = bl.ScaleSpace.make(sigma, sigma, 1)
+    L.mmx_set_fused(4)
+    got = bl.log_cube_blocks(dv, 0, origins, shapes, space)
+    path = L.mmx_last_zx_path()
+    L.mmx_set_fused(2)
+    ref2 = bl.log_cube_blocks(dv, 0, origins, shapes, space)
+    imax = np.iinfo(vol.dtype).max
+    e64 = e2 = 0.0
+    for o, s, g, r2 in zip(origins, shapes, got, ref2):
+        sub = vol[o[0]:o[0] + s[0], o[1]:o[1] + s[1], o[2]:o[2] + s[2]].astype(np.float64) * (1.0 / imax)
+        want = -ndi.gaussian_laplace(sub, sigma) * sigma ** 2
+        e64 = max(e64, float(np.abs(g[..., 0] - want).max()))
+        e2 = max(e2, float(np.abs(r2[..., 0] - want).max()))
+    ok = path == 4 and e64 < TOL
+    worst = max(worst, e64)
+    fails += 0 if ok else 1
+    print(f"{'ok  ' if ok else 'FAIL'} {label:44s} R={int(space.radii[0]):2d} path={path} "
+          f"|zx4-f64|={e64:.2e} |zx2-f64|={e2:.2e}")
+
+
+for dtype in (np.uint16, np.uint8):
+    imax = np.iinfo(dtype).max
+    vol = rng.integers(0, imax + 1, size=(96, 40, 320), dtype=dtype)
+    vol[20:60, 5:30, 100:200] = (vol[20:60, 5:30, 100:200] // 16)        # a darker region (small values)
+    al = 8 if dtype == np.uint16 else 16
+    for sigma in (1.0, 1.5, 2.0, 2.6, 3.0, 3.5, 4.0, 4.3, 5.0, 6.0):
+        R = int(4 * sigma + 0.5)
+        cases = {
+            "one wide block": ([(0, 0, 0)], [(70, 30, 261)]),
+            "mixed widths / depths": ([(0, 0, 0), (3, 1, al), (5, 2, 2 * al), (0, 7, 3 * al)],
+                                      [(64, 32, 256), (37, 30, 61), (max(R + 1, 17), 31, max(R, 24)), (96, 29, max(R, 8))]),
+            "narrow": ([(2, 3, al)], [(max(R + 1, 33), 30, max(R, 8))]),
+            "multiples of 16": ([(0, 0, 0)], [(48, 32, 48)]),
+        }
+        for name, (orig, shp) in cases.items():
+            run(vol, orig, shp, sigma, f"{np.dtype(dtype).name} sigma {sigma} {name}")
+
+print(f"worst deviation from float64: {worst:.3e} (tolerance {TOL:.1e}); failures: {fails}")
+sys.exit(1 if fails else 0)
