@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 8
+#define MMX_ABI_VERSION 9
 
 typedef enum {
     MMX_OK = 0,
@@ -115,21 +115,33 @@ int mmx_device_count(void);
  *                NOT WRITTEN TO d_log (a response below the threshold can neither be a peak nor out-vote
  *                one): d_log is then only meaningful together with the entries.  Only the fused path produces
  *                the entries, and only when every block's rows fit its share (tiny blocks do not):
- *                *h_mask_written (host) says whether this call did (if not, d_log is complete).          */
+ *                *h_mask_written (host) says whether this call did (if not, d_log is complete).
+ *   zx_mode    : how the Z and X passes run (a per-call argument: the library keeps no mode).
+ *                MMX_ZX_AUTO (default): the fastest kernel that takes the geometry (today MMX_ZX_PACKED, else the
+ *                separate passes); the others exist for cross-checks and measurements.  All agree within float32 rounding, and the peak decisions are
+ *                taken on exact float64 values either way (mmx_rescore_f64).
+ *   h_zx_path  : optional out (host): the MMX_ZX_* kernel this call actually ran (MMX_ZX_SEPARATE when the
+ *                geometry fell back to the three separate passes)                                          */
+typedef enum {
+    MMX_ZX_AUTO = -1,
+    MMX_ZX_SEPARATE = 0,  /* three separate passes (register-ring column kernels + LDS row kernel)          */
+    MMX_ZX_PACKED = 2,    /* zx2_kernel: fused Z+X, wave-specialised, packed float32 VALU math              */
+    MMX_ZX_MFMA_F32 = 3,  /* zx3_kernel: Z on the VALU, X on v_mfma_f32_16x16x4_f32 (measured experiment)   */
+    MMX_ZX_MFMA_F16 = 4,  /* zx4_kernel: X+Z on v_mfma_f32_16x16x32_f16 with split-float16 operands,
+                             register resident (integer voxels; measured experiment)                       */
+    MMX_ZX_MFMA_F16_LDS = 5 /* zx5_kernel: the same arithmetic, voxels and results staged through LDS      */
+} mmx_zx_mode;
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                       int n_blocks, int64_t slot_elems,
                       const double* h_w0, const double* h_w2, int radius, double norm,
                       float* d_log, float* d_work, uint64_t* d_nms_mask, float nms_lo, float nms_eps,
-                      int* h_mask_written, void* stream);
+                      int* h_mask_written, int zx_mode, int* h_zx_path, void* stream);
 
-/* Select how the following mmx_log_batch_f32 calls run the Z and X passes: 0 = three separate passes,
- * 1 = first fused Z+X kernel (kept for comparison), 2 = wave-specialised packed-math fused Z+X kernel
- * (default; env MMX_FUSE sets the initial value).  Geometries the fused kernels do not take fall back to
- * the separate passes.  All three agree within float32 rounding (the NMS decisions are exact either way). */
-int mmx_set_fused(int mode);
-/* Diagnostic: which Z+X kernel the calling thread's last mmx_log_batch_f32 ran (0 = separate passes,
- * 1-4 = fused designs) -- tests use it to prove that a result came from the kernel they mean to check. */
-int mmx_last_zx_path(void);
+/* Bytes of device workspace one batch needs for `n_sigma` scales: the 4 intermediate arrays of
+ * mmx_log_batch_f32 (d_work), one d_log array per scale and, with `with_masks`, the NMS entries of every scale
+ * (d_nms_mask, 16-byte aligned).  slot_elems = the largest nz * ny * px of the batch (px = nx rounded up to
+ * MMX_ROW_ALIGN).  Layout used by the Python host code: [d_work | d_log x n_sigma | pad to 16 | masks]. */
+size_t mmx_workspace_bytes(int n_blocks, int64_t slot_elems, int n_sigma, int with_masks);
 
 /* Same contract, always through the generic (any radius <= MMX_MAX_RADIUS_GENERIC, any block
  * extent) kernels.  mmx_log_batch_f32 picks per pass between the register-ring kernels and

@@ -17,11 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 8
+MMX_ABI_VERSION = 9
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
 MMX_CAND_CONTESTED = 1
+#: ``mmx_zx_mode``: how mmx_log_batch_f32 runs its Z and X passes (a per-call argument)
+MMX_ZX_AUTO, MMX_ZX_SEPARATE, MMX_ZX_PACKED, MMX_ZX_MFMA_F32, MMX_ZX_MFMA_F16, MMX_ZX_MFMA_F16_LDS = -1, 0, 2, 3, 4, 5
 
 #: NumPy mirror of ``mmx_block`` (32 bytes).
 BLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("nz", "<i4"), ("ny", "<i4"), ("nx", "<i4"),
@@ -70,7 +72,7 @@ _lib = None
 #: every symbol ``include/mmx.h`` declares
 SYMBOLS = (
     "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
-    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_set_fused", "mmx_last_zx_path", "mmx_peaks_batch", "mmx_rescore_f64",
+    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
@@ -100,11 +102,10 @@ def lib() -> ctypes.CDLL:
     L.mmx_device_count.restype = c_int
     log_args = [POINTER(Volume), vp, vp, c_int, c_int64, POINTER(c_double), POINTER(c_double),
                 c_int, c_double, vp, vp]
-    L.mmx_log_batch_f32.argtypes = log_args + [vp, c_float, c_float, POINTER(c_int), vp]
+    L.mmx_log_batch_f32.argtypes = log_args + [vp, c_float, c_float, POINTER(c_int), c_int, POINTER(c_int), vp]
     L.mmx_log_batch_f32_generic.argtypes = log_args + [vp]
-    L.mmx_set_fused.argtypes = [c_int]
-    L.mmx_set_fused.restype = c_int
-    L.mmx_last_zx_path.restype = c_int
+    L.mmx_workspace_bytes.argtypes = [c_int, c_int64, c_int, c_int]
+    L.mmx_workspace_bytes.restype = ctypes.c_size_t
     L.mmx_peaks_batch.argtypes = [vp, vp, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
                                   c_uint32, vp, vp]
     L.mmx_rescore_f64.argtypes = [POINTER(Volume), vp, c_int, vp, c_uint32, vp, vp, vp,
@@ -148,7 +149,7 @@ def lib() -> ctypes.CDLL:
     L.mmx_preprocess_batch_generic.restype = c_int
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name == "mmx_preprocess_fast_lds":
+        if name in ("mmx_preprocess_fast_lds", "mmx_workspace_bytes"):
             continue
         if fn.restype is None or name.startswith(("mmx_log", "mmx_peaks", "mmx_rescore",
                                                   "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing", "mmx_calib", "mmx_host")):

@@ -31,6 +31,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -48,6 +49,11 @@ except Exception as exc:  # pragma: no cover
 EPS_REL = 2e-5
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9
+#: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
+#: default for kernel experiments; tests set it to cross-check the kernels against each other)
+ZX_MODE = int(os.environ.get("MMX_FUSE", nat.MMX_ZX_AUTO))
+#: the ``mmx_zx_mode`` the most recent ``mmx_log_batch_f32`` call of this process actually ran
+LAST_ZX_PATH = None
 
 _NP_TO_MMX = {np.dtype(np.uint8): nat.MMX_U8, np.dtype(np.uint16): nat.MMX_U16,
               np.dtype(np.float32): nat.MMX_F32, np.dtype(np.float64): nat.MMX_F64}
@@ -243,6 +249,8 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     Blocks keep their order (z-major grid order).
     """
     per_vox = (4 + num_sigma) * 4 + (num_sigma + 1) // 2 + extra_bytes_per_voxel     # + the NMS bit masks
+    if not len(shapes):
+        return []
     batches: List[List[int]] = []
     cur: List[int] = []
     cur_slot = 0
@@ -333,12 +341,16 @@ def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: Sc
     vol32 = dvol.view(channel, True)
     fn = L.mmx_log_batch_f32_generic if generic else L.mmx_log_batch_f32
     log_base = ws.data_ptr() + 4 * nb * slot * 4
+    global LAST_ZX_PATH
+    path = ctypes.c_int(0)
     for s in range(ns):
         nat.check(fn(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                      nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
                      int(space.radii[s]), float(space.norms[s]),
-                     log_base + s * nb * slot * 4, ws.data_ptr(), *(() if generic else (None, 0.0, 0.0, None)),
+                     log_base + s * nb * slot * 4, ws.data_ptr(),
+                     *(() if generic else (None, 0.0, 0.0, None, ZX_MODE, ctypes.byref(path))),
                      _stream_ptr()), "mmx_log_batch_f32")
+        LAST_ZX_PATH = None if generic else path.value
     torch.cuda.synchronize()
     logs = ws[4 * nb * slot:].view(ns, nb, slot).cpu().numpy()
     out = []
@@ -444,15 +456,17 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     if slot >= (1 << 29):
         raise nat.MmxError("block too large for one workspace slot (>= 2^29 voxels)")
     mask_words = (nb * slot) >> 5            # 16-byte entries per sigma (include/mmx.h: d_nms_mask)
-    ws = bufs.workspace((4 + ns) * nb * slot + 4 + ns * mask_words * 4)
+    ws = bufs.workspace(-(-int(L.mmx_workspace_bytes(nb, slot, ns, 1)) // 4))
     d_blocks = _to_device_bytes(blocks, dev)
     stream = _stream_ptr()
     log_base = ws.data_ptr() + 4 * nb * slot * 4
     # NMS pre-filter masks, [ns][nb][slot / 32] uint64: written by the Y pass of the fused path
     mask_base = (log_base + ns * nb * slot * 4 + 15) & ~15
     written = ctypes.c_int(0)
+    path = ctypes.c_int(0)
 
     def passes(with_mask: bool):
+        global LAST_ZX_PATH
         all_written, any_written = with_mask, False
         for s in range(ns):
             nat.check(L.mmx_log_batch_f32(
@@ -460,8 +474,9 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                 nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]), int(space.radii[s]),
                 float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(),
                 (mask_base + s * mask_words * 16) if with_mask else None, thr - eps, eps,
-                ctypes.byref(written), stream),
+                ctypes.byref(written), ZX_MODE, ctypes.byref(path), stream),
                 "mmx_log_batch_f32")
+            LAST_ZX_PATH = path.value
             all_written = all_written and written.value == 1
             any_written = any_written or written.value == 1
         return all_written, any_written

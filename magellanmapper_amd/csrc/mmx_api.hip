@@ -23,11 +23,6 @@ int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask
 
 namespace {
 thread_local char g_hip_err[256] = "";
-thread_local int g_last_zx = 0;   // which Z+X kernel the last mmx_log_batch_f32 of this thread ran (0 = separate passes)
-
-// 0 = three separate passes, 1 = first fused Z+X kernel (kept for comparison), 2 = wave-specialised
-// packed-math fused Z+X kernel (default: fastest; geometries it does not take use the separate passes)
-std::atomic<int> g_fused{getenv("MMX_FUSE") ? atoi(getenv("MMX_FUSE")) : 2};
 
 struct span { hipEvent_t a, b; int kind; };
 std::mutex g_tm;
@@ -106,10 +101,15 @@ int mmx_timing_read(double* ms, int64_t* launches, int n)
 
 int mmx_abi_version(void) { return MMX_ABI_VERSION; }
 
-int mmx_set_fused(int on)
+size_t mmx_workspace_bytes(int n_blocks, int64_t slot_elems, int n_sigma, int with_masks)
 {
-    g_fused.store(on);
-    return MMX_OK;
+    if (n_blocks < 1 || slot_elems < 1 || n_sigma < 1) return 0;
+    size_t bytes = (size_t)(4 + n_sigma) * (size_t)n_blocks * (size_t)slot_elems * sizeof(float);
+    if (with_masks) {
+        bytes = (bytes + 15) & ~(size_t)15;
+        bytes += (size_t)n_sigma * (((size_t)n_blocks * (size_t)slot_elems) >> 5) * 16;
+    }
+    return bytes;
 }
 
 const char* mmx_strerror(int status)
@@ -127,7 +127,6 @@ const char* mmx_strerror(int status)
 
 const char* mmx_last_hip_error(void) { return g_hip_err; }
 
-int mmx_last_zx_path(void) { return g_last_zx; }
 
 int mmx_device_count(void)
 {
@@ -146,9 +145,11 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
                       int n_blocks, int64_t slot_elems,
                       const double* h_w0, const double* h_w2, int radius, double norm,
                       float* d_log, float* d_work, uint64_t* d_nms_mask, float nms_lo, float nms_eps,
-                      int* h_mask_written, void* stream)
+                      int* h_mask_written, int zx_mode, int* h_zx_path, void* stream)
 {
     if (h_mask_written) *h_mask_written = 0;
+    if (h_zx_path) *h_zx_path = MMX_ZX_SEPARATE;
+    if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_MFMA_F16_LDS || zx_mode == 1) return MMX_ERR_ARG;
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
         return MMX_ERR_ARG;
     if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
@@ -215,28 +216,36 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         return t;
     };
     int rc;
-    // Fused path (experimental, off by default: mmx_set_fused / MMX_FUSE=1): Z and X in one kernel
-    // (Gz / Gzz never touch HBM), then Y.  Same results; on MI355X it is currently slower than the
-    // three separate passes (register-limited occupancy of the fused kernel).
+    // Fused path: Z and X in one kernel (Gz / Gzz never touch HBM), then Y.
     int max_ny = 0, max_px = 0;
     for (int i = 0; i < n_blocks; ++i) {
         if (h_blocks[i].ny > max_ny) max_ny = h_blocks[i].ny;
         if (h_blocks[i].px > max_px) max_px = h_blocks[i].px;
     }
-    const int fuse_mode = g_fused.load();
-    const bool fused = fuse_mode != 0 && fast_r && lane_ok && fast_y && min_nz >= radius + 1 && min_nx >= radius &&
-                       max_px <= 512 && vol->stride_y < (1 << 30);
+    const bool fused = zx_mode != MMX_ZX_SEPARATE && fast_r && lane_ok && fast_y && min_nz >= radius + 1 &&
+                       min_nx >= radius && max_px <= 512 && vol->stride_y < (1 << 30);
     if (fused) {
         mmx_taps_f32 tzz = taps(wz0, wz2), txx = taps(wy0, wy2), tyy = taps(wx0, wx2);
+        int path = MMX_ZX_PACKED;
         { mmx_timed_scope ts(MMX_K_ZX, s);
           rc = MMX_ERR_UNSUPPORTED;
-          if (fuse_mode == 4)     // X + Z on the matrix cores (integer voxels); geometries it does not take: zx2
+          // AUTO = the packed-VALU kernel.  The matrix-core kernels are correct and selectable, but measured on
+          // the benchmark volume none is faster (5.3 - 6.0 ms per 64 blocks whatever the
+          // radius, against 4.4 - 6.3 ms; in bench.py, where planes are 8 MiB apart, 5.9 against 5.5 on average)
+          const bool mfma16 = zx_mode == MMX_ZX_MFMA_F16 || zx_mode == MMX_ZX_MFMA_F16_LDS;
+          if (mfma16) {    // integer voxels, aligned rows; geometries it does not take: the packed kernel
+              path = zx_mode == MMX_ZX_MFMA_F16_LDS ? MMX_ZX_MFMA_F16_LDS : MMX_ZX_MFMA_F16;
               rc = mmx_launch_zx4(vol, d_blocks, h_blocks, n_blocks, slot_elems, txx, radius, t0, t1, t2,
-                                  (size_t)(2 * n_slots * slot_elems) * sizeof(float), s);
-          if (rc != MMX_ERR_UNSUPPORTED) g_last_zx = 4;
-          else if (fuse_mode == 3) { g_last_zx = 3; rc = mmx_launch_zx3(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
-          else if (fuse_mode == 2 || fuse_mode == 4) { g_last_zx = 2; rc = mmx_launch_zx2(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); }
-          else { g_last_zx = 1; rc = mmx_launch_zx(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s); } }
+                                  (size_t)(2 * n_slots * slot_elems) * sizeof(float), path == MMX_ZX_MFMA_F16_LDS, s);
+          } else if (zx_mode == MMX_ZX_MFMA_F32) {
+              path = MMX_ZX_MFMA_F32;
+              rc = mmx_launch_zx3(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);
+          }
+          if (rc == MMX_ERR_UNSUPPORTED) {
+              path = MMX_ZX_PACKED;
+              rc = mmx_launch_zx2(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);
+          } }
+        if (rc == MMX_OK && h_zx_path) *h_zx_path = path;
         if (rc == MMX_OK) {
             mmx_timed_scope ts(MMX_K_Y2, s);
             // the mask rows of a block (ny rows of ceil(nz * px / 64) words) must fit its slot / 32 words
@@ -253,7 +262,6 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         if (rc == MMX_OK) return MMX_OK;
         if (rc != MMX_ERR_UNSUPPORTED) return rc;   // unsupported geometry: separate passes below
     }
-    g_last_zx = 0;
     { mmx_timed_scope ts(fast_z ? MMX_K_ZPASS : MMX_K_GENERIC, s);
     if (fast_z) rc = mmx_launch_zpass(vol, d_blocks, n_blocks, max_zcols, slot_elems, taps(wz0, wz2), radius, t0, t1, s);
     else rc = mmx_launch_generic_pass(0, vol, d_blocks, n_blocks, max_vox, slot_elems, wz0, wz2, radius, nullptr, nullptr, t0, t1, s); }

@@ -38,9 +38,6 @@ int mmx_launch_xpass(const mmx_block* d_blocks, int n_blocks, int max_rows, int 
                      int64_t slot_elems, const mmx_taps_f32& taps, int radius,
                      const float* d_a, const float* d_bc, float* d_log, hipStream_t stream);
 
-int mmx_launch_zx(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_ny, int max_px,
-                  int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
-                  float* d_p, float* d_q, hipStream_t stream);
 int mmx_launch_zx2(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_ny, int max_px,
                    int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
                    float* d_p, float* d_q, hipStream_t s);
@@ -49,7 +46,7 @@ int mmx_launch_zx3(const mmx_volume* vol, const mmx_block* d_blocks, int n_block
                    float* d_p, float* d_q, hipStream_t s);
 int mmx_launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
                    int64_t slot_elems, const mmx_taps_f32& tx, int radius, float* d_p, float* d_q,
-                   void* d_scratch, size_t scratch_bytes, hipStream_t stream);
+                   void* d_scratch, size_t scratch_bytes, int staged, hipStream_t stream);
 int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
                   float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);

@@ -69,8 +69,8 @@ def test_log_cube_within_tolerance(gpu, case):
 
 @pytest.mark.parametrize("case", ["u16_5sigma", "u8_3sigma", "f32_2sigma", "u16_twoscale10"])
 def test_fused_zx_path_gives_the_same_cube(gpu, case):
-    """The fused Z+X kernels (mmx_set_fused 1: first design, 2: wave-specialised packed math, the default)
-    must reproduce the three-pass result (mode 0)."""
+    """The fused Z+X kernels (zx_mode 2: wave-specialised packed math, 3: float32 MFMA X pass, 4 / 5: split-float16
+    MFMA X+Z, register resident / staged through LDS) must reproduce the three-pass result (mode 0)."""
     from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
     g = load_golden("bloblog_%s.npz" % case)
@@ -78,14 +78,16 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
     dvol = bl.DeviceVolume(g["volume"])
     space = bl.ScaleSpace.make(float(g["min_sigma"]), float(g["max_sigma"]), int(g["num_sigma"]))
     shape = g["volume"].shape
+    default = bl.ZX_MODE
     try:
-        nat.lib().mmx_set_fused(0)
+        bl.ZX_MODE = nat.MMX_ZX_SEPARATE
         nat.timing_enable(True)
         sep = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
         kinds = nat.timing_read()
         assert kinds["zxpass"][1] == 0 and (kinds["zpass"][1] > 0 or kinds["generic"][1] > 0)
-        for mode in (1, 2):
-            nat.lib().mmx_set_fused(mode)
+        assert bl.LAST_ZX_PATH == nat.MMX_ZX_SEPARATE
+        for mode in (2, 3, 4, 5):
+            bl.ZX_MODE = mode
             fused = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
             kinds = nat.timing_read()
             # the fused kernels really ran (wherever the geometry lets any register-resident pass run)
@@ -93,7 +95,7 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
             assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL
             assert np.max(np.abs(fused - sep)) < 2e-6 * max(1.0, float(np.abs(sep).max()))
     finally:
-        nat.lib().mmx_set_fused(2)
+        bl.ZX_MODE = default
         nat.timing_enable(False)
 
 
@@ -484,7 +486,7 @@ def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
         detector.Blobs(np.ones((1, 4))).format_blobs()
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2])
+@pytest.mark.parametrize("fused", [0, 2, 3, 4, 5])
 def test_every_kernel_radius_matches_oracle(gpu, fused):
     """Each compiled radius (1..24 register-resident, 25 generic) of the separable passes against the
     float64 oracle cube.  Regression: the X pass read its register window in pairs but sized it odd for
@@ -494,7 +496,7 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
     vol = synth.make_volume(3, (35, 42, 48), 12)
     dvol = bl.DeviceVolume(vol)
     img = blo.img_as_float(vol)
-    nat.lib().mmx_set_fused(int(fused))
+    default, bl.ZX_MODE = bl.ZX_MODE, int(fused)
     try:
         for R in range(1, 26):
             sigma = (R + 0.2) / 4.0
@@ -503,8 +505,13 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
             got = np.squeeze(bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [vol.shape], space)[0])
             want = blo.log_cube(img, np.array([[sigma] * 3]))[..., 0]
             assert np.abs(got - want).max() < LOG_TOL * 1e-2, R
+            # the kernel asked for is the kernel that ran (its geometry conditions hold for this volume)
+            if fused in (2, 3) and 1 <= R <= 24:
+                assert bl.LAST_ZX_PATH == fused, (R, bl.LAST_ZX_PATH)
+            if fused in (4, 5) and 1 <= R <= 24:
+                assert bl.LAST_ZX_PATH == fused, (R, bl.LAST_ZX_PATH)
     finally:
-        nat.lib().mmx_set_fused(2)
+        bl.ZX_MODE = default
 
 
 def test_block_shape_and_dtype_sweep_matches_oracle(gpu):

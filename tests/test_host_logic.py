@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     vol = _native.Volume(0, 1, 0, 1, 1, 1)
     w = np.ones(3)
     assert lib.mmx_log_batch_f32(ctypes.byref(vol), None, None, 1, 8, _native.as_double_ptr(w),
-                                 _native.as_double_ptr(w), 2, 1.0, None, None, None, 0.0, 0.0, None, None) == 1
+                                 _native.as_double_ptr(w), 2, 1.0, None, None, None, 0.0, 0.0, None, -1, None, None) == 1
 
 
 def test_product_path_never_imports_the_oracle():

@@ -43,6 +43,8 @@ log_base = ws.data_ptr() + 4 * nb * slot * 4
 mask_words = (nb * slot) >> 5
 masks = torch.zeros(ns * mask_words * 2, dtype=torch.int64, device=dev)
 written = ctypes.c_int(0)
+zxp = ctypes.c_int(0)
+ZX = int(os.environ.get('MMX_FUSE', -1))
 for rep in range(a.reps + 1):
     if rep == 1:
         nat.timing_enable(True)
@@ -52,7 +54,7 @@ for rep in range(a.reps + 1):
         nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                      nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, s * s,
                      log_base + i * nb * slot * 4, ws.data_ptr(), *(() if a.generic else ((masks.data_ptr() + i * mask_words * 16) if a.mask else None, 0.1 - 2e-5, 2e-5,
-                                                    ctypes.byref(written))), stream), "log")
+                                                    ctypes.byref(written), ZX, ctypes.byref(zxp))), stream), "log")
         assert not a.mask or written.value == 1
         if rep >= 1:
             t = nat.timing_read()
@@ -69,7 +71,7 @@ for rep in range(a.reps + 1):
         res.setdefault(("peaks", ns), []).append(t["peaks"][0])
 torch.cuda.synchronize()
 alg = {"zpass": 10, "ypass": 16, "xpass": 12, "generic": 38 / 3, "zxpass": 10, "y2pass": 12}
-print(f"blocks {nb} x {e}^3 = {nvox/1e6:.0f} Mvox; candidates {int(count.item())}; zx path {L.mmx_last_zx_path()}")
+print(f"blocks {nb} x {e}^3 = {nvox/1e6:.0f} Mvox; candidates {int(count.item())}; zx path {zxp.value}")
 for (k, R), v in sorted(res.items()):
     ms = float(np.median(v))
     if k == "peaks":
@@ -83,7 +85,7 @@ if os.environ.get("ZX2_PROFILE"):
     R = k1.kernel_radius(a.sigmas[-1])
     w0 = k1.gaussian_half_kernel(a.sigmas[-1], 0, R); w2 = k1.gaussian_half_kernel(a.sigmas[-1], 2, R)
     nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, nat.as_double_ptr(w0),
-                 nat.as_double_ptr(w2), R, 1.0, log_base, ws.data_ptr(), None, 0.0, 0.0, None, stream), "log")
+                 nat.as_double_ptr(w2), R, 1.0, log_base, ws.data_ptr(), None, 0.0, 0.0, None, ZX, None, stream), "log")
     torch.cuda.synchronize()
     P = ws[:nb * slot].view(nb, slot).cpu().numpy()
     px = int(blocks["px"][0])

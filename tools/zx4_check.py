@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Float32 LoG cubes of the matrix-core X+Z kernel (mmx_set_fused(4)) against SciPy's float64
+"""Float32 LoG cubes of the matrix-core X+Z kernel (zx_mode 4 / 5) against SciPy's float64
 ``gaussian_laplace`` and against the packed-VALU kernel (mode 2), over radii, widths, depths and dtypes,
 mixed-geometry batches included.  Prints the largest deviations; exits non-zero above the tolerance.
 
@@ -16,6 +16,7 @@ import torch  # noqa: E402
 
 from magellanmapper_amd import _native as nat, blob_log as bl  # noqa: E402
 
+MODE = int(os.environ.get('ZX_CHECK_MODE', 4))     # 4: register resident, 5: staged through LDS
 TOL = 2e-6      # of the image value scale (eps / 4 of the exactness machinery is 5e-6)
 rng = np.random.default_rng(7)
 L = nat.lib()
@@ -27,10 +28,10 @@ def run(vol, origins, shapes, sigma, label):
     global worst, fails
     dv = bl.DeviceVolume(vol)
     space = bl.ScaleSpace.make(sigma, sigma, 1)
-    L.mmx_set_fused(4)
+    bl.ZX_MODE = MODE
     got = bl.log_cube_blocks(dv, 0, origins, shapes, space)
-    path = L.mmx_last_zx_path()
-    L.mmx_set_fused(2)
+    path = bl.LAST_ZX_PATH
+    bl.ZX_MODE = 2
     ref2 = bl.log_cube_blocks(dv, 0, origins, shapes, space)
     imax = np.iinfo(vol.dtype).max
     e64 = e2 = 0.0
@@ -39,7 +40,7 @@ def run(vol, origins, shapes, sigma, label):
         want = -ndi.gaussian_laplace(sub, sigma) * sigma ** 2
         e64 = max(e64, float(np.abs(g[..., 0] - want).max()))
         e2 = max(e2, float(np.abs(r2[..., 0] - want).max()))
-    ok = path == 4 and e64 < TOL
+    ok = path == MODE and e64 < TOL
     worst = max(worst, e64)
     fails += 0 if ok else 1
     print(f"{'ok  ' if ok else 'FAIL'} {label:44s} R={int(space.radii[0]):2d} path={path} "
