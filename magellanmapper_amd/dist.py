@@ -53,16 +53,29 @@ def _device_for_collectives():
     return torch.device("cpu")
 
 
-def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: int
+_last_gather_ms = 0.0
+
+
+def last_gather_ms() -> float:
+    """Wall milliseconds the most recent :func:`gather_tables` of this process spent (0 without a group)."""
+    return _last_gather_ms
+
+
+def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: int, decode_on: Optional[int] = None
                   ) -> List[Tuple[int, Optional[np.ndarray]]]:
     """All ranks' ``(block_index, table | None)`` lists, merged and sorted by block index.
 
-    Wire format: every table row is prefixed with its block index; ranks exchange row
-    counts and column counts first (one small all_gather), then one all_gather of the
-    row-padded float64 tables.
+    Wire format: every table row is prefixed with its block index; ranks exchange row counts, column counts
+    and one flag per block first (one small all_gather), then one all_gather of the row-padded float64 tables
+    (two collectives per call, a few MB: latency bound).  ``decode_on``: only that rank unpacks the tables (the
+    rank that prunes); the others get ``(index, None)`` placeholders back and skip the host work.
     """
+    global _last_gather_ms
+    _last_gather_ms = 0.0
     if not _active() or world_size() == 1:
         return sorted(local, key=lambda e: e[0])
+    import time
+    t_start = time.perf_counter()
     dev = _device_for_collectives()
     n_ranks = world_size()
     rows = [np.concatenate((np.full((len(t), 1), i, dtype=np.float64), t), axis=1)
@@ -73,7 +86,10 @@ def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: in
     # merges to an empty table, not to None), 2 = rows follow]
     max_share = -(-n_items // n_ranks)
     lo = share_bounds(n_items, rank(), n_ranks)[0]
-    tcols = max([t.shape[1] for _, t in local if t is not None] or [0])
+    widths = {t.shape[1] for _, t in local if t is not None}
+    if len(widths) > 1:
+        raise ValueError(f"block tables of one rank differ in width: {sorted(widths)}")
+    tcols = max(widths or [0])
     meta_np = np.zeros(3 + max_share, dtype=np.int64)
     meta_np[:3] = (mine.shape[0], mine.shape[1], tcols)
     for i, t in local:
@@ -81,28 +97,57 @@ def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: in
     meta = torch.from_numpy(meta_np).to(dev)
     metas = [torch.zeros_like(meta) for _ in range(n_ranks)]
     tdist.all_gather(metas, meta)
-    metas = [m.cpu().numpy() for m in metas]
-    max_rows = int(max(m[0] for m in metas))
-    n_cols = int(max(m[1] for m in metas))
+    metas = torch.stack(metas).cpu().numpy()
+    max_rows = int(metas[:, 0].max())
+    n_cols = int(metas[:, 1].max())
+    # every rank that holds rows must hold them at the same width (co-localisation columns are appended to
+    # every block table or to none): a narrower table would come back padded with zero columns
+    have = metas[metas[:, 0] > 0, 1]
+    if len(have) and not np.all(have == have[0]):
+        raise ValueError(f"ranks hold block tables of different widths: {sorted(set(int(v) - 1 for v in have))}")
+    decode = decode_on is None or decode_on == rank()
     out: List[Tuple[int, Optional[np.ndarray]]] = []
-    for r, m in enumerate(metas):
-        lo_r = share_bounds(n_items, r, n_ranks)[0]
-        for pos in np.nonzero(m[3:] == 1)[0]:
-            out.append((lo_r + int(pos), np.zeros((0, int(m[2])))))
+    recv = None
     if max_rows and n_cols:
         padded = np.zeros((max_rows, n_cols))
         padded[:mine.shape[0], :mine.shape[1]] = mine
         send = torch.from_numpy(padded).to(dev)
         recv = [torch.empty_like(send) for _ in range(n_ranks)]
         tdist.all_gather(recv, send)
-        for m, buf in zip(metas, recv):
-            tbl = buf.cpu().numpy()[:int(m[0])]
-            if len(tbl):
-                idx = tbl[:, 0].astype(np.int64)
-                # rows of one block are contiguous and in order
-                cuts = np.nonzero(np.diff(idx))[0] + 1
-                for part in np.split(tbl, cuts):
-                    out.append((int(part[0, 0]), np.ascontiguousarray(part[:, 1:])))
+    if decode:
+        for r, m in enumerate(metas):
+            lo_r = share_bounds(n_items, r, n_ranks)[0]
+            for pos in np.nonzero(m[3:] == 1)[0]:
+                out.append((lo_r + int(pos), np.zeros((0, int(m[2])))))
+        if recv is not None:
+            bufs = torch.stack(recv).cpu().numpy()                  # one device -> host copy
+            for m, tbl in zip(metas, bufs):
+                tbl = tbl[:int(m[0]), :int(m[1])]                   # this rank's own rows and width
+                if len(tbl):
+                    idx = tbl[:, 0].astype(np.int64)
+                    # rows of one block are contiguous and in order
+                    cuts = np.nonzero(np.diff(idx))[0] + 1
+                    for part in np.split(tbl, cuts):
+                        out.append((int(part[0, 0]), np.ascontiguousarray(part[:, 1:])))
     present = {i for i, _ in out}
     out.extend((i, None) for i in range(n_items) if i not in present)
+    _last_gather_ms = (time.perf_counter() - t_start) * 1e3
     return sorted(out, key=lambda e: e[0])
+
+
+def broadcast_table(table: Optional[np.ndarray], src: int = 0) -> Optional[np.ndarray]:
+    """``table`` of rank ``src`` (a float64 2-D array or ``None``) on every rank."""
+    if not _active() or world_size() == 1:
+        return table
+    dev = _device_for_collectives()
+    is_src = rank() == src
+    meta = torch.tensor([-1, 0] if (not is_src or table is None) else list(table.shape), dtype=torch.int64, device=dev)
+    tdist.broadcast(meta, src)
+    rows, cols = (int(v) for v in meta.cpu())
+    if rows < 0:
+        return None
+    buf = (torch.from_numpy(np.ascontiguousarray(table, dtype=np.float64)).to(dev) if is_src
+           else torch.empty((rows, cols), dtype=torch.float64, device=dev))
+    if rows * cols:
+        tdist.broadcast(buf, src)
+    return table if is_src else buf.cpu().numpy()

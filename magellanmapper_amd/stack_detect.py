@@ -230,8 +230,17 @@ class StackDetector:
                                                          exclude=exclude_of, coloc=coloc)
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
+        return cls.assemble_seg_rois(local, grid, n_extra, arena)
+
+    @staticmethod
+    def assemble_seg_rois(local, grid, n_extra: int = 0, arena=None):
+        """``(block index, table | None)`` pairs of this rank -> the grid-shaped object array of ALL blocks.
+        With torch.distributed initialised the tables of every rank are gathered first; only rank 0 (the rank
+        that prunes) unpacks them, the other ranks get ``None`` placeholders."""
+        from . import dist
+        coords = list(np.ndindex(*grid))
         seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
-        gathered = dist.gather_tables(local, len(coords))
+        gathered = dist.gather_tables(local, len(coords), decode_on=0)     # only the pruning rank unpacks
         if arena is None and dist.rank() == 0:
             # several ranks: the pruning rank lays the gathered tables out back to back (grid order)
             # so that merge_blobs and the native prune step take their fast path as on one GPU
@@ -341,13 +350,20 @@ def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, chann
         blocks.exclude_border, coloc, channels)
     detection_time = time() - time_detection_start
 
+    # Several ranks (torch.distributed): the gathered tables are unpacked on rank 0 only, rank 0 prunes and
+    # writes the CSVs, every rank returns the same final table (one broadcast).
+    from . import dist
+    is_root = dist.rank() == 0
     time_pruning_start = time()
-    segments_all, df_pruning = StackPruner.prune_blobs_mp(
-        roi, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
-        blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    segments_all, df_pruning = (None, None)
+    if is_root:
+        segments_all, df_pruning = StackPruner.prune_blobs_mp(
+            roi, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+            blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    segments_all = dist.broadcast_table(segments_all)
     pruning_time = time() - time_pruning_start
 
-    if df_pruning is not None and save_dfs and len(df_pruning):
+    if is_root and df_pruning is not None and save_dfs and len(df_pruning):
         _save_pruning_ratios(df_pruning)
 
     blobs = detector.Blobs(segments_all, path=filename_blobs)
@@ -369,7 +385,7 @@ def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, chann
     times = {StackTimes.DETECTION: [detection_time], StackTimes.PRUNING: [pruning_time],
              StackTimes.TOTAL: time() - time_start}
     blobs.times = times
-    if save_dfs:
+    if save_dfs and is_root:
         import pandas as pd
         pd.DataFrame({k.value: v for k, v in times.items()}).to_csv(
             "stack_detection_times.csv", index=False)

@@ -57,13 +57,120 @@ def _worker(rank, world, port, n_items, out_dir):
         td.destroy_process_group()
 
 
-def test_gather_tables_two_ranks(tmp_path):
+def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    tmp.spawn(_worker, args=(2, port, 11, str(tmp_path)), nprocs=2, join=True)
-    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
-    assert int(open(tmp_path / "ok0").read()) + int(open(tmp_path / "ok1").read()) == 11
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 11), (3, 10), (4, 13)])
+def test_gather_tables_uneven_shares(tmp_path, world, n_items):
+    """Uneven shares (10 blocks over 3 ranks, 13 over 4), blocks without a table and EMPTY tables."""
+    tmp.spawn(_worker, args=(world, _free_port(), n_items, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+    assert sum(int(open(tmp_path / f"ok{r}").read()) for r in range(world)) == n_items
+
+
+# ---------------------------------------------------------------- the whole N-rank tail: gather -> prune on rank 0
+GRID_SHAPE, SEGMENT = (70, 96, 100), 40
+
+
+def _block_tables(seed=11, n_cols=11):
+    """Per-block 11(+2)-column tables as detection would leave them: seeded blob centres, every block lists the
+    centres inside its (overlapping) extent, so that duplicates sit in the overlaps; one block EMPTY, one None."""
+    from magellanmapper_amd import config, stack_detect
+    config.setup_roi_profiles(None)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.roi_profile.update(segment_size=SEGMENT, denoise_size=None)
+    blocks = stack_detect.setup_blocks(config.roi_profile, GRID_SHAPE)
+    rng = np.random.default_rng(seed)
+    centres = rng.integers(0, GRID_SHAPE, (1500, 3))
+    tables = []
+    grid = blocks.sub_roi_slices.shape
+    for k, c in enumerate(np.ndindex(*grid)):
+        slc = blocks.sub_roi_slices[c]
+        lo = np.array([s.indices(n)[0] for s, n in zip(slc, GRID_SHAPE)])
+        hi = np.array([s.indices(n)[1] for s, n in zip(slc, GRID_SHAPE)])
+        inside = np.all((centres >= lo) & (centres < hi), axis=1)
+        pts = centres[inside] + rng.integers(-1, 2, (int(inside.sum()), 3))      # each block sees it a voxel off
+        pts = np.clip(pts, lo, hi - 1)
+        if k == 4:
+            tables.append(np.zeros((0, n_cols)))
+            continue
+        if k == 7 or not len(pts):
+            tables.append(None)
+            continue
+        t = np.full((len(pts), n_cols), -1.0)
+        t[:, 0:3] = pts
+        t[:, 3] = 5.0
+        t[:, 6] = 0
+        t[:, 7:10] = pts
+        if n_cols > 11:
+            t[:, 11:] = rng.integers(0, 2, (len(pts), n_cols - 11))
+        tables.append(t)
+    return blocks, tables
+
+
+def _prune(blocks, seg_rois):
+    from magellanmapper_amd import stack_detect
+
+    class Img:
+        shape = GRID_SHAPE
+    return stack_detect.StackPruner.prune_blobs_mp(Img, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                   blocks.sub_rois_offsets, [0], blocks.overlap_padding)[0]
+
+
+def _worker_prune(rank, world, port, n_cols, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from magellanmapper_amd import dist as d, stack_detect
+        blocks, tables = _block_tables(n_cols=n_cols)
+        mine = d.my_share(len(tables))
+        seg = stack_detect.StackDetector.assemble_seg_rois([(i, tables[i]) for i in mine],
+                                                           blocks.sub_roi_slices.shape, n_cols - 11)
+        pruned = _prune(blocks, seg) if rank == 0 else None
+        pruned = d.broadcast_table(pruned)
+        np.save(os.path.join(out_dir, f"pruned{rank}.npy"), pruned)
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_cols", [(2, 11), (3, 11), (4, 13)])
+def test_ranks_gather_then_rank0_prunes_like_one_process(tmp_path, world, n_cols):
+    """Block tables sharded over 2-4 ranks (uneven shares, an EMPTY and a missing block, 13-column tables with
+    co-localisation flags), gathered, pruned on rank 0 and broadcast: the same table, row for row, as one
+    process pruning all blocks -- on every rank."""
+    from magellanmapper_amd import stack_detect
+    blocks, tables = _block_tables(n_cols=n_cols)
+    seg = stack_detect.StackDetector.assemble_seg_rois(list(enumerate(tables)), blocks.sub_roi_slices.shape,
+                                                       n_cols - 11)
+    want = _prune(blocks, seg)
+    assert want is not None and 200 < len(want) < sum(len(t) for t in tables if t is not None)
+    tmp.spawn(_worker_prune, args=(world, _free_port(), n_cols, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"pruned{r}.npy"), want)
+
+
+def test_gather_rejects_tables_of_different_widths():
+    from magellanmapper_amd import dist as d
+    with pytest.raises(ValueError):
+        # (single process: the per-rank check; across ranks the meta exchange makes the same check)
+        import torch.distributed as td
+        td.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{_free_port()}")
+        try:
+            d._active()
+            # world_size 1 short-circuits: call the width check through a 1-rank "multi-rank" path
+            old = d.world_size
+            d.world_size = lambda: 2
+            try:
+                d.gather_tables([(0, np.ones((1, 11))), (1, np.ones((1, 13)))], 2)
+            finally:
+                d.world_size = old
+        finally:
+            td.destroy_process_group()
 
 
 def test_single_process_passthrough():

@@ -1,0 +1,148 @@
+"""The BASELINE.json configurations at (or near) their real geometry, through the C ABI, against the oracle.
+
+  * two blocks of the benchmark geometry (261 wide, 5 sigmas, kernel radii 12..20, the seed-3 generator):
+    per-block tables and the pruned table
+  * C2 (configs[1]): 512 x 512 x 256, single sigma, through ``bench.py --config c2``
+  * C5-shaped (configs[4]): a 2-channel volume, preprocessing on, intensity co-localisation, the blocks
+    sharded over 2 and 3 ranks that share the GPU (gloo), through ``bench.py --config c5``
+"""
+import json
+import multiprocessing as mp
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+RES = np.array([[1.0, 1.0, 1.0]])
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda", 0)
+
+
+def _host_volume(shape, seed, channels=1):
+    """bench.py's generator on the host (the benchmark's blob field: density, amplitude, background)."""
+    import torch
+    from magellanmapper_amd import synth
+    c0 = synth.make_volume_device(shape, seed, torch.device("cpu")).to(torch.int32)
+    if channels == 1:
+        return c0.numpy().astype(np.uint16)
+    c1 = synth.make_volume_device(shape, seed + 1, torch.device("cpu")).to(torch.int32)
+    c1 = torch.maximum(c1, (c0 * 7) // 10)
+    return torch.stack((c0, c1), dim=-1).numpy().astype(np.uint16)
+
+
+def _bench_profile(**over):
+    sys.path.insert(0, ROOT)
+    import bench
+    return dict(bench._BASE_PROFILE, **over)
+
+
+def _oracle_block(args):
+    coord, offset, last, sub, profile = args
+    sys.path.insert(0, ROOT)
+    from oracle import magmap_oracle as mmo
+    return coord, mmo.detect_sub_roi(coord, offset, last, None, sub, None, [profile], RES)
+
+
+def test_two_blocks_of_the_benchmark_geometry(gpu):
+    """Blocks as the 2048^2 x 1024 volume cuts them: 261 voxels wide (256 + the 5 overlap columns, the tail
+    producer wave of the fused kernel), 5 sigmas 3..5 (radii 12, 14, 16, 18, 20), uint16 from the seed-3 generator;
+    only the depth is cut to 101 planes so that the float64 oracle takes seconds per block."""
+    from magellanmapper_amd import blob_log as bl, config, stack_detect
+    from oracle import magmap_oracle as mmo
+    shape = (101, 261, 517)
+    vol = _host_volume(shape, 3)
+    profile = _bench_profile()
+    config.setup_roi_profiles(None)
+    config.resolutions, config.filename = RES, "cfgtest"
+    config.roi_profile.update(profile)
+    blk = stack_detect.setup_blocks(config.roi_profile, (101, 261, 512))       # tol / overlap as the benchmark's
+    slices = np.empty((1, 1, 2), dtype=object)
+    slices[0, 0, 0] = (slice(0, 101), slice(0, 261), slice(0, 261))
+    slices[0, 0, 1] = (slice(0, 101), slice(0, 261), slice(256, 517))
+    offsets = np.zeros((1, 1, 2, 3), dtype=int)
+    offsets[0, 0, 1] = (0, 0, 256)
+    seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, bl.DeviceVolume(vol), slices, offsets, None, None,
+                                                           False, [0])
+    assert bl.LAST_ZX_PATH == 2                       # the fused packed-math kernel took this geometry
+    st = stack_detect.StackDetector.last_stats
+    assert st.n_blocks == 2 and st.max_f32_error < 0.25 * bl.EPS_REL
+    got, _ = stack_detect.StackPruner.prune_blobs_mp(vol, seg, blk.overlap, blk.tol, slices, offsets, [0],
+                                                     blk.overlap_padding)
+    last = np.array([0, 0, 1])
+    jobs = [(c, offsets[c], last, vol[slices[c]], profile) for c in ((0, 0, 0), (0, 0, 1))]
+    want_seg = np.zeros((1, 1, 2), dtype=object)
+    with mp.get_context("spawn").Pool(2) as pool:
+        for c, tbl in pool.imap_unordered(_oracle_block, jobs):
+            want_seg[c] = tbl
+    for c in ((0, 0, 0), (0, 0, 1)):
+        assert want_seg[c] is not None and len(want_seg[c]) > 200
+        np.testing.assert_array_equal(seg[c], want_seg[c])          # per-block tables, row for row
+    want, _ = mmo.prune_blobs_mp(shape, want_seg, blk.overlap, blk.tol, slices, offsets, [0], blk.overlap_padding)
+    assert len(want) < len(want_seg[0, 0, 0]) + len(want_seg[0, 0, 1])      # the seam had duplicates
+    np.testing.assert_array_equal(got, want)
+
+
+def _run_bench(tmp_path, ranks, *extra, timeout=900):
+    env = dict(os.environ, MMX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", *extra]
+    if ranks > 1:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + cmd
+    run = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout, env=env,
+                         cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-3000:]
+    return json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_c2_single_sigma_volume_matches_oracle(gpu, tmp_path):
+    """BASELINE.json configs[1] at full size: 512 x 512 x 256 uint16, one sigma (3), segment_size 256 -> 4 blocks of
+    256 x 261 x 261; the final table of ``bench.py --config c2`` equals the oracle's, and the run reports its roofline."""
+    from oracle import magmap_oracle as mmo
+    shape = (256, 512, 512)
+    vol = _host_volume(shape, 2)
+    np.save(tmp_path / "c2.npy", vol)
+    line = _run_bench(tmp_path, 1, "--config", "c2", "--volume", str(tmp_path / "c2.npy"), "--dump",
+                      str(tmp_path / "c2.npz"))
+    assert line["config"]["blocks_per_rank"] == 4 and line["roofline"]["kernel"] in ("zxpass", "y2pass")
+    profile = _bench_profile(min_sigma_factor=3, max_sigma_factor=3, num_sigma=1)
+    want, _ = mmo.detect_blobs_blocks(vol, None, [profile], RES)
+    got = np.load(tmp_path / "c2.npz")["final"]
+    assert len(want) > 3000
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_c5_shaped_two_channel_coloc_over_ranks(gpu, tmp_path, ranks):
+    """BASELINE.json configs[4] in small: 2 channels (30 % of channel 1's blobs of its own), per-block preprocessing
+    (denoise_size 25), both channels detected, intensity co-localisation, blocks sharded over ranks that share this
+    GPU (gloo), gathered and pruned on rank 0: final table and ``colocs`` equal the oracle's."""
+    from oracle import magmap_oracle as mmo
+    shape = (56, 150, 160)
+    vol = _host_volume(shape, 3, channels=2)
+    np.save(tmp_path / "c5.npy", vol)
+    line = _run_bench(tmp_path, ranks, "--config", "c5", "--segment-size", "64", "--volume", str(tmp_path / "c5.npy"),
+                      "--dump", str(tmp_path / "c5.npz"))
+    assert line["n_gpus"] == ranks and len(line["ranks"]) == ranks
+    assert sum(r["blocks"] for r in line["ranks"]) == 9                 # 1 x 3 x 3 blocks, uneven over 2 ranks
+    profile = _bench_profile(denoise_size=25, segment_size=64)
+    want, stages = mmo.detect_blobs_blocks(vol, [0, 1], [profile, profile], RES, near_max=[-1.0, -1.0], coloc=True)
+    dump = np.load(tmp_path / "c5.npz")
+    assert len(want) > 100 and set(np.unique(want[:, 6])) == {0.0, 1.0}
+    np.testing.assert_array_equal(dump["final"], want)
+    np.testing.assert_array_equal(dump["colocs"], stages["colocs"])
