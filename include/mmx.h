@@ -392,6 +392,17 @@ int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int
 int mmx_host_map_columns(const double* table, int64_t ld, int64_t n, const int32_t* src_cols,
                          int32_t n_map, double* out, int64_t out_ld, int32_t dst_col0);
 
+/* ---- match-based co-localisation: the two third-party calls of the reference's
+ * verifier.find_closest_blobs_cdist (magmap/cv/verifier.py:47-119).
+ * mmx_cdist_f64: d_out[i * m + j] = || a_i - b_j ||_2 for float64 points of `dim` (<= 8) coordinates -- replaces
+ *   scipy.spatial.distance.cdist(a, b) (:85), same operation order, no FMA: bit-equal.  n <= 65535.
+ * mmx_host_lsap: optimal assignment of a dense nr x nc float64 cost matrix (host memory) -- replaces
+ *   scipy.optimize.linear_sum_assignment(dists) (:86): min(nr, nc) pairs in ascending row order, and where the
+ *   optimum is not unique (blob coordinates are integers: tied distances are common) the SAME optimum SciPy's
+ *   shortest-augmenting-path solver returns. */
+int mmx_cdist_f64(const double* d_a, int64_t n, const double* d_b, int64_t m, int dim, double* d_out, void* stream);
+int mmx_host_lsap(const double* cost, int64_t nr, int64_t nc, int64_t* out_rows, int64_t* out_cols);
+
 /* PMC calibration (tools/pmc_calib.py): one streaming launch over n_elems elements with a known
  * byte count.  kind 0: float copy, 4 B per lane; 1: float copy, 16 B per lane; 2: uint16 read. */
 int mmx_calib_stream(int kind, const void* d_in, void* d_out, int64_t n_elems, void* stream);

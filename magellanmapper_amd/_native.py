@@ -78,6 +78,7 @@ SYMBOLS = (
     "mmx_calib_stream", "mmx_host_prune_axis",
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
     "mmx_coloc_means", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
+    "mmx_cdist_f64", "mmx_host_lsap",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass", "preproc", "coloc")
@@ -143,6 +144,10 @@ def lib() -> ctypes.CDLL:
     L.mmx_unmix_batch.restype = c_int
     L.mmx_host_take_rows.argtypes = [vp, c_int64, vp, c_int64, c_int64, vp, POINTER(c_int32), vp]
     L.mmx_host_map_columns.argtypes = [vp, c_int64, c_int64, POINTER(c_int32), c_int32, vp, c_int64, c_int32]
+    L.mmx_cdist_f64.argtypes = [vp, c_int64, vp, c_int64, c_int, vp, vp]
+    L.mmx_cdist_f64.restype = c_int
+    L.mmx_host_lsap.argtypes = [vp, c_int64, c_int64, vp, vp]
+    L.mmx_host_lsap.restype = c_int
     L.mmx_coloc_means.argtypes = [POINTER(Volume), vp, c_int, vp, vp, c_int, vp, vp, vp]
     L.mmx_coloc_means.restype = c_int
     L.mmx_preprocess_batch.restype = c_int

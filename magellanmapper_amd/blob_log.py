@@ -44,6 +44,17 @@ try:  # torch is the device-memory / stream plumbing
     import torch
 except Exception as exc:  # pragma: no cover
     raise ImportError("magellanmapper_amd needs PyTorch-ROCm for device memory") from exc
+try:
+    # A declared dependency of the product path (not of the kernels): when two overlapping blobs of a block
+    # each win one pair and lose another, scikit-image's outcome depends on the order in which
+    # ``cKDTree.query_pairs`` returns the pairs (skimage/feature/blob.py:169-172) -- implementation defined, so
+    # the only faithful source is the same call (``_reference_pair_order``; 13 of the 256 benchmark blocks).
+    # Fixtures were made with SciPy 1.7.1, the reference pins 1.15.3 (envs/requirements.txt:47); both agree on
+    # every golden case.  SciPy is the reference's own dependency, so it is present wherever this drops in.
+    from scipy import spatial as _scipy_spatial
+except Exception as exc:  # pragma: no cover
+    raise ImportError("magellanmapper_amd needs SciPy (scipy.spatial.cKDTree) for the reference's pair "
+                      "order in chained overlap prunes") from exc
 
 #: half-width of the float32 "contested" band, relative to the input's value scale
 EPS_REL = 2e-5
@@ -237,6 +248,7 @@ class BatchStats:
     n_blobs: int = 0
     n_overlap_pairs: int = 0
     n_order_fallbacks: int = 0
+    n_band_retries: int = 0       # batches nominated again because float32 strayed too far from float64
     max_f32_error: float = 0.0
 
 
@@ -507,7 +519,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     done.record()
     return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
                 nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
-                vol_exact=vol_exact, pre=pre, exact=exact)
+                vol_exact=vol_exact, pre=pre, exact=exact, eps=eps)
 
 
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
@@ -515,6 +527,7 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
     """Wait for one batch's candidates and turn them into ordered raw peaks
     ``(coords int64 (n, 4), values float64 (n,))`` per block."""
     job["done"].synchronize()
+    eps = job.get("eps", eps)
     which, cap, ns = job["which"], job["cap"], job["ns"]
     count = int(bufs.host_counts[which].item()) & 0xFFFFFFFF
     if count > cap:
@@ -535,22 +548,53 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
         table = bufs.cands[which]
         cands = (table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
                  if count else np.zeros(0, dtype=nat.CAND_DTYPE))
-        stats.n_blocks += job["nb"]
-        stats.n_voxels += job["n_vox"]
-        stats.n_candidates += count
-        return _resolve_peaks(cands, job["blocks"], job["shapes"], ns, thr, dvol, job["vol_exact"],
-                              job["d_blocks"], d_w0, d_w2, space, job["store_f32"], stats, eps,
-                              job.get("exact", False))
+        try:
+            out = _resolve_peaks(cands, job["blocks"], job["shapes"], ns, thr, dvol, job["vol_exact"],
+                                 job["d_blocks"], d_w0, d_w2, space, job["store_f32"], stats, eps,
+                                 job.get("exact", False))
+        except _BandTooNarrow as exc:
+            out = None
+            err = exc.err
+            wider = max(2.0 * eps, 8.0 * err)
+        if out is not None:
+            stats.n_blocks += job["nb"]
+            stats.n_voxels += job["n_vox"]
+            stats.n_candidates += count
+            return out
+    # the float32 values were further from the exact ones than the band allows: nominate this batch again
+    # with a band of 8 x the deviation found (the exact re-score then decides as always).  The pipeline has
+    # reused the workspace, so the passes run again.
+    if job.get("retries", 0) >= 6:
+        raise nat.MmxError(f"float32 LoG deviates from the exact values by {err:.3g}: no usable band")
+    stats.n_band_retries += 1
+    torch.cuda.current_stream().synchronize()
+    redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr, wider, bufs, which,
+                           d_w0, d_w2, cap=None, pre=job.get("pre"), exact=True)
+    redo["batch"] = job.get("batch")
+    redo["retries"] = job.get("retries", 0) + 1
+    return _finish_detect(redo, dvol, space, thr, wider, bufs, d_w0, d_w2, stats)
+
+
+class _BandTooNarrow(Exception):
+    """The float32 values of a batch deviate from the exact ones by more than a quarter of the nomination
+    band: the batch is nominated again with a wider band (``_finish_detect``)."""
+
+    def __init__(self, err: float):
+        super().__init__(err)
+        self.err = err
 
 
 def _check_f32_error(v32, v64, eps, stats):
+    """Every candidate the reference would find is nominated as long as |float32 - float64| < eps / 4 (a true
+    maximum then stays within eps of its float32 neighbours and of the threshold).  A larger deviation -- a float
+    image with a huge dynamic range, say -- is not fatal: the caller widens the band and nominates again."""
     if len(v32):
         err = float(np.max(np.abs(v32.astype(np.float64) - v64)))
-        stats.max_f32_error = max(stats.max_f32_error, err)
+        if not np.isfinite(err):
+            raise nat.MmxError("non-finite LoG values: the image holds NaN or infinite voxels")
         if not err < 0.25 * eps:
-            raise nat.MmxError(
-                f"float32 LoG deviates from the exact value by {err:.3g} (band {eps:.3g}): "
-                "refusing to decide peaks on it")
+            raise _BandTooNarrow(err)
+        stats.max_f32_error = max(stats.max_f32_error, err)
 
 
 def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_w0, d_w2,
@@ -570,11 +614,13 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
     nb = len(blocks)
     keep = np.ones(len(cands), dtype=bool)
     contested = np.nonzero(cands["flags"] & nat.MMX_CAND_CONTESTED)[0]
-    stats.n_contested += len(contested)
     v32 = cands["v"].astype(np.float64)
     if exact:
-        _check_f32_error(cands["v"], cands["v64"], eps, stats)
+        _check_f32_error(cands["v"], cands["v64"], eps, stats)      # (raises before any counter moves)
         selves = np.zeros(0, dtype=np.int64)
+    stats.n_contested += len(contested)
+    if exact:
+        pass
     else:
         # candidates of one block whose float32 values are within eps of each other: their order is open
         cslot = cands["slot"].astype(np.int64)
@@ -691,10 +737,9 @@ def _reference_pair_order(lm: np.ndarray) -> np.ndarray:
     """The visiting order ``_prune_blobs`` uses (blob.py:169-172): iteration order of the
     Python ``set`` returned by SciPy's ``cKDTree.query_pairs``.  It is implementation
     defined, so when the outcome depends on it the only faithful source is the same call."""
-    from scipy import spatial
     sigma = lm[:, -1].max()
     distance = 2 * sigma * math.sqrt(lm.shape[1] - 1)
-    tree = spatial.cKDTree(lm[:, :-1])
+    tree = _scipy_spatial.cKDTree(lm[:, :-1])
     return np.array(list(tree.query_pairs(distance)))
 
 

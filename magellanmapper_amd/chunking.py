@@ -35,6 +35,17 @@ def is_fork() -> bool:
     return mp.get_start_method(False) == "fork"
 
 
+def get_mp_pool(initializer=None, initargs=None):
+    """A ``multiprocessing.Pool`` sized by ``config.cpus`` and the first ROI profile's ``mp_max_tasks``
+    (reference magmap/cv/chunking.py:143-167).  The detection path here sends blocks to the GPU, not to a pool;
+    callers of the reference's helper (the match-based co-localiser, user scripts) still get their pool.  Worker
+    processes must not touch the GPU the parent holds: use it for host-only work."""
+    prof = config.get_roi_profile(0)
+    max_tasks = None if not prof else prof["mp_max_tasks"]
+    return mp.Pool(processes=config.cpus, maxtasksperchild=max_tasks, initializer=initializer,
+                   initargs=() if initargs is None else initargs)
+
+
 def stack_splitter(shape: Sequence[int], max_pixels: Sequence[int],
                    overlap: Optional[Sequence[int]] = None) -> Tuple[np.ndarray, np.ndarray]:
     """``(sub_roi_slices, sub_rois_offsets)``: an object array of slice triples indexed by

@@ -29,15 +29,20 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/mmx.h"
 
 namespace {
 // A small persistent pool: the tables have ~3e5 rows, so one parallel section is a fraction of a
 // millisecond of work and creating threads per section would cost as much as the work itself.
+// fork(): the child inherits the pool object but none of its threads (the reference's default start method is
+// "fork"), so a parallel section there would wait for workers that do not exist.  The pool remembers the pid it
+// was built in; in any other process every section runs on the calling thread.
 class pool {
 public:
     static pool& get() { static pool p; return p; }
-    int size() const { return (int)workers_.size() + 1; }
+    int size() const { return owner_ == getpid() ? (int)workers_.size() + 1 : 1; }
     // run fn(t, n) for t = 0..n-1, n <= size(); the caller is thread 0
     void run(int n, const std::function<void(int, int)>& fn)
     {
@@ -58,10 +63,15 @@ private:
     {
         const unsigned hw = std::thread::hardware_concurrency();
         const int n = (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+        owner_ = getpid();
         for (int t = 1; t < n; ++t) workers_.emplace_back([this, t] { loop(t); });
     }
     ~pool()
     {
+        if (owner_ != getpid()) {          // a forked child: the threads were never here
+            for (auto& w : workers_) w.detach();
+            return;
+        }
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
         cv_.notify_all();
         for (auto& w : workers_) w.join();
@@ -87,6 +97,7 @@ private:
         }
     }
     std::vector<std::thread> workers_;
+    pid_t owner_ = 0;
     std::mutex m_, serial_;
     std::condition_variable cv_, done_;
     const std::function<void(int, int)>* fn_ = nullptr;
@@ -328,5 +339,103 @@ extern "C" int mmx_host_take_rows(const double* table, int64_t ld, const int64_t
             for (int a = 0; a < 3; ++a) o[abs_cols[a]] = abs_zyx[3 * r + a];
         }
     });
+    return MMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// mmx_host_lsap -- rectangular linear sum assignment (minimum total cost, every row of the shorter side assigned),
+// what the reference's match-based co-localisation gets from scipy.optimize.linear_sum_assignment
+// (magmap/cv/verifier.py:86: `rowis, colis = optimize.linear_sum_assignment(dists)`).
+//
+// Algorithm: shortest augmenting paths with dual variables (D. F. Crouse, "On implementing 2D rectangular
+// assignment algorithms", IEEE Trans. Aerospace and Electronic Systems 52(4), 2016), the algorithm SciPy
+// implements.  Blob coordinates are integers, so many distances are EQUAL and the optimum is often not unique:
+// to return the assignment the reference gets, the free choices follow SciPy's: rows are inserted in order; the
+// columns not yet scanned are kept in an array initialised in DESCENDING order and scanned front to back, a
+// scanned column is replaced by the array's last entry; among equal tentative distances the LAST candidate in
+// scan order that is still unassigned wins, otherwise the first one found; a matrix with more rows than columns
+// is solved transposed and its pairs returned sorted by row.  Outputs are `min(nr, nc)` (row, column) pairs in
+// ascending row order.  Returns MMX_ERR_ARG for NaN / -inf entries or when no finite assignment exists.
+extern "C" int mmx_host_lsap(const double* cost, int64_t nr, int64_t nc, int64_t* out_rows, int64_t* out_cols)
+{
+    if (nr < 0 || nc < 0 || (nr && nc && (!cost || !out_rows || !out_cols))) return MMX_ERR_ARG;
+    if (nr == 0 || nc == 0) return MMX_OK;
+    const bool transposed = nc < nr;
+    std::vector<double> tmp;
+    const double* c = cost;
+    int64_t n_small = nr, n_big = nc;        // the problem solved has n_small rows <= n_big columns
+    if (transposed) {
+        tmp.resize((size_t)(nr * nc));
+        for (int64_t i = 0; i < nr; ++i)
+            for (int64_t j = 0; j < nc; ++j) tmp[(size_t)(j * nr + i)] = cost[i * nc + j];
+        c = tmp.data();
+        n_small = nc;
+        n_big = nr;
+    }
+    for (int64_t k = 0; k < nr * nc; ++k)
+        if (c[k] != c[k] || c[k] == -INFINITY) return MMX_ERR_ARG;
+
+    std::vector<double> dual_row((size_t)n_small, 0.0), dual_col((size_t)n_big, 0.0), dist((size_t)n_big);
+    std::vector<int64_t> pred((size_t)n_big, -1), col_of_row((size_t)n_small, -1), row_of_col((size_t)n_big, -1);
+    std::vector<int64_t> todo((size_t)n_big);
+    std::vector<char> row_seen((size_t)n_small), col_seen((size_t)n_big);
+
+    for (int64_t start = 0; start < n_small; ++start) {
+        // ---- grow a shortest-path tree from `start` until it reaches an unassigned column
+        int64_t n_todo = n_big;
+        for (int64_t k = 0; k < n_big; ++k) todo[(size_t)k] = n_big - 1 - k;
+        std::fill(row_seen.begin(), row_seen.end(), 0);
+        std::fill(col_seen.begin(), col_seen.end(), 0);
+        std::fill(dist.begin(), dist.end(), INFINITY);
+        double reach = 0.0;
+        int64_t row = start, sink = -1;
+        while (sink < 0) {
+            row_seen[(size_t)row] = 1;
+            int64_t best_at = -1;
+            double best = INFINITY;
+            for (int64_t k = 0; k < n_todo; ++k) {
+                const int64_t col = todo[(size_t)k];
+                const double through = reach + c[row * n_big + col] - dual_row[(size_t)row] - dual_col[(size_t)col];
+                if (through < dist[(size_t)col]) {
+                    dist[(size_t)col] = through;
+                    pred[(size_t)col] = row;
+                }
+                if (dist[(size_t)col] < best || (dist[(size_t)col] == best && row_of_col[(size_t)col] < 0)) {
+                    best = dist[(size_t)col];
+                    best_at = k;
+                }
+            }
+            reach = best;
+            if (reach == INFINITY) return MMX_ERR_ARG;       // no finite assignment
+            const int64_t col = todo[(size_t)best_at];
+            if (row_of_col[(size_t)col] < 0) sink = col;
+            else row = row_of_col[(size_t)col];
+            col_seen[(size_t)col] = 1;
+            todo[(size_t)best_at] = todo[(size_t)--n_todo];
+        }
+        // ---- dual update
+        dual_row[(size_t)start] += reach;
+        for (int64_t i = 0; i < n_small; ++i)
+            if (row_seen[(size_t)i] && i != start) dual_row[(size_t)i] += reach - dist[(size_t)col_of_row[(size_t)i]];
+        for (int64_t j = 0; j < n_big; ++j)
+            if (col_seen[(size_t)j]) dual_col[(size_t)j] -= reach - dist[(size_t)j];
+        // ---- flip the path from the sink back to `start`
+        for (int64_t col = sink;;) {
+            const int64_t i = pred[(size_t)col];
+            row_of_col[(size_t)col] = i;
+            std::swap(col_of_row[(size_t)i], col);
+            if (i == start) break;
+        }
+    }
+    if (!transposed) {
+        for (int64_t i = 0; i < n_small; ++i) { out_rows[i] = i; out_cols[i] = col_of_row[(size_t)i]; }
+    } else {
+        // solved on the transpose: col_of_row[j] is the ORIGINAL row assigned to original column j; pairs in
+        // ascending original-row order
+        std::vector<int64_t> order((size_t)n_small);
+        for (int64_t j = 0; j < n_small; ++j) order[(size_t)j] = j;
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return col_of_row[(size_t)a] < col_of_row[(size_t)b]; });
+        for (int64_t k = 0; k < n_small; ++k) { out_rows[k] = col_of_row[(size_t)order[(size_t)k]]; out_cols[k] = order[(size_t)k]; }
+    }
     return MMX_OK;
 }

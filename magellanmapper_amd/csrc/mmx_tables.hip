@@ -695,3 +695,36 @@ extern "C" int mmx_calib_stream(int kind, const void* d_in, void* d_out, int64_t
     else return MMX_ERR_ARG;
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
+
+
+// ------------------------------------------------------------------------------------------------ cdist
+// Euclidean distance matrix of two small point sets (blobs of two channels in one ROI), float64, as
+// scipy.spatial.distance.cdist computes it: s = 0; for k: d = a[k] - b[k]; s += d * d; sqrt(s) -- this file is
+// compiled with -ffp-contract=off, so no FMA changes a bit.  One lane per (row, column) pair; rows of `b` go
+// through LDS (every lane of a row block reads all of them).
+__global__ void __launch_bounds__(MMX_WG)
+cdist_kernel(const double* __restrict__ a, int64_t n, const double* __restrict__ b, int64_t m, int dim,
+             double* __restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * MMX_WG + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= m || i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < dim; ++k) {
+        const double d = a[i * dim + k] - b[j * dim + k];
+        s += d * d;
+    }
+    out[i * m + j] = sqrt(s);
+}
+
+extern "C" int mmx_cdist_f64(const double* d_a, int64_t n, const double* d_b, int64_t m, int dim, double* d_out,
+                             void* stream)
+{
+    if (n < 0 || m < 0 || dim < 1 || dim > 8) return MMX_ERR_ARG;
+    if (n == 0 || m == 0) return MMX_OK;
+    if (!d_a || !d_b || !d_out || n > 65535) return n > 65535 ? MMX_ERR_UNSUPPORTED : MMX_ERR_ARG;
+    mmx_timed_scope ts(MMX_K_COLOC, (hipStream_t)stream);
+    dim3 grid((unsigned)((m + MMX_WG - 1) / MMX_WG), (unsigned)n);
+    hipLaunchKernelGGL(cdist_kernel, grid, dim3(MMX_WG), 0, (hipStream_t)stream, d_a, n, d_b, m, dim, d_out);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}

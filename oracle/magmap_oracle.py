@@ -436,3 +436,30 @@ def detect_blobs_blocks(roi: np.ndarray, channels: Optional[Sequence[int]],
         final = segments_all[:, [0, 1, 2, 3, 4, 5, 6, 10]]
     return final, dict(blocks=blocks, seg_rois=seg_rois, merged=merged_before,
                        pruned11=segments_all, ratios=ratios, colocs=colocs)
+
+
+# ----------------------------------------------------------------------- A15
+#: keys that must agree for channels to share one set of blocks (magmap/settings/roi_prof.py:35-41)
+BLOCK_SIZES = ("segment_size", "denoise_size", "prune_tol_factor", "sub_stack_max_pixels", "isotropic")
+
+
+def detect_blobs_stack(roi: np.ndarray, profiles: Sequence[dict], resolutions, near_max=(-1.0,), coloc=False):
+    """Whole-image detection over all channels -> ``(final table | None, grouped)``.
+
+    magmap/cv/stack_detect.py:520-615: the channels share one set of blocks when their profiles agree on
+    every ``BLOCK_SIZES`` key (:554-561, ``ROIProfile.is_identical_settings``, roi_prof.py:272-297: ``==`` on
+    the values of the first profile against each other one); otherwise every channel is detected and pruned
+    on its own block grid (``detect_blobs_blocks`` with ``channels=[c]``) and the final tables are concatenated
+    in channel order (``libmag.combine_arrs``)."""
+    channels = list(range(roi.shape[3])) if roi.ndim > 3 else [0]
+    profs = [profiles[c] if len(profiles) > c else profiles[0] for c in channels]
+    grouped = all(profs[0].get(k) == p.get(k) for p in profs[1:] for k in BLOCK_SIZES)
+    groups = [channels] if grouped else [[c] for c in channels]
+    finals = []
+    for chl in groups:
+        final, _ = detect_blobs_blocks(roi, chl, profiles, resolutions, near_max=near_max, coloc=coloc)
+        if final is not None:
+            finals.append(final)
+    if not finals:
+        return None, grouped
+    return (finals[0] if len(finals) == 1 else np.concatenate(finals)), grouped

@@ -515,6 +515,10 @@ def main():
         return main_unmix()
     if sys.argv[1:] == ["isotropic"]:     # only the isotropic-rescale fixtures (added later)
         return main_isotropic()
+    if sys.argv[1:] == ["match"]:         # only the match-based co-localisation fixtures (added later)
+        return main_match()
+    if sys.argv[1:] == ["grouping"]:      # only the channel-grouping fixtures of detect_blobs_stack (added later)
+        return main_grouping()
     # ---- blob_log arithmetic
     bloblog_case("u16_1sigma", make_volume(11, (40, 56, 60), 22), 3, 3, 1)
     bloblog_case("u16_5sigma", make_volume(12, (48, 64, 72), 30), 3, 5, 5)
@@ -570,6 +574,8 @@ def main():
     main_image5d()
     main_unmix()
     main_isotropic()
+    main_grouping()
+    main_match()
 
 
 def main_isotropic():
@@ -649,6 +655,141 @@ def main_image5d():
     config.near_max = [-1.0]
     print("image5d: %s %s, resolutions %s, near_max %s" % (img5d.img.shape, img5d.img.dtype,
                                                           config.resolutions, highs))
+
+
+def grouping_case(name, roi, **over):
+    """``stack_detect.detect_blobs_stack`` end to end (channel grouping by ROIProfile.BLOCK_SIZES, :554-561, one
+    detect_blobs_blocks per group, combine_arrs): the final table, the archive it saved, the grouping decision."""
+    import tempfile
+    from magmap.settings import roi_prof
+    config.resolutions = np.array([[1., 1., 1.]])
+    config.near_max = [-1.0] * roi.shape[3]
+    config.cpus = 4
+    config.channel = None
+    yaml = "/root/reference/profiles/roi_blobs.yaml"
+    setup_profile(names=[yaml, yaml], **over)          # one profile per channel
+    quiet(chunking.set_mp_start_method)
+    img5d = np_io.Image5d(roi[None])
+    img5d.is_roi = True
+    chls = list(range(roi.shape[3]))
+    identical = roi_prof.ROIProfile.is_identical_settings(
+        [config.get_roi_profile(c) for c in chls], roi_prof.ROIProfile.BLOCK_SIZES)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        config.filename = os.path.join(tmp, "grp")
+        try:
+            _, _, blobs = quiet(stack_detect.detect_blobs_stack, os.path.join(tmp, "grp"), img5d)
+            arch = np.load(os.path.join(tmp, "grp_blobs.npz"))
+            arch_segments = arch["segments"]
+        finally:
+            os.chdir(cwd)
+    grids = np.array([quiet(stack_detect.setup_blocks, config.get_roi_profile(c), roi.shape[:3]).sub_roi_slices.shape
+                      for c in chls])
+    np.savez_compressed(os.path.join(HERE, "grouping_%s.npz" % name), roi=roi, identical=np.array(bool(identical)),
+                        final=blobs.blobs, archive_segments=arch_segments, grids=grids,
+                        overrides=repr(over), versions=repr(VERSIONS))
+    print("grouping_%s: identical block sizes %s, grids %s, %d blobs" % (name, identical, grids.tolist(), len(blobs.blobs)))
+
+
+def main_grouping():
+    vol = np.stack((make_volume(61, (48, 72, 76), 30), make_volume(62, (48, 72, 76), 26)), axis=-1)
+    grouping_case("equal", vol, segment_size=40, num_sigma=3)
+    grouping_case("unequal", vol, segment_size={"per_channel": [40, 30]}, num_sigma=3)
+    grouping_case("unequal_tol", vol, segment_size=36, prune_tol_factor={"per_channel": [(1, 1, 1), (1, 0.9, 0.9)]},
+                  num_sigma=3)
+
+
+def make_blob_table(seed, shape, n, n_chl=2, shared=0.6, jitter=2):
+    """An 8-column final blob table (z, y, x, radius, confirmed, truth, channel, region) as detection leaves it:
+    ``n`` integer centres per channel, a ``shared`` fraction of every later channel's blobs sitting within
+    ``jitter`` voxels of a channel-0 blob (so that distances repeat: sqrt of small integers -- ties for the
+    assignment solver), the rest on their own."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, shape, (n, 3))
+    rows = []
+    for c in range(n_chl):
+        if c == 0:
+            pts = base
+        else:
+            k = int(shared * n)
+            near = base[rng.permutation(n)[:k]] + rng.integers(-jitter, jitter + 1, (k, 3))
+            pts = np.concatenate((near, rng.integers(0, shape, (n - k, 3))))
+            pts = np.clip(pts, 0, np.subtract(shape, 1))
+        t = np.full((len(pts), 8), -1.0)
+        t[:, :3] = pts
+        t[:, 3] = 5.196152422706632
+        t[:, 6] = c
+        rows.append(t)
+    return np.concatenate(rows)
+
+
+def match_cases():
+    """verifier.find_closest_blobs_cdist (cdist + scipy.optimize.linear_sum_assignment + threshold),
+    verifier.match_blobs_roi, colocalizer.colocalize_blobs_match and StackColocalizer.colocalize_stack."""
+    from magmap.cv import colocalizer, verifier
+    out = {}
+    rng = np.random.default_rng(71)
+    # ---- the assignment itself: rectangular both ways, integer coordinates (tied distances), scaling, threshold
+    specs = [(5, 5, 6), (12, 7, 8), (7, 12, 8), (40, 40, 12), (60, 35, 10), (1, 9, 5), (9, 1, 5), (30, 30, 3),
+             (80, 100, 20)]
+    for k, (n, m, span) in enumerate(specs):
+        a = rng.integers(0, span, (n, 4)).astype(float)
+        b = rng.integers(0, span, (m, 4)).astype(float)
+        scaling = np.array([1.0, 1.0, 1.0]) if k % 2 == 0 else np.array([5.0 / 3.0, 1.0, 1.0])
+        thresh = None if k == 3 else 3.0 + (k % 3)
+        rowis, colis, dists = verifier.find_closest_blobs_cdist(a, b, thresh, scaling)
+        out.update({"lsap%d_a" % k: a, "lsap%d_b" % k: b, "lsap%d_scaling" % k: scaling,
+                    "lsap%d_thresh" % k: np.array(np.nan if thresh is None else thresh),
+                    "lsap%d_rows" % k: rowis, "lsap%d_cols" % k: colis, "lsap%d_dists" % k: dists})
+    out["n_lsap"] = np.array(len(specs))
+    # ---- one ROI: inner / outer matching of two channels' blobs
+    config.resolutions = np.array([[1., 1., 1.]])
+    setup_profile(segment_size=40, num_sigma=3)
+    table = make_blob_table(72, (40, 60, 64), 90, n_chl=3)
+    blobs = detector.Blobs(table.copy())
+    tol = np.array([5.0, 5.0, 5.0])
+    for k, (offset, size) in enumerate((((0, 0, 0), (64, 60, 40)), ((10, 8, 4), (40, 44, 30)), ((60, 50, 30), (4, 10, 10)))):
+        matches = quiet(colocalizer.colocalize_blobs_match, blobs, offset, size, tol)
+        out["roi%d_offset" % k] = np.array(offset)
+        out["roi%d_size" % k] = np.array(size)
+        out["roi%d_keys" % k] = np.array(sorted(matches.keys())).reshape(-1, 2)
+        for key, bm in matches.items():
+            df = bm.df
+            nrow = 0 if df is None else len(df)
+            out["roi%d_%d_%d_blob1" % (k, *key)] = np.vstack(df["Blob1"]) if nrow else np.empty((0, 8))
+            out["roi%d_%d_%d_blob2" % (k, *key)] = np.vstack(df["Blob2"]) if nrow else np.empty((0, 8))
+            out["roi%d_%d_%d_dist" % (k, *key)] = np.array(df["Distance"], dtype=float) if nrow else np.empty(0)
+    out["roi_table"] = table
+    out["roi_tol"] = tol
+    # ---- whole stack: larger-overlap block split, per-block matching, shortest-distance de-duplication
+    for name, shape, n, n_chl, seg, res in (("stackA", (48, 120, 128), 700, 2, 40, (1., 1., 1.)),
+                                            ("stackB", (40, 100, 96), 400, 3, 36, (2.0, 0.8, 0.8))):
+        config.resolutions = np.array([res])
+        config.cpus = 4
+        setup_profile(segment_size=seg, num_sigma=3)
+        quiet(chunking.set_mp_start_method)
+        tbl = make_blob_table(73 + n_chl, shape, n, n_chl=n_chl, jitter=3)
+        blobs = detector.Blobs(tbl.copy())
+        matches = quiet(colocalizer.StackColocalizer.colocalize_stack, shape, blobs)
+        out[name + "_table"] = tbl
+        out[name + "_shape"] = np.array(shape)
+        out[name + "_res"] = np.array(res)
+        out[name + "_segment_size"] = np.array(seg)
+        out[name + "_keys"] = np.array(sorted(matches.keys())).reshape(-1, 2)
+        for key, bm in matches.items():
+            df = bm.df
+            out["%s_%d_%d_blob1" % (name, *key)] = np.vstack(df["Blob1"]) if len(df) else np.empty((0, 8))
+            out["%s_%d_%d_blob2" % (name, *key)] = np.vstack(df["Blob2"]) if len(df) else np.empty((0, 8))
+            out["%s_%d_%d_dist" % (name, *key)] = np.array(df["Distance"], dtype=float)
+            print("match %s %s: %d matches" % (name, key, len(df)))
+    out["versions"] = np.array(repr(VERSIONS))
+    np.savez_compressed(os.path.join(HERE, "match.npz"), **out)
+    print("match.npz: %d arrays" % len(out))
+
+
+def main_match():
+    match_cases()
 
 
 def main_coloc():

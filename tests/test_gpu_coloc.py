@@ -112,3 +112,73 @@ def test_single_channel_coloc_is_switched_off_like_the_reference(gpu, monkeypatc
     with pytest.raises(ValueError):        # np.hstack((segments, None)) in the reference's detect_sub_roi
         stack_detect.StackDetector.detect_sub_roi((0, 0, 0), (0, 0, 0), (0, 0, 0), None, None, None,
                                                   roi, None, coloc=True)
+
+
+# ------------------------------------------------------------------------- match-based co-localisation
+def _match_config(seg, res=(1.0, 1.0, 1.0)):
+    from magellanmapper_amd import config
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(segment_size=int(seg), num_sigma=3, denoise_size=None)
+    config.resolutions = np.array([res])
+    config.cpus = 4
+
+
+def _frame_arrays(bm):
+    df = bm.df
+    if df is None or not len(df):
+        return np.empty((0, 8)), np.empty((0, 8)), np.empty(0)
+    return np.vstack(df["Blob1"]), np.vstack(df["Blob2"]), np.asarray(df["Distance"], dtype=float)
+
+
+def test_find_closest_blobs_cdist_matches_reference(gpu):
+    """Device distance matrix + native assignment against the real ``verifier.find_closest_blobs_cdist``
+    (``scipy`` cdist + linear_sum_assignment): pairs and float64 distances identical."""
+    from magellanmapper_amd import verifier
+    g = load_golden("match.npz")
+    for k in range(int(g["n_lsap"])):
+        thresh = None if np.isnan(g["lsap%d_thresh" % k]) else float(g["lsap%d_thresh" % k])
+        rows, cols, dists = verifier.find_closest_blobs_cdist(g["lsap%d_a" % k], g["lsap%d_b" % k], thresh,
+                                                              g["lsap%d_scaling" % k])
+        np.testing.assert_array_equal(rows, g["lsap%d_rows" % k])
+        np.testing.assert_array_equal(cols, g["lsap%d_cols" % k])
+        np.testing.assert_array_equal(dists, g["lsap%d_dists" % k])
+
+
+def test_colocalize_blobs_match_matches_reference(gpu):
+    from magellanmapper_amd import colocalizer, detector
+    g = load_golden("match.npz")
+    _match_config(40)
+    try:
+        for k in range(3):
+            blobs = detector.Blobs(g["roi_table"].copy())
+            got = colocalizer.colocalize_blobs_match(blobs, tuple(g["roi%d_offset" % k]), tuple(g["roi%d_size" % k]),
+                                                     g["roi_tol"])
+            keys = [tuple(int(v) for v in key) for key in g["roi%d_keys" % k]]
+            assert sorted(got) == keys
+            for key in keys:
+                for name, arr in zip(("blob1", "blob2", "dist"), _frame_arrays(got[key])):
+                    np.testing.assert_array_equal(arr, g["roi%d_%d_%d_%s" % (k, *key, name)])
+        assert colocalizer.colocalize_blobs_match(None, (0, 0, 0), (1, 1, 1), g["roi_tol"]) is None
+    finally:
+        detector.Blobs(np.ones((1, 4))).format_blobs()
+
+
+@pytest.mark.parametrize("name", ["stackA", "stackB"])
+def test_stack_colocalizer_matches_reference(gpu, name):
+    """``StackColocalizer.colocalize_stack`` (2 and 3 channels, isotropic and anisotropic voxels): every match of
+    the real reference, in its order, with its float64 distance."""
+    from magellanmapper_amd import colocalizer, detector
+    g = load_golden("match.npz")
+    _match_config(g[name + "_segment_size"], tuple(g[name + "_res"]))
+    try:
+        blobs = detector.Blobs(g[name + "_table"].copy())
+        got = colocalizer.StackColocalizer.colocalize_stack(tuple(int(v) for v in g[name + "_shape"]), blobs)
+        keys = [tuple(int(v) for v in key) for key in g[name + "_keys"]]
+        assert sorted(got) == keys
+        for key in keys:
+            assert isinstance(got[key], colocalizer.BlobMatch)
+            for col, arr in zip(("blob1", "blob2", "dist"), _frame_arrays(got[key])):
+                np.testing.assert_array_equal(arr, g["%s_%d_%d_%s" % (name, *key, col)])
+            assert got[key].get_mean_coords().shape == (len(got[key].df), 3)
+    finally:
+        detector.Blobs(np.ones((1, 4))).format_blobs()

@@ -672,3 +672,57 @@ def test_irregular_block_geometry_matches_oracle(gpu, tmp_path, monkeypatch, geo
     else:
         assert blobs.blobs is not None and blobs.blobs.shape == want.shape
         np.testing.assert_array_equal(lexsorted(blobs.blobs), lexsorted(want))
+
+
+GROUPING_CASES = sorted(os.path.basename(p)[len("grouping_"):-4]
+                        for p in glob.glob(os.path.join(GOLDEN, "grouping_*.npz")))
+
+
+@pytest.mark.parametrize("case", GROUPING_CASES)
+def test_detect_blobs_stack_channel_grouping_matches_reference(gpu, case, tmp_path, monkeypatch):
+    """A15 end to end on the device path: ``detect_blobs_stack`` groups the channels by ``ROIProfile.BLOCK_SIZES``
+    (equal ``segment_size``: one grid; unequal ``segment_size`` or ``prune_tol_factor``: one grid per channel),
+    final table and saved archive identical to the real reference's."""
+    from magellanmapper_amd import config, detector, stack_detect
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("grouping_%s.npz" % case)
+    over = ast.literal_eval(str(g["overrides"]))
+    roi = g["roi"]
+    config.setup_roi_profiles(None)
+    config.roi_profiles = [type(config.roi_profile)(config.roi_profile) for _ in range(roi.shape[3])]
+    for i, prof in enumerate(config.roi_profiles):
+        prof["denoise_size"] = None
+        for k, v in over.items():
+            prof[k] = v["per_channel"][i] if isinstance(v, dict) and "per_channel" in v else v
+    config.roi_profile = config.roi_profiles[0]
+    config.resolutions, config.near_max, config.channel = np.array([[1.0, 1.0, 1.0]]), [-1.0] * roi.shape[3], None
+    config.filename = str(tmp_path / "grp")
+    try:
+        grids = [stack_detect.setup_blocks(config.get_roi_profile(c), roi.shape[:3]).sub_roi_slices.shape
+                 for c in range(roi.shape[3])]
+        np.testing.assert_array_equal(np.array(grids), g["grids"])
+        img5d = stack_detect.Image5d(roi[None])
+        img5d.is_roi = True
+        _, _, blobs = stack_detect.detect_blobs_stack(str(tmp_path / "grp"), img5d)
+        np.testing.assert_array_equal(blobs.blobs, g["final"])
+        back = detector.Blobs().load_blobs(str(tmp_path / "grp_blobs.npz"))
+        np.testing.assert_array_equal(back.blobs, g["archive_segments"])
+    finally:
+        config.setup_roi_profiles(None)
+        config.resolutions, config.near_max = None, [-1.0]
+        detector.Blobs(np.ones((1, 4))).format_blobs()
+
+
+def test_a_band_narrower_than_the_float32_error_widens_itself(gpu, monkeypatch):
+    """The float32 passes only nominate; when their values stray from the exact ones by more than a quarter of the
+    nomination band (forced here with an absurdly narrow band) the batch is nominated again with a wider one
+    instead of failing -- and the blobs are still the reference's."""
+    from magellanmapper_amd import blob_log as bl
+    g = load_golden("bloblog_u16_5sigma.npz")
+    monkeypatch.setattr(bl, "EPS_REL", 1e-9)
+    stats = bl.BatchStats()
+    dvol = bl.DeviceVolume(g["volume"])
+    got = bl.blob_log_blocks(dvol, 0, [(0, 0, 0)], [g["volume"].shape], float(g["min_sigma"]), float(g["max_sigma"]),
+                             int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]), stats=stats)[0]
+    assert stats.n_band_retries >= 1 and stats.n_blocks == 1
+    np.testing.assert_array_equal(got, g["pruned"])

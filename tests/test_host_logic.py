@@ -509,3 +509,77 @@ def test_map_columns_native_matches_numpy():
     cols = (ctypes.c_int32 * 2)(0, 99)
     t = np.zeros((4, 4))
     assert lib.mmx_host_map_columns(t.ctypes.data, 4, 4, cols, 2, t.ctypes.data, 4, 0) == 1     # bad column
+
+
+def test_native_prune_works_in_a_forked_child():
+    """The host thread pool lives in the dlopen'd library; after fork() its threads are gone (the reference's
+    default start method is 'fork').  A table large enough for the threaded path must still prune in the child."""
+    import multiprocessing as mp
+    from magellanmapper_amd import _native as nat
+    rng = np.random.default_rng(0)
+    n = 60000
+    table = rng.random((n, 6))
+    rows = np.arange(n, dtype=np.int64)[::-1].copy()
+    absz = rng.random((n, 3))
+    cols = (ctypes.c_int32 * 3)(0, 1, 2)
+
+    def take():
+        out = np.empty((n, 5))
+        nat.check(nat.lib().mmx_host_take_rows(table.ctypes.data, 6, rows.ctypes.data, n, 5, absz.ctypes.data, cols,
+                                               out.ctypes.data), "take")
+        return out
+
+    want = take()                      # builds the pool (threads) in this process
+
+    def child(q):
+        q.put(bool(np.array_equal(take(), want)))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    p.join(60)
+    assert p.exitcode == 0, "the forked child hung or died in the native table code"
+    assert q.get(timeout=5) is True
+
+
+def test_get_mp_pool_follows_config():
+    from magellanmapper_amd import chunking, config
+    config.setup_roi_profiles(None)
+    old = config.cpus
+    config.cpus = 2
+    try:
+        with chunking.get_mp_pool() as pool:
+            assert pool._processes == 2
+            assert pool.map(abs, [-1, 2, -3]) == [1, 2, 3]
+    finally:
+        config.cpus = old
+
+
+def test_native_assignment_solver_returns_scipys_optimum():
+    """mmx_host_lsap (host code of the C ABI) on the reference's own cases (tests/golden/match.npz: integer
+    coordinates, so tied distances; rectangular both ways) and on random tie-heavy matrices: the same pairs as
+    scipy.optimize.linear_sum_assignment, not merely the same cost."""
+    from scipy import optimize
+    from scipy.spatial import distance
+    from conftest import load_golden
+    from magellanmapper_amd import verifier
+    g = load_golden("match.npz")
+    for k in range(int(g["n_lsap"])):
+        sc = g["lsap%d_scaling" % k]
+        cost = distance.cdist(g["lsap%d_a" % k][:, :3] * sc, g["lsap%d_b" % k][:, :3] * sc)
+        rows, cols = verifier.linear_sum_assignment(cost)
+        thresh = g["lsap%d_thresh" % k]
+        keep = np.ones(len(rows), bool) if np.isnan(thresh) else cost[rows, cols] < thresh
+        np.testing.assert_array_equal(rows[keep], g["lsap%d_rows" % k])
+        np.testing.assert_array_equal(cols[keep], g["lsap%d_cols" % k])
+    rng = np.random.default_rng(5)
+    for trial in range(400):
+        n, m = rng.integers(1, 30, 2)
+        cost = rng.integers(0, 4, (n, m)).astype(float) if trial % 2 else distance.cdist(
+            rng.integers(0, 6, (n, 3)).astype(float), rng.integers(0, 6, (m, 3)).astype(float))
+        rows, cols = verifier.linear_sum_assignment(cost)
+        want = optimize.linear_sum_assignment(cost)
+        np.testing.assert_array_equal(rows, want[0])
+        np.testing.assert_array_equal(cols, want[1])
+    assert _native.lib().mmx_host_lsap(np.array([[np.nan]]).ctypes.data, 1, 1, None, None) == 1

@@ -293,3 +293,84 @@ def test_prune_blobs_mp_matches_reference():
     np.testing.assert_array_equal(pruned, g["sp_pruned"])
     got = np.array([ratios[str(k)] for k in g["sp_ratio_cols"]]).T
     np.testing.assert_allclose(got, g["sp_ratios"])
+
+
+GROUPING_CASES = sorted(os.path.basename(p)[len("grouping_"):-4]
+                        for p in glob.glob(os.path.join(GOLDEN, "grouping_*.npz")))
+
+
+def _grouping_profiles(g):
+    import ast
+    from magellanmapper_amd import config
+    over = ast.literal_eval(str(g["overrides"]))
+    profs = []
+    for i in range(g["roi"].shape[3]):
+        config.setup_roi_profiles(None)
+        prof = dict(config.roi_profile)
+        prof["denoise_size"] = None
+        for k, v in over.items():
+            prof[k] = v["per_channel"][i] if isinstance(v, dict) and "per_channel" in v else v
+        profs.append(prof)
+    return profs
+
+
+@pytest.mark.parametrize("case", GROUPING_CASES)
+def test_detect_blobs_stack_channel_grouping_matches_reference(case):
+    """A15: channels whose profiles differ in a BLOCK_SIZES key get their own block grids (real reference
+    ``detect_blobs_stack`` with equal / unequal ``segment_size`` and unequal ``prune_tol_factor``)."""
+    assert len(GROUPING_CASES) >= 3
+    g = load_golden("grouping_%s.npz" % case)
+    final, grouped = mmo.detect_blobs_stack(g["roi"], _grouping_profiles(g), np.array([[1.0, 1.0, 1.0]]),
+                                            near_max=[-1.0] * g["roi"].shape[3])
+    assert grouped == bool(g["identical"])
+    np.testing.assert_array_equal(final, g["final"])
+    np.testing.assert_array_equal(g["archive_segments"], g["final"])
+
+
+# ----------------------------------------------------------------------------- match-based co-localisation
+def _match_profile(seg):
+    from magellanmapper_amd import config
+    config.setup_roi_profiles(None)
+    prof = dict(config.roi_profile)
+    prof.update(segment_size=int(seg), num_sigma=3, denoise_size=None)
+    return prof
+
+
+def test_assignment_with_threshold_matches_reference():
+    """verifier.find_closest_blobs_cdist: integer coordinates (tied distances), rectangular both ways, scaling."""
+    from oracle import match_oracle as mo
+    g = load_golden("match.npz")
+    for k in range(int(g["n_lsap"])):
+        thresh = None if np.isnan(g["lsap%d_thresh" % k]) else float(g["lsap%d_thresh" % k])
+        rows, cols, dists = mo.find_closest_blobs_cdist(g["lsap%d_a" % k], g["lsap%d_b" % k], thresh,
+                                                        g["lsap%d_scaling" % k])
+        np.testing.assert_array_equal(rows, g["lsap%d_rows" % k])
+        np.testing.assert_array_equal(cols, g["lsap%d_cols" % k])
+        np.testing.assert_array_equal(dists, g["lsap%d_dists" % k])
+
+
+def test_colocalize_blobs_match_one_roi_matches_reference():
+    from oracle import match_oracle as mo
+    g = load_golden("match.npz")
+    for k in range(3):
+        got = mo.colocalize_blobs_match(g["roi_table"].copy(), g["roi%d_offset" % k], g["roi%d_size" % k], g["roi_tol"])
+        keys = [tuple(int(v) for v in key) for key in g["roi%d_keys" % k]]
+        assert sorted(got) == keys
+        for key in keys:
+            for name, arr in zip(("blob1", "blob2", "dist"), got[key]):
+                np.testing.assert_array_equal(arr, g["roi%d_%d_%d_%s" % (k, *key, name)])
+
+
+@pytest.mark.parametrize("name", ["stackA", "stackB"])
+def test_colocalize_stack_matches_reference(name):
+    """StackColocalizer.colocalize_stack: the larger-overlap block split, per-block matching, shortest-distance
+    de-duplication -- row for row as the real reference."""
+    from oracle import match_oracle as mo
+    g = load_golden("match.npz")
+    got = mo.colocalize_stack(tuple(g[name + "_shape"]), g[name + "_table"].copy(),
+                              _match_profile(g[name + "_segment_size"]), np.array([g[name + "_res"]]))
+    keys = [tuple(int(v) for v in key) for key in g[name + "_keys"]]
+    assert sorted(got) == keys and len(keys) >= 1
+    for key in keys:
+        for col, arr in zip(("blob1", "blob2", "dist"), got[key]):
+            np.testing.assert_array_equal(arr, g["%s_%d_%d_%s" % (name, *key, col)])
