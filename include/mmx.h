@@ -231,7 +231,12 @@ typedef struct {
                                     in the reference (plot_3d.py:151)                               */
     int32_t rgb_guess;           /* 1 = scikit-image < 0.19: an array whose LAST axis has length 3 is
                                     taken for RGB and not blurred along it (filters/_gaussian.py)   */
-} mmx_preproc_params;     /* 48 bytes */
+    double tv_weight;            /* profile tot_var_denoise as a float (True = 1.0); 0 = off.  Total-variation
+                                    denoising of the clipped tile (plot_3d.py:147-149 ->
+                                    skimage.restoration.denoise_tv_chambolle): only through
+                                    mmx_preprocess_batch_generic, 7 doubles of scratch per voxel            */
+    double tv_factor;            /* (1 / 6) / weight, as the host's float division gives it               */
+} mmx_preproc_params;     /* 64 bytes */
 
 #define MMX_PP_IDENTITY 1    /* vmin == vmax: voxels pass through unstretched                        */
 #define MMX_PP_ERODED 2      /* mean > erosion_threshold                                             */
@@ -264,7 +269,7 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
                          mmx_subblock_info* d_info, void* stream);
 
 /* Same contract for any extent: data in d_scratch (each sub-block owns 2*nz*ny*nx doubles at its
- * scratch_off), one output per lane and pass. */
+ * scratch_off -- 7*nz*ny*nx with params->tv_weight set), one output per lane and pass. */
 int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_subs,
                                  const mmx_subblock* h_subs, int n_subs,
                                  const mmx_quantile_class* d_qclasses, int n_qclasses,

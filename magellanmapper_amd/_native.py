@@ -60,7 +60,7 @@ class PreprocParams(Structure):
     """``mmx_preproc_params``."""
     _fields_ = [("clip_min", c_double), ("clip_max", c_double), ("max_thresh", c_double),
                 ("unsharp_strength", c_double), ("erosion_threshold", c_double),
-                ("radius", c_int32), ("rgb_guess", c_int32)]
+                ("radius", c_int32), ("rgb_guess", c_int32), ("tv_weight", c_double), ("tv_factor", c_double)]
 
 
 class MmxError(RuntimeError):

@@ -301,7 +301,11 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     int zset = -1;
 
     // voxel rows: plane z0 + li, chunk of 8 x at xl[m] (clamped into the block; the fragments know)
+#ifdef ZX4_ROWS_Y      // access-pattern experiment (wrong results): tile rows = 16 rows of ONE plane, march along y
+    const InT* in = vol + bd.src_off + (int64_t)y * stride_z;
+#else
     const InT* in = vol + bd.src_off + (int64_t)y * stride_y;
+#endif
     unsigned xoff[NKX];
 #pragma unroll
     for (int m = 0; m < NKX; ++m) {
@@ -310,12 +314,20 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         xl = xl > W - 8 ? W - 8 : xl;
         xoff[m] = (unsigned)xl * (unsigned)sizeof(InT);
     }
+#ifdef ZX4_ROWS_Y
+    const unsigned zstride_b = (unsigned)(stride_y * (int64_t)sizeof(InT));
+#else
     const unsigned zstride_b = (unsigned)(stride_z * (int64_t)sizeof(InT));
+#endif
     auto load_tile = [&](int t, typename pc::raw_t (&raw)[NKX]) __attribute__((always_inline)) {
 #ifdef ZX5_LD_SMALL
         t = 0;
 #endif
+#ifdef ZX4_ROWS_Y
+        const rsrc4_t rs = make_rsrc4(in + (int64_t)(16 * t) * stride_y);
+#else
         const rsrc4_t rs = make_rsrc4(in + (int64_t)(16 * t) * stride_z);
+#endif
         int zr = nz - 1 - 16 * t;                                // last real plane relative to the tile
         zr = li < zr ? li : zr;
         const unsigned zo = (unsigned)zr * zstride_b;
@@ -334,7 +346,11 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
     const unsigned row_b = (unsigned)px * 4u;
     const unsigned plane_b = (unsigned)bd.ny * row_b;
+#ifdef ZX4_ROWS_Y
+    unsigned obase = (unsigned)li * row_b + (unsigned)y * plane_b + (unsigned)(16 * c + 4 * kq) * 4u;
+#else
     unsigned obase = (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
+#endif
 
     // voxels of the next ZX4_PF z tiles, in flight.  vmcnt counts loads and stores together and in issue order:
     // a tile loaded only one step ahead could not be used before the stores of the step in between have been
@@ -467,7 +483,11 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, Q), rq, obase, 0, ZX4_ST_AUX);
 #endif
             }
+#ifdef ZX4_ROWS_Y
+            obase += 16u * row_b;
+#else
             obase += 16u * plane_b;
+#endif
         }
 #ifdef ZX4_LOCKSTEP
         __syncthreads();

@@ -48,9 +48,12 @@
 
 struct pp_args {
     double clip_min, clip_max, max_thresh, strength, ero_thr;
+    double tv_weight, tv_factor;          // total-variation denoising: weight (0 = off), tau / weight
     int64_t dst_sy, dst_sz;
     int32_t do_unsharp, do_erosion, rgb_guess, _pad;
 };
+#define PP_TV_SCRATCH 7      // doubles of scratch per voxel with total-variation denoising on (2 without)
+#define PP_MAXLEAF 2048      // leaves of NumPy's pairwise summation tree kept in LDS (n <= ~130 000 voxels)
 
 namespace {
 
@@ -188,6 +191,49 @@ __device__ double pp_pairwise(F val, int n, pp_stack* S)
         } else { ret = S->acc[t] + ret; --sp; }
     }
     return 0. + ret;   // the reduction starts from the identity (add.reduce)
+}
+
+// NumPy's pairwise summation tree evaluated in parallel: the leaves (runs of <= 128 elements, fixed by n alone)
+// are enumerated once per tile, every lane sums whole leaves (pp_pairwise_leaf, NumPy's 8 accumulators), one
+// lane folds the leaf sums in the tree's order.  Bit-equal to ndarray.sum() of a contiguous float64 array.
+struct pp_leaves { int lo[PP_MAXLEAF]; int n[PP_MAXLEAF]; double sum[2][PP_MAXLEAF]; int count; };
+
+__device__ void pp_enum_leaves(int n, pp_stack* S, pp_leaves* Lv)       // one lane
+{
+    int sp = 0, cnt = 0;
+    S->lo[0] = 0; S->n[0] = n; sp = 1;
+    while (sp > 0) {
+        --sp;
+        const int lo = S->lo[sp], m = S->n[sp];
+        if (m <= 128) {
+            if (cnt < PP_MAXLEAF) { Lv->lo[cnt] = lo; Lv->n[cnt] = m; }
+            ++cnt;
+            continue;
+        }
+        int n2 = m / 2; n2 -= n2 % 8;
+        S->lo[sp] = lo + n2; S->n[sp] = m - n2; ++sp;       // right half: popped after the left one
+        S->lo[sp] = lo; S->n[sp] = n2; ++sp;
+    }
+    Lv->count = cnt;
+}
+
+__device__ double pp_fold_leaves(int n, pp_stack* S, const pp_leaves* Lv, int which)     // one lane
+{
+    int sp = 0, next = 0;
+    double ret = 0.;
+    S->lo[0] = 0; S->n[0] = n; S->st[0] = 0; sp = 1;
+    while (sp > 0) {
+        const int t = sp - 1;
+        const int lo = S->lo[t], m = S->n[t];
+        if (m <= 128) { ret = Lv->sum[which][next++]; --sp; continue; }
+        int n2 = m / 2; n2 -= n2 % 8;
+        if (S->st[t] == 0) { S->st[t] = 1; S->lo[sp] = lo; S->n[sp] = n2; S->st[sp] = 0; ++sp; }
+        else if (S->st[t] == 1) {
+            S->acc[t] = ret; S->st[t] = 2;
+            S->lo[sp] = lo + n2; S->n[sp] = m - n2; S->st[sp] = 0; ++sp;
+        } else { ret = S->acc[t] + ret; --sp; }
+    }
+    return 0. + ret;
 }
 
 // One in-place Gaussian pass over the lines of one axis, lines held in registers.
@@ -860,12 +906,102 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
         info[blockIdx.x] = o;
     }
 
-    double* cur = bufA;
-    double* oth = bufB;
+    // ---- total-variation denoising of the clipped tile (reference plot_3d.py:147-149 ->
+    // skimage.restoration.denoise_tv_chambolle, restoration/_denoise.py:315-393): Chambolle's projection
+    // iteration on the dual field p, every voxel operation and both energy sums (NumPy pairwise order) as
+    // NumPy does them, so that the iteration stops where the reference's stops and returns the same bits.
+    const bool tv = A.tv_weight != 0.0;
+    double* p0 = bufB + n;
+    if (tv) {
+        __shared__ pp_leaves s_leaves;
+        __shared__ int s_done;
+        __shared__ double s_e[2];                         // E_init, E_previous
+        double* img = bufA;
+        double* outb = bufB;
+        double* p1 = p0 + n;
+        double* p2 = p1 + n;
+        double* sq = p2 + n;                              // d^2, then the gradient norms
+        double* nm = sq + n;
+        const int64_t pl = ny * nx;
+        const double tau = 1.0 / 6.0;                     // 1 / (2 * ndim)
+        for (int64_t i = tid; i < n; i += PP_WG_GENERIC) { p0[i] = 0.0; p1[i] = 0.0; p2[i] = 0.0; }
+        if (tid == 0) { pp_enum_leaves((int)n, &s_stack, &s_leaves); s_done = 0; }
+        __syncthreads();
+        const bool par = s_leaves.count <= PP_MAXLEAF;
+#pragma unroll 1
+        for (int it = 0; it < 200; ++it) {
+            for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+                const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
+                double d = 0.0;
+                if (it > 0) {
+                    d = -((p0[i] + p1[i]) + p2[i]);               // -p.sum(0)
+                    if (z > 0) d += p0[i - pl];
+                    if (y > 0) d += p1[i - nx];
+                    if (x > 0) d += p2[i - 1];
+                }
+                outb[i] = it > 0 ? img[i] + d : img[i];
+                sq[i] = d * d;
+            }
+            __syncthreads();
+            for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+                const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
+                const double o = outb[i];
+                const double g0 = z < nz - 1 ? outb[i + pl] - o : 0.0;
+                const double g1 = y < ny - 1 ? outb[i + nx] - o : 0.0;
+                const double g2 = x < nx - 1 ? outb[i + 1] - o : 0.0;
+                double nrm = sqrt((g0 * g0 + g1 * g1) + g2 * g2);
+                nm[i] = nrm;
+                nrm = nrm * A.tv_factor;
+                nrm = nrm + 1.0;
+                p0[i] = (p0[i] - tau * g0) / nrm;
+                p1[i] = (p1[i] - tau * g1) / nrm;
+                p2[i] = (p2[i] - tau * g2) / nrm;
+            }
+            __syncthreads();
+            if (par) {
+                const int nl = s_leaves.count;
+                for (int k = tid; k < 2 * nl; k += PP_WG_GENERIC) {
+                    const int w = k >= nl, l = w ? k - nl : k;
+                    const double* a = w ? nm : sq;
+                    auto val = [&](int i) { return a[i]; };
+                    s_leaves.sum[w][l] = pp_pairwise_leaf(val, s_leaves.lo[l], s_leaves.n[l]);
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                double e1, e2;
+                if (par) { e1 = pp_fold_leaves((int)n, &s_stack, &s_leaves, 0); e2 = pp_fold_leaves((int)n, &s_stack, &s_leaves, 1); }
+                else {
+                    auto v1 = [&](int i) { return sq[i]; };
+                    auto v2 = [&](int i) { return nm[i]; };
+                    e1 = pp_pairwise(v1, (int)n, &s_stack);
+                    e2 = pp_pairwise(v2, (int)n, &s_stack);
+                }
+                double E = e1;
+                E = E + A.tv_weight * e2;
+                E = E / (double)n;
+                if (it == 0) { s_e[0] = E; s_e[1] = E; }
+                else if (fabs(s_e[1] - E) < 2.e-4 * s_e[0]) s_done = 1;
+                else s_e[1] = E;
+            }
+            __syncthreads();
+            if (s_done) break;
+        }
+    }
+
+    // buffers from here on: `cur` = blur input / result, t1 / t2 = the blur's ping-pong pair, `den_buf` = the
+    // denoised tile the unsharp mask adds to (recomputed from the voxels without total-variation denoising)
+    const double* den_buf = tv ? bufB : nullptr;
+    double* cur = tv ? bufB : bufA;
+    double* const t1 = tv ? p0 : bufB;
+    double* const t2 = tv ? p0 + n : bufA;
+    double* oth = tv ? p0 + 2 * n : bufB;
     if (A.do_unsharp) {
+        int pass = 0;
 #pragma unroll 1
         for (int axis = 0; axis < 3; ++axis) {
             if (axis == 2 && A.rgb_guess && nx == 3) break;
+            double* const dstb = (pass & 1) ? t2 : t1;
             const int64_t L = axis == 0 ? nz : axis == 1 ? ny : nx;
             const int64_t stride = axis == 0 ? ny * nx : axis == 1 ? nx : 1;
             for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
@@ -877,11 +1013,13 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
                     const int64_t b = c + k > L - 1 ? L - 1 : c + k;
                     acc += (line[a * stride] + line[b * stride]) * wts[k];
                 }
-                oth[i] = acc;
+                dstb[i] = acc;
             }
             __syncthreads();
-            double* t = cur; cur = oth; oth = t;
+            cur = dstb;
+            ++pass;
         }
+        if (!tv) oth = cur == bufA ? bufB : bufA;
     }
 
     const bool erode = flags & MMX_PP_ERODED;
@@ -889,7 +1027,8 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
         const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
         double o;
         if (A.do_unsharp) {
-            const double den = pp_clip(S.plain((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
+            const double den = tv ? den_buf[i]
+                                  : pp_clip(S.plain((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
             const double m = A.strength * cur[i];
             const double hp = den - m;
             o = den + hp;
@@ -925,6 +1064,7 @@ pp_args pp_make_args(const mmx_preproc_params* p, int64_t dst_sy, int64_t dst_sz
     pp_args A;
     A.clip_min = p->clip_min; A.clip_max = p->clip_max; A.max_thresh = p->max_thresh;
     A.strength = p->unsharp_strength; A.ero_thr = p->erosion_threshold;
+    A.tv_weight = p->tv_weight; A.tv_factor = p->tv_factor;
     A.dst_sy = dst_sy; A.dst_sz = dst_sz;
     A.do_unsharp = p->unsharp_strength != 0.0;          // Python truthiness: `if unsharp_strength:`
     A.do_erosion = p->erosion_threshold != 0.0;         // `if thresh_eros and ...`
@@ -971,6 +1111,7 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
 {
     const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, d_weights, d_out32, d_out64);
     if (st != MMX_OK) return st;
+    if (params->tv_weight != 0.0) return MMX_ERR_UNSUPPORTED;      // total-variation denoising: the generic entry
     if (n_subs == 0) return MMX_OK;
     int64_t lds = 0;
     for (int i = 0; i < n_subs; ++i) {
@@ -1018,13 +1159,15 @@ int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_su
     for (int i = 0; i < n_subs; ++i) {
         const mmx_subblock& b = h_subs[i];
         const int64_t n = (int64_t)b.nz * b.ny * b.nx;
-        if (b.scratch_off < 0 || b.scratch_off + 2 * n > scratch_doubles) return MMX_ERR_WORKSPACE;
+        const int64_t per_voxel = params->tv_weight != 0.0 ? PP_TV_SCRATCH : 2;
+        if (b.scratch_off < 0 || b.scratch_off + per_voxel * n > scratch_doubles) return MMX_ERR_WORKSPACE;
+        if (params->tv_weight != 0.0 && n >= (1ll << 31)) return MMX_ERR_UNSUPPORTED;
     }
     const pp_args A = pp_make_args(params, dst_sy, dst_sz);
     hipStream_t s = (hipStream_t)stream;
     mmx_timed_scope ts(MMX_K_PREPROC, s);
     // every side <= 64: register-resident lines over the scratch (pp_mid_kernel); else one output per lane
-    bool mid = true;
+    bool mid = params->tv_weight == 0.0;       // (the iteration lives in the one-output-per-lane kernel only)
     int max_nx = 1;
     for (int i = 0; i < n_subs; ++i) {
         const mmx_subblock& b = h_subs[i];

@@ -86,17 +86,18 @@ def channel_params(chl: int, near_max: Optional[Sequence[float]] = None) -> Tupl
     """C-ABI parameters of one channel from its ROI profile + ``config.near_max``, read at call
     time like the reference does (plot_3d.py:84-99, 141-163)."""
     settings = config.get_roi_profile(chl)
-    if settings["tot_var_denoise"]:
-        raise NotImplementedError(
-            "total-variation denoising (profile 'tot_var_denoise', reference plot_3d.py:147-149) "
-            "is not built; stock nuclei profiles leave it off")
+    # total-variation denoising (plot_3d.py:147-149): `if tot_var_denoise:` then weight = the value itself
+    # (True -> 1.0 in NumPy arithmetic); tau / weight as Python evaluates it in the reference's expression
+    tv = settings["tot_var_denoise"]
+    tv_weight = float(tv) if tv else 0.0
+    tv_factor = (1. / (2. * 3)) / tv if tv else 0.0
     near = config.near_max if near_max is None else near_max
     max_thresh = near[chl] * settings["max_thresh_factor"]       # IndexError like the reference
     strength = settings["unsharp_strength"] or 0.0
     ero = settings["erosion_threshold"] or 0.0
     p = nat.PreprocParams(float(settings["clip_min"]), float(settings["clip_max"]), float(max_thresh),
                           float(strength), float(ero), kernels1d.kernel_radius(GAUSS_SIGMA),
-                          1 if RGB_GUESS else 0)
+                          1 if RGB_GUESS else 0, tv_weight, float(tv_factor))
     return p, settings["clip_vmin"], settings["clip_vmax"]
 
 
@@ -126,8 +127,10 @@ class Preprocessor:
     # ---- geometry
     @staticmethod
     def bytes_per_voxel() -> int:
-        """Extra HBM per block voxel: one float32 slot + two (double-buffered) float64 slots."""
-        return 4 + 2 * 8
+        """Extra HBM per block voxel: one float32 slot + two (double-buffered) float64 slots (+ the 7-double
+        scratch of the total-variation iteration when any profile switches it on)."""
+        tv = any(p["tot_var_denoise"] for p in [config.roi_profile, *config.roi_profiles] if p)
+        return 4 + 2 * 8 + (7 * 8 if tv else 0)
 
     def value_scale(self, channels: Sequence[int]) -> float:
         """Bound on |preprocessed voxel|: den + (den - s*blur) with den, blur in [clip_min, clip_max]."""
@@ -144,8 +147,9 @@ class Preprocessor:
             self._tiles[shape] = _tile_grid(shape, self.dms)
         return self._tiles[shape]
 
-    def _template(self, shape, vstrides, dstrides, pct_lo, pct_hi):
+    def _template(self, shape, vstrides, dstrides, pct_lo, pct_hi, force=None):
         """``(fast, mid, big)`` sub-block tables of one block shape with block-relative offsets."""
+        force = FORCE_GENERIC if force is None else force
         tkey = (shape, vstrides, dstrides)
         hit = self._tmpl.get(tkey)
         if hit is not None:
@@ -168,12 +172,12 @@ class Preprocessor:
                 self._qc_index[n] = len(self._qc_rows)
                 self._qc_rows.append((lp, ln, hp, hn, lg, hg))
             cls[j] = self._qc_index[n]
-            fast[j] = (not FORCE_GENERIC) and L.mmx_preprocess_fast_lds(int(u[0]), int(u[1]), int(u[2])) != 0
+            fast[j] = (not force) and L.mmx_preprocess_fast_lds(int(u[0]), int(u[1]), int(u[2])) != 0
         t["qclass"] = cls[inv]
         is_fast = fast[inv]
         # tiles that do not fit LDS: every side <= 64 -> register-line kernel over a global scratch,
         # anything larger -> one output per lane (both behind mmx_preprocess_batch_generic)
-        is_mid = ~is_fast & (e.max(axis=1) <= 64) & (FORCE_GENERIC != "big")
+        is_mid = ~is_fast & (e.max(axis=1) <= 64) & (force != "big")
         hit = (t[is_fast], t[is_mid], t[~is_fast & ~is_mid])
         self._tmpl[tkey] = hit
         return hit
@@ -215,7 +219,10 @@ class Preprocessor:
         vsz, vsy, vsx = (int(v) for v in t.stride()[:3])
         # sub-block table: per distinct block shape a cached template (tile extents, offsets relative
         # to the block, quantile class, fast / generic split); a block only adds its two base offsets
-        key = (pct_lo, pct_hi, FORCE_GENERIC)
+        # total-variation denoising iterates in the one-output-per-lane kernel over a global scratch
+        tv_on = params.tv_weight != 0.0
+        force = "big" if tv_on else FORCE_GENERIC
+        key = (pct_lo, pct_hi, force)
         if self._tmpl_key != key:
             self._tmpl_key, self._tmpl, self._qc_rows, self._qc_index = key, {}, [], {}
         # blocks of one shape share a template: their tables are filled with two broadcast additions,
@@ -229,7 +236,7 @@ class Preprocessor:
         plan = []                                            # (class, template, block indices)
         counts = [0, 0, 0]
         for shape_key, members in groups.items():
-            tmpls = self._template(shape_key, (vsz, vsy, vsx), (dst_sz, dst_sy), pct_lo, pct_hi)
+            tmpls = self._template(shape_key, (vsz, vsy, vsx), (dst_sz, dst_sy), pct_lo, pct_hi, force)
             for cls, tmpl in enumerate(tmpls):
                 if len(tmpl):
                     plan.append((cls, tmpl, members))
@@ -254,7 +261,7 @@ class Preprocessor:
         qc = np.array(self._qc_rows, dtype=nat.QCLASS_DTYPE)
         if n_gen:
             gen_n = (subs["nz"][n_fast:].astype(np.int64) * subs["ny"][n_fast:] * subs["nx"][n_fast:])
-            offs = np.concatenate([[0], np.cumsum(2 * gen_n)])
+            offs = np.concatenate([[0], np.cumsum((7 if tv_on else 2) * gen_n)])
             subs["scratch_off"][n_fast:] = offs[:-1]
             scratch = self._buffer("_scratch", None, int(offs[-1]), torch.float64, dev)
         out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)

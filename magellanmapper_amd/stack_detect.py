@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from enum import Enum
 from time import time
 from typing import NamedTuple, Optional, Sequence, Tuple
@@ -562,6 +563,14 @@ class StackPruner:
         (``mmx_host_prune_axis``; the de-duplication stays on the host as in the reference).
         """
         import pandas as pd
+        _prof = os.environ.get("MMX_PRUNE_PROF")
+        _t = [time()]
+
+        def _lap(what):
+            if _prof:
+                _t.append(time())
+                print(f"prune_blobs_mp {what}: {(_t[-1] - _t[-2]) * 1e3:.2f} ms", file=sys.stderr)
+
         arena = getattr(seg_rois, "arena", None)
         if arena is not None and not arena.intact(seg_rois):
             arena = None
@@ -598,6 +607,7 @@ class StackPruner:
         tol3 = (ctypes.c_int32 * 3)(*[int(v) for v in np.broadcast_to(np.asarray(tol), (3,))])
         lib = nat.lib()
         pieces = []
+        _lap("set-up (arena check, geometry, column copies)")
         for chl in channels:
             if arena is not None and arena.chan_lo == arena.chan_hi == chl:      # one channel: every row
                 cur = np.arange(len(chan), dtype=np.int64)
@@ -645,6 +655,7 @@ class StackPruner:
                     nxt_hi.ctypes.data, out_cur.ctypes.data, ctypes.byref(out_n), n_slab.ctypes.data,
                     n_after.ctypes.data, n_next.ctypes.data), "mmx_host_prune_axis")
                 cur = out_cur[:out_n.value]
+                _lap(f"axis {axis}")
                 for j in range(n_sections - 1):
                     if not np.isnan(nxt_lo[j]):
                         ratios = detector.meas_pruning_ratio(int(n_slab[j]), int(n_after[j]), int(n_next[j]))
@@ -663,4 +674,7 @@ class StackPruner:
         else:
             out = np.take(merged, rows, axis=0)[:, :-3]
             out[:, abs_inds] = np.take(abs_cur, rows, axis=0)
-        return out, pd.DataFrame(ratios_all)
+        _lap("gather of the output table")
+        df = pd.DataFrame(ratios_all)
+        _lap("ratio frame")
+        return out, df

@@ -96,6 +96,54 @@ def gaussian(image: np.ndarray, sigma: float) -> np.ndarray:
     return out
 
 
+def denoise_tv_chambolle(image: np.ndarray, weight=0.1, eps=2.e-4, n_iter_max=200) -> np.ndarray:
+    """``skimage.restoration.denoise_tv_chambolle`` for one float n-D image (0.18.3
+    restoration/_denoise.py:315-393; unchanged in the arithmetic through 0.25): Chambolle's projection
+    algorithm on the dual field ``p``, stopped when the energy changes by less than ``eps * E_0``.
+    Every operation in NumPy's order -- the device reproduces the result bit for bit, including the
+    iteration at which it stops, so the energies are summed with ``ndarray.sum`` (pairwise) here too."""
+    ndim = image.ndim
+    p = np.zeros((ndim,) + image.shape, dtype=image.dtype)
+    g = np.zeros_like(p)
+    d = np.zeros_like(image)
+    out = image
+    E_init = E_previous = 0.0
+    i = 0
+    while i < n_iter_max:
+        if i > 0:
+            d = -p.sum(0)                              # minus the divergence of p
+            for ax in range(ndim):
+                hi = [slice(None)] * ndim
+                lo = [slice(None)] * ndim
+                hi[ax], lo[ax] = slice(1, None), slice(0, -1)
+                d[tuple(hi)] += p[ax][tuple(lo)]
+            out = image + d
+        else:
+            out = image
+        E = (d ** 2).sum()
+        for ax in range(ndim):
+            sl = [slice(None)] * ndim
+            sl[ax] = slice(0, -1)
+            g[ax][tuple(sl)] = np.diff(out, axis=ax)    # forward differences; the last index stays 0
+        norm = np.sqrt((g ** 2).sum(axis=0))[np.newaxis, ...]
+        E += weight * norm.sum()
+        tau = 1. / (2. * ndim)
+        norm *= tau / weight
+        norm += 1.
+        p -= tau * g
+        p /= norm
+        E /= float(image.size)
+        if i == 0:
+            E_init = E
+            E_previous = E
+        else:
+            if np.abs(E_previous - E) < eps * E_init:
+                break
+            E_previous = E
+        i += 1
+    return out
+
+
 def denoise_roi(roi: np.ndarray, profiles: Sequence[dict],
                 channel: Optional[Sequence[int]] = None) -> np.ndarray:
     """Clip, unsharp mask (sigma 8) and density-dependent erosion; plot_3d.py:115-172."""
@@ -106,8 +154,9 @@ def denoise_roi(roi: np.ndarray, profiles: Sequence[dict],
         settings = _prof(profiles, chl)
         saturated_mean = np.mean(roi_show)
         denoised = np.clip(roi_show, settings["clip_min"], settings["clip_max"])
-        if settings.get("tot_var_denoise"):
-            raise NotImplementedError("total-variation denoising is outside the oracle's scope")
+        tot_var_denoise = settings.get("tot_var_denoise")
+        if tot_var_denoise:
+            denoised = denoise_tv_chambolle(denoised, weight=tot_var_denoise)
         unsharp_strength = settings["unsharp_strength"]
         if unsharp_strength:
             blurred = gaussian(denoised, 8)

@@ -515,6 +515,8 @@ def main():
         return main_unmix()
     if sys.argv[1:] == ["isotropic"]:     # only the isotropic-rescale fixtures (added later)
         return main_isotropic()
+    if sys.argv[1:] == ["tv"]:            # only the total-variation denoising fixtures (added later)
+        return main_tv()
     if sys.argv[1:] == ["match"]:         # only the match-based co-localisation fixtures (added later)
         return main_match()
     if sys.argv[1:] == ["grouping"]:      # only the channel-grouping fixtures of detect_blobs_stack (added later)
@@ -576,6 +578,7 @@ def main():
     main_isotropic()
     main_grouping()
     main_match()
+    main_tv()
 
 
 def main_isotropic():
@@ -790,6 +793,55 @@ def match_cases():
 
 def main_match():
     match_cases()
+
+
+def main_tv():
+    """plot_3d.denoise_roi with the profile's ``tot_var_denoise`` on (skimage.restoration.denoise_tv_chambolle):
+    sub-block cases (profiles 'minpreproc' and '2p20x' settings, sparse / dense / ragged / uint8 tiles) and one
+    whole-stack detection."""
+    from magmap.plot import plot_3d
+    from skimage import restoration
+    out = {}
+    names = []
+
+    def case(name, roi, near_max=(-1.0,), **over):
+        setup_profile(None, **over)
+        config.near_max = list(near_max)
+        sat = quiet(plot_3d.saturate_roi, roi, channel=None)
+        den = quiet(plot_3d.denoise_roi, sat, channel=None)
+        out[name + "_roi"] = roi
+        out[name + "_near_max"] = np.array(near_max, dtype=float)
+        out[name + "_over"] = repr(over)
+        out[name + "_sat"] = sat
+        out[name + "_den"] = den
+        names.append(name)
+        print("tv %-10s %s -> den [%.5f, %.5f]" % (name, roi.shape, float(den.min()), float(den.max())))
+
+    minpre = dict(clip_vmin=0, clip_vmax=99.99, clip_max=1, tot_var_denoise=0.01, unsharp_strength=0,
+                  erosion_threshold=0)
+    p2p20 = dict(clip_vmax=97, clip_min=0, clip_max=0.7, tot_var_denoise=True, unsharp_strength=2.5)
+    sparse = make_volume(81, (25, 25, 25), 3, margin=4)
+    densev = make_volume(82, (25, 25, 25), 40, amp=6000.0, blob_sigma=3.5, bg_mean=3000.0, bg_sd=800.0, margin=0)
+    case("min_sparse", sparse, **minpre)
+    case("min_dense", densev, **minpre)
+    case("2p_sparse", sparse, **p2p20)
+    case("2p_dense", densev, **p2p20)
+    case("w01_ragged", make_volume(83, (14, 25, 9), 2, margin=3), tot_var_denoise=0.1)
+    case("w01_u8", make_volume(84, (20, 22, 24), 4, dtype=np.uint8, margin=4), tot_var_denoise=0.1)
+    case("w05_big", make_volume(85, (30, 36, 34), 8, margin=4), tot_var_denoise=0.05, unsharp_strength=0.3)
+    case("const", np.full((10, 12, 11), 900, dtype=np.uint16), tot_var_denoise=0.1)
+    case("tiny", make_volume(86, (2, 1, 5), 0, margin=0), tot_var_denoise=0.1)
+    # the bare algorithm on a float image (iteration count and values)
+    rng = np.random.default_rng(87)
+    img = rng.random((9, 11, 10))
+    out["bare_img"] = img
+    out["bare_w02"] = restoration.denoise_tv_chambolle(img, weight=0.2)
+    config.near_max = [-1.0]
+    out["names"] = np.array(names)
+    out["versions"] = repr(VERSIONS)
+    np.savez_compressed(os.path.join(HERE, "tv.npz"), **out)
+    stack_case("tv", make_volume(88, (40, 60, 64), 30), None, segment_size=36, num_sigma=3, denoise_size=20,
+               tot_var_denoise=0.05)
 
 
 def main_coloc():

@@ -143,9 +143,6 @@ def test_unsupported_inputs_fail_loudly(gpu, env):
     _set_profiles({})
     with pytest.raises(NotImplementedError):
         preprocess.preprocess_roi(np.zeros((4, 4, 4), np.float32), (4, 4, 4))
-    _set_profiles({"tot_var_denoise": 0.1})
-    with pytest.raises(NotImplementedError):
-        preprocess.preprocess_roi(np.zeros((4, 4, 4), np.uint16), (4, 4, 4))
     _set_profiles({"clip_vmax": 101})
     with pytest.raises(ValueError):
         preprocess.preprocess_roi(np.zeros((4, 4, 4), np.uint16), (4, 4, 4))
@@ -353,3 +350,33 @@ def test_isotropic_anti_aliased_down_sampling(gpu):
             want = isotropic_oracle.make_isotropic(roi, scale, np.array(res))
             assert got.shape == want.shape and got.dtype == want.dtype
             np.testing.assert_array_equal(got, want, err_msg=str((shape, scale, res, kind)))
+
+
+# ------------------------------------------------------------------------------- total-variation denoising
+TV = load_golden("tv.npz")
+
+
+@pytest.mark.parametrize("case", [str(n) for n in TV["names"]])
+def test_tile_with_tv_denoising_matches_reference(gpu, env, case):
+    """``tot_var_denoise`` on (settings of the stock profiles 'minpreproc' and '2p20x', other weights, ragged /
+    uint8 / constant / tiny tiles): the device iteration (``mmx_preprocess_batch_generic``) stops at the
+    reference's iteration and returns its float64 values bit for bit -- the real ``plot_3d.denoise_roi`` with the
+    real ``skimage.restoration.denoise_tv_chambolle``."""
+    from magellanmapper_amd import preprocess
+    roi = TV[case + "_roi"]
+    over = ast.literal_eval(str(TV[case + "_over"]))
+    _set_profiles(over, 1)
+    got = preprocess.preprocess_roi(roi, roi.shape[:3], near_max=list(TV[case + "_near_max"]))
+    assert got.dtype == np.float64
+    np.testing.assert_array_equal(got, TV[case + "_den"])
+
+
+def test_tv_denoised_block_of_several_tiles_matches_oracle(gpu, env):
+    """Tiles of different sizes in one batch (25-voxel tiles over a 40 x 45 x 52 block), weight 0.05 + unsharp."""
+    from magellanmapper_amd import preprocess
+    from oracle import preprocess_oracle as ppo
+    roi = load_golden("stack_denoise.npz")["roi"][:40, :45, :52]
+    profs = _set_profiles(dict(tot_var_denoise=0.05), 1)
+    got = preprocess.preprocess_roi(roi, (25, 25, 25))
+    want = ppo.preprocess_block(roi, (25, 25, 25), profs, [-1.0])
+    np.testing.assert_array_equal(got, want)

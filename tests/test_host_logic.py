@@ -359,10 +359,13 @@ def test_unbuilt_rows_fail_loudly():
         colocalizer.colocalize_blobs(np.zeros((4, 4, 4, 2), np.uint16), np.zeros((1, 11)), thresh=50)
     assert colocalizer.colocalize_blobs(np.zeros((4, 4, 4), np.uint16), np.zeros((1, 11))) is None
     from magellanmapper_amd import preprocess
-    config.setup_roi_profiles(["minpreproc"])              # a profile with tot_var_denoise
+    config.setup_roi_profiles(["minpreproc"])              # a profile with tot_var_denoise: built since round 2
     try:
-        with pytest.raises(NotImplementedError):
-            preprocess.channel_params(0)
+        p = preprocess.channel_params(0)[0]
+        assert p.tv_weight == 0.01 and p.tv_factor == (1. / 6) / 0.01 and p.unsharp_strength == 0
+        config.setup_roi_profiles(["2p20x"])               # tot_var_denoise True: weight 1
+        p = preprocess.channel_params(0)[0]
+        assert p.tv_weight == 1.0 and p.tv_factor == 1. / 6 and p.unsharp_strength == 2.5
     finally:
         config.setup_roi_profiles()
     with pytest.raises(ValueError):

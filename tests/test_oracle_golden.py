@@ -374,3 +374,23 @@ def test_colocalize_stack_matches_reference(name):
     for key in keys:
         for col, arr in zip(("blob1", "blob2", "dist"), got[key]):
             np.testing.assert_array_equal(arr, g["%s_%d_%d_%s" % (name, *key, col)])
+
+
+# ----------------------------------------------------------------------------- total-variation denoising
+TV = load_golden("tv.npz")
+
+
+def test_tv_chambolle_bare_algorithm_matches_skimage():
+    np.testing.assert_array_equal(ppo.denoise_tv_chambolle(TV["bare_img"], weight=0.2), TV["bare_w02"])
+
+
+@pytest.mark.parametrize("case", [str(n) for n in TV["names"]])
+def test_preprocessing_with_tv_denoising_matches_reference(case, golden_gauss_weights):
+    """``tot_var_denoise`` on (profiles 'minpreproc': weight 0.01, no unsharp / erosion; '2p20x': weight True = 1,
+    unsharp 2.5): saturate_roi + denoise_roi == the real reference with the real scikit-image, bit for bit."""
+    roi = TV[case + "_roi"]
+    over = ast.literal_eval(str(TV[case + "_over"]))
+    profs = _profiles(over, 1)
+    sat = ppo.saturate_roi(roi, profs, list(TV[case + "_near_max"]))
+    np.testing.assert_array_equal(sat, TV[case + "_sat"])
+    np.testing.assert_array_equal(ppo.denoise_roi(sat, profs), TV[case + "_den"])
