@@ -191,10 +191,12 @@ def main():
         # a bounded sample (10-30 s of CPU work): about one block per core, at least two z-layers of blocks where
         # the volume has them so that the sample prunes seams along all three axes
         want_blocks = max(2, cores)
-        bz = 2 if shape[0] > 256 else 1
+        # (c5: both channels are preprocessed tile by tile in Python loops and detected -- one layer of 96-plane
+        #  blocks keeps the oracle at tens of seconds)
+        bz = 2 if (shape[0] > 256 and n_chl == 1) else 1
         by = max(1, min(shape[1] // 256, int(np.sqrt(want_blocks / bz) + 0.5)))
         bx = max(1, min(shape[2] // 256, -(-want_blocks // (bz * by))))
-        sz = min(shape[0], 320 if bz == 2 else 256)
+        sz = min(shape[0], 320 if bz == 2 else (96 if n_chl > 1 else 256))
         sshape = (sz, min(shape[1], 256 * by), min(shape[2], 256 * bx))
         sample = make_host_sample(sshape) if host_vol is None else np.ascontiguousarray(
             host_vol[:sshape[0], :sshape[1], :sshape[2]])
@@ -222,6 +224,10 @@ def main():
     from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
     from magellanmapper_amd import config, detector, dist, stack_detect, synth
+
+    # host allocator: the per-step tables (tens of MB) come from the heap and stay mapped between steps instead
+    # of being mmap'd, page-faulted in and unmapped every step (8 ms of a 198 ms step, tools/steptrace.py)
+    nat.keep_host_heap()
 
     config.resolutions = RESOLUTIONS
     config.filename = "bench"

@@ -193,3 +193,21 @@ def timing_read() -> dict:
     n = (c_int64 * len(KERNEL_KINDS))()
     check(lib().mmx_timing_read(ms, n, len(KERNEL_KINDS)), "mmx_timing_read")
     return {k: (ms[i], n[i]) for i, k in enumerate(KERNEL_KINDS)}
+
+
+def keep_host_heap(mmap_threshold: int = 1 << 30, trim_threshold: int = (1 << 31) - 1) -> bool:
+    """glibc ``mallopt``: serve large host arrays from the heap and keep freed heap memory mapped.
+
+    A whole-volume detection builds tables of tens of MB per call (the merged blob table, its compact
+    columns, the pruned output).  By default glibc ``mmap``s every allocation above 32 MiB: each call then pays
+    page faults for fresh zero pages and an ``munmap`` when the arrays die -- ~8 ms per 2048 x 2048 x 1024 volume.
+    Long-running detection processes (and ``bench.py``) call this once; it changes the allocator of the WHOLE
+    process (memory is returned to the OS later), which is why importing the package does not do it.
+    Returns False where ``mallopt`` is not available (non-glibc)."""
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        ok1 = libc.mallopt(-3, int(mmap_threshold))      # M_MMAP_THRESHOLD
+        ok2 = libc.mallopt(-1, int(trim_threshold))      # M_TRIM_THRESHOLD
+        return bool(ok1 and ok2)
+    except (OSError, AttributeError):
+        return False

@@ -276,14 +276,18 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
         cur_slot = slot
     if cur:
         batches.append(cur)
-    # The host work of the LAST batch is not hidden behind any GPU work: taper the tail by
-    # splitting the final batch (1/2, 1/4, 1/4 ...) while it stays large.
-    while len(batches[-1]) > 24:
-        last = batches.pop()
-        cut = len(last) - max(12, len(last) // 4)
-        batches.extend([last[:cut], last[cut:]])
-        if len(batches[-1]) <= 24:
-            break
+    # The host finishes batch k (candidates -> peaks -> per-block prune -> tables: ~0.33 ms per block of the
+    # benchmark volume) while the GPU runs batch k + 1 (~0.66 ms per block), and nothing hides the host work of
+    # the LAST batch: halve the tail batches (each still gives the GPU as much work as the host has left from the
+    # batch before) down to a last batch of <= 16 blocks.  Measured (tools/steptrace.py): 89 / 89 / 59 / 19 blocks
+    # left the host 8 ms behind the GPU at the end and 18 ms of tail; 89 / 89 / 39 / 20 / 10 / 9 does not.
+    taper = int(os.environ.get("MMX_TAPER", 16))
+    last = batches.pop()
+    while len(last) > max(1, taper):
+        cut = (len(last) + 1) // 2
+        batches.append(last[:cut])
+        last = last[cut:]
+    batches.append(last)
     return batches
 
 
@@ -300,10 +304,18 @@ class _Buffers:
     def __init__(self, dev):
         self.dev = dev
         self.ws = None
-        self.cands = [None, None]
-        self.counts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.host_counts = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.cands = []
+        self.counts = []
+        self.host_counts = []
         self.side = torch.cuda.Stream(device=dev, priority=-1)
+        self.slots(2)
+
+    def slots(self, n: int):
+        """At least ``n`` candidate-table slots (one per batch in flight)."""
+        while len(self.cands) < n:
+            self.cands.append(None)
+            self.counts.append(torch.zeros(1, dtype=torch.int32, device=self.dev))
+            self.host_counts.append(torch.zeros(1, dtype=torch.int32).pin_memory())
 
     def workspace(self, n_floats: int):
         if self.ws is None or self.ws.numel() < n_floats:
@@ -425,39 +437,63 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     d_w2 = torch.from_numpy(space.w2_tab).to(dvol.tensor.device)
     batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
                            0 if pre is None else pre.bytes_per_voxel())
-    pending = None
-    for k in range(len(batches) + 1):
-        job = None
-        if k < len(batches):
-            batch = batches[k]
-            job = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
-                                  space, float(threshold), eps, bufs, k & 1, d_w0, d_w2, pre=pre,
-                                  exact=bool(True if exact_values is None else exact_values))
-            job["batch"] = batch
-        if pending is not None:      # host + side-stream work of the previous batch, GPU busy with `job`
-            peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats)
-            with torch.cuda.stream(bufs.side):
-                pruned = _prune_batch(peaks, space, float(overlap), dvol.tensor.device, stats)
-            for i, pk, res in zip(pending["batch"], peaks, pruned):
-                results[i] = res
-                peaks_out[i] = pk
-            if on_batch is not None:    # caller's per-block post-processing, still overlapped
-                on_batch(pending["batch"], pruned)
-        pending = job
+    exact = bool(True if exact_values is None else exact_values)
+    n_b = len(batches)
+    # How far the GPU queue runs ahead of the host.  Raw volumes: EVERY batch is enqueued before the host looks at
+    # the first result, so the GPU runs the batches back to back whatever the host is doing (measured: enqueueing
+    # batch k + 1 only after the host work of batch k - 1 left the GPU idle ~4 ms per batch once the host work of
+    # a batch outlasted the kernels of the next).  Each batch in flight owns a candidate table; the workspace is
+    # shared (stream order).  With preprocessing the float64 tiles are double-buffered, so one batch ahead.
+    ahead = n_b if pre is None else 1
+    bufs.slots(ahead + 1)
+    prepared = None
+    if pre is None:
+        # block tables of every batch go to the device BEFORE the first kernel: a pageable host -> device copy
+        # waits for everything queued on the stream before it
+        prepared = [_make_blocks(dvol, channel, [origins[i] for i in b], [shapes[i] for i in b]) for b in batches]
+        prepared = [(blk, slot, _to_device_bytes(blk, dvol.tensor.device)) for blk, slot in prepared]
+        # ... and the shared workspace has its final size before anything is queued on it
+        if prepared:
+            bufs.workspace(max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, len(space.sigmas), 1)) // 4)
+                               for blk, slot, _ in prepared))
+    jobs: List[Optional[dict]] = [None] * n_b
+    enq = 0
+    for k in range(n_b):
+        while enq < min(n_b, k + 1 + ahead):           # batch k itself and `ahead` batches behind it
+            batch = batches[enq]
+            jobs[enq] = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
+                                        space, float(threshold), eps, bufs, enq % (ahead + 1), d_w0, d_w2, pre=pre,
+                                        exact=exact, prepared=None if prepared is None else prepared[enq])
+            jobs[enq]["batch"] = batch
+            enq += 1
+        pending, jobs[k] = jobs[k], None
+        # host + side-stream work of batch k, the GPU busy with the batches behind it
+        peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats)
+        with torch.cuda.stream(bufs.side):
+            pruned = _prune_batch(peaks, space, float(overlap), dvol.tensor.device, stats)
+        for i, pk, res in zip(pending["batch"], peaks, pruned):
+            results[i] = res
+            peaks_out[i] = pk
+        if on_batch is not None:    # caller's per-block post-processing, still overlapped
+            on_batch(pending["batch"], pruned)
     return (results, peaks_out) if return_peaks else results
 
 
 # --------------------------------------------------------------------------- A0-A4
 def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
                     bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None,
-                    exact: bool = False):
+                    exact: bool = False, prepared=None):
     """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU.
     ``exact``: also re-score every candidate in float64 (otherwise ``_resolve_peaks`` re-scores the few
     whose decision depends on it)."""
     L = nat.lib()
     dev = dvol.tensor.device
+    d_blocks = None
     if pre is None:
-        blocks, slot = _make_blocks(dvol, channel, origins, shapes)
+        if prepared is not None:
+            blocks, slot, d_blocks = prepared
+        else:
+            blocks, slot = _make_blocks(dvol, channel, origins, shapes)
         vol32 = dvol.view(channel, True)
         vol_exact = dvol.view(channel, False)
         store_f32 = 1 if dvol.np_dtype == np.float32 else 0
@@ -469,7 +505,8 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
         raise nat.MmxError("block too large for one workspace slot (>= 2^29 voxels)")
     mask_words = (nb * slot) >> 5            # 16-byte entries per sigma (include/mmx.h: d_nms_mask)
     ws = bufs.workspace(-(-int(L.mmx_workspace_bytes(nb, slot, ns, 1)) // 4))
-    d_blocks = _to_device_bytes(blocks, dev)
+    if d_blocks is None:
+        d_blocks = _to_device_bytes(blocks, dev)
     stream = _stream_ptr()
     log_base = ws.data_ptr() + 4 * nb * slot * 4
     # NMS pre-filter masks, [ns][nb][slot / 32] uint64: written by the Y pass of the fused path

@@ -1,21 +1,25 @@
 #!/bin/bash
-# Collect the round's rocprofv3 evidence on the GPU box (run through gpurun):
-#   kernel trace + stats of bench.py, and two separate PMC passes (FETCH_SIZE / WRITE_SIZE) for the
-#   bench and for the known-byte calibration streams.  Outputs under gpurun_out/prof_<tag>/.
+# Collect the round's evidence on the GPU box (run through gpurun): bench lines of the three configs, the
+# rocprofv3 kernel trace + stats of the headline command, and two separate PMC passes (FETCH_SIZE / WRITE_SIZE)
+# for the bench and for the known-byte calibration streams.  Outputs under gpurun_out/prof_<tag>/.
 set -u
-tag=${1:-r01}
-extra=${2:-}          # extra bench.py arguments, e.g. "--denoise 25"
+tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="bench.py --steps 2 --warmup 1 --no-cpu-baseline $extra"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $B > $out/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $B > $out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $B > $out/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/cal_fetch -- python tools/pmc_calib.py > $out/cal_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/cal_write -- python tools/pmc_calib.py > $out/cal_write.log 2>&1
+timeout 600 python bench.py --steps 10 --warmup 3 > $out/bench_c3.json 2> $out/bench_c3.err
+timeout 300 python bench.py --config c2 --steps 20 --warmup 5 > $out/bench_c2.json 2> $out/bench_c2.err
+timeout 600 python bench.py --config c5 --steps 3 --warmup 1 > $out/bench_c5.json 2> $out/bench_c5.err
+B="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $B > $out/trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $B > $out/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $B > $out/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/cal_fetch -- python tools/pmc_calib.py > $out/cal_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/cal_write -- python tools/pmc_calib.py > $out/cal_write.log 2>&1
 python tools/pmc_summary.py $out > $out/summary.txt 2>&1
-cat $out/summary.txt
+tail -30 $out/summary.txt
 # keep the merge small
-find $out -name "*kernel_trace.csv" -size +8M -delete
-find $out -name "*counter_collection.csv" -size +8M -delete
+find $out -name "*kernel_trace.csv" -size +4M -delete
+find $out -name "*counter_collection.csv" -size +4M -delete
+find $out -name "*.db" -delete
+du -sh $out

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Host timeline of one full-volume step (c3): when each batch is enqueued, when the host starts / ends finishing
+it, when the GPU goes idle, how long the tail after the last kernel is and what it consists of.
+
+    python tools/steptrace.py [--budget-gb 64]
+"""
+import argparse, functools, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from magellanmapper_amd import blob_log as bl, config, detector, stack_detect, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--budget-gb", type=float, default=64.0)
+ap.add_argument("--keep-heap", action="store_true", help="mallopt: big arrays from the heap, freed memory stays mapped")
+a = ap.parse_args()
+if a.keep_heap:
+    from magellanmapper_amd import _native
+    _native.keep_host_heap()
+cfg = bench.CONFIGS["c3"]
+shape = cfg["shape"]
+dev = torch.device("cuda", 0)
+config.resolutions = bench.RESOLUTIONS; config.filename = "p"
+config.setup_roi_profiles(None); config.roi_profile.update(bench._BASE_PROFILE)
+vol = synth.make_volume_device(shape, 3, dev)
+dvol = bl.DeviceVolume(vol)
+blocks = stack_detect.setup_blocks(config.roi_profile, shape)
+bl.blob_log_blocks = functools.partial(bl.blob_log_blocks, budget_bytes=int(a.budget_gb * (1 << 30)))
+log = []
+T0 = [0.0]
+
+
+def wrap(mod, name, tag):
+    fn = getattr(mod, name)
+
+    def inner(*args, **kw):
+        t = time.perf_counter()
+        out = fn(*args, **kw)
+        extra = ""
+        if name == "_enqueue_detect":
+            extra = f"{out['nb']} blocks"
+            ev = torch.cuda.Event(enable_timing=True); ev.record(); out["_ev"] = ev; evs.append(ev)
+        log.append((t - T0[0], time.perf_counter() - T0[0], tag, extra))
+        return out
+    setattr(mod, name, inner)
+
+
+evs = []
+wrap(bl, "_enqueue_detect", "enqueue batch")
+wrap(bl, "_finish_detect", "finish batch (candidates -> peaks)")
+wrap(bl, "_prune_batch", "per-block overlap prune")
+orig_prune = stack_detect.StackPruner.prune_blobs_mp.__func__
+
+
+def step():
+    seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, dvol, blocks.sub_roi_slices, blocks.sub_rois_offsets,
+                                                           None, None, False, [0])
+    t = time.perf_counter()
+    pruned, _ = stack_detect.StackPruner.prune_blobs_mp(dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                        blocks.sub_rois_offsets, [0], blocks.overlap_padding)
+    log.append((t - T0[0], time.perf_counter() - T0[0], "StackPruner.prune_blobs_mp", ""))
+    t = time.perf_counter()
+    bb = detector.Blobs(pruned); bb.replace_rel_with_abs_blob_coords(pruned); final = bb.remove_abs_blob_coords(True)
+    log.append((t - T0[0], time.perf_counter() - T0[0], "final columns", ""))
+    return final
+
+
+for _ in range(2):
+    step()
+log.clear(); evs.clear()
+torch.cuda.synchronize()
+start = torch.cuda.Event(enable_timing=True); start.record()
+T0[0] = time.perf_counter()
+step()
+t_end = time.perf_counter() - T0[0]
+torch.cuda.synchronize()
+gpu_done = [start.elapsed_time(e) for e in evs]
+print(f"step wall {t_end * 1e3:.1f} ms; GPU finished the kernels of batch k at {['%.1f' % g for g in gpu_done]} ms")
+for t0, t1, tag, extra in log:
+    print(f"  {t0 * 1e3:8.2f} -> {t1 * 1e3:8.2f} ms ({(t1 - t0) * 1e3:6.2f})  {tag} {extra}")
+print(f"tail after the last kernel: {t_end * 1e3 - gpu_done[-1]:.1f} ms")
+ts = []
+for _ in range(5):
+    torch.cuda.synchronize(); t = time.perf_counter(); step(); ts.append((time.perf_counter() - t) * 1e3)
+print("5 more steps (ms):", ["%.1f" % v for v in ts])
