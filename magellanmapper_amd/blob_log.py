@@ -279,9 +279,10 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     # The host finishes batch k (candidates -> peaks -> per-block prune -> tables: ~0.33 ms per block of the
     # benchmark volume) while the GPU runs batch k + 1 (~0.66 ms per block), and nothing hides the host work of
     # the LAST batch: halve the tail batches (each still gives the GPU as much work as the host has left from the
-    # batch before) down to a last batch of <= 16 blocks.  Measured (tools/steptrace.py): 89 / 89 / 59 / 19 blocks
-    # left the host 8 ms behind the GPU at the end and 18 ms of tail; 89 / 89 / 39 / 20 / 10 / 9 does not.
-    taper = int(os.environ.get("MMX_TAPER", 16))
+    # batch before) down to a last batch of <= 8 blocks.  Measured (tools/steptrace.py): 89 / 89 / 59 / 19 blocks
+    # left the host 8 ms behind the GPU at the end and 18 ms of tail; 89 / 89 / 39 / 20 / 10 / 5 / 4 does not
+    # (a last batch of <= 8 against <= 16 blocks: 193 against 195 ms per step, same box, alternating runs).
+    taper = int(os.environ.get("MMX_TAPER", 8))
     last = batches.pop()
     while len(last) > max(1, taper):
         cut = (len(last) + 1) // 2
