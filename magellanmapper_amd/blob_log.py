@@ -283,8 +283,10 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     # left the host 8 ms behind the GPU at the end and 18 ms of tail; 89 / 89 / 39 / 20 / 10 / 5 / 4 does not
     # (a last batch of <= 8 against <= 16 blocks: 193 against 195 ms per step, same box, alternating runs).
     taper = int(os.environ.get("MMX_TAPER", 8))
+    vox = [int(s_[0]) * int(s_[1]) * int(s_[2]) for s_ in shapes]
     last = batches.pop()
-    while len(last) > max(1, taper):
+    # (only batches with real work in them: below ~64 Mvoxel a batch is a few hundred microseconds of kernels)
+    while len(last) > max(1, taper) and sum(vox[i] for i in last) > (64 << 20):
         cut = (len(last) + 1) // 2
         batches.append(last[:cut])
         last = last[cut:]

@@ -61,14 +61,17 @@ def last_gather_ms() -> float:
     return _last_gather_ms
 
 
-def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: int, decode_on: Optional[int] = None
-                  ) -> List[Tuple[int, Optional[np.ndarray]]]:
+def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: int, decode_on: Optional[int] = None,
+                  raw: bool = False):
     """All ranks' ``(block_index, table | None)`` lists, merged and sorted by block index.
 
     Wire format: every table row is prefixed with its block index; ranks exchange row counts, column counts
     and one flag per block first (one small all_gather), then one all_gather of the row-padded float64 tables
     (two collectives per call, a few MB: latency bound).  ``decode_on``: only that rank unpacks the tables (the
     rank that prunes); the others get ``(index, None)`` placeholders back and skip the host work.
+    ``raw`` (several ranks only): the decoding rank gets ``(block index per row, all rows in block order, indices
+    of EMPTY blocks)`` instead of per-block tables -- what the pruning rank turns into its arena with a handful of
+    whole-array copies instead of one Python iteration per block; other ranks get ``None``.
     """
     global _last_gather_ms
     _last_gather_ms = 0.0
@@ -106,6 +109,27 @@ def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: in
     if len(have) and not np.all(have == have[0]):
         raise ValueError(f"ranks hold block tables of different widths: {sorted(set(int(v) - 1 for v in have))}")
     decode = decode_on is None or decode_on == rank()
+    if raw:
+        if recv_needed := (max_rows and n_cols):
+            padded = np.zeros((max_rows, n_cols))
+            padded[:mine.shape[0], :mine.shape[1]] = mine
+            send = torch.from_numpy(padded).to(dev)
+            recv = [torch.empty_like(send) for _ in range(n_ranks)]
+            tdist.all_gather(recv, send)
+        result = None
+        if decode:
+            empties = [share_bounds(n_items, r, n_ranks)[0] + int(pos)
+                       for r, m in enumerate(metas) for pos in np.nonzero(m[3:] == 1)[0]]
+            width = int(metas[:, 2].max())
+            if recv_needed:
+                bufs = torch.stack(recv).cpu().numpy()
+                parts = [b[:int(m[0]), :int(m[1])] for m, b in zip(metas, bufs) if m[0]]
+                rows = np.concatenate(parts) if len(parts) > 1 else parts[0]
+                result = (rows[:, 0].astype(np.int64), np.ascontiguousarray(rows[:, 1:]), empties)
+            else:
+                result = (np.zeros(0, dtype=np.int64), np.zeros((0, width)), empties)
+        _last_gather_ms = (time.perf_counter() - t_start) * 1e3
+        return result
     out: List[Tuple[int, Optional[np.ndarray]]] = []
     recv = None
     if max_rows and n_cols:

@@ -104,6 +104,28 @@ class _TableArena:
         a, b = self.spans[tuple(coord)]
         return self.store[a:b, :self.n_cols]
 
+    @classmethod
+    def from_rows(cls, idx: np.ndarray, rows: np.ndarray, coords: np.ndarray):
+        """The arena of tables that arrive as ONE array in block order (``idx``: block index per row,
+        ascending; ``coords``: grid coordinate of every block index): whole-array copies, no per-block loop."""
+        self = cls(rows.shape[1], 0)
+        n = len(rows)
+        self.cap = max(n, 1)
+        self.store = np.empty((self.cap, self.n_cols + 3))
+        self.store[:n, :self.n_cols] = rows
+        tags = coords[idx]
+        self.store[:n, self.n_cols:] = tags
+        self.zyx = np.ascontiguousarray(rows[:, :3], dtype=np.int32) if n else np.empty((1, 3), dtype=np.int32)
+        self.tag = np.ascontiguousarray(tags, dtype=np.int32) if n else np.empty((1, 3), dtype=np.int32)
+        self.abs = np.ascontiguousarray(rows[:, 7:10]) if n else np.empty((1, 3))
+        self.n = n
+        if n:
+            blocks, first = np.unique(idx, return_index=True)
+            ends = np.append(first[1:], n)
+            self.spans = {tuple(int(v) for v in coords[b]): (int(a), int(e)) for b, a, e in zip(blocks, first, ends)}
+            self.chan_lo, self.chan_hi = rows[:, 6].min(), rows[:, 6].max()
+        return self
+
     def intact(self, blob_rois) -> bool:
         """True when ``blob_rois`` still holds exactly the arena's tables, in grid order."""
         at = 0
@@ -241,15 +263,27 @@ class StackDetector:
         from . import dist
         coords = list(np.ndindex(*grid))
         seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
-        gathered = dist.gather_tables(local, len(coords), decode_on=0)     # only the pruning rank unpacks
-        if arena is None and dist.rank() == 0:
-            # several ranks: the pruning rank lays the gathered tables out back to back (grid order)
-            # so that merge_blobs and the native prune step take their fast path as on one GPU
-            arena = _TableArena(11 + n_extra, len(gathered))
-            for i, tbl in gathered:
-                if tbl is not None and len(tbl):
-                    arena.add(coords[i], tbl)
-        for i, tbl in gathered:
+        if dist.world_size() > 1:
+            # several ranks: the pruning rank receives all rows as one array in block order and lays them out as
+            # its arena with whole-array copies (merge_blobs and the native prune step then take their fast path
+            # as on one GPU); the other ranks keep None placeholders
+            got = dist.gather_tables(local, len(coords), decode_on=0, raw=True)
+            if got is not None:
+                idx, rows, empties = got
+                arena = _TableArena.from_rows(idx, rows, np.asarray(coords, dtype=np.int64))
+                for coord in arena.spans:
+                    seg_rois[coord] = arena.view(coord)
+                for i in empties:
+                    seg_rois[coords[i]] = np.zeros((0, rows.shape[1]))
+                for coord in np.ndindex(*grid):
+                    if isinstance(seg_rois[coord], (int, np.integer)):
+                        seg_rois[coord] = None
+                seg_rois.arena = arena
+            else:
+                for coord in np.ndindex(*grid):
+                    seg_rois[coord] = None
+            return seg_rois
+        for i, tbl in sorted(local, key=lambda e: e[0]):
             if arena is not None and tbl is not None and len(tbl):
                 tbl = arena.view(coords[i])         # the copy that lives in the arena
             seg_rois[coords[i]] = tbl
