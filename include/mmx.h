@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 9
+#define MMX_ABI_VERSION 10
 
 typedef enum {
     MMX_OK = 0,
@@ -115,11 +115,18 @@ int mmx_device_count(void);
  *                NOT WRITTEN TO d_log (a response below the threshold can neither be a peak nor out-vote
  *                one): d_log is then only meaningful together with the entries.  Only the fused path produces
  *                the entries, and only when every block's rows fit its share (tiny blocks do not):
- *                *h_mask_written (host) says whether this call did (if not, d_log is complete).
+ *                *h_mask_written (host) says whether this call did (0: no, d_log is complete) and in which
+ *                layout: MMX_MASK_ROWS (1) as above; MMX_MASK_QUADS (2, left by MMX_ZX_TILED): per row y one entry
+ *                per 4 planes x 16 columns, entry y * ceil(nz/4) * ceil(nx/16) + (z >> 2) * ceil(nx/16) + (x >> 4),
+ *                bit ((z & 3) << 4) | (x & 15), the unwritten segments of d_log being those 64 voxels.  Pass the
+ *                value on to mmx_peaks_batch (every sigma of a batch must have produced the same layout).
  *   zx_mode    : how the Z and X passes run (a per-call argument: the library keeps no mode).
- *                MMX_ZX_AUTO (default): the fastest kernel that takes the geometry (today MMX_ZX_PACKED, else the
- *                separate passes); the others exist for cross-checks and measurements.  All agree within float32 rounding, and the peak decisions are
- *                taken on exact float64 values either way (mmx_rescore_f64).
+ *                MMX_ZX_AUTO (default): the fastest kernel that takes the geometry (MMX_ZX_TILED for integer
+ *                voxels, else MMX_ZX_PACKED, else the separate passes); the others exist for cross-checks and
+ *                measurements.  All agree within float32 rounding, and the peak decisions are taken on exact
+ *                float64 values either way (mmx_rescore_f64).  MMX_ZX_TILED works from an operand-ordered copy of
+ *                the blocks' voxels inside d_work, which does not depend on sigma: mmx_zx_pack makes it once per
+ *                batch, and MMX_ZX_TILED | MMX_ZX_PREPACKED then skips making it again for every sigma.
  *   h_zx_path  : optional out (host): the MMX_ZX_* kernel this call actually ran (MMX_ZX_SEPARATE when the
  *                geometry fell back to the three separate passes)                                          */
 typedef enum {
@@ -129,13 +136,25 @@ typedef enum {
     MMX_ZX_MFMA_F32 = 3,  /* zx3_kernel: Z on the VALU, X on v_mfma_f32_16x16x4_f32 (measured experiment)   */
     MMX_ZX_MFMA_F16 = 4,  /* zx4_kernel: X+Z on v_mfma_f32_16x16x32_f16 with split-float16 operands,
                              register resident (integer voxels; measured experiment)                       */
-    MMX_ZX_MFMA_F16_LDS = 5 /* zx5_kernel: the same arithmetic, voxels and results staged through LDS      */
+    MMX_ZX_MFMA_F16_LDS = 5,/* zx5_kernel: the same arithmetic, voxels and results staged through LDS      */
+    MMX_ZX_TILED = 6      /* zx4's arithmetic on an operand-ordered copy of the voxels (zx6_pack_kernel), P / Q
+                             handed to the Y pass (y6_kernel) as 16 x 16 tiles: every access one contiguous KiB */
 } mmx_zx_mode;
+#define MMX_ZX_PREPACKED 0x100   /* or-ed into MMX_ZX_TILED: mmx_zx_pack ran on this d_work for these blocks */
+#define MMX_MASK_ROWS 1
+#define MMX_MASK_QUADS 2
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                       int n_blocks, int64_t slot_elems,
                       const double* h_w0, const double* h_w2, int radius, double norm,
                       float* d_log, float* d_work, uint64_t* d_nms_mask, float nms_lo, float nms_eps,
                       int* h_mask_written, int zx_mode, int* h_zx_path, void* stream);
+
+/* The sigma-independent part of MMX_ZX_TILED: the operand-ordered copy of the blocks' voxels, written into the
+ * part of d_work (same pointer, blocks and slot_elems as the mmx_log_batch_f32 calls that follow) that the tiled
+ * path leaves alone.  MMX_ERR_UNSUPPORTED (nothing written) for float voxels or when the pieces do not fit
+ * d_work: call mmx_log_batch_f32 without MMX_ZX_PREPACKED then. */
+int mmx_zx_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                int64_t slot_elems, float* d_work, void* stream);
 
 /* Bytes of device workspace one batch needs for `n_sigma` scales: the 4 intermediate arrays of
  * mmx_log_batch_f32 (d_work), one d_log array per scale and, with `with_masks`, the NMS entries of every scale
@@ -157,9 +176,10 @@ int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks,
  *   d_log        : [n_sigma][n_blocks][slot_elems] float32 (sigma-major)
  *   d_nms_mask   : optional [n_sigma][(n_blocks * slot_elems) >> 5] 16-byte entries written by mmx_log_batch_f32 with
  *                  nms_lo = thr - eps and nms_eps = eps for EVERY sigma (NULL = read every voxel)
+ *   mask_layout  : MMX_MASK_ROWS / MMX_MASK_QUADS as reported by those calls (ignored without d_nms_mask)
  *   eps          : candidates are emitted when v >= nbr_max - eps and v > thr - eps
  *   d_cands/cap  : output table; *d_count keeps counting past cap (caller retries)  */
-int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int n_sigma, const mmx_block* d_blocks,
+int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int mask_layout, int n_sigma, const mmx_block* d_blocks,
                     const mmx_block* h_blocks, int n_blocks, int64_t slot_elems,
                     float thr, float eps, mmx_cand* d_cands, uint32_t cap,
                     uint32_t* d_count, void* stream);
@@ -358,8 +378,8 @@ int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const
  * events, returns summed milliseconds and launch counts per kernel family (index =
  * MMX_K_*: 0 z pass, 1 y pass, 2 x pass, 3 generic passes, 4 peaks, 5 rescore,
  * 6 overlap pairs, 7 close pairs, 8 fused z+x pass, 9 y pass of the fused path, 10 preprocessing,
- * 11 co-localisation means) and starts a new window. */
-#define MMX_K_COUNT 12
+ * 11 co-localisation means, 12 operand-ordered voxel copy of the tiled path) and starts a new window. */
+#define MMX_K_COUNT 13
 int mmx_timing_enable(int on);
 int mmx_timing_read(double* ms, int64_t* launches, int n);
 

@@ -17,13 +17,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 9
+MMX_ABI_VERSION = 10
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
 MMX_CAND_CONTESTED = 1
 #: ``mmx_zx_mode``: how mmx_log_batch_f32 runs its Z and X passes (a per-call argument)
 MMX_ZX_AUTO, MMX_ZX_SEPARATE, MMX_ZX_PACKED, MMX_ZX_MFMA_F32, MMX_ZX_MFMA_F16, MMX_ZX_MFMA_F16_LDS = -1, 0, 2, 3, 4, 5
+MMX_ZX_TILED, MMX_ZX_PREPACKED = 6, 0x100
+#: NMS entry layouts ``mmx_log_batch_f32`` reports and ``mmx_peaks_batch`` takes
+MMX_MASK_ROWS, MMX_MASK_QUADS = 1, 2
 
 #: NumPy mirror of ``mmx_block`` (32 bytes).
 BLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("nz", "<i4"), ("ny", "<i4"), ("nx", "<i4"),
@@ -72,7 +75,7 @@ _lib = None
 #: every symbol ``include/mmx.h`` declares
 SYMBOLS = (
     "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
-    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
+    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_zx_pack", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
@@ -81,7 +84,7 @@ SYMBOLS = (
     "mmx_cdist_f64", "mmx_host_lsap",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
-                "close_pairs", "zxpass", "y2pass", "preproc", "coloc")
+                "close_pairs", "zxpass", "y2pass", "preproc", "coloc", "zxpack")
 
 
 def lib() -> ctypes.CDLL:
@@ -107,7 +110,8 @@ def lib() -> ctypes.CDLL:
     L.mmx_log_batch_f32_generic.argtypes = log_args + [vp]
     L.mmx_workspace_bytes.argtypes = [c_int, c_int64, c_int, c_int]
     L.mmx_workspace_bytes.restype = ctypes.c_size_t
-    L.mmx_peaks_batch.argtypes = [vp, vp, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
+    L.mmx_zx_pack.argtypes = [POINTER(Volume), vp, vp, c_int, c_int64, vp, vp]
+    L.mmx_peaks_batch.argtypes = [vp, vp, c_int, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
                                   c_uint32, vp, vp]
     L.mmx_rescore_f64.argtypes = [POINTER(Volume), vp, c_int, vp, c_uint32, vp, vp, vp,
                                   POINTER(c_int32), POINTER(c_double), c_int, c_int, vp]

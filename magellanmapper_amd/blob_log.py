@@ -517,35 +517,52 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     written = ctypes.c_int(0)
     path = ctypes.c_int(0)
 
-    def passes(with_mask: bool):
+    def passes(with_mask: bool, mode: int):
+        """Every scale of the batch -> the set of entry layouts the calls reported (0 = no entries)."""
         global LAST_ZX_PATH
-        all_written, any_written = with_mask, False
+        layouts = set()
+        # the tiled path works from an operand-ordered copy of the voxels that does not depend on sigma: made
+        # once here, trusted by the calls below for as long as every call so far ran the tiled path (any other
+        # path uses the same part of the workspace for something else)
+        packed = False
+        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED):
+            rc = L.mmx_zx_pack(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
+                               ws.data_ptr(), stream)
+            if rc not in (0, 5):                 # MMX_OK, MMX_ERR_UNSUPPORTED (float voxels, workspace shape)
+                nat.check(rc, "mmx_zx_pack")
+            packed = rc == 0
         for s in range(ns):
             nat.check(L.mmx_log_batch_f32(
                 ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                 nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]), int(space.radii[s]),
                 float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(),
                 (mask_base + s * mask_words * 16) if with_mask else None, thr - eps, eps,
-                ctypes.byref(written), ZX_MODE, ctypes.byref(path), stream),
+                ctypes.byref(written), (nat.MMX_ZX_TILED | nat.MMX_ZX_PREPACKED) if packed else mode,
+                ctypes.byref(path), stream),
                 "mmx_log_batch_f32")
             LAST_ZX_PATH = path.value
-            all_written = all_written and written.value == 1
-            any_written = any_written or written.value == 1
-        return all_written, any_written
+            packed = packed and path.value == nat.MMX_ZX_TILED
+            layouts.add(written.value if with_mask else 0)
+        return layouts
 
-    # With the entries the Y pass leaves whole segments of the cube unwritten, so it is all scales or none:
-    # if one scale cannot produce them (a radius outside the fused kernels, tiny blocks) every scale is
-    # computed again in full.
-    mask_ok, some = passes(True)
-    if some and not mask_ok:
-        passes(False)
+    # With the entries the Y pass leaves whole segments of the cube unwritten, so it is all scales, in one
+    # layout, or none: if one scale cannot produce them (a radius outside the fused kernels, tiny blocks) or
+    # the scales ran different kernels, every scale is computed again -- with the packed kernel's entries if a
+    # scale produced those, else in full.
+    layouts = passes(True, ZX_MODE)
+    if layouts == {nat.MMX_MASK_ROWS, nat.MMX_MASK_QUADS}:
+        layouts = passes(True, nat.MMX_ZX_PACKED)
+    if len(layouts) > 1:
+        layouts = passes(False, ZX_MODE)
+    mask_layout = layouts.pop()
+    mask_ok = mask_layout > 0
     n_vox = int(sum(int(np.prod(s)) for s in shapes))
     if cap is None:
         cap = max(4096, min(n_vox * ns, n_vox // 2000 * ns + 65536))
     table = bufs.cand_table(which, cap)
     count = bufs.counts[which]
     count.zero_()
-    nat.check(L.mmx_peaks_batch(log_base, mask_base if mask_ok else None, ns, d_blocks.data_ptr(),
+    nat.check(L.mmx_peaks_batch(log_base, mask_base if mask_ok else None, mask_layout, ns, d_blocks.data_ptr(),
                                 blocks.ctypes.data, nb, slot, thr, eps, table.data_ptr(), cap,
                                 count.data_ptr(), stream),
               "mmx_peaks_batch")

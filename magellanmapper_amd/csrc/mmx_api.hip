@@ -16,7 +16,7 @@ int mmx_launch_peaks(const float* d_log, int n_sigma, int64_t sigma_stride, cons
 int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask, int n_sigma,
                             int64_t sigma_stride, const mmx_block* d_blocks, int n_blocks, int max_vox,
                             int64_t slot_elems, float thr, float eps, mmx_cand* d_cands, uint32_t cap,
-                            uint32_t* d_count, hipStream_t stream);
+                            uint32_t* d_count, int quads, hipStream_t stream);
 
 #include <mutex>
 #include <vector>
@@ -149,7 +149,9 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
 {
     if (h_mask_written) *h_mask_written = 0;
     if (h_zx_path) *h_zx_path = MMX_ZX_SEPARATE;
-    if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_MFMA_F16_LDS || zx_mode == 1) return MMX_ERR_ARG;
+    const bool prepacked = zx_mode == (MMX_ZX_TILED | MMX_ZX_PREPACKED);
+    if (prepacked) zx_mode = MMX_ZX_TILED;
+    if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_TILED || zx_mode == 1) return MMX_ERR_ARG;
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
         return MMX_ERR_ARG;
     if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
@@ -227,13 +229,27 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     if (fused) {
         mmx_taps_f32 tzz = taps(wz0, wz2), txx = taps(wy0, wy2), tyy = taps(wx0, wx2);
         int path = MMX_ZX_PACKED;
+        // AUTO = the tiled matrix-core path for integer voxels, else the packed-VALU kernel.  (The register-only
+        // and LDS-staged matrix-core kernels are correct and selectable, but no faster than the packed one:
+        // DESIGN.md section 4b -- their 16 planes x 64 bytes accesses were the limit, which the tiled form removes.)
+        mmx_zx6_plan plan;
+        bool tiled = (zx_mode == MMX_ZX_TILED || zx_mode == MMX_ZX_AUTO) &&
+                     (vol->dtype == MMX_U8 || vol->dtype == MMX_U16) &&
+                     mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, &plan) == MMX_OK;
+        if (tiled && !prepacked) {
+            mmx_timed_scope ts(MMX_K_ZXPACK, s);
+            rc = mmx_launch_zx6_pack(vol, d_blocks, h_blocks, n_blocks, plan, d_work, s);
+            if (rc == MMX_ERR_HIP) return hip_fail(hipGetLastError(), "voxel copy of the tiled path");
+            tiled = rc == MMX_OK;
+        }
         { mmx_timed_scope ts(MMX_K_ZX, s);
           rc = MMX_ERR_UNSUPPORTED;
-          // AUTO = the packed-VALU kernel.  The matrix-core kernels are correct and selectable, but measured on
-          // the benchmark volume none is faster (5.3 - 6.0 ms per 64 blocks whatever the
-          // radius, against 4.4 - 6.3 ms; in bench.py, where planes are 8 MiB apart, 5.9 against 5.5 on average)
           const bool mfma16 = zx_mode == MMX_ZX_MFMA_F16 || zx_mode == MMX_ZX_MFMA_F16_LDS;
-          if (mfma16) {    // integer voxels, aligned rows; geometries it does not take: the packed kernel
+          if (tiled) {
+              path = MMX_ZX_TILED;
+              rc = mmx_launch_zx6(vol, d_blocks, h_blocks, n_blocks, plan, txx, radius, d_work, s);
+              tiled = rc == MMX_OK;
+          } else if (mfma16) {    // integer voxels, aligned rows; geometries it does not take: the packed kernel
               path = zx_mode == MMX_ZX_MFMA_F16_LDS ? MMX_ZX_MFMA_F16_LDS : MMX_ZX_MFMA_F16;
               rc = mmx_launch_zx4(vol, d_blocks, h_blocks, n_blocks, slot_elems, txx, radius, t0, t1, t2,
                                   (size_t)(2 * n_slots * slot_elems) * sizeof(float), path == MMX_ZX_MFMA_F16_LDS, s);
@@ -251,12 +267,19 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
             // the mask rows of a block (ny rows of ceil(nz * px / 64) words) must fit its slot / 32 words
             bool want_mask = d_nms_mask != nullptr && h_mask_written != nullptr;
             for (int b = 0; want_mask && b < n_blocks; ++b) {
-                const int64_t need = (int64_t)h_blocks[b].ny * (((int64_t)h_blocks[b].nz * h_blocks[b].px + 63) >> 6);
+                const mmx_block& hb = h_blocks[b];
+                const int64_t need = tiled ? (int64_t)hb.ny * ((hb.nz + 3) >> 2) * ((hb.nx + 15) >> 4)
+                                           : (int64_t)hb.ny * (((int64_t)hb.nz * hb.px + 63) >> 6);
                 if (need > (slot_elems >> 5) - 1) want_mask = false;
             }
-            rc = mmx_launch_y2(d_blocks, n_blocks, max_ycols, slot_elems, tyy, radius, t0, t1, d_log,
-                               want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s);
-            if (rc == MMX_OK && want_mask) *h_mask_written = 1;
+            if (tiled)
+                rc = mmx_launch_y6(d_blocks, n_blocks, plan, slot_elems, tyy, radius, d_work,
+                                   reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_work) + plan.q_off), d_log,
+                                   want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s);
+            else
+                rc = mmx_launch_y2(d_blocks, n_blocks, max_ycols, slot_elems, tyy, radius, t0, t1, d_log,
+                                   want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s);
+            if (rc == MMX_OK && want_mask) *h_mask_written = tiled ? MMX_MASK_QUADS : MMX_MASK_ROWS;
         }
         if (rc == MMX_ERR_HIP) return hip_fail(hipGetLastError(), "fused passes");
         if (rc == MMX_OK) return MMX_OK;
@@ -316,7 +339,25 @@ int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks, 
     return mmx_launch_generic_pass(2, vol, d_blocks, n_blocks, max_vox, slot_elems, a, b, radius, t2, t3, d_log, nullptr, s);
 }
 
-int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int n_sigma, const mmx_block* d_blocks,
+int mmx_zx_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                int64_t slot_elems, float* d_work, void* stream)
+{
+    if (!vol || !vol->d_data || !d_blocks || !h_blocks || !d_work || n_blocks < 1 || slot_elems < 1) return MMX_ERR_ARG;
+    if (vol->dtype != MMX_U8 && vol->dtype != MMX_U16) return MMX_ERR_UNSUPPORTED;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_block& b = h_blocks[i];
+        if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
+        if (b.px < b.nx || b.px % MMX_ROW_ALIGN) return MMX_ERR_ARG;
+    }
+    mmx_zx6_plan plan;
+    int rc = mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, &plan);
+    if (rc != MMX_OK) return rc;
+    mmx_timed_scope ts(MMX_K_ZXPACK, (hipStream_t)stream);
+    rc = mmx_launch_zx6_pack(vol, d_blocks, h_blocks, n_blocks, plan, d_work, (hipStream_t)stream);
+    return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "voxel copy of the tiled path") : rc;
+}
+
+int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int mask_layout, int n_sigma, const mmx_block* d_blocks,
                     const mmx_block* h_blocks, int n_blocks, int64_t slot_elems,
                     float thr, float eps, mmx_cand* d_cands, uint32_t cap,
                     uint32_t* d_count, void* stream)
@@ -324,6 +365,7 @@ int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int n_sigma,
     if (!d_log || !d_blocks || !h_blocks || !d_cands || !d_count) return MMX_ERR_ARG;
     if (n_sigma < 1 || n_blocks < 1 || slot_elems < 1 || !(eps >= 0.f)) return MMX_ERR_ARG;
     if (slot_elems % MMX_ROW_ALIGN) return MMX_ERR_ARG;
+    if (d_nms_mask && mask_layout != MMX_MASK_ROWS && mask_layout != MMX_MASK_QUADS) return MMX_ERR_ARG;
     int max_vox = 0;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
@@ -337,7 +379,7 @@ int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int n_sigma,
     if (d_nms_mask)
         rc = mmx_launch_peaks_sparse(d_log, (const unsigned long long*)d_nms_mask, n_sigma,
                                      (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox, slot_elems,
-                                     thr, eps, d_cands, cap, d_count, (hipStream_t)stream);
+                                     thr, eps, d_cands, cap, d_count, mask_layout == MMX_MASK_QUADS, (hipStream_t)stream);
     else
         rc = mmx_launch_peaks(d_log, n_sigma, (int64_t)n_blocks * slot_elems, d_blocks, n_blocks, max_vox,
                               slot_elems, thr, eps, d_cands, cap, d_count, (hipStream_t)stream);

@@ -47,6 +47,26 @@ int mmx_launch_zx3(const mmx_volume* vol, const mmx_block* d_blocks, int n_block
 int mmx_launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
                    int64_t slot_elems, const mmx_taps_f32& tx, int radius, float* d_p, float* d_q,
                    void* d_scratch, size_t scratch_bytes, int staged, hipStream_t stream);
+// Tiled fused path (zx_mode 6): where its pieces live inside the four intermediate arrays of d_work
+// (4 n_blocks slot_elems floats).  P and Q as 16 x 16 tiles (mmx_fused4.hip: zx4_kernel<.., TILED>), the Toeplitz
+// fragment tables of the current sigma, and the operand-ordered copy of the blocks' voxels (zx6_pack_kernel),
+// which survives from one sigma of a batch to the next.
+struct mmx_zx6_plan {
+    int64_t tile_stride;    // floats per block of tiled P (and of Q): max over blocks of ntx ntz ny 256
+    int64_t pack_stride;    // uint16 elements per block of packed voxels: max over blocks of ny ntz nch8 128
+    int64_t q_off, tab_off, pack_off;      // byte offsets into d_work (P at 0)
+    int64_t tab_bytes;
+    int max_tiles;          // max ntx ntz
+    int max_rowtiles;       // max ny ntz
+};
+int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elems, mmx_zx6_plan* plan);
+int mmx_launch_zx6_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                        const mmx_zx6_plan& plan, void* d_work, hipStream_t stream);
+int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                   const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, hipStream_t stream);
+int mmx_launch_y6(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
+                  const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
+                  float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);
 int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
                   float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);
@@ -54,7 +74,7 @@ int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t
 // ---- optional per-kernel-family timing with HIP events on the launch stream (bench.py) ----
 enum mmx_kernel_kind {
     MMX_K_ZPASS = 0, MMX_K_YPASS, MMX_K_XPASS, MMX_K_GENERIC, MMX_K_PEAKS, MMX_K_RESCORE,
-    MMX_K_PAIRS, MMX_K_CLOSE, MMX_K_ZX, MMX_K_Y2, MMX_K_PREPROC, MMX_K_COLOC, MMX_K_END
+    MMX_K_PAIRS, MMX_K_CLOSE, MMX_K_ZX, MMX_K_Y2, MMX_K_PREPROC, MMX_K_COLOC, MMX_K_ZXPACK, MMX_K_END
 };
 void mmx_time_begin(int kind, hipStream_t s);
 void mmx_time_end(int kind, hipStream_t s);

@@ -199,6 +199,148 @@ int launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slo
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
+// ---------------------------------------------------------------- Y pass on tiled (P, Q)  (zx_mode 6)
+// Same arithmetic, other geometry: P and Q arrive as 16 z x 16 x tiles of 1 KiB, the tiles of one (column tile c,
+// z tile U) following each other along y (mmx_fused4.hip: zx4_kernel<.., TILED>).  A workgroup owns one (c, U);
+// each of its four waves marches along y over 4 planes x 16 columns of it: one contiguous 256-byte piece per
+// array and step, the next one a KiB further on.  The LoG cube stays row-major (the NMS and re-scoring kernels
+// read single voxels from it): a wave stores four 64-byte row pieces, and only where something is above the
+// threshold.  NMS entries: per row y one entry per (4 planes, 16 columns) = this wave's footprint,
+// index y * (nzq * ntx) + (z >> 2) * ntx + (x >> 4), bit ((z & 3) << 4) | (x & 15)  (mmx_peaks.hip: layout 2).
+template <int R, bool MASK>
+__global__ void __launch_bounds__(MMX_WG)
+y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile_stride,
+          const float* __restrict__ gp, const float* __restrict__ gq,
+          float* __restrict__ out, y2_taps taps,
+          unsigned long long* __restrict__ mask, float nms_lo, float nms_eps)
+{
+    constexpr int N = 2 * R + 1;
+    constexpr int M = N + kPrefetch;
+    const mmx_block bd = blocks[blockIdx.y];
+    const int ntx = (bd.nx + 15) >> 4, ntz = (bd.nz + 15) >> 4;
+    const int tile = blockIdx.x;
+    if (tile >= ntx * ntz) return;
+    const int c = tile / ntz, U = tile - c * ntz;
+    const int zq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (16 * U + 4 * zq >= bd.nz) return;                       // whole wave past the block (no barriers here)
+    const int lane = threadIdx.x & 63;
+    const int xi = lane & 15;
+    const int z = 16 * U + 4 * zq + (lane >> 4), x = 16 * c + xi;
+    const int n = bd.ny;
+    const bool real = z < bd.nz && x < bd.nx;
+    const float* i1 = gp + (int64_t)bd.slot * tile_stride + (int64_t)tile * n * 256;
+    const float* i2 = gq + (int64_t)bd.slot * tile_stride + (int64_t)tile * n * 256;
+    float* w1 = out + (int64_t)bd.slot * slot_elems;
+    const unsigned voff = (unsigned)(zq * 64 + lane) * 4u;                          // inside a tile
+    // (lanes past the block keep an in-range address: they never store)
+    const unsigned ooff = (unsigned)((real ? z : 0) * bd.ny * bd.px + (real ? x : 0)) * 4u;   // row 0 of this voxel's column
+    const int nent = ((bd.nz + 3) >> 2) * ntx;
+    ulonglong2* mrow = MASK ? reinterpret_cast<ulonglong2*>(mask) + ((int64_t)bd.slot * slot_elems >> 5) +
+                              (4 * U + zq) * ntx + c
+                            : nullptr;
+    unsigned long long ab_prev = 0;
+    const bool has_l = xi > 0, has_r = xi < 15 && x + 1 < bd.nx;
+    float prev1 = -INFINITY, prev2 = -INFINITY, nbx_prev = -INFINITY;
+    int ydone = 0;
+
+    const rsrc_t rs1 = make_rsrc(i1), rs2 = make_rsrc(i2), rsw = make_rsrc(w1);
+    v2f r[M];     // (P, Q) window
+#pragma unroll
+    for (int j = -R; j < R + kPrefetch; ++j) {
+        const unsigned row = (unsigned)reflect_once(j, n) * 1024u;
+        r[(j + M) % M] = (v2f){__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, row, 0)),
+                               __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, row, 0))};
+    }
+    const unsigned row_b = (unsigned)bd.px * 4u;
+    unsigned qoff = (unsigned)(R + kPrefetch) * 1024u;      // next tile to load (bytes)
+    unsigned woff = 0;                                      // row being written
+    auto step = [&](int s, auto reflecting, int y) __attribute__((always_inline)) {
+        float n1, n2;
+        if constexpr (decltype(reflecting)::value) {
+            const unsigned rnext = (unsigned)reflect_once(y + R + kPrefetch, n) * 1024u;
+            n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, rnext, 0));
+            n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, rnext, 0));
+        } else {
+            n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, qoff, 0));
+            n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, qoff, 0));
+        }
+        qoff += 1024u;
+        v2f a2 = r[s] * taps.w[0];
+        v2f b2 = (r[(s - 1 + M) % M] + r[(s + 1) % M]) * taps.w[1];
+#pragma unroll
+        for (int k = 2; k <= R; k += 2) {
+            const v2f sa = r[(s - k + M) % M] + r[(s + k) % M];
+            a2 = __builtin_elementwise_fma(sa, taps.w[k], a2);
+            if (k + 1 <= R) {
+                const v2f sb = r[(s - k - 1 + M) % M] + r[(s + k + 1) % M];
+                b2 = __builtin_elementwise_fma(sb, taps.w[k + 1], b2);
+            }
+        }
+        a2 += b2;
+        const float acc = a2.x + a2.y;
+        const unsigned long long ab = MASK ? __ballot(real & (acc > nms_lo)) : ~0ull;
+        if (ab && real) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rsw, ooff, woff, 0);
+        woff += row_b;
+        r[(s + R + kPrefetch) % M] = (v2f){n1, n2};
+        if constexpr (MASK) {
+            // x neighbours inside the 16-lane rows (DPP row shifts); lanes with no source keep `acc`, which
+            // has_l / has_r discard: the first and last column of a tile are not tested against the next tile
+            const float l = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
+                (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+            const float rr = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
+                (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+            const float nbx = fmaxf(has_l ? l : -INFINITY, has_r ? rr : -INFINITY);
+            if (ydone > 0) {      // decide row ydone - 1, now that its successor is known
+                const bool cand = real & (prev1 > nms_lo) &
+                                  !(fmaxf(fmaxf(prev2, acc), nbx_prev) > prev1 + nms_eps);
+                const unsigned long long m = __ballot(cand);
+                if (lane == 0) *mrow = make_ulonglong2(m, ab_prev);
+                mrow += nent;
+            }
+            prev2 = prev1; prev1 = acc; nbx_prev = nbx;
+            ab_prev = ab;
+            ++ydone;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int y0 = 0;
+#pragma unroll 1
+    for (; y0 + M + R + kPrefetch <= n; y0 += M) {
+#pragma unroll
+        for (int s = 0; s < M; ++s) step(s, std::false_type{}, 0);
+    }
+#pragma unroll 1
+    for (; y0 < n; y0 += M) {
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            if (y0 + s >= n) break;
+            step(s, std::true_type{}, y0 + s);
+        }
+    }
+    if constexpr (MASK) {     // the last row has no successor
+        const bool cand = real & (prev1 > nms_lo) & !(fmaxf(prev2, nbx_prev) > prev1 + nms_eps);
+        const unsigned long long m = __ballot(cand);
+        if (lane == 0) *mrow = make_ulonglong2(m, ab_prev);
+    }
+}
+
+template <int R>
+int launch_y6(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
+              const mmx_taps_f32& taps, const float* d_p, const float* d_q, float* d_log,
+              unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t s)
+{
+    dim3 grid(plan.max_tiles, n_blocks);
+    y2_taps pk;
+    for (int k = 0; k <= R; ++k) pk.w[k] = (v2f){taps.w2[k], taps.w0[k]};
+    if (d_mask)
+        hipLaunchKernelGGL((y6_kernel<R, true>), grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, plan.tile_stride, d_p, d_q,
+                           d_log, pk, d_mask, nms_lo, nms_eps);
+    else
+        hipLaunchKernelGGL((y6_kernel<R, false>), grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, plan.tile_stride, d_p, d_q,
+                           d_log, pk, d_mask, nms_lo, nms_eps);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
 }  // namespace
 
 #define MMX_FOR_EACH_RADIUS(X) \
@@ -211,6 +353,18 @@ int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t
 {
     switch (radius) {
 #define X(R) case R: return launch_y2<R>(d_blocks, n_blocks, max_cols, slot_elems, taps, d_p, d_q, d_log, d_mask, nms_lo, nms_eps, stream);
+        MMX_FOR_EACH_RADIUS(X)
+#undef X
+        default: return MMX_ERR_UNSUPPORTED;
+    }
+}
+
+int mmx_launch_y6(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
+                  const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
+                  float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream)
+{
+    switch (radius) {
+#define X(R) case R: return launch_y6<R>(d_blocks, n_blocks, plan, slot_elems, taps, d_p, d_q, d_log, d_mask, nms_lo, nms_eps, stream);
         MMX_FOR_EACH_RADIUS(X)
 #undef X
         default: return MMX_ERR_UNSUPPORTED;

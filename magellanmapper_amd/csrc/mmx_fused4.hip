@@ -67,7 +67,7 @@ struct mmx_zx4_cfg {
     int wcls[MMX_ZX4_MAXCLS];              // widths (nx)
     int zcls[MMX_ZX4_MAXCLS];              // depths (nz)
     int maxcol, maxu;                      // table extents: columns per width class, z tiles per depth class
-    int staged;                            // 1: the kernel reads every chunk at its natural position (zx5), 0: clamped into the row (zx4)
+    int staged;                            // 0: chunks clamped into the row (zx4); 1: at their natural position (zx5); 2: same, windows at 16 c - R8 (zx6)
 };
 
 namespace {
@@ -150,7 +150,8 @@ zx4_setup(mmx_zx4_cfg cfg, u4_4* __restrict__ xtab, u4_4* __restrict__ ztab)
         const int W = cfg.wcls[cl];
         const float* w = kern ? cfg.w2 : cfg.w0;
         const int xo = 16 * c + col;
-        const int xc = cg::xstart(c) + 32 * m + 8 * kq;             // natural start of this lane's chunk
+        // natural start of this lane's chunk (tiled form, staged == 2: windows start at 16 c - R8, any multiple of 8)
+        const int xc = (cfg.staged == 2 ? 16 * c - cg::R8 : cg::xstart(c)) + 32 * m + 8 * kq;
         int xl = xc < 0 ? 0 : xc;
         xl = xl > W - 8 ? W - 8 : xl;                               // where the kernel loads it from
         if (cfg.staged) xl = xc;
@@ -202,12 +203,12 @@ template <typename InT> struct pieces4;
 template <> struct pieces4<uint16_t> {
     static constexpr int NP = 2;
     using raw_t = u4_4;
-    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off)
+    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off, unsigned soff = 0)
     {
 #ifdef ZX4_NO_LOAD
         return (u4_4){off, off * 3u, off * 5u, off * 7u};
 #endif
-        return __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, ZX4_LD_AUX));
+        return __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, ZX4_LD_AUX));
     }
     static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo)
     {
@@ -227,9 +228,9 @@ template <> struct pieces4<uint16_t> {
 template <> struct pieces4<uint8_t> {
     static constexpr int NP = 1;
     using raw_t = u2_4;
-    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off)
+    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off, unsigned soff = 0)
     {
-        return __builtin_bit_cast(u2_4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+        return __builtin_bit_cast(u2_4, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
     }
     static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo)
     {
@@ -253,7 +254,10 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_4, a), __builtin_bit_cast(h8_4, b), c, 0, 0, 0);
 }
 
-template <int NKX, int LA, typename InT>
+// TILED (zx_mode 6): the voxels come from the operand-ordered copy zx6_pack_kernel leaves (`vol` = that copy,
+// stride_z = its elements per block) and P / Q leave as 16 x 16 tiles of 1 KiB (slot_elems = tile elements per
+// block), which y6_kernel (mmx_fused.hip) reads: every global access of a wave is then one contiguous KiB.
+template <int NKX, int LA, typename InT, bool TILED = false>
 __global__ void __launch_bounds__(256, 2)
 zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
@@ -304,16 +308,24 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #ifdef ZX4_ROWS_Y      // access-pattern experiment (wrong results): tile rows = 16 rows of ONE plane, march along y
     const InT* in = vol + bd.src_off + (int64_t)y * stride_z;
 #else
-    const InT* in = vol + bd.src_off + (int64_t)y * stride_y;
+    const InT* in = TILED ? vol + (int64_t)bd.slot * stride_z : vol + bd.src_off + (int64_t)y * stride_y;
 #endif
+    const int nch8 = (W + 7) >> 3;                               // TILED: 256-byte units (8 columns x 16 planes) per row tile
     unsigned xoff[NKX];
 #pragma unroll
     for (int m = 0; m < NKX; ++m) {
-        int xl = cg::xstart(c) + 32 * m + 8 * kq;
-        xl = xl < 0 ? 0 : xl;
-        xl = xl > W - 8 ? W - 8 : xl;
-        xoff[m] = (unsigned)xl * (unsigned)sizeof(InT);
+        if constexpr (TILED) {
+            int j = 2 * c - cg::R8 / 8 + 4 * m + kq;             // unit of this lane; outside the row: any unit, zero weights
+            j = j < 0 ? 0 : (j > nch8 - 1 ? nch8 - 1 : j);
+            xoff[m] = (unsigned)(j * 256 + li * 16);
+        } else {
+            int xl = cg::xstart(c) + 32 * m + 8 * kq;
+            xl = xl < 0 ? 0 : xl;
+            xl = xl > W - 8 ? W - 8 : xl;
+            xoff[m] = (unsigned)xl * (unsigned)sizeof(InT);
+        }
     }
+    const rsrc4_t rin = make_rsrc4(in);
 #ifdef ZX4_ROWS_Y
     const unsigned zstride_b = (unsigned)(stride_y * (int64_t)sizeof(InT));
 #else
@@ -323,6 +335,12 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #ifdef ZX5_LD_SMALL
         t = 0;
 #endif
+        if constexpr (TILED) {
+            const unsigned so = (unsigned)((y * ntz + t) * nch8) * 256u;      // wave-uniform: the row tile
+#pragma unroll
+            for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rin, xoff[m], so);
+            return;
+        }
 #ifdef ZX4_ROWS_Y
         const rsrc4_t rs = make_rsrc4(in + (int64_t)(16 * t) * stride_y);
 #else
@@ -345,11 +363,14 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
     const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
     const unsigned row_b = (unsigned)px * 4u;
-    const unsigned plane_b = (unsigned)bd.ny * row_b;
+    // TILED: tile (c, U, y) of 16 z x 16 x floats, row-major, at ((c ntz + U) ny + y) KiB: the tiles of one (c, U)
+    // follow each other along y, the direction y6_kernel marches in
+    const unsigned plane_b = TILED ? (unsigned)bd.ny * 64u : (unsigned)bd.ny * row_b;
 #ifdef ZX4_ROWS_Y
     unsigned obase = (unsigned)li * row_b + (unsigned)y * plane_b + (unsigned)(16 * c + 4 * kq) * 4u;
 #else
-    unsigned obase = (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
+    unsigned obase = TILED ? (unsigned)((c * ntz * bd.ny + y) * 1024 + (4 * li + kq) * 16)
+                           : (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
 #endif
 
     // voxels of the next ZX4_PF z tiles, in flight.  vmcnt counts loads and stores together and in issue order:
@@ -461,7 +482,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #else
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(P), "v"(Q));       // the slot's previous results stayed in these registers until now
-            if (STEADY || 16 * U + li < nz) {
+            if (STEADY || TILED || 16 * U + li < nz) {     // (a tile is stored whole: its padding belongs to it)
 #endif
                 // the results reach the slot's registers through opaque moves: the stores then read registers
                 // that nothing else may be allocated to before the slot comes round again
@@ -881,7 +902,149 @@ int launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------- tiled variant (zx_mode 6)
+// Operand-ordered copy of the blocks' voxels, made once per batch: for every block row y and z tile t the row
+// tile of 16 planes x nx voxels as units of 8 columns x 16 planes (256 bytes, plane-major inside), widened to
+// uint16: the four units a lane group of zx4_kernel<.., TILED> needs for one k-step are one contiguous KiB
+// wherever the window starts.  Planes past the block and columns past the row read as zero.  Any strides, any
+// alignment: the copy is what lifts zx4's 16-byte alignment rules.
+template <typename InT>
+__global__ void __launch_bounds__(256)
+zx6_pack_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y, int64_t stride_x,
+                const mmx_block* __restrict__ blocks, uint16_t* __restrict__ pack, int64_t pack_stride)
+{
+    constexpr int PITCH = 512 + 8;                       // uint16 per LDS row (fused paths take px <= 512)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[16][PITCH];
+    const mmx_block bd = blocks[blockIdx.y];
+    const int ntz = (bd.nz + 15) >> 4, nch8 = (bd.nx + 7) >> 3;
+    const int yt = blockIdx.x;
+    if (yt >= bd.ny * ntz) return;
+    const int y = yt / ntz, t = yt - y * ntz;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const InT* src = vol + bd.src_off + (int64_t)y * stride_y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i, z = 16 * t + r;
+        for (int x = lane; x < 8 * nch8; x += 64)
+            tile[r][x] = (z < bd.nz && x < bd.nx) ? (uint16_t)src[(int64_t)z * stride_z + (int64_t)x * stride_x] : (uint16_t)0;
+    }
+    __syncthreads();
+    u4_4* dst = reinterpret_cast<u4_4*>(pack + (int64_t)bd.slot * pack_stride) + (int64_t)yt * nch8 * 16;
+    for (int u = threadIdx.x; u < nch8 * 16; u += 256) {
+        const int j = u >> 4, r = u & 15;
+        dst[u] = *reinterpret_cast<const u4_4*>(&tile[r][8 * j]);
+    }
+}
+
+template <int NKX, int LA>
+int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+               const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, hipStream_t s)
+{
+    using cg = cls4<NKX, LA>;
+    mmx_zx4_cfg cfg;
+    for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) { cfg.w0[k] = tx.w0[k]; cfg.w2[k] = tx.w2[k]; }
+    cfg.radius = radius;
+    // the pieces carry v / 2^16 of the widened voxel: skimage's img_as_float scale on top
+    cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(65536.0 / 255.0);
+    cfg.ncw = cfg.ncz = 0;
+    cfg.staged = 2;
+    cfg.maxcol = cfg.maxu = 0;
+    int max_waves = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_block& b = h_blocks[i];
+        if (b.nx < radius || b.nz < radius) return MMX_ERR_UNSUPPORTED;       // single reflection
+        int j;
+        for (j = 0; j < cfg.ncw && cfg.wcls[j] != b.nx; ++j) {}
+        if (j == cfg.ncw) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; cfg.wcls[cfg.ncw++] = b.nx; }
+        for (j = 0; j < cfg.ncz && cfg.zcls[j] != b.nz; ++j) {}
+        if (j == cfg.ncz) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; cfg.zcls[cfg.ncz++] = b.nz; }
+        const int ntx = (b.nx + 15) / 16, ntz = (b.nz + 15) / 16;
+        if (ntx > cfg.maxcol) cfg.maxcol = ntx;
+        if (ntz > cfg.maxu) cfg.maxu = ntz;
+        if (b.ny * ntx > max_waves) max_waves = b.ny * ntx;
+    }
+    for (int j = cfg.ncw; j < MMX_ZX4_MAXCLS; ++j) cfg.wcls[j] = -1;
+    for (int j = cfg.ncz; j < MMX_ZX4_MAXCLS; ++j) cfg.zcls[j] = -1;
+    const int nx_entries = cfg.ncw * cfg.maxcol * NKX * 2;
+    const int nz_entries = cfg.ncz * cfg.maxu * cg::NKZ * 2;
+    const size_t xbytes = (size_t)nx_entries * 2 * 64 * sizeof(u4_4);
+    const size_t zbytes = (size_t)nz_entries * 2 * 64 * sizeof(u4_4);
+    if ((int64_t)(xbytes + zbytes) > plan.tab_bytes) return MMX_ERR_UNSUPPORTED;
+    char* w = reinterpret_cast<char*>(d_work);
+    u4_4* xtab = reinterpret_cast<u4_4*>(w + plan.tab_off);
+    u4_4* ztab = reinterpret_cast<u4_4*>(w + plan.tab_off + xbytes);
+    hipLaunchKernelGGL((zx4_setup<NKX, LA>), dim3((nx_entries + nz_entries + 3) / 4), dim3(256), 0, s, cfg, xtab, ztab);
+    dim3 grid((max_waves + 3) / 4, n_blocks);
+    hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true>), grid, dim3(256), 0, s,
+                       reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
+                       plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
+                       xtab, ztab, cfg);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
 }  // namespace
+
+int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elems, mmx_zx6_plan* plan)
+{
+    int64_t tile = 0, pk = 0;
+    int max_tiles = 0, max_rowtiles = 0, maxcol = 0, maxu = 0;
+    int wcls[MMX_ZX4_MAXCLS], zcls[MMX_ZX4_MAXCLS], ncw = 0, ncz = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        const mmx_block& b = h_blocks[i];
+        if (b.px > 512) return MMX_ERR_UNSUPPORTED;
+        int j;
+        for (j = 0; j < ncw && wcls[j] != b.nx; ++j) {}
+        if (j == ncw) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; wcls[ncw++] = b.nx; }
+        for (j = 0; j < ncz && zcls[j] != b.nz; ++j) {}
+        if (j == ncz) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; zcls[ncz++] = b.nz; }
+        const int ntx = (b.nx + 15) / 16, ntz = (b.nz + 15) / 16, nch8 = (b.nx + 7) / 8;
+        const int64_t te = (int64_t)ntx * ntz * b.ny * 256, pe = (int64_t)b.ny * ntz * nch8 * 128;
+        if (te > tile) tile = te;
+        if (pe > pk) pk = pe;
+        if (ntx * ntz > max_tiles) max_tiles = ntx * ntz;
+        if (b.ny * ntz > max_rowtiles) max_rowtiles = b.ny * ntz;
+        if (ntx > maxcol) maxcol = ntx;
+        if (ntz > maxu) maxu = ntz;
+    }
+    if (tile * 4 >= (int64_t(1) << 31) || pk * 2 >= (int64_t(1) << 31)) return MMX_ERR_UNSUPPORTED;   // 32-bit offsets in a block
+    plan->tile_stride = tile;
+    plan->pack_stride = pk;
+    plan->q_off = (int64_t)n_blocks * tile * 4;
+    plan->tab_off = 2 * plan->q_off;
+    // the largest tables any radius class needs: widths x columns x 2 k-steps, depths x z tiles x 3, two kernels each
+    plan->tab_bytes = (int64_t)(ncw * maxcol * 2 * 2 + ncz * maxu * 3 * 2) * 2 * 64 * 16;
+    plan->pack_off = (plan->tab_off + plan->tab_bytes + 255) & ~int64_t(255);
+    plan->max_tiles = max_tiles;
+    plan->max_rowtiles = max_rowtiles;
+    const int64_t need = plan->pack_off + (int64_t)n_blocks * pk * 2;
+    return need <= 4 * (int64_t)n_blocks * slot_elems * 4 ? MMX_OK : MMX_ERR_UNSUPPORTED;
+}
+
+int mmx_launch_zx6_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                        const mmx_zx6_plan& plan, void* d_work, hipStream_t stream)
+{
+    (void)h_blocks;
+    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8) return MMX_ERR_UNSUPPORTED;
+    uint16_t* pack = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_work) + plan.pack_off);
+    dim3 grid(plan.max_rowtiles, n_blocks);
+    if (vol->dtype == MMX_U16)
+        hipLaunchKernelGGL((zx6_pack_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, vol->stride_x, d_blocks, pack, plan.pack_stride);
+    else
+        hipLaunchKernelGGL((zx6_pack_kernel<uint8_t>), grid, dim3(256), 0, stream, (const uint8_t*)vol->d_data,
+                           vol->stride_z, vol->stride_y, vol->stride_x, d_blocks, pack, plan.pack_stride);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
+                   const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, hipStream_t stream)
+{
+    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8) return MMX_ERR_UNSUPPORTED;
+    if (radius < 1 || radius > MMX_MAX_RADIUS_FAST) return MMX_ERR_UNSUPPORTED;
+    if (radius <= 8) return launch_zx6<1, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, stream);
+    if (radius <= 16) return launch_zx6<2, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, stream);
+    return launch_zx6<2, 2>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, stream);
+}
 
 // tx: the PLAIN half kernels (no input scale, no norm); d_scratch: device memory the fused path does not
 // otherwise use (the fragment tables: a few hundred KB)

@@ -180,13 +180,20 @@ struct sparse_ctx {
     peak_ctx c;
     const ulonglong2* ent;      // entries of this block, sigma 0
     int64_t ent_sigma_stride;   // entries per sigma
-    int nwords;                 // entries per row
+    int nwords;                 // entries per row y
+    int quads, ntx;             // entry layout 2 (y6_kernel): one entry per 4 planes x 16 columns, ntx per plane quad
 };
+
+// entry holding voxel (z, y, x).  Layout 1 (y2_kernel): 64 consecutive columns of the (z, x) plane of row y;
+// layout 2 (y6_kernel): planes 4 (z >> 2) .. + 3 x columns 16 (x >> 4) .. + 15, bit ((z & 3) << 4) | (x & 15)
+__device__ __forceinline__ int64_t sparse_entry(const sparse_ctx& k, int z, int y, int x)
+{
+    return (int64_t)y * k.nwords + (k.quads ? (z >> 2) * k.ntx + (x >> 4) : (z * k.c.px + x) >> 6);
+}
 
 __device__ __forceinline__ float sparse_at(const sparse_ctx& k, int s, int z, int y, int x)
 {
-    const int col = z * k.c.px + x;
-    const unsigned long long above = k.ent[(int64_t)s * k.ent_sigma_stride + (int64_t)y * k.nwords + (col >> 6)].y;
+    const unsigned long long above = k.ent[(int64_t)s * k.ent_sigma_stride + sparse_entry(k, z, y, x)].y;
     if (!above) return -INFINITY;
     return k.c.base[(int64_t)s * k.c.sigma_stride + (int64_t)z * k.c.plane + y * k.c.px + x];
 }
@@ -209,15 +216,14 @@ __device__ __forceinline__ void check_voxel_sparse(const sparse_ctx& k, int s, i
                 const int yy = y + dy;
                 if (yy < 0 || yy >= ny) { border = true; continue; }
                 // the three x neighbours share (at most two) entries and one row
-                const int col0 = zz * c.px + x;
-                const ulonglong2* er = k.ent + (int64_t)ss * k.ent_sigma_stride + (int64_t)yy * k.nwords;
+                const ulonglong2* er = k.ent + (int64_t)ss * k.ent_sigma_stride;
                 const float* row = c.base + (int64_t)ss * c.sigma_stride + (int64_t)zz * c.plane + yy * c.px;
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int xx = x + dx;
                     if (xx < 0 || xx >= nx) { border = true; continue; }
                     if ((ds | dz | dy | dx) == 0) continue;
-                    if (er[(col0 + dx) >> 6].y) m = fmaxf(m, row[xx]);
+                    if (er[sparse_entry(k, zz, yy, xx)].y) m = fmaxf(m, row[xx]);
                 }
             }
             if (m > reject) return;
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(MMX_WG)
 peaks_sparse_kernel(const float* __restrict__ log, const ulonglong2* __restrict__ entries,
                     int ns, int64_t sigma_stride, const mmx_block* __restrict__ blocks, int64_t slot_elems,
                     float thr, float eps, mmx_cand* __restrict__ out, uint32_t cap,
-                    uint32_t* __restrict__ count)
+                    uint32_t* __restrict__ count, int quads)
 {
     const mmx_block bd = blocks[blockIdx.y];
     sparse_ctx k;
@@ -261,7 +267,9 @@ peaks_sparse_kernel(const float* __restrict__ log, const ulonglong2* __restrict_
     c.plane = bd.ny * bd.px; c.slot = bd.slot;
     c.thr = thr; c.eps = eps; c.out = out; c.cap = cap; c.count = count;
     const int ncol = bd.nz * bd.px;
-    k.nwords = (ncol + 63) >> 6;
+    k.quads = quads;
+    k.ntx = (bd.nx + 15) >> 4;
+    k.nwords = quads ? ((bd.nz + 3) >> 2) * k.ntx : (ncol + 63) >> 6;
     k.ent = entries + ((int64_t)bd.slot * slot_elems >> 5);
     k.ent_sigma_stride = sigma_stride >> 5;
     const int64_t per_sigma = (int64_t)bd.ny * k.nwords;
@@ -277,9 +285,16 @@ peaks_sparse_kernel(const float* __restrict__ log, const ulonglong2* __restrict_
         const int64_t r = i - (int64_t)s * per_sigma;
         const int y = (int)(r / k.nwords);
         const int w = (int)(r - (int64_t)y * k.nwords);
-        const int col = (w << 6) + b;
-        const int z = col / bd.px;
-        const int x = col - z * bd.px;
+        int z, x;
+        if (k.quads) {
+            const int zqi = w / k.ntx;
+            z = 4 * zqi + (b >> 4);
+            x = 16 * (w - zqi * k.ntx) + (b & 15);
+        } else {
+            const int col = (w << 6) + b;
+            z = col / bd.px;
+            x = col - z * bd.px;
+        }
         if (x >= bd.nx || z >= bd.nz) return;
         const float v = c.base[(int64_t)s * sigma_stride + (int64_t)z * c.plane + y * bd.px + x];
         // (the y and x neighbours were tested when the bit was set: most set bits are the in-plane maxima of
@@ -350,7 +365,7 @@ peaks_sparse_kernel(const float* __restrict__ log, const ulonglong2* __restrict_
 int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask, int n_sigma,
                             int64_t sigma_stride, const mmx_block* d_blocks, int n_blocks, int max_vox,
                             int64_t slot_elems, float thr, float eps, mmx_cand* d_cands, uint32_t cap,
-                            uint32_t* d_count, hipStream_t stream)
+                            uint32_t* d_count, int quads, hipStream_t stream)
 {
     int64_t words = ((int64_t)max_vox / 64 + 1024) * n_sigma;
     int gx = (int)((words + MMX_WG * 8 - 1) / (MMX_WG * 8));      // 8 words per lane and round
@@ -359,7 +374,7 @@ int mmx_launch_peaks_sparse(const float* d_log, const unsigned long long* d_mask
     dim3 grid(gx, n_blocks);
     hipLaunchKernelGGL(peaks_sparse_kernel, grid, dim3(MMX_WG), 0, stream, d_log,
                        reinterpret_cast<const ulonglong2*>(d_mask), n_sigma, sigma_stride,
-                       d_blocks, slot_elems, thr, eps, d_cands, cap, d_count);
+                       d_blocks, slot_elems, thr, eps, d_cands, cap, d_count, quads);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 

@@ -75,7 +75,7 @@ def test_two_blocks_of_the_benchmark_geometry(gpu):
     offsets[0, 0, 1] = (0, 0, 256)
     seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, bl.DeviceVolume(vol), slices, offsets, None, None,
                                                            False, [0])
-    assert bl.LAST_ZX_PATH == 2                       # the fused packed-math kernel took this geometry
+    assert bl.LAST_ZX_PATH == 6                       # the tiled matrix-core kernels took this geometry
     st = stack_detect.StackDetector.last_stats
     assert st.n_blocks == 2 and st.max_f32_error < 0.25 * bl.EPS_REL
     got, _ = stack_detect.StackPruner.prune_blobs_mp(vol, seg, blk.overlap, blk.tol, slices, offsets, [0],

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected before any device work."""
     lib = _native.lib()
-    assert lib.mmx_peaks_batch(None, None, 1, None, None, 1, 1, 0.1, 1e-5, None, 1, None, None) == 1
+    assert lib.mmx_peaks_batch(None, None, 0, 1, None, None, 1, 1, 0.1, 1e-5, None, 1, None, None) == 1
     vol = _native.Volume(0, 1, 0, 1, 1, 1)
     w = np.ones(3)
     assert lib.mmx_log_batch_f32(ctypes.byref(vol), None, None, 1, 8, _native.as_double_ptr(w),

@@ -45,17 +45,22 @@ masks = torch.zeros(ns * mask_words * 2, dtype=torch.int64, device=dev)
 written = ctypes.c_int(0)
 zxp = ctypes.c_int(0)
 ZX = int(os.environ.get('MMX_FUSE', -1))
+PRE = os.environ.get('MMX_PREPACK', '1') == '1'
 for rep in range(a.reps + 1):
     if rep == 1:
         nat.timing_enable(True)
+    packed = False
+    if ZX in (-1, 6) and PRE and not a.generic:
+        packed = L.mmx_zx_pack(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, ws.data_ptr(), stream) == 0
     for i, s in enumerate(a.sigmas):
         R = k1.kernel_radius(s)
         w0 = k1.gaussian_half_kernel(s, 0, R); w2 = k1.gaussian_half_kernel(s, 2, R)
         nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                      nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, s * s,
                      log_base + i * nb * slot * 4, ws.data_ptr(), *(() if a.generic else ((masks.data_ptr() + i * mask_words * 16) if a.mask else None, 0.1 - 2e-5, 2e-5,
-                                                    ctypes.byref(written), ZX, ctypes.byref(zxp))), stream), "log")
-        assert not a.mask or written.value == 1
+                                                    ctypes.byref(written), (6 | 0x100) if packed else ZX, ctypes.byref(zxp))), stream), "log")
+        assert not a.mask or written.value in (1, 2)
+        layout = written.value
         if rep >= 1:
             t = nat.timing_read()
             for k, (ms, n) in t.items():
@@ -64,13 +69,13 @@ for rep in range(a.reps + 1):
     cap = 1 << 20
     table = torch.empty(cap * 48, dtype=torch.uint8, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
-    nat.check(L.mmx_peaks_batch(log_base, masks.data_ptr() if a.mask else None, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, 0.1, 2e-5,
+    nat.check(L.mmx_peaks_batch(log_base, masks.data_ptr() if a.mask else None, layout, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, 0.1, 2e-5,
                                 table.data_ptr(), cap, count.data_ptr(), stream), "peaks")
     if rep >= 1:
         t = nat.timing_read()
         res.setdefault(("peaks", ns), []).append(t["peaks"][0])
 torch.cuda.synchronize()
-alg = {"zpass": 10, "ypass": 16, "xpass": 12, "generic": 38 / 3, "zxpass": 10, "y2pass": 12}
+alg = {"zpass": 10, "ypass": 16, "xpass": 12, "generic": 38 / 3, "zxpass": 10, "y2pass": 12, "zxpack": 4}
 print(f"blocks {nb} x {e}^3 = {nvox/1e6:.0f} Mvox; candidates {int(count.item())}; zx path {zxp.value}")
 for (k, R), v in sorted(res.items()):
     ms = float(np.median(v))

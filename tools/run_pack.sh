@@ -1,0 +1,1 @@
+timeout 1700 python -m pytest tests -q -m gpu 2>&1 | tail -8
