@@ -134,9 +134,10 @@ def main():
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="z y x (default: the named config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--budget-gb", type=float, default=0.0,
-                    help="workspace budget per batch (default: 64 GiB, less when the free HBM of this rank's GPU "
-                         "does not allow it; larger batches are SLOWER: the host work of a batch is hidden "
-                         "behind the kernels of the next one, so the last batch should be small)")
+                    help="workspace budget per batch (default: 16 GiB = 22 blocks of the benchmark geometry, less when "
+                         "the free HBM of this rank's GPU does not allow it; larger batches are SLOWER: the host starts "
+                         "on a batch only when its kernels are done and its work is hidden behind the kernels of the "
+                         "next ones -- measured 157 / 161 / 165 / 170 ms per volume at 16 / 24 / 32 / 48 GiB)")
     ap.add_argument("--denoise", type=int, default=0, metavar="SIZE",
                     help="per-block preprocessing on (profile denoise_size) for c2 / c3; c5 has it at 25")
     ap.add_argument("--volume", default=None, metavar="NPY",
@@ -309,7 +310,7 @@ def main():
     else:
         free_b, _ = torch.cuda.mem_get_info()
         sharers = max(1, -(-world // max(1, torch.cuda.device_count()))) if backend != "nccl" else 1
-        budget = min(64 << 30, int(0.55 * free_b / sharers))
+        budget = min(16 << 30, int(0.55 * free_b / sharers))
     bl.blob_log_blocks = functools.partial(bl.blob_log_blocks, budget_bytes=budget)
 
     # ---------------- the HIP path on the CPU-baseline sample must give the identical table

@@ -291,6 +291,19 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
         batches.append(last[:cut])
         last = last[cut:]
     batches.append(last)
+    # ... and nothing hides the GPU time of the FIRST batch from the host, which has nothing to do until its
+    # candidates arrive: with the tiled kernels the host work per block (~0.5 ms) is as long as the kernels'
+    # (~0.55 ms), so a first batch of 89 blocks put the host 50 ms behind for the whole step (tail after the last
+    # kernel 24 - 38 ms).  The first batch is therefore split into a ramp of `MMX_RAMP`, 2 x, 4 x ... blocks.
+    ramp = int(os.environ.get("MMX_RAMP", 16))
+    first = batches[0]
+    if ramp > 0 and len(batches) > 1 and len(first) > 2 * ramp and sum(vox[i] for i in first) > (64 << 20):
+        head = []
+        while len(first) > 2 * ramp:
+            head.append(first[:ramp])
+            first = first[ramp:]
+            ramp *= 2
+        batches[0:1] = head + [first]
     return batches
 
 

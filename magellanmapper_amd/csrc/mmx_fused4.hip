@@ -76,6 +76,9 @@ namespace {
 #define ZX4_PF 3
 #endif
 constexpr int kPF4 = ZX4_PF;       // z tiles of voxels in flight per wave
+#ifndef ZX6_PF
+#define ZX6_PF 2
+#endif
 constexpr float kLoScale = 2048.f;
 constexpr float kLoInv = 1.f / 2048.f;
 
@@ -258,7 +261,11 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
 // stride_z = its elements per block) and P / Q leave as 16 x 16 tiles of 1 KiB (slot_elems = tile elements per
 // block), which y6_kernel (mmx_fused.hip) reads: every global access of a wave is then one contiguous KiB.
 template <int NKX, int LA, typename InT, bool TILED = false>
-__global__ void __launch_bounds__(256, 2)
+#ifdef ZX6_FAKE_LOADER
+__global__ void __launch_bounds__(320, 2)
+#else
+__global__ void __launch_bounds__(256, TILED && LA == 1 ? 3 : 2)      // (LA == 2 needs 170 registers: two waves per SIMD)
+#endif
 zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
            float* __restrict__ gp, float* __restrict__ gq,
@@ -267,14 +274,21 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     using cg = cls4<NKX, LA>;
     using pc = pieces4<InT>;
     constexpr int NKZ = cg::NKZ, NT = cg::NT;
+    // TILED, radius <= 16: the Z fragments of the interior z tiles live in LDS, shared by the workgroup's waves, and
+    // two z tiles are in flight instead of three: 154 registers, three waves per SIMD.  (Radius > 16 has three
+    // k-steps of Z fragments: fetching them from LDS every step costs more than the third wave gives.)
+    constexpr bool ZLDS = TILED && LA == 1;
+    constexpr int PF = ZLDS ? ZX6_PF : kPF4;         // z tiles of voxels in flight per wave
     const mmx_block bd = blocks[blockIdx.y];
     const int W = bd.nx, nz = bd.nz, px = bd.px;
     const int ntx = (W + 15) >> 4;
     // (readfirstlane: the wave index is uniform, but only this tells the compiler -- otherwise every buffer
     //  descriptor below is built per lane and each load becomes a waterfall loop)
-    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of this block: (y, column)
+    // TILED: workgroups are dealt to the 8 XCDs round robin; neighbours along x read overlapping windows, so the
+    // workgroups one XCD gets (every 8th) are made neighbours: its L2 then serves the overlap (gridDim.x % 8 == 0)
+    const int bx = TILED ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int gw = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of this block: (y, column)
     const int y = gw / ntx;
-    if (y >= bd.ny) return;                                   // whole wave (no barriers in this kernel)
     const int c = gw - y * ntx;
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, kq = lane >> 4;
@@ -282,6 +296,39 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     for (int i = 1; i < cfg.ncw; ++i) cw = cfg.wcls[i] == W ? i : cw;
     for (int i = 1; i < cfg.ncz; ++i) cz = cfg.zcls[i] == nz ? i : cz;
     const int ntz = (nz + 15) >> 4;
+    const int R = cfg.radius;
+    const int u_lo = (R + 15) >> 4;                             // first U with 16 U - R >= 0
+    const int u_hi = (nz - 16 - R) >> 4;                        // last U with 16 U + 15 + R <= nz - 1 (may be < u_lo)
+    const u4_4* zt = ztab + ((size_t)cz * cfg.maxu * NKZ * 2) * 128 + lane;
+    // (the steps at the ends of the block take their fragments straight from the table)
+    __shared__ u4_4 zl[ZLDS ? NKZ * 4 * 64 : 1];
+    if constexpr (ZLDS) {
+        const u4_4* zi = ztab + ((size_t)(cz * cfg.maxu + (u_lo < cfg.maxu ? u_lo : 0)) * NKZ * 2) * 128;
+        for (int e = threadIdx.x; e < NKZ * 4 * 64; e += 256) zl[e] = zi[e];
+        __syncthreads();
+    }
+#ifdef ZX6_FAKE_LOADER   // interference experiment: a fifth wave issues the workgroup's loads, nobody waits for them
+    if constexpr (TILED) if ((threadIdx.x >> 6) == 4) {
+        const int gw0 = bx * 4, y0 = gw0 / ntx, c0 = gw0 - y0 * ntx;
+        if (y0 >= bd.ny) return;
+        const rsrc4_t rl = make_rsrc4(vol + (int64_t)bd.slot * stride_z);
+        const int nch = (W + 7) >> 3;
+        int j0 = 2 * c0 - cg::R8 / 8;
+        u4_4 acc = {0u, 0u, 0u, 0u};
+        for (int t = 0; t < ntz; ++t) {
+            const unsigned so = (unsigned)((y0 * ntz + t) * nch) * 256u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int j = j0 + 4 * q + kq; j = j < 0 ? 0 : (j > nch - 1 ? nch - 1 : j);
+                const u4_4 v = __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(rl, (unsigned)(j * 256 + li * 16), so, 0));
+                acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
+            }
+        }
+        if (acc[0] == 0x12345678u && acc[3] == 0x9abcdef0u) gp[0] = 1.f;      // (keeps the loads alive)
+        return;
+    }
+#endif
+    if (y >= bd.ny) return;                                   // whole wave (no barriers below)
 
     // X fragments of this column: [m][kernel][piece]
     u4_4 xw[NKX][2][2];
@@ -295,13 +342,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 xw[m][k][1] = xt[(m * 2 + k) * 128 + 64];
             }
     }
-    // Z fragments: [ks][kernel][piece], of the z tile being produced (reloaded when its class changes)
-    u4_4 zw[NKZ][2][2];
-    const u4_4* zt = ztab + ((size_t)cz * cfg.maxu * NKZ * 2) * 128 + lane;
+    // Z fragments: [ks][kernel][piece], of the z tile being produced (reloaded when its class changes);
     // interior z tiles share one set: the first tile whose taps all fall inside the block
-    const int R = cfg.radius;
-    const int u_lo = (R + 15) >> 4;                             // first U with 16 U - R >= 0
-    const int u_hi = (nz - 16 - R) >> 4;                        // last U with 16 U + 15 + R <= nz - 1 (may be < u_lo)
+    u4_4 zw[ZLDS ? 1 : NKZ][2][2];
     int zset = -1;
 
     // voxel rows: plane z0 + li, chunk of 8 x at xl[m] (clamped into the block; the fragments know)
@@ -337,6 +380,11 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #endif
         if constexpr (TILED) {
             const unsigned so = (unsigned)((y * ntz + t) * nch8) * 256u;      // wave-uniform: the row tile
+#ifdef ZX6_FAKE_LOADER
+#pragma unroll
+            for (int m = 0; m < NKX; ++m) raw[m] = (u4_4){so + xoff[m], so * 3u, xoff[m] * 5u, so * 7u};
+            return;
+#endif
 #pragma unroll
             for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rin, xoff[m], so);
             return;
@@ -365,11 +413,19 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const unsigned row_b = (unsigned)px * 4u;
     // TILED: tile (c, U, y) of 16 z x 16 x floats, row-major, at ((c ntz + U) ny + y) KiB: the tiles of one (c, U)
     // follow each other along y, the direction y6_kernel marches in
+#ifdef ZX6_ORDER_CYU   // store-order experiment (breaks y6): a wave's tiles follow each other
+    const unsigned plane_b = TILED ? 64u : (unsigned)bd.ny * row_b;
+#else
     const unsigned plane_b = TILED ? (unsigned)bd.ny * 64u : (unsigned)bd.ny * row_b;
+#endif
 #ifdef ZX4_ROWS_Y
     unsigned obase = (unsigned)li * row_b + (unsigned)y * plane_b + (unsigned)(16 * c + 4 * kq) * 4u;
 #else
+#ifdef ZX6_ORDER_CYU
+    unsigned obase = TILED ? (unsigned)(((c * bd.ny + y) * ntz) * 1024 + (4 * li + kq) * 16)
+#else
     unsigned obase = TILED ? (unsigned)((c * ntz * bd.ny + y) * 1024 + (4 * li + kq) * 16)
+#endif
                            : (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
 #endif
 
@@ -378,9 +434,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // acknowledged by L2 -- measured, that wait and not the arithmetic set the step time (5.3 ms against 2.1 ms
     // without the stores).  With PF steps of distance the stores older than the tile being consumed have had
     // PF - 1 whole steps to complete.
-    typename pc::raw_t raw[kPF4][NKX];
+    typename pc::raw_t raw[PF][NKX];
 #pragma unroll
-    for (int u = 0; u < kPF4; ++u) load_tile(u < ntz ? u : ntz - 1, raw[u]);
+    for (int u = 0; u < PF; ++u) load_tile(u < ntz ? u : ntz - 1, raw[u]);
 
     // One march step: X pass of z tile t into the window, Z pass of z tile t - LA out of it.  STEADY = the
     // branch-free form for the tiles in the middle of the block (every tile real, interior Z fragments already
@@ -389,9 +445,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // Results on their way to memory: a store reads its data registers asynchronously, so the compiler makes the
     // next writer of those registers wait (vmcnt) until the store has completed.  Each ring slot therefore has
     // its own result registers, kept allocated (an empty asm "use") until the slot comes round again.
-    f4_4 outP[kPF4], outQ[kPF4];
+    f4_4 outP[PF], outQ[PF];
 #pragma unroll
-    for (int u = 0; u < kPF4; ++u) { outP[u] = (f4_4){0.f, 0.f, 0.f, 0.f}; outQ[u] = outP[u]; }
+    for (int u = 0; u < PF; ++u) { outP[u] = (f4_4){0.f, 0.f, 0.f, 0.f}; outQ[u] = outP[u]; }
     auto step = [&](int t, auto steady_tag, typename pc::raw_t (&rw)[NKX], f4_4& P, f4_4& Q) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         // shift the window by one z tile
@@ -408,8 +464,8 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             // the scheduler must not sink these loads to the end of the unrolled ring (it does, given the chance:
             // all of a ring's loads then sit right in front of their first use)
             __builtin_amdgcn_sched_barrier(0);
-            if (STEADY) load_tile(t + kPF4 < ntz ? t + kPF4 : ntz - 1, rw);
-            else if (t + kPF4 < ntz) load_tile(t + kPF4, rw);
+            if (STEADY) load_tile(t + PF < ntz ? t + PF : ntz - 1, rw);
+            else if (t + PF < ntz) load_tile(t + PF, rw);
             __builtin_amdgcn_sched_barrier(0);
             f4_4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
 #pragma unroll
@@ -446,8 +502,8 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         const int U = t - LA;
         if (STEADY || U >= 0) {
             // ---- Z pass of z tile U
-            if constexpr (!STEADY) {
-                const int want = (U >= u_lo && U <= u_hi) ? u_lo : U;
+            const int want = (U >= u_lo && U <= u_hi) ? u_lo : U;
+            if constexpr (!STEADY && !ZLDS) {
                 if (want != zset) {
                     zset = want;
 #pragma unroll
@@ -466,15 +522,26 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 const u4_4 al = {win[1][2 * ks][0], win[1][2 * ks][1], win[1][2 * ks + 1][0], win[1][2 * ks + 1][1]};
                 const u4_4 bh = {win[2][2 * ks][0], win[2][2 * ks][1], win[2][2 * ks + 1][0], win[2][2 * ks + 1][1]};
                 const u4_4 bl = {win[3][2 * ks][0], win[3][2 * ks][1], win[3][2 * ks + 1][0], win[3][2 * ks + 1][1]};
-                p0 = mfma16(ah, zw[ks][0][0], p0);
-                q0 = mfma16(bh, zw[ks][0][0], q0);
-                p1 = mfma16(ah, zw[ks][0][1], p1);
-                q1 = mfma16(bh, zw[ks][0][1], q1);
-                p1 = mfma16(al, zw[ks][0][0], p1);
-                q1 = mfma16(bl, zw[ks][0][0], q1);
-                q0 = mfma16(ah, zw[ks][1][0], q0);
-                q1 = mfma16(ah, zw[ks][1][1], q1);
-                q1 = mfma16(al, zw[ks][1][0], q1);
+                u4_4 z00, z01, z10, z11;          // [kernel][piece]
+                if constexpr (!ZLDS) {
+                    z00 = zw[ks][0][0]; z01 = zw[ks][0][1]; z10 = zw[ks][1][0]; z11 = zw[ks][1][1];
+                } else if constexpr (STEADY) {
+                    z00 = zl[(ks * 4 + 0) * 64 + lane]; z01 = zl[(ks * 4 + 1) * 64 + lane];
+                    z10 = zl[(ks * 4 + 2) * 64 + lane]; z11 = zl[(ks * 4 + 3) * 64 + lane];
+                } else {
+                    const u4_4* zp = zt + ((size_t)(want * NKZ + ks) * 2) * 128;
+                    z00 = zp[0]; z01 = zp[64]; z10 = zp[128]; z11 = zp[192];
+                }
+                p0 = mfma16(ah, z00, p0);
+                q0 = mfma16(bh, z00, q0);
+                p1 = mfma16(ah, z01, p1);
+                q1 = mfma16(bh, z01, q1);
+                p1 = mfma16(al, z00, p1);
+                q1 = mfma16(bl, z00, q1);
+                q0 = mfma16(ah, z10, q0);
+                q1 = mfma16(ah, z11, q1);
+                q1 = mfma16(al, z10, q1);
+                if constexpr (ZLDS && !STEADY) __builtin_amdgcn_sched_barrier(0);    // one k-step's fragments at a time
             }
 #ifdef ZX4_NO_STORE
             asm volatile("" ::"v"(p0), "v"(p1), "v"(q0), "v"(q1));
@@ -518,20 +585,20 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // tiles [0, tA): generic steps up to the first interior output tile (U = t - LA >= u_lo), rounded up to a
     // multiple of the ring; [tA, tB): steady steps (U in [u_lo, u_hi], t < ntz), whole rings; the rest generic.
     const int t_end = ntz + LA;
-    int tA = ((u_lo + LA + kPF4 - 1) / kPF4) * kPF4;
+    int tA = ((u_lo + LA + PF - 1) / PF) * PF;
     int nB = (u_hi + LA + 1 < ntz ? u_hi + LA + 1 : ntz) - tA;       // steady steps available
-    nB = nB > 0 ? (nB / kPF4) * kPF4 : 0;
-    if (tA > t_end) tA = ((t_end + kPF4 - 1) / kPF4) * kPF4;
+    nB = nB > 0 ? (nB / PF) * PF : 0;
+    if (tA > t_end) tA = ((t_end + PF - 1) / PF) * PF;
     const int tB = tA + nB;
 #pragma unroll 1
-    for (int t0 = 0; t0 < tA; t0 += kPF4) {
+    for (int t0 = 0; t0 < tA; t0 += PF) {
 #pragma unroll
-        for (int u = 0; u < kPF4; ++u)
+        for (int u = 0; u < PF; ++u)
             if (t0 + u < t_end) step(t0 + u, std::false_type{}, raw[u], outP[u], outQ[u]);
     }
     if (nB > 0) {
         // interior Z fragments (the generic steps may have left an edge set in the registers)
-        if (zset != u_lo) {
+        if (!ZLDS && zset != u_lo) {
             zset = u_lo;
 #pragma unroll
             for (int ks = 0; ks < NKZ; ++ks)
@@ -545,15 +612,15 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         // at their first use, would be a static vmcnt(N) that in steady state waits for the previous step's stores
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 #pragma unroll 1
-        for (int t0 = tA; t0 < tB; t0 += kPF4) {
+        for (int t0 = tA; t0 < tB; t0 += PF) {
 #pragma unroll
-            for (int u = 0; u < kPF4; ++u) step(t0 + u, std::true_type{}, raw[u], outP[u], outQ[u]);
+            for (int u = 0; u < PF; ++u) step(t0 + u, std::true_type{}, raw[u], outP[u], outQ[u]);
         }
     }
 #pragma unroll 1
-    for (int t0 = tB; t0 < t_end; t0 += kPF4) {
+    for (int t0 = tB; t0 < t_end; t0 += PF) {
 #pragma unroll
-        for (int u = 0; u < kPF4; ++u)
+        for (int u = 0; u < PF; ++u)
             if (t0 + u < t_end) step(t0 + u, std::false_type{}, raw[u], outP[u], outQ[u]);
     }
 }
@@ -922,11 +989,34 @@ zx6_pack_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const int y = yt / ntz, t = yt - y * ntz;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const InT* src = vol + bd.src_off + (int64_t)y * stride_y;
+    // rows that start on 8-byte boundaries (the usual case: block origins on multiples of 4 voxels): 4 voxels per
+    // lane and load; the last, partial group of a row and everything else one voxel at a time
+    bool quads = false;
+    if constexpr (sizeof(InT) == 2)
+        quads = stride_x == 1 && ((bd.src_off | stride_y | stride_z) & 3) == 0 && (reinterpret_cast<uintptr_t>(vol) & 7) == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 4 * wave + i, z = 16 * t + r;
-        for (int x = lane; x < 8 * nch8; x += 64)
-            tile[r][x] = (z < bd.nz && x < bd.nx) ? (uint16_t)src[(int64_t)z * stride_z + (int64_t)x * stride_x] : (uint16_t)0;
+        if (z >= bd.nz) {
+            for (int x = lane * 4; x < 8 * nch8; x += 256) *reinterpret_cast<u2_4*>(&tile[r][x]) = (u2_4){0u, 0u};
+        } else if (quads) {
+            const InT* row = src + (int64_t)z * stride_z;
+            for (int x = lane * 4; x < 8 * nch8; x += 256) {
+                u2_4 v = {0u, 0u};
+                if (x + 3 < bd.nx) {
+                    v = *reinterpret_cast<const u2_4*>(row + x);
+                } else {
+                    unsigned e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = x + j < bd.nx ? (unsigned)row[x + j] : 0u;
+                    v = (u2_4){e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+                }
+                *reinterpret_cast<u2_4*>(&tile[r][x]) = v;
+            }
+        } else {
+            for (int x = lane; x < 8 * nch8; x += 64)
+                tile[r][x] = x < bd.nx ? (uint16_t)src[(int64_t)z * stride_z + (int64_t)x * stride_x] : (uint16_t)0;
+        }
     }
     __syncthreads();
     u4_4* dst = reinterpret_cast<u4_4*>(pack + (int64_t)bd.slot * pack_stride) + (int64_t)yt * nch8 * 16;
@@ -974,8 +1064,12 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     u4_4* xtab = reinterpret_cast<u4_4*>(w + plan.tab_off);
     u4_4* ztab = reinterpret_cast<u4_4*>(w + plan.tab_off + xbytes);
     hipLaunchKernelGGL((zx4_setup<NKX, LA>), dim3((nx_entries + nz_entries + 3) / 4), dim3(256), 0, s, cfg, xtab, ztab);
-    dim3 grid((max_waves + 3) / 4, n_blocks);
+    dim3 grid((((max_waves + 3) / 4) + 7) & ~7, n_blocks);        // (a multiple of 8: the XCD-aware order in the kernel)
+#ifdef ZX6_FAKE_LOADER
+    hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true>), grid, dim3(320), 0, s,
+#else
     hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true>), grid, dim3(256), 0, s,
+#endif
                        reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
                        plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
                        xtab, ztab, cfg);

@@ -13,6 +13,7 @@ from magellanmapper_amd import blob_log as bl, config, detector, stack_detect, s
 ap = argparse.ArgumentParser()
 ap.add_argument("--budget-gb", type=float, default=64.0)
 ap.add_argument("--keep-heap", action="store_true", help="mallopt: big arrays from the heap, freed memory stays mapped")
+ap.add_argument("--profile", action="store_true", help="cProfile one more step: where the host time goes")
 a = ap.parse_args()
 if a.keep_heap:
     from magellanmapper_amd import _native
@@ -83,3 +84,12 @@ ts = []
 for _ in range(5):
     torch.cuda.synchronize(); t = time.perf_counter(); step(); ts.append((time.perf_counter() - t) * 1e3)
 print("5 more steps (ms):", ["%.1f" % v for v in ts])
+
+if a.profile:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable(); step(); pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)
+    st.sort_stats("cumulative").print_stats(45)
