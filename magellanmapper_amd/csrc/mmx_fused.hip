@@ -200,10 +200,10 @@ int launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slo
 }
 
 // ---------------------------------------------------------------- Y pass on tiled (P, Q)  (zx_mode 6)
-// Same arithmetic, other geometry: P and Q arrive as 16 z x 16 x tiles of 1 KiB, the tiles of one (column tile c,
-// z tile U) following each other along y (mmx_fused4.hip: zx4_kernel<.., TILED>).  A workgroup owns one (c, U);
-// each of its four waves marches along y over 4 planes x 16 columns of it: one contiguous 256-byte piece per
-// array and step, the next one a KiB further on.  The LoG cube stays row-major (the NMS and re-scoring kernels
+// Same arithmetic, other geometry: P and Q arrive as 16 z x 16 x tiles of 1 KiB in (y, c, U) order
+// (mmx_fused4.hip: zx4_kernel<.., TILED>).  A workgroup owns one (column tile c, z tile U); each of its four waves
+// marches along y over 4 planes x 16 columns of it: one contiguous 256-byte piece per array and step, the next
+// one ntx ntz KiB further on -- at any time the workgroups of a block read inside the same few hundred KiB.  The LoG cube stays row-major (the NMS and re-scoring kernels
 // read single voxels from it): a wave stores four 64-byte row pieces, and only where something is above the
 // threshold.  NMS entries: per row y one entry per (4 planes, 16 columns) = this wave's footprint,
 // index y * (nzq * ntx) + (z >> 2) * ntx + (x >> 4), bit ((z & 3) << 4) | (x & 15)  (mmx_peaks.hip: layout 2).
@@ -228,8 +228,9 @@ y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     const int z = 16 * U + 4 * zq + (lane >> 4), x = 16 * c + xi;
     const int n = bd.ny;
     const bool real = z < bd.nz && x < bd.nx;
-    const float* i1 = gp + (int64_t)bd.slot * tile_stride + (int64_t)tile * n * 256;
-    const float* i2 = gq + (int64_t)bd.slot * tile_stride + (int64_t)tile * n * 256;
+    const float* i1 = gp + (int64_t)bd.slot * tile_stride + (int64_t)tile * 256;
+    const float* i2 = gq + (int64_t)bd.slot * tile_stride + (int64_t)tile * 256;
+    const unsigned trow_b = (unsigned)(ntx * ntz) * 1024u;      // bytes from one y to the next
     float* w1 = out + (int64_t)bd.slot * slot_elems;
     const unsigned voff = (unsigned)(zq * 64 + lane) * 4u;                          // inside a tile
     // (lanes past the block keep an in-range address: they never store)
@@ -247,24 +248,24 @@ y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     v2f r[M];     // (P, Q) window
 #pragma unroll
     for (int j = -R; j < R + kPrefetch; ++j) {
-        const unsigned row = (unsigned)reflect_once(j, n) * 1024u;
+        const unsigned row = (unsigned)reflect_once(j, n) * trow_b;
         r[(j + M) % M] = (v2f){__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, row, 0)),
                                __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, row, 0))};
     }
     const unsigned row_b = (unsigned)bd.px * 4u;
-    unsigned qoff = (unsigned)(R + kPrefetch) * 1024u;      // next tile to load (bytes)
+    unsigned qoff = (unsigned)(R + kPrefetch) * trow_b;     // next tile to load (bytes)
     unsigned woff = 0;                                      // row being written
     auto step = [&](int s, auto reflecting, int y) __attribute__((always_inline)) {
         float n1, n2;
         if constexpr (decltype(reflecting)::value) {
-            const unsigned rnext = (unsigned)reflect_once(y + R + kPrefetch, n) * 1024u;
+            const unsigned rnext = (unsigned)reflect_once(y + R + kPrefetch, n) * trow_b;
             n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, rnext, 0));
             n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, rnext, 0));
         } else {
             n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, qoff, 0));
             n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, qoff, 0));
         }
-        qoff += 1024u;
+        qoff += trow_b;
         v2f a2 = r[s] * taps.w[0];
         v2f b2 = (r[(s - 1 + M) % M] + r[(s + 1) % M]) * taps.w[1];
 #pragma unroll

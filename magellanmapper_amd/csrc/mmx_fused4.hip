@@ -259,7 +259,8 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
 
 // TILED (zx_mode 6): the voxels come from the operand-ordered copy zx6_pack_kernel leaves (`vol` = that copy,
 // stride_z = its elements per block) and P / Q leave as 16 x 16 tiles of 1 KiB (slot_elems = tile elements per
-// block), which y6_kernel (mmx_fused.hip) reads: every global access of a wave is then one contiguous KiB.
+// block) in (y, c, U) order, which y6_kernel (mmx_fused.hip) reads: every global access of a wave is then one
+// contiguous KiB.
 template <int NKX, int LA, typename InT, bool TILED = false>
 #ifdef ZX6_FAKE_LOADER
 __global__ void __launch_bounds__(320, 2)
@@ -411,21 +412,16 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
     const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
     const unsigned row_b = (unsigned)px * 4u;
-    // TILED: tile (c, U, y) of 16 z x 16 x floats, row-major, at ((c ntz + U) ny + y) KiB: the tiles of one (c, U)
-    // follow each other along y, the direction y6_kernel marches in
-#ifdef ZX6_ORDER_CYU   // store-order experiment (breaks y6): a wave's tiles follow each other
+    // TILED: tile (y, c, U) of 16 z x 16 x floats, row-major, at ((y ntx + c) ntz + U) KiB: what a wave writes
+    // during its march is contiguous, the waves of a workgroup and the workgroups of a row follow each other --
+    // the kernel's stores are one sequential stream -- and y6_kernel's workgroups, one per (c, U), all read inside
+    // the same ntx ntz KiB at any time.  (Measured against the (c, U, y) order: no difference in either kernel; both
+    // run at the request rate the memory system sustains)
     const unsigned plane_b = TILED ? 64u : (unsigned)bd.ny * row_b;
-#else
-    const unsigned plane_b = TILED ? (unsigned)bd.ny * 64u : (unsigned)bd.ny * row_b;
-#endif
 #ifdef ZX4_ROWS_Y
     unsigned obase = (unsigned)li * row_b + (unsigned)y * plane_b + (unsigned)(16 * c + 4 * kq) * 4u;
 #else
-#ifdef ZX6_ORDER_CYU
-    unsigned obase = TILED ? (unsigned)(((c * bd.ny + y) * ntz) * 1024 + (4 * li + kq) * 16)
-#else
-    unsigned obase = TILED ? (unsigned)((c * ntz * bd.ny + y) * 1024 + (4 * li + kq) * 16)
-#endif
+    unsigned obase = TILED ? (unsigned)(((y * ntx + c) * ntz) * 1024 + (4 * li + kq) * 16)
                            : (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
 #endif
 

@@ -1,5 +1,2 @@
-timeout 1700 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-for b in 16 24; do
-timeout 300 python bench.py --no-cpu-baseline --steps 6 --warmup 2 --budget-gb $b 2>/dev/null | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print($b, d['ms_per_step'], d['value'], d['table_sha1'][:8], {k:v['ms_per_step'] for k,v in d['kernels'].items()})"
-done
+MMX_FUSE=6 timeout 200 python tools/kbench.py --blocks 64 --mask --sigmas 3 3.5 4 4.5 5 2>&1 | grep -E "zx path|zxpass|zxpack|y2pass"
+ZX_CHECK_MODE=6 timeout 600 python tools/zx4_check.py 2>&1 | tail -1
