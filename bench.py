@@ -425,11 +425,14 @@ def main():
         if dom:
             launches = ktimes[dom][1]
             roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"],
-                    "note": ("zxpass = fused Z+X pass: its 10 algorithmic B/voxel/sigma replace the 22 of the separate "
-                             "Z and X passes; it is bound by packed-fp32 VALU issue and by the latency of its per-row "
-                             "loads, not by HBM (DESIGN.md section 4b); the HBM-bound Y pass of the step runs at "
+                    "note": ("zxpass = fused Z+X pass on the matrix cores (zx_mode 6, tiled): its 10 algorithmic "
+                             "B/voxel/sigma replace the 22 of the separate Z and X passes (+ 0.8 B/voxel/sigma for the "
+                             "operand-ordered voxel copy, 'zxpack', made once per batch).  Its MFMAs are hidden: with "
+                             "them removed the kernel takes the same time; what bounds it is the rate at which the "
+                             "memory system takes its 64-byte write requests with ~80 requests in flight per CU "
+                             "(DESIGN.md section 4b).  The Y pass of the step runs at "
                              f"{stream_k.get('y2pass', {}).get('alg_GBps', 0) / HBM_PEAK_GBS:.2f} of peak on its "
-                             "algorithmic bytes, see 'kernels' and 'pipeline_roofline' for the whole step")
+                             "algorithmic bytes; see 'kernels' and 'pipeline_roofline' for the whole step")
                     if dom == "zxpass" else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),

@@ -21,9 +21,11 @@ def load_counter(d, counter):
 def short(name):
     if "pp_fast_kernel" in name or "pp_generic_kernel" in name or "pp_mid_kernel" in name:
         return "preproc"
-    if "zx2_kernel" in name or "zx_kernel" in name:
+    if "zx6_pack_kernel" in name:
+        return "zxpack"
+    if "zx2_kernel" in name or "zx_kernel" in name or "zx4_kernel" in name:
         return "zxpass"
-    if "y2_kernel" in name:
+    if "y2_kernel" in name or "y6_kernel" in name:
         return "y2pass"
     if "peaks_sparse_kernel" in name:
         return "peaks"
@@ -56,17 +58,17 @@ for k, (rb, wb) in known.items():
 # access shape -> calibration stream
 read_cal = {"zpass": cal["calib_read_u16"][0], "ypass": cal["calib_copy_b32"][0],
             "xpass": cal["calib_copy_b128"][0], "peaks": cal["calib_copy_b128"][0],
-            "preproc": cal["calib_read_u16"][0], "zxpass": cal["calib_read_u16"][0],
-            "y2pass": cal["calib_copy_b32"][0]}
+            "preproc": cal["calib_read_u16"][0], "zxpass": cal["calib_copy_b128"][0],     # tiled path: 16 B per lane
+            "zxpack": cal["calib_read_u16"][0], "y2pass": cal["calib_copy_b32"][0]}
 write_cal = {"zpass": cal["calib_copy_b32"][1], "ypass": cal["calib_copy_b32"][1],
              "xpass": cal["calib_copy_b128"][1], "peaks": cal["calib_copy_b128"][1],
              "preproc": cal["calib_copy_b32"][1], "zxpass": cal["calib_copy_b128"][1],
-             "y2pass": cal["calib_copy_b32"][1]}
+             "zxpack": cal["calib_copy_b128"][1], "y2pass": cal["calib_copy_b32"][1]}
 f, fc = per_kernel(load_counter(os.path.join(root, "pmc_fetch"), "FETCH_SIZE"))
 w, wc = per_kernel(load_counter(os.path.join(root, "pmc_write"), "WRITE_SIZE"))
 res = {}
 print("per-kernel HBM traffic per launch (calibrated):")
-for k in ("preproc", "zxpass", "y2pass", "zpass", "ypass", "xpass", "peaks"):
+for k in ("preproc", "zxpack", "zxpass", "y2pass", "zpass", "ypass", "xpass", "peaks"):
     if not fc[k]:
         continue
     rd = f[k] / fc[k] * read_cal[k]
