@@ -727,3 +727,99 @@ def test_a_band_narrower_than_the_float32_error_widens_itself(gpu, monkeypatch):
                              int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]), stats=stats)[0]
     assert stats.n_band_retries >= 1 and stats.n_blocks == 1
     np.testing.assert_array_equal(got, g["pruned"])
+
+
+def _abi_batch(vol, origins, shapes, sigmas, zx_mode, prepack, thr=0.1, eps=2e-5):
+    """One batch straight through the C ABI: ``(path, mask layout, candidates sorted, LoG cubes)``."""
+    import ctypes
+    import torch
+    from magellanmapper_amd import _native as nat, blob_log as bl, kernels1d as k1
+    L = nat.lib()
+    dvol = bl.DeviceVolume(vol)
+    dev = dvol.tensor.device
+    blocks, slot = bl._make_blocks(dvol, 0, origins, shapes)
+    nb, ns = len(blocks), len(sigmas)
+    ws = torch.zeros((4 + ns) * nb * slot, dtype=torch.float32, device=dev)
+    d_blocks = bl._to_device_bytes(blocks, dev)
+    v32 = dvol.view(0, True)
+    stream = torch.cuda.current_stream().cuda_stream
+    log_base = ws.data_ptr() + 4 * nb * slot * 4
+    mask_words = (nb * slot) >> 5
+    masks = torch.zeros(ns * mask_words * 2, dtype=torch.int64, device=dev)
+    written, path = ctypes.c_int(0), ctypes.c_int(0)
+    mode = zx_mode
+    if prepack:
+        nat.check(L.mmx_zx_pack(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, ws.data_ptr(),
+                                stream), "mmx_zx_pack")
+        mode = nat.MMX_ZX_TILED | nat.MMX_ZX_PREPACKED
+    layouts, paths = set(), set()
+    for i, s in enumerate(sigmas):
+        R = k1.kernel_radius(s)
+        w0, w2 = k1.gaussian_half_kernel(s, 0, R), k1.gaussian_half_kernel(s, 2, R)
+        nat.check(L.mmx_log_batch_f32(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
+                                      nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, s * s,
+                                      log_base + i * nb * slot * 4, ws.data_ptr(), masks.data_ptr() + i * mask_words * 16,
+                                      thr - eps, eps, ctypes.byref(written), mode, ctypes.byref(path), stream), "log")
+        layouts.add(written.value)
+        paths.add(path.value)
+    assert len(layouts) == 1 and len(paths) == 1
+    cap = 1 << 16
+    table = torch.zeros(cap * nat.CAND_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    layout = layouts.pop()
+    nat.check(L.mmx_peaks_batch(log_base, masks.data_ptr(), layout, ns, d_blocks.data_ptr(), blocks.ctypes.data, nb,
+                                slot, thr, eps, table.data_ptr(), cap, count.data_ptr(), stream), "peaks")
+    torch.cuda.synchronize()
+    n = int(count.item())
+    assert 0 < n <= cap
+    c = table[:n * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
+    key = np.stack([c["slot"], c["s"], c["z"], c["y"], c["x"]], axis=1).astype(np.int64)
+    order = np.lexsort(key.T[::-1])
+    return paths.pop(), layout, key[order], c["v"][order], c["flags"][order]
+
+
+def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
+    """``zx_mode`` 6 straight through ``include/mmx.h``: it reports the quad entry layout, ``mmx_peaks_batch`` finds
+    exactly the candidates it finds from the packed kernel's row entries (same voxels, same flags, float32 values
+    within rounding), and the voxel copy made once by ``mmx_zx_pack`` (``MMX_ZX_PREPACKED``) gives bit-identical
+    candidates to the copy every call makes itself.  Ragged blocks of different widths and depths in one batch."""
+    from magellanmapper_amd import _native as nat, synth
+    vol = synth.make_volume(5, (70, 90, 150), 40)
+    origins = [(0, 0, 0), (3, 5, 64), (20, 11, 7)]
+    shapes = [(70, 90, 64), (67, 85, 86), (50, 61, 37)]
+    sig = [3.0, 3.5, 4.0]
+    p2, l2, k2, v2, f2 = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_PACKED, False)
+    p6, l6, k6, v6, f6 = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED, False)
+    p6p, l6p, k6p, v6p, f6p = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED, True)
+    pa, la, ka, va, fa = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_AUTO, False)
+    assert (p2, l2) == (nat.MMX_ZX_PACKED, nat.MMX_MASK_ROWS)
+    assert (p6, l6) == (p6p, l6p) == (pa, la) == (nat.MMX_ZX_TILED, nat.MMX_MASK_QUADS)
+    assert len(k2) >= 40
+    assert np.array_equal(k2, k6) and np.array_equal(f2, f6)
+    assert np.max(np.abs(v2 - v6)) < 2e-6
+    assert np.array_equal(k6, k6p) and np.array_equal(v6, v6p) and np.array_equal(f6, f6p)
+    assert np.array_equal(k6, ka) and np.array_equal(v6, va)
+
+
+def test_zx_pack_refuses_what_the_tiled_path_cannot_take(gpu):
+    """Float voxels have no exact float16 split: ``mmx_zx_pack`` says unsupported (nothing written) and the log call
+    falls back to the packed kernel and its row entries."""
+    import ctypes
+    import torch
+    from magellanmapper_amd import _native as nat, blob_log as bl, synth
+    vol = (synth.make_volume(2, (40, 48, 64), 10) / 65535.0).astype(np.float32)
+    dvol = bl.DeviceVolume(vol)
+    blocks, slot = bl._make_blocks(dvol, 0, [(0, 0, 0)], [vol.shape])
+    ws = torch.zeros(5 * slot, dtype=torch.float32, device=dvol.tensor.device)
+    d_blocks = bl._to_device_bytes(blocks, dvol.tensor.device)
+    v32 = dvol.view(0, True)
+    rc = nat.lib().mmx_zx_pack(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, 1, slot, ws.data_ptr(), None)
+    assert rc == 5                                  # MMX_ERR_UNSUPPORTED
+    assert nat.lib().mmx_zx_pack(None, None, None, 1, slot, None, None) == 1      # MMX_ERR_ARG
+    space = bl.ScaleSpace.make(3.0, 3.0, 1)
+    default, bl.ZX_MODE = bl.ZX_MODE, nat.MMX_ZX_TILED
+    try:
+        bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [vol.shape], space)
+        assert bl.LAST_ZX_PATH == nat.MMX_ZX_PACKED
+    finally:
+        bl.ZX_MODE = default

@@ -586,3 +586,17 @@ def test_native_assignment_solver_returns_scipys_optimum():
         np.testing.assert_array_equal(rows, want[0])
         np.testing.assert_array_equal(cols, want[1])
     assert _native.lib().mmx_host_lsap(np.array([[np.nan]]).ctypes.data, 1, 1, None, None) == 1
+
+
+def test_plan_batches_ramp_and_taper():
+    """Batches of a full volume: the first budget-sized batch is split into a ramp (the host has nothing to do until
+    the first candidates arrive), the last into a taper (nothing hides the host work of the last batch); every block
+    once, in order."""
+    from magellanmapper_amd import blob_log as bl
+    shapes = [(261, 261, 261)] * 256
+    b = bl.plan_batches(shapes, 5, 64 << 30)
+    assert [len(x) for x in b] == [16, 32, 41, 89, 39, 20, 10, 5, 4]
+    assert sum(b, []) == list(range(256))
+    b = bl.plan_batches(shapes, 5, 16 << 30)
+    assert sum(b, []) == list(range(256)) and max(len(x) for x in b) == 22 and len(b[-1]) <= 8
+    assert [len(x) for x in bl.plan_batches([(40, 40, 40)] * 9, 3, 1 << 30)] == [9]      # tiny blocks: one batch
