@@ -76,7 +76,10 @@ typedef struct {
 } mmx_volume;
 
 /* Scale-space candidate (A4).  48 bytes.  `flags` bit 0: contested -- within eps of
- * a neighbour or of the threshold, the float64 value must decide. */
+ * a neighbour or of the threshold, the float64 value must decide.  Bit 1 (MMX_CAND_BAND, set by the sparse NMS):
+ * `band` bit j / `flags` bit 16 + (j - 64) tells whether neighbour j of the 80 (C order of (ds, dz, dy, dx) over
+ * {-1, 0, 1}^4, the centre left out) has a float32 value within eps below the candidate's or above it -- the
+ * only neighbours whose exact values can decide a contested candidate. */
 typedef struct {
     int32_t slot;      /* block slot in the batch          */
     int32_t s;         /* sigma index                      */
@@ -85,10 +88,11 @@ typedef struct {
     float v;           /* float32 scale-normalised -LoG    */
     float nbr_max;     /* float32 max over the 80 neighbours, 0-padded outside the cube */
     double v64;        /* exact float64 value (filled by mmx_rescore_f64), NaN before   */
-    double _reserved;
+    uint64_t band;     /* with MMX_CAND_BAND: neighbours 0..63 in the band (64..79: flags bits 16..31) */
 } mmx_cand;
 
 #define MMX_CAND_CONTESTED 1u
+#define MMX_CAND_BAND 2u
 
 /* ---- library / device ---------------------------------------------------- */
 int mmx_abi_version(void);
@@ -124,7 +128,9 @@ int mmx_device_count(void);
  *                MMX_ZX_AUTO (default): the fastest kernel that takes the geometry (MMX_ZX_TILED for integer
  *                voxels, else MMX_ZX_PACKED, else the separate passes); the others exist for cross-checks and
  *                measurements.  All agree within float32 rounding, and the peak decisions are taken on exact
- *                float64 values either way (mmx_rescore_f64).  MMX_ZX_TILED works from an operand-ordered copy of
+ *                float64 values either way (mmx_rescore_f64).  With entries requested and nms_eps at least four times
+ *                mmx_tiled_q16_error_bound(), AUTO hands the intermediates over as 16-bit fixed point
+ *                (MMX_ZX_TILED_Q16).  MMX_ZX_TILED works from an operand-ordered copy of
  *                the blocks' voxels inside d_work, which does not depend on sigma: mmx_zx_pack makes it once per
  *                batch, and MMX_ZX_TILED | MMX_ZX_PREPACKED then skips making it again for every sigma.
  *   h_zx_path  : optional out (host): the MMX_ZX_* kernel this call actually ran (MMX_ZX_SEPARATE when the
@@ -137,10 +143,13 @@ typedef enum {
     MMX_ZX_MFMA_F16 = 4,  /* zx4_kernel: X+Z on v_mfma_f32_16x16x32_f16 with split-float16 operands,
                              register resident (integer voxels; measured experiment)                       */
     MMX_ZX_MFMA_F16_LDS = 5,/* zx5_kernel: the same arithmetic, voxels and results staged through LDS      */
-    MMX_ZX_TILED = 6      /* zx4's arithmetic on an operand-ordered copy of the voxels (zx6_pack_kernel), P / Q
+    MMX_ZX_TILED = 6,     /* zx4's arithmetic on an operand-ordered copy of the voxels (zx6_pack_kernel), P / Q
                              handed to the Y pass (y6_kernel) as 16 x 16 tiles: every access one contiguous KiB */
+    MMX_ZX_TILED_Q16 = 7  /* the same with the tiles as 16-bit fixed point (half the intermediate bytes): the LoG
+                             values carry a rounding error of at most mmx_tiled_q16_error_bound(); AUTO picks it
+                             only when entries are asked for with nms_eps >= 4 x that bound                     */
 } mmx_zx_mode;
-#define MMX_ZX_PREPACKED 0x100   /* or-ed into MMX_ZX_TILED: mmx_zx_pack ran on this d_work for these blocks */
+#define MMX_ZX_PREPACKED 0x100   /* or-ed into MMX_ZX_TILED / MMX_ZX_TILED_Q16: mmx_zx_pack ran on this d_work for these blocks */
 #define MMX_MASK_ROWS 1
 #define MMX_MASK_QUADS 2
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
@@ -148,6 +157,12 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
                       const double* h_w0, const double* h_w2, int radius, double norm,
                       float* d_log, float* d_work, uint64_t* d_nms_mask, float nms_lo, float nms_eps,
                       int* h_mask_written, int zx_mode, int* h_zx_path, void* stream);
+
+/* Largest deviation of an MMX_ZX_TILED_Q16 LoG value from the float32 paths' (which are within a few 1e-7 of the
+ * exact value), in units of the image's value scale, for voxels in [0, 1] (uint8 / uint16 after img_as_float): a
+ * function of the weights alone (3.7e-5 for any sigma).  A true maximum is nominated as long as the NMS band is four
+ * times this (mmx_rescore_f64 then decides on exact values as always).  < 0 on bad arguments. */
+double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm);
 
 /* The sigma-independent part of MMX_ZX_TILED: the operand-ordered copy of the blocks' voxels, written into the
  * part of d_work (same pointer, blocks and slot_elems as the mmx_log_batch_f32 calls that follow) that the tiled

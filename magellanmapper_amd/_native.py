@@ -22,9 +22,10 @@ MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
 MMX_CAND_CONTESTED = 1
+MMX_CAND_BAND = 2
 #: ``mmx_zx_mode``: how mmx_log_batch_f32 runs its Z and X passes (a per-call argument)
 MMX_ZX_AUTO, MMX_ZX_SEPARATE, MMX_ZX_PACKED, MMX_ZX_MFMA_F32, MMX_ZX_MFMA_F16, MMX_ZX_MFMA_F16_LDS = -1, 0, 2, 3, 4, 5
-MMX_ZX_TILED, MMX_ZX_PREPACKED = 6, 0x100
+MMX_ZX_TILED, MMX_ZX_TILED_Q16, MMX_ZX_PREPACKED = 6, 7, 0x100
 #: NMS entry layouts ``mmx_log_batch_f32`` reports and ``mmx_peaks_batch`` takes
 MMX_MASK_ROWS, MMX_MASK_QUADS = 1, 2
 
@@ -35,7 +36,7 @@ MMX_ROW_ALIGN = 32
 #: NumPy mirror of ``mmx_cand`` (48 bytes).
 CAND_DTYPE = np.dtype([("slot", "<i4"), ("s", "<i4"), ("z", "<i4"), ("y", "<i4"), ("x", "<i4"),
                        ("flags", "<u4"), ("v", "<f4"), ("nbr_max", "<f4"), ("v64", "<f8"),
-                       ("_reserved", "<f8")], align=True)
+                       ("band", "<u8")], align=True)
 assert BLOCK_DTYPE.itemsize == 32 and CAND_DTYPE.itemsize == 48
 #: NumPy mirrors of ``mmx_subblock`` (40 bytes), ``mmx_quantile_class`` (32), ``mmx_subblock_info`` (32)
 SUBBLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("scratch_off", "<i8"),
@@ -75,7 +76,7 @@ _lib = None
 #: every symbol ``include/mmx.h`` declares
 SYMBOLS = (
     "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
-    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_zx_pack", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
+    "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_zx_pack", "mmx_tiled_q16_error_bound", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
@@ -111,6 +112,8 @@ def lib() -> ctypes.CDLL:
     L.mmx_workspace_bytes.argtypes = [c_int, c_int64, c_int, c_int]
     L.mmx_workspace_bytes.restype = ctypes.c_size_t
     L.mmx_zx_pack.argtypes = [POINTER(Volume), vp, vp, c_int, c_int64, vp, vp]
+    L.mmx_tiled_q16_error_bound.argtypes = [POINTER(c_double), POINTER(c_double), c_int, c_double]
+    L.mmx_tiled_q16_error_bound.restype = c_double
     L.mmx_peaks_batch.argtypes = [vp, vp, c_int, c_int, vp, vp, c_int, c_int64, c_float, c_float, vp,
                                   c_uint32, vp, vp]
     L.mmx_rescore_f64.argtypes = [POINTER(Volume), vp, c_int, vp, c_uint32, vp, vp, vp,

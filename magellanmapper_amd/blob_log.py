@@ -57,7 +57,10 @@ except Exception as exc:  # pragma: no cover
                       "order in chained overlap prunes") from exc
 
 #: half-width of the float32 "contested" band, relative to the input's value scale
-EPS_REL = 2e-5
+EPS_REL = float(os.environ.get("MMX_EPS_REL", 2e-5))
+#: the band for raw integer volumes, whose default kernels hand the Z+X results to the Y pass as 16-bit fixed point
+#: (``MMX_ZX_TILED_Q16``: rounding error <= 3.7e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
+EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2e-4))
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
@@ -449,6 +452,9 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     peaks_out: List[Optional[Tuple[np.ndarray, np.ndarray]]] = [None] * len(shapes)
     bufs = _buffers_for(dvol.tensor.device)
     eps = EPS_REL * (dvol.value_scale() if pre is None else pre.value_scale([channel]))
+    if (pre is None and dvol.np_dtype in (np.uint8, np.uint16) and EPS_REL_Q16 > EPS_REL
+            and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)):
+        eps = EPS_REL_Q16 * dvol.value_scale()
     d_w0 = torch.from_numpy(space.w0_tab).to(dvol.tensor.device)
     d_w2 = torch.from_numpy(space.w2_tab).to(dvol.tensor.device)
     batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
@@ -538,7 +544,14 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
         # once here, trusted by the calls below for as long as every call so far ran the tiled path (any other
         # path uses the same part of the workspace for something else)
         packed = False
-        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED):
+        tiled_mode = nat.MMX_ZX_TILED
+        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16):
+            # 16-bit intermediates when the band covers their rounding error fourfold (or when asked for by name)
+            bound = max(float(L.mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
+                                                          int(space.radii[s]), float(space.norms[s]))) for s in range(ns))
+            if mode == nat.MMX_ZX_TILED_Q16 or (0 <= 4.0 * bound <= eps):
+                tiled_mode = nat.MMX_ZX_TILED_Q16
+        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16):
             rc = L.mmx_zx_pack(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                                ws.data_ptr(), stream)
             if rc not in (0, 5):                 # MMX_OK, MMX_ERR_UNSUPPORTED (float voxels, workspace shape)
@@ -550,11 +563,11 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                 nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]), int(space.radii[s]),
                 float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(),
                 (mask_base + s * mask_words * 16) if with_mask else None, thr - eps, eps,
-                ctypes.byref(written), (nat.MMX_ZX_TILED | nat.MMX_ZX_PREPACKED) if packed else mode,
+                ctypes.byref(written), (tiled_mode | nat.MMX_ZX_PREPACKED) if packed else mode,
                 ctypes.byref(path), stream),
                 "mmx_log_batch_f32")
             LAST_ZX_PATH = path.value
-            packed = packed and path.value == nat.MMX_ZX_TILED
+            packed = packed and path.value == tiled_mode
             layouts.add(written.value if with_mask else 0)
         return layouts
 
@@ -717,7 +730,16 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
         xx = c["x"][:, None] + offs[None, :, 3]
         inside = ((ss >= 0) & (ss < ns) & (zz >= 0) & (zz < dims[:, 0:1]) &
                   (yy >= 0) & (yy < dims[:, 1:2]) & (xx >= 0) & (xx < dims[:, 2:3]))
-        owner, which = np.nonzero(inside)
+        probe = inside
+        if len(c) and np.all(c["flags"] & nat.MMX_CAND_BAND):
+            # the sparse NMS kernel recorded which neighbours have float32 values within eps below the candidate's
+            # (or above it): with |float32 - float64| < eps / 4 every other neighbour is below it in float64 too
+            bits = np.arange(64, dtype=np.uint64)
+            in_band = np.concatenate([(c["band"][:, None] >> bits[None, :]) & np.uint64(1),
+                                      ((c["flags"][:, None] >> np.arange(16, 32, dtype=np.uint32)[None, :]) & 1)
+                                      .astype(np.uint64)], axis=1).astype(bool)
+            probe = inside & in_band
+        owner, which = np.nonzero(probe)
         n_nb = len(owner)
         probes = np.zeros(n_nb + len(selves), dtype=nat.CAND_DTYPE)
         probes["slot"][:n_nb] = c["slot"][owner]

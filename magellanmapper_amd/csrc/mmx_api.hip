@@ -141,6 +141,28 @@ int mmx_device_count(void)
     return ok;
 }
 
+// Q16 tiles (MMX_ZX_TILED_Q16): P in [0, BP] as unorm16, Q in [-BQ, BQ] as snorm16.  For voxels in [0, 1] (integer
+// types after img_as_float) the bounds follow from the weights alone -- |P| <= (sum w0)^2, |Q| <= 2 sum|w2| sum w0,
+// folding reflected taps only merges weights -- and so does the error the rounding leaves in the LoG value:
+//   norm (sum|w2| BP / 65535 + sum w0 BQ / 32767) / 2,
+// i.e. 3.7e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7.
+static void q16_bounds(const double* w0, const double* w2, int radius, double norm, double* bp, double* bq, double* err)
+{
+    double s0 = w0[0], s2 = fabs(w2[0]);
+    for (int k = 1; k <= radius; ++k) { s0 += 2.0 * w0[k]; s2 += 2.0 * fabs(w2[k]); }
+    *bp = s0 * s0 * (1.0 + 1e-6);
+    *bq = 2.0 * s2 * s0 * (1.0 + 1e-6);
+    *err = norm * (s2 * *bp / 65535.0 + s0 * *bq / 32767.0) / 2.0 + 1e-6;
+}
+
+double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm)
+{
+    if (!h_w0 || !h_w2 || radius < 0 || radius > MMX_MAX_RADIUS_GENERIC) return -1.0;
+    double bp, bq, err;
+    q16_bounds(h_w0, h_w2, radius, norm, &bp, &bq, &err);
+    return err;
+}
+
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                       int n_blocks, int64_t slot_elems,
                       const double* h_w0, const double* h_w2, int radius, double norm,
@@ -149,9 +171,9 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
 {
     if (h_mask_written) *h_mask_written = 0;
     if (h_zx_path) *h_zx_path = MMX_ZX_SEPARATE;
-    const bool prepacked = zx_mode == (MMX_ZX_TILED | MMX_ZX_PREPACKED);
-    if (prepacked) zx_mode = MMX_ZX_TILED;
-    if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_TILED || zx_mode == 1) return MMX_ERR_ARG;
+    const bool prepacked = zx_mode == (MMX_ZX_TILED | MMX_ZX_PREPACKED) || zx_mode == (MMX_ZX_TILED_Q16 | MMX_ZX_PREPACKED);
+    if (prepacked) zx_mode &= ~MMX_ZX_PREPACKED;
+    if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_TILED_Q16 || zx_mode == 1) return MMX_ERR_ARG;
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
         return MMX_ERR_ARG;
     if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
@@ -233,7 +255,13 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         // and LDS-staged matrix-core kernels are correct and selectable, but no faster than the packed one:
         // DESIGN.md section 4b -- their 16 planes x 64 bytes accesses were the limit, which the tiled form removes.)
         mmx_zx6_plan plan;
-        bool tiled = (zx_mode == MMX_ZX_TILED || zx_mode == MMX_ZX_AUTO) &&
+        // Q16 tiles when asked for, or under AUTO when the caller's NMS band covers their rounding error fourfold
+        // (the condition under which every true maximum is still nominated)
+        double q_bp = 0, q_bq = 0, q_err = 0;
+        q16_bounds(h_w0, h_w2, radius, norm, &q_bp, &q_bq, &q_err);
+        const bool q16 = zx_mode == MMX_ZX_TILED_Q16 ||
+                         (zx_mode == MMX_ZX_AUTO && d_nms_mask && h_mask_written && (double)nms_eps >= 4.0 * q_err);
+        bool tiled = (zx_mode == MMX_ZX_TILED || zx_mode == MMX_ZX_TILED_Q16 || zx_mode == MMX_ZX_AUTO) &&
                      (vol->dtype == MMX_U8 || vol->dtype == MMX_U16) &&
                      mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, &plan) == MMX_OK;
         if (tiled && !prepacked) {
@@ -246,8 +274,9 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
           rc = MMX_ERR_UNSUPPORTED;
           const bool mfma16 = zx_mode == MMX_ZX_MFMA_F16 || zx_mode == MMX_ZX_MFMA_F16_LDS;
           if (tiled) {
-              path = MMX_ZX_TILED;
-              rc = mmx_launch_zx6(vol, d_blocks, h_blocks, n_blocks, plan, txx, radius, d_work, s);
+              path = q16 ? MMX_ZX_TILED_Q16 : MMX_ZX_TILED;
+              rc = mmx_launch_zx6(vol, d_blocks, h_blocks, n_blocks, plan, txx, radius, d_work,
+                                  q16 ? (float)(1.0 / q_bp) : 0.f, q16 ? (float)(1.0 / q_bq) : 0.f, s);
               tiled = rc == MMX_OK;
           } else if (mfma16) {    // integer voxels, aligned rows; geometries it does not take: the packed kernel
               path = zx_mode == MMX_ZX_MFMA_F16_LDS ? MMX_ZX_MFMA_F16_LDS : MMX_ZX_MFMA_F16;
@@ -274,7 +303,8 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
             }
             if (tiled)
                 rc = mmx_launch_y6(d_blocks, n_blocks, plan, slot_elems, tyy, radius, d_work,
-                                   reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_work) + plan.q_off), d_log,
+                                   reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_work) + plan.q_off),
+                                   q16 ? (float)(q_bp / 65535.0) : 0.f, q16 ? (float)(q_bq / 32767.0) : 0.f, d_log,
                                    want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s);
             else
                 rc = mmx_launch_y2(d_blocks, n_blocks, max_ycols, slot_elems, tyy, radius, t0, t1, d_log,

@@ -63,9 +63,11 @@ int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elem
 int mmx_launch_zx6_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
                         const mmx_zx6_plan& plan, void* d_work, hipStream_t stream);
 int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
-                   const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, hipStream_t stream);
+                   const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, float qp, float qq,
+                   hipStream_t stream);
+// cp, cq > 0: d_p holds Q16 tiles, P = unorm16 * cp, Q = snorm16 * cq (d_q unused); 0: float32 tiles
 int mmx_launch_y6(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
-                  const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
+                  const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q, float cp, float cq,
                   float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);
 int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,

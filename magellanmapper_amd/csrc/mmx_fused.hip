@@ -207,7 +207,9 @@ int launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slo
 // read single voxels from it): a wave stores four 64-byte row pieces, and only where something is above the
 // threshold.  NMS entries: per row y one entry per (4 planes, 16 columns) = this wave's footprint,
 // index y * (nzq * ntx) + (z >> 2) * ntx + (x >> 4), bit ((z & 3) << 4) | (x & 15)  (mmx_peaks.hip: layout 2).
-template <int R, bool MASK>
+// Q16: one dword per voxel in the tile, P = unorm16 (low half), Q = snorm16 (high half); their scales ride in the
+// weights.  Half the bytes and half the load instructions.
+template <int R, bool MASK, bool Q16>
 __global__ void __launch_bounds__(MMX_WG)
 y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile_stride,
           const float* __restrict__ gp, const float* __restrict__ gq,
@@ -245,25 +247,31 @@ y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     int ydone = 0;
 
     const rsrc_t rs1 = make_rsrc(i1), rs2 = make_rsrc(i2), rsw = make_rsrc(w1);
+    auto unpack = [](unsigned d) __attribute__((always_inline)) {
+        return (v2f){(float)(d & 0xffffu), (float)((int)d >> 16)};
+    };
     v2f r[M];     // (P, Q) window
 #pragma unroll
     for (int j = -R; j < R + kPrefetch; ++j) {
         const unsigned row = (unsigned)reflect_once(j, n) * trow_b;
-        r[(j + M) % M] = (v2f){__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, row, 0)),
-                               __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, row, 0))};
+        if constexpr (Q16)
+            r[(j + M) % M] = unpack(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, row, 0));
+        else
+            r[(j + M) % M] = (v2f){__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, row, 0)),
+                                   __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, row, 0))};
     }
     const unsigned row_b = (unsigned)bd.px * 4u;
     unsigned qoff = (unsigned)(R + kPrefetch) * trow_b;     // next tile to load (bytes)
     unsigned woff = 0;                                      // row being written
     auto step = [&](int s, auto reflecting, int y) __attribute__((always_inline)) {
-        float n1, n2;
+        float n1, n2 = 0.f;
         if constexpr (decltype(reflecting)::value) {
             const unsigned rnext = (unsigned)reflect_once(y + R + kPrefetch, n) * trow_b;
             n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, rnext, 0));
-            n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, rnext, 0));
+            if constexpr (!Q16) n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, rnext, 0));
         } else {
             n1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, voff, qoff, 0));
-            n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, qoff, 0));
+            if constexpr (!Q16) n2 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs2, voff, qoff, 0));
         }
         qoff += trow_b;
         v2f a2 = r[s] * taps.w[0];
@@ -282,7 +290,8 @@ y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
         const unsigned long long ab = MASK ? __ballot(real & (acc > nms_lo)) : ~0ull;
         if (ab && real) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rsw, ooff, woff, 0);
         woff += row_b;
-        r[(s + R + kPrefetch) % M] = (v2f){n1, n2};
+        if constexpr (Q16) r[(s + R + kPrefetch) % M] = unpack(__float_as_uint(n1));
+        else r[(s + R + kPrefetch) % M] = (v2f){n1, n2};
         if constexpr (MASK) {
             // x neighbours inside the 16-lane rows (DPP row shifts); lanes with no source keep `acc`, which
             // has_l / has_r discard: the first and last column of a tile are not tested against the next tile
@@ -327,18 +336,19 @@ y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
 
 template <int R>
 int launch_y6(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
-              const mmx_taps_f32& taps, const float* d_p, const float* d_q, float* d_log,
+              const mmx_taps_f32& taps, const float* d_p, const float* d_q, float cp, float cq, float* d_log,
               unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t s)
 {
     dim3 grid(plan.max_tiles, n_blocks);
     y2_taps pk;
-    for (int k = 0; k <= R; ++k) pk.w[k] = (v2f){taps.w2[k], taps.w0[k]};
-    if (d_mask)
-        hipLaunchKernelGGL((y6_kernel<R, true>), grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, plan.tile_stride, d_p, d_q,
-                           d_log, pk, d_mask, nms_lo, nms_eps);
-    else
-        hipLaunchKernelGGL((y6_kernel<R, false>), grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, plan.tile_stride, d_p, d_q,
-                           d_log, pk, d_mask, nms_lo, nms_eps);
+    const bool q16 = cp > 0.f;
+    for (int k = 0; k <= R; ++k) pk.w[k] = q16 ? (v2f){taps.w2[k] * cp, taps.w0[k] * cq} : (v2f){taps.w2[k], taps.w0[k]};
+#define MMX_Y6_LAUNCH(MK, QQ) \
+    hipLaunchKernelGGL((y6_kernel<R, MK, QQ>), grid, dim3(MMX_WG), 0, s, d_blocks, slot_elems, plan.tile_stride, d_p, d_q, \
+                       d_log, pk, d_mask, nms_lo, nms_eps)
+    if (d_mask) { if (q16) MMX_Y6_LAUNCH(true, true); else MMX_Y6_LAUNCH(true, false); }
+    else        { if (q16) MMX_Y6_LAUNCH(false, true); else MMX_Y6_LAUNCH(false, false); }
+#undef MMX_Y6_LAUNCH
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
@@ -361,11 +371,11 @@ int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t
 }
 
 int mmx_launch_y6(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
-                  const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
+                  const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q, float cp, float cq,
                   float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream)
 {
     switch (radius) {
-#define X(R) case R: return launch_y6<R>(d_blocks, n_blocks, plan, slot_elems, taps, d_p, d_q, d_log, d_mask, nms_lo, nms_eps, stream);
+#define X(R) case R: return launch_y6<R>(d_blocks, n_blocks, plan, slot_elems, taps, d_p, d_q, cp, cq, d_log, d_mask, nms_lo, nms_eps, stream);
         MMX_FOR_EACH_RADIUS(X)
 #undef X
         default: return MMX_ERR_UNSUPPORTED;

@@ -67,6 +67,7 @@ struct mmx_zx4_cfg {
     int wcls[MMX_ZX4_MAXCLS];              // widths (nx)
     int zcls[MMX_ZX4_MAXCLS];              // depths (nz)
     int maxcol, maxu;                      // table extents: columns per width class, z tiles per depth class
+    float qp, qq;                          // Q16 tiles: P / bound(P) and Q / bound(Q) land in [0, 1] and [-1, 1]
     int staged;                            // 0: chunks clamped into the row (zx4); 1: at their natural position (zx5); 2: same, windows at 16 c - R8 (zx6)
 };
 
@@ -261,7 +262,10 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
 // stride_z = its elements per block) and P / Q leave as 16 x 16 tiles of 1 KiB (slot_elems = tile elements per
 // block) in (y, c, U) order, which y6_kernel (mmx_fused.hip) reads: every global access of a wave is then one
 // contiguous KiB.
-template <int NKX, int LA, typename InT, bool TILED = false>
+// Q16 (zx_mode 7): the tile holds one dword per voxel, P as unorm16 of P / bound(P) in the low half and Q as snorm16
+// of Q / bound(Q) in the high half (the bounds follow from the weights alone: mmx_tiled_q16_error_bound) -- half
+// the bytes for the Y pass to read and for this kernel to write, at a known error that the caller's band must cover.
+template <int NKX, int LA, typename InT, bool TILED = false, bool Q16 = false>
 #ifdef ZX6_FAKE_LOADER
 __global__ void __launch_bounds__(320, 2)
 #else
@@ -549,6 +553,23 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #endif
                 // the results reach the slot's registers through opaque moves: the stores then read registers
                 // that nothing else may be allocated to before the slot comes round again
+                if constexpr (Q16) {
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const float pa = __builtin_fmaf(p1[r], kLoInv, p0[r]) * cfg.qp, pb = __builtin_fmaf(p1[r + 1], kLoInv, p0[r + 1]) * cfg.qp;
+                        const float qa = __builtin_fmaf(q1[r], kLoInv, q0[r]) * cfg.qq, qb = __builtin_fmaf(q1[r + 1], kLoInv, q0[r + 1]) * cfg.qq;
+                        const unsigned pu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(pa, pb));   // [Pa | Pb]
+                        const unsigned qs = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_i16(qa, qb));   // [Qa | Qb]
+                        const unsigned da = __builtin_amdgcn_perm(qs, pu, 0x05040100u);     // [Pa | Qa]
+                        const unsigned db = __builtin_amdgcn_perm(qs, pu, 0x07060302u);     // [Pb | Qb]
+                        float ra, rb;
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(ra) : "v"(__uint_as_float(da)));
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(rb) : "v"(__uint_as_float(db)));
+                        P[r] = ra;
+                        P[r + 1] = rb;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P), rp, obase, 0, ZX4_ST_AUX);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pv = __builtin_fmaf(p1[r], kLoInv, p0[r]);
@@ -566,6 +587,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P), rp, obase, 0, ZX4_ST_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, Q), rq, obase, 0, ZX4_ST_AUX);
 #endif
+                }
             }
 #ifdef ZX4_ROWS_Y
             obase += 16u * row_b;
@@ -1024,7 +1046,7 @@ zx6_pack_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 
 template <int NKX, int LA>
 int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
-               const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, hipStream_t s)
+               const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, float qp, float qq, hipStream_t s)
 {
     using cg = cls4<NKX, LA>;
     mmx_zx4_cfg cfg;
@@ -1034,6 +1056,7 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(65536.0 / 255.0);
     cfg.ncw = cfg.ncz = 0;
     cfg.staged = 2;
+    cfg.qp = qp; cfg.qq = qq;
     cfg.maxcol = cfg.maxu = 0;
     int max_waves = 0;
     for (int i = 0; i < n_blocks; ++i) {
@@ -1061,14 +1084,16 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     u4_4* ztab = reinterpret_cast<u4_4*>(w + plan.tab_off + xbytes);
     hipLaunchKernelGGL((zx4_setup<NKX, LA>), dim3((nx_entries + nz_entries + 3) / 4), dim3(256), 0, s, cfg, xtab, ztab);
     dim3 grid((((max_waves + 3) / 4) + 7) & ~7, n_blocks);        // (a multiple of 8: the XCD-aware order in the kernel)
-#ifdef ZX6_FAKE_LOADER
-    hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true>), grid, dim3(320), 0, s,
-#else
-    hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true>), grid, dim3(256), 0, s,
-#endif
-                       reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
-                       plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
-                       xtab, ztab, cfg);
+    if (qp > 0.f)
+        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, true>), grid, dim3(256), 0, s,
+                           reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
+                           plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
+                           xtab, ztab, cfg);
+    else
+        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, false>), grid, dim3(256), 0, s,
+                           reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
+                           plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
+                           xtab, ztab, cfg);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
@@ -1126,14 +1151,16 @@ int mmx_launch_zx6_pack(const mmx_volume* vol, const mmx_block* d_blocks, const 
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
 
+// qp, qq > 0: Q16 tiles (P qp in [0, 1], Q qq in [-1, 1]); 0: float32 tiles
 int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
-                   const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, hipStream_t stream)
+                   const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, float qp, float qq,
+                   hipStream_t stream)
 {
     if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8) return MMX_ERR_UNSUPPORTED;
     if (radius < 1 || radius > MMX_MAX_RADIUS_FAST) return MMX_ERR_UNSUPPORTED;
-    if (radius <= 8) return launch_zx6<1, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, stream);
-    if (radius <= 16) return launch_zx6<2, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, stream);
-    return launch_zx6<2, 2>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, stream);
+    if (radius <= 8) return launch_zx6<1, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, qp, qq, stream);
+    if (radius <= 16) return launch_zx6<2, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, qp, qq, stream);
+    return launch_zx6<2, 2>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, qp, qq, stream);
 }
 
 // tx: the PLAIN half kernels (no input scale, no norm); d_scratch: device memory the fused path does not

@@ -89,7 +89,7 @@ __device__ __forceinline__ void check_voxel(const peak_ctx& c, int s, int idx, f
         r.v = v;
         r.nbr_max = m;
         r.v64 = __longlong_as_double(0x7ff8000000000000LL);
-        r._reserved = 0.0;
+        r.band = 0;
         c.out[pos] = r;
     }
 }
@@ -204,8 +204,13 @@ __device__ __forceinline__ void check_voxel_sparse(const sparse_ctx& k, int s, i
     const peak_ctx& c = k.c;
     const int nz = c.nz, ny = c.ny, nx = c.nx;
     const float reject = v + c.eps;
+    const float band_lo = v - c.eps;       // a neighbour below this cannot out-vote the candidate whatever the exact values
     float m = -INFINITY;
     bool border = false;
+    // which of the 80 neighbours (C order of (ds, dz, dy, dx), the centre left out) lie in the band: the only ones
+    // whose exact values the host needs when the candidate turns out contested
+    unsigned long long band = 0;
+    unsigned band_hi = 0;
     for (int ds = -1; ds <= 1; ++ds) {
         const int ss = s + ds;
         if (ss < 0 || ss >= c.ns) { border = true; continue; }
@@ -223,7 +228,16 @@ __device__ __forceinline__ void check_voxel_sparse(const sparse_ctx& k, int s, i
                     const int xx = x + dx;
                     if (xx < 0 || xx >= nx) { border = true; continue; }
                     if ((ds | dz | dy | dx) == 0) continue;
-                    if (er[sparse_entry(k, zz, yy, xx)].y) m = fmaxf(m, row[xx]);
+                    if (er[sparse_entry(k, zz, yy, xx)].y) {
+                        const float u = row[xx];
+                        m = fmaxf(m, u);
+                        if (u >= band_lo) {
+                            int j = (((ds + 1) * 3 + (dz + 1)) * 3 + (dy + 1)) * 3 + (dx + 1);
+                            j -= j > 40;
+                            if (j < 64) band |= 1ull << j;
+                            else band_hi |= 1u << (j - 64);
+                        }
+                    }
                 }
             }
             if (m > reject) return;
@@ -240,11 +254,11 @@ __device__ __forceinline__ void check_voxel_sparse(const sparse_ctx& k, int s, i
         r.z = z;
         r.y = y;
         r.x = x;
-        r.flags = contested ? MMX_CAND_CONTESTED : 0u;
+        r.flags = (contested ? MMX_CAND_CONTESTED : 0u) | MMX_CAND_BAND | (band_hi << 16);
         r.v = v;
         r.nbr_max = m;
         r.v64 = __longlong_as_double(0x7ff8000000000000LL);
-        r._reserved = 0.0;
+        r.band = band;
         c.out[pos] = r;
     }
 }

@@ -87,14 +87,15 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
         kinds = nat.timing_read()
         assert kinds["zxpass"][1] == 0 and (kinds["zpass"][1] > 0 or kinds["generic"][1] > 0)
         assert bl.LAST_ZX_PATH == nat.MMX_ZX_SEPARATE
-        for mode in (2, 3, 4, 5, 6):
+        for mode in (2, 3, 4, 5, 6, 7):
             bl.ZX_MODE = mode
             fused = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
             kinds = nat.timing_read()
             # the fused kernels really ran (wherever the geometry lets any register-resident pass run)
             assert kinds["zxpass"][1] > 0 or kinds["generic"][1] > 0 or kinds["zpass"][1] > 0
             assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL
-            assert np.max(np.abs(fused - sep)) < 2e-6 * max(1.0, float(np.abs(sep).max()))
+            # (mode 7 hands 16-bit intermediates to the Y pass: rounding error <= 3.7e-5 of the value scale)
+            assert np.max(np.abs(fused - sep)) < (4e-5 if bl.LAST_ZX_PATH == 7 else 2e-6) * max(1.0, float(np.abs(sep).max()))
     finally:
         bl.ZX_MODE = default
         nat.timing_enable(False)
@@ -120,8 +121,11 @@ def test_blob_log_identical_to_reference(gpu, case):
     np.testing.assert_array_equal(res[0], g["pruned"])
     np.testing.assert_array_equal(res[0], res_o)
     if stats.n_candidates:
-        assert stats.max_f32_error < 5e-6 * max(1.0, float(np.abs(g["volume"]).max())
-                                                 if g["volume"].dtype.kind == "f" else 1.0)
+        # a quarter of the nomination band: 5e-6 for the float32 paths, 5e-5 where the default path hands 16-bit
+        # intermediates to the Y pass (raw integer volumes, radii <= 24; their bound is 3.7e-5)
+        q16 = bl.LAST_ZX_PATH == 7
+        assert stats.max_f32_error < (3.8e-5 if q16 else 5e-6) * max(1.0, float(np.abs(g["volume"]).max())
+                                                                     if g["volume"].dtype.kind == "f" else 1.0)
 
 
 def test_rescore_bit_exact_at_arbitrary_points(gpu):
@@ -487,7 +491,7 @@ def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
         detector.Blobs(np.ones((1, 4))).format_blobs()
 
 
-@pytest.mark.parametrize("fused", [0, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("fused", [0, 2, 3, 4, 5, 6, 7])
 def test_every_kernel_radius_matches_oracle(gpu, fused):
     """Each compiled radius (1..24 register-resident, 25 generic) of the separable passes against the
     float64 oracle cube.  Regression: the X pass read its register window in pairs but sized it odd for
@@ -505,11 +509,16 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
             assert space.radii[0] == R
             got = np.squeeze(bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [vol.shape], space)[0])
             want = blo.log_cube(img, np.array([[sigma] * 3]))[..., 0]
-            assert np.abs(got - want).max() < LOG_TOL * 1e-2, R
+            tol = LOG_TOL * 1e-2
+            if fused == 7:      # 16-bit intermediates: the bound the library states for these weights
+                tol = nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[0]), nat.as_double_ptr(space.w2[0]),
+                                                          R, float(space.norms[0]))
+                assert 3e-5 < tol < 6e-5
+            assert np.abs(got - want).max() < tol, R
             # the kernel asked for is the kernel that ran (its geometry conditions hold for this volume)
             if fused in (2, 3) and 1 <= R <= 24:
                 assert bl.LAST_ZX_PATH == fused, (R, bl.LAST_ZX_PATH)
-            if fused in (4, 5, 6) and 1 <= R <= 24:
+            if fused in (4, 5, 6, 7) and 1 <= R <= 24:
                 assert bl.LAST_ZX_PATH == fused, (R, bl.LAST_ZX_PATH)
     finally:
         bl.ZX_MODE = default
@@ -628,7 +637,8 @@ def test_selective_rescore_gives_the_exact_order(gpu):
         else:
             np.testing.assert_array_equal(pk_a[0][0], pk_b[0][0])
             np.testing.assert_array_equal(res_a[0], res_b[0])
-        assert np.abs(pk_a[0][1] - pk_b[0][1]).max() < 5e-6
+        # (candidates that were not re-scored keep their float32 values: within a quarter of the band of the exact ones)
+        assert np.abs(pk_a[0][1] - pk_b[0][1]).max() < (0.25 * bl.EPS_REL_Q16 if bl.LAST_ZX_PATH == 7 else 5e-6)
         assert st_b.n_rescored <= st_b.n_candidates
         n_sel += st_b.n_rescored
         n_all += st_b.n_candidates
@@ -718,14 +728,23 @@ def test_a_band_narrower_than_the_float32_error_widens_itself(gpu, monkeypatch):
     """The float32 passes only nominate; when their values stray from the exact ones by more than a quarter of the
     nomination band (forced here with an absurdly narrow band) the batch is nominated again with a wider one
     instead of failing -- and the blobs are still the reference's."""
-    from magellanmapper_amd import blob_log as bl
+    from magellanmapper_amd import _native as nat, blob_log as bl
     g = load_golden("bloblog_u16_5sigma.npz")
     monkeypatch.setattr(bl, "EPS_REL", 1e-9)
+    monkeypatch.setattr(bl, "EPS_REL_Q16", 0.0)           # (no wider band for the 16-bit intermediates: float32 tiles)
     stats = bl.BatchStats()
     dvol = bl.DeviceVolume(g["volume"])
     got = bl.blob_log_blocks(dvol, 0, [(0, 0, 0)], [g["volume"].shape], float(g["min_sigma"]), float(g["max_sigma"]),
                              int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]), stats=stats)[0]
     assert stats.n_band_retries >= 1 and stats.n_blocks == 1
+    np.testing.assert_array_equal(got, g["pruned"])
+    # the 16-bit intermediates forced under a band their rounding error (<= 3.7e-5) does not fit: same way out
+    monkeypatch.setattr(bl, "EPS_REL_Q16", 2e-5)
+    monkeypatch.setattr(bl, "ZX_MODE", nat.MMX_ZX_TILED_Q16)
+    stats = bl.BatchStats()
+    got = bl.blob_log_blocks(dvol, 0, [(0, 0, 0)], [g["volume"].shape], float(g["min_sigma"]), float(g["max_sigma"]),
+                             int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]), stats=stats)[0]
+    assert bl.LAST_ZX_PATH == nat.MMX_ZX_TILED_Q16 and stats.n_band_retries >= 1
     np.testing.assert_array_equal(got, g["pruned"])
 
 
@@ -751,7 +770,7 @@ def _abi_batch(vol, origins, shapes, sigmas, zx_mode, prepack, thr=0.1, eps=2e-5
     if prepack:
         nat.check(L.mmx_zx_pack(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot, ws.data_ptr(),
                                 stream), "mmx_zx_pack")
-        mode = nat.MMX_ZX_TILED | nat.MMX_ZX_PREPACKED
+        mode = (nat.MMX_ZX_TILED_Q16 if eps >= 1.5e-4 else nat.MMX_ZX_TILED) | nat.MMX_ZX_PREPACKED
     layouts, paths = set(), set()
     for i, s in enumerate(sigmas):
         R = k1.kernel_radius(s)
@@ -799,6 +818,20 @@ def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
     assert np.max(np.abs(v2 - v6)) < 2e-6
     assert np.array_equal(k6, k6p) and np.array_equal(v6, v6p) and np.array_equal(f6, f6p)
     assert np.array_equal(k6, ka) and np.array_equal(v6, va)
+    # 16-bit intermediates: what AUTO picks once the band covers their rounding error fourfold.  Every candidate of the
+    # narrow band is still nominated, its value within the bound the library states for these weights.
+    p7, l7, k7, v7, f7 = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_AUTO, True, eps=2e-4)
+    assert (p7, l7) == (nat.MMX_ZX_TILED_Q16, nat.MMX_MASK_QUADS)
+    from magellanmapper_amd import kernels1d as k1
+    bound = max(nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(k1.gaussian_half_kernel(s_, 0, k1.kernel_radius(s_))),
+                                                    nat.as_double_ptr(k1.gaussian_half_kernel(s_, 2, k1.kernel_radius(s_))),
+                                                    k1.kernel_radius(s_), s_ * s_) for s_ in sig)
+    assert 3e-5 < bound < 4e-5
+    pos = {tuple(r): i for i, r in enumerate(k7)}
+    idx = [pos.get(tuple(r), -1) for r in k2]
+    assert min(idx) >= 0
+    assert np.max(np.abs(v7[idx] - v2)) < bound
+    assert np.all(f7 & nat.MMX_CAND_BAND)
 
 
 def test_zx_pack_refuses_what_the_tiled_path_cannot_take(gpu):

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from magellanmapper_amd import _native as nat, blob_log as bl  # noqa: E402
 
 MODE = int(os.environ.get('ZX_CHECK_MODE', 4))     # 4: register resident, 5: staged through LDS, 6: tiled
-TOL = 2e-6      # of the image value scale (eps / 4 of the exactness machinery is 5e-6)
+TOL = 5e-5 if MODE == 7 else 2e-6      # of the image value scale (eps / 4 is 5e-6; Q16 tiles: bound 3.7e-5, eps / 4 = 5e-5)
 rng = np.random.default_rng(7)
 L = nat.lib()
 worst = 0.0
