@@ -160,7 +160,7 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
 
 /* Largest deviation of an MMX_ZX_TILED_Q16 LoG value from the float32 paths' (which are within a few 1e-7 of the
  * exact value), in units of the image's value scale, for voxels in [0, 1] (uint8 / uint16 after img_as_float): a
- * function of the weights alone (3.7e-5 for any sigma).  A true maximum is nominated as long as the NMS band is four
+ * function of the weights alone (4.3e-5 for any sigma >= 1).  A true maximum is nominated as long as the NMS band is four
  * times this (mmx_rescore_f64 then decides on exact values as always).  < 0 on bad arguments. */
 double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm);
 

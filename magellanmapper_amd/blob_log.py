@@ -59,7 +59,7 @@ except Exception as exc:  # pragma: no cover
 #: half-width of the float32 "contested" band, relative to the input's value scale
 EPS_REL = float(os.environ.get("MMX_EPS_REL", 2e-5))
 #: the band for raw integer volumes, whose default kernels hand the Z+X results to the Y pass as 16-bit fixed point
-#: (``MMX_ZX_TILED_Q16``: rounding error <= 3.7e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
+#: (``MMX_ZX_TILED_Q16``: error <= 4.3e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
 EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2e-4))
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9

@@ -145,14 +145,18 @@ int mmx_device_count(void)
 // types after img_as_float) the bounds follow from the weights alone -- |P| <= (sum w0)^2, |Q| <= 2 sum|w2| sum w0,
 // folding reflected taps only merges weights -- and so does the error the rounding leaves in the LoG value:
 //   norm (sum|w2| BP / 65535 + sum w0 BQ / 32767) / 2,
-// i.e. 3.7e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7.
+// i.e. 3.7e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7 and the product
+// term the 16-bit kernel leaves out (0.55e-5): 4.3e-5 in all.
 static void q16_bounds(const double* w0, const double* w2, int radius, double norm, double* bp, double* bq, double* err)
 {
     double s0 = w0[0], s2 = fabs(w2[0]);
     for (int k = 1; k <= radius; ++k) { s0 += 2.0 * w0[k]; s2 += 2.0 * fabs(w2[k]); }
     *bp = s0 * s0 * (1.0 + 1e-6);
     *bq = 2.0 * s2 * s0 * (1.0 + 1e-6);
-    *err = norm * (s2 * *bp / 65535.0 + s0 * *bq / 32767.0) / 2.0 + 1e-6;
+    // ... plus what the 16-bit kernel drops in the X pass (low voxel byte x low weight piece: 255 / 65536 x 2^-11 per
+    // unit of weight): P off by 1.9e-6 s0^2, Q by 1.9e-6 x 2 s2 s0
+    const double drop = 255.0 / 65536.0 / 2048.0;
+    *err = norm * (s2 * (*bp / 65535.0 / 2.0 + drop * s0 * s0) + s0 * (*bq / 32767.0 / 2.0 + drop * 2.0 * s2 * s0)) + 1e-6;
 }
 
 double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm)

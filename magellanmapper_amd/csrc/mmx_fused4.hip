@@ -269,7 +269,7 @@ template <int NKX, int LA, typename InT, bool TILED = false, bool Q16 = false>
 #ifdef ZX6_FAKE_LOADER
 __global__ void __launch_bounds__(320, 2)
 #else
-__global__ void __launch_bounds__(256, TILED && LA == 1 ? 3 : 2)      // (LA == 2 needs 170 registers: two waves per SIMD)
+__global__ void __launch_bounds__(256, TILED && (LA == 1 || Q16) ? 3 : 2)      // (float32 tiles, LA == 2: 232 registers)
 #endif
 zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
@@ -281,8 +281,10 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     constexpr int NKZ = cg::NKZ, NT = cg::NT;
     // TILED, radius <= 16: the Z fragments of the interior z tiles live in LDS, shared by the workgroup's waves, and
     // two z tiles are in flight instead of three: 154 registers, three waves per SIMD.  (Radius > 16 has three
-    // k-steps of Z fragments: fetching them from LDS every step costs more than the third wave gives.)
-    constexpr bool ZLDS = TILED && LA == 1;
+    // k-steps of Z fragments: with float32 tiles, which are bound by their stores, fetching them from LDS every step
+    // costs more than the third wave gives -- 4.19 against 3.87 ms --; with 16-bit tiles, 168 registers, it pays:
+    // 3.10 against 3.15 ms.)
+    constexpr bool ZLDS = TILED && (LA == 1 || Q16);
     constexpr int PF = ZLDS ? ZX6_PF : kPF4;         // z tiles of voxels in flight per wave
     const mmx_block bd = blocks[blockIdx.y];
     const int W = bd.nx, nz = bd.nz, px = bd.px;
@@ -477,8 +479,12 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 if constexpr (pc::NP == 2) {
                     a0 = mfma16(dl[m], xw[m][0][0], a0);
                     b0 = mfma16(dl[m], xw[m][1][0], b0);
-                    a1 = mfma16(dl[m], xw[m][0][1], a1);
-                    b1 = mfma16(dl[m], xw[m][1][1], b1);
+                    // (low voxel byte x low weight piece: <= 2^-19 of a product.  The float32 tiles keep it; the 16-bit
+                    //  tiles' error bound has room for it: mmx_tiled_q16_error_bound counts 1.9e-6 per X sum)
+                    if constexpr (!Q16) {
+                        a1 = mfma16(dl[m], xw[m][0][1], a1);
+                        b1 = mfma16(dl[m], xw[m][1][1], b1);
+                    }
                 }
             }
             // combine the two accumulators and split into float16 pieces: v = acc0 + acc1 / 2048
@@ -990,7 +996,8 @@ int launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
 // ------------------------------------------------------------------------------- tiled variant (zx_mode 6)
 // Operand-ordered copy of the blocks' voxels, made once per batch: for every block row y and z tile t the row
 // tile of 16 planes x nx voxels as units of 8 columns x 16 planes (256 bytes, plane-major inside), widened to
-// uint16: the four units a lane group of zx4_kernel<.., TILED> needs for one k-step are one contiguous KiB
+// uint16 (uint8 voxels shifted into the high byte): the four units a lane group of zx4_kernel<.., TILED> needs for one
+// k-step are one contiguous KiB
 // wherever the window starts.  Planes past the block and columns past the row read as zero.  Any strides, any
 // alignment: the copy is what lifts zx4's 16-byte alignment rules.
 template <typename InT>
@@ -1033,7 +1040,8 @@ zx6_pack_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             }
         } else {
             for (int x = lane; x < 8 * nch8; x += 64)
-                tile[r][x] = x < bd.nx ? (uint16_t)src[(int64_t)z * stride_z + (int64_t)x * stride_x] : (uint16_t)0;
+                tile[r][x] = x < bd.nx ? (uint16_t)((unsigned)src[(int64_t)z * stride_z + (int64_t)x * stride_x] << (sizeof(InT) == 1 ? 8 : 0))
+                                       : (uint16_t)0;     // (uint8 voxels go to the HIGH byte: the exact high float16 piece carries them)
         }
     }
     __syncthreads();
@@ -1053,7 +1061,7 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) { cfg.w0[k] = tx.w0[k]; cfg.w2[k] = tx.w2[k]; }
     cfg.radius = radius;
     // the pieces carry v / 2^16 of the widened voxel: skimage's img_as_float scale on top
-    cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(65536.0 / 255.0);
+    cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(65536.0 / (255.0 * 256.0));
     cfg.ncw = cfg.ncz = 0;
     cfg.staged = 2;
     cfg.qp = qp; cfg.qq = qq;

@@ -157,7 +157,7 @@ def test_full_size_c3_volume_properties_and_digest(gpu, tmp_path):
     line = _run_bench(tmp_path, 1, "--dump", str(tmp_path / "c3.npz"), timeout=1200)
     assert line["config"]["blocks_per_rank"] == 256 and line["n_gpus"] == 1
     assert line["table_sha1"] == "5fba8ef88362dfa0a7d9fb8caaef869ea416eb85"
-    assert line["detector_stats"]["max_f32_error"] < 3.8e-5 and line["detector_stats"]["n_band_retries"] == 0   # Q16 bound
+    assert line["detector_stats"]["max_f32_error"] < 4.4e-5 and line["detector_stats"]["n_band_retries"] == 0   # Q16 bound
     final = np.load(tmp_path / "c3.npz")["final"]
     assert final.shape == (line["blobs"], 8) and line["blobs"] == 292044
     zyx = final[:, :3]
