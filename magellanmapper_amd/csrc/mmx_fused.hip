@@ -295,15 +295,23 @@ y6_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
         if constexpr (MASK) {
             // x neighbours inside the 16-lane rows (DPP row shifts); lanes with no source keep `acc`, which
             // has_l / has_r discard: the first and last column of a tile are not tested against the next tile
-            const float l = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
-                (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
-            const float rr = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
-                (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
-            const float nbx = fmaxf(has_l ? l : -INFINITY, has_r ? rr : -INFINITY);
+            // (three quarters of the footprints hold nothing above the threshold: the neighbour values of such a row are
+            //  never looked at, and a row with nothing above it has no candidates -- wave-uniform branches)
+            float nbx = -INFINITY;
+            if (ab) {
+                const float l = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
+                    (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+                const float rr = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
+                    (int)__float_as_uint(acc), (int)__float_as_uint(acc), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+                nbx = fmaxf(has_l ? l : -INFINITY, has_r ? rr : -INFINITY);
+            }
             if (ydone > 0) {      // decide row ydone - 1, now that its successor is known
-                const bool cand = real & (prev1 > nms_lo) &
-                                  !(fmaxf(fmaxf(prev2, acc), nbx_prev) > prev1 + nms_eps);
-                const unsigned long long m = __ballot(cand);
+                unsigned long long m = 0;
+                if (ab_prev) {
+                    const bool cand = real & (prev1 > nms_lo) &
+                                      !(fmaxf(fmaxf(prev2, acc), nbx_prev) > prev1 + nms_eps);
+                    m = __ballot(cand);
+                }
                 if (lane == 0) *mrow = make_ulonglong2(m, ab_prev);
                 mrow += nent;
             }

@@ -266,11 +266,7 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
 // of Q / bound(Q) in the high half (the bounds follow from the weights alone: mmx_tiled_q16_error_bound) -- half
 // the bytes for the Y pass to read and for this kernel to write, at a known error that the caller's band must cover.
 template <int NKX, int LA, typename InT, bool TILED = false, bool Q16 = false>
-#ifdef ZX6_FAKE_LOADER
-__global__ void __launch_bounds__(320, 2)
-#else
 __global__ void __launch_bounds__(256, TILED && (LA == 1 || Q16) ? 3 : 2)      // (float32 tiles, LA == 2: 232 registers)
-#endif
 zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
            float* __restrict__ gp, float* __restrict__ gq,
@@ -314,27 +310,6 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         for (int e = threadIdx.x; e < NKZ * 4 * 64; e += 256) zl[e] = zi[e];
         __syncthreads();
     }
-#ifdef ZX6_FAKE_LOADER   // interference experiment: a fifth wave issues the workgroup's loads, nobody waits for them
-    if constexpr (TILED) if ((threadIdx.x >> 6) == 4) {
-        const int gw0 = bx * 4, y0 = gw0 / ntx, c0 = gw0 - y0 * ntx;
-        if (y0 >= bd.ny) return;
-        const rsrc4_t rl = make_rsrc4(vol + (int64_t)bd.slot * stride_z);
-        const int nch = (W + 7) >> 3;
-        int j0 = 2 * c0 - cg::R8 / 8;
-        u4_4 acc = {0u, 0u, 0u, 0u};
-        for (int t = 0; t < ntz; ++t) {
-            const unsigned so = (unsigned)((y0 * ntz + t) * nch) * 256u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int j = j0 + 4 * q + kq; j = j < 0 ? 0 : (j > nch - 1 ? nch - 1 : j);
-                const u4_4 v = __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(rl, (unsigned)(j * 256 + li * 16), so, 0));
-                acc[0] ^= v[0]; acc[1] ^= v[1]; acc[2] ^= v[2]; acc[3] ^= v[3];
-            }
-        }
-        if (acc[0] == 0x12345678u && acc[3] == 0x9abcdef0u) gp[0] = 1.f;      // (keeps the loads alive)
-        return;
-    }
-#endif
     if (y >= bd.ny) return;                                   // whole wave (no barriers below)
 
     // X fragments of this column: [m][kernel][piece]
@@ -387,11 +362,6 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #endif
         if constexpr (TILED) {
             const unsigned so = (unsigned)((y * ntz + t) * nch8) * 256u;      // wave-uniform: the row tile
-#ifdef ZX6_FAKE_LOADER
-#pragma unroll
-            for (int m = 0; m < NKX; ++m) raw[m] = (u4_4){so + xoff[m], so * 3u, xoff[m] * 5u, so * 7u};
-            return;
-#endif
 #pragma unroll
             for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rin, xoff[m], so);
             return;

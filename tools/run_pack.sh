@@ -1,3 +1,3 @@
-ZX_CHECK_MODE=7 timeout 600 python tools/zx4_check.py 2>&1 | tail -1
-ZX_CHECK_MODE=6 timeout 600 python tools/zx4_check.py 2>&1 | tail -1
-timeout 1700 python -m pytest tests -q -m gpu 2>&1 | tail -3
+for t in 2 1; do echo "== threads $t"
+MMX_HOST_THREADS=$t timeout 600 python tools/steptrace.py --keep-heap --budget-gb 16 2>&1 | grep -E "step wall|tail after|more steps|StackPruner|final col" 
+done
