@@ -771,16 +771,19 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
         keep[contested] = cands["v64"][contested] >= nbr_max
     keep &= cands["v64"] > thr
     sel = np.nonzero(keep)[0]
-    # plain contiguous columns from here on (record-array fancy indexing is slow)
-    slot = cands["slot"].astype(np.int64)[sel]
-    cs, cz, cy, cx = (cands[f].astype(np.int64)[sel] for f in ("s", "z", "y", "x"))
+    # plain contiguous columns from here on (record-array field access walks 48-byte strides): the five leading
+    # int32 fields (slot, s, z, y, x) in one gather
+    ints = np.ascontiguousarray(cands).view(np.int32).reshape(-1, nat.CAND_DTYPE.itemsize // 4)[sel, :5].astype(np.int64)
+    slot, cs, cz, cy, cx = (ints[:, j] for j in range(5))
     v64 = cands["v64"][sel]
-    # group by block; inside a block the C order of np.nonzero on the (z, y, x, sigma) cube
+    # group by block; inside a block the C order of np.nonzero on the (z, y, x, sigma) cube: one sort on one key
+    # (a voxel of a block appears once, so the key is unique)
     dims = np.asarray(shapes, dtype=np.int64)
     lin = ((cz * dims[slot, 1] + cy) * dims[slot, 2] + cx) * ns + cs
-    order = np.lexsort((lin, slot))
+    span = int(np.max(dims[:, 0] * dims[:, 1] * dims[:, 2])) * ns
+    order = np.argsort(slot * span + lin, kind="stable") if span * len(shapes) < (1 << 62) else np.lexsort((lin, slot))
     slot = slot[order]
-    coords_all = np.stack([cz[order], cy[order], cx[order], cs[order]], axis=1)
+    coords_all = ints[order][:, [2, 3, 4, 1]]
     vals_all = v64[order]
     bounds = np.searchsorted(slot, np.arange(len(shapes) + 1))
     out = []
