@@ -425,14 +425,16 @@ def main():
         if dom:
             launches = ktimes[dom][1]
             roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"],
-                    "note": ("zxpass = fused Z+X pass on the matrix cores (zx_mode 6, tiled): its 10 algorithmic "
-                             "B/voxel/sigma replace the 22 of the separate Z and X passes (+ 0.8 B/voxel/sigma for the "
-                             "operand-ordered voxel copy, 'zxpack', made once per batch).  Its MFMAs are hidden: with "
-                             "them removed the kernel takes the same time; what bounds it is the rate at which the "
-                             "memory system takes its 64-byte write requests with ~80 requests in flight per CU "
-                             "(DESIGN.md section 4b).  The Y pass of the step runs at "
+                    "note": ("zxpass = fused Z+X pass on the matrix cores (zx_mode 7: tiled, 16-bit intermediates): the "
+                             "10 algorithmic B/voxel/sigma of the contract replace the 22 of the separate Z and X passes "
+                             "(+ 0.8 B/voxel/sigma for the operand-ordered voxel copy, 'zxpack', made once per batch); "
+                             "the kernel itself moves 6.4 B/voxel because P and Q leave as 16-bit fixed point (error "
+                             "bound 4.3e-5, covered fourfold by the NMS band; decisions are taken on exact float64 "
+                             "values).  'traffic' below the algorithmic bytes is that.  With float32 tiles it sat at "
+                             "the ~80 L2 requests a CU keeps in flight; now its VALU is 58 % and its MFMA pipe 43 % "
+                             "busy: instruction issue (DESIGN.md section 4b).  The Y pass of the step runs at "
                              f"{stream_k.get('y2pass', {}).get('alg_GBps', 0) / HBM_PEAK_GBS:.2f} of peak on its "
-                             "algorithmic bytes; see 'kernels' and 'pipeline_roofline' for the whole step")
+                             "contract bytes (it reads 16-bit tiles too); see 'kernels' and 'pipeline_roofline'")
                     if dom == "zxpass" else None,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),
