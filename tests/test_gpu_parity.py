@@ -856,3 +856,28 @@ def test_zx_pack_refuses_what_the_tiled_path_cannot_take(gpu):
         assert bl.LAST_ZX_PATH == nat.MMX_ZX_PACKED
     finally:
         bl.ZX_MODE = default
+
+
+def test_tiled_path_geometry_limits_and_interleaved_channels(gpu):
+    """What the tiled kernels take and what they hand back to the packed kernel: a (z, y, x, c) image is read with
+    its channel stride by the voxel copy (no alignment or stride rule left), more than eight distinct block widths
+    in one batch exceed its fragment tables (the whole batch takes the packed kernel) -- the blobs equal the
+    oracle's either way."""
+    from magellanmapper_amd import _native as nat, blob_log as bl, synth
+    from oracle import blob_log_oracle as blo
+    a = synth.make_volume(11, (40, 50, 90), 25)
+    b = synth.make_volume(12, (40, 50, 90), 25)
+    img = np.stack([a, b], axis=-1)                               # channels interleaved along x in memory
+    dvol = bl.DeviceVolume(img)
+    for chl, vol in ((0, a), (1, b)):
+        got = bl.blob_log_blocks(dvol, chl, [(0, 0, 0), (3, 4, 21)], [(40, 50, 64), (37, 46, 69)], 3.0, 4.0, 3, 0.05, 0.5)
+        assert bl.LAST_ZX_PATH == nat.MMX_ZX_TILED_Q16
+        for o, shp, res in zip([(0, 0, 0), (3, 4, 21)], [(40, 50, 64), (37, 46, 69)], got):
+            sub = vol[o[0]:o[0] + shp[0], o[1]:o[1] + shp[1], o[2]:o[2] + shp[2]]
+            np.testing.assert_array_equal(res, blo.blob_log(sub, 3.0, 4.0, 3, 0.05, 0.5))
+    widths = [40, 44, 48, 52, 56, 60, 64, 68, 72, 76]             # ten width classes: one more than the tables hold
+    shapes = [(40, 50, w) for w in widths]
+    got = bl.blob_log_blocks(bl.DeviceVolume(a), 0, [(0, 0, 0)] * len(widths), shapes, 3.0, 4.0, 3, 0.05, 0.5)
+    assert bl.LAST_ZX_PATH == nat.MMX_ZX_PACKED
+    for shp, res in zip(shapes, got):
+        np.testing.assert_array_equal(res, blo.blob_log(a[:, :, :shp[2]], 3.0, 4.0, 3, 0.05, 0.5))
