@@ -3,7 +3,15 @@
 //
 //   zx4_kernel :  I (u8 / u16, read once, x contiguous)  ->  P = G(z) G(x) I
 //                                                            Q = G(z) G''(x) I + G''(z) G(x) I
-// feeding y2_kernel (mmx_fused.hip) exactly as zx2_kernel (mmx_fused2.hip) does.
+// in three forms that share the arithmetic below:
+//   zx_mode 4  (TILED = false)  row-major voxels in, row-major P / Q out, feeding y2_kernel (mmx_fused.hip) exactly
+//                               as zx2_kernel (mmx_fused2.hip) does -- the experiment that showed the arithmetic at
+//                               1.8 ms and the kernel at 5.3: every access is "16 planes x 64 bytes";
+//   zx_mode 6  (TILED)          voxels from the operand-ordered copy zx6_pack_kernel makes once per batch, P / Q out
+//                               as 16 x 16 tiles of float32 -- every access one contiguous KiB -- feeding y6_kernel;
+//   zx_mode 7  (TILED, Q16)     the same with the tiles as one dword per voxel (P unorm16, Q snorm16 of value /
+//                               bound): the default, whenever the caller's NMS band covers the stated rounding bound.
+// zx5_kernel (zx_mode 5) is the LDS-staged experiment in between.  DESIGN.md section 4b has the measurements.
 //
 // Why.  zx2_kernel needs 5R packed VALU instructions per voxel and a workgroup-wide LDS hand-off per 8 planes;
 // measured, neither its arithmetic nor its skeleton (loads, LDS, barriers: 3.5 of its 5.4 ms per 64 blocks at
