@@ -279,21 +279,54 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
         cur_slot = slot
     if cur:
         batches.append(cur)
-    # The host finishes batch k (candidates -> peaks -> per-block prune -> tables: ~0.33 ms per block of the
-    # benchmark volume) while the GPU runs batch k + 1 (~0.66 ms per block), and nothing hides the host work of
-    # the LAST batch: halve the tail batches (each still gives the GPU as much work as the host has left from the
-    # batch before) down to a last batch of <= 8 blocks.  Measured (tools/steptrace.py): 89 / 89 / 59 / 19 blocks
-    # left the host 8 ms behind the GPU at the end and 18 ms of tail; 89 / 89 / 39 / 20 / 10 / 5 / 4 does not
-    # (a last batch of <= 8 against <= 16 blocks: 193 against 195 ms per step, same box, alternating runs).
-    taper = int(os.environ.get("MMX_TAPER", 8))
+    # The host finishes batch k (candidates -> peaks -> per-block prune -> tables: ~0.45 ms per block of the
+    # benchmark volume) while the GPU runs batch k + 1 (~0.46 ms per block with the tiled kernels), so it trails the
+    # GPU by the host time of one batch, and nothing hides that of the LAST batches: the tail of the block list is
+    # re-split into batches that shrink geometrically towards the end (... 18 / 11 / 7 / 4 blocks) -- each still
+    # gives the GPU about as much work as the host has left from the batch before.  Measured (tools/steptrace.py):
+    # 89 / 89 / 59 / 19 blocks left the host 8 ms behind the GPU at the end and 18 ms of tail, 89 / 89 / 39 / 20 /
+    # 10 / 5 / 4 did not; with 22-block batches a tail of 22 / 7 / 7 against 18 / 18 / 11 / 7 / 4.
+    taper = int(os.environ.get("MMX_TAPER", 4))
     vox = [int(s_[0]) * int(s_[1]) * int(s_[2]) for s_ in shapes]
-    last = batches.pop()
-    # (only batches with real work in them: below ~64 Mvoxel a batch is a few hundred microseconds of kernels)
-    while len(last) > max(1, taper) and sum(vox[i] for i in last) > (64 << 20):
-        cut = (len(last) + 1) // 2
-        batches.append(last[:cut])
-        last = last[cut:]
-    batches.append(last)
+
+    def fits(batch):
+        slot = max(int(shapes[i][0]) * int(shapes[i][1]) * (-(-int(shapes[i][2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
+                   for i in batch)
+        return len(batch) == 1 or len(batch) * slot * per_vox <= budget_bytes
+
+    full = max(len(b_) for b_ in batches)
+    tail = batches.pop()
+    while batches and len(tail) < 2 * full:
+        tail = batches.pop() + tail
+    # (only where there is real work: below ~64 Mvoxel a batch is a few hundred microseconds of kernels)
+    if taper > 0 and len(tail) > taper and sum(vox[i] for i in tail) > (64 << 20):
+        sizes, step = [], float(taper)
+        while sum(sizes) + int(step) <= len(tail) and int(step) < full:
+            sizes.append(int(step))
+            step *= 1.6
+        rest = len(tail) - sum(sizes)
+        n_front = -(-rest // full) if rest else 0
+        front = [rest // n_front + (1 if j < rest % n_front else 0) for j in range(n_front)] if n_front else []
+        at, pieces = 0, []
+        for n in front + sizes[::-1]:
+            pieces.append(tail[at:at + n])
+            at += n
+        tail_batches = []
+        for piece in pieces:                    # (blocks of different sizes: a piece may exceed the budget its count suggests)
+            while not fits(piece):
+                cut = len(piece) // 2
+                tail_batches.append(piece[:cut])
+                piece = piece[cut:]
+            tail_batches.append(piece)
+        batches.extend(tail_batches)
+    else:
+        stack = [tail]
+        while stack:                             # (the merged tail of small batches must still fit the budget)
+            piece = stack.pop(0)
+            if fits(piece):
+                batches.append(piece)
+            else:
+                stack[0:0] = [piece[:len(piece) // 2], piece[len(piece) // 2:]]
     # ... and nothing hides the GPU time of the FIRST batch from the host, which has nothing to do until its
     # candidates arrive: with the tiled kernels the host work per block (~0.5 ms) is as long as the kernels'
     # (~0.55 ms), so a first batch of 89 blocks put the host 50 ms behind for the whole step (tail after the last

@@ -595,8 +595,17 @@ def test_plan_batches_ramp_and_taper():
     from magellanmapper_amd import blob_log as bl
     shapes = [(261, 261, 261)] * 256
     b = bl.plan_batches(shapes, 5, 64 << 30)
-    assert [len(x) for x in b] == [16, 32, 41, 89, 39, 20, 10, 5, 4]
+    n = [len(x) for x in b]
+    assert n[:2] == [16, 32] and n[-4:] == [16, 10, 6, 4] and max(n) <= 89        # ramp ... taper
     assert sum(b, []) == list(range(256))
     b = bl.plan_batches(shapes, 5, 16 << 30)
-    assert sum(b, []) == list(range(256)) and max(len(x) for x in b) == 22 and len(b[-1]) <= 8
+    n = [len(x) for x in b]
+    assert sum(b, []) == list(range(256)) and max(n) == 22 and n[-4:] == [16, 10, 6, 4]
+    assert all(n[i] >= n[i + 1] for i in range(len(n) - 5, len(n) - 1))          # shrinking towards the end
+    # blocks of different sizes: no batch may exceed the budget, whatever the taper merged
+    mixed = [(261, 261, 261)] * 30 + [(261, 261, 64)] * 40 + [(261, 261, 261)] * 10
+    per_vox = (4 + 5) * 4 + 3
+    for batch in bl.plan_batches(mixed, 5, 4 << 30):
+        slot = max(m[0] * m[1] * (-(-m[2] // 32) * 32) for m in (mixed[i] for i in batch))
+        assert len(batch) == 1 or len(batch) * slot * per_vox <= (4 << 30)
     assert [len(x) for x in bl.plan_batches([(40, 40, 40)] * 9, 3, 1 << 30)] == [9]      # tiny blocks: one batch
