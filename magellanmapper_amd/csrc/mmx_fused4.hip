@@ -171,7 +171,9 @@ zx4_setup(mmx_zx4_cfg cfg, u4_4* __restrict__ xtab, u4_4* __restrict__ ztab)
         for (int j = 0; j < 8; ++j) {
             const int p = xl + j;
             const bool ok = p >= xc && p < xc + 8 && p >= 0 && p < W && xo < W;
-            wt[j] = ok ? folded_tap(w, R, p, xo, W) * cfg.xscale : 0.f;
+            // (16-bit tiles: their scales ride in the weights -- G(x) carries 1 / bound(P), G''(x) 1 / bound(Q), and
+            //  the order-2 Z fragments below the ratio -- so that the kernel's results come out ready to convert)
+            wt[j] = ok ? folded_tap(w, R, p, xo, W) * cfg.xscale * (cfg.qp > 0.f ? (kern ? cfg.qq : cfg.qp) : 1.f) : 0.f;
         }
         dst = xtab + (size_t)e * 2 * 64;
     } else if (e < nx_entries + nz_entries) {
@@ -188,7 +190,7 @@ zx4_setup(mmx_zx4_cfg cfg, u4_4* __restrict__ xtab, u4_4* __restrict__ ztab)
             const int i = 2 * ks + (j >> 2);                        // window tile of this k
             const int zi = 16 * (U - LA + i) + 4 * kq + (j & 3);
             const bool ok = i < cg::NT - 1 && zi >= 0 && zi < nz && zo < nz;
-            wt[j] = ok ? folded_tap(w, R, zi, zo, nz) : 0.f;
+            wt[j] = ok ? folded_tap(w, R, zi, zo, nz) * (cfg.qp > 0.f && kern ? cfg.qq / cfg.qp : 1.f) : 0.f;
         }
         dst = ztab + (size_t)ez * 2 * 64;
     } else {
@@ -540,8 +542,8 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 if constexpr (Q16) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
-                        const float pa = __builtin_fmaf(p1[r], kLoInv, p0[r]) * cfg.qp, pb = __builtin_fmaf(p1[r + 1], kLoInv, p0[r + 1]) * cfg.qp;
-                        const float qa = __builtin_fmaf(q1[r], kLoInv, q0[r]) * cfg.qq, qb = __builtin_fmaf(q1[r + 1], kLoInv, q0[r + 1]) * cfg.qq;
+                        const float pa = __builtin_fmaf(p1[r], kLoInv, p0[r]), pb = __builtin_fmaf(p1[r + 1], kLoInv, p0[r + 1]);
+                        const float qa = __builtin_fmaf(q1[r], kLoInv, q0[r]), qb = __builtin_fmaf(q1[r + 1], kLoInv, q0[r + 1]);
                         const unsigned pu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(pa, pb));   // [Pa | Pb]
                         const unsigned qs = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_i16(qa, qb));   // [Qa | Qb]
                         const unsigned da = __builtin_amdgcn_perm(qs, pu, 0x05040100u);     // [Pa | Qa]
