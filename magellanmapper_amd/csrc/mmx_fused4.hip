@@ -904,7 +904,7 @@ int launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
                void* d_scratch, size_t scratch_bytes, bool staged, hipStream_t s)
 {
     using cg = cls4<NKX, LA>;
-    mmx_zx4_cfg cfg;
+    mmx_zx4_cfg cfg{};          // (every field the setup kernel reads has a value: qp = qq = 0 means float32 tiles)
     for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) { cfg.w0[k] = tx.w0[k]; cfg.w2[k] = tx.w2[k]; }
     cfg.radius = radius;
     cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(256.0 / 255.0);
@@ -1037,7 +1037,7 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
                const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, float qp, float qq, hipStream_t s)
 {
     using cg = cls4<NKX, LA>;
-    mmx_zx4_cfg cfg;
+    mmx_zx4_cfg cfg{};          // (every field the setup kernel reads has a value: qp = qq = 0 means float32 tiles)
     for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) { cfg.w0[k] = tx.w0[k]; cfg.w2[k] = tx.w2[k]; }
     cfg.radius = radius;
     // the pieces carry v / 2^16 of the widened voxel: skimage's img_as_float scale on top

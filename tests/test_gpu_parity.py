@@ -93,7 +93,7 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
             kinds = nat.timing_read()
             # the fused kernels really ran (wherever the geometry lets any register-resident pass run)
             assert kinds["zxpass"][1] > 0 or kinds["generic"][1] > 0 or kinds["zpass"][1] > 0
-            assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL
+            assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL, (mode, bl.LAST_ZX_PATH)
             # (mode 7 hands 16-bit intermediates to the Y pass: error <= 4.3e-5 of the value scale)
             assert np.max(np.abs(fused - sep)) < (4.5e-5 if bl.LAST_ZX_PATH == 7 else 2e-6) * max(1.0, float(np.abs(sep).max()))
     finally:
