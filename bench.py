@@ -443,6 +443,25 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src,
                     "alg_bytes_per_launch": int(ALG_BYTES[dom] * my_vox * ns * args.steps / max(1, launches)),
                     "avg_launch_ms": round(ktimes[dom][0] / max(1, launches), 4)}
+            if dom == "zxpass" and bl.LAST_ZX_PATH in (nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16):
+                # the same kernel against the matrix-core roofline: MFMAs it issues (16 x 16 x 32 float16, 16 384 flop
+                # each) per 16 x 16 tile step -- X pass 12 (16-bit tiles) or 16 per two k-steps, 6 / 8 for radius <= 8;
+                # Z pass 9 per k-step -- over every block row, column tile and z step of this rank's blocks
+                from magellanmapper_amd import kernels1d as k1
+                space = bl.ScaleSpace.make(PROFILE["min_sigma_factor"] * detector.calc_scaling_factor()[2],
+                                           PROFILE["max_sigma_factor"] * detector.calc_scaling_factor()[2], ns)
+                q16 = bl.LAST_ZX_PATH == nat.MMX_ZX_TILED_Q16
+                flop = 0.0
+                for i in range(lo, hi):
+                    shp = [s_.indices(n_)[1] - s_.indices(n_)[0] for s_, n_ in zip(blocks.sub_roi_slices[coords[i]], shape)]
+                    for R in space.radii:
+                        nkx, la = (1, 1) if R <= 8 else ((2, 1) if R <= 16 else (2, 2))
+                        per_step = nkx * (6 if q16 else 8) + (la + 1) * 9
+                        flop += shp[1] * -(-shp[2] // 16) * (-(-shp[0] // 16) + la) * per_step * 16384.0
+                tfs = flop * args.steps / (ktimes[dom][0] * 1e-3) / 1e12
+                roof["mfma"] = {"achieved_TFLOPs": round(tfs, 1), "peak_TFLOPs": 2500.0, "frac": round(tfs / 2500.0, 4),
+                                "note": "float16 MFMA flops the kernel issues (split-float16 products: 3 MFMAs per float32 "
+                                        "product) over its duration, against the dense float16 peak"}
         gpu_ms = sum(ms for ms, n in ktimes.values()) / args.steps
         b_alg = B_ALG_PER_SIGMA * ns * n_chl
         vol_bytes = nvox * n_chl * 2
