@@ -255,6 +255,10 @@ class BatchStats:
     max_f32_error: float = 0.0
 
 
+#: debugging aid: cap on the blocks of one batch (``MMX_MAX_BATCH``; bisecting a batch-size dependent failure)
+_MAX_BATCH = int(os.environ.get("MMX_MAX_BATCH", 1 << 30))
+
+
 def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
                  budget_bytes: int, extra_bytes_per_voxel: int = 0) -> List[List[int]]:
     """Group block indices into batches whose workspace fits ``budget_bytes``.
@@ -272,7 +276,7 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     for i, shp in enumerate(shapes):
         vox = int(shp[0]) * int(shp[1]) * (-(-int(shp[2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
         slot = max(cur_slot, vox)
-        if cur and (len(cur) + 1) * slot * per_vox > budget_bytes:
+        if cur and ((len(cur) + 1) * slot * per_vox > budget_bytes or len(cur) >= _MAX_BATCH):
             batches.append(cur)
             cur, slot = [], vox
         cur.append(i)

@@ -65,8 +65,12 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     extern __shared__ double smem[];
     uint32_t n = cap;
     if (count) { const uint32_t c = *count; n = c < cap ? c : cap; }
-    if (blockIdx.x >= n) return;
-    const mmx_cand pt = pts[blockIdx.x];
+    // (one workgroup per point; the grid is two-dimensional because grid.x * 256 threads must stay below 2^32:
+    //  a batch whose candidates sit on a plateau -- spectral unmixing clips whole regions to 0 -- asks for the
+    //  80 neighbours of several 10^5 candidates, > 16.7 M points in one call)
+    const uint32_t idx = blockIdx.y * gridDim.x + blockIdx.x;
+    if (idx >= n) return;
+    const mmx_cand pt = pts[idx];
     if (pt.slot < 0 || pt.slot >= prm.n_blocks) return;
     const mmx_block bd = blocks[pt.slot];
     const int R = prm.radius[pt.s];
@@ -148,7 +152,7 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
         sum += t1;
         sum += t2;
         const StoreT cube = (-sum) * (StoreT)prm.norm[pt.s];
-        pts[blockIdx.x].v64 = (double)cube;
+        pts[idx].v64 = (double)cube;
     }
 }
 
@@ -157,7 +161,10 @@ int launch(const mmx_volume* vol, const mmx_block* d_blocks, mmx_cand* d_pts, ui
            const uint32_t* d_count, const double* d_w0, const double* d_w2,
            const mmx_rescore_params& prm, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL((rescore_kernel<InT, StoreT>), dim3(cap), dim3(MMX_WG), lds, s,
+    const uint32_t gx = cap < (1u << 22) ? cap : (1u << 22);
+    const uint32_t gy = (cap + gx - 1) / gx;
+    if (gy > 65535u) return MMX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((rescore_kernel<InT, StoreT>), dim3(gx, gy), dim3(MMX_WG), lds, s,
                        (const InT*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_blocks,
                        d_pts, cap, d_count, d_w0, d_w2, prm);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;

@@ -881,3 +881,39 @@ def test_tiled_path_geometry_limits_and_interleaved_channels(gpu):
     assert bl.LAST_ZX_PATH == nat.MMX_ZX_PACKED
     for shp, res in zip(shapes, got):
         np.testing.assert_array_equal(res, blo.blob_log(a[:, :, :shp[2]], 3.0, 4.0, 3, 0.05, 0.5))
+
+
+def test_plateau_of_contested_candidates_in_one_batch(gpu, tmp_path, monkeypatch):
+    """Found by tools/soak_stack.py (seed 202, trial 617): spectral unmixing clips whole regions of the second channel
+    to 0, every voxel of such a plateau is a contested candidate, and one batch of 125 small blocks asked for the exact
+    values of 19 million neighbours in one call -- more workgroups than a one-dimensional grid of 256-thread groups may
+    have (2^32 threads): the launch wrapped silently, the missing values read as NaN and two thirds of the channel's
+    blobs were dropped.  ``want`` in the fixture is the oracle's table for the dumped volume (two channels, isotropic
+    rescale, unmixing, a profile of its own for channel 1); the oracle runs again here."""
+    import ast
+    from magellanmapper_amd import config, preprocess, stack_detect
+    from oracle import magmap_oracle as mmo
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(preprocess, "RGB_GUESS", True)
+    g = load_golden("soak_stack_202_617.npz")
+    vol, res = g["vol"], g["res"]
+    over, unmix, ch1 = (ast.literal_eval(str(g[k])) for k in ("over", "unmix", "ch1"))
+    config.setup_roi_profiles(["default"] * 2)
+    for p in config.roi_profiles:
+        p.update(over)
+    config.roi_profiles[1].update(ch1)
+    config.roi_profile.update(over)
+    monkeypatch.setattr(config, "resolutions", res)
+    monkeypatch.setattr(config, "filename", "soak")
+    monkeypatch.setattr(config, "near_max", [-1.0, -1.0])
+    for p in config.roi_profiles:
+        p.spectral_unmixing = unmix
+    config.roi_profile.spectral_unmixing = unmix
+    profs = [dict(p, spectral_unmixing=unmix) for p in config.roi_profiles]
+    want, _ = mmo.detect_blobs_blocks(vol, None, profs, res, near_max=config.near_max, coloc=False)
+    _, _, blobs = stack_detect.detect_blobs_blocks("soak", stack_detect.Image5d(vol[None]), None, None, None,
+                                                   False, False, True, False)
+    srt = lambda t: t[np.lexsort(t.T[::-1])]       # noqa: E731
+    np.testing.assert_array_equal(srt(want), srt(g["want"]))
+    assert stack_detect.StackDetector.last_stats.n_probes > (1 << 24)        # the case the fix is about
+    np.testing.assert_array_equal(srt(blobs.blobs), srt(want))

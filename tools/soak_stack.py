@@ -14,6 +14,8 @@ from oracle import magmap_oracle as mmo
 ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=20)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--only", type=int, nargs="*", default=None, help="run only these trials of the sequence (same draws)")
+ap.add_argument("--dump", default=None, help="save volume, settings, both tables of mismatching trials to this .npz prefix")
 a = ap.parse_args()
 preprocess.RGB_GUESS = True          # like the oracle (scikit-image 0.18.3: see tools/soak_preproc.py)
 rng = np.random.default_rng(a.seed)
@@ -64,6 +66,8 @@ for trial in range(a.trials):
         p.spectral_unmixing = unmix
     config.roi_profile.spectral_unmixing = unmix
     profs = [dict(p, spectral_unmixing=unmix) for p in config.roi_profiles]
+    if a.only is not None and trial not in a.only:
+        continue
     try:
         want, st = mmo.detect_blobs_blocks(vol, None, profs, res, near_max=config.near_max, coloc=coloc)
     except (OverflowError, ValueError, ZeroDivisionError) as e:
@@ -92,6 +96,9 @@ for trial in range(a.trials):
         bad += 1
         print("MISMATCH trial", trial, shape, nch, res.tolist(), over, coloc, unmix,
               None if got is None else got.shape, None if want is None else want.shape, flush=True)
+        if a.dump:
+            np.savez_compressed(f"{a.dump}_{a.seed}_{trial}.npz", vol=vol, res=res, got=np.zeros(0) if got is None else got,
+                                want=np.zeros(0) if want is None else want, over=repr(over), coloc=coloc, unmix=repr(unmix))
 print(f"stack soak seed {a.seed}: {a.trials} trials, {rows} final blob rows compared, {bad} mismatching stacks, "
       f"{time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
