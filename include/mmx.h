@@ -53,6 +53,10 @@ typedef enum { MMX_U8 = 0, MMX_U16 = 1, MMX_F32 = 2, MMX_F64 = 3 } mmx_dtype;
  * (scipy/ndimage/_filters.py:313-315). */
 #define MMX_MAX_RADIUS_FAST 24
 #define MMX_MAX_RADIUS_GENERIC 255
+/* most blocks one call takes (a launch puts the block on grid.y): MMX_ERR_UNSUPPORTED beyond; callers split batches */
+#define MMX_MAX_BLOCKS 65535
+/* voxels of ball(2), the neighbourhood a blob can own in the intensity co-localisation */
+#define MMX_COLOC_BALL 33
 
 /* One block of a batch (device array of these is passed to the kernels). */
 typedef struct {
@@ -327,6 +331,13 @@ int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_su
 int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
                     const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
                     double* d_mean, int32_t* d_count, void* stream);
+/* The same, and the owned voxels themselves: d_voxels[n_blobs][MMX_COLOC_BALL] float64, the first d_count[b]
+ * entries of row b in the C order of the reference's boolean-mask selection -- what its percentile thresholds
+ * are taken over (`np.percentile(roi[mask >= 0, chl], thresh)`, magmap/cv/colocalizer.py:403-409).
+ * d_voxels may be NULL (then this is mmx_coloc_means). */
+int mmx_coloc_voxels(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
+                     const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
+                     double* d_mean, int32_t* d_count, double* d_voxels, void* stream);
 
 /* ---- U1: spectral unmixing ahead of detection
  * replaces: detector.detect_blobs' `roi_detect = np.subtract(roi_detect, fac * roi[..., k]);
@@ -434,7 +445,7 @@ int mmx_host_map_columns(const double* table, int64_t ld, int64_t n, const int32
 
 /* ---- match-based co-localisation: the two third-party calls of the reference's
  * verifier.find_closest_blobs_cdist (magmap/cv/verifier.py:47-119).
- * mmx_cdist_f64: d_out[i * m + j] = || a_i - b_j ||_2 for float64 points of `dim` (<= 8) coordinates -- replaces
+ * mmx_cdist_f64: d_out[i * m + j] = || a_i - b_j ||_2 for float64 points of `dim` (<= 64) coordinates -- replaces
  *   scipy.spatial.distance.cdist(a, b) (:85), same operation order, no FMA: bit-equal.  n <= 65535.
  * mmx_host_lsap: optimal assignment of a dense nr x nc float64 cost matrix (host memory) -- replaces
  *   scipy.optimize.linear_sum_assignment(dists) (:86): min(nr, nc) pairs in ascending row order, and where the

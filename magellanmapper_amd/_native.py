@@ -28,6 +28,8 @@ MMX_ZX_AUTO, MMX_ZX_SEPARATE, MMX_ZX_PACKED, MMX_ZX_MFMA_F32, MMX_ZX_MFMA_F16, M
 MMX_ZX_TILED, MMX_ZX_TILED_Q16, MMX_ZX_PREPACKED = 6, 7, 0x100
 #: NMS entry layouts ``mmx_log_batch_f32`` reports and ``mmx_peaks_batch`` takes
 MMX_MASK_ROWS, MMX_MASK_QUADS = 1, 2
+MMX_MAX_BLOCKS = 65535
+MMX_COLOC_BALL = 33
 
 #: NumPy mirror of ``mmx_block`` (32 bytes).
 BLOCK_DTYPE = np.dtype([("src_off", "<i8"), ("nz", "<i4"), ("ny", "<i4"), ("nx", "<i4"),
@@ -81,7 +83,7 @@ SYMBOLS = (
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
-    "mmx_coloc_means", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
+    "mmx_coloc_means", "mmx_coloc_voxels", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
     "mmx_cdist_f64", "mmx_host_lsap",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
@@ -157,6 +159,8 @@ def lib() -> ctypes.CDLL:
     L.mmx_host_lsap.restype = c_int
     L.mmx_coloc_means.argtypes = [POINTER(Volume), vp, c_int, vp, vp, c_int, vp, vp, vp]
     L.mmx_coloc_means.restype = c_int
+    L.mmx_coloc_voxels.argtypes = [POINTER(Volume), vp, c_int, vp, vp, c_int, vp, vp, vp, vp]
+    L.mmx_coloc_voxels.restype = c_int
     L.mmx_preprocess_batch.restype = c_int
     L.mmx_preprocess_batch_generic.restype = c_int
     for name in SYMBOLS:

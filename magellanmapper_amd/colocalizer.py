@@ -8,8 +8,9 @@ own blobs.  The per-blob means come from the device (``mmx_coloc_means``, bit-eq
 NumPy's summation order); thresholds and flags are a handful of NumPy reductions on the
 ``(n_blobs, n_channels)`` matrix.
 
-Only the default ``thresh="min"`` of the block path (``StackDetector.detect_sub_roi``,
-stack_detect.py:159-162) is built; a percentile threshold raises ``NotImplementedError``.
+The block path (``StackDetector.detect_sub_roi``, stack_detect.py:159-162) uses the default ``thresh="min"``;
+a number asks for that percentile of a channel's intensities over all voxels its own blobs own instead
+(:403-409): the device hands those voxels out (``mmx_coloc_voxels``), ``np.percentile`` takes it from there.
 
 Match-based co-localisation (reference :20-337, :444-501): :class:`BlobMatch`, :func:`colocalize_blobs_match`
 and :class:`StackColocalizer` pair the blobs of every two channels by optimal assignment on their distances
@@ -34,9 +35,11 @@ except ImportError:  # pragma: no cover
 from . import _native as nat
 
 
-def _flags_from_means(table: np.ndarray, means: np.ndarray, shape3, n_channels: int) -> np.ndarray:
+def _flags_from_means(table: np.ndarray, means: np.ndarray, shape3, n_channels: int,
+                      thresholds: Optional[Dict[int, float]] = None) -> np.ndarray:
     """Thresholds + flags of one block: ``means[b, c]`` = mean of channel ``c`` over blob ``b``'s
-    voxels (NaN when it owns none).  Rows outside the ROI get zeros (colocalizer.py:375-378, 434-436)."""
+    voxels (NaN when it owns none).  Rows outside the ROI get zeros (colocalizer.py:375-378, 434-436).
+    ``thresholds``: per-channel thresholds to use instead of the smallest mean of the channel's own blobs."""
     colocs = np.zeros((table.shape[0], n_channels), dtype=np.uint8)
     if table.shape[0] == 0:
         return colocs
@@ -48,9 +51,12 @@ def _flags_from_means(table: np.ndarray, means: np.ndarray, shape3, n_channels: 
         if other < 0 or other >= n_channels:
             raise IndexError(f"index {other} is out of bounds for axis 0 with size {n_channels}")
         own = in_roi & (chl == other)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            thr = np.amin(means[own, other])          # NaN (a blob that owns nothing) poisons it
+        if thresholds is not None:
+            thr = thresholds[int(other)]
+        else:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                thr = np.amin(means[own, other])      # NaN (a blob that owns nothing) poisons it
         hit = in_roi & np.isin(chl, present) & (means[:, other] >= thr)
         colocs[hit, other] = 1
     return colocs
@@ -58,13 +64,15 @@ def _flags_from_means(table: np.ndarray, means: np.ndarray, shape3, n_channels: 
 
 def colocalize_blocks_device(volumes: Dict[int, nat.Volume], blocks: np.ndarray, d_blocks,
                              shapes, tables: List[Optional[np.ndarray]], n_channels: int,
-                             dev, means_only: bool = False) -> List[Optional[np.ndarray]]:
+                             dev, means_only: bool = False, percentile=None) -> List[Optional[np.ndarray]]:
     """Flags for the tables of one batch of blocks.
 
     ``volumes[c]`` is the device view of image channel ``c`` (raw voxels or a preprocessed slot
     buffer) addressed through ``blocks[i].src_off``; channels without a view cannot have blobs.
     ``tables[i]`` is block ``i``'s 11-column table with block-relative coordinates (or ``None``).
     ``means_only`` returns the ``(rows, n_channels)`` mean matrices (NaN where not computed) instead.
+    ``percentile``: a channel's threshold is this percentile of its intensities over every voxel owned by one of
+    its own in-ROI blobs of the block (reference :403-409) instead of the smallest per-blob mean.
     """
     L = nat.lib()
     live = [i for i, t in enumerate(tables) if t is not None and len(t)]
@@ -89,14 +97,35 @@ def colocalize_blocks_device(volumes: Dict[int, nat.Volume], blocks: np.ndarray,
     d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
     means = np.full((n, n_channels), np.nan)
     stream = torch.cuda.current_stream().cuda_stream
+    owned: Dict[int, Tuple[np.ndarray, np.ndarray]] = {}
+    d_vox = torch.empty((n, nat.MMX_COLOC_BALL), dtype=torch.float64, device=dev) if percentile is not None else None
     for c, vol in sorted(volumes.items()):
-        nat.check(L.mmx_coloc_means(ctypes.byref(vol), d_blocks.data_ptr(), len(blocks), d_rows.data_ptr(),
-                                    d_off.data_ptr(), n, d_mean.data_ptr(), d_cnt.data_ptr(), stream),
-                  "mmx_coloc_means")
+        if d_vox is None:
+            nat.check(L.mmx_coloc_means(ctypes.byref(vol), d_blocks.data_ptr(), len(blocks), d_rows.data_ptr(),
+                                        d_off.data_ptr(), n, d_mean.data_ptr(), d_cnt.data_ptr(), stream),
+                      "mmx_coloc_means")
+        else:
+            nat.check(L.mmx_coloc_voxels(ctypes.byref(vol), d_blocks.data_ptr(), len(blocks), d_rows.data_ptr(),
+                                         d_off.data_ptr(), n, d_mean.data_ptr(), d_cnt.data_ptr(),
+                                         d_vox.data_ptr(), stream), "mmx_coloc_voxels")
+            owned[c] = (d_vox.cpu().numpy(), d_cnt.cpu().numpy())
         means[:, c] = d_mean.cpu().numpy()
     for i in live:
         a, b = offsets[i], offsets[i + 1]
-        out[i] = means[a:b] if means_only else _flags_from_means(tables[i], means[a:b], shapes[i], n_channels)
+        if means_only:
+            out[i] = means[a:b]
+            continue
+        thresholds = None
+        if percentile is not None:
+            t, shp = tables[i], shapes[i]
+            in_roi = np.all([t[:, k] >= 0 for k in range(3)] + [t[:, k] < shp[k] for k in range(3)], axis=0)
+            thresholds = {}
+            for c, (vox, cnt) in owned.items():
+                mine = np.flatnonzero(in_roi & (t[:, 6].astype(int) == c)) + a
+                if len(mine):        # (the channel's last blob always owns its own centre: never empty)
+                    vals = np.concatenate([vox[r, :cnt[r]] for r in mine])
+                    thresholds[c] = np.percentile(vals, percentile)
+        out[i] = _flags_from_means(tables[i], means[a:b], shapes[i], n_channels, thresholds)
     return out
 
 
@@ -105,21 +134,86 @@ def colocalize_blobs(roi, blobs: Optional[np.ndarray], thresh=None) -> Optional[
     from . import blob_log as bl
     if blobs is None or roi is None or len(roi.shape) < 4:
         return None
-    if thresh is not None and thresh != "min":
-        raise NotImplementedError("only the default thresh='min' is built on this path")
+    percentile = None if thresh is None or (isinstance(thresh, str) and thresh == "min") else float(thresh)
     dvol = roi if isinstance(roi, bl.DeviceVolume) else bl.DeviceVolume(roi)
     shape3 = tuple(dvol.shape[:3])
     blocks, _ = bl._make_blocks(dvol, 0, [(0, 0, 0)], [shape3])
     d_blocks = bl._to_device_bytes(blocks, dvol.tensor.device)
     volumes = {c: dvol.view(c, False) for c in range(dvol.n_channels)}
     return colocalize_blocks_device(volumes, blocks, d_blocks, [shape3], [np.asarray(blobs)],
-                                    dvol.n_channels, dvol.tensor.device)[0]
+                                    dvol.n_channels, dvol.tensor.device, percentile=percentile)[0]
 
 
 # ------------------------------------------------------------------------- match-based co-localisation
+class _PairTable:
+    """The rows of a :class:`BlobMatch` as arrays: ``first`` / ``second`` hold one blob row per match (the base
+    channel's blob and its partner), ``dist`` their distance, ``ids`` the optional id columns."""
+    __slots__ = ("first", "second", "dist", "ids")
+
+    ID_COLS = ("MatchID", "RoiID", "Blob1ID", "Blob2ID")
+
+    def __init__(self, first: np.ndarray, second: np.ndarray, dist: np.ndarray, ids: Optional[dict] = None):
+        self.dist = np.asarray(dist, dtype=np.float64).reshape(-1)
+        self.first = self._rows(first, len(self.dist))
+        self.second = self._rows(second, len(self.dist))
+        self.ids = {k: (None if v is None else list(v)) for k, v in (ids or {}).items()}
+
+    @staticmethod
+    def _rows(rows, n: int) -> np.ndarray:
+        rows = np.asarray(rows, dtype=np.float64)
+        if n == 0:
+            return np.zeros((0, rows.shape[1] if rows.ndim == 2 else 0))
+        return rows.reshape(n, -1)
+
+    def __len__(self) -> int:
+        return len(self.dist)
+
+    def take(self, rows: np.ndarray) -> "_PairTable":
+        rows = np.asarray(rows, dtype=np.int64)
+        ids = {k: (None if v is None else [v[i] for i in rows]) for k, v in self.ids.items()}
+        return _PairTable(self.first[rows], self.second[rows], self.dist[rows], ids)
+
+    @classmethod
+    def joined(cls, parts: Sequence["_PairTable"]) -> "_PairTable":
+        parts = [p for p in parts if p is not None and len(p)]
+        if not parts:
+            return cls(np.zeros((0, 0)), np.zeros((0, 0)), np.zeros(0))
+        ids = {}
+        for name in cls.ID_COLS:
+            if any(p.ids.get(name) is not None for p in parts):
+                ids[name] = [v for p in parts for v in (p.ids.get(name) or [None] * len(p))]
+        return cls(np.concatenate([p.first for p in parts]), np.concatenate([p.second for p in parts]),
+                   np.concatenate([p.dist for p in parts]), ids)
+
+    @classmethod
+    def from_frame(cls, frame) -> "_PairTable":
+        n = len(frame)
+        if n == 0 or "Blob1" not in frame or "Blob2" not in frame:
+            return cls(np.zeros((0, 0)), np.zeros((0, 0)), np.zeros(0))
+        ids = {name: frame[name].tolist() for name in cls.ID_COLS if name in frame}
+        dist = frame["Distance"].to_numpy(dtype=float) if "Distance" in frame else np.full(n, np.nan)
+        return cls(np.vstack(frame["Blob1"].tolist()), np.vstack(frame["Blob2"].tolist()), dist, ids)
+
+    def to_frame(self):
+        """The data frame the reference's consumers read: one row per match, the seven ``BlobMatch.Cols`` in
+        their order, blob rows as arrays; no columns at all without matches (what a frame made from an empty
+        dictionary looks like)."""
+        import pandas as pd
+        n = len(self)
+        if n == 0:
+            return pd.DataFrame()
+        none = [None] * n
+        ids = {name: (self.ids.get(name) or none) for name in self.ID_COLS}
+        return pd.DataFrame({"MatchID": ids["MatchID"], "RoiID": ids["RoiID"], "Blob1ID": ids["Blob1ID"],
+                             "Blob1": list(self.first), "Blob2ID": ids["Blob2ID"], "Blob2": list(self.second),
+                             "Distance": self.dist})
+
+
 class BlobMatch:
-    """Blob matches as a data frame (reference colocalizer.py:20-162): one row per match with the two blob rows
-    and their (scaled) distance; same column names as the reference so that its consumers read it."""
+    """Blob matches of one channel pair (the interface of the reference's class, colocalizer.py:20-162:
+    ``Cols``, ``df``, ``coords``, ``cmap``, ``get_blobs``, ``get_blobs_all``, ``update_blobs``,
+    ``get_mean_coords``).  The matches live in a :class:`_PairTable` of arrays; ``df`` renders them as the data
+    frame the reference keeps (same column names and order), and assigning a frame to ``df`` reads it back in."""
 
     class Cols(Enum):
         MATCH_ID = "MatchID"
@@ -131,58 +225,69 @@ class BlobMatch:
         DIST = "Distance"
 
     def __init__(self, matches=None, match_id=None, roi_id=None, blob1_id=None, blob2_id=None, df=None):
-        import pandas as pd
-        self.df = None
-        self.coords = None
-        self.cmap = None
-        if df is not None:
+        self.coords: Optional[np.ndarray] = None
+        self.cmap: Optional[np.ndarray] = None
+        self._pairs: Optional[_PairTable] = None
+        self._frame = None
+        if df is not None:                      # a frame wins over every other argument
             self.df = df
-            return
-        if matches is None:
-            return
-        n = len(matches)
-        ids = {BlobMatch.Cols.MATCH_ID: match_id, BlobMatch.Cols.ROI_ID: roi_id,
-               BlobMatch.Cols.BLOB1_ID: blob1_id, BlobMatch.Cols.BLOB2_ID: blob2_id}
-        data = {}
-        for col in BlobMatch.Cols:
-            if col in ids:
-                data[col.value] = [None] * n if ids[col] is None else list(ids[col])
-            else:
-                k = {BlobMatch.Cols.BLOB1: 0, BlobMatch.Cols.BLOB2: 1, BlobMatch.Cols.DIST: 2}[col]
-                data[col.value] = [m[k] for m in matches]
-        self.df = pd.DataFrame(data)
+        elif matches is not None:
+            triples = list(matches)
+            ids = dict(MatchID=match_id, RoiID=roi_id, Blob1ID=blob1_id, Blob2ID=blob2_id)
+            self._pairs = _PairTable([t[0] for t in triples], [t[1] for t in triples],
+                                     [t[2] for t in triples], ids)
 
-    def __repr__(self):
-        return "Empty blob matches" if self.df is None else repr(self.df)
-
-    def get_blobs(self, n: int) -> Optional[np.ndarray]:
-        col = BlobMatch.Cols.BLOB1 if n == 1 else BlobMatch.Cols.BLOB2
-        if self.df is None or col.value not in self.df or len(self.df[col.value]) == 0:
-            return None
-        return np.vstack(self.df[col.value])
-
-    def get_blobs_all(self) -> Optional[List[np.ndarray]]:
-        out = []
-        for n in (1, 2):
-            blobs = self.get_blobs(n)
-            if blobs is None:
-                return None
-            out.append(blobs)
+    @classmethod
+    def from_arrays(cls, blob1: np.ndarray, blob2: np.ndarray, dist: np.ndarray) -> "BlobMatch":
+        """Matches given as two equally long blob tables and their distances."""
+        out = cls()
+        out._pairs = _PairTable(blob1, blob2, dist)
         return out
 
+    @property
+    def pairs(self) -> Optional[_PairTable]:
+        return self._pairs
+
+    @property
+    def df(self):
+        if self._frame is None and self._pairs is not None:
+            self._frame = self._pairs.to_frame()
+        return self._frame
+
+    @df.setter
+    def df(self, frame):
+        self._frame = frame
+        self._pairs = None if frame is None else _PairTable.from_frame(frame)
+
+    def __len__(self) -> int:
+        return 0 if self._pairs is None else len(self._pairs)
+
+    def __repr__(self):
+        return "Empty blob matches" if self._pairs is None else repr(self.df)
+
+    def get_blobs(self, n: int) -> Optional[np.ndarray]:
+        """The blob rows of side ``n`` (1: the base channel's blobs, anything else: their partners); ``None``
+        without matches."""
+        if not len(self):
+            return None
+        return self._pairs.first if n == 1 else self._pairs.second
+
+    def get_blobs_all(self) -> Optional[List[np.ndarray]]:
+        return [self._pairs.first, self._pairs.second] if len(self) else None
+
     def update_blobs(self, fn, *args):
-        if self.df is None:
+        """Replace both sides' blob rows by ``fn(rows, *args)``."""
+        if not len(self):
             return
-        for i, col in enumerate((BlobMatch.Cols.BLOB1, BlobMatch.Cols.BLOB2)):
-            blobs = self.get_blobs(i + 1)
-            if blobs is not None:
-                self.df[col.value] = fn(blobs, *args).tolist()
+        self._pairs.first = np.asarray(fn(self._pairs.first, *args), dtype=np.float64)
+        self._pairs.second = np.asarray(fn(self._pairs.second, *args), dtype=np.float64)
+        self._frame = None
 
     def get_mean_coords(self):
-        blobs = self.get_blobs_all()
-        if blobs is None:
+        """``(n, 3)`` midpoints of the matched pairs (also kept in ``coords``); ``None`` without matches."""
+        if not len(self):
             return None
-        self.coords = np.mean([b[:, :3] for b in blobs], axis=0)
+        self.coords = (self._pairs.first[:, :3] + self._pairs.second[:, :3]) / 2
         return self.coords
 
 
@@ -190,30 +295,48 @@ def colocalize_blobs_match(blobs, offset: Sequence[int], size: Sequence[int], to
                            inner_padding: Optional[Sequence[int]] = None,
                            channels: Optional[Sequence[int]] = None) -> Optional[Dict[Tuple[int, int], BlobMatch]]:
     """Pair the blobs of every two channels inside one ROI (``offset`` / ``size`` / ``tol`` in x, y, z) by
-    optimal assignment -> ``{(channel, other channel): BlobMatch}``, ``None`` without blobs
-    (reference colocalizer.py:444-501)."""
+    optimal assignment -> ``{(channel, higher channel): BlobMatch}``, ``None`` without blobs
+    (reference colocalizer.py:444-501).  The lower channel is the base side of each pair; the matched rows come
+    back with their confirmed / truth flags reset to -1."""
+    from itertools import combinations
     from . import verifier
     if blobs is None:
         return None
-    thresh, scaling, inner_pad, resize, blobs_roi = verifier.setup_match_blobs_roi(tol, blobs)
-    if inner_padding is None:
-        inner_padding = inner_pad
-    matches_chls = {}
-    blob_chls = np.unique(blobs.get_blobs_channel(blobs_roi)).astype(int)
+    thresh, scaling, default_padding, resize, table = verifier.setup_match_blobs_roi(tol, blobs)
+    padding = default_padding if inner_padding is None else inner_padding
+    present = [int(c) for c in np.unique(blobs.get_blobs_channel(table))]
     if channels is not None:
-        blob_chls = [c for c in blob_chls if c in channels]
-    for chl in blob_chls:
-        blobs_chl = blobs.blobs_in_channel(blobs_roi, chl)
-        for chl_other in blob_chls:
-            if chl >= chl_other:          # each pair once
-                continue
-            blobs_chl_other = blobs.blobs_in_channel(blobs_roi, chl_other)
-            matches = verifier.match_blobs_roi(blobs_chl_other, blobs_chl, offset, size, thresh, scaling,
-                                               inner_padding, resize)[4]
-            matches.update_blobs(blobs.set_blob_truth, -1)
-            matches.update_blobs(blobs.set_blob_confirmed, -1)
-            matches_chls[(int(chl), int(chl_other))] = matches
-    return matches_chls
+        present = [c for c in present if c in channels]
+    per_channel = {c: blobs.blobs_in_channel(table, c) for c in present}
+    out: Dict[Tuple[int, int], BlobMatch] = {}
+    for low, high in combinations(present, 2):           # ascending channels: (0, 1), (0, 2), (1, 2) ...
+        found = verifier.match_blobs_roi(per_channel[high], per_channel[low], offset, size, thresh, scaling,
+                                         padding, resize)[4]
+        found.update_blobs(blobs.set_blob_truth, -1)
+        found.update_blobs(blobs.set_blob_confirmed, -1)
+        out[(low, high)] = found
+    return out
+
+
+def _keep_shortest(pairs: _PairTable, side: str) -> _PairTable:
+    """Blobs of one ``side`` (``"first"`` / ``"second"``) that appear in several matches -- found again in a
+    neighbouring block, or paired with different partners there -- keep the shortest one, the earliest of equally
+    short ones.  Row order as the reference leaves it (colocalizer.py:301-331): untouched when nothing repeats,
+    otherwise the blobs matched once in ascending z, y, x, then the repeated ones in ascending z, y, x."""
+    zyx = getattr(pairs, side)[:, :3]
+    n = len(zyx)
+    by_pos = np.lexsort((np.arange(n), zyx[:, 2], zyx[:, 1], zyx[:, 0]))          # position, then table order
+    srt = zyx[by_pos]
+    starts = np.flatnonzero(np.concatenate(([True], np.any(srt[1:] != srt[:-1], axis=1))))
+    sizes = np.diff(np.append(starts, n))
+    if sizes.max(initial=1) <= 1:
+        return pairs
+    group = np.repeat(np.arange(len(starts)), sizes)            # group of every sorted row
+    # inside a group: shortest distance first, table order among equals
+    by_len = np.lexsort((by_pos, pairs.dist[by_pos], group))
+    best = by_pos[by_len[starts]]                                 # (groups keep their start after the re-sort)
+    once = sizes == 1
+    return pairs.take(np.concatenate((best[once], best[~once])))
 
 
 class StackColocalizer:
@@ -226,51 +349,42 @@ class StackColocalizer:
 
     @classmethod
     def colocalize_block(cls, coord, offset, shape, blobs=None, tol=None, setup_cli: bool = False, channels=None):
+        """One block (``offset`` / ``shape`` in z, y, x) -> ``(coord, {channel pair: BlobMatch})``; arguments left
+        ``None`` fall back to the class attributes, as in the reference's worker."""
         blobs = cls.blobs if blobs is None else blobs
         tol = cls.match_tol if tol is None else tol
         channels = cls.channels if channels is None else channels
-        matches = colocalize_blobs_match(blobs, offset[::-1], shape[::-1], tol, channels=channels)
-        return coord, matches
+        return coord, colocalize_blobs_match(blobs, offset[::-1], shape[::-1], tol, channels=channels)
 
     @classmethod
     def colocalize_stack(cls, shape: Sequence[int], blobs, channels: Optional[Sequence[int]] = None
                          ) -> Dict[Tuple[int, int], BlobMatch]:
-        """``{(channel, other channel): BlobMatch}`` for the stack of ``shape`` (z, y, x)."""
-        import pandas as pd
+        """``{(channel, higher channel): BlobMatch}`` for the stack of ``shape`` (z, y, x)."""
         from concurrent.futures import ThreadPoolExecutor
         from . import chunking, config, stack_detect, verifier
-        blocks = stack_detect.setup_blocks(config.roi_profile, shape)
-        match_tol = np.multiply(blocks.overlap_base, config.roi_profile["verify_tol_factor"])
-        # blocks with the inner padding of the matcher on top of the raw overlap
-        inner_pad = np.add(verifier.setup_match_blobs_roi(match_tol)[2], blocks.overlap_base)
-        sub_roi_slices, sub_rois_offsets = chunking.stack_splitter(shape, blocks.max_pixels, inner_pad[::-1])
-        jobs = []
-        for coord in np.ndindex(*sub_roi_slices.shape):
-            slices = sub_roi_slices[coord]
-            jobs.append((coord, sub_rois_offsets[coord], [s.stop - s.start for s in slices]))
-        workers = max(1, int(config.cpus or 1))
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            results = list(pool.map(lambda j: cls.colocalize_block(j[0], j[1], j[2], blobs, match_tol, False,
-                                                                   channels), jobs))
-        matches_all: Dict[Tuple[int, int], list] = {}
-        for _, matches in results:                       # block order, as the reference collects them
-            for key, val in matches.items():
-                matches_all.setdefault(key, []).append(val.df)
-        # blobs matched in several blocks (or to several partners) keep their shortest match, first of equals
-        for key in matches_all:
-            matches = pd.concat(matches_all[key])
-            if matches.size > 0:
-                for blobi in (BlobMatch.Cols.BLOB1, BlobMatch.Cols.BLOB2):
-                    coords = np.vstack(matches[blobi.value])[:, :3]
-                    _, first, inv, counts = np.unique(coords, axis=0, return_index=True, return_inverse=True,
-                                                      return_counts=True)
-                    inv = np.asarray(inv).reshape(-1)
-                    if np.sum(counts > 1) > 0:
-                        dist = matches[BlobMatch.Cols.DIST.value].to_numpy()
-                        keep = list(first[counts == 1])
-                        for i in np.nonzero(counts > 1)[0]:
-                            rows = np.nonzero(inv == i)[0]
-                            keep.append(rows[dist[rows] == np.amin(dist[rows])][0])
-                        matches = matches.iloc[np.asarray(keep, dtype=int)]
-            matches_all[key] = BlobMatch(df=matches)
-        return matches_all
+        geometry = stack_detect.setup_blocks(config.roi_profile, shape)
+        tol = np.multiply(geometry.overlap_base, config.roi_profile["verify_tol_factor"])
+        # the stack is cut again: blocks overlap by the matcher's inner padding on top of the detection overlap
+        reach = np.add(verifier.setup_match_blobs_roi(tol)[2], geometry.overlap_base)
+        cuts, corners = chunking.stack_splitter(shape, geometry.max_pixels, reach[::-1])
+
+        def work(coord):
+            extent = [s.stop - s.start for s in cuts[coord]]
+            return cls.colocalize_block(coord, corners[coord], extent, blobs, tol, False, channels)[1]
+
+        with ThreadPoolExecutor(max_workers=max(1, int(config.cpus or 1))) as pool:
+            per_block = list(pool.map(work, list(np.ndindex(*cuts.shape))))       # grid order, z slowest
+        gathered: Dict[Tuple[int, int], list] = {}
+        for found in per_block:
+            for pair, match in (found or {}).items():
+                gathered.setdefault(pair, []).append(match.pairs)
+        out = {}
+        for pair, parts in gathered.items():
+            table = _PairTable.joined(parts)
+            for side in ("first", "second"):
+                if len(table):
+                    table = _keep_shortest(table, side)
+            match = BlobMatch()
+            match._pairs = table
+            out[pair] = match
+        return out

@@ -181,6 +181,7 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
         return MMX_ERR_ARG;
     if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
+    if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     if (radius > MMX_MAX_RADIUS_GENERIC) return MMX_ERR_UNSUPPORTED;
     if (slot_elems >= (int64_t(1) << 29)) return MMX_ERR_UNSUPPORTED;  // 32-bit byte offsets in a slot
     if (slot_elems % MMX_ROW_ALIGN) return MMX_ERR_ARG;
@@ -344,6 +345,7 @@ int mmx_log_batch_f32_generic(const mmx_volume* vol, const mmx_block* d_blocks, 
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
         return MMX_ERR_ARG;
     if (n_blocks < 1 || radius < 0 || radius > MMX_MAX_RADIUS_GENERIC || slot_elems < 1) return MMX_ERR_ARG;
+    if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     double in_scale = 1.0;
     if (vol->dtype == MMX_U8) in_scale = 1.0 / 255.0;
     else if (vol->dtype == MMX_U16) in_scale = 1.0 / 65535.0;
@@ -377,6 +379,7 @@ int mmx_zx_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_bloc
                 int64_t slot_elems, float* d_work, void* stream)
 {
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !d_work || n_blocks < 1 || slot_elems < 1) return MMX_ERR_ARG;
+    if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     if (vol->dtype != MMX_U8 && vol->dtype != MMX_U16) return MMX_ERR_UNSUPPORTED;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
@@ -398,6 +401,7 @@ int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int mask_lay
 {
     if (!d_log || !d_blocks || !h_blocks || !d_cands || !d_count) return MMX_ERR_ARG;
     if (n_sigma < 1 || n_blocks < 1 || slot_elems < 1 || !(eps >= 0.f)) return MMX_ERR_ARG;
+    if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     if (slot_elems % MMX_ROW_ALIGN) return MMX_ERR_ARG;
     if (d_nms_mask && mask_layout != MMX_MASK_ROWS && mask_layout != MMX_MASK_QUADS) return MMX_ERR_ARG;
     int max_vox = 0;

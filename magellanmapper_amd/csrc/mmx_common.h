@@ -7,6 +7,7 @@
 #include "../../include/mmx.h"
 
 #define MMX_WG 256  // workgroup size used by the streaming kernels (4 waves of 64)
+#define MMX_MAX_GRID_X 2147483647  // workgroups along x of one launch
 
 // Half kernels (index k = distance from the centre tap) passed BY VALUE in the
 // kernarg segment, so that with a fully unrolled tap loop every weight is a scalar

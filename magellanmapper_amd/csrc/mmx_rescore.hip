@@ -68,7 +68,9 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     // (one workgroup per point; the grid is two-dimensional because grid.x * 256 threads must stay below 2^32:
     //  a batch whose candidates sit on a plateau -- spectral unmixing clips whole regions to 0 -- asks for the
     //  80 neighbours of several 10^5 candidates, > 16.7 M points in one call)
-    const uint32_t idx = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint64_t idx64 = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;      // (cap near 2^32: no 32-bit wrap)
+    if (idx64 >= cap) return;
+    const uint32_t idx = (uint32_t)idx64;
     if (idx >= n) return;
     const mmx_cand pt = pts[idx];
     if (pt.slot < 0 || pt.slot >= prm.n_blocks) return;
@@ -162,9 +164,9 @@ int launch(const mmx_volume* vol, const mmx_block* d_blocks, mmx_cand* d_pts, ui
            const mmx_rescore_params& prm, size_t lds, hipStream_t s)
 {
     const uint32_t gx = cap < (1u << 22) ? cap : (1u << 22);
-    const uint32_t gy = (cap + gx - 1) / gx;
+    const uint64_t gy = ((uint64_t)cap + gx - 1) / gx;
     if (gy > 65535u) return MMX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((rescore_kernel<InT, StoreT>), dim3(gx, gy), dim3(MMX_WG), lds, s,
+    hipLaunchKernelGGL((rescore_kernel<InT, StoreT>), dim3(gx, (uint32_t)gy), dim3(MMX_WG), lds, s,
                        (const InT*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_blocks,
                        d_pts, cap, d_count, d_w0, d_w2, prm);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;

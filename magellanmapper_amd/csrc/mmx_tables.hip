@@ -132,6 +132,7 @@ extern "C" int mmx_overlap_pairs(const double* d_blobs, const int32_t* d_offsets
                                  uint32_t cap, uint32_t* d_count, void* stream)
 {
     if (!d_blobs || !d_offsets || !d_pairs || !d_frac || !d_count || n_blocks < 1 || !(max_sigma > 0)) return MMX_ERR_ARG;
+    if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     dim3 grid(8, n_blocks);
     mmx_timed_scope ts(MMX_K_PAIRS, (hipStream_t)stream);
     hipLaunchKernelGGL(overlap_pairs_kernel, grid, dim3(MMX_WG), 0, (hipStream_t)stream, d_blobs, d_offsets,
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(64)
 coloc_means_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
                    const mmx_block* __restrict__ blocks, const int32_t* __restrict__ blobs,
                    const int32_t* __restrict__ offsets, int n_blobs, double* __restrict__ mean,
-                   int32_t* __restrict__ count)
+                   int32_t* __restrict__ count, double* __restrict__ voxels)
 {
     __shared__ double vals[33];
     const int b = blockIdx.x;
@@ -223,6 +224,8 @@ coloc_means_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t 
         vals[rank] = (double)vol[bd.src_off + vz * sz + vy * sy + vx * sx];
     }
     __syncthreads();
+    // (optional) the owned voxels themselves, in the selection's C order: percentile thresholds
+    if (voxels && lane < n) voxels[(int64_t)b * MMX_COLOC_BALL + lane] = vals[lane];
     if (lane == 0) {
         double res;
         if (n < 8) {
@@ -243,20 +246,21 @@ coloc_means_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t 
 }
 }  // namespace
 
-extern "C" int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
-                               const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
-                               double* d_mean, int32_t* d_count, void* stream)
+extern "C" int mmx_coloc_voxels(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
+                                const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
+                                double* d_mean, int32_t* d_count, double* d_voxels, void* stream)
 {
     if (!vol || !vol->d_data || !d_blocks || n_blocks < 1 || !d_blobs || !d_offsets || n_blobs < 0 ||
         !d_mean || !d_count)
         return MMX_ERR_ARG;
     if (n_blobs == 0) return MMX_OK;
+    if (n_blobs > MMX_MAX_GRID_X) return MMX_ERR_UNSUPPORTED;      // one workgroup per blob, one-dimensional grid
     hipStream_t s = (hipStream_t)stream;
     mmx_timed_scope ts(MMX_K_COLOC, s);
 #define MMX_COLOC_LAUNCH(T)                                                                              \
     hipLaunchKernelGGL(coloc_means_kernel<T>, dim3(n_blobs), dim3(64), 0, s, (const T*)vol->d_data,        \
                        vol->stride_z, vol->stride_y, vol->stride_x, d_blocks, d_blobs, d_offsets, n_blobs, \
-                       d_mean, d_count)
+                       d_mean, d_count, d_voxels)
     switch (vol->dtype) {
         case MMX_U8: MMX_COLOC_LAUNCH(uint8_t); break;
         case MMX_U16: MMX_COLOC_LAUNCH(uint16_t); break;
@@ -266,6 +270,13 @@ extern "C" int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks,
     }
 #undef MMX_COLOC_LAUNCH
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
+
+extern "C" int mmx_coloc_means(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
+                               const int32_t* d_blobs, const int32_t* d_offsets, int n_blobs,
+                               double* d_mean, int32_t* d_count, void* stream)
+{
+    return mmx_coloc_voxels(vol, d_blocks, n_blocks, d_blobs, d_offsets, n_blobs, d_mean, d_count, nullptr, stream);
 }
 
 // ---- spectral unmixing ahead of detection (magmap/cv/detector.py:910-921): for the detected channel
@@ -313,7 +324,7 @@ extern "C" int mmx_unmix_batch(const mmx_volume* vol, const mmx_volume* h_subs, 
     if (!vol || !vol->d_data || (n_subs && (!h_subs || !h_facs)) || n_subs < 0 || !d_blocks || !h_blocks ||
         n_blocks < 1 || !d_out32 || !d_out64)
         return MMX_ERR_ARG;
-    if (n_subs > MMX_UNMIX_MAX) return MMX_ERR_UNSUPPORTED;
+    if (n_subs > MMX_UNMIX_MAX || n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     unmix_args U;
     memset(&U, 0, sizeof U);
     U.n_subs = n_subs;
@@ -523,10 +534,11 @@ extern "C" int mmx_minmax_batch(const mmx_volume* vol, const mmx_block* d_blocks
                                 int n_blocks, double* d_minmax, void* stream)
 {
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || n_blocks < 1 || !d_minmax) return MMX_ERR_ARG;
+    if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     int64_t max_rows = 1;
     for (int i = 0; i < n_blocks; ++i)
         max_rows = std::max<int64_t>(max_rows, (int64_t)h_blocks[i].nz * h_blocks[i].ny);
-    if (max_rows >= (int64_t(1) << 30)) return MMX_ERR_UNSUPPORTED;
+    if (max_rows >= (int64_t(1) << 30) || n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     // 16 rows per wave: few enough atomics, enough workgroups (4 waves each) to fill the chip
     dim3 grid((unsigned)std::min<int64_t>((max_rows + 63) / 64, 4096), (unsigned)n_blocks);
@@ -601,7 +613,7 @@ extern "C" int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_bl
     int64_t max_rows = 1;
     for (int i = 0; i < n_blocks; ++i)
         max_rows = std::max<int64_t>(max_rows, (int64_t)h_blocks[i].nz * h_blocks[i].ny);
-    if (max_rows >= (int64_t(1) << 30)) return MMX_ERR_UNSUPPORTED;
+    if (max_rows >= (int64_t(1) << 30) || n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)std::min<int64_t>((max_rows + 15) / 16, 65535), (unsigned)n_blocks);
     mmx_timed_scope ts(MMX_K_GENERIC, s);
@@ -655,6 +667,7 @@ extern "C" int mmx_resize_batch_as(const mmx_volume* vol, const mmx_resize_block
         if ((int64_t)b.out_nz * b.out_ny >= (int64_t(1) << 31)) return MMX_ERR_UNSUPPORTED;
         max_rows = std::max<int64_t>(max_rows, (int64_t)b.out_nz * b.out_ny);
     }
+    if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     // 16 rows per wave: the per-wave set-up (block record, x tables) is three dependent memory round trips
     dim3 grid((unsigned)std::min<int64_t>((max_rows + 16 * (MMX_WG / 64) - 1) / (16 * (MMX_WG / 64)), 65535), (unsigned)n_blocks);
@@ -741,7 +754,7 @@ cdist_kernel(const double* __restrict__ a, int64_t n, const double* __restrict__
 extern "C" int mmx_cdist_f64(const double* d_a, int64_t n, const double* d_b, int64_t m, int dim, double* d_out,
                              void* stream)
 {
-    if (n < 0 || m < 0 || dim < 1 || dim > 8) return MMX_ERR_ARG;
+    if (n < 0 || m < 0 || dim < 1 || dim > 64) return MMX_ERR_ARG;    // (whole blob rows are 8 - 16 values wide)
     if (n == 0 || m == 0) return MMX_OK;
     if (!d_a || !d_b || !d_out || n > 65535) return n > 65535 ? MMX_ERR_UNSUPPORTED : MMX_ERR_ARG;
     mmx_timed_scope ts(MMX_K_COLOC, (hipStream_t)stream);

@@ -407,6 +407,15 @@ def coloc_cases():
     case("outside", vol, outside, roi_key="two_roi")
     case("f64", vol.astype(np.float64) / 65535.0 * 1.7 + 0.2, blobs, roi_key="two_roi:f64")
     case("single", vol[..., 0], blobs, roi_key="two_roi:ch0")         # 3-D ROI -> None
+    # percentile thresholds (colocalizer.py:403-409): a channel's threshold is a percentile of its intensities over
+    # every voxel its own blobs own
+    case("two_p5", vol, blobs, 5, roi_key="two_roi")
+    case("two_p50", vol, blobs, 50, roi_key="two_roi")
+    case("three_p99", vol3, blobs3, 99.5, roi_key="three_roi")
+    case("sel1_p20", vol3, quiet(detector.detect_blobs, vol3, [1]), 20, roi_key="three_roi")
+    case("crowd_p30", vol, crowd, 30, roi_key="two_roi")
+    case("outside_p5", vol, outside, 5, roi_key="two_roi")
+    case("f64_p42", vol.astype(np.float64) / 65535.0 * 1.7 + 0.2, blobs, 42.5, roi_key="two_roi:f64")
     out["names"] = np.array(names)
     out["versions"] = repr(VERSIONS)
     np.savez_compressed(os.path.join(HERE, "coloc.npz"), **out)
@@ -507,6 +516,8 @@ def main():
     print("versions:", VERSIONS)
     if sys.argv[1:] == ["preproc"]:       # only the preprocessing fixtures (added later)
         return main_preproc()
+    if sys.argv[1:] == ["coloc_cases"]:   # only coloc.npz (percentile cases added later)
+        return coloc_cases()
     if sys.argv[1:] == ["coloc"]:         # only the co-localisation fixtures (added later)
         return main_coloc()
     if sys.argv[1:] == ["image5d"]:       # only the on-disk image fixtures (added later)
@@ -765,6 +776,33 @@ def match_cases():
             out["roi%d_%d_%d_dist" % (k, *key)] = np.array(df["Distance"], dtype=float) if nrow else np.empty(0)
     out["roi_table"] = table
     out["roi_tol"] = tol
+    # ---- verifier.match_blobs_roi itself (all five outputs, flags as it leaves them): anisotropic tolerances, a
+    # core smaller than the default padding allows, base blobs whose truth flag is already 0 / 1 outside the core
+    flagged = table.copy()
+    rng2 = np.random.default_rng(77)
+    flagged[:, 5] = rng2.integers(-1, 2, len(flagged))
+    flagged[:, 4] = rng2.integers(-1, 2, len(flagged))
+    mspecs = (((0, 0, 0), (64, 60, 40), (5.0, 5.0, 5.0), table, 1, 0),
+              ((6, 4, 2), (50, 40, 30), (7.0, 5.0, 3.0), flagged, 2, 0),
+              ((20, 20, 10), (9, 7, 5), (5.0, 5.0, 5.0), flagged, 2, 1),
+              ((0, 0, 0), (64, 60, 40), (2.0, 2.0, 2.0), flagged, 1, 2))
+    for k, (offset, size, mtol, tbl, chl_det, chl_base) in enumerate(mspecs):
+        thresh, scaling, pad, _, _ = quiet(verifier.setup_match_blobs_roi, np.array(mtol))
+        det = tbl[tbl[:, 6] == chl_det]
+        base = tbl[tbl[:, 6] == chl_base]
+        got = quiet(verifier.match_blobs_roi, det.copy(), base.copy(), offset, size, thresh, scaling, pad)
+        df = got[4].df
+        nrow = 0 if df is None else len(df)
+        out.update({"mroi%d_det" % k: det, "mroi%d_base" % k: base, "mroi%d_offset" % k: np.array(offset),
+                    "mroi%d_size" % k: np.array(size), "mroi%d_tol" % k: np.array(mtol),
+                    "mroi%d_inner_plus" % k: got[0], "mroi%d_truth_inner_plus" % k: got[1],
+                    "mroi%d_offset_inner" % k: np.asarray(got[2], dtype=float),
+                    "mroi%d_size_inner" % k: np.asarray(got[3], dtype=float),
+                    "mroi%d_blob1" % k: np.vstack(df["Blob1"]) if nrow else np.empty((0, 8)),
+                    "mroi%d_blob2" % k: np.vstack(df["Blob2"]) if nrow else np.empty((0, 8)),
+                    "mroi%d_dist" % k: np.array(df["Distance"], dtype=float) if nrow else np.empty(0)})
+        print("match_blobs_roi %d: %d matches, inner+ %s, truth+ %s" % (k, nrow, got[0].shape, got[1].shape))
+    out["n_mroi"] = np.array(len(mspecs))
     # ---- whole stack: larger-overlap block split, per-block matching, shortest-distance de-duplication
     for name, shape, n, n_chl, seg, res in (("stackA", (48, 120, 128), 700, 2, 40, (1., 1., 1.)),
                                             ("stackB", (40, 100, 96), 400, 3, 36, (2.0, 0.8, 0.8))):

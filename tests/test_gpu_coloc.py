@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from test_oracle_golden import COLOC, coloc_roi
+from test_oracle_golden import COLOC, coloc_roi, coloc_thresh
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ def gpu():
 @pytest.mark.parametrize("case", [str(n) for n in COLOC["names"]])
 def test_colocalize_blobs_matches_reference(gpu, case):
     from magellanmapper_amd import colocalizer
-    got = colocalizer.colocalize_blobs(coloc_roi(COLOC, case), COLOC[case + "_blobs"])
+    got = colocalizer.colocalize_blobs(coloc_roi(COLOC, case), COLOC[case + "_blobs"], coloc_thresh(COLOC, case))
     want = COLOC[case + "_colocs"]
     if want.shape[0] == 0:
         assert got is None
@@ -142,6 +142,18 @@ def test_find_closest_blobs_cdist_matches_reference(gpu):
         np.testing.assert_array_equal(rows, g["lsap%d_rows" % k])
         np.testing.assert_array_equal(cols, g["lsap%d_cols" % k])
         np.testing.assert_array_equal(dists, g["lsap%d_dists" % k])
+
+
+def test_match_blobs_roi_matches_reference(gpu):
+    """All five outputs of ``verifier.match_blobs_roi`` (flags as the reference leaves them) with the device distance
+    matrix: anisotropic tolerances, a tiny ROI, base blobs flagged 0 / 1 outside the core."""
+    from test_host_logic import _check_match_blobs_roi
+    from magellanmapper_amd import detector, verifier
+    _match_config(40)
+    try:
+        _check_match_blobs_roi(load_golden("match.npz"), verifier)
+    finally:
+        detector.Blobs(np.ones((1, 4))).format_blobs()
 
 
 def test_colocalize_blobs_match_matches_reference(gpu):

@@ -355,7 +355,7 @@ def test_stack_level_prune_from_golden_block_tables(monkeypatch):
 
 def test_unbuilt_rows_fail_loudly():
     from magellanmapper_amd import colocalizer
-    with pytest.raises(NotImplementedError):       # percentile thresholds of the intensity co-localisation
+    with pytest.raises(_native.MmxError):          # percentile thresholds are built: no GPU -> loud failure, no fallback
         colocalizer.colocalize_blobs(np.zeros((4, 4, 4, 2), np.uint16), np.zeros((1, 11)), thresh=50)
     assert colocalizer.colocalize_blobs(np.zeros((4, 4, 4), np.uint16), np.zeros((1, 11))) is None
     from magellanmapper_amd import preprocess
@@ -586,6 +586,67 @@ def test_native_assignment_solver_returns_scipys_optimum():
         np.testing.assert_array_equal(rows, want[0])
         np.testing.assert_array_equal(cols, want[1])
     assert _native.lib().mmx_host_lsap(np.array([[np.nan]]).ctypes.data, 1, 1, None, None) == 1
+
+
+def _check_match_blobs_roi(g, verifier):
+    """``verifier.match_blobs_roi`` against the real function's five outputs (tests/golden/match.npz, ``mroi*``)."""
+    for k in range(int(g["n_mroi"])):
+        thresh, scaling, pad, _, _ = verifier.setup_match_blobs_roi(g["mroi%d_tol" % k])
+        det, base = g["mroi%d_det" % k].copy(), g["mroi%d_base" % k].copy()
+        got = verifier.match_blobs_roi(det, base, tuple(g["mroi%d_offset" % k]), tuple(g["mroi%d_size" % k]),
+                                       thresh, scaling, pad)
+        np.testing.assert_array_equal(got[0], g["mroi%d_inner_plus" % k])
+        np.testing.assert_array_equal(got[1], g["mroi%d_truth_inner_plus" % k])
+        np.testing.assert_array_equal(np.asarray(got[2], dtype=float), g["mroi%d_offset_inner" % k])
+        np.testing.assert_array_equal(np.asarray(got[3], dtype=float), g["mroi%d_size_inner" % k])
+        pairs = got[4].pairs
+        np.testing.assert_array_equal(pairs.first.reshape(-1, 8), g["mroi%d_blob1" % k])
+        np.testing.assert_array_equal(pairs.second.reshape(-1, 8), g["mroi%d_blob2" % k])
+        np.testing.assert_array_equal(pairs.dist, g["mroi%d_dist" % k])
+        # the caller's tables are not written to (the reference works on copies too)
+        np.testing.assert_array_equal(det, g["mroi%d_det" % k])
+        np.testing.assert_array_equal(base, g["mroi%d_base" % k])
+
+
+def test_match_logic_on_the_host(monkeypatch):
+    """The row-number bookkeeping of ``verifier.match_blobs_roi``, ``colocalizer.colocalize_blobs_match`` and the
+    shortest-match de-duplication of ``StackColocalizer`` against fixtures from the real reference, with SciPy's
+    ``cdist`` standing in for the device distance matrix (``mmx_cdist_f64`` is bit-equal to it, checked on the GPU);
+    the native assignment solver is the product's."""
+    from scipy.spatial import distance
+    from conftest import load_golden
+    from magellanmapper_amd import colocalizer, detector, verifier
+    monkeypatch.setattr(verifier, "_cdist", lambda a, b: distance.cdist(a, b) if len(a) and len(b)
+                        else np.zeros((len(a), len(b))))
+    g = load_golden("match.npz")
+    config.setup_roi_profiles(None)
+    config.cpus = 2
+    try:
+        _check_match_blobs_roi(g, verifier)
+        for name in ("stackA", "stackB"):
+            config.roi_profile.update(segment_size=int(g[name + "_segment_size"]), num_sigma=3, denoise_size=None)
+            config.resolutions = np.array([tuple(g[name + "_res"])])
+            blobs = detector.Blobs(g[name + "_table"].copy())
+            got = colocalizer.StackColocalizer.colocalize_stack(tuple(int(v) for v in g[name + "_shape"]), blobs)
+            assert sorted(got) == [tuple(int(v) for v in key) for key in g[name + "_keys"]]
+            for key, bm in got.items():
+                df = bm.df
+                assert list(df.columns) == [c.value for c in colocalizer.BlobMatch.Cols]
+                np.testing.assert_array_equal(np.vstack(df["Blob1"]), g["%s_%d_%d_blob1" % (name, *key)])
+                np.testing.assert_array_equal(np.vstack(df["Blob2"]), g["%s_%d_%d_blob2" % (name, *key)])
+                np.testing.assert_array_equal(df["Distance"].to_numpy(), g["%s_%d_%d_dist" % (name, *key)])
+                # a frame handed back in is read into the same table
+                again = colocalizer.BlobMatch(df=df)
+                np.testing.assert_array_equal(again.get_blobs(2), bm.get_blobs(2))
+                np.testing.assert_array_equal(again.get_mean_coords(), bm.get_mean_coords())
+        empty = colocalizer.BlobMatch([])
+        assert empty.get_blobs(1) is None and empty.get_blobs_all() is None and len(empty.df) == 0
+        assert colocalizer.BlobMatch().df is None and repr(colocalizer.BlobMatch()) == "Empty blob matches"
+        bm = colocalizer.BlobMatch([(np.arange(8.), np.arange(8.) + 1, 1.5)], match_id=[7])
+        assert bm.df["MatchID"].tolist() == [7] and bm.df["RoiID"].tolist() == [None]
+    finally:
+        config.resolutions = np.array([[1.0, 1.0, 1.0]])
+        detector.Blobs(np.ones((1, 4))).format_blobs()
 
 
 def test_plan_batches_ramp_and_taper():

@@ -254,11 +254,17 @@ def coloc_roi(g, case):
     return roi
 
 
+def coloc_thresh(g, case):
+    """The case's ``thresh`` argument: ``None`` (stored as -1: the minimum mean) or a percentile."""
+    t = float(g[case + "_thresh"])
+    return None if t < 0 else t
+
+
 @pytest.mark.parametrize("case", [str(n) for n in COLOC["names"]])
 def test_colocalize_blobs_matches_reference(case):
     """colocalizer.colocalize_blobs restated == the real reference (colocalizer.py:340-441)."""
     g = COLOC
-    got = coloc_oracle.colocalize_blobs(coloc_roi(g, case), g[case + "_blobs"])
+    got = coloc_oracle.colocalize_blobs(coloc_roi(g, case), g[case + "_blobs"], coloc_thresh(g, case))
     want = g[case + "_colocs"]
     if want.size == 0 and want.ndim == 2 and want.shape[0] == 0:
         assert got is None
