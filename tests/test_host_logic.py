@@ -381,7 +381,7 @@ def test_coloc_flags_from_means_match_reference():
     from scipy import ndimage as ndi
     from magellanmapper_amd import colocalizer
     from oracle import coloc_oracle
-    from test_oracle_golden import COLOC, coloc_roi
+    from test_oracle_golden import COLOC, coloc_roi, coloc_thresh
     for case in [str(n) for n in COLOC["names"]]:
         roi, blobs, want = coloc_roi(COLOC, case), COLOC[case + "_blobs"], COLOC[case + "_colocs"]
         if roi.ndim < 4:
@@ -390,17 +390,21 @@ def test_coloc_flags_from_means_match_reference():
         shape3 = roi.shape[:3]
         inside = np.all((blobs[:, :3] >= 0) & (blobs[:, :3] < shape3), axis=1)
         means = np.full((len(blobs), n_chl), np.nan)
+        pct = coloc_thresh(COLOC, case)
+        thresholds = None if pct is None else {}
         for bc in range(n_chl):
             sel = np.where(inside & (blobs[:, 6] == bc))[0]
             mask = -np.ones(shape3, dtype=int)
             c = blobs[sel, :3].astype(int)
             mask[c[:, 0], c[:, 1], c[:, 2]] = sel
             mask = ndi.grey_dilation(mask, footprint=coloc_oracle.ball(2))
+            if pct is not None and len(sel):      # percentile of the channel over every voxel its blobs own
+                thresholds[bc] = np.percentile(roi[mask >= 0, bc], pct)
             for b in sel:
                 vox = mask == b
                 for oc in range(n_chl):
                     means[b, oc] = np.mean(roi[vox, oc]) if vox.any() else np.nan
-        got = colocalizer._flags_from_means(blobs, means, shape3, n_chl)
+        got = colocalizer._flags_from_means(blobs, means, shape3, n_chl, thresholds)
         np.testing.assert_array_equal(got, want, err_msg=case)
 
 
