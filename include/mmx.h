@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 10
+#define MMX_ABI_VERSION 11
 
 typedef enum {
     MMX_OK = 0,
@@ -97,6 +97,8 @@ typedef struct {
 
 #define MMX_CAND_CONTESTED 1u
 #define MMX_CAND_BAND 2u
+/* an entry appended by mmx_expand_probes: a neighbour of the contested candidate `band` (its table index) */
+#define MMX_CAND_PROBE 4u
 
 /* ---- library / device ---------------------------------------------------- */
 int mmx_abi_version(void);
@@ -215,6 +217,18 @@ int mmx_rescore_f64(const mmx_volume* vol, const mmx_block* d_blocks, int n_bloc
                     mmx_cand* d_pts, uint32_t cap, const uint32_t* d_count,
                     const double* d_w0, const double* d_w2, const int32_t* h_radius,
                     const double* h_norm, int n_sigma, int store_f32, void* stream);
+
+/* ---- the neighbours that can out-vote a contested candidate, appended to the candidate table (A4)
+ * replaces: the exact `image == maximum_filter(image)` comparison of peak_local_max (skimage/feature/peak.py:35-49)
+ * for the candidates float32 cannot settle: after this call and one mmx_rescore_f64 over the whole table the host
+ * has every float64 value those decisions need.
+ *   d_cands/cap/d_count : the table mmx_peaks_batch filled; *d_count keeps counting past cap
+ *   d_n_cands           : out, *d_count as it was before this call (entries below it are candidates, the rest
+ *                         probes: flags = MMX_CAND_PROBE, slot/s/z/y/x of the neighbour, band = index of its candidate)
+ * For a candidate flagged MMX_CAND_BAND only the neighbours in its band are appended, otherwise all (<= 80)
+ * neighbours inside the cube. */
+int mmx_expand_probes(mmx_cand* d_cands, uint32_t cap, uint32_t* d_count, uint32_t* d_n_cands,
+                      const mmx_block* d_blocks, int n_blocks, int n_sigma, void* stream);
 
 /* ---- A5 support: all blob pairs of one block whose sphere-overlap fraction exceeds
  * `overlap` (skimage/feature/blob.py:84-187: _blob_overlap / _prune_blobs)
@@ -442,6 +456,36 @@ int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int
  * replace_rel_with_abs_blob_coords / remove_abs_blob_coords).  `out` may alias `table`. */
 int mmx_host_map_columns(const double* table, int64_t ld, int64_t n, const int32_t* src_cols,
                          int32_t n_map, double* out, int64_t out_ld, int32_t dst_col0);
+
+/* ---- per-batch host work of the detection, native and threaded over blocks (no device work; host pointers).
+ * mmx_host_resolve_peaks: peak membership on the exact float64 values and the reference's two orders
+ *   replaces: `image == maximum_filter(image)` & `image > threshold`, np.nonzero, argsort(-values) of
+ *   skimage.feature.peak_local_max (skimage/feature/peak.py:9-50) for the candidates of one batch.
+ *   cands[0, n_cands) candidates, cands[n_cands, n_total) probes (mmx_expand_probes), all re-scored.
+ *   out_nz_coords/out_nz_vals: per block the peaks in np.nonzero order ([z, y, x, sigma index] int32, float64);
+ *   out_coords/out_vals: the same rows by descending value, equal values in nonzero order; offsets[n_blocks + 1];
+ *   ties[b] = 1 when block b holds two equal values (np.argsort's order of equal keys is its own: ask NumPy);
+ *   stats[4]: contested candidates, peaks, max |float32 - float64| (inf when a value is not finite: nothing else
+ *   is then written), blocks dropped as constant cubes (peak.py:41-43).
+ * mmx_host_overlap_prune: skimage.feature.blob._prune_blobs (blob.py:84-187) on those peaks: `alive` per row, final
+ *   for blocks with open_blocks[b] == 0 when *n_knife == 0 and *n_pairs <= cap; all pairs above overlap - band in
+ *   pairs/frac for the caller's exact re-evaluation (knife-edge fractions) and reference pair order (open blocks).
+ * mmx_host_emit_tables: the 11-column block tables (magmap/cv/detector.py:88-113, 934-943) shifted to ROI
+ *   coordinates (stack_detect.py:164-170) and tagged with the block's grid coordinate (chunking.py:410-445),
+ *   written into the caller's merged table from row0 on (row pitch ld >= 14: 11 + extra columns + 3 tags), plus
+ *   the compact int32 / float64 columns mmx_host_prune_axis reads.  MMX_ERR_WORKSPACE when `capacity` rows do not
+ *   suffice (nothing written). */
+int mmx_host_resolve_peaks(const mmx_cand* cands, uint32_t n_cands, uint32_t n_total, const mmx_block* blocks,
+                           int n_blocks, int n_sigma, double thr, int32_t* out_nz_coords, double* out_nz_vals,
+                           int32_t* out_coords, double* out_vals, int32_t* offsets, uint8_t* ties, double* stats);
+int mmx_host_overlap_prune(const int32_t* coords, const int32_t* offsets, int n_blocks, const double* sigmas,
+                           int n_sigma, double overlap, double band, uint8_t* alive, uint8_t* open_blocks,
+                           int32_t* pairs, double* frac, int64_t cap, int64_t* n_pairs, int64_t* n_knife);
+int mmx_host_emit_tables(const int32_t* coords, const uint8_t* alive, const int32_t* offsets, int n_blocks,
+                         const double* sigmas, int n_sigma, double channel, const double* block_offsets,
+                         const int32_t* block_tags, const int32_t* interior, double* store, int64_t ld,
+                         int32_t* zyx, int32_t* tag, double* abs_zyx, int64_t row0, int64_t capacity,
+                         int64_t* rows_per_block);
 
 /* ---- match-based co-localisation: the two third-party calls of the reference's
  * verifier.find_closest_blobs_cdist (magmap/cv/verifier.py:47-119).

@@ -17,12 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 10
+MMX_ABI_VERSION = 11
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
 MMX_CAND_CONTESTED = 1
 MMX_CAND_BAND = 2
+MMX_CAND_PROBE = 4
 #: ``mmx_zx_mode``: how mmx_log_batch_f32 runs its Z and X passes (a per-call argument)
 MMX_ZX_AUTO, MMX_ZX_SEPARATE, MMX_ZX_PACKED, MMX_ZX_MFMA_F32, MMX_ZX_MFMA_F16, MMX_ZX_MFMA_F16_LDS = -1, 0, 2, 3, 4, 5
 MMX_ZX_TILED, MMX_ZX_TILED_Q16, MMX_ZX_PREPACKED = 6, 7, 0x100
@@ -84,7 +85,8 @@ SYMBOLS = (
     "mmx_calib_stream", "mmx_host_prune_axis",
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
     "mmx_coloc_means", "mmx_coloc_voxels", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
-    "mmx_cdist_f64", "mmx_host_lsap",
+    "mmx_cdist_f64", "mmx_host_lsap", "mmx_expand_probes", "mmx_host_resolve_peaks", "mmx_host_overlap_prune",
+    "mmx_host_emit_tables",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass", "preproc", "coloc", "zxpack")
@@ -161,6 +163,13 @@ def lib() -> ctypes.CDLL:
     L.mmx_coloc_means.restype = c_int
     L.mmx_coloc_voxels.argtypes = [POINTER(Volume), vp, c_int, vp, vp, c_int, vp, vp, vp, vp]
     L.mmx_coloc_voxels.restype = c_int
+    L.mmx_expand_probes.argtypes = [vp, c_uint32, vp, vp, vp, c_int, c_int, vp]
+    L.mmx_expand_probes.restype = c_int
+    L.mmx_host_resolve_peaks.argtypes = [vp, c_uint32, c_uint32, vp, c_int, c_int, c_double, vp, vp, vp, vp, vp, vp, vp]
+    L.mmx_host_overlap_prune.argtypes = [vp, vp, c_int, vp, c_int, c_double, c_double, vp, vp, vp, vp, c_int64,
+                                         POINTER(c_int64), POINTER(c_int64)]
+    L.mmx_host_emit_tables.argtypes = [vp, vp, vp, c_int, vp, c_int, c_double, vp, vp, vp, vp, c_int64, vp, vp, vp,
+                                       c_int64, c_int64, vp]
     L.mmx_preprocess_batch.restype = c_int
     L.mmx_preprocess_batch_generic.restype = c_int
     for name in SYMBOLS:

@@ -68,6 +68,13 @@ OVERLAP_BAND = 1e-9
 ZX_MODE = int(os.environ.get("MMX_FUSE", nat.MMX_ZX_AUTO))
 #: the ``mmx_zx_mode`` the most recent ``mmx_log_batch_f32`` call of this process actually ran
 LAST_ZX_PATH = None
+#: who takes the per-batch decisions on the re-scored candidates: "native" (``mmx_host_resolve_peaks`` /
+#: ``mmx_host_overlap_prune``: threaded, outside the GIL, no second device round trip) or "numpy" (the same rules as
+#: array expressions; kept as a cross-check -- tests run both -- and for ``exact_values=False``)
+HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
+#: candidate-table entries copied to pinned host memory together with the counts, before the host knows how many
+#: there are (a batch of the benchmark volume holds ~3e4; more entries cost a second, synchronous copy)
+_PREFIX_ENTRIES = 1 << 16
 
 _NP_TO_MMX = {np.dtype(np.uint8): nat.MMX_U8, np.dtype(np.uint16): nat.MMX_U16,
               np.dtype(np.float32): nat.MMX_F32, np.dtype(np.float64): nat.MMX_F64}
@@ -363,6 +370,7 @@ class _Buffers:
         self.cands = []
         self.counts = []
         self.host_counts = []
+        self.host_tabs = []
         self.side = torch.cuda.Stream(device=dev, priority=-1)
         self.slots(2)
 
@@ -370,14 +378,22 @@ class _Buffers:
         """At least ``n`` candidate-table slots (one per batch in flight)."""
         while len(self.cands) < n:
             self.cands.append(None)
-            self.counts.append(torch.zeros(1, dtype=torch.int32, device=self.dev))
-            self.host_counts.append(torch.zeros(1, dtype=torch.int32).pin_memory())
+            # [0]: entries in the table (candidates + probes, counts past the capacity); [1]: candidates among them
+            self.counts.append(torch.zeros(2, dtype=torch.int32, device=self.dev))
+            self.host_counts.append(torch.zeros(2, dtype=torch.int32).pin_memory())
+            self.host_tabs.append(None)
 
     def workspace(self, n_floats: int):
         if self.ws is None or self.ws.numel() < n_floats:
             self.ws = None
             self.ws = torch.empty(n_floats, dtype=torch.float32, device=self.dev)
         return self.ws
+
+    def host_table(self, which: int):
+        """Pinned staging for the first ``_PREFIX_ENTRIES`` entries of slot ``which``'s candidate table."""
+        if self.host_tabs[which] is None:
+            self.host_tabs[which] = torch.empty(_PREFIX_ENTRIES * nat.CAND_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+        return self.host_tabs[which]
 
     def cand_table(self, which: int, cap: int):
         need = cap * nat.CAND_DTYPE.itemsize
@@ -462,7 +478,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                     num_sigma: int, threshold: float, overlap: float, *,
                     budget_bytes: int = 24 << 30, stats: Optional[BatchStats] = None,
                     return_peaks: bool = False, on_batch=None, pre=None,
-                    exact_values: Optional[bool] = None):
+                    exact_values: Optional[bool] = None, sink=None):
     """``blob_log`` of every block -> list of ``(n, 4)`` float64 ``[z, y, x, sigma]`` arrays.
 
     ``exact_values`` (default True): re-score EVERY candidate in float64 in the batch's own kernel queue, so
@@ -479,6 +495,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     with the next one.  ``pre`` (a ``preprocess.Preprocessor``) saturates + denoises every block
     on the device first (reference stack_detect.py:122-150); detection then runs on the
     float64 result exactly as the reference's ``blob_log`` does.
+    ``sink(indices, peak_batch)`` (native host path only) takes each batch as a :class:`PeakBatch` -- rows, ``alive``
+    flags, block offsets -- instead of per-block arrays; the call then returns ``None`` entries for those blocks.
     """
     _require_gpu()
     space = ScaleSpace.make(min_sigma, max_sigma, num_sigma)
@@ -528,8 +546,16 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         pending, jobs[k] = jobs[k], None
         # host + side-stream work of batch k, the GPU busy with the batches behind it
         peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats)
-        with torch.cuda.stream(bufs.side):
-            pruned = _prune_batch(peaks, space, float(overlap), dvol.tensor.device, stats)
+        if isinstance(peaks, PeakBatch):
+            pb = _prune_batch_native(peaks, space, float(overlap), stats)
+            if sink is not None:        # the caller builds its tables from the arrays (native, no per-block lists)
+                sink(pending["batch"], pb)
+                continue
+            pruned = [pb.blobs(b) for b in range(len(pb))]
+            peaks = [pb.block(b) for b in range(len(pb))] if return_peaks else [None] * len(pb)
+        else:
+            with torch.cuda.stream(bufs.side):
+                pruned = _prune_batch(peaks, space, float(overlap), dvol.tensor.device, stats)
         for i, pk, res in zip(pending["batch"], peaks, pruned):
             results[i] = res
             peaks_out[i] = pk
@@ -629,17 +655,25 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                                 blocks.ctypes.data, nb, slot, thr, eps, table.data_ptr(), cap,
                                 count.data_ptr(), stream),
               "mmx_peaks_batch")
+    native = bool(exact and HOST_PATH == "native")
+    if native:
+        # the neighbours that can out-vote the contested candidates join the table: one re-score, one copy
+        nat.check(L.mmx_expand_probes(table.data_ptr(), cap, count.data_ptr(), count.data_ptr() + 4,
+                                      d_blocks.data_ptr(), nb, ns, stream), "mmx_expand_probes")
     if exact:
         nat.check(L.mmx_rescore_f64(
             ctypes.byref(vol_exact), d_blocks.data_ptr(), nb, table.data_ptr(), cap,
             count.data_ptr(), d_w0.data_ptr(), d_w2.data_ptr(), nat.as_int32_ptr(space.radii),
             nat.as_double_ptr(space.norms), ns, store_f32, stream), "mmx_rescore_f64")
     bufs.host_counts[which].copy_(count, non_blocking=True)
+    if native:
+        n_pre = min(cap, _PREFIX_ENTRIES) * nat.CAND_DTYPE.itemsize
+        bufs.host_table(which)[:n_pre].copy_(table[:n_pre], non_blocking=True)
     done = torch.cuda.Event()
     done.record()
     return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
                 nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
-                vol_exact=vol_exact, pre=pre, exact=exact, eps=eps)
+                vol_exact=vol_exact, pre=pre, exact=exact, eps=eps, native=native)
 
 
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
@@ -649,9 +683,14 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
     job["done"].synchronize()
     eps = job.get("eps", eps)
     which, cap, ns = job["which"], job["cap"], job["ns"]
-    count = int(bufs.host_counts[which].item()) & 0xFFFFFFFF
+    native = job.get("native", False)
+    words = bufs.host_counts[which].numpy().view(np.uint32)
+    count = int(words[0])
+    n_cands = int(words[1]) if native else count
+    if native and n_cands >= job["n_vox"] * ns:
+        count = n_cands = 0                 # constant cubes (below)
     if count > cap:
-        if count >= job["n_vox"] * ns:
+        if count >= job["n_vox"] * ns and not native:
             # every voxel of every block "equals its maximum": only possible for constant
             # cubes, which scikit-image treats as having no peaks (peak.py:41-43)
             count = 0
@@ -666,12 +705,19 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
             return _finish_detect(redo, dvol, space, thr, eps, bufs, d_w0, d_w2, stats)
     with torch.cuda.stream(bufs.side):
         table = bufs.cands[which]
-        cands = (table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
-                 if count else np.zeros(0, dtype=nat.CAND_DTYPE))
         try:
-            out = _resolve_peaks(cands, job["blocks"], job["shapes"], ns, thr, dvol, job["vol_exact"],
-                                 job["d_blocks"], d_w0, d_w2, space, job["store_f32"], stats, eps,
-                                 job.get("exact", False))
+            if native:
+                if count <= _PREFIX_ENTRIES:
+                    cands = bufs.host_table(which).numpy()[:count * nat.CAND_DTYPE.itemsize].view(nat.CAND_DTYPE)
+                else:
+                    cands = table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
+                out = _resolve_peaks_native(cands, n_cands, job["blocks"], ns, thr, stats, eps)
+            else:
+                cands = (table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
+                         if count else np.zeros(0, dtype=nat.CAND_DTYPE))
+                out = _resolve_peaks(cands, job["blocks"], job["shapes"], ns, thr, dvol, job["vol_exact"],
+                                     job["d_blocks"], d_w0, d_w2, space, job["store_f32"], stats, eps,
+                                     job.get("exact", False))
         except _BandTooNarrow as exc:
             out = None
             err = exc.err
@@ -679,7 +725,7 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
         if out is not None:
             stats.n_blocks += job["nb"]
             stats.n_voxels += job["n_vox"]
-            stats.n_candidates += count
+            stats.n_candidates += n_cands
             return out
     # the float32 values were further from the exact ones than the band allows: nominate this batch again
     # with a band of 8 x the deviation found (the exact re-score then decides as always).  The pipeline has
@@ -842,6 +888,74 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
     return out
 
 
+class PeakBatch:
+    """The raw peaks of one batch as the native host code leaves them: ``coords[offsets[b]:offsets[b + 1]]`` are
+    block ``b``'s ``[z, y, x, sigma index]`` rows (int32) by descending float64 response ``vals`` -- the
+    reference's order (``argsort(-values)`` of the ``np.nonzero`` rows, peak.py:17).  After the overlap prune
+    ``alive`` marks the surviving rows and ``sigmas`` maps the last column to the blob's sigma."""
+    __slots__ = ("coords", "vals", "offsets", "alive", "sigmas")
+
+    def __init__(self, coords, vals, offsets):
+        self.coords, self.vals, self.offsets = coords, vals, offsets
+        self.alive = None
+        self.sigmas = None
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def block(self, b: int) -> Tuple[np.ndarray, np.ndarray]:
+        """``(coords int64 (n, 4), values float64 (n,))`` of block ``b``."""
+        lo, hi = self.offsets[b], self.offsets[b + 1]
+        return self.coords[lo:hi].astype(np.int64), self.vals[lo:hi]
+
+    def blobs(self, b: int) -> np.ndarray:
+        """Block ``b``'s pruned ``[z, y, x, sigma]`` rows (float64), ``np.empty((0, 3))`` without peaks."""
+        lo, hi = self.offsets[b], self.offsets[b + 1]
+        if lo == hi:
+            return np.empty((0, 3))
+        rows = self.coords[lo:hi][self.alive[lo:hi].view(bool)]
+        out = rows.astype(np.float64)
+        out[:, 3] = self.sigmas[rows[:, 3]]
+        return out
+
+
+def _resolve_peaks_native(cands, n_cands: int, blocks, ns: int, thr: float, stats: BatchStats, eps: float) -> PeakBatch:
+    """``mmx_host_resolve_peaks``: the decisions of ``_resolve_peaks`` for a table whose candidates AND probes
+    (``mmx_expand_probes``) were re-scored on the device; blocks whose peaks tie take their order from NumPy."""
+    L = nat.lib()
+    nb = len(blocks)
+    n_total = len(cands)
+    nz_coords = np.empty((max(n_cands, 1), 4), dtype=np.int32)
+    nz_vals = np.empty(max(n_cands, 1))
+    coords = np.empty_like(nz_coords)
+    vals = np.empty_like(nz_vals)
+    offsets = np.zeros(nb + 1, dtype=np.int32)
+    ties = np.zeros(nb, dtype=np.uint8)
+    st = np.zeros(4)
+    nat.check(L.mmx_host_resolve_peaks(cands.ctypes.data if n_total else None, n_cands, n_total, blocks.ctypes.data,
+                                       nb, ns, float(thr), nz_coords.ctypes.data, nz_vals.ctypes.data,
+                                       coords.ctypes.data, vals.ctypes.data, offsets.ctypes.data, ties.ctypes.data,
+                                       st.ctypes.data), "mmx_host_resolve_peaks")
+    err = float(st[2])
+    if n_cands:
+        if not np.isfinite(err):
+            raise nat.MmxError("non-finite LoG values: the image holds NaN or infinite voxels")
+        if not err < 0.25 * eps:
+            raise _BandTooNarrow(err)                      # (before any counter moves)
+        stats.max_f32_error = max(stats.max_f32_error, err)
+    stats.n_contested += int(st[0])
+    stats.n_probes += n_total - n_cands
+    stats.n_peaks += int(st[1])
+    for b in np.nonzero(ties)[0]:
+        # equal float64 responses inside one block: the reference's order is whatever np.argsort makes of them
+        lo, hi = offsets[b], offsets[b + 1]
+        rank = np.argsort(-nz_vals[lo:hi])                 # the reference's call on the reference's array (peak.py:17)
+        coords[lo:hi] = nz_coords[lo:hi][rank]
+        vals[lo:hi] = nz_vals[lo:hi][rank]
+    n = int(offsets[-1])
+    return PeakBatch(coords[:n], vals[:n], offsets)
+
+
 # ------------------------------------------------------------------------------ A5
 def _exact_overlap(b1: np.ndarray, b2: np.ndarray) -> float:
     """``_blob_overlap`` with the reference's exact libm calls, for the knife-edge pairs
@@ -873,6 +987,85 @@ def _reference_pair_order(lm: np.ndarray) -> np.ndarray:
     distance = 2 * sigma * math.sqrt(lm.shape[1] - 1)
     tree = _scipy_spatial.cKDTree(lm[:, :-1])
     return np.array(list(tree.query_pairs(distance)))
+
+
+def _apply_pairs(allb, sig, offsets, pairs, frac, overlap: float, stats: BatchStats, only_blocks=None) -> None:
+    """The sequential rule of ``_prune_blobs`` (blob.py:172-186) on the over-limit pairs: ``sig`` of the losers is
+    zeroed in place.  ``pairs`` are global rows (i < j) in any order, ``frac`` their overlap fractions; fractions
+    within ``OVERLAP_BAND`` of the limit are re-evaluated with the reference's exact libm calls first.
+    ``only_blocks``: leave every other block alone (its outcome is already known)."""
+    frac = frac.copy()
+    for k in np.nonzero(np.abs(frac - overlap) <= OVERLAP_BAND)[0]:   # knife edge: exact libm
+        frac[k] = _exact_overlap(allb[pairs[k, 0]], allb[pairs[k, 1]])
+    act = pairs[frac > overlap]
+    if not len(act):
+        return
+    i, j = act[:, 0], act[:, 1]
+    block_of_pair = np.searchsorted(offsets, i, side="right") - 1
+    if only_blocks is not None:
+        sel = np.isin(block_of_pair, only_blocks)
+        act, i, j, block_of_pair = act[sel], i[sel], j[sel], block_of_pair[sel]
+        if not len(act):
+            return
+    first_bigger = sig[i] > sig[j]
+    loser = np.where(first_bigger, j, i)
+    winner = np.where(first_bigger, i, j)
+    chained = np.intersect1d(loser, winner)
+    chain_blocks = np.unique(np.searchsorted(offsets, chained, side="right") - 1)
+    simple = ~np.isin(block_of_pair, chain_blocks)
+    sig[loser[simple]] = 0
+    for b in chain_blocks:
+        stats.n_order_fallbacks += 1
+        lo, hi = offsets[b], offsets[b + 1]
+        mine = block_of_pair == b
+        active = {(int(a_) - lo, int(b_) - lo) for a_, b_ in act[mine]}
+        bs = sig[lo:hi]
+        for a_, b_ in _reference_pair_order(allb[lo:hi]):
+            a_, b_ = int(a_), int(b_)
+            if (a_, b_) in active and bs[a_] > 0 and bs[b_] > 0:
+                if bs[a_] > bs[b_]:
+                    bs[b_] = 0
+                else:
+                    bs[a_] = 0
+
+
+def _prune_batch_native(pb: PeakBatch, space: ScaleSpace, overlap: float, stats: BatchStats) -> PeakBatch:
+    """``mmx_host_overlap_prune`` on the host's own peaks (no upload, no kernel, no wait): ``pb.alive`` per row.
+    Blocks whose outcome depends on the order scikit-image visits the pairs in, and batches with a fraction on the
+    knife edge, go through :func:`_apply_pairs` with the pairs the native search found."""
+    L = nat.lib()
+    nb = len(pb)
+    n = len(pb.coords)
+    pb.sigmas = np.ascontiguousarray(space.sigmas, dtype=np.float64)
+    pb.alive = np.ones(n, dtype=np.uint8)
+    if n == 0:
+        return pb
+    open_blocks = np.zeros(nb, dtype=np.uint8)
+    cap = max(1024, 4 * n)
+    n_pairs, n_knife = ctypes.c_int64(0), ctypes.c_int64(0)
+    while True:
+        pairs = np.empty((cap, 2), dtype=np.int32)
+        frac = np.empty(cap)
+        nat.check(L.mmx_host_overlap_prune(pb.coords.ctypes.data, pb.offsets.ctypes.data, nb, pb.sigmas.ctypes.data,
+                                           len(pb.sigmas), float(overlap), OVERLAP_BAND, pb.alive.ctypes.data,
+                                           open_blocks.ctypes.data, pairs.ctypes.data, frac.ctypes.data, cap,
+                                           ctypes.byref(n_pairs), ctypes.byref(n_knife)), "mmx_host_overlap_prune")
+        if n_pairs.value <= cap:
+            break
+        cap = n_pairs.value + 64
+    stats.n_overlap_pairs += n_pairs.value
+    todo = None if n_knife.value else np.nonzero(open_blocks)[0]
+    if todo is None or len(todo):
+        allb = pb.coords.astype(np.float64)
+        allb[:, 3] = pb.sigmas[pb.coords[:, 3]]
+        sig = allb[:, 3].copy()
+        if todo is not None:
+            sig[pb.alive == 0] = 0         # (the closed blocks' outcome stands)
+        _apply_pairs(allb, sig, pb.offsets, pairs[:n_pairs.value].astype(np.int64), frac[:n_pairs.value], overlap,
+                     stats, only_blocks=todo)
+        pb.alive = (sig > 0).astype(np.uint8)
+    stats.n_blobs += int(pb.alive.sum())
+    return pb
 
 
 def _prune_batch(peaks, space: ScaleSpace, overlap: float, dev, stats: BatchStats):
@@ -912,35 +1105,8 @@ def _prune_batch(peaks, space: ScaleSpace, overlap: float, dev, stats: BatchStat
     sig = allb[:, 3].copy()
     stats.n_overlap_pairs += n
     if n:
-        pairs = d_pairs[:n].cpu().numpy().astype(np.int64)
-        frac = d_frac[:n].cpu().numpy()
-        for k in np.nonzero(np.abs(frac - overlap) <= OVERLAP_BAND)[0]:   # knife edge: exact libm
-            frac[k] = _exact_overlap(allb[pairs[k, 0]], allb[pairs[k, 1]])
-        act = pairs[frac > overlap]
-        if len(act):
-            # the device appends pairs in arbitrary order; (i, j) itself always has i < j
-            i, j = act[:, 0], act[:, 1]
-            first_bigger = sig[i] > sig[j]
-            loser = np.where(first_bigger, j, i)
-            winner = np.where(first_bigger, i, j)
-            chained = np.intersect1d(loser, winner)
-            block_of_pair = np.searchsorted(offsets, i, side="right") - 1
-            chain_blocks = np.unique(np.searchsorted(offsets, chained, side="right") - 1)
-            simple = ~np.isin(block_of_pair, chain_blocks)
-            sig[loser[simple]] = 0
-            for b in chain_blocks:
-                stats.n_order_fallbacks += 1
-                lo, hi = offsets[b], offsets[b + 1]
-                mine = block_of_pair == b
-                active = {(int(a_) - lo, int(b_) - lo) for a_, b_ in act[mine]}
-                bs = sig[lo:hi]
-                for a_, b_ in _reference_pair_order(allb[lo:hi]):
-                    a_, b_ = int(a_), int(b_)
-                    if (a_, b_) in active and bs[a_] > 0 and bs[b_] > 0:
-                        if bs[a_] > bs[b_]:
-                            bs[b_] = 0
-                        else:
-                            bs[a_] = 0
+        _apply_pairs(allb, sig, offsets, d_pairs[:n].cpu().numpy().astype(np.int64), d_frac[:n].cpu().numpy(),
+                     overlap, stats)
     results = []
     for b in range(len(peaks)):
         lo, hi = offsets[b], offsets[b + 1]

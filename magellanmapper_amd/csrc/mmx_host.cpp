@@ -439,3 +439,364 @@ extern "C" int mmx_host_lsap(const double* cost, int64_t nr, int64_t nc, int64_t
     }
     return MMX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-batch host work of the detection (A4 decisions, A5, block tables), native and threaded over blocks.
+//
+// What the reference does here, per block, on float64 NumPy arrays (skimage/feature/peak.py:9-50, 114-319 and
+// blob.py:146-187, then magmap/cv/detector.py:934-943, stack_detect.py:164-170):
+//   coordinates = np.nonzero(mask)            -> C order over (z, y, x, sigma)
+//   order = np.argsort(-values)               -> descending response
+//   pairs within 2 sigma_max sqrt(3) whose sphere overlap exceeds `overlap`: the smaller sigma is zeroed (the
+//   first of the pair on equal sigmas), a zeroed blob zeroes nothing;  radius = sigma sqrt(3); 11 columns;
+//   block offset added to the rel and abs coordinates.
+// The device nominates candidates in float32 and re-scores them (and the neighbours that can out-vote the contested
+// ones, mmx_expand_probes) in float64; these functions take the decisions on those float64 values.
+
+namespace {
+struct cand_rec {           // mmx_cand, 48 bytes
+    int32_t slot, s, z, y, x;
+    uint32_t flags;
+    float v, nbr_max;
+    double v64;
+    uint64_t band;
+};
+static_assert(sizeof(cand_rec) == 48 && sizeof(cand_rec) == sizeof(mmx_cand), "mmx_cand layout");
+}  // namespace
+
+// Exact peak membership and the reference's two orders.
+//   cands[0, n_cands): candidates; cands[n_cands, n_total): probes (band = index of the candidate they may out-vote)
+//   out_nz_* : the peaks of every block in np.nonzero order (C order of the (z, y, x, sigma) cube)
+//   out_*    : the same rows per block by descending value (stable: equal values keep the nonzero order)
+//   offsets  : [n_blocks + 1] row ranges of the blocks in both
+//   ties     : [n_blocks] 1 when two peaks of the block have EQUAL values -- np.argsort's order of equal keys is
+//              its own (an unstable introsort): the caller then takes that block's order from NumPy itself
+//   stats    : [4] candidates flagged contested, peaks, max |float32 - float64| over the candidates (NaN / inf when
+//              a value is not finite), blocks dropped as constant cubes
+extern "C" int mmx_host_resolve_peaks(const mmx_cand* cands_, uint32_t n_cands, uint32_t n_total,
+                                      const mmx_block* blocks, int n_blocks, int n_sigma, double thr,
+                                      int32_t* out_nz_coords, double* out_nz_vals, int32_t* out_coords, double* out_vals,
+                                      int32_t* offsets, uint8_t* ties, double* stats)
+{
+    if ((!cands_ && n_total) || n_cands > n_total || !blocks || n_blocks < 1 || n_sigma < 1 || !offsets || !ties || !stats ||
+        (n_cands && (!out_nz_coords || !out_nz_vals || !out_coords || !out_vals)))
+        return MMX_ERR_ARG;
+    const cand_rec* cands = reinterpret_cast<const cand_rec*>(cands_);
+    // ---- the best exact value among the neighbours that can out-vote each contested candidate
+    std::vector<double> rival;
+    if (n_total > n_cands) {
+        rival.assign(n_cands, -INFINITY);
+        for (uint32_t p = n_cands; p < n_total; ++p) {
+            const cand_rec& q = cands[p];
+            if (!(q.flags & MMX_CAND_PROBE) || q.band >= n_cands) return MMX_ERR_ARG;
+            if (!(q.v64 == q.v64)) {                                       // (never re-scored / NaN voxels)
+                stats[0] = stats[1] = stats[3] = 0.0; stats[2] = INFINITY;
+                for (int b = 0; b <= n_blocks; ++b) offsets[b] = 0;
+                return MMX_OK;
+            }
+            if (q.v64 > rival[q.band]) rival[q.band] = q.v64;
+        }
+    }
+    // ---- keep / drop per candidate, and its place in the cube
+    const int T = n_cands < 4096 ? 1 : std::min(pool::get().size(), n_blocks > 1 ? 16 : 4);
+    std::vector<int64_t> key(n_cands);               // position in the block's (z, y, x, sigma) cube, -1: dropped
+    std::vector<std::vector<int64_t>> per_block((size_t)T, std::vector<int64_t>((size_t)n_blocks + 1, 0));
+    std::vector<double> errs((size_t)T, 0.0);
+    std::vector<int64_t> n_cont((size_t)T, 0);
+    std::vector<int> bad((size_t)T, 0);
+    parallel(T, [&](int t, int nt) {
+        const uint32_t lo = (uint32_t)((uint64_t)n_cands * t / nt), hi = (uint32_t)((uint64_t)n_cands * (t + 1) / nt);
+        double err = 0.0;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const cand_rec& c = cands[i];
+            key[i] = -1;
+            if (c.slot < 0 || c.slot >= n_blocks || c.s < 0 || c.s >= n_sigma) { bad[(size_t)t] = 1; continue; }
+            const mmx_block& bd = blocks[c.slot];
+            if (c.z < 0 || c.z >= bd.nz || c.y < 0 || c.y >= bd.ny || c.x < 0 || c.x >= bd.nx) { bad[(size_t)t] = 1; continue; }
+            const double e = std::fabs((double)c.v - c.v64);
+            if (e != e) err = INFINITY;               // (NaN voxels: reported as a non-finite deviation)
+            else if (e > err) err = e;
+            bool keep = c.v64 > thr;
+            if (c.flags & MMX_CAND_CONTESTED) {
+                ++n_cont[(size_t)t];
+                double m = rival.empty() ? -INFINITY : rival[i];
+                const bool border = c.s == 0 || c.s == n_sigma - 1 || c.z == 0 || c.z == bd.nz - 1 || c.y == 0 ||
+                                    c.y == bd.ny - 1 || c.x == 0 || c.x == bd.nx - 1;
+                if (border && !(m > 0.0)) m = 0.0;     // the cube is zero-padded (mode='constant', cval 0)
+                keep = keep && c.v64 >= m;
+            }
+            if (keep) {
+                key[i] = (((int64_t)c.z * bd.ny + c.y) * bd.nx + c.x) * n_sigma + c.s;
+                ++per_block[(size_t)t][(size_t)c.slot];
+            }
+        }
+        errs[(size_t)t] = err;
+    });
+    double err = 0.0;
+    int64_t contested = 0;
+    for (int t = 0; t < T; ++t) {
+        if (bad[(size_t)t]) return MMX_ERR_ARG;
+        if (errs[(size_t)t] > err) err = errs[(size_t)t];
+        contested += n_cont[(size_t)t];
+    }
+    stats[0] = (double)contested; stats[1] = 0.0; stats[2] = err; stats[3] = 0.0;
+    // ---- rows per block (a block whose every voxel is a "peak" is a constant cube: no peaks, peak.py:41-43)
+    std::vector<int64_t> count((size_t)n_blocks, 0);
+    for (int b = 0; b < n_blocks; ++b)
+        for (int t = 0; t < T; ++t) count[(size_t)b] += per_block[(size_t)t][(size_t)b];
+    std::vector<char> trivial((size_t)n_blocks, 0);
+    offsets[0] = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        const int64_t cube = (int64_t)blocks[b].nz * blocks[b].ny * blocks[b].nx * n_sigma;
+        if (count[(size_t)b] == cube && cube > 1) { trivial[(size_t)b] = 1; stats[3] += 1.0; }
+        const int64_t next = (int64_t)offsets[b] + (trivial[(size_t)b] ? 0 : count[(size_t)b]);
+        if (next > INT32_MAX) return MMX_ERR_UNSUPPORTED;
+        offsets[b + 1] = (int32_t)next;
+        ties[b] = 0;
+    }
+    stats[1] = (double)offsets[n_blocks];
+    if (!std::isfinite(err) || offsets[n_blocks] == 0) return MMX_OK;
+    // ---- scatter the kept candidates to their blocks (chunk order: any; sorted next), then per block the two orders
+    std::vector<std::pair<int64_t, uint32_t>> rows((size_t)offsets[n_blocks]);       // (cube position, candidate)
+    {
+        std::vector<int64_t> at((size_t)n_blocks);
+        for (int b = 0; b < n_blocks; ++b) at[(size_t)b] = offsets[b];
+        for (uint32_t i = 0; i < n_cands; ++i) {
+            if (key[i] < 0) continue;
+            const int b = cands[i].slot;
+            if (trivial[(size_t)b]) continue;
+            rows[(size_t)at[(size_t)b]++] = std::make_pair(key[i], i);
+        }
+    }
+    parallel(std::min(T, n_blocks), [&](int t, int nt) {
+        std::vector<uint32_t> order;
+        for (int b = t; b < n_blocks; b += nt) {
+            const int64_t lo = offsets[b], hi = offsets[b + 1];
+            if (lo == hi) continue;
+            std::sort(rows.begin() + lo, rows.begin() + hi);          // a voxel appears once: keys are unique
+            order.resize((size_t)(hi - lo));
+            for (int64_t r = lo; r < hi; ++r) {
+                const cand_rec& c = cands[rows[(size_t)r].second];
+                int32_t* o = out_nz_coords + 4 * r;
+                o[0] = c.z; o[1] = c.y; o[2] = c.x; o[3] = c.s;
+                out_nz_vals[r] = c.v64;
+                order[(size_t)(r - lo)] = (uint32_t)(r - lo);
+            }
+            const double* v = out_nz_vals + lo;
+            std::stable_sort(order.begin(), order.end(), [v](uint32_t a, uint32_t b2) { return v[a] > v[b2]; });
+            uint8_t tie = 0;
+            for (int64_t r = lo; r < hi; ++r) {
+                const int64_t src = lo + order[(size_t)(r - lo)];
+                std::memcpy(out_coords + 4 * r, out_nz_coords + 4 * src, 4 * sizeof(int32_t));
+                out_vals[r] = out_nz_vals[src];
+                if (r > lo && out_vals[r] == out_vals[r - 1]) tie = 1;
+            }
+            ties[b] = tie;
+        }
+    });
+    return MMX_OK;
+}
+
+// Sphere-overlap pruning of every block (skimage/feature/blob.py:84-187), on the peaks in descending-response order.
+//   coords  : [n][4] int32 (z, y, x, sigma index), blocks delimited by offsets[n_blocks + 1]
+//   alive   : out [n] 1 = the blob survives.  Final for every block whose flag in `open_blocks` is 0.
+//   open_blocks : out [n_blocks] 1 = some blob of the block loses one over-limit pair and wins another: the outcome
+//             depends on the ORDER scikit-image visits the pairs in (cKDTree.query_pairs, implementation defined),
+//             which the caller takes from the same call; such a block's `alive` flags are all 1
+//   pairs / frac / cap / n_pairs : every pair (global rows i < j) whose overlap fraction exceeds overlap - band, in
+//             no particular order; *n_pairs counts past cap (the caller retries with a larger table)
+//   n_knife : out, pairs within `band` of the limit: their fraction must be re-evaluated with the reference's exact
+//             libm calls (caller); when non-zero NOTHING in `alive` is final
+extern "C" int mmx_host_overlap_prune(const int32_t* coords, const int32_t* offsets, int n_blocks,
+                                      const double* sigmas, int n_sigma, double overlap, double band,
+                                      uint8_t* alive, uint8_t* open_blocks, int32_t* pairs, double* frac,
+                                      int64_t cap, int64_t* n_pairs, int64_t* n_knife)
+{
+    if (!offsets || n_blocks < 1 || !sigmas || n_sigma < 1 || !open_blocks || !n_pairs || !n_knife || cap < 0 ||
+        (cap && (!pairs || !frac)))
+        return MMX_ERR_ARG;
+    const int64_t n = offsets[n_blocks];
+    if (n && (!coords || !alive)) return MMX_ERR_ARG;
+    double smax = 0.0;
+    for (int s = 0; s < n_sigma; ++s) smax = std::max(smax, sigmas[s]);
+    if (!(smax > 0.0)) return MMX_ERR_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        if (coords[4 * i + 3] < 0 || coords[4 * i + 3] >= n_sigma) return MMX_ERR_ARG;
+        alive[i] = 1;
+    }
+    for (int b = 0; b < n_blocks; ++b) open_blocks[b] = 0;
+    const double root3 = std::sqrt(3.0);
+    const double kPi = 3.141592653589793;           // math.pi
+    // no overlap beyond sqrt(3) (s_i + s_j) <= 2 sqrt(3) s_max: cells of that size, 27 of them around a blob
+    const double cell = 2.0 * root3 * smax + 1.0;
+    const int T = n < 2000 ? 1 : std::min(pool::get().size(), 16);
+    struct found { int32_t i, j; double f; };
+    std::vector<std::vector<found>> per_thread((size_t)T);
+    parallel(std::min(T, n_blocks), [&](int t, int nt) {
+        std::vector<int32_t> cell_of, start, sorted;
+        auto& out = per_thread[(size_t)t];
+        for (int b = t; b < n_blocks; b += nt) {
+            const int32_t lo = offsets[b], hi = offsets[b + 1];
+            const int m = hi - lo;
+            if (m < 2) continue;
+            int mx[3] = {0, 0, 0};
+            for (int32_t r = lo; r < hi; ++r)
+                for (int a = 0; a < 3; ++a) {
+                    if (coords[4 * (int64_t)r + a] < 0) { mx[0] = -1; break; }
+                    mx[a] = std::max(mx[a], coords[4 * (int64_t)r + a]);
+                }
+            if (mx[0] < 0) continue;                    // (negative coordinates never come from the detector)
+            const int gz = (int)(mx[0] / cell) + 1, gy = (int)(mx[1] / cell) + 1, gx = (int)(mx[2] / cell) + 1;
+            const int64_t n_cells = (int64_t)gz * gy * gx;
+            cell_of.resize((size_t)m);
+            start.assign((size_t)n_cells + 1, 0);
+            for (int k = 0; k < m; ++k) {
+                const int32_t* c = coords + 4 * (int64_t)(lo + k);
+                const int ci = ((int)(c[0] / cell) * gy + (int)(c[1] / cell)) * gx + (int)(c[2] / cell);
+                cell_of[(size_t)k] = ci;
+                ++start[(size_t)ci + 1];
+            }
+            for (int64_t c = 0; c < n_cells; ++c) start[(size_t)c + 1] += start[(size_t)c];
+            sorted.resize((size_t)m);
+            {
+                std::vector<int32_t> at(start.begin(), start.end() - 1);
+                for (int k = 0; k < m; ++k) sorted[(size_t)at[(size_t)cell_of[(size_t)k]]++] = k;
+            }
+            for (int i = 0; i < m; ++i) {
+                const int32_t* ci = coords + 4 * (int64_t)(lo + i);
+                const double zi = ci[0], yi = ci[1], xi = ci[2], si = sigmas[ci[3]];
+                const int cz = (int)(ci[0] / cell), cy = (int)(ci[1] / cell), cx = (int)(ci[2] / cell);
+                for (int az = std::max(0, cz - 1); az <= std::min(gz - 1, cz + 1); ++az)
+                    for (int ay = std::max(0, cy - 1); ay <= std::min(gy - 1, cy + 1); ++ay)
+                        for (int ax = std::max(0, cx - 1); ax <= std::min(gx - 1, cx + 1); ++ax) {
+                            const int64_t cc = ((int64_t)az * gy + ay) * gx + ax;
+                            for (int32_t q = start[(size_t)cc]; q < start[(size_t)cc + 1]; ++q) {
+                                const int j = sorted[(size_t)q];
+                                if (j <= i) continue;                       // every pair once, i < j
+                                const int32_t* cj = coords + 4 * (int64_t)(lo + j);
+                                const double sj = sigmas[cj[3]];
+                                if (si == 0.0 && sj == 0.0) continue;
+                                double r1, r2, ms;
+                                if (si > sj) { ms = si; r1 = 1.0; r2 = sj / si; }
+                                else         { ms = sj; r2 = 1.0; r1 = si / sj; }
+                                const double den = ms * root3;
+                                const double d0 = cj[0] / den - zi / den;
+                                const double d1 = cj[1] / den - yi / den;
+                                const double d2 = cj[2] / den - xi / den;
+                                const double d = std::sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+                                if (d > r1 + r2) continue;
+                                double f;
+                                if (d <= std::fabs(r1 - r2)) {
+                                    f = 1.0;
+                                } else {
+                                    const double rs = r1 + r2;
+                                    const double tt = rs - d;
+                                    const double vol = kPi / (12 * d) * (tt * tt) *
+                                                       (d * d + 2 * d * rs - 3 * (r1 * r1 + r2 * r2) + 6 * r1 * r2);
+                                    const double rm = r1 < r2 ? r1 : r2;
+                                    f = vol / (4. / 3 * kPi * (rm * rm * rm));
+                                }
+                                if (f > overlap - band) out.push_back(found{lo + i, lo + j, f});
+                            }
+                        }
+            }
+        }
+    });
+    int64_t total = 0, knife = 0;
+    for (auto& v : per_thread) total += (int64_t)v.size();
+    *n_pairs = total;
+    {
+        int64_t at = 0;
+        for (auto& v : per_thread)
+            for (const found& p : v) {
+                if (std::fabs(p.f - overlap) <= band) ++knife;
+                if (at < cap) { pairs[2 * at] = p.i; pairs[2 * at + 1] = p.j; frac[at] = p.f; }
+                ++at;
+            }
+    }
+    *n_knife = knife;
+    if (knife || total > cap) return MMX_OK;
+    // ---- the sequential rule where its outcome does not depend on the order: loser = the smaller sigma, the first of
+    // the pair on equal sigmas; a block is "open" when one of its blobs both loses and wins
+    std::vector<uint8_t> role((size_t)n, 0);        // bit 0: loses some pair, bit 1: wins some pair
+    for (int64_t k = 0; k < total; ++k) {
+        if (!(frac[k] > overlap)) continue;
+        const int32_t i = pairs[2 * k], j = pairs[2 * k + 1];
+        const bool first_bigger = sigmas[coords[4 * (int64_t)i + 3]] > sigmas[coords[4 * (int64_t)j + 3]];
+        role[(size_t)(first_bigger ? j : i)] |= 1;
+        role[(size_t)(first_bigger ? i : j)] |= 2;
+    }
+    for (int b = 0; b < n_blocks; ++b) {
+        bool open = false;
+        for (int32_t r = offsets[b]; r < offsets[b + 1] && !open; ++r) open = role[(size_t)r] == 3;
+        open_blocks[b] = open ? 1 : 0;
+        if (!open)
+            for (int32_t r = offsets[b]; r < offsets[b + 1]; ++r)
+                if (role[(size_t)r] & 1) alive[r] = 0;
+    }
+    return MMX_OK;
+}
+
+// Block tables of the surviving blobs, written straight into the caller's merged table (the arena the pruning
+// step works on): per row the reference's 11 columns (magmap/cv/detector.py:88-113, 325-364: z, y, x, radius =
+// sigma sqrt(3), confirmed -1, truth -1, channel, abs z, y, x, region -1), coordinates shifted by the block's offset
+// in the ROI (stack_detect.py:164-170), `n_extra` further columns left untouched, then the block's grid coordinate in
+// the 3 tag columns (chunking.merge_blobs :410-445); and the compact copies the native pruning reads.
+//   interior : optional [n_blocks][6] block-relative bounds lo z, y, x, hi z, y, x: rows outside are dropped
+//              (detector.get_blobs_interior, applied before the shift as detect_blobs does, :952-955)
+//   store    : [.. ][ld] float64, rows from row0 on are written; zyx/tag: [..][3] int32; abs_zyx: [..][3] float64
+//   rows_per_block : out [n_blocks]
+extern "C" int mmx_host_emit_tables(const int32_t* coords, const uint8_t* alive, const int32_t* offsets, int n_blocks,
+                                    const double* sigmas, int n_sigma, double channel, const double* block_offsets,
+                                    const int32_t* block_tags, const int32_t* interior,
+                                    double* store, int64_t ld, int32_t* zyx, int32_t* tag, double* abs_zyx,
+                                    int64_t row0, int64_t capacity, int64_t* rows_per_block)
+{
+    if (!offsets || n_blocks < 1 || !sigmas || !block_offsets || !block_tags || !store || ld < 14 || !zyx || !tag ||
+        !abs_zyx || row0 < 0 || !rows_per_block)
+        return MMX_ERR_ARG;
+    const int64_t n = offsets[n_blocks];
+    if (n && (!coords || !alive)) return MMX_ERR_ARG;
+    auto inside = [&](int b, const int32_t* c) {
+        if (!interior) return true;
+        const int32_t* q = interior + 6 * (int64_t)b;
+        return c[0] >= q[0] && c[1] >= q[1] && c[2] >= q[2] && c[0] < q[3] && c[1] < q[4] && c[2] < q[5];
+    };
+    std::vector<int64_t> first((size_t)n_blocks + 1, row0);
+    for (int b = 0; b < n_blocks; ++b) {
+        int64_t k = 0;
+        for (int32_t r = offsets[b]; r < offsets[b + 1]; ++r) {
+            if (coords[4 * (int64_t)r + 3] < 0 || coords[4 * (int64_t)r + 3] >= n_sigma) return MMX_ERR_ARG;
+            k += alive[r] && inside(b, coords + 4 * (int64_t)r);
+        }
+        rows_per_block[b] = k;
+        first[(size_t)b + 1] = first[(size_t)b] + k;
+    }
+    if (first[(size_t)n_blocks] > capacity) return MMX_ERR_WORKSPACE;
+    const double root3 = std::sqrt(3.0);
+    const int T = n < 4000 ? 1 : std::min(pool::get().size(), 16);
+    parallel(std::min(T, n_blocks), [&](int t, int nt) {
+        for (int b = t; b < n_blocks; b += nt) {
+            int64_t at = first[(size_t)b];
+            const double* off = block_offsets + 3 * (int64_t)b;
+            const int32_t* tg = block_tags + 3 * (int64_t)b;
+            for (int32_t r = offsets[b]; r < offsets[b + 1]; ++r) {
+                const int32_t* c = coords + 4 * (int64_t)r;
+                if (!alive[r] || !inside(b, c)) continue;
+                double* o = store + at * ld;
+                for (int a = 0; a < 3; ++a) {
+                    const double p = (double)c[a] + off[a];
+                    o[a] = p; o[7 + a] = p;
+                    abs_zyx[3 * at + a] = p;
+                    zyx[3 * at + a] = (int32_t)p;
+                    tag[3 * at + a] = tg[a];
+                    o[ld - 3 + a] = (double)tg[a];
+                }
+                o[3] = sigmas[c[3]] * root3;
+                o[4] = -1.0; o[5] = -1.0; o[6] = channel; o[10] = -1.0;
+                ++at;
+            }
+        }
+    });
+    return MMX_OK;
+}

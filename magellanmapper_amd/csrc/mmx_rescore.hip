@@ -20,6 +20,7 @@
 // just streamed by the float32 passes); the work is ~1e5 float64 operations per point and
 // there are ~1e3 points per block, so this costs a few per cent of the float32 passes.
 
+#include <algorithm>
 #include <type_traits>
 
 #include "mmx_common.h"
@@ -173,6 +174,60 @@ int launch(const mmx_volume* vol, const mmx_block* d_blocks, mmx_cand* d_pts, ui
 }
 
 }  // namespace
+
+// ---- probes: the neighbours whose exact values decide a contested candidate, appended to the candidate table
+// itself so that ONE re-score launch and ONE copy bring the host everything it needs (the host used to build this
+// list from the candidates, upload it and wait for a second re-score: two device round trips per batch).
+namespace {
+__global__ void __launch_bounds__(MMX_WG)
+expand_probes_kernel(mmx_cand* __restrict__ tab, uint32_t cap, uint32_t* __restrict__ count,
+                     const uint32_t* __restrict__ n_cands, const mmx_block* __restrict__ blocks, int n_blocks, int ns)
+{
+    const uint32_t n = *n_cands < cap ? *n_cands : cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * MMX_WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * MMX_WG) {
+        const mmx_cand c = tab[i];
+        if (!(c.flags & MMX_CAND_CONTESTED) || c.slot < 0 || c.slot >= n_blocks) continue;
+        const mmx_block bd = blocks[c.slot];
+        const bool banded = (c.flags & MMX_CAND_BAND) != 0;
+        int j = 0;
+        for (int ds = -1; ds <= 1; ++ds)
+            for (int dz = -1; dz <= 1; ++dz)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if ((ds | dz | dy | dx) == 0) continue;
+                        const int bit = j++;
+                        const int ss = c.s + ds, zz = c.z + dz, yy = c.y + dy, xx = c.x + dx;
+                        if (ss < 0 || ss >= ns || zz < 0 || zz >= bd.nz || yy < 0 || yy >= bd.ny || xx < 0 || xx >= bd.nx)
+                            continue;
+                        if (banded && !(bit < 64 ? (c.band >> bit) & 1ull : (c.flags >> (16 + bit - 64)) & 1u)) continue;
+                        const uint32_t pos = atomicAdd(count, 1u);
+                        if (pos < cap) {
+                            mmx_cand r;
+                            r.slot = c.slot; r.s = ss; r.z = zz; r.y = yy; r.x = xx;
+                            r.flags = MMX_CAND_PROBE;
+                            r.v = 0.f; r.nbr_max = 0.f;
+                            r.v64 = __longlong_as_double(0x7ff8000000000000LL);
+                            r.band = i;                      // the candidate this neighbour may out-vote
+                            tab[pos] = r;
+                        }
+                    }
+    }
+}
+}  // namespace
+
+extern "C" int mmx_expand_probes(mmx_cand* d_cands, uint32_t cap, uint32_t* d_count, uint32_t* d_n_cands,
+                                 const mmx_block* d_blocks, int n_blocks, int n_sigma, void* stream)
+{
+    if (!d_cands || !d_count || !d_n_cands || !d_blocks || n_blocks < 1 || n_sigma < 1) return MMX_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(d_n_cands, d_count, sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return MMX_ERR_HIP;
+    if (cap == 0) return MMX_OK;
+    mmx_timed_scope ts(MMX_K_RESCORE, s);
+    const uint32_t gx = std::min<uint32_t>(1024u, (cap + MMX_WG - 1) / MMX_WG);
+    hipLaunchKernelGGL(expand_probes_kernel, dim3(gx), dim3(MMX_WG), 0, s, d_cands, cap, d_count, d_n_cands, d_blocks,
+                       n_blocks, n_sigma);
+    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
+}
 
 extern "C" int mmx_rescore_f64(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks,
                                mmx_cand* d_pts, uint32_t cap, const uint32_t* d_count,

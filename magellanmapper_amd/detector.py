@@ -394,7 +394,7 @@ def detect_blobs(roi, channel: Optional[Sequence[int]],
 
 def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                                on_block=None, denoise_max_shape=None, exclude=None,
-                               coloc: bool = False) -> List[Optional[np.ndarray]]:
+                               coloc: bool = False, sink=None) -> List[Optional[np.ndarray]]:
     """:func:`detect_blobs` for many blocks of one resident volume in one device pass.
 
     Returns one 11-column table (block-relative coordinates) or ``None`` per block, rows
@@ -406,6 +406,9 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
     block ``i``'s border-exclusion matrix, applied as ``detect_blobs`` applies it (:952-955); with
     ``coloc`` the intensity co-localisation flags are then appended as extra columns
     (stack_detect.py:159-162; :mod:`colocalizer`) -- both before ``on_block``.
+    ``sink(indices, peak_batch, channel) -> tables`` (optional) builds the finished tables of a batch itself from
+    the native host path's arrays (``blob_log.PeakBatch``; ``stack_detect._ArenaSink`` writes them straight into the
+    merged table): used for one channel without rescale / co-localisation, instead of ``exclude`` + ``on_block``.
     """
     from . import blob_log as bl
     multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
@@ -490,12 +493,18 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                 for i, tbl in zip(indices, tbls):
                     done[i] = on_block(i, tbl) if on_block is not None else tbl
 
+        to_sink = None
+        if sink is not None and len(channels) == 1 and iso_factor is None and not coloc:
+            def to_sink(indices, pb, chl=chl):
+                for i, tbl in zip(indices, sink(indices, pb, chl)):
+                    done[i] = tbl
+
         bl.blob_log_blocks(
             dvol, chl if multichannel else 0, origins, log_shapes,
             min_sigma=settings["min_sigma_factor"] * scaling_factor,
             max_sigma=settings["max_sigma_factor"] * scaling_factor,
             num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
-            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=source)
+            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=source, sink=to_sink)
     return done
 
 

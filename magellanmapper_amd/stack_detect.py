@@ -140,6 +140,63 @@ class _TableArena:
         return at == self.n
 
 
+class _ArenaSink:
+    """Finished block tables straight from the native host path into the arena (``mmx_host_emit_tables``): what
+    ``detect_blobs`` (11 columns, border exclusion), ``detect_sub_roi`` (shift to ROI coordinates) and
+    ``merge_blobs`` (grid-coordinate tags) do per block in the reference, for a whole batch in one native call."""
+
+    def __init__(self, arena: _TableArena, grid_coords, block_offsets, shapes, exclude_of):
+        self.arena = arena
+        self.grid_coords = np.asarray(grid_coords, dtype=np.int32).reshape(-1, 3)     # per block of this rank's share
+        self.block_offsets = np.ascontiguousarray(block_offsets, dtype=np.float64).reshape(-1, 3)
+        self.shapes = shapes
+        self.exclude_of = exclude_of
+
+    def __call__(self, indices, pb, chl):
+        ar = self.arena
+        idx = np.asarray(indices, dtype=np.int64)
+        nb = len(idx)
+        alive_before = np.concatenate(([0], np.cumsum(pb.alive, dtype=np.int64)))
+        per_block_before = alive_before[pb.offsets[1:]] - alive_before[pb.offsets[:-1]]
+        need = ar.n + int(alive_before[-1])
+        if need > ar.cap:
+            ar._grow(need)
+        interior = None
+        if self.exclude_of is not None:
+            interior = np.empty((nb, 6), dtype=np.int32)
+            for k, i in enumerate(indices):
+                ex = self.exclude_of(i)
+                lo = np.zeros(3) if ex is None else np.asarray(ex[0], dtype=float)
+                hi = np.asarray(self.shapes[i], dtype=float) - (0 if ex is None else np.asarray(ex[1], dtype=float))
+                interior[k, :3] = np.ceil(lo)            # integer coordinates: z >= lo  <=>  z >= ceil(lo)
+                interior[k, 3:] = np.ceil(hi)            #                      z < hi   <=>  z < ceil(hi)
+        offs = np.ascontiguousarray(self.block_offsets[idx])
+        tags = np.ascontiguousarray(self.grid_coords[idx])
+        rows = np.zeros(nb, dtype=np.int64)
+        nat.check(nat.lib().mmx_host_emit_tables(
+            pb.coords.ctypes.data, pb.alive.ctypes.data, pb.offsets.ctypes.data, nb, pb.sigmas.ctypes.data,
+            len(pb.sigmas), float(chl), offs.ctypes.data, tags.ctypes.data,
+            None if interior is None else interior.ctypes.data, ar.store.ctypes.data, ar.store.shape[1],
+            ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data, ar.n, ar.cap, rows.ctypes.data),
+            "mmx_host_emit_tables")
+        out = []
+        at = ar.n
+        for k in range(nb):
+            if per_block_before[k] == 0:
+                out.append(None)                         # no blobs at all: detect_blobs returns None (:941-942)
+            elif rows[k] == 0:
+                out.append(np.zeros((0, ar.n_cols)))     # all excluded: an EMPTY table
+            else:
+                coord = tuple(int(v) for v in tags[k])
+                ar.spans[coord] = (at, at + int(rows[k]))
+                out.append(ar.store[at:at + int(rows[k]), :ar.n_cols])
+                at += int(rows[k])
+        if at > ar.n:
+            ar.chan_lo, ar.chan_hi = min(ar.chan_lo, chl), max(ar.chan_hi, chl)
+        ar.n = at
+        return out
+
+
 class _SegRois(np.ndarray):
     """Object array of per-block tables that remembers the arena its tables live in."""
     arena = None
@@ -248,9 +305,13 @@ class StackDetector:
 
         if mine:
             dvol = img if isinstance(img, bl.DeviceVolume) else bl.DeviceVolume(img)
+            sink = None
+            if arena is not None and n_extra == 0:
+                sink = _ArenaSink(arena, [coords[i] for i in mine], [sub_rois_offsets[coords[i]] for i in mine],
+                                  shapes, exclude_of if exclude_border is not None else None)
             tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
                                                          denoise_max_shape=denoise_max_shape,
-                                                         exclude=exclude_of, coloc=coloc)
+                                                         exclude=exclude_of, coloc=coloc, sink=sink)
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
         return cls.assemble_seg_rois(local, grid, n_extra, arena)

@@ -31,6 +31,15 @@ def gpu():
     return torch.device("cuda", 0)
 
 
+@pytest.fixture(params=["native", "numpy"])
+def host_path(request, monkeypatch):
+    """Both host formulations of the per-batch decisions: the native one (``mmx_host_resolve_peaks`` & co., the
+    default) and the NumPy one it replaced (kept as a cross-check and for ``exact_values=False``)."""
+    from magellanmapper_amd import blob_log as bl
+    monkeypatch.setattr(bl, "HOST_PATH", request.param)
+    return request.param
+
+
 BLOBLOG_CASES = sorted(os.path.basename(p)[len("bloblog_"):-4]
                        for p in glob.glob(os.path.join(GOLDEN, "bloblog_*.npz")))
 DETECT_CASES = sorted(os.path.basename(p)[len("detect_"):-4]
@@ -102,7 +111,7 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
 
 
 @pytest.mark.parametrize("case", BLOBLOG_CASES)
-def test_blob_log_identical_to_reference(gpu, case):
+def test_blob_log_identical_to_reference(gpu, case, host_path):
     """A4 + A5: ordered raw peaks with bit-exact float64 values, and the pruned blobs."""
     from magellanmapper_amd import blob_log as bl
     g = load_golden("bloblog_%s.npz" % case)
@@ -198,7 +207,7 @@ def test_large_sigma_takes_generic_path(gpu):
     np.testing.assert_array_equal(got, want)
 
 
-def test_contested_ties_resolved_exactly(gpu):
+def test_contested_ties_resolved_exactly(gpu, host_path):
     """A mirror-symmetric volume has exact float64 ties between mirrored voxels: plateaus of
     equal maxima must come out exactly as scikit-image reports them."""
     from magellanmapper_amd import blob_log as bl
@@ -269,7 +278,7 @@ def golden_preproc_env(monkeypatch):
 
 
 @pytest.mark.parametrize("case", STACK_CASES)
-def test_detect_blobs_blocks_matches_reference(gpu, case, tmp_path, monkeypatch, golden_preproc_env):
+def test_detect_blobs_blocks_matches_reference(gpu, case, tmp_path, monkeypatch, golden_preproc_env, host_path):
     """A8-A14 (and P1-P3 for the ``denoise*`` cases): per-block tables, merged table and final
     8-column table identical to the real reference's ``detect_blobs_blocks``."""
     from magellanmapper_amd import chunking, config, stack_detect
@@ -365,7 +374,7 @@ def _oracle_final(vol, prof_over):
     return mmo.detect_blobs_blocks(vol, None, [prof], config.resolutions)[0]
 
 
-def test_many_blocks_several_batches_identical_to_oracle(gpu, tmp_path, monkeypatch):
+def test_many_blocks_several_batches_identical_to_oracle(gpu, tmp_path, monkeypatch, host_path):
     """32 blocks through the pipelined batches (forced small workspace -> several batches, tapered
     tail, side-stream follow-ups) and the native host prune; final table identical to the oracle."""
     import functools
@@ -387,7 +396,7 @@ def test_many_blocks_several_batches_identical_to_oracle(gpu, tmp_path, monkeypa
     np.testing.assert_array_equal(lexsorted(blobs.blobs), lexsorted(want))
 
 
-def test_candidate_table_overflow_is_retried(gpu, monkeypatch):
+def test_candidate_table_overflow_is_retried(gpu, monkeypatch, host_path):
     """A candidate table that is too small must be detected and the batch redone."""
     from magellanmapper_amd import blob_log as bl
     from oracle import blob_log_oracle as blo
@@ -409,7 +418,7 @@ def test_candidate_table_overflow_is_retried(gpu, monkeypatch):
     np.testing.assert_array_equal(got, want)
 
 
-def test_constant_image_plateaus(gpu):
+def test_constant_image_plateaus(gpu, host_path):
     """Constant images: with one sigma every voxel equals its 3^4 maximum and scikit-image reports
     no peaks at all (peak.py:41-43); with two sigmas the brighter scale is one big plateau of
     peaks (all exact float64 ties) that the overlap prune then thins out -- both must match."""
@@ -883,7 +892,7 @@ def test_tiled_path_geometry_limits_and_interleaved_channels(gpu):
         np.testing.assert_array_equal(res, blo.blob_log(a[:, :, :shp[2]], 3.0, 4.0, 3, 0.05, 0.5))
 
 
-def test_plateau_of_contested_candidates_in_one_batch(gpu, tmp_path, monkeypatch):
+def test_plateau_of_contested_candidates_in_one_batch(gpu, tmp_path, monkeypatch, host_path):
     """Found by tools/soak_stack.py (seed 202, trial 617): spectral unmixing clips whole regions of the second channel
     to 0, every voxel of such a plateau is a contested candidate, and one batch of 125 small blocks asked for the exact
     values of 19 million neighbours in one call -- more workgroups than a one-dimensional grid of 256-thread groups may

@@ -694,3 +694,228 @@ def test_q16_error_bound_is_a_function_of_the_weights():
         assert abs(got - want) < 1e-12, sigma
         assert 3.5e-5 < got < 4.8e-5 and 4 * got <= bl.EPS_REL_Q16, (sigma, got)
     assert lib.mmx_tiled_q16_error_bound(None, None, 3, 1.0) < 0
+
+
+# ---------------------------------------------------------------- native per-batch host work (mmx_host.cpp)
+def _random_candidates(rng, shapes, ns, n_per_block, tie_every=0):
+    """A candidate table as the device leaves it: random voxels (each once), float64 values, float32 stand-ins,
+    some contested with probes appended (band = index of their candidate)."""
+    from magellanmapper_amd import _native as nat
+    recs, probes = [], []
+    for slot, shp in enumerate(shapes):
+        cube = int(np.prod(shp)) * ns
+        lin = rng.choice(cube, size=min(n_per_block, cube), replace=False)
+        s = lin % ns
+        x = (lin // ns) % shp[2]
+        y = (lin // (ns * shp[2])) % shp[1]
+        z = lin // (ns * shp[2] * shp[1])
+        v = rng.random(len(lin)) * 0.5
+        if tie_every:
+            v[::tie_every] = 0.3125               # exact ties inside the block
+        for k in range(len(lin)):
+            recs.append((slot, s[k], z[k], y[k], x[k], 0, np.float32(v[k]), 0.0, v[k], 0))
+    cands = np.array(recs, dtype=nat.CAND_DTYPE)
+    rng.shuffle(cands)
+    contested = rng.random(len(cands)) < 0.2
+    cands["flags"][contested] = nat.MMX_CAND_CONTESTED
+    for i in np.nonzero(contested)[0]:
+        for _ in range(int(rng.integers(0, 4))):
+            # a rival somewhere next to it: sometimes above, sometimes below the candidate
+            probes.append((cands["slot"][i], 0, 0, 0, 0, nat.MMX_CAND_PROBE, 0.0, 0.0,
+                           cands["v64"][i] + rng.choice([-0.01, 0.0, 0.01]), i))
+    table = np.concatenate([cands, np.array(probes, dtype=nat.CAND_DTYPE)]) if probes else cands
+    return table, len(cands)
+
+
+def _resolve_with_numpy(table, n_cands, shapes, ns, thr):
+    """The rules of blob_log._resolve_peaks on a fully re-scored table, as plain NumPy per block."""
+    c, p = table[:n_cands], table[n_cands:]
+    rival = np.full(n_cands, -np.inf)
+    np.maximum.at(rival, p["band"].astype(np.int64), p["v64"])
+    dims = np.array([shapes[k] for k in c["slot"]]).reshape(-1, 3)
+    border = ((c["s"] == 0) | (c["s"] == ns - 1) | (c["z"] == 0) | (c["z"] == dims[:, 0] - 1) | (c["y"] == 0) |
+              (c["y"] == dims[:, 1] - 1) | (c["x"] == 0) | (c["x"] == dims[:, 2] - 1))
+    rival[border] = np.maximum(rival[border], 0.0)
+    keep = c["v64"] > thr
+    cont = (c["flags"] & 1) != 0
+    keep[cont] &= c["v64"][cont] >= rival[cont]
+    out = []
+    for b, shp in enumerate(shapes):
+        rows = c[keep & (c["slot"] == b)]
+        if len(rows) == int(np.prod(shp)) * ns and len(rows) > 1:
+            rows = rows[:0]
+        lin = ((rows["z"].astype(np.int64) * shp[1] + rows["y"]) * shp[2] + rows["x"]) * ns + rows["s"]
+        rows = rows[np.argsort(lin)]
+        rank = np.argsort(-rows["v64"])
+        out.append((np.stack([rows[f][rank] for f in ("z", "y", "x", "s")], axis=1).astype(np.int64).reshape(-1, 4),
+                    rows["v64"][rank]))
+    return out
+
+
+def test_native_peak_resolution_matches_the_numpy_rules():
+    """mmx_host_resolve_peaks (through blob_log._resolve_peaks_native): contested candidates against their probes,
+    zero padding at the cube border, the threshold, np.nonzero order, descending order, exact ties handed to
+    np.argsort, a constant cube, the float32 deviation check."""
+    from magellanmapper_amd import _native as nat, blob_log as bl
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        ns = int(rng.integers(1, 6))
+        shapes = [tuple(int(v) for v in rng.integers(2, 9, 3)) for _ in range(int(rng.integers(1, 7)))]
+        if trial == 3:
+            shapes.append((2, 1, 2))            # every voxel of this one a candidate: constant cube -> no peaks
+        table, n_c = _random_candidates(rng, shapes, ns, 10 ** 6 if trial == 3 else 40, tie_every=7 if trial % 3 == 0 else 0)
+        if trial == 3:
+            keep = (table["slot"] != len(shapes) - 1) | (table["flags"] & nat.MMX_CAND_PROBE != 0)
+            keep[:n_c] |= True                  # keep all of the constant cube's voxels, uncontested
+            table["flags"][:n_c][table["slot"][:n_c] == len(shapes) - 1] = 0
+            table["v64"][:n_c][table["slot"][:n_c] == len(shapes) - 1] = 0.4
+            table["v"][:n_c][table["slot"][:n_c] == len(shapes) - 1] = np.float32(0.4)
+        blocks = np.zeros(len(shapes), dtype=nat.BLOCK_DTYPE)
+        for k, shp in enumerate(shapes):
+            blocks[k] = (0, shp[0], shp[1], shp[2], k, 32, 0)
+        stats = bl.BatchStats()
+        pb = bl._resolve_peaks_native(table, n_c, blocks, ns, 0.1, stats, 1e-3)
+        want = _resolve_with_numpy(table, n_c, shapes, ns, 0.1)
+        assert len(pb) == len(shapes)
+        for b in range(len(shapes)):
+            coords, vals = pb.block(b)
+            np.testing.assert_array_equal(coords, want[b][0])
+            np.testing.assert_array_equal(vals, want[b][1])
+        assert stats.n_peaks == sum(len(w[1]) for w in want) and stats.n_probes == len(table) - n_c
+        assert stats.n_contested == int(np.count_nonzero(table["flags"][:n_c] & 1))
+    # float32 too far from float64: the caller widens the band; NaN: an error
+    table, n_c = _random_candidates(rng, [(4, 4, 4)], 2, 10)
+    blocks = np.zeros(1, dtype=nat.BLOCK_DTYPE)
+    blocks[0] = (0, 4, 4, 4, 0, 32, 0)
+    table["v"][0] += np.float32(0.01)
+    with pytest.raises(bl._BandTooNarrow):
+        bl._resolve_peaks_native(table, n_c, blocks, 2, 0.1, bl.BatchStats(), 1e-3)
+    table["v64"][1] = np.nan
+    with pytest.raises(nat.MmxError):
+        bl._resolve_peaks_native(table, n_c, blocks, 2, 0.1, bl.BatchStats(), 1e-3)
+    empty = bl._resolve_peaks_native(table[:0], 0, blocks, 2, 0.1, bl.BatchStats(), 1e-3)
+    assert len(empty.coords) == 0 and list(empty.offsets) == [0, 0]
+
+
+def _prune_with_numpy(allb, offsets, overlap):
+    """skimage's _prune_blobs rule per block by brute force (every pair, in any order: only used where no blob both
+    wins and loses, where the order cannot matter)."""
+    from magellanmapper_amd import blob_log as bl
+    sig = allb[:, 3].copy()
+    chain = []
+    for b in range(len(offsets) - 1):
+        lo, hi = offsets[b], offsets[b + 1]
+        losers, winners = set(), set()
+        for i in range(lo, hi):
+            for j in range(i + 1, hi):
+                if bl._exact_overlap(allb[i], allb[j]) > overlap:
+                    l, w = (j, i) if allb[i, 3] > allb[j, 3] else (i, j)
+                    losers.add(l)
+                    winners.add(w)
+        if losers & winners:
+            chain.append(b)
+        else:
+            sig[list(losers)] = 0
+    return sig > 0, chain
+
+
+def test_native_overlap_prune_matches_brute_force():
+    """mmx_host_overlap_prune: crowded random peaks of several scales; closed blocks equal the brute-force rule, open
+    blocks (a blob both wins and loses) are reported, and the full path (blob_log._prune_batch_native, which takes
+    the reference's pair order for those) equals the array formulation fed with the same pairs."""
+    from magellanmapper_amd import blob_log as bl
+    rng = np.random.default_rng(12)
+    space = bl.ScaleSpace.make(2.0, 5.0, 4)
+    n_open = 0
+    for trial in range(6):
+        sizes = rng.integers(0, 60, int(rng.integers(1, 6)))
+        offsets = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+        n = int(offsets[-1])
+        coords = np.empty((n, 4), dtype=np.int32)
+        coords[:, :3] = rng.integers(0, 40, (n, 3))
+        coords[:, 3] = rng.integers(0, 4, n)
+        pb = bl.PeakBatch(coords, rng.random(n), offsets)
+        stats = bl.BatchStats()
+        pb = bl._prune_batch_native(pb, space, 0.5, stats)
+        allb = coords.astype(np.float64)
+        allb[:, 3] = space.sigmas[coords[:, 3]]
+        want_alive, chain = _prune_with_numpy(allb, offsets, 0.5)
+        n_open += len(chain)
+        assert stats.n_order_fallbacks == len(chain)
+        for b in range(len(sizes)):
+            lo, hi = offsets[b], offsets[b + 1]
+            if b not in chain:
+                np.testing.assert_array_equal(pb.alive[lo:hi].astype(bool), want_alive[lo:hi], err_msg=f"{trial}/{b}")
+            got = pb.blobs(b)
+            assert got.shape == ((int(pb.alive[lo:hi].sum()), 4) if hi > lo else (0, 3))
+        # open blocks: the same pairs through the array formulation alone
+        sig = allb[:, 3].copy()
+        pairs = np.array([(i, j) for b in range(len(sizes)) for i in range(offsets[b], offsets[b + 1])
+                          for j in range(i + 1, offsets[b + 1])], dtype=np.int64).reshape(-1, 2)
+        frac = np.array([bl._exact_overlap(allb[i], allb[j]) for i, j in pairs])
+        sel = frac > 0.5 - bl.OVERLAP_BAND
+        bl._apply_pairs(allb, sig, offsets, pairs[sel], frac[sel], 0.5, bl.BatchStats())
+        np.testing.assert_array_equal(pb.alive.astype(bool), sig > 0)
+    assert n_open > 0          # (the trials do exercise the order-dependent case)
+
+
+def test_native_table_emit_matches_the_python_tables():
+    """mmx_host_emit_tables: 11 columns + tags + compact copies, block offsets, border exclusion, capacity check --
+    against the table building of detector.detect_blobs_blocks_device + StackDetector._finish_block."""
+    import ctypes
+    from magellanmapper_amd import _native as nat, detector
+    rng = np.random.default_rng(13)
+    sig = np.array([3.0, 3.5, 4.0])
+    offsets = np.array([0, 5, 5, 12, 20], dtype=np.int32)
+    n = 20
+    coords = np.empty((n, 4), dtype=np.int32)
+    coords[:, :3] = rng.integers(0, 30, (n, 3))
+    coords[:, 3] = rng.integers(0, 3, n)
+    alive = (rng.random(n) < 0.7).astype(np.uint8)
+    boffs = rng.integers(0, 500, (4, 3)).astype(np.float64)
+    tags = rng.integers(0, 8, (4, 3)).astype(np.int32)
+    interior = np.array([[2, 2, 2, 28, 28, 28]] * 4, dtype=np.int32)
+    detector.Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry to the 11 columns
+    for use_interior in (False, True):
+        ld, row0, cap = 16, 3, 40
+        store = np.full((cap, ld), 7.5)
+        zyx = np.zeros((cap, 3), np.int32)
+        tag = np.zeros((cap, 3), np.int32)
+        absz = np.zeros((cap, 3))
+        per = np.zeros(4, dtype=np.int64)
+        rc = nat.lib().mmx_host_emit_tables(coords.ctypes.data, alive.ctypes.data, offsets.ctypes.data, 4,
+                                            sig.ctypes.data, 3, 1.0, boffs.ctypes.data, tags.ctypes.data,
+                                            interior.ctypes.data if use_interior else None, store.ctypes.data, ld,
+                                            zyx.ctypes.data, tag.ctypes.data, absz.ctypes.data, row0, cap,
+                                            per.ctypes.data)
+        assert rc == 0
+        at = row0
+        for b in range(4):
+            rows = coords[offsets[b]:offsets[b + 1]][alive[offsets[b]:offsets[b + 1]].astype(bool)]
+            tbl = rows.astype(np.float64)
+            tbl[:, 3] = sig[rows[:, 3]]
+            big = np.empty((len(rows), 11))
+            big[:, :4] = tbl
+            big[:, 3] = big[:, 3] * np.sqrt(3)
+            big[:, 4:6] = -1
+            big[:, 6] = 1.0
+            big[:, 7:10] = big[:, :3]
+            big[:, 10] = -1
+            if use_interior:
+                big = detector.get_blobs_interior(big, (30, 30, 30), (2, 2, 2), (2, 2, 2))
+            detector.Blobs.shift_blob_rel_coords(big, boffs[b])
+            detector.Blobs.shift_blob_abs_coords(big, boffs[b])
+            assert per[b] == len(big)
+            np.testing.assert_array_equal(store[at:at + len(big), :11], big)
+            np.testing.assert_array_equal(store[at:at + len(big), 11:13], 7.5)          # extra columns untouched
+            np.testing.assert_array_equal(store[at:at + len(big), 13:], np.broadcast_to(tags[b], (len(big), 3)))
+            np.testing.assert_array_equal(zyx[at:at + len(big)], big[:, :3].astype(np.int32))
+            np.testing.assert_array_equal(absz[at:at + len(big)], big[:, 7:10])
+            np.testing.assert_array_equal(tag[at:at + len(big)], np.broadcast_to(tags[b], (len(big), 3)))
+            at += len(big)
+        np.testing.assert_array_equal(store[:row0], 7.5)
+        np.testing.assert_array_equal(store[at:], 7.5)
+        assert nat.lib().mmx_host_emit_tables(
+            coords.ctypes.data, alive.ctypes.data, offsets.ctypes.data, 4, sig.ctypes.data, 3, 1.0, boffs.ctypes.data,
+            tags.ctypes.data, None, store.ctypes.data, ld, zyx.ctypes.data, tag.ctypes.data, absz.ctypes.data, row0,
+            row0 + 1, per.ctypes.data) == 4          # MMX_ERR_WORKSPACE

@@ -11,7 +11,7 @@ import bench
 from magellanmapper_amd import blob_log as bl, config, detector, stack_detect, synth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--budget-gb", type=float, default=64.0)
+ap.add_argument("--budget-gb", type=float, default=16.0)
 ap.add_argument("--keep-heap", action="store_true", help="mallopt: big arrays from the heap, freed memory stays mapped")
 ap.add_argument("--profile", action="store_true", help="cProfile one more step: where the host time goes")
 a = ap.parse_args()
@@ -50,6 +50,8 @@ evs = []
 wrap(bl, "_enqueue_detect", "enqueue batch")
 wrap(bl, "_finish_detect", "finish batch (candidates -> peaks)")
 wrap(bl, "_prune_batch", "per-block overlap prune")
+wrap(bl, "_prune_batch_native", "per-block overlap prune (native)")
+wrap(stack_detect._ArenaSink, "__call__", "tables -> arena (native)")
 orig_prune = stack_detect.StackPruner.prune_blobs_mp.__func__
 
 
