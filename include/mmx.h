@@ -451,6 +451,31 @@ int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
 int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int64_t n,
                        int64_t n_cols, const double* abs_zyx, const int32_t abs_cols[3], double* out);
 
+/* All three axis passes of the pruning for one REGION of the stack (the whole stack, one rank's blocks, or a group
+ * of blocks pruned while the GPU still works on later ones): a table holding the region's own rows (ids
+ * [own_lo, own_hi)) between those rows of its neighbours that lie within 3 x tol of its extent (a pass looks tol far
+ * and sees the outcome of the passes before it), in the merged table's order.  Own rows get the verdicts and
+ * averaged coordinates the reference's whole-table passes (magmap/cv/stack_detect.py:680-861) give them; the
+ * passes being stable sorts by group, a survivor's place in the final table is the place of its key
+ * (group on axis 2, axis 1, axis 0) among all survivors, regions in order on equal keys.
+ *   cur[n_cur]: rows of one channel (own and halo), table order; n_sections[a] <= 1: no pass on axis a
+ *   bounds / nxt_lo / nxt_hi / last_end / tol: as for mmx_host_prune_axis, per axis
+ *   out_rows / out_keys / *out_n: own survivors in final order; abs_zyx updated in place
+ *   n_slab / n_after / n_next: [3][stat_ld] statistics over OWN rows
+ * mmx_host_merge_by_key: out = the stable sort by key of rows[n][ld] (first n_cols columns), keys < n_keys.
+ * mmx_host_gather_by_key: the same for survivors still in the merged table: row ids[i], its three abs columns
+ *   replaced by abs_rows[i][3]. */
+int mmx_host_prune_region(const int32_t* zyx, const int32_t* tag, double* abs_zyx, const int64_t* cur, int64_t n_cur,
+                          int64_t own_lo, int64_t own_hi, const int32_t n_sections[3], const double* const bounds[3],
+                          const double last_end[3], const int32_t tol[3], const double* const nxt_lo[3],
+                          const double* const nxt_hi[3], int64_t* out_rows, int64_t* out_keys, int64_t* out_n,
+                          int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld);
+int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
+                          int64_t n_cols, double* out);
+int mmx_host_gather_by_key(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
+                           int64_t n_keys, int64_t n_cols, const double* abs_rows, const int32_t abs_cols[3],
+                           double* out);
+
 /* out[i][dst_col0 + j] = table[i][src_cols[j]], i < n, j < n_map (<= 64), threaded.  The column shuffles that
  * end a stack detection (reference magmap/cv/stack_detect.py:461-467 -> detector.py
  * replace_rel_with_abs_blob_coords / remove_abs_blob_coords).  `out` may alias `table`. */

@@ -17,6 +17,7 @@
 //   check rows, each group in the current table order.
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -121,14 +122,19 @@ int host_threads(int64_t n_rows)
 }
 }  // namespace
 
-extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
-                                   const int64_t* cur, int64_t n_cur, int axis, int n_sections,
-                                   const double* bounds, double last_end, const int32_t tol[3],
-                                   const double* nxt_lo, const double* nxt_hi,
-                                   int64_t* out_cur, int64_t* out_n,
-                                   int64_t* n_slab, int64_t* n_after, int64_t* n_next)
+namespace {
+// One axis of the pruning.  `own_lo` / `own_hi`: only rows whose id lies in [own_lo, own_hi) count towards the
+// statistics (a table that holds a region's own rows plus a halo of its neighbours' rows: every row is counted by
+// exactly one region); `group_out` (optional, indexed like `cur`): the group id each row was given (-1: dropped).
+int prune_axis_impl(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
+                    const int64_t* cur, int64_t n_cur, int axis, int n_sections,
+                    const double* bounds, double last_end, const int32_t tol[3],
+                    const double* nxt_lo, const double* nxt_hi,
+                    int64_t* out_cur, int64_t* out_n,
+                    int64_t* n_slab, int64_t* n_after, int64_t* n_next,
+                    int64_t own_lo, int64_t own_hi, int32_t* group_out)
 {
-    if (!zyx || !tag || !abs_zyx || (!cur && n_cur) || !bounds || !tol || !out_cur || !out_n ||
+    if ((n_cur && (!zyx || !tag || !abs_zyx || !cur || !out_cur)) || !bounds || !tol || !out_n ||
         !n_slab || !n_after || !n_next || axis < 0 || axis > 2 || n_sections < 2 || n_cur < 0)
         return MMX_ERR_ARG;
     static const bool prof = getenv("MMX_PRUNE_PROF") != nullptr;
@@ -155,14 +161,16 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
         for (int64_t i = lo; i < hi; ++i) {
             const int64_t row = cur[i];
             const double pos = (double)zyx[3 * row + axis];
-            for (int j = 0; j < n_slabs; ++j)
-                if (nxt_lo[j] == nxt_lo[j] && pos >= nxt_lo[j] && pos < nxt_hi[j]) ++P.n_next[(size_t)j];
+            const bool own = row >= own_lo && row < own_hi;
+            if (own)
+                for (int j = 0; j < n_slabs; ++j)
+                    if (nxt_lo[j] == nxt_lo[j] && pos >= nxt_lo[j] && pos < nxt_hi[j]) ++P.n_next[(size_t)j];
             // region = (number of bounds <= pos) - 1   (np.searchsorted(bounds, pos, side="right") - 1)
             const int region = (int)(std::upper_bound(bounds, bounds + n_regions, pos) - bounds) - 1;
             if (region < 0 || !(pos < last_end)) continue;
             const int sec = region >> 1;
             if ((region & 1) == 0) { group[(size_t)i] = sec; continue; }
-            ++P.n_slab[(size_t)sec];
+            if (own) ++P.n_slab[(size_t)sec];
             const int32_t tg = tag[3 * row + axis];
             if (tg == sec) { group[(size_t)i] = n_sections + 2 * sec; P.masters[(size_t)sec].push_back(i); }
             else if (tg == sec + 1) { group[(size_t)i] = n_sections + 2 * sec + 1; P.checks[(size_t)sec].push_back(i); }
@@ -238,7 +246,10 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
         for (int j = t; j < n_slabs; j += nt) {
             const auto& M = masters[(size_t)j];
             const auto& C = checks[(size_t)j];
-            int64_t kept = (int64_t)C.size();
+            auto is_own = [&](int64_t i) { const int64_t row = cur[i]; return row >= own_lo && row < own_hi; };
+            int64_t kept = 0, own_masters = 0;
+            for (size_t k = 0; k < C.size(); ++k) kept += is_own(C[k]);
+            for (size_t m = 0; m < M.size(); ++m) own_masters += is_own(M[m]);
             if (!M.empty() && !C.empty()) {
                 const auto& last = lasts[(size_t)j];
                 const auto& hit = hits[(size_t)j];
@@ -255,9 +266,9 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
                     for (int a = 0; a < 3; ++a) am[a] = new_abs[3 * m + a];
                 }
                 for (size_t k = 0; k < C.size(); ++k)
-                    if (hit[k]) { group[(size_t)C[k]] = -1; --kept; }
+                    if (hit[k]) { group[(size_t)C[k]] = -1; kept -= is_own(C[k]); }
             }
-            n_after[j] = (int64_t)M.size() + kept;
+            n_after[j] = own_masters + kept;
         }
     });
 
@@ -285,6 +296,7 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
         for (int64_t i = lo; i < hi; ++i) {
             const int g = group[(size_t)i];
             if (g >= 0) out_cur[h[(size_t)g]++] = cur[i];
+            if (group_out) group_out[i] = g;
         }
     });
     if (prof) {
@@ -293,6 +305,127 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
         fprintf(stderr, "prune axis %d: n %ld classify %ld us, merge %ld, match %ld, sort %ld\n", axis, (long)n_cur,
                 us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4));
     }
+    return MMX_OK;
+}
+}  // namespace
+
+extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
+                                   const int64_t* cur, int64_t n_cur, int axis, int n_sections,
+                                   const double* bounds, double last_end, const int32_t tol[3],
+                                   const double* nxt_lo, const double* nxt_hi,
+                                   int64_t* out_cur, int64_t* out_n,
+                                   int64_t* n_slab, int64_t* n_after, int64_t* n_next)
+{
+    return prune_axis_impl(zyx, tag, abs_zyx, cur, n_cur, axis, n_sections, bounds, last_end, tol, nxt_lo, nxt_hi,
+                           out_cur, out_n, n_slab, n_after, n_next, INT64_MIN, INT64_MAX, nullptr);
+}
+
+// All three axes of the pruning for one REGION of the stack: a table that holds the region's own rows (ids
+// [own_lo, own_hi)) between the rows of its neighbours that lie within reach of them (the halo), all in the merged
+// table's order.  Every decision of the reference's three passes about a row depends only on rows within
+// 3 x tol of it (a pass looks tol far, and what it finds depends on the passes before), so the region's own rows
+// get the verdicts and averaged coordinates the whole-table passes give them as long as the halo is that wide;
+// halo rows may come out wrong and are dropped from the output.  A surviving row's place in the whole table's final
+// order is that of its key among all survivors -- the passes are stable sorts by group, so the final order is the
+// stable sort by (group on axis 2, group on axis 1, group on axis 0) -- ties between regions in region order.
+//   cur / n_cur  : the rows of one channel, table order (own and halo)
+//   n_sections[a] <= 1 : axis a has one block, no pass (group 0)
+//   bounds[a], nxt_lo[a], nxt_hi[a], last_end[a] : as for mmx_host_prune_axis, per axis
+//   out_rows / out_keys / out_n : the own survivors in final order and their keys; abs_zyx holds their averaged
+//                  coordinates afterwards (and garbage-free but possibly unfinished values for halo rows)
+//   n_slab / n_after / n_next : [3][max_slabs] statistics over OWN rows (row pitch `stat_ld`)
+extern "C" int mmx_host_prune_region(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
+                                     const int64_t* cur, int64_t n_cur, int64_t own_lo, int64_t own_hi,
+                                     const int32_t n_sections[3], const double* const bounds[3],
+                                     const double last_end[3], const int32_t tol[3],
+                                     const double* const nxt_lo[3], const double* const nxt_hi[3],
+                                     int64_t* out_rows, int64_t* out_keys, int64_t* out_n,
+                                     int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld)
+{
+    if ((n_cur && (!zyx || !tag || !abs_zyx || !cur || !out_rows || !out_keys)) || n_cur < 0 || !n_sections || !bounds ||
+        !last_end || !tol || !nxt_lo || !nxt_hi || !out_n || !n_slab || !n_after || !n_next)
+        return MMX_ERR_ARG;
+    for (int a = 0; a < 3; ++a)
+        if (n_sections[a] > 1 && (stat_ld < n_sections[a] - 1 || !bounds[a] || !nxt_lo[a] || !nxt_hi[a])) return MMX_ERR_ARG;
+    int64_t max_row = -1;
+    for (int64_t i = 0; i < n_cur; ++i) { if (cur[i] < 0) return MMX_ERR_ARG; max_row = std::max(max_row, cur[i]); }
+    std::vector<int64_t> key((size_t)(max_row + 1), 0);
+    std::vector<int64_t> a_rows(cur, cur + n_cur), b_rows((size_t)n_cur);
+    std::vector<int32_t> group((size_t)n_cur);
+    int64_t n = n_cur, stride = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (n_sections[a] <= 1) continue;
+        int64_t n_out = 0;
+        const int st = prune_axis_impl(zyx, tag, abs_zyx, a_rows.data(), n, a, n_sections[a], bounds[a], last_end[a], tol,
+                                       nxt_lo[a], nxt_hi[a], b_rows.data(), &n_out, n_slab + a * stat_ld,
+                                       n_after + a * stat_ld, n_next + a * stat_ld, own_lo, own_hi, group.data());
+        if (st != MMX_OK) return st;
+        for (int64_t i = 0; i < n; ++i)
+            if (group[(size_t)i] >= 0) key[(size_t)a_rows[(size_t)i]] += stride * group[(size_t)i];
+        stride *= (int64_t)n_sections[a] + 2 * ((int64_t)n_sections[a] - 1);
+        a_rows.swap(b_rows);
+        n = n_out;
+    }
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t row = a_rows[(size_t)i];
+        if (row >= own_lo && row < own_hi) { out_rows[k] = row; out_keys[k] = key[(size_t)row]; ++k; }
+    }
+    *out_n = k;
+    return MMX_OK;
+}
+
+// Final table of a stack from the survivors of its regions: the stable sort of the concatenated rows (regions in
+// order) by key.  `keys` are small (the product of the three group counts): a counting sort.
+//   rows : [n][ld] float64, the first n_cols columns are copied; out : [n][n_cols]
+extern "C" int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
+                                     int64_t n_cols, double* out)
+{
+    if (n < 0 || n_keys < 1 || n_cols < 1 || n_cols > ld || (n && (!rows || !keys || !out))) return MMX_ERR_ARG;
+    if (n_keys > (int64_t(1) << 26)) return MMX_ERR_UNSUPPORTED;
+    std::vector<int64_t> at((size_t)n_keys + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (keys[i] < 0 || keys[i] >= n_keys) return MMX_ERR_ARG;
+        ++at[(size_t)keys[i] + 1];
+    }
+    for (int64_t k = 0; k < n_keys; ++k) at[(size_t)k + 1] += at[(size_t)k];
+    std::vector<int64_t> dst((size_t)n);
+    for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = at[(size_t)keys[i]]++;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i)
+            std::memcpy(out + dst[(size_t)i] * n_cols, rows + i * ld, (size_t)n_cols * sizeof(double));
+    });
+    return MMX_OK;
+}
+
+// The same for survivors that still live in the merged table: row ids[i] of `table` (its first n_cols columns), the
+// three abs columns replaced by abs_rows[i], written to its place by key.
+extern "C" int mmx_host_gather_by_key(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys,
+                                      int64_t n, int64_t n_keys, int64_t n_cols, const double* abs_rows,
+                                      const int32_t abs_cols[3], double* out)
+{
+    if (n < 0 || n_keys < 1 || n_cols < 1 || n_cols > ld || !abs_cols || (n && (!table || !ids || !keys || !out || !abs_rows)))
+        return MMX_ERR_ARG;
+    if (n_keys > (int64_t(1) << 26)) return MMX_ERR_UNSUPPORTED;
+    for (int a = 0; a < 3; ++a)
+        if (abs_cols[a] < 0 || abs_cols[a] >= n_cols) return MMX_ERR_ARG;
+    std::vector<int64_t> at((size_t)n_keys + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (keys[i] < 0 || keys[i] >= n_keys || ids[i] < 0) return MMX_ERR_ARG;
+        ++at[(size_t)keys[i] + 1];
+    }
+    for (int64_t k = 0; k < n_keys; ++k) at[(size_t)k + 1] += at[(size_t)k];
+    std::vector<int64_t> dst((size_t)n);
+    for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = at[(size_t)keys[i]]++;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            double* o = out + dst[(size_t)i] * n_cols;
+            std::memcpy(o, table + ids[i] * ld, (size_t)n_cols * sizeof(double));
+            for (int a = 0; a < 3; ++a) o[abs_cols[a]] = abs_rows[3 * i + a];
+        }
+    });
     return MMX_OK;
 }
 

@@ -159,6 +159,60 @@ def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: in
     return sorted(out, key=lambda e: e[0])
 
 
+def raise_together(failure: Optional[BaseException], what: str = "a rank") -> None:
+    """Agree on whether any rank failed before the next collective: re-raises ``failure`` on the rank that holds it
+    and raises ``RuntimeError`` on all the others, instead of leaving them waiting in a collective the failed rank
+    never enters (one tiny all_reduce; nothing without a process group beyond re-raising)."""
+    if _active() and world_size() > 1:
+        flag = torch.tensor([0 if failure is None else 1], dtype=torch.int64, device=_device_for_collectives())
+        tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
+        if int(flag.item()) and failure is None:
+            raise RuntimeError(f"{what} failed on another rank; see its log")
+    if failure is not None:
+        raise failure
+
+
+def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.ndarray]:
+    """Every rank's ``(n_r, c)`` float64 array, in rank order (two collectives: the row counts, then the rows padded
+    to the largest count).  Ranks without rows may pass ``n_cols=None`` / a ``(0, 0)`` array: the width is agreed on
+    first.  Without a process group: ``[rows]``."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    if rows.ndim != 2:
+        rows = rows.reshape(len(rows), -1) if rows.size else np.zeros((0, 0))
+    if not _active() or world_size() == 1:
+        return [rows]
+    dev = _device_for_collectives()
+    n_ranks = world_size()
+    meta = torch.tensor([rows.shape[0], rows.shape[1] if rows.shape[0] else int(n_cols or 0)], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(n_ranks)]
+    tdist.all_gather(metas, meta)
+    metas = torch.stack(metas).cpu().numpy()
+    width = int(metas[:, 1].max())
+    have = metas[metas[:, 0] > 0, 1]
+    if len(have) and not np.all(have == have[0]):
+        raise ValueError(f"ranks hold rows of different widths: {sorted(set(int(v) for v in have))}")
+    most = int(metas[:, 0].max())
+    if most == 0 or width == 0:
+        return [np.zeros((0, width)) for _ in range(n_ranks)]
+    padded = np.zeros((most, width))
+    padded[:rows.shape[0], :rows.shape[1]] = rows
+    send = torch.from_numpy(padded).to(dev)
+    recv = [torch.empty_like(send) for _ in range(n_ranks)]
+    tdist.all_gather(recv, send)
+    bufs = torch.stack(recv).cpu().numpy()                       # one device -> host copy
+    return [bufs[r, :int(metas[r, 0])] for r in range(n_ranks)]
+
+
+def all_reduce_sum(values: np.ndarray) -> np.ndarray:
+    """Element-wise sum of an int64 array over the ranks (the array itself without a process group)."""
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    if not _active() or world_size() == 1:
+        return values
+    t = torch.from_numpy(values.copy()).to(_device_for_collectives())
+    tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
 def broadcast_table(table: Optional[np.ndarray], src: int = 0) -> Optional[np.ndarray]:
     """``table`` of rank ``src`` (a float64 2-D array or ``None``) on every rank."""
     if not _active() or world_size() == 1:

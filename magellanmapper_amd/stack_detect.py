@@ -70,6 +70,9 @@ class _TableArena:
         self.n = 0
         self.spans = {}
         self.chan_lo, self.chan_hi = np.inf, -np.inf       # range of the channel column over all rows
+        # rows before the k-th block that was added (blocks arrive in grid order; blocks without rows count too):
+        # what the region-wise pruning addresses blocks by
+        self.row_end = [0]
 
     def _grow(self, need: int):
         cap = max(2 * self.cap, need)
@@ -99,6 +102,10 @@ class _TableArena:
             self.chan_hi = max(self.chan_hi, table[:, 6].max())
         self.n += rows
         self.spans[tuple(coord)] = (a, a + rows)
+
+    def landed(self, n_blocks: int = 1) -> None:
+        """``n_blocks`` more blocks of the share are complete (their rows, if any, are in the arena)."""
+        self.row_end.extend([self.n] * n_blocks)
 
     def view(self, coord):
         a, b = self.spans[tuple(coord)]
@@ -151,6 +158,7 @@ class _ArenaSink:
         self.block_offsets = np.ascontiguousarray(block_offsets, dtype=np.float64).reshape(-1, 3)
         self.shapes = shapes
         self.exclude_of = exclude_of
+        self.pruner = None
 
     def __call__(self, indices, pb, chl):
         ar = self.arena
@@ -194,12 +202,120 @@ class _ArenaSink:
         if at > ar.n:
             ar.chan_lo, ar.chan_hi = min(ar.chan_lo, chl), max(ar.chan_hi, chl)
         ar.n = at
+        # (row_end per block of the batch: rows of the blocks before it)
+        ends = ar.row_end[-1] + np.cumsum(rows)
+        ar.row_end.extend(int(v) for v in ends)
+        if self.pruner is not None:
+            self.pruner.advance()
         return out
 
 
+def _region_reach(tol3) -> np.ndarray:
+    """How far beyond a region's extent rows can influence the pruning of the region's own rows: a pass matches
+    rows up to ``tol`` apart and depends on the outcome of the passes before it, three passes in all; one ``tol``
+    of margin on top."""
+    return 4 * np.asarray(tol3, dtype=np.int64)
+
+
+def _rows_within(zyx: np.ndarray, lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+    """Row numbers of ``zyx`` inside the box ``[lo, hi)``."""
+    return np.flatnonzero(np.all((zyx >= lo) & (zyx < hi), axis=1))
+
+
+class _RegionPruner:
+    """The overlap pruning of one process' table done region by region while later blocks are still being detected.
+
+    A region is a run of consecutive blocks (one row of the block grid along x); it is pruned -- all three passes,
+    ``StackPruner._prune_table`` on its own rows plus the rows of neighbouring regions within reach -- as soon as
+    it and its neighbours have landed, which leaves the last few regions and the merge for the end of the step.
+    Results equal the whole-table passes (``mmx_host_prune_region`` says why); ``StackPruner.prune_blobs_mp`` uses
+    them when it is called with the very parameters they were made for, and prunes the whole table otherwise."""
+
+    def __init__(self, arena: _TableArena, plan, channels, sub_roi_slices, shape3, share):
+        self.arena, self.plan, self.channels = arena, plan, list(channels)
+        grid = sub_roi_slices.shape
+        coords = list(np.ndindex(*grid))
+        run = max(1, int(grid[2]))
+        reach = _region_reach(plan["tol"])
+        self.regions = []
+        for k0 in range(0, len(share), run):
+            ks = range(k0, min(k0 + run, len(share)))
+            ext = np.array([[s.indices(n)[:2] for s, n in zip(sub_roi_slices[coords[share[k]]], shape3)] for k in ks])
+            lo, hi = ext[:, :, 0].min(axis=0), ext[:, :, 1].max(axis=0)
+            self.regions.append(dict(k_lo=ks[0], k_hi=ks[-1] + 1, lo=lo - reach, hi=hi + reach, box=(lo, hi)))
+        for i, r in enumerate(self.regions):
+            near = [j for j, q in enumerate(self.regions) if j != i and
+                    np.all(q["box"][0] < r["hi"]) and np.all(q["box"][1] > r["lo"])]
+            r["near"] = near
+            r["ready_at"] = max([r["k_hi"]] + [self.regions[j]["k_hi"] for j in near])
+        self.done = [None] * len(self.regions)
+        self.next = 0
+
+    def matches(self, arena, plan, channels) -> bool:
+        same = arena is self.arena and list(channels) == self.channels and plan["n_keys"] == self.plan["n_keys"]
+        same = same and np.array_equal(plan["tol"], self.plan["tol"])
+        for a, b in zip(plan["axes"], self.plan["axes"]):
+            same = same and ((a is None) == (b is None))
+            if same and a is not None:
+                same = all(np.array_equal(a[k], b[k], equal_nan=True) for k in ("bounds", "nxt_lo", "nxt_hi")) and \
+                       a["last_end"] == b["last_end"]
+        return bool(same)
+
+    def advance(self) -> None:
+        """Prune every region whose blocks and neighbours have all landed (``arena.row_end`` tells)."""
+        landed = len(self.arena.row_end) - 1
+        while self.next < len(self.regions) and self.regions[self.next]["ready_at"] <= landed:
+            self._run(self.next)
+            self.next += 1
+
+    def _run(self, i: int) -> None:
+        ar, r = self.arena, self.regions[i]
+        ends = ar.row_end
+        own = np.arange(ends[r["k_lo"]], ends[r["k_hi"]], dtype=np.int64)
+        before, after = [], []
+        for j in r["near"]:
+            q = self.regions[j]
+            a, b = ends[q["k_lo"]], ends[q["k_hi"]]
+            ids = a + _rows_within(ar.zyx[a:b], r["lo"], r["hi"])
+            (before if j < i else after).append(ids)
+        ids = np.concatenate(before + [own] + after) if (before or after) else own
+        n_before = sum(len(x) for x in before)
+        zyx = np.ascontiguousarray(ar.zyx[ids])
+        tags = np.ascontiguousarray(ar.tag[ids])
+        abs_l = np.ascontiguousarray(ar.abs[ids])
+        chan = None
+        if not (len(self.channels) == 1 and ar.chan_lo == ar.chan_hi == self.channels[0]):
+            chan = ar.store[ids, 6]
+        rows, keys, counts = StackPruner._prune_table(zyx, tags, abs_l, chan, n_before, n_before + len(own),
+                                                      self.channels, self.plan)
+        self.done[i] = (ids[rows], keys, abs_l[rows], counts)
+
+    def finish(self, abs_inds):
+        """Whatever is left, then the merge: ``(final table, counts)``."""
+        for i in range(self.next, len(self.regions)):
+            self._run(i)
+        self.next = len(self.regions)
+        ar = self.arena
+        ids = np.ascontiguousarray(np.concatenate([d[0] for d in self.done]), dtype=np.int64)
+        keys = np.ascontiguousarray(np.concatenate([d[1] for d in self.done]), dtype=np.int64)
+        abs_rows = np.ascontiguousarray(np.concatenate([d[2] for d in self.done]), dtype=np.float64)
+        counts = sum(d[3] for d in self.done)
+        ncol = ar.store.shape[1] - 3
+        out = np.empty((len(ids), ncol))
+        cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
+        nat.check(nat.lib().mmx_host_gather_by_key(
+            ar.store.ctypes.data, ar.store.strides[0] // 8, ids.ctypes.data, keys.ctypes.data, len(ids),
+            self.plan["n_keys"] * len(self.channels), ncol, abs_rows.ctypes.data, cols3, out.ctypes.data),
+            "mmx_host_gather_by_key")
+        return out, counts
+
+
 class _SegRois(np.ndarray):
-    """Object array of per-block tables that remembers the arena its tables live in."""
+    """Object array of per-block tables that remembers the arena its tables live in, the regions already pruned
+    while the detection ran, and whether it holds this rank's blocks only."""
     arena = None
+    pruner = None
+    local_only = False
 
 
 class StackDetector:
@@ -214,6 +330,17 @@ class StackDetector:
     channel = None
     #: counters of the last :meth:`detect_blobs_sub_rois` call (``blob_log.BatchStats``)
     last_stats = None
+    #: pruning parameters the NEXT :meth:`detect_blobs_sub_rois` call may prune ahead with (:meth:`plan_pruning`)
+    prune_hint = None
+
+    @classmethod
+    def plan_pruning(cls, overlap, tol, overlap_padding, channels) -> None:
+        """Tell the next :meth:`detect_blobs_sub_rois` call what ``StackPruner.prune_blobs_mp`` will be called
+        with, so that finished regions of the stack are pruned while the GPU is still busy with later blocks
+        (the host idles through most of a detection).  One shot; purely an optimisation: ``prune_blobs_mp`` checks
+        that its own arguments are the ones planned for and otherwise prunes the whole table as always."""
+        cls.prune_hint = (np.asarray(overlap), np.asarray(tol),
+                          None if overlap_padding is None else np.asarray(overlap_padding), list(channels))
 
     @staticmethod
     def _exclude_matrix(coord, last_coord, exclude_border):
@@ -288,19 +415,37 @@ class StackDetector:
         stats = bl.BatchStats()
         tables = []
         n_extra = (img.shape[3] if len(img.shape) > 3 else 0) if coloc else 0
-        arena = _TableArena(11 + n_extra, len(mine)) if dist.world_size() == 1 else None
+        hint, cls.prune_hint = cls.prune_hint, None
+        regular = hint is not None and all(
+            StackPruner._axis_geometry(a, shape3, hint[0], hint[1] if hint[2] is None else hint[2], sub_roi_slices,
+                                       sub_rois_offsets)[1] for a in range(3) if sub_rois_offsets.shape[a] > 1)
+        # several ranks: with the pruning planned (plan_pruning) and a regular block geometry every rank keeps its
+        # own tables and the pruning itself is distributed; otherwise the tables are gathered on rank 0
+        local_only = dist.world_size() > 1 and regular and os.environ.get("MMX_DIST_PRUNE", "1") != "0"
+        arena = _TableArena(11 + n_extra, len(mine)) if (dist.world_size() == 1 or local_only) else None
         pos = {i: k for k, i in enumerate(mine)}
 
         def exclude_of(k):
             return cls._exclude_matrix(coords[mine[k]], last_coord, exclude_border)
+
+        pruner = None
+        if regular and dist.world_size() == 1 and mine and os.environ.get("MMX_PRUNE_AHEAD", "1") != "0":
+            ov, tl, pad, prune_channels = hint
+            pruner = _RegionPruner(arena, StackPruner._axis_plan(shape3, ov, tl, tl if pad is None else pad,
+                                                                 sub_roi_slices, sub_rois_offsets),
+                                   prune_channels, sub_roi_slices, shape3, mine)
 
         def finish(k, tbl):
             # shift to ROI coordinates as soon as the block's batch is done (border exclusion and
             # co-localisation have happened on the block-relative table, in the reference's order)
             coord = coords[mine[k]]
             tbl = cls._finish_block(tbl, shapes[k], None, sub_rois_offsets[coord])
-            if tbl is not None and arena is not None and len(tbl):
-                arena.add(coord, tbl)
+            if arena is not None:
+                if tbl is not None and len(tbl):
+                    arena.add(coord, tbl)
+                arena.landed()
+                if pruner is not None:
+                    pruner.advance()
             return tbl
 
         if mine:
@@ -309,21 +454,36 @@ class StackDetector:
             if arena is not None and n_extra == 0:
                 sink = _ArenaSink(arena, [coords[i] for i in mine], [sub_rois_offsets[coords[i]] for i in mine],
                                   shapes, exclude_of if exclude_border is not None else None)
+                sink.pruner = pruner
             tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
                                                          denoise_max_shape=denoise_max_shape,
                                                          exclude=exclude_of, coloc=coloc, sink=sink)
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
-        return cls.assemble_seg_rois(local, grid, n_extra, arena)
+        seg_rois = cls.assemble_seg_rois(local, grid, n_extra, arena, local_only=local_only)
+        if pruner is not None and seg_rois.arena is arena:
+            seg_rois.pruner = pruner
+        return seg_rois
 
     @staticmethod
-    def assemble_seg_rois(local, grid, n_extra: int = 0, arena=None):
+    def assemble_seg_rois(local, grid, n_extra: int = 0, arena=None, local_only: bool = False):
         """``(block index, table | None)`` pairs of this rank -> the grid-shaped object array of ALL blocks.
         With torch.distributed initialised the tables of every rank are gathered first; only rank 0 (the rank
-        that prunes) unpacks them, the other ranks get ``None`` placeholders."""
+        that prunes) unpacks them, the other ranks get ``None`` placeholders -- unless ``local_only``: then every
+        rank keeps the tables of its own blocks (``None`` for the others) and ``StackPruner.prune_blobs_mp`` prunes
+        them as a collective."""
         from . import dist
         coords = list(np.ndindex(*grid))
         seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
+        if dist.world_size() > 1 and local_only:
+            for coord in coords:
+                seg_rois[coord] = None
+            for i, tbl in local:
+                if arena is not None and tbl is not None and len(tbl):
+                    tbl = arena.view(coords[i])
+                seg_rois[coords[i]] = tbl
+            seg_rois.arena, seg_rois.local_only = arena, True
+            return seg_rois
         if dist.world_size() > 1:
             # several ranks: the pruning rank receives all rows as one array in block order and lays them out as
             # its arena with whole-array copies (merge_blobs and the native prune step then take their fast path
@@ -441,6 +601,7 @@ def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, chann
         channels = detector._channels_of(roi.ndim, num_chls_roi, None)[1]
     settings = config.get_roi_profile(channels[0])       # first channel's block settings
     blocks = setup_blocks(settings, roi.shape)
+    StackDetector.plan_pruning(blocks.overlap, blocks.tol, blocks.overlap_padding, channels)
     seg_rois = StackDetector.detect_blobs_sub_rois(
         img5d, roi, blocks.sub_roi_slices, blocks.sub_rois_offsets, blocks.denoise_max_shape,
         blocks.exclude_border, coloc, channels)
@@ -452,11 +613,22 @@ def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, chann
     is_root = dist.rank() == 0
     time_pruning_start = time()
     segments_all, df_pruning = (None, None)
-    if is_root:
+    if getattr(seg_rois, "local_only", False):
+        # every rank holds its own blocks' tables: the pruning is a collective and leaves the table on all of them
         segments_all, df_pruning = StackPruner.prune_blobs_mp(
             roi, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
             blocks.sub_rois_offsets, channels, blocks.overlap_padding)
-    segments_all = dist.broadcast_table(segments_all)
+    else:
+        failure = None
+        if is_root:
+            try:
+                segments_all, df_pruning = StackPruner.prune_blobs_mp(
+                    roi, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                    blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+            except Exception as exc:      # the other ranks are about to wait for the table: tell them first
+                failure = exc
+        dist.raise_together(failure, "pruning on rank 0")
+        segments_all = dist.broadcast_table(segments_all)
     pruning_time = time() - time_pruning_start
 
     if is_root and df_pruning is not None and save_dfs and len(df_pruning):
@@ -642,6 +814,209 @@ class StackPruner:
         return np.vstack(blobs_all)[:, :-3], ratios_all
 
     @classmethod
+    def _axis_plan(cls, shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets):
+        """The constants of the three passes (regular geometry): per axis ``None`` (one section: no pass) or the
+        region boundaries ``[pass 0 | slab 0 | pass 1 | ...]``, the far end, and the "adjacent region" of every
+        slab's pruning-ratio statistic (reference :757-785); plus the tolerances."""
+        grid = sub_roi_slices.shape
+        coord_last = tuple(np.subtract(grid, 1))
+        axes = []
+        for axis in range(3):
+            n_sections = sub_rois_offsets.shape[axis]
+            if n_sections <= 1:
+                axes.append(None)
+                continue
+            # The axis is tiled by [pass 0][slab 0][pass 1][slab 1] ... [pass last]; slab j
+            # = [end_j - (overlap + pad), end_j + pad) belongs to the boundary j | j + 1.
+            shift = overlap[axis] + overlap_padding[axis]
+            bounds, nxt_lo, nxt_hi = [], [], []
+            last_end = 0
+            for j in range(n_sections):
+                coord = [0, 0, 0]
+                coord[axis] = j
+                coord = tuple(coord)
+                start = sub_rois_offsets[coord][axis]
+                extent = len(range(*sub_roi_slices[coord][axis].indices(shape3[axis])))
+                end = start + extent
+                last_end = end
+                bounds.append(start + (shift if j > 0 else 0))          # pass j begins
+                if j < n_sections - 1:
+                    bounds.append(end - shift)                          # slab j begins
+                    lo = end + tol[axis]
+                    hi = lo + overlap[axis] + 2 * overlap_padding[axis]
+                    roi_end = sub_rois_offsets[coord_last][axis] + extent
+                    ok = lo < roi_end and hi < roi_end
+                    nxt_lo.append(lo if ok else np.nan)
+                    nxt_hi.append(hi if ok else np.nan)
+            axes.append(dict(n_sections=int(n_sections), bounds=np.asarray(bounds, dtype=np.float64),
+                             last_end=float(last_end), nxt_lo=np.asarray(nxt_lo, dtype=np.float64),
+                             nxt_hi=np.asarray(nxt_hi, dtype=np.float64)))
+        tol3 = np.array([int(v) for v in np.broadcast_to(np.asarray(tol), (3,))], dtype=np.int32)
+        n_keys = 1
+        for ax in axes:
+            if ax is not None:
+                n_keys *= 3 * ax["n_sections"] - 2
+        return dict(axes=axes, tol=tol3, n_keys=int(n_keys), max_slabs=max([1] + [ax["n_sections"] - 1 for ax in axes if ax]))
+
+    @classmethod
+    def _prune_table(cls, zyx, tags, abs_cur, chan, own_lo, own_hi, channels, plan):
+        """The three passes over one table (``mmx_host_prune_region``), channel by channel: ``(rows, keys, counts)``
+        -- the ids of the surviving rows among ``[own_lo, own_hi)`` in their final order, the key of each (the
+        channel's position in ``channels`` is the most significant part), and the statistics
+        ``counts[channel][axis][slab] = (rows in the slab, rows left, rows in the adjacent region)`` over own rows.
+        ``abs_cur`` is updated in place.  ``chan``: channel of every row, ``None`` when all belong to ``channels[0]``."""
+        axes = plan["axes"]
+        lib = nat.lib()
+        n_sec = (ctypes.c_int32 * 3)(*[0 if ax is None else ax["n_sections"] for ax in axes])
+        last_end = (ctypes.c_double * 3)(*[0.0 if ax is None else ax["last_end"] for ax in axes])
+
+        def ptrs(name):
+            return (ctypes.c_void_p * 3)(*[None if ax is None else ax[name].ctypes.data for ax in axes])
+
+        bounds, nxt_lo, nxt_hi = ptrs("bounds"), ptrs("nxt_lo"), ptrs("nxt_hi")
+        tol3 = plan["tol"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        ld = plan["max_slabs"]
+        counts = np.zeros((len(channels), 3, ld, 3), dtype=np.int64)
+        rows_all, keys_all = [], []
+        for ci, chl in enumerate(channels):
+            if chan is None:
+                cur = np.arange(len(zyx), dtype=np.int64)
+            else:
+                cur = np.ascontiguousarray(np.nonzero(np.isin(chan, chl))[0], dtype=np.int64)  # row ids, table order
+            out_rows = np.empty(len(cur), dtype=np.int64)
+            out_keys = np.empty(len(cur), dtype=np.int64)
+            out_n = ctypes.c_int64(0)
+            stat = np.zeros((3, 3, ld), dtype=np.int64)       # [kind][axis][slab]
+            nat.check(lib.mmx_host_prune_region(
+                zyx.ctypes.data, tags.ctypes.data, abs_cur.ctypes.data, cur.ctypes.data, len(cur), int(own_lo),
+                int(own_hi), n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi, out_rows.ctypes.data,
+                out_keys.ctypes.data, ctypes.byref(out_n), stat[0].ctypes.data, stat[1].ctypes.data,
+                stat[2].ctypes.data, ld), "mmx_host_prune_region")
+            counts[ci] = np.moveaxis(stat, 0, -1)
+            rows_all.append(out_rows[:out_n.value])
+            keys_all.append(out_keys[:out_n.value] + ci * plan["n_keys"])
+        rows = rows_all[0] if len(rows_all) == 1 else np.concatenate(rows_all)
+        keys = keys_all[0] if len(keys_all) == 1 else np.concatenate(keys_all)
+        return np.ascontiguousarray(rows, dtype=np.int64), np.ascontiguousarray(keys, dtype=np.int64), counts
+
+    @staticmethod
+    def _ratios_from_counts(counts, plan):
+        """Pruning-ratio columns (reference :673-676, 836-838) from the slab statistics, in the reference's order:
+        channels, then axes, then slabs."""
+        ratios_all = {}
+        for per_channel in counts:
+            for axis, ax in enumerate(plan["axes"]):
+                if ax is None:
+                    continue
+                for j in range(ax["n_sections"] - 1):
+                    if np.isnan(ax["nxt_lo"][j]):
+                        continue
+                    n_slab, n_after, n_next = (int(v) for v in per_channel[axis][j])
+                    ratios = detector.meas_pruning_ratio(n_slab, n_after, n_next)
+                    if ratios:
+                        for col, val in zip(("blobs", "ratio_pruning", "ratio_adjacent"), ratios):
+                            ratios_all.setdefault(col, []).append(val)
+        return ratios_all
+
+    @staticmethod
+    def _take_rows(merged, rows, abs_cur, abs_inds):
+        """``merged[rows][:, :-3]`` with the three abs columns taken from ``abs_cur[rows]``."""
+        ncol = merged.shape[1]
+        if merged.dtype == np.float64 and merged.strides[1] == 8 and merged.strides[0] % 8 == 0:
+            out = np.empty((len(rows), ncol - 3))
+            cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
+            nat.check(nat.lib().mmx_host_take_rows(
+                merged.ctypes.data, merged.strides[0] // 8, rows.ctypes.data, len(rows), ncol - 3,
+                abs_cur.ctypes.data, cols3, out.ctypes.data), "mmx_host_take_rows")
+            return out
+        out = np.take(merged, rows, axis=0)[:, :-3]
+        out[:, abs_inds] = np.take(abs_cur, rows, axis=0)
+        return out
+
+    @classmethod
+    def _prune_distributed(cls, seg_rois, shape3, plan, sub_roi_slices, channels):
+        """Several ranks, each holding the tables of its own blocks (``seg_rois.local_only``): every rank prunes
+        its own rows -- the three passes on its rows plus the other ranks' rows within reach of its blocks
+        (``mmx_host_prune_region``) -- and the survivors are merged by key on every rank.  Collective: all ranks
+        call it, all get the same ``(table, counts)``; ``(None, None)`` when no rank holds a table.
+
+        Two exchanges (RCCL all_gather over xGMI on GPUs): the rows near another rank's blocks -- a few per cent of
+        the table: 10 values a row --, then the surviving rows in their final form with their keys."""
+        from . import dist
+        ar = seg_rois.arena
+        world, me = dist.world_size(), dist.rank()
+        grid = sub_roi_slices.shape
+        coords = list(np.ndindex(*grid))
+        n = ar.n
+        ncol = ar.store.shape[1]
+        has_table = any(seg_rois[c] is not None and not isinstance(seg_rois[c], (int, np.integer)) for c in coords)
+        flags = dist.all_reduce_sum(np.array([1 if has_table else 0, n], dtype=np.int64))
+        if flags[0] == 0:
+            return None, None
+        abs_inds = detector.Blobs._get_abs_inds()
+        reach = _region_reach(plan["tol"])
+        # the extent of every rank's blocks
+        boxes = []
+        for q in range(world):
+            lo_b, hi_b = dist.share_bounds(len(coords), q, world)
+            if hi_b <= lo_b:
+                boxes.append(None)
+                continue
+            ext = np.array([[s.indices(m)[:2] for s, m in zip(sub_roi_slices[coords[i]], shape3)]
+                            for i in range(lo_b, hi_b)])
+            boxes.append((ext[:, :, 0].min(axis=0) - reach, ext[:, :, 1].max(axis=0) + reach))
+        zyx, tags, abs_own = ar.zyx[:n], ar.tag[:n], ar.abs[:n]
+        chan_own = ar.store[:n, 6]
+        near = np.zeros(n, dtype=bool)
+        for q, box in enumerate(boxes):
+            if q != me and box is not None and n:
+                near |= np.all((zyx >= box[0]) & (zyx < box[1]), axis=1)
+        sel = np.flatnonzero(near)
+        payload = np.empty((len(sel), 10))
+        payload[:, 0:3], payload[:, 3:6] = zyx[sel], tags[sel]
+        payload[:, 6:9], payload[:, 9] = abs_own[sel], chan_own[sel]
+        parts = dist.all_gather_rows(payload, 10)
+        mine_box = boxes[me]
+        before, after = [], []
+        for q, part in enumerate(parts):
+            if q == me or mine_box is None or not len(part):
+                continue
+            keep = _rows_within(part[:, :3], mine_box[0], mine_box[1])
+            (before if q < me else after).append(part[keep])
+        halo_b = np.concatenate(before) if before else np.zeros((0, 10))
+        halo_a = np.concatenate(after) if after else np.zeros((0, 10))
+        zyx_l = np.ascontiguousarray(np.concatenate((halo_b[:, 0:3], zyx, halo_a[:, 0:3])), dtype=np.int32)
+        tag_l = np.ascontiguousarray(np.concatenate((halo_b[:, 3:6], tags, halo_a[:, 3:6])), dtype=np.int32)
+        abs_l = np.ascontiguousarray(np.concatenate((halo_b[:, 6:9], abs_own, halo_a[:, 6:9])), dtype=np.float64)
+        chan_l = np.concatenate((halo_b[:, 9], chan_own, halo_a[:, 9]))
+        own_lo = len(halo_b)
+        rows, keys, counts = cls._prune_table(zyx_l, tag_l, abs_l, chan_l, own_lo, own_lo + n, channels, plan)
+        # own survivors in their final form + the key that places them
+        mine = np.empty((len(rows), ncol - 2))
+        if len(rows):
+            ids = np.ascontiguousarray(rows - own_lo, dtype=np.int64)
+            abs_rows = np.ascontiguousarray(abs_l[rows])
+            cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
+            ident = np.zeros(len(rows), dtype=np.int64)          # (one key: keeps the order, replaces the abs columns)
+            body = np.empty((len(rows), ncol - 3))
+            nat.check(nat.lib().mmx_host_gather_by_key(
+                ar.store.ctypes.data, ar.store.strides[0] // 8, ids.ctypes.data, ident.ctypes.data, len(rows), 1,
+                ncol - 3, abs_rows.ctypes.data, cols3, body.ctypes.data), "mmx_host_gather_by_key")
+            mine[:, :ncol - 3] = body
+            mine[:, ncol - 3] = keys
+        everyone = dist.all_gather_rows(mine, ncol - 2)
+        table = np.concatenate(everyone) if len(everyone) > 1 else everyone[0]
+        table = np.ascontiguousarray(table)
+        out = np.empty((len(table), ncol - 3))
+        if len(table):
+            all_keys = np.ascontiguousarray(table[:, ncol - 3], dtype=np.int64)
+            nat.check(nat.lib().mmx_host_merge_by_key(
+                table.ctypes.data, ncol - 2, all_keys.ctypes.data, len(table), plan["n_keys"] * len(channels),
+                ncol - 3, out.ctypes.data), "mmx_host_merge_by_key")
+        counts = dist.all_reduce_sum(counts.reshape(-1)).reshape(counts.shape)
+        return out, counts
+
+    @classmethod
     def prune_blobs_mp(cls, img, seg_rois, overlap, tol, sub_roi_slices, sub_rois_offsets,
                        channels, overlap_padding=None):
         """Prune duplicates in the overlap slabs, per channel, axis by axis (:679-861).
@@ -666,15 +1041,23 @@ class StackPruner:
                 _t.append(time())
                 print(f"prune_blobs_mp {what}: {(_t[-1] - _t[-2]) * 1e3:.2f} ms", file=sys.stderr)
 
+        if overlap_padding is None:
+            overlap_padding = tol
+        shape3 = img.shape[:3]
+        if getattr(seg_rois, "local_only", False):
+            # several ranks, each with the tables of its own blocks: a collective (every rank calls this)
+            detector.Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry
+            plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
+            out, counts = cls._prune_distributed(seg_rois, shape3, plan, sub_roi_slices, channels)
+            if out is None:
+                return None, None
+            return out, pd.DataFrame(cls._ratios_from_counts(counts, plan))
         arena = getattr(seg_rois, "arena", None)
         if arena is not None and not arena.intact(seg_rois):
             arena = None
         merged = arena.store[:arena.n] if arena is not None and arena.n else chunking.merge_blobs(seg_rois)
         if merged is None:
             return None, None
-        if overlap_padding is None:
-            overlap_padding = tol
-        shape3 = img.shape[:3]
         grid = sub_roi_slices.shape
         coord_last = tuple(np.subtract(grid, 1))
         ratio_cols = ("blobs", "ratio_pruning", "ratio_adjacent")
@@ -687,89 +1070,32 @@ class StackPruner:
         ncol = merged.shape[1]
         detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
         abs_inds = detector.Blobs._get_abs_inds()
-        chan = detector.Blobs.get_blobs_channel(merged)
-        # compact columns for the native per-axis step (libmmx_hip.so: mmx_host_prune_axis)
-        if arena is not None:                 # filled while the GPU was busy
-            zyx, tags = arena.zyx[:arena.n], arena.tag[:arena.n]
+        plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
+        # regions of this very call finished while the GPU was still detecting (StackDetector.plan_pruning)
+        early = getattr(seg_rois, "pruner", None)
+        if early is not None and arena is not None and early.matches(arena, plan, channels):
+            out, counts = early.finish(abs_inds)
+            _lap("regions pruned during detection: the rest + merge")
         else:
-            zyx = np.ascontiguousarray(merged[:, :3], dtype=np.int32)  # detection coordinates never change
-            tags = np.ascontiguousarray(merged[:, ncol - 3:], dtype=np.int32)
-        # the only values pruning changes (a private copy: the per-block tables stay as detected)
-        if arena is not None and list(abs_inds) == [7, 8, 9]:
-            abs_cur = arena.abs[:arena.n].copy()
-        else:
-            abs_cur = np.ascontiguousarray(merged[:, abs_inds], dtype=np.float64)
-        tol3 = (ctypes.c_int32 * 3)(*[int(v) for v in np.broadcast_to(np.asarray(tol), (3,))])
-        lib = nat.lib()
-        pieces = []
-        _lap("set-up (arena check, geometry, column copies)")
-        for chl in channels:
-            if arena is not None and arena.chan_lo == arena.chan_hi == chl:      # one channel: every row
-                cur = np.arange(len(chan), dtype=np.int64)
+            chan = detector.Blobs.get_blobs_channel(merged)
+            # compact columns for the native step (libmmx_hip.so: mmx_host_prune_region)
+            if arena is not None:                 # filled while the GPU was busy
+                zyx, tags = arena.zyx[:arena.n], arena.tag[:arena.n]
             else:
-                cur = np.ascontiguousarray(np.nonzero(np.isin(chan, chl))[0], dtype=np.int64)  # row ids, table order
-            for axis in range(3):
-                n_sections = sub_rois_offsets.shape[axis]
-                if n_sections <= 1:
-                    continue
-                # The axis is tiled by [pass 0][slab 0][pass 1][slab 1] ... [pass last]; slab j
-                # = [end_j - (overlap + pad), end_j + pad) belongs to the boundary j | j + 1.
-                shift = overlap[axis] + overlap_padding[axis]
-                bounds, nxt_lo, nxt_hi = [], [], []
-                last_end = 0
-                for j in range(n_sections):
-                    coord = [0, 0, 0]
-                    coord[axis] = j
-                    coord = tuple(coord)
-                    start = sub_rois_offsets[coord][axis]
-                    slc = sub_roi_slices[coord]
-                    extent = len(range(*slc[axis].indices(shape3[axis])))
-                    end = start + extent
-                    last_end = end
-                    bounds.append(start + (shift if j > 0 else 0))          # pass j begins
-                    if j < n_sections - 1:
-                        bounds.append(end - shift)                          # slab j begins
-                        # "adjacent region" of the pruning-ratio statistic (reference :772-785)
-                        lo = end + tol[axis]
-                        hi = lo + overlap[axis] + 2 * overlap_padding[axis]
-                        roi_end = sub_rois_offsets[coord_last][axis] + extent
-                        ok = lo < roi_end and hi < roi_end
-                        nxt_lo.append(lo if ok else np.nan)
-                        nxt_hi.append(hi if ok else np.nan)
-                bounds = np.asarray(bounds, dtype=np.float64)
-                nxt_lo = np.asarray(nxt_lo, dtype=np.float64)
-                nxt_hi = np.asarray(nxt_hi, dtype=np.float64)
-                out_cur = np.empty(len(cur), dtype=np.int64)
-                out_n = ctypes.c_int64(0)
-                n_slab = np.zeros(n_sections - 1, dtype=np.int64)
-                n_after = np.zeros_like(n_slab)
-                n_next = np.zeros_like(n_slab)
-                nat.check(lib.mmx_host_prune_axis(
-                    zyx.ctypes.data, tags.ctypes.data, abs_cur.ctypes.data, cur.ctypes.data, len(cur),
-                    axis, n_sections, bounds.ctypes.data, float(last_end), tol3, nxt_lo.ctypes.data,
-                    nxt_hi.ctypes.data, out_cur.ctypes.data, ctypes.byref(out_n), n_slab.ctypes.data,
-                    n_after.ctypes.data, n_next.ctypes.data), "mmx_host_prune_axis")
-                cur = out_cur[:out_n.value]
-                _lap(f"axis {axis}")
-                for j in range(n_sections - 1):
-                    if not np.isnan(nxt_lo[j]):
-                        ratios = detector.meas_pruning_ratio(int(n_slab[j]), int(n_after[j]), int(n_next[j]))
-                        if ratios:
-                            for col, val in zip(ratio_cols, ratios):
-                                ratios_all.setdefault(col, []).append(val)
-            pieces.append(cur)
-        rows = np.concatenate(pieces)
-        rows = np.ascontiguousarray(rows, dtype=np.int64)
-        if merged.dtype == np.float64 and merged.strides[1] == 8 and merged.strides[0] % 8 == 0:
-            out = np.empty((len(rows), ncol - 3))
-            cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
-            nat.check(lib.mmx_host_take_rows(
-                merged.ctypes.data, merged.strides[0] // 8, rows.ctypes.data, len(rows), ncol - 3,
-                abs_cur.ctypes.data, cols3, out.ctypes.data), "mmx_host_take_rows")
-        else:
-            out = np.take(merged, rows, axis=0)[:, :-3]
-            out[:, abs_inds] = np.take(abs_cur, rows, axis=0)
-        _lap("gather of the output table")
-        df = pd.DataFrame(ratios_all)
+                zyx = np.ascontiguousarray(merged[:, :3], dtype=np.int32)  # detection coordinates never change
+                tags = np.ascontiguousarray(merged[:, ncol - 3:], dtype=np.int32)
+            # the only values pruning changes (a private copy: the per-block tables stay as detected)
+            if arena is not None and list(abs_inds) == [7, 8, 9]:
+                abs_cur = arena.abs[:arena.n].copy()
+            else:
+                abs_cur = np.ascontiguousarray(merged[:, abs_inds], dtype=np.float64)
+            one_channel = arena is not None and len(channels) == 1 and arena.chan_lo == arena.chan_hi == channels[0]
+            _lap("set-up (arena check, geometry, column copies)")
+            rows, _, counts = cls._prune_table(zyx, tags, abs_cur, None if one_channel else chan, 0, len(zyx),
+                                               channels, plan)
+            _lap("three axis passes")
+            out = cls._take_rows(merged, rows, abs_cur, abs_inds)
+            _lap("gather of the output table")
+        df = pd.DataFrame(cls._ratios_from_counts(counts, plan))
         _lap("ratio frame")
         return out, df

@@ -178,3 +178,100 @@ def test_single_process_passthrough():
     out = dist.gather_tables(local, 3)
     assert [i for i, _ in out] == [0, 2]
     assert dist.rank() == 0 and dist.world_size() == 1 and dist.my_share(4) == [0, 1, 2, 3]
+
+
+# ---------------------------------------------------------------- distributed pruning: every rank prunes its own rows
+def _worker_dist_prune(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from magellanmapper_amd import dist as d, stack_detect as sd
+        blocks, tables, shape, channels, n_extra = _dist_case(case)
+        grid = blocks.sub_roi_slices.shape
+        coords = list(np.ndindex(*grid))
+        mine = d.my_share(len(coords))
+        arena = sd._TableArena(11 + n_extra, len(mine))
+        local = []
+        for i in mine:
+            tbl = tables[i]
+            if tbl is not None and len(tbl):
+                arena.add(coords[i], tbl)
+            arena.landed()
+            local.append((i, tbl))
+        seg = sd.StackDetector.assemble_seg_rois(local, grid, n_extra, arena, local_only=True)
+        assert seg.local_only and all(seg[coords[i]] is None for i in range(len(coords)) if i not in mine)
+
+        class Img:
+            pass
+        Img.shape = shape
+        pruned, df = sd.StackPruner.prune_blobs_mp(Img, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                   blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+        np.save(os.path.join(out_dir, f"pruned{rank}.npy"), np.zeros((0, 0)) if pruned is None else pruned)
+        np.save(os.path.join(out_dir, f"ratios{rank}.npy"), np.zeros((0, 0)) if df is None else df.to_numpy())
+    finally:
+        td.destroy_process_group()
+
+
+def _dist_case(case):
+    """Block tables of a synthetic stack (test_host_logic._synthetic_block_tables: near-duplicates in the overlaps)
+    with the oddities a stack can have: EMPTY and missing blocks, co-localisation columns, two channels, more ranks
+    than z-layers, a stack whose blocks are all EMPTY / all missing."""
+    from magellanmapper_amd import config, stack_detect as sd
+    from test_host_logic import _synthetic_block_tables
+    config.setup_roi_profiles(None)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    shape, seg, channels, n_extra, n_blobs = (96, 150, 170), 40, [0], 0, 6000
+    if case == "extra_columns_two_channels":
+        channels, n_extra = [0, 1], 2
+    elif case == "flat":
+        shape, seg, n_blobs = (30, 200, 260), 50, 3000
+    config.roi_profile.update(segment_size=seg, denoise_size=None)
+    blocks = sd.setup_blocks(config.roi_profile, shape)
+    rng = np.random.default_rng(31)
+    by_coord = _synthetic_block_tables(rng, shape, blocks, n_blobs, channels, n_extra=n_extra)
+    tables = [by_coord[c] for c in np.ndindex(*blocks.sub_roi_slices.shape)]
+    if case in ("holes", "extra_columns_two_channels"):
+        tables[3] = np.zeros((0, 11 + n_extra))          # all blobs excluded: EMPTY
+        tables[5] = None
+        tables[len(tables) - 1] = None
+    elif case == "all_empty":
+        tables = [np.zeros((0, 11)) if k % 2 else None for k in range(len(tables))]
+    elif case == "nothing":
+        tables = [None] * len(tables)
+    return blocks, tables, shape, channels, n_extra
+
+
+@pytest.mark.parametrize("world,case", [(2, "plain"), (3, "holes"), (4, "extra_columns_two_channels"), (4, "flat"),
+                                        (3, "all_empty"), (2, "nothing")])
+def test_distributed_pruning_equals_one_process(tmp_path, world, case):
+    """Every rank holds the tables of its own blocks only, prunes its own rows (three passes on its rows plus the
+    other ranks' rows within reach of its blocks) and merges everybody's survivors by key: the table -- rows, order,
+    averaged coordinates -- and the pruning-ratio statistics one process gets from the whole table, on every rank;
+    uneven shares, EMPTY / missing blocks, 13-column two-channel tables, nothing at all."""
+    from magellanmapper_amd import stack_detect as sd
+    blocks, tables, shape, channels, n_extra = _dist_case(case)
+    seg = sd.StackDetector.assemble_seg_rois(list(enumerate(tables)), blocks.sub_roi_slices.shape, n_extra)
+
+    class Img:
+        pass
+    Img.shape = shape
+    want, df = sd.StackPruner.prune_blobs_mp(Img, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                             blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    if case == "nothing":
+        assert want is None
+    elif case == "all_empty":
+        assert want.shape == (0, 11)
+    else:
+        assert 1000 < len(want) < sum(len(t) for t in tables if t is not None)
+    tmp.spawn(_worker_dist_prune, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"pruned{r}.npy")
+        ratios = np.load(tmp_path / f"ratios{r}.npy")
+        if want is None:
+            assert got.size == 0 and got.shape == (0, 0)
+            continue
+        assert got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(ratios.reshape(df.shape), df.to_numpy())

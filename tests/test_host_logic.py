@@ -919,3 +919,100 @@ def test_native_table_emit_matches_the_python_tables():
             coords.ctypes.data, alive.ctypes.data, offsets.ctypes.data, 4, sig.ctypes.data, 3, 1.0, boffs.ctypes.data,
             tags.ctypes.data, None, store.ctypes.data, ld, zyx.ctypes.data, tag.ctypes.data, absz.ctypes.data, row0,
             row0 + 1, per.ctypes.data) == 4          # MMX_ERR_WORKSPACE
+
+
+# ---------------------------------------------------------------- region-wise pruning (stack_detect._RegionPruner)
+def _synthetic_block_tables(rng, shape, blocks, n_blobs, channels=(0,), jitter=3, n_extra=0):
+    """Per-block tables as a detection leaves them: every block reports the blobs of a common field that fall into
+    its extent, each with its own jitter (so the overlaps hold near-duplicates, some within the pruning tolerance,
+    some just outside it), coordinates in the ROI frame."""
+    field = {c: rng.integers(0, shape, (n_blobs, 3)) for c in channels}
+    tables = {}
+    for coord in np.ndindex(*blocks.sub_roi_slices.shape):
+        ext = [s.indices(n)[:2] for s, n in zip(blocks.sub_roi_slices[coord], shape)]
+        parts = []
+        for c in channels:
+            pts = field[c] + rng.integers(-jitter, jitter + 1, field[c].shape)
+            inside = np.all([(pts[:, a] >= ext[a][0]) & (pts[:, a] < ext[a][1]) for a in range(3)], axis=0)
+            pts = pts[inside]
+            t = np.full((len(pts), 11 + n_extra), -1.0)
+            t[:, :3] = pts
+            t[:, 3] = 5.2
+            t[:, 6] = c
+            t[:, 7:10] = pts
+            if n_extra:
+                t[:, 11:] = rng.integers(0, 2, (len(pts), n_extra))
+            parts.append(t)
+        tbl = np.concatenate(parts)
+        tables[coord] = tbl if len(tbl) else None
+    return tables
+
+
+@pytest.mark.parametrize("case", ["one_channel", "two_channels_extra_columns", "thin_last_blocks", "one_axis"])
+def test_region_wise_pruning_equals_the_whole_table_passes(case):
+    """The three passes run region by region (own rows + a halo of neighbouring rows) as blocks land, then merged
+    by key, against the same passes over the whole table: identical rows in identical order, identical averaged
+    coordinates, identical pruning-ratio statistics."""
+    from magellanmapper_amd import stack_detect as sd
+    rng = np.random.default_rng({"one_channel": 21, "two_channels_extra_columns": 22, "thin_last_blocks": 23,
+                                 "one_axis": 24}[case])
+    shape = {"thin_last_blocks": (80, 140, 110), "one_axis": (40, 40, 300)}.get(case, (96, 150, 170))
+    channels = [0, 1] if case == "two_channels_extra_columns" else [0]
+    n_extra = 2 if case == "two_channels_extra_columns" else 0
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(segment_size=32 if case != "one_axis" else 50, denoise_size=None)
+    blocks = sd.setup_blocks(config.roi_profile, shape)
+    tables = _synthetic_block_tables(rng, shape, blocks, 9000 if case != "one_axis" else 1500, channels, n_extra=n_extra)
+    grid = blocks.sub_roi_slices.shape
+    share = list(range(int(np.prod(grid))))
+    coords = list(np.ndindex(*grid))
+
+    before_last = []
+
+    def build(with_pruner):
+        arena = sd._TableArena(11 + n_extra, len(share))
+        pruner = None
+        if with_pruner:
+            plan = sd.StackPruner._axis_plan(shape, blocks.overlap, blocks.tol, blocks.overlap_padding,
+                                             blocks.sub_roi_slices, blocks.sub_rois_offsets)
+            pruner = sd._RegionPruner(arena, plan, channels, blocks.sub_roi_slices, shape, share)
+        seg = np.zeros(grid, dtype=object).view(sd._SegRois)
+        for k in share:
+            if pruner is not None and k == share[-1]:
+                before_last.append(pruner.next)
+            tbl = tables[coords[k]]
+            if tbl is not None:
+                arena.add(coords[k], tbl)
+                tbl = arena.view(coords[k])
+            arena.landed()
+            seg[coords[k]] = tbl
+            if pruner is not None:
+                pruner.advance()
+        seg.arena, seg.pruner = arena, pruner
+        return seg, pruner
+
+    class Img:
+        pass
+    Img.shape = shape
+    seg_a, _ = build(False)
+    want, df_want = sd.StackPruner.prune_blobs_mp(Img, seg_a, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                   blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    seg_b, pruner = build(True)
+    got, df_got = sd.StackPruner.prune_blobs_mp(Img, seg_b, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                 blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    assert pruner.next == len(pruner.regions) and all(d is not None for d in pruner.done)      # (it was used)
+    if len(pruner.regions) > 4:
+        assert 0 < before_last[0] < len(pruner.regions)      # some regions early, the last ones once everything landed
+    assert len(want) < sum(len(t) for t in tables.values() if t is not None)                    # duplicates were removed
+    np.testing.assert_array_equal(got, want)
+    assert list(df_got.columns) == list(df_want.columns)
+    np.testing.assert_array_equal(df_got.to_numpy(), df_want.to_numpy())
+    # other parameters than planned for: the regions are ignored, the whole table is pruned
+    seg_c, pruner_c = build(True)
+    tol2 = np.asarray(blocks.tol) - 1
+    got2, _ = sd.StackPruner.prune_blobs_mp(Img, seg_c, blocks.overlap, tol2, blocks.sub_roi_slices,
+                                            blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    want2, _ = sd.StackPruner.prune_blobs_mp(Img, build(False)[0], blocks.overlap, tol2, blocks.sub_roi_slices,
+                                             blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    np.testing.assert_array_equal(got2, want2)
