@@ -5,29 +5,38 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+``python bench.py --gpus N`` with N > 1 and no ``WORLD_SIZE`` in the environment starts its N ranks itself (a child
+``torch.distributed.run``, before this process touches the GPU) and relays rank 0's line.
+
 Workloads (BASELINE.json configs; the default, c3, is the one the metric is quoted on):
   c3  2048 x 2048 x 1024 uint16, 5-sigma LoG scale space + NMS + prune   (configs[2]; N > 1: configs[3])
   c2  512 x 512 x 256 uint16, single-sigma LoG                            (configs[1])
   c5  2-channel 2048 x 2048 x 512 uint16 tile of a tiled light-sheet stack: per-block preprocessing
       (denoise_size 25), detection of both channels, intensity co-localisation, prune (configs[4])
 At N > 1 the SAME volume's blocks are sharded over the ranks (strong scaling).  A *step* is one full pass of
-the hot path over the volume: all blocks through the HIP kernels, the blob-table gather, the overlap pruning;
+the hot path over the volume: all blocks through the HIP kernels, the blob-table exchange, the overlap pruning;
 the volume is resident in HBM before the timed region starts.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline      dominant kernel: algorithmic bytes / HIP-event time on its launch stream; the device-copy rate
-                measured in this run beside the 8 TB/s peak
+  roofline      dominant kernel: algorithmic bytes (per VOLUME voxel) / HIP-event time on its
+                launch stream against the 8 TB/s peak; the bytes it really moves and its VALU / MFMA busy fractions
+                from the committed counter passes of this same code (null when the kernels changed since)
   cpu_baseline  the oracle (NumPy/SciPy restatement of the reference) on this box's host cores over a bounded
                 sample of the same workload, detection and pruning seconds apart
-  ranks         per-rank kernel / gather / prune milliseconds (N > 1)
+  ranks         per-rank kernel / exchange / prune milliseconds (N > 1)
+  sub_records   (default command on one GPU only) compact c2 and c5 results: value, ms_per_step, roofline
+                fraction, parity of a sample against the oracle
 """
 from __future__ import annotations
 
 import argparse
+import functools
 import hashlib
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -56,6 +65,8 @@ CONFIGS = {
                       "5-sigma LoG detection of both channels + intensity co-localisation",
                what="2 channels, denoise_size 25, sigma 3..5 x5, co-localisation"),
 }
+#: steps / warm-up of the compact sub-records the default command appends
+SUB_RECORDS = {"c2": (40, 5), "c5": (3, 1)}
 RESOLUTIONS = np.array([[1.0, 1.0, 1.0]])
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
 #: algorithmic HBM bytes per voxel per sigma of each kernel
@@ -63,6 +74,14 @@ ALG_BYTES = {"zpass": 2 + 8, "ypass": 8 + 8, "xpass": 8 + 4, "peaks": 4,
              # fused path (default): Z+X in one kernel (Gz / Gzz never leave the CU), then Y
              "zxpass": 2 + 8, "y2pass": 8 + 4}
 B_ALG_PER_SIGMA = 50                # SURVEY.md section 8d contract figure
+#: kernel families enqueued on the stream the LoG passes run on (everything but the side-stream table kernels)
+MAIN_STREAM = ("zpass", "ypass", "xpass", "generic", "peaks", "zxpass", "y2pass", "preproc", "zxpack", "rescore")
+#: committed counter passes of this command (tools/profile_round.sh): HBM bytes per launch, VALU / MFMA busy
+PMC_FILE = "profiles/r03_pmc_counters.json"
+ZX_DTYPES = {7: "f16x2 MFMA (f32 accumulate) + 16-bit fixed-point intermediates; f64 re-score of every candidate",
+             6: "f16x2 MFMA (f32 accumulate), f32 intermediates; f64 re-score of every candidate",
+             2: "f32 (packed VALU); f64 re-score of every candidate",
+             0: "f32 (separate passes); f64 re-score of every candidate"}
 
 
 # ------------------------------------------------------------------ CPU baseline (oracle)
@@ -124,111 +143,103 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
-# ------------------------------------------------------------------------------ main
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
-    ap.add_argument("--shape", type=int, nargs=3, default=None, help="z y x (default: the named config's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--budget-gb", type=float, default=0.0,
-                    help="workspace budget per batch (default: 16 GiB = 22 blocks of the benchmark geometry, less when "
-                         "the free HBM of this rank's GPU does not allow it; larger batches are SLOWER: the host starts "
-                         "on a batch only when its kernels are done and its work is hidden behind the kernels of the "
-                         "next ones -- measured 157 / 161 / 165 / 170 ms per volume at 16 / 24 / 32 / 48 GiB)")
-    ap.add_argument("--denoise", type=int, default=0, metavar="SIZE",
-                    help="per-block preprocessing on (profile denoise_size) for c2 / c3; c5 has it at 25")
-    ap.add_argument("--volume", default=None, metavar="NPY",
-                    help="a (z, y, x[, c]) uint16 host volume to detect instead of the generated one (parity tests)")
-    ap.add_argument("--dump", default=None, metavar="NPZ", help="rank 0 writes the final table (and colocs) here")
-    ap.add_argument("--segment-size", type=int, default=0, help="profile segment_size (default 256; parity tests use smaller blocks)")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="pool size of the CPU baseline (default: all physical cores)")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    PROFILE = dict(_BASE_PROFILE, **cfg["profile"])
-    if args.denoise:
-        PROFILE["denoise_size"] = args.denoise
-    if args.segment_size:
-        PROFILE["segment_size"] = args.segment_size
-    host_vol = np.load(args.volume, mmap_mode="r") if args.volume else None
-    shape = tuple(host_vol.shape[:3]) if host_vol is not None else (tuple(args.shape) if args.shape else cfg["shape"])
-    n_chl = (host_vol.shape[3] if host_vol.ndim > 3 else 1) if host_vol is not None else cfg["channels"]
+def source_digest() -> str:
+    """SHA-1 over the kernel sources the library is built from: the committed counter passes name the digest they
+    were taken with, and a line only quotes them while the sources are still those."""
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "magellanmapper_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".inc", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()
+
+
+def self_launch(argv, n: int) -> int:
+    """Start the ``n`` ranks as a child ``torch.distributed.run`` and relay what rank 0 prints.  Runs before this
+    process has imported torch or touched the GPU (a process that has initialised the GPU must not be replaced, and
+    the children must find the GPUs unclaimed)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def make_host_sample(shp, seed, n_chl):
+    """Host sample of the workload from the same generator (per-channel seeds, channel 1 shares 70 % of channel 0)."""
+    import torch
+    from magellanmapper_amd import synth as _synth
+    cpu_dev = torch.device("cpu")
+    c0 = _synth.make_volume_device(shp, seed, cpu_dev).to(torch.int32)
+    if n_chl == 1:
+        return c0.numpy().astype(np.uint16)
+    c1 = _synth.make_volume_device(shp, seed + 1, cpu_dev).to(torch.int32)
+    c1 = torch.maximum(c1, (c0 * 7) // 10)
+    return torch.stack((c0, c1), dim=-1).numpy().astype(np.uint16)
+
+
+def config_setup(name: str, args, host_vol):
+    """``(cfg, profile, shape, n_channels, coloc)`` of a named workload with the command line's overrides."""
+    cfg = CONFIGS[name]
+    profile = dict(_BASE_PROFILE, **cfg["profile"])
+    if args.denoise and name == args.config:
+        profile["denoise_size"] = args.denoise
+    if args.segment_size and name == args.config:
+        profile["segment_size"] = args.segment_size
+    use_vol = host_vol if name == args.config else None
+    shape = tuple(use_vol.shape[:3]) if use_vol is not None else (
+        tuple(args.shape) if (args.shape and name == args.config) else cfg["shape"])
+    n_chl = (use_vol.shape[3] if use_vol.ndim > 3 else 1) if use_vol is not None else cfg["channels"]
+    return cfg, profile, shape, n_chl, bool(cfg["coloc"] and n_chl > 1)
+
+
+def run_cpu_baseline(name, args, host_vol):
+    """The oracle on a bounded sample of workload ``name`` (before the GPU is initialised: the worker pool is spawned)."""
+    cfg, profile, shape, n_chl, coloc = config_setup(name, args, host_vol)
+    phys = physical_cores()
+    cores = args.cpu_cores or phys
+    # a bounded sample (10-30 s of CPU work): about one block per core, at least two z-layers of blocks where
+    # the volume has them so that the sample prunes seams along all three axes
+    want_blocks = max(2, cores)
+    # (c5: both channels are preprocessed tile by tile in Python loops and detected -- one layer of 96-plane
+    #  blocks keeps the oracle at tens of seconds)
+    bz = 2 if (shape[0] > 256 and n_chl == 1) else 1
+    by = max(1, min(shape[1] // 256, int(np.sqrt(want_blocks / bz) + 0.5)))
+    bx = max(1, min(shape[2] // 256, -(-want_blocks // (bz * by))))
+    sz = min(shape[0], 320 if bz == 2 else (96 if n_chl > 1 else 256))
+    sshape = (sz, min(shape[1], 256 * by), min(shape[2], 256 * bx))
+    use_vol = host_vol if name == args.config else None
+    sample = make_host_sample(sshape, cfg["seed"], n_chl) if use_vol is None else np.ascontiguousarray(
+        use_vol[:sshape[0], :sshape[1], :sshape[2]])
     channels = list(range(n_chl))
-    coloc = bool(cfg["coloc"] and n_chl > 1)
-    seed = cfg["seed"]
+    cpu_final, t_det, t_tot, n_jobs = cpu_baseline(sample, cores, profile, channels, coloc)
+    cpu = {"value": round(int(np.prod(sshape)) / t_tot / 1e6, 3), "unit": "Mvoxels/s",
+           "cores": min(cores, n_jobs), "kind": "port",
+           "cpu_count": os.cpu_count(), "physical_cores": phys,
+           "detection_s": round(t_det, 2), "pruning_s": round(t_tot - t_det, 2),
+           "sample": f"{sshape[0]}x{sshape[1]}x{sshape[2]} (z,y,x){' x %d channels' % n_chl if n_chl > 1 else ''} "
+                     f"volume from the same generator (seed, blob density, profile, segment_size as the GPU run), "
+                     f"{n_jobs} blocks over a pool of {min(cores, n_jobs)} processes "
+                     f"(reference strategy, stack_detect.py:222-257)",
+           "blobs": 0 if cpu_final is None else int(len(cpu_final))}
+    return dict(cpu=cpu, final=cpu_final, sample=sample)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
-    # before anything touches the GPU runtime (the host driver only supports dmabuf IPC)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
+    """One workload on the GPU(s): warm-up, the timed region, the record (rank 0; ``None`` elsewhere)."""
     import torch
     import torch.distributed as tdist
-
-    def make_host_sample(shp):
-        """Host sample of the workload from the same generator (per-channel seeds, channel 1 shares 70 % of channel 0)."""
-        from magellanmapper_amd import synth as _synth
-        cpu_dev = torch.device("cpu")
-        c0 = _synth.make_volume_device(shp, seed, cpu_dev).to(torch.int32)
-        if n_chl == 1:
-            return c0.numpy().astype(np.uint16)
-        c1 = _synth.make_volume_device(shp, seed + 1, cpu_dev).to(torch.int32)
-        c1 = torch.maximum(c1, (c0 * 7) // 10)
-        return torch.stack((c0, c1), dim=-1).numpy().astype(np.uint16)
-
-    # ---------------- CPU baseline (rank 0, N = 1 only) BEFORE the GPU is initialised: the worker
-    # pool is spawned (fork + exec), which must not happen from a process that holds a GPU context
-    cpu = None
-    cpu_final = None
-    sample = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        phys = physical_cores()
-        cores = args.cpu_cores or phys
-        # a bounded sample (10-30 s of CPU work): about one block per core, at least two z-layers of blocks where
-        # the volume has them so that the sample prunes seams along all three axes
-        want_blocks = max(2, cores)
-        # (c5: both channels are preprocessed tile by tile in Python loops and detected -- one layer of 96-plane
-        #  blocks keeps the oracle at tens of seconds)
-        bz = 2 if (shape[0] > 256 and n_chl == 1) else 1
-        by = max(1, min(shape[1] // 256, int(np.sqrt(want_blocks / bz) + 0.5)))
-        bx = max(1, min(shape[2] // 256, -(-want_blocks // (bz * by))))
-        sz = min(shape[0], 320 if bz == 2 else (96 if n_chl > 1 else 256))
-        sshape = (sz, min(shape[1], 256 * by), min(shape[2], 256 * bx))
-        sample = make_host_sample(sshape) if host_vol is None else np.ascontiguousarray(
-            host_vol[:sshape[0], :sshape[1], :sshape[2]])
-        cpu_final, t_det, t_tot, n_jobs = cpu_baseline(sample, cores, PROFILE, channels, coloc)
-        cpu = {"value": round(int(np.prod(sshape)) / t_tot / 1e6, 3), "unit": "Mvoxels/s",
-               "cores": min(cores, n_jobs), "kind": "port",
-               "cpu_count": os.cpu_count(), "physical_cores": phys,
-               "detection_s": round(t_det, 2), "pruning_s": round(t_tot - t_det, 2),
-               "sample": f"{sshape[0]}x{sshape[1]}x{sshape[2]} (z,y,x){' x %d channels' % n_chl if n_chl > 1 else ''} "
-                         f"volume from the same generator (seed, blob density, profile, segment_size as the GPU run), "
-                         f"{n_jobs} blocks over a pool of {min(cores, n_jobs)} processes "
-                         f"(reference strategy, stack_detect.py:222-257)",
-               "blobs": 0 if cpu_final is None else int(len(cpu_final))}
-    # one rank per GPU; MMX_DIST_BACKEND=gloo + fewer GPUs than ranks is only for functional tests
-    backend = os.environ.get("MMX_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
-    local_dev = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
-    torch.cuda.set_device(local_dev)
-    dev = torch.device("cuda", local_dev)
-    if world > 1:
-        if backend == "nccl":
-            tdist.init_process_group("nccl", device_id=dev)
-        else:
-            tdist.init_process_group(backend)
-
     from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
     from magellanmapper_amd import config, detector, dist, stack_detect, synth
-
-    # host allocator: the per-step tables (tens of MB) come from the heap and stay mapped between steps instead
-    # of being mmap'd, page-faulted in and unmapped every step (8 ms of a 198 ms step, tools/steptrace.py)
-    nat.keep_host_heap()
+    rank, world, dev, backend = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"]
+    cfg, PROFILE, shape, n_chl, coloc = config_setup(name, args, host_vol)
+    use_vol = host_vol if name == args.config else None
+    channels = list(range(n_chl))
+    seed = cfg["seed"]
 
     config.resolutions = RESOLUTIONS
     config.filename = "bench"
@@ -248,8 +259,8 @@ def main():
     z0 = min(s.indices(shape[0])[0] for s in zs) if zs else 0
     z1 = max(s.indices(shape[0])[1] for s in zs) if zs else 1
     t_gen = time.time()
-    if host_vol is not None:
-        slab = torch.from_numpy(np.ascontiguousarray(host_vol[z0:z1]).view(np.int16)).to(dev).view(torch.uint16)
+    if use_vol is not None:
+        slab = torch.from_numpy(np.ascontiguousarray(use_vol[z0:z1]).view(np.int16)).to(dev).view(torch.uint16)
     else:
         slab = synth.make_volume_device(shape, seed, dev, z_range=(z0, z1))
         if n_chl > 1:     # channel 1: its own blob field plus 70 % of channel 0's (co-localised blobs)
@@ -283,54 +294,330 @@ def main():
         colocs = pruned[:, 10:10 + n_chl].astype(np.uint8) if coloc else None
         return bb.remove_abs_blob_coords(True), colocs
 
-    def one_step():
+    def detect_and_prune(vol, blk):
+        """What ``stack_detect.detect_blobs_blocks`` does between loading the image and writing its files: every rank
+        detects its share of the blocks; the pruning then is either a collective of all ranks (each prunes its own
+        rows) or, where the block geometry does not allow that, rank 0's after a gather."""
         t_a = time.perf_counter()
+        stack_detect.StackDetector.plan_pruning(blk.overlap, blk.tol, blk.overlap_padding, channels)
         seg = stack_detect.StackDetector.detect_blobs_sub_rois(
-            None, dvol, blocks.sub_roi_slices, blocks.sub_rois_offsets, blocks.denoise_max_shape,
-            blocks.exclude_border, coloc, channels)
+            None, vol, blk.sub_roi_slices, blk.sub_rois_offsets, blk.denoise_max_shape,
+            blk.exclude_border, coloc, channels)
         st = stack_detect.StackDetector.last_stats
         t_b = time.perf_counter()
         final = colocs = None
-        if rank == 0:
+        if rank == 0 or getattr(seg, "local_only", False):
             pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
-                dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices, blocks.sub_rois_offsets,
-                channels, blocks.overlap_padding)
-            final, colocs = finish(pruned)
+                vol, seg, blk.overlap, blk.tol, blk.sub_roi_slices, blk.sub_rois_offsets,
+                channels, blk.overlap_padding)
+            if rank == 0:
+                final, colocs = finish(pruned)
         t_c = time.perf_counter()
         timers["gather_ms"] += dist.last_gather_ms()
         timers["detect_ms"] += (t_b - t_a) * 1e3 - dist.last_gather_ms()
         timers["prune_ms"] += (t_c - t_b) * 1e3
         return final, colocs, st
 
+    def one_step():
+        return detect_and_prune(dvol, blocks)
+
     # workspace budget per batch: from the free HBM of this GPU unless given (ranks that share a GPU in the
     # functional tests share its memory)
-    import functools
     if args.budget_gb > 0:
         budget = int(args.budget_gb * (1 << 30))
     else:
         free_b, _ = torch.cuda.mem_get_info()
         sharers = max(1, -(-world // max(1, torch.cuda.device_count()))) if backend != "nccl" else 1
         budget = min(16 << 30, int(0.55 * free_b / sharers))
-    bl.blob_log_blocks = functools.partial(bl.blob_log_blocks, budget_bytes=budget)
+    bl.blob_log_blocks = functools.partial(ctx["blob_log_blocks"], budget_bytes=budget)
 
     # ---------------- the HIP path on the CPU-baseline sample must give the identical table
     parity = None
-    if cpu is not None:
+    cpu = None
+    if baseline is not None:
+        cpu, cpu_final, sample = baseline["cpu"], baseline["final"], baseline["sample"]
         sblocks = stack_detect.setup_blocks(config.roi_profile, sample.shape[:3])
         sdvol = bl.DeviceVolume(sample)
-        seg = stack_detect.StackDetector.detect_blobs_sub_rois(
-            None, sdvol, sblocks.sub_roi_slices, sblocks.sub_rois_offsets, sblocks.denoise_max_shape,
-            None, coloc, channels)
-        pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
-            sdvol, seg, sblocks.overlap, sblocks.tol, sblocks.sub_roi_slices, sblocks.sub_rois_offsets,
-            channels, sblocks.overlap_padding)
-        gpu_final, _ = finish(pruned)
+        gpu_final, _, _ = detect_and_prune(sdvol, sblocks)
         parity = bool(cpu_final is not None and gpu_final is not None and gpu_final.shape == cpu_final.shape and
                       np.array_equal(canon(gpu_final), canon(cpu_final)))
         del sdvol
 
+    # ---------------- warm-up, then the timed region
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        one_step()
+    for k in timers:
+        timers[k] = 0.0
+    nat.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    final = colocs = None
+    stats = None
+    for _ in range(steps):
+        final, colocs, stats = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = nat.timing_read()
+    nat.timing_enable(False)
+    per_rank = None
+    if world > 1:
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        mine = torch.tensor([sum(ms for ms, n in ktimes.values()) / steps, timers["detect_ms"] / steps,
+                             timers["gather_ms"] / steps, timers["prune_ms"] / steps, float(hi - lo)],
+                            dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        tdist.all_gather(allr, mine)
+        per_rank = [dict(zip(("kernel_ms", "detect_wall_ms", "gather_ms", "prune_ms", "blocks"),
+                             (round(float(v), 2) for v in r.cpu()))) for r in allr]
+    del dvol, slab
+    bl.release_buffers()
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+
+    nvox = int(np.prod(shape))
+    ns = PROFILE["num_sigma"]
+    # VOLUME voxels (all channels) of this rank's share: the contract's per-voxel figures count volume voxels, the
+    # overlap between blocks (x 1.05 at the benchmark geometry) is the builder's loss (SURVEY.md section 8d)
+    my_vox = nvox * n_chl * (hi - lo) / max(1, n_blocks)
+    flags = []
+    per_kernel = {}
+    for k, (ms, n) in ktimes.items():
+        if n:
+            per_kernel[k] = {"ms_per_step": round(ms / steps, 3), "launches_per_step": n // steps}
+            if k in ALG_BYTES:
+                gbs = ALG_BYTES[k] * my_vox * ns * steps / (ms * 1e-3) / 1e9
+                per_kernel[k]["alg_GBps"] = round(gbs, 1)
+                if gbs > HBM_PEAK_GBS:
+                    flags.append(f"kernels.{k}.alg_GBps")
+                    per_kernel[k]["note"] = ("above the 8 TB/s peak: quoted on the contract's byte count (peaks: 4 B per "
+                                             "voxel and sigma), while the kernel reads the sparse NMS entries the Y pass "
+                                             "leaves (16 B per 64 voxels and sigma plus the lines of the set bits)")
+            elif k == "preproc":      # once per voxel (not per sigma): 2 B in, 8 + 4 B out; fp64-VALU bound
+                per_kernel[k]["alg_GBps"] = round(14 * my_vox * steps / (ms * 1e-3) / 1e9, 1)
+    stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
+    dom = max(stream_k, key=lambda k: stream_k[k]["ms_per_step"]) if stream_k else None
+    zx_path = bl.LAST_ZX_PATH
+    roof = None
+    if dom:
+        launches = ktimes[dom][1]
+        avg_ms = ktimes[dom][0] / max(1, launches)
+        # what the committed counter passes of this command say about the same kernel, while the sources they were
+        # taken with are still the ones this library was built from
+        traffic = actual_frac = valu_busy = mfma_busy = None
+        counters_note = None
+        try:
+            with open(os.path.join(ROOT, PMC_FILE)) as f:
+                pmc = json.load(f)
+            fresh = pmc.get("source_digest") == source_digest()
+            usable = (fresh and name == "c3" and tuple(shape) == cfg["shape"] and world == 1 and
+                      dom in pmc.get("per_launch_GB", {}))
+            if usable:
+                traffic = round(pmc["per_launch_GB"][dom]["total_GB"] * 1e9)
+                actual_frac = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                busy = pmc.get("busy", {}).get(dom, {})
+                valu_busy, mfma_busy = busy.get("valu_busy"), busy.get("mfma_busy")
+                counters_note = (PMC_FILE + ": rocprofv3 --pmc passes of this command (separate FETCH_SIZE / WRITE_SIZE "
+                                 "/ SQ passes, calibrated as MI355X_MICROARCH.md prescribes); bytes per launch averaged "
+                                 "over all launches of the kernel; not collected in this run")
+            elif not fresh:
+                counters_note = PMC_FILE + " was taken with other kernel sources (digest mismatch): not quoted"
+        except (OSError, KeyError, ValueError):
+            counters_note = "no committed counter passes for this code"
+        roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),
+                "alg_bytes_per_launch": int(ALG_BYTES[dom] * my_vox * ns * steps / max(1, launches)),
+                "avg_launch_ms": round(avg_ms, 4),
+                "traffic": traffic, "actual_frac": actual_frac, "valu_busy": valu_busy, "mfma_busy": mfma_busy,
+                "counters": counters_note,
+                "copy_GBps": ctx.get("copy_gbps"),
+                "frac_of_copy": None if not ctx.get("copy_gbps") else round(stream_k[dom]["alg_GBps"] / ctx["copy_gbps"], 4),
+                "note": "achieved = SURVEY.md 8d's algorithmic bytes of this pass (zxpass: 2 B voxels in + 8 B "
+                        "intermediates out per volume voxel and sigma) / its HIP-event time; the kernel itself moves "
+                        "fewer bytes than that ('traffic'): its intermediates are 16-bit fixed point and it is bound by "
+                        "instruction issue, not by HBM (DESIGN.md section 4b)" if dom == "zxpass" else None}
+        if dom == "zxpass" and zx_path in (nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16):
+            # the same kernel against the matrix-core roofline: MFMAs it issues (16 x 16 x 32 float16, 16 384 flop
+            # each) per 16 x 16 tile step -- X pass 12 (16-bit tiles) or 16 per two k-steps, 6 / 8 for radius <= 8;
+            # Z pass 9 per k-step -- over every block row, column tile and z step of this rank's blocks
+            space = bl.ScaleSpace.make(PROFILE["min_sigma_factor"] * detector.calc_scaling_factor()[2],
+                                       PROFILE["max_sigma_factor"] * detector.calc_scaling_factor()[2], ns)
+            q16 = zx_path == nat.MMX_ZX_TILED_Q16
+            flop = 0.0
+            for i in range(lo, hi):
+                shp = [s_.indices(n_)[1] - s_.indices(n_)[0] for s_, n_ in zip(blocks.sub_roi_slices[coords[i]], shape)]
+                for R in space.radii:
+                    nkx, la = (1, 1) if R <= 8 else ((2, 1) if R <= 16 else (2, 2))
+                    per_step = nkx * (6 if q16 else 8) + (la + 1) * 9
+                    flop += shp[1] * -(-shp[2] // 16) * (-(-shp[0] // 16) + la) * per_step * 16384.0
+            tfs = flop * n_chl * steps / (ktimes[dom][0] * 1e-3) / 1e12
+            roof["mfma"] = {"achieved_TFLOPs": round(tfs, 1), "peak_TFLOPs": 2500.0, "frac": round(tfs / 2500.0, 4),
+                            "note": "float16 MFMA flops the kernel issues (split-float16 products: 3 MFMAs per float32 "
+                                    "product) over its duration, against the dense float16 peak"}
+    gpu_ms = sum(ms for ms, n in ktimes.values()) / steps
+    main_ms = sum(ms for k, (ms, n) in ktimes.items() if k in MAIN_STREAM) / steps
+    b_alg = B_ALG_PER_SIGMA * ns * n_chl
+    vol_bytes = nvox * n_chl * 2
+    frac_kernels = b_alg * (nvox / world) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    frac_wall = b_alg * nvox / (elapsed / steps) / 1e9 / HBM_PEAK_GBS / world
+    for key, val in (("pipeline_roofline.frac_kernels", frac_kernels), ("pipeline_roofline.frac_wall", frac_wall),
+                     ("roofline.frac", roof["frac"] if roof else 0)):
+        if val > 1:
+            flags.append(key)
+    h2d_gbps = ctx.get("h2d_gbps")
+    out = {
+        "metric": cfg["metric"],
+        "value": round(nvox * steps / elapsed / 1e6, 2), "unit": "Mvoxels/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate") if PROFILE["denoise_size"] is None
+                 else "f64 preprocessing; " + ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate"),
+        "zx_path": zx_path, "host_path": bl.HOST_PATH,
+        "data": "synthetic" if use_vol is None else args.volume,
+        "config": {"workload": f"{name}: {shape[2]}x{shape[1]}x{shape[0]} (x,y,z) uint16 Gaussian-blob volume, "
+                               f"seed {seed}, {n_blocks} blocks (segment_size {PROFILE['segment_size']}, overlap 5), {cfg['what']}, "
+                               "threshold 0.1, overlap 0.5; detect + table exchange + prune"
+                               + (f"; per-block preprocessing (denoise_size {PROFILE['denoise_size']}: saturate + "
+                                  "unsharp + erosion in float64)" if PROFILE["denoise_size"] else ""),
+                   "blocks_per_rank": hi - lo, "parallelism": f"blocks sharded over {world} GPU(s)",
+                   "batch_budget_GB": round(budget / (1 << 30), 1)},
+        "blobs": 0 if final is None else int(len(final)),
+        # digest of the final 8-column table of the last step (computed after the timed region): the same
+        # for every path / batch size / rank count that is correct (tests compare smaller volumes with the
+        # oracle row by row; this is the full-size cross-check)
+        "table_sha1": None if final is None else hashlib.sha1(np.ascontiguousarray(final).tobytes()).hexdigest(),
+        "blobs_per_s": round((0 if final is None else len(final)) * steps / elapsed, 1),
+        "roofline": roof,
+        "pipeline_roofline": {
+            "alg_bytes_per_voxel": b_alg,
+            "gpu_kernel_ms_per_step_rank0": round(gpu_ms, 2),
+            "main_stream_kernel_ms_per_step_rank0": round(main_ms, 2),
+            "achieved_GBps_kernels": round(frac_kernels * HBM_PEAK_GBS, 1),
+            "frac_kernels": round(frac_kernels, 4),
+            "achieved_GBps_wall": round(frac_wall * HBM_PEAK_GBS * world, 1),
+            "frac_wall": round(frac_wall, 4),
+            # wall clock not covered by a kernel on the stream the LoG passes run on: start-up before the first
+            # launch, launch gaps, and the tail after the last kernel (last batch's host work, pruning, final columns)
+            "host_exposed_ms_per_step": round(elapsed / steps * 1e3 - main_ms, 2) if world == 1 else None},
+        "above_contract_roofline": flags or None,
+        "above_contract_roofline_note": None if not flags else (
+            "fractions above 1 are quoted on SURVEY.md 8d's byte count (50 B per voxel and sigma: three unfused passes "
+            "with float32 intermediates); the fused kernels with 16-bit intermediates move about 14 B: the contract "
+            "roofline is saturated and no longer discriminates, see roofline.actual_frac / valu_busy / mfma_busy"),
+        "h2d": None if h2d_gbps is None else {
+            "GBps_measured": round(h2d_gbps, 1), "volume_GB": round(vol_bytes / 1e9, 2),
+            "ms_for_volume": round(vol_bytes / (h2d_gbps * 1e9) * 1e3, 1),
+            "note": "pinned host -> device copy rate measured in this run (256 MiB x 4), extrapolated to the volume; "
+                    "the timed region starts with the volume resident (contract), a caller handing a host "
+                    "volume pays this once per volume"},
+        "kernels": per_kernel,
+        "ranks": per_rank,
+        "detector_stats": {k: (round(float(v), 9) if isinstance(v, (float, np.floating)) else int(v))
+                           for k, v in vars(stats).items()},
+        "cpu_baseline": cpu, "parity_sample_identical": parity,
+        "volume_gen_s": round(t_gen, 2),
+    }
+    if args.dump and name == args.config:
+        np.savez(args.dump, final=np.zeros((0, 8)) if final is None else final,
+                 colocs=np.zeros((0, n_chl), dtype=np.uint8) if colocs is None else colocs)
+    return out
+
+
+def compact(rec):
+    """The sub-record form of a full record."""
+    pr, roof = rec["pipeline_roofline"], rec["roofline"] or {}
+    return {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"],
+            "ms_per_step": rec["ms_per_step"], "blobs": rec["blobs"], "table_sha1": rec["table_sha1"],
+            "frac_wall": pr["frac_wall"], "main_stream_kernel_ms_per_step": pr["main_stream_kernel_ms_per_step_rank0"],
+            "host_exposed_ms_per_step": pr["host_exposed_ms_per_step"],
+            "dominant_kernel": roof.get("kernel"), "dominant_kernel_frac": roof.get("frac"),
+            "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in rec["kernels"].items()},
+            "parity_sample_identical": rec["parity_sample_identical"],
+            "cpu_baseline": None if rec["cpu_baseline"] is None else
+            {k: rec["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")},
+            "config": rec["config"]["workload"], "dtype": rec["dtype"]}
+
+
+# ------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="workload (default c3; the default command on one GPU also appends compact c2 and c5 sub-records)")
+    ap.add_argument("--no-sub-records", action="store_true", help="default command: c3 only")
+    ap.add_argument("--shape", type=int, nargs=3, default=None, help="z y x (default: the named config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--budget-gb", type=float, default=0.0,
+                    help="workspace budget per batch (default: 16 GiB = 22 blocks of the benchmark geometry, less when "
+                         "the free HBM of this rank's GPU does not allow it; larger batches are SLOWER: the host starts "
+                         "on a batch only when its kernels are done and its work is hidden behind the kernels of the "
+                         "next ones -- measured 157 / 161 / 165 / 170 ms per volume at 16 / 24 / 32 / 48 GiB)")
+    ap.add_argument("--denoise", type=int, default=0, metavar="SIZE",
+                    help="per-block preprocessing on (profile denoise_size) for c2 / c3; c5 has it at 25")
+    ap.add_argument("--volume", default=None, metavar="NPY",
+                    help="a (z, y, x[, c]) uint16 host volume to detect instead of the generated one (parity tests)")
+    ap.add_argument("--dump", default=None, metavar="NPZ", help="rank 0 writes the final table (and colocs) here")
+    ap.add_argument("--segment-size", type=int, default=0, help="profile segment_size (default 256; parity tests use smaller blocks)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="pool size of the CPU baseline (default: all physical cores)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # N ranks wanted, none launched: launch them (before anything here touches the GPU)
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    explicit = args.config is not None
+    args.config = args.config or "c3"
+    host_vol = np.load(args.volume, mmap_mode="r") if args.volume else None
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    # before anything touches the GPU runtime (the host driver only supports dmabuf IPC)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    subs = [] if (explicit or args.no_sub_records or world > 1 or args.volume or args.shape or args.denoise
+                  or args.segment_size or args.dump) else list(SUB_RECORDS)
+
+    import torch
+    import torch.distributed as tdist
+
+    # ---------------- CPU baselines (rank 0, N = 1 only) BEFORE the GPU is initialised: the worker
+    # pool is spawned (fork + exec), which must not happen from a process that holds a GPU context
+    baselines = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        for name in [args.config] + subs:
+            baselines[name] = run_cpu_baseline(name, args, host_vol)
+    # one rank per GPU; MMX_DIST_BACKEND=gloo + fewer GPUs than ranks is only for functional tests
+    backend = os.environ.get("MMX_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+    local_dev = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    if world > 1:
+        if backend == "nccl":
+            tdist.init_process_group("nccl", device_id=dev)
+        else:
+            tdist.init_process_group(backend)
+
+    from magellanmapper_amd import _native as nat
+    from magellanmapper_amd import blob_log as bl
+
+    # host allocator: the per-step tables (tens of MB) come from the heap and stay mapped between steps instead
+    # of being mmap'd, page-faulted in and unmapped every step (8 ms of a 198 ms step, tools/steptrace.py)
+    nat.keep_host_heap()
+    ctx = dict(rank=rank, world=world, dev=dev, backend=backend, blob_log_blocks=bl.blob_log_blocks)
+
     # ---------------- measured beside the roofline peak: a device copy and the host -> device link
-    copy_gbps = h2d_gbps = None
     if rank == 0:
         n = 1 << 28                                   # 1 GiB in + 1 GiB out: far beyond the 256 MiB Infinity Cache
         a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
@@ -343,7 +630,7 @@ def main():
             nat.check(nat.lib().mmx_calib_stream(1, a.data_ptr(), b.data_ptr(), n, s_ptr), "mmx_calib_stream")
         ev[1].record()
         torch.cuda.synchronize()
-        copy_gbps = 2 * 2 * n * 4 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9
+        ctx["copy_gbps"] = round(2 * 2 * n * 4 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e9, 1)
         hbuf = torch.empty(1 << 28, dtype=torch.uint8).pin_memory()       # 256 MiB pinned
         dbuf = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
         dbuf.copy_(hbuf, non_blocking=True)
@@ -352,163 +639,17 @@ def main():
         for _ in range(4):
             dbuf.copy_(hbuf, non_blocking=True)
         torch.cuda.synchronize()
-        h2d_gbps = 4 * (1 << 28) / (time.perf_counter() - t_h) / 1e9
+        ctx["h2d_gbps"] = 4 * (1 << 28) / (time.perf_counter() - t_h) / 1e9
         del a, b, hbuf, dbuf
+        torch.cuda.empty_cache()
 
-    # ---------------- warm-up, then the timed region
-    def barrier():
-        if world > 1:
-            tdist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    for k in timers:
-        timers[k] = 0.0
-    nat.timing_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    final = colocs = None
-    stats = None
-    for _ in range(args.steps):
-        final, colocs, stats = one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ktimes = nat.timing_read()
-    nat.timing_enable(False)
-    per_rank = None
-    if world > 1:
-        cdev = dev if backend == "nccl" else "cpu"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        mine = torch.tensor([sum(ms for ms, n in ktimes.values()) / args.steps, timers["detect_ms"] / args.steps,
-                             timers["gather_ms"] / args.steps, timers["prune_ms"] / args.steps, float(hi - lo)],
-                            dtype=torch.float64, device=cdev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        tdist.all_gather(allr, mine)
-        per_rank = [dict(zip(("kernel_ms", "detect_wall_ms", "gather_ms", "prune_ms", "blocks"),
-                             (round(float(v), 2) for v in r.cpu()))) for r in allr]
-
+    out = run_gpu(args.config, args, host_vol, baselines.get(args.config), args.steps, args.warmup, ctx)
+    if subs and out is not None:
+        out["sub_records"] = {}
+        for name in subs:
+            st, wu = SUB_RECORDS[name]
+            out["sub_records"][name] = compact(run_gpu(name, args, host_vol, baselines.get(name), st, wu, ctx))
     if rank == 0:
-        nvox = int(np.prod(shape))
-        ns = PROFILE["num_sigma"]
-        my_vox = stats.n_voxels                       # block voxels (all channels) this rank filtered per step
-        per_kernel = {}
-        for k, (ms, n) in ktimes.items():
-            if n:
-                per_kernel[k] = {"ms_per_step": round(ms / args.steps, 3), "launches_per_step": n // args.steps}
-                if k in ALG_BYTES:
-                    gbs = ALG_BYTES[k] * my_vox * ns * args.steps / (ms * 1e-3) / 1e9
-                    per_kernel[k]["alg_GBps"] = round(gbs, 1)
-                    if k == "peaks" and gbs > HBM_PEAK_GBS:
-                        per_kernel[k]["note"] = ("sparse NMS over the entries the Y pass leaves (16 B per 64 voxels and "
-                                                 "sigma, plus the lines of the set bits); alg_GBps is quoted on the "
-                                                 "4 B contract figure")
-                elif k == "preproc":      # once per voxel (not per sigma): 2 B in, 8 + 4 B out; fp64-VALU bound
-                    per_kernel[k]["alg_GBps"] = round(14 * my_vox * args.steps / (ms * 1e-3) / 1e9, 1)
-        stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
-        dom = max(stream_k, key=lambda k: stream_k[k]["ms_per_step"]) if stream_k else None
-        roof = None
-        # HBM bytes per launch of the dominant kernel: NOT measured in this run (PMC passes need rocprofv3); when the
-        # committed PMC summary of this same command names the kernel, its figure is quoted with its source
-        traffic = traffic_src = None
-        try:
-            src = "profiles/r02_pmc_traffic.json"
-            with open(os.path.join(ROOT, src)) as f:
-                pmc = json.load(f)
-            if args.config == "c3" and tuple(shape) == cfg["shape"] and world == 1 and dom in pmc["per_launch_GB"]:
-                traffic = round(pmc["per_launch_GB"][dom]["total_GB"] * 1e9)
-                traffic_src = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, calibrated; not this run)"
-        except (OSError, KeyError, ValueError):
-            pass
-        if dom:
-            launches = ktimes[dom][1]
-            roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"],
-                    "note": ("zxpass = fused Z+X pass on the matrix cores (zx_mode 7: tiled, 16-bit intermediates): the "
-                             "10 algorithmic B/voxel/sigma of the contract replace the 22 of the separate Z and X passes "
-                             "(+ 0.8 B/voxel/sigma for the operand-ordered voxel copy, 'zxpack', made once per batch); "
-                             "the kernel itself moves 6.4 B/voxel because P and Q leave as 16-bit fixed point (error "
-                             "bound 4.3e-5, covered fourfold by the NMS band; decisions are taken on exact float64 "
-                             "values).  'traffic' below the algorithmic bytes is that.  With float32 tiles it sat at "
-                             "the ~80 L2 requests a CU keeps in flight; now its VALU is 58 % and its MFMA pipe 43 % "
-                             "busy: instruction issue (DESIGN.md section 4b).  The Y pass of the step runs at "
-                             f"{stream_k.get('y2pass', {}).get('alg_GBps', 0) / HBM_PEAK_GBS:.2f} of peak on its "
-                             "contract bytes (it reads 16-bit tiles too); see 'kernels' and 'pipeline_roofline'")
-                    if dom == "zxpass" else None,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),
-                    "copy_GBps": None if copy_gbps is None else round(copy_gbps, 1),
-                    "frac_of_copy": None if not copy_gbps else round(stream_k[dom]["alg_GBps"] / copy_gbps, 4),
-                    "traffic": traffic, "traffic_source": traffic_src,
-                    "alg_bytes_per_launch": int(ALG_BYTES[dom] * my_vox * ns * args.steps / max(1, launches)),
-                    "avg_launch_ms": round(ktimes[dom][0] / max(1, launches), 4)}
-            if dom == "zxpass" and bl.LAST_ZX_PATH in (nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16):
-                # the same kernel against the matrix-core roofline: MFMAs it issues (16 x 16 x 32 float16, 16 384 flop
-                # each) per 16 x 16 tile step -- X pass 12 (16-bit tiles) or 16 per two k-steps, 6 / 8 for radius <= 8;
-                # Z pass 9 per k-step -- over every block row, column tile and z step of this rank's blocks
-                from magellanmapper_amd import kernels1d as k1
-                space = bl.ScaleSpace.make(PROFILE["min_sigma_factor"] * detector.calc_scaling_factor()[2],
-                                           PROFILE["max_sigma_factor"] * detector.calc_scaling_factor()[2], ns)
-                q16 = bl.LAST_ZX_PATH == nat.MMX_ZX_TILED_Q16
-                flop = 0.0
-                for i in range(lo, hi):
-                    shp = [s_.indices(n_)[1] - s_.indices(n_)[0] for s_, n_ in zip(blocks.sub_roi_slices[coords[i]], shape)]
-                    for R in space.radii:
-                        nkx, la = (1, 1) if R <= 8 else ((2, 1) if R <= 16 else (2, 2))
-                        per_step = nkx * (6 if q16 else 8) + (la + 1) * 9
-                        flop += shp[1] * -(-shp[2] // 16) * (-(-shp[0] // 16) + la) * per_step * 16384.0
-                tfs = flop * args.steps / (ktimes[dom][0] * 1e-3) / 1e12
-                roof["mfma"] = {"achieved_TFLOPs": round(tfs, 1), "peak_TFLOPs": 2500.0, "frac": round(tfs / 2500.0, 4),
-                                "note": "float16 MFMA flops the kernel issues (split-float16 products: 3 MFMAs per float32 "
-                                        "product) over its duration, against the dense float16 peak"}
-        gpu_ms = sum(ms for ms, n in ktimes.values()) / args.steps
-        b_alg = B_ALG_PER_SIGMA * ns * n_chl
-        vol_bytes = nvox * n_chl * 2
-        out = {
-            "metric": cfg["metric"],
-            "value": round(nvox * args.steps / elapsed / 1e6, 2), "unit": "Mvoxels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if host_vol is None else args.volume,
-            "config": {"workload": f"{args.config}: {shape[2]}x{shape[1]}x{shape[0]} (x,y,z) uint16 Gaussian-blob volume, "
-                                   f"seed {seed}, {n_blocks} blocks (segment_size {PROFILE['segment_size']}, overlap 5), {cfg['what']}, "
-                                   "threshold 0.1, overlap 0.5; detect + gather + prune"
-                                   + (f"; per-block preprocessing (denoise_size {PROFILE['denoise_size']}: saturate + "
-                                      "unsharp + erosion in float64)" if PROFILE["denoise_size"] else ""),
-                       "blocks_per_rank": hi - lo, "parallelism": f"blocks sharded over {world} GPU(s)",
-                       "batch_budget_GB": round(budget / (1 << 30), 1)},
-            "blobs": 0 if final is None else int(len(final)),
-            # digest of the final 8-column table of the last step (computed after the timed region): the same
-            # for every path / batch size / rank count that is correct (tests compare smaller volumes with the
-            # oracle row by row; this is the full-size cross-check)
-            "table_sha1": None if final is None else hashlib.sha1(np.ascontiguousarray(final).tobytes()).hexdigest(),
-            "blobs_per_s": round((0 if final is None else len(final)) * args.steps / elapsed, 1),
-            "roofline": roof,
-            "pipeline_roofline": {
-                "alg_bytes_per_voxel": b_alg,
-                "gpu_kernel_ms_per_step_rank0": round(gpu_ms, 2),
-                "achieved_GBps_kernels": round(b_alg * (nvox / world) / (gpu_ms * 1e-3) / 1e9, 1),
-                "frac_kernels": round(b_alg * (nvox / world) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "achieved_GBps_wall": round(b_alg * nvox / (elapsed / args.steps) / 1e9, 1),
-                "frac_wall": round(b_alg * nvox / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS / world, 4),
-                "host_exposed_ms_per_step": round(elapsed / args.steps * 1e3 - gpu_ms, 2) if world == 1 else None},
-            "h2d": None if h2d_gbps is None else {
-                "GBps_measured": round(h2d_gbps, 1), "volume_GB": round(vol_bytes / 1e9, 2),
-                "ms_for_volume": round(vol_bytes / (h2d_gbps * 1e9) * 1e3, 1),
-                "note": "pinned host -> device copy rate measured in this run (256 MiB x 4), extrapolated to the volume; "
-                        "the timed region starts with the volume resident (contract), a caller handing a host "
-                        "volume pays this once per volume"},
-            "kernels": per_kernel,
-            "ranks": per_rank,
-            "detector_stats": {k: (round(float(v), 9) if isinstance(v, (float, np.floating)) else int(v))
-                               for k, v in vars(stats).items()},
-            "cpu_baseline": cpu, "parity_sample_identical": parity,
-            "volume_gen_s": round(t_gen, 2),
-        }
-        if args.dump:
-            np.savez(args.dump, final=np.zeros((0, 8)) if final is None else final,
-                     colocs=np.zeros((0, n_chl), dtype=np.uint8) if colocs is None else colocs)
         print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()

@@ -133,7 +133,9 @@ int mmx_device_count(void);
  *   zx_mode    : how the Z and X passes run (a per-call argument: the library keeps no mode).
  *                MMX_ZX_AUTO (default): the fastest kernel that takes the geometry (MMX_ZX_TILED for integer
  *                voxels, else MMX_ZX_PACKED, else the separate passes); the others exist for cross-checks and
- *                measurements.  All agree within float32 rounding, and the peak decisions are taken on exact
+ *                measurements.  Float voxels take MMX_ZX_TILED when it is asked for BY NAME: its copy holds
+ *                every voxel as two float16 pieces (22 significant bits, like the weights), which covers
+ *                |v| < 65504 and thins out below ~2^-10 -- the caller knows the value range, the library does not.  All agree within float32 rounding, and the peak decisions are taken on exact
  *                float64 values either way (mmx_rescore_f64).  With entries requested and nms_eps at least four times
  *                mmx_tiled_q16_error_bound(), AUTO hands the intermediates over as 16-bit fixed point
  *                (MMX_ZX_TILED_Q16).  MMX_ZX_TILED works from an operand-ordered copy of
@@ -166,14 +168,15 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
 
 /* Largest deviation of an MMX_ZX_TILED_Q16 LoG value from the float32 paths' (which are within a few 1e-7 of the
  * exact value), in units of the image's value scale, for voxels in [0, 1] (uint8 / uint16 after img_as_float): a
- * function of the weights alone (4.3e-5 for any sigma >= 1).  A true maximum is nominated as long as the NMS band is four
+ * function of the weights alone (4.6e-5 for any sigma >= 1).  A true maximum is nominated as long as the NMS band is four
  * times this (mmx_rescore_f64 then decides on exact values as always).  < 0 on bad arguments. */
 double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm);
 
 /* The sigma-independent part of MMX_ZX_TILED: the operand-ordered copy of the blocks' voxels, written into the
  * part of d_work (same pointer, blocks and slot_elems as the mmx_log_batch_f32 calls that follow) that the tiled
- * path leaves alone.  MMX_ERR_UNSUPPORTED (nothing written) for float voxels or when the pieces do not fit
- * d_work: call mmx_log_batch_f32 without MMX_ZX_PREPACKED then. */
+ * path leaves alone.  MMX_ERR_UNSUPPORTED (nothing written) for float64 voxels or when the pieces do not fit
+ * d_work: call mmx_log_batch_f32 without MMX_ZX_PREPACKED then.  float32 voxels are split into float16 pieces here
+ * (see zx_mode above for the value range this suits). */
 int mmx_zx_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
                 int64_t slot_elems, float* d_work, void* stream);
 
@@ -470,6 +473,19 @@ int mmx_host_prune_region(const int32_t* zyx, const int32_t* tag, double* abs_zy
                           const double last_end[3], const int32_t tol[3], const double* const nxt_lo[3],
                           const double* const nxt_hi[3], int64_t* out_rows, int64_t* out_keys, int64_t* out_n,
                           int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld);
+/* mmx_host_prune_region for a region whose rows are still in the merged table: `parts` [n_parts][2] are ascending row
+ * ranges of it, part `own_part` the region itself, the others its neighbours, of which only rows inside
+ * [box_lo, box_hi) take part; every channel of `channels` in turn (chan: the table's channel column, pitch chan_ld
+ * doubles, or NULL = all rows are channels[0]); out_ids: the region's survivors as rows of the merged table,
+ * out_keys: channel position x n_keys + key, out_abs: their averaged coordinates [..][3]; the merged table itself is
+ * not written to.  Statistics [n_channels][3][stat_ld].  (out_keys of mmx_host_prune_region may be NULL.) */
+int mmx_host_prune_parts(const int32_t* zyx, const int32_t* tag, const double* abs_zyx, const double* chan,
+                         int64_t chan_ld, const int64_t* parts, int n_parts, int own_part, const int32_t box_lo[3],
+                         const int32_t box_hi[3], const double* channels, int n_channels,
+                         const int32_t n_sections[3], const double* const bounds[3], const double last_end[3],
+                         const int32_t tol[3], const double* const nxt_lo[3], const double* const nxt_hi[3],
+                         int64_t n_keys, int64_t* out_ids, int64_t* out_keys, double* out_abs, int64_t* out_n,
+                         int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld);
 int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
                           int64_t n_cols, double* out);
 int mmx_host_gather_by_key(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,

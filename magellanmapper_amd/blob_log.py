@@ -72,6 +72,8 @@ LAST_ZX_PATH = None
 #: ``mmx_host_overlap_prune``: threaded, outside the GIL, no second device round trip) or "numpy" (the same rules as
 #: array expressions; kept as a cross-check -- tests run both -- and for ``exact_values=False``)
 HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
+#: value scales (largest |voxel|) for which float voxels take the tiled matrix-core path (float16 pieces: exponent range)
+FLOAT_TILED_RANGE = (2.0 ** -6, 2.0 ** 12)
 #: candidate-table entries copied to pinned host memory together with the counts, before the host knows how many
 #: there are (a batch of the benchmark volume holds ~3e4; more entries cost a second, synchronous copy)
 _PREFIX_ENTRIES = 1 << 16
@@ -506,7 +508,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     results: List[Optional[np.ndarray]] = [None] * len(shapes)
     peaks_out: List[Optional[Tuple[np.ndarray, np.ndarray]]] = [None] * len(shapes)
     bufs = _buffers_for(dvol.tensor.device)
-    eps = EPS_REL * (dvol.value_scale() if pre is None else pre.value_scale([channel]))
+    vscale = float(dvol.value_scale() if pre is None else pre.value_scale([channel]))
+    eps = EPS_REL * vscale
     if (pre is None and dvol.np_dtype in (np.uint8, np.uint16) and EPS_REL_Q16 > EPS_REL
             and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)):
         eps = EPS_REL_Q16 * dvol.value_scale()
@@ -540,7 +543,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             batch = batches[enq]
             jobs[enq] = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
                                         space, float(threshold), eps, bufs, enq % (ahead + 1), d_w0, d_w2, pre=pre,
-                                        exact=exact, prepared=None if prepared is None else prepared[enq])
+                                        exact=exact, prepared=None if prepared is None else prepared[enq],
+                                        vscale=vscale)
             jobs[enq]["batch"] = batch
             enq += 1
         pending, jobs[k] = jobs[k], None
@@ -567,7 +571,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
 # --------------------------------------------------------------------------- A0-A4
 def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
                     bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None,
-                    exact: bool = False, prepared=None):
+                    exact: bool = False, prepared=None, vscale: Optional[float] = None):
     """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU.
     ``exact``: also re-score every candidate in float64 (otherwise ``_resolve_peaks`` re-scores the few
     whose decision depends on it)."""
@@ -608,13 +612,18 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
         # path uses the same part of the workspace for something else)
         packed = False
         tiled_mode = nat.MMX_ZX_TILED
-        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16):
+        is_float = vol32.dtype == nat.MMX_F32
+        # float voxels (float images, preprocessed blocks): the tiled path holds each as two float16 pieces, which
+        # suits values of ordinary magnitude -- the range is known here, not in the library (include/mmx.h: zx_mode)
+        float_ok = is_float and vscale is not None and FLOAT_TILED_RANGE[0] <= vscale <= FLOAT_TILED_RANGE[1]
+        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16) and not is_float:
             # 16-bit intermediates when the band covers their rounding error fourfold (or when asked for by name)
             bound = max(float(L.mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
                                                           int(space.radii[s]), float(space.norms[s]))) for s in range(ns))
             if mode == nat.MMX_ZX_TILED_Q16 or (0 <= 4.0 * bound <= eps):
                 tiled_mode = nat.MMX_ZX_TILED_Q16
-        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16):
+        if (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16) and not is_float) or \
+                (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED) and float_ok):
             rc = L.mmx_zx_pack(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                                ws.data_ptr(), stream)
             if rc not in (0, 5):                 # MMX_OK, MMX_ERR_UNSUPPORTED (float voxels, workspace shape)
@@ -673,7 +682,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     done.record()
     return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
                 nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
-                vol_exact=vol_exact, pre=pre, exact=exact, eps=eps, native=native)
+                vol_exact=vol_exact, pre=pre, exact=exact, eps=eps, native=native, vscale=vscale)
 
 
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
@@ -700,7 +709,7 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
             torch.cuda.current_stream().synchronize()
             redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr,
                                    eps, bufs, which, d_w0, d_w2, cap=count + 1024, pre=job.get("pre"),
-                                   exact=job.get("exact", False))
+                                   exact=job.get("exact", False), vscale=job.get("vscale"))
             redo["batch"] = job.get("batch")
             return _finish_detect(redo, dvol, space, thr, eps, bufs, d_w0, d_w2, stats)
     with torch.cuda.stream(bufs.side):
@@ -735,7 +744,7 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
     stats.n_band_retries += 1
     torch.cuda.current_stream().synchronize()
     redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr, wider, bufs, which,
-                           d_w0, d_w2, cap=None, pre=job.get("pre"), exact=True)
+                           d_w0, d_w2, cap=None, pre=job.get("pre"), exact=True, vscale=job.get("vscale"))
     redo["batch"] = job.get("batch")
     redo["retries"] = job.get("retries", 0) + 1
     return _finish_detect(redo, dvol, space, thr, wider, bufs, d_w0, d_w2, stats)

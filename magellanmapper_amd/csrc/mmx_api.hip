@@ -145,8 +145,10 @@ int mmx_device_count(void)
 // types after img_as_float) the bounds follow from the weights alone -- |P| <= (sum w0)^2, |Q| <= 2 sum|w2| sum w0,
 // folding reflected taps only merges weights -- and so does the error the rounding leaves in the LoG value:
 //   norm (sum|w2| BP / 65535 + sum w0 BQ / 32767) / 2,
-// i.e. 3.7e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7 and the product
-// term the 16-bit kernel leaves out (0.55e-5): 4.3e-5 in all.
+// i.e. 3.7e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7, the product
+// term the 16-bit kernel leaves out (0.55e-5) and the rounding of its X accumulators, which run with the voxel
+// pieces' exponent offsets still in them (values up to 8 instead of 1: four roundings of 2^-22 each, 0.3e-5):
+// 4.6e-5 in all.
 static void q16_bounds(const double* w0, const double* w2, int radius, double norm, double* bp, double* bq, double* err)
 {
     double s0 = w0[0], s2 = fabs(w2[0]);
@@ -156,7 +158,11 @@ static void q16_bounds(const double* w0, const double* w2, int radius, double no
     // ... plus what the 16-bit kernel drops in the X pass (low voxel byte x low weight piece: 255 / 65536 x 2^-11 per
     // unit of weight): P off by 1.9e-6 s0^2, Q by 1.9e-6 x 2 s2 s0
     const double drop = 255.0 / 65536.0 / 2048.0;
-    *err = norm * (s2 * (*bp / 65535.0 / 2.0 + drop * s0 * s0) + s0 * (*bq / 32767.0 / 2.0 + drop * 2.0 * s2 * s0)) + 1e-6;
+    // ... and the float32 rounding of X accumulators that carry the pieces' offsets (<= 8: ulp 2^-21, half of it per
+    // MFMA, four MFMAs into each; relative to the bounds, the fragments carry 1 / bound)
+    const double biased = 4.0 * 0x1p-22;
+    *err = norm * (s2 * (*bp / 65535.0 / 2.0 + drop * s0 * s0 + biased * *bp) +
+                   s0 * (*bq / 32767.0 / 2.0 + drop * 2.0 * s2 * s0 + biased * *bq)) + 1e-6;
 }
 
 double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm)
@@ -264,11 +270,13 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         // (the condition under which every true maximum is still nominated)
         double q_bp = 0, q_bq = 0, q_err = 0;
         q16_bounds(h_w0, h_w2, radius, norm, &q_bp, &q_bq, &q_err);
-        const bool q16 = zx_mode == MMX_ZX_TILED_Q16 ||
-                         (zx_mode == MMX_ZX_AUTO && d_nms_mask && h_mask_written && (double)nms_eps >= 4.0 * q_err);
-        bool tiled = (zx_mode == MMX_ZX_TILED || zx_mode == MMX_ZX_TILED_Q16 || zx_mode == MMX_ZX_AUTO) &&
-                     (vol->dtype == MMX_U8 || vol->dtype == MMX_U16) &&
-                     mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, &plan) == MMX_OK;
+        // (float voxels: the tiled path when asked for by name -- its float16 pieces cover |v| < 65504 and lose
+        //  precision below ~2^-10, the caller knows the range -- with float32 tiles: the 16-bit bounds assume [0, 1])
+        const bool integer = vol->dtype == MMX_U8 || vol->dtype == MMX_U16;
+        const bool q16 = integer && (zx_mode == MMX_ZX_TILED_Q16 ||
+                         (zx_mode == MMX_ZX_AUTO && d_nms_mask && h_mask_written && (double)nms_eps >= 4.0 * q_err));
+        bool tiled = (zx_mode == MMX_ZX_TILED || ((zx_mode == MMX_ZX_TILED_Q16 || zx_mode == MMX_ZX_AUTO) && integer)) &&
+                     mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, vol->dtype, &plan) == MMX_OK;
         if (tiled && !prepacked) {
             mmx_timed_scope ts(MMX_K_ZXPACK, s);
             rc = mmx_launch_zx6_pack(vol, d_blocks, h_blocks, n_blocks, plan, d_work, s);
@@ -380,14 +388,14 @@ int mmx_zx_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_bloc
 {
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !d_work || n_blocks < 1 || slot_elems < 1) return MMX_ERR_ARG;
     if (n_blocks > MMX_MAX_BLOCKS) return MMX_ERR_UNSUPPORTED;
-    if (vol->dtype != MMX_U8 && vol->dtype != MMX_U16) return MMX_ERR_UNSUPPORTED;
+    if (vol->dtype != MMX_U8 && vol->dtype != MMX_U16 && vol->dtype != MMX_F32) return MMX_ERR_UNSUPPORTED;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
         if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.slot != i) return MMX_ERR_ARG;
         if (b.px < b.nx || b.px % MMX_ROW_ALIGN) return MMX_ERR_ARG;
     }
     mmx_zx6_plan plan;
-    int rc = mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, &plan);
+    int rc = mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, vol->dtype, &plan);
     if (rc != MMX_OK) return rc;
     mmx_timed_scope ts(MMX_K_ZXPACK, (hipStream_t)stream);
     rc = mmx_launch_zx6_pack(vol, d_blocks, h_blocks, n_blocks, plan, d_work, (hipStream_t)stream);

@@ -60,7 +60,7 @@ struct mmx_zx6_plan {
     int max_tiles;          // max ntx ntz
     int max_rowtiles;       // max ny ntz
 };
-int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elems, mmx_zx6_plan* plan);
+int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elems, int voxel_dtype, mmx_zx6_plan* plan);
 int mmx_launch_zx6_pack(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
                         const mmx_zx6_plan& plan, void* d_work, hipStream_t stream);
 int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,

@@ -237,6 +237,18 @@ template <> struct pieces4<uint16_t> {
             lo[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2_4, tl) - sixty4th);
         }
     }
+    // The same pieces with their exponent offsets left in: hi = 4 + b / 256, lo = 2^-6 + b / 65536.  A constant added
+    // to every element of an A operand adds (constant x column sum of B) to every row of the product: the kernel
+    // starts its accumulators at minus that, computed once per wave -- half the split's instructions.
+    static constexpr float kBiasHi = 4.0f, kBiasLo = 0.015625f;
+    static __device__ __forceinline__ void split_biased(const raw_t& d, u4_4& hi, u4_4& lo)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hi[i] = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07030501u);
+            lo[i] = __builtin_amdgcn_perm(0x24002400u, d[i], 0x07020500u);
+        }
+    }
 };
 // 8 consecutive uint8 voxels (2 dwords) -> one exact piece: b / 256
 template <> struct pieces4<uint8_t> {
@@ -258,7 +270,39 @@ template <> struct pieces4<uint8_t> {
         }
         lo = hi;
     }
+    static constexpr float kBiasHi = 4.0f, kBiasLo = 0.0f;
+    static __device__ __forceinline__ void split_biased(const raw_t& d, u4_4& hi, u4_4& lo)
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            hi[2 * i] = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07010500u);
+            hi[2 * i + 1] = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07030502u);
+        }
+        lo = hi;
+    }
 };
+
+// float voxels (TILED only): zx6_pack_f32_kernel has split them already -- per unit of 8 columns x 16 planes the high
+// float16 pieces (256 bytes) then the low ones, v = hi + lo / 2048 -- two 16-byte loads per k-step, no unpacking
+struct presplit_t { u4_4 h, l; };
+template <> struct pieces4<float> {
+    static constexpr int NP = 2;
+    using raw_t = presplit_t;
+    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off, unsigned soff = 0)
+    {
+        raw_t v;
+        v.h = __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, ZX4_LD_AUX));
+        v.l = __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(r, off + 256u, soff, ZX4_LD_AUX));
+        return v;
+    }
+    static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo) { hi = d.h; lo = d.l; }
+    static constexpr float kBiasHi = 0.f, kBiasLo = 0.f;
+    static __device__ __forceinline__ void split_biased(const raw_t& d, u4_4& hi, u4_4& lo) { hi = d.h; lo = d.l; }
+};
+template <typename InT> struct is_f32_4 { static constexpr bool value = false; };
+template <> struct is_f32_4<float> { static constexpr bool value = true; };
+template <typename InT> struct lo_scaled4 { static constexpr bool value = false; };     // low piece carries x 2048?
+template <> struct lo_scaled4<float> { static constexpr bool value = true; };
 
 __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4& c)
 {
@@ -276,7 +320,7 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
 // of Q / bound(Q) in the high half (the bounds follow from the weights alone: mmx_tiled_q16_error_bound) -- half
 // the bytes for the Y pass to read and for this kernel to write, at a known error that the caller's band must cover.
 template <int NKX, int LA, typename InT, bool TILED = false, bool Q16 = false>
-__global__ void __launch_bounds__(256, TILED && (LA == 1 || Q16) ? 3 : 2)      // (float32 tiles, LA == 2: 232 registers)
+__global__ void __launch_bounds__(256, (TILED && (LA == 1 || Q16) && !is_f32_4<InT>::value) ? 3 : 2)   // (float32 tiles, LA == 2: 232 registers)
 zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
            float* __restrict__ gp, float* __restrict__ gq,
@@ -285,6 +329,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     using cg = cls4<NKX, LA>;
     using pc = pieces4<InT>;
     constexpr int NKZ = cg::NKZ, NT = cg::NT;
+    constexpr int kUnit = std::is_same<InT, float>::value ? 512 : 256;      // bytes of a unit of the voxel copy
+    constexpr bool LO_SCALED = lo_scaled4<InT>::value;
+    static_assert(TILED || !std::is_same<InT, float>::value, "float voxels: tiled form only");
     // TILED, radius <= 16: the Z fragments of the interior z tiles live in LDS, shared by the workgroup's waves, and
     // two z tiles are in flight instead of three: 154 registers, three waves per SIMD.  (Radius > 16 has three
     // k-steps of Z fragments: with float32 tiles, which are bound by their stores, fetching them from LDS every step
@@ -334,6 +381,28 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 xw[m][k][1] = xt[(m * 2 + k) * 128 + 64];
             }
     }
+    // 16-bit tiles: the voxel pieces keep their exponent offsets (pieces4::split_biased) and the X accumulators start
+    // at minus what the offsets add -- (offset x column sum of the fragments), the same for the four rows a lane holds.
+    // The sums come from the matrix cores themselves: an A operand of ones.  Their float32 rounding (values of ~5
+    // instead of <= 1: 5e-7) is inside what mmx_tiled_q16_error_bound states.
+    constexpr bool BIASED = TILED && Q16;
+    f4_4 a_start = {0.f, 0.f, 0.f, 0.f}, b_start = a_start;
+    if constexpr (BIASED) {
+        const u4_4 ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+        f4_4 sh[2] = {a_start, a_start}, sl[2] = {a_start, a_start};
+#pragma unroll
+        for (int m = 0; m < NKX; ++m)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                sh[k] = mfma16(ones, xw[m][k][0], sh[k]);
+                sl[k] = mfma16(ones, xw[m][k][1], sl[k]);
+            }
+        // a0 takes (hi + lo pieces) x high fragments, a1 hi pieces x low fragments (scaled by 2048), v = a0 + a1 / 2048
+        const float ca = -((pc::kBiasHi + (pc::NP == 2 ? pc::kBiasLo : 0.f)) * sh[0][0] + pc::kBiasHi * sl[0][0] * kLoInv);
+        const float cb = -((pc::kBiasHi + (pc::NP == 2 ? pc::kBiasLo : 0.f)) * sh[1][0] + pc::kBiasHi * sl[1][0] * kLoInv);
+        a_start = (f4_4){ca, ca, ca, ca};
+        b_start = (f4_4){cb, cb, cb, cb};
+    }
     // Z fragments: [ks][kernel][piece], of the z tile being produced (reloaded when its class changes);
     // interior z tiles share one set: the first tile whose taps all fall inside the block
     u4_4 zw[ZLDS ? 1 : NKZ][2][2];
@@ -352,7 +421,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         if constexpr (TILED) {
             int j = 2 * c - cg::R8 / 8 + 4 * m + kq;             // unit of this lane; outside the row: any unit, zero weights
             j = j < 0 ? 0 : (j > nch8 - 1 ? nch8 - 1 : j);
-            xoff[m] = (unsigned)(j * 256 + li * 16);
+            xoff[m] = (unsigned)(j * kUnit + li * 16);
         } else {
             int xl = cg::xstart(c) + 32 * m + 8 * kq;
             xl = xl < 0 ? 0 : xl;
@@ -371,7 +440,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         t = 0;
 #endif
         if constexpr (TILED) {
-            const unsigned so = (unsigned)((y * ntz + t) * nch8) * 256u;      // wave-uniform: the row tile
+            const unsigned so = (unsigned)((y * ntz + t) * nch8) * (unsigned)kUnit;      // wave-uniform: the row tile
 #pragma unroll
             for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rin, xoff[m], so);
             return;
@@ -441,7 +510,10 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             // ---- X pass of z tile t
             u4_4 dh[NKX], dl[NKX];
 #pragma unroll
-            for (int m = 0; m < NKX; ++m) pc::split(rw[m], dh[m], dl[m]);
+            for (int m = 0; m < NKX; ++m) {
+                if constexpr (BIASED) pc::split_biased(rw[m], dh[m], dl[m]);
+                else pc::split(rw[m], dh[m], dl[m]);
+            }
             // (past the last tile the ring re-reads it: loads without a branch, never used)
             // the scheduler must not sink these loads to the end of the unrolled ring (it does, given the chance:
             // all of a ring's loads then sit right in front of their first use)
@@ -449,14 +521,18 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             if (STEADY) load_tile(t + PF < ntz ? t + PF : ntz - 1, rw);
             else if (t + PF < ntz) load_tile(t + PF, rw);
             __builtin_amdgcn_sched_barrier(0);
-            f4_4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+            f4_4 a0 = a_start, a1 = {0.f, 0.f, 0.f, 0.f}, b0 = b_start, b1 = a1;
 #pragma unroll
             for (int m = 0; m < NKX; ++m) {
                 a0 = mfma16(dh[m], xw[m][0][0], a0);
                 b0 = mfma16(dh[m], xw[m][1][0], b0);
                 a1 = mfma16(dh[m], xw[m][0][1], a1);
                 b1 = mfma16(dh[m], xw[m][1][1], b1);
-                if constexpr (pc::NP == 2) {
+                if constexpr (LO_SCALED) {
+                    // (float voxels: the low piece carries x 2048 like the low fragments; low x low is 2^-22 of a product)
+                    a1 = mfma16(dl[m], xw[m][0][0], a1);
+                    b1 = mfma16(dl[m], xw[m][1][0], b1);
+                } else if constexpr (pc::NP == 2) {
                     a0 = mfma16(dl[m], xw[m][0][0], a0);
                     b0 = mfma16(dl[m], xw[m][1][0], b0);
                     // (low voxel byte x low weight piece: <= 2^-19 of a product.  The float32 tiles keep it; the 16-bit
@@ -474,6 +550,24 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 const float bv0 = __builtin_fmaf(b1[r], kLoInv, b0[r]), bv1 = __builtin_fmaf(b1[r + 1], kLoInv, b0[r + 1]);
                 const f2_4 av = {av0, av1}, bv = {bv0, bv1};
                 const h2_4 ah = __builtin_convertvector(av, h2_4), bh = __builtin_convertvector(bv, h2_4);
+                if constexpr (Q16) {
+                    // 16-bit tiles: the low piece is the plain residual v - half(v), not scaled by 2048 -- values are
+                    // <= 1 here (the fragments carry 1 / bound), so the residual is below 2^-12 and float16 keeps it to
+                    // 2^-24 absolute, a 250th of the 16-bit quantum; v_fma_mix{lo,hi}_f16 makes it in ONE instruction per
+                    // value (f32 - f16 -> f16, written into one half of the register) instead of convert, subtract,
+                    // scale, convert.  The Z pass below adds it at full weight.
+                    const unsigned ahp = __builtin_bit_cast(unsigned, ah), bhp = __builtin_bit_cast(unsigned, bh);
+                    unsigned alp, blp;
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(alp) : "v"(av0), "v"(ahp));
+                    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(alp) : "v"(av1), "v"(ahp));
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(blp) : "v"(bv0), "v"(bhp));
+                    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(blp) : "v"(bv1), "v"(bhp));
+                    win[0][2 * LA][r >> 1] = ahp;
+                    win[1][2 * LA][r >> 1] = alp;
+                    win[2][2 * LA][r >> 1] = bhp;
+                    win[3][2 * LA][r >> 1] = blp;
+                    continue;
+                }
                 const f2_4 ar = {__builtin_fmaf((float)ah.x, -kLoScale, av0 * kLoScale), __builtin_fmaf((float)ah.y, -kLoScale, av1 * kLoScale)};
                 const f2_4 br = {__builtin_fmaf((float)bh.x, -kLoScale, bv0 * kLoScale), __builtin_fmaf((float)bh.y, -kLoScale, bv1 * kLoScale)};
                 win[0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
@@ -522,11 +616,17 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 q0 = mfma16(bh, z00, q0);
                 p1 = mfma16(ah, z01, p1);
                 q1 = mfma16(bh, z01, q1);
-                p1 = mfma16(al, z00, p1);
-                q1 = mfma16(bl, z00, q1);
+                if constexpr (Q16) {          // (unscaled low pieces: into the full-weight accumulators)
+                    p0 = mfma16(al, z00, p0);
+                    q0 = mfma16(bl, z00, q0);
+                } else {
+                    p1 = mfma16(al, z00, p1);
+                    q1 = mfma16(bl, z00, q1);
+                }
                 q0 = mfma16(ah, z10, q0);
                 q1 = mfma16(ah, z11, q1);
-                q1 = mfma16(al, z10, q1);
+                if constexpr (Q16) q0 = mfma16(al, z10, q0);
+                else q1 = mfma16(al, z10, q1);
                 if constexpr (ZLDS && !STEADY) __builtin_amdgcn_sched_barrier(0);    // one k-step's fragments at a time
             }
 #ifdef ZX4_NO_STORE
@@ -1032,6 +1132,49 @@ zx6_pack_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     }
 }
 
+// The same copy for float32 voxels, split into float16 pieces on the way (v = hi + lo / 2048: 22 significant bits, what
+// the fragments carry too): per unit the 16 planes' high pieces (256 bytes), then their low pieces.  Valid for
+// |v| < 65504 and loses nothing worth having above ~2^-10: the caller vouches for the range (MMX_ZX_FLOAT_RANGE_OK).
+__global__ void __launch_bounds__(256)
+zx6_pack_f32_kernel(const float* __restrict__ vol, int64_t stride_z, int64_t stride_y, int64_t stride_x,
+                    const mmx_block* __restrict__ blocks, uint16_t* __restrict__ pack, int64_t pack_stride)
+{
+    constexpr int PITCH = 512 + 4;                       // dwords (hi | lo << 16) per LDS row
+    __shared__ __attribute__((aligned(16))) unsigned tile[16][PITCH];
+    const mmx_block bd = blocks[blockIdx.y];
+    const int ntz = (bd.nz + 15) >> 4, nch8 = (bd.nx + 7) >> 3;
+    const int yt = blockIdx.x;
+    if (yt >= bd.ny * ntz) return;
+    const int y = yt / ntz, t = yt - y * ntz;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* src = vol + bd.src_off + (int64_t)y * stride_y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * wave + i, z = 16 * t + r;
+        for (int x = lane; x < 8 * nch8; x += 64) {
+            float v = 0.f;
+            if (z < bd.nz && x < bd.nx) v = src[(int64_t)z * stride_z + (int64_t)x * stride_x];
+            const _Float16 h = (_Float16)v;
+            const _Float16 l = (_Float16)((v - (float)h) * kLoScale);
+            tile[r][x] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+        }
+    }
+    __syncthreads();
+    u4_4* dst = reinterpret_cast<u4_4*>(pack + (int64_t)bd.slot * pack_stride) + (int64_t)yt * nch8 * 32;
+    for (int u = threadIdx.x; u < nch8 * 16; u += 256) {
+        const int j = u >> 4, r = u & 15;
+        const u4_4 a = *reinterpret_cast<const u4_4*>(&tile[r][8 * j]);
+        const u4_4 b = *reinterpret_cast<const u4_4*>(&tile[r][8 * j + 4]);
+        // dwords (hi | lo << 16) of 8 columns -> 4 dwords of packed high pieces, 4 of packed low pieces
+        const u4_4 hi = {__builtin_amdgcn_perm(a[1], a[0], 0x05040100u), __builtin_amdgcn_perm(a[3], a[2], 0x05040100u),
+                         __builtin_amdgcn_perm(b[1], b[0], 0x05040100u), __builtin_amdgcn_perm(b[3], b[2], 0x05040100u)};
+        const u4_4 lo = {__builtin_amdgcn_perm(a[1], a[0], 0x07060302u), __builtin_amdgcn_perm(a[3], a[2], 0x07060302u),
+                         __builtin_amdgcn_perm(b[1], b[0], 0x07060302u), __builtin_amdgcn_perm(b[3], b[2], 0x07060302u)};
+        dst[j * 32 + r] = hi;
+        dst[j * 32 + 16 + r] = lo;
+    }
+}
+
 template <int NKX, int LA>
 int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
                const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, float qp, float qq, hipStream_t s)
@@ -1041,7 +1184,8 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) { cfg.w0[k] = tx.w0[k]; cfg.w2[k] = tx.w2[k]; }
     cfg.radius = radius;
     // the pieces carry v / 2^16 of the widened voxel: skimage's img_as_float scale on top
-    cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(65536.0 / (255.0 * 256.0));
+    cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) :
+                 (vol->dtype == MMX_U8 ? (float)(65536.0 / (255.0 * 256.0)) : 1.f);      // (float voxels: as they are)
     cfg.ncw = cfg.ncz = 0;
     cfg.staged = 2;
     cfg.qp = qp; cfg.qq = qq;
@@ -1072,7 +1216,13 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     u4_4* ztab = reinterpret_cast<u4_4*>(w + plan.tab_off + xbytes);
     hipLaunchKernelGGL((zx4_setup<NKX, LA>), dim3((nx_entries + nz_entries + 3) / 4), dim3(256), 0, s, cfg, xtab, ztab);
     dim3 grid((((max_waves + 3) / 4) + 7) & ~7, n_blocks);        // (a multiple of 8: the XCD-aware order in the kernel)
-    if (qp > 0.f)
+    if (vol->dtype == MMX_F32) {
+        if (qp > 0.f) return MMX_ERR_UNSUPPORTED;                 // (16-bit tiles need voxels in [0, 1])
+        hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true, false>), grid, dim3(256), 0, s,
+                           reinterpret_cast<const float*>(w + plan.pack_off), plan.pack_stride / 2, (int64_t)0, d_blocks,
+                           plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
+                           xtab, ztab, cfg);
+    } else if (qp > 0.f)
         hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, true>), grid, dim3(256), 0, s,
                            reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
                            plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
@@ -1087,8 +1237,9 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
 
 }  // namespace
 
-int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elems, mmx_zx6_plan* plan)
+int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elems, int voxel_dtype, mmx_zx6_plan* plan)
 {
+    const int pieces = voxel_dtype == MMX_F32 ? 2 : 1;        // float voxels: two float16 pieces per voxel in the copy
     int64_t tile = 0, pk = 0;
     int max_tiles = 0, max_rowtiles = 0, maxcol = 0, maxu = 0;
     int wcls[MMX_ZX4_MAXCLS], zcls[MMX_ZX4_MAXCLS], ncw = 0, ncz = 0;
@@ -1101,7 +1252,7 @@ int mmx_zx6_plan_make(const mmx_block* h_blocks, int n_blocks, int64_t slot_elem
         for (j = 0; j < ncz && zcls[j] != b.nz; ++j) {}
         if (j == ncz) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; zcls[ncz++] = b.nz; }
         const int ntx = (b.nx + 15) / 16, ntz = (b.nz + 15) / 16, nch8 = (b.nx + 7) / 8;
-        const int64_t te = (int64_t)ntx * ntz * b.ny * 256, pe = (int64_t)b.ny * ntz * nch8 * 128;
+        const int64_t te = (int64_t)ntx * ntz * b.ny * 256, pe = (int64_t)b.ny * ntz * nch8 * 128 * pieces;
         if (te > tile) tile = te;
         if (pe > pk) pk = pe;
         if (ntx * ntz > max_tiles) max_tiles = ntx * ntz;
@@ -1127,10 +1278,13 @@ int mmx_launch_zx6_pack(const mmx_volume* vol, const mmx_block* d_blocks, const 
                         const mmx_zx6_plan& plan, void* d_work, hipStream_t stream)
 {
     (void)h_blocks;
-    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8) return MMX_ERR_UNSUPPORTED;
+    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8 && vol->dtype != MMX_F32) return MMX_ERR_UNSUPPORTED;
     uint16_t* pack = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_work) + plan.pack_off);
     dim3 grid(plan.max_rowtiles, n_blocks);
-    if (vol->dtype == MMX_U16)
+    if (vol->dtype == MMX_F32)
+        hipLaunchKernelGGL(zx6_pack_f32_kernel, grid, dim3(256), 0, stream, (const float*)vol->d_data,
+                           vol->stride_z, vol->stride_y, vol->stride_x, d_blocks, pack, plan.pack_stride);
+    else if (vol->dtype == MMX_U16)
         hipLaunchKernelGGL((zx6_pack_kernel<uint16_t>), grid, dim3(256), 0, stream, (const uint16_t*)vol->d_data,
                            vol->stride_z, vol->stride_y, vol->stride_x, d_blocks, pack, plan.pack_stride);
     else
@@ -1144,7 +1298,7 @@ int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_b
                    const mmx_zx6_plan& plan, const mmx_taps_f32& tx, int radius, void* d_work, float qp, float qq,
                    hipStream_t stream)
 {
-    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8) return MMX_ERR_UNSUPPORTED;
+    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8 && vol->dtype != MMX_F32) return MMX_ERR_UNSUPPORTED;
     if (radius < 1 || radius > MMX_MAX_RADIUS_FAST) return MMX_ERR_UNSUPPORTED;
     if (radius <= 8) return launch_zx6<1, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, qp, qq, stream);
     if (radius <= 16) return launch_zx6<2, 1>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, qp, qq, stream);

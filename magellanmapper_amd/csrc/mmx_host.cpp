@@ -334,6 +334,57 @@ extern "C" int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, doubl
 //   out_rows / out_keys / out_n : the own survivors in final order and their keys; abs_zyx holds their averaged
 //                  coordinates afterwards (and garbage-free but possibly unfinished values for halo rows)
 //   n_slab / n_after / n_next : [3][max_slabs] statistics over OWN rows (row pitch `stat_ld`)
+namespace {
+int prune_region_impl(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
+                      const int64_t* cur, int64_t n_cur, int64_t own_lo, int64_t own_hi,
+                      const int32_t n_sections[3], const double* const bounds[3],
+                      const double last_end[3], const int32_t tol[3],
+                      const double* const nxt_lo[3], const double* const nxt_hi[3],
+                      int64_t* out_rows, int64_t* out_keys, int64_t* out_n,
+                      int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld)
+{
+    for (int a = 0; a < 3; ++a)
+        if (n_sections[a] > 1 && (stat_ld < n_sections[a] - 1 || !bounds[a] || !nxt_lo[a] || !nxt_hi[a])) return MMX_ERR_ARG;
+    int64_t max_row = -1;
+    for (int64_t i = 0; i < n_cur; ++i) { if (cur[i] < 0) return MMX_ERR_ARG; max_row = std::max(max_row, cur[i]); }
+    std::vector<int64_t> key(out_keys ? (size_t)(max_row + 1) : 0, 0);
+    std::vector<int64_t> a_rows(cur, cur + n_cur), b_rows((size_t)n_cur);
+    std::vector<int32_t> group(out_keys ? (size_t)n_cur : 0);
+    int64_t n = n_cur, stride = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (n_sections[a] <= 1) continue;
+        int64_t n_out = 0;
+        const int st = prune_axis_impl(zyx, tag, abs_zyx, a_rows.data(), n, a, n_sections[a], bounds[a], last_end[a], tol,
+                                       nxt_lo[a], nxt_hi[a], b_rows.data(), &n_out, n_slab + a * stat_ld,
+                                       n_after + a * stat_ld, n_next + a * stat_ld, own_lo, own_hi,
+                                       out_keys ? group.data() : nullptr);
+        if (st != MMX_OK) return st;
+        if (out_keys) {
+            const int64_t* rows = a_rows.data();
+            parallel(host_threads(n), [&](int t, int nt) {
+                for (int64_t i = n * t / nt; i < n * (t + 1) / nt; ++i)       // (a row appears once in `rows`)
+                    if (group[(size_t)i] >= 0) key[(size_t)rows[i]] += stride * group[(size_t)i];
+            });
+        }
+        stride *= (int64_t)n_sections[a] + 2 * ((int64_t)n_sections[a] - 1);
+        a_rows.swap(b_rows);
+        n = n_out;
+    }
+    int64_t k = 0;
+    if (own_lo == INT64_MIN && own_hi == INT64_MAX && !out_keys) {       // the whole table: every survivor, no keys
+        std::memcpy(out_rows, a_rows.data(), (size_t)n * sizeof(int64_t));
+        k = n;
+    } else {
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t row = a_rows[(size_t)i];
+            if (row >= own_lo && row < own_hi) { out_rows[k] = row; if (out_keys) out_keys[k] = key[(size_t)row]; ++k; }
+        }
+    }
+    *out_n = k;
+    return MMX_OK;
+}
+}  // namespace
+
 extern "C" int mmx_host_prune_region(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
                                      const int64_t* cur, int64_t n_cur, int64_t own_lo, int64_t own_hi,
                                      const int32_t n_sections[3], const double* const bounds[3],
@@ -342,36 +393,84 @@ extern "C" int mmx_host_prune_region(const int32_t* zyx, const int32_t* tag, dou
                                      int64_t* out_rows, int64_t* out_keys, int64_t* out_n,
                                      int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld)
 {
-    if ((n_cur && (!zyx || !tag || !abs_zyx || !cur || !out_rows || !out_keys)) || n_cur < 0 || !n_sections || !bounds ||
+    if ((n_cur && (!zyx || !tag || !abs_zyx || !cur || !out_rows)) || n_cur < 0 || !n_sections || !bounds ||
         !last_end || !tol || !nxt_lo || !nxt_hi || !out_n || !n_slab || !n_after || !n_next)
         return MMX_ERR_ARG;
-    for (int a = 0; a < 3; ++a)
-        if (n_sections[a] > 1 && (stat_ld < n_sections[a] - 1 || !bounds[a] || !nxt_lo[a] || !nxt_hi[a])) return MMX_ERR_ARG;
-    int64_t max_row = -1;
-    for (int64_t i = 0; i < n_cur; ++i) { if (cur[i] < 0) return MMX_ERR_ARG; max_row = std::max(max_row, cur[i]); }
-    std::vector<int64_t> key((size_t)(max_row + 1), 0);
-    std::vector<int64_t> a_rows(cur, cur + n_cur), b_rows((size_t)n_cur);
-    std::vector<int32_t> group((size_t)n_cur);
-    int64_t n = n_cur, stride = 1;
-    for (int a = 0; a < 3; ++a) {
-        if (n_sections[a] <= 1) continue;
-        int64_t n_out = 0;
-        const int st = prune_axis_impl(zyx, tag, abs_zyx, a_rows.data(), n, a, n_sections[a], bounds[a], last_end[a], tol,
-                                       nxt_lo[a], nxt_hi[a], b_rows.data(), &n_out, n_slab + a * stat_ld,
-                                       n_after + a * stat_ld, n_next + a * stat_ld, own_lo, own_hi, group.data());
-        if (st != MMX_OK) return st;
-        for (int64_t i = 0; i < n; ++i)
-            if (group[(size_t)i] >= 0) key[(size_t)a_rows[(size_t)i]] += stride * group[(size_t)i];
-        stride *= (int64_t)n_sections[a] + 2 * ((int64_t)n_sections[a] - 1);
-        a_rows.swap(b_rows);
-        n = n_out;
+    return prune_region_impl(zyx, tag, abs_zyx, cur, n_cur, own_lo, own_hi, n_sections, bounds, last_end, tol, nxt_lo,
+                             nxt_hi, out_rows, out_keys, out_n, n_slab, n_after, n_next, stat_ld);
+}
+
+// The same for a region whose rows are still in the merged table: `parts` are row ranges of that table in ascending
+// order, part `own_part` the region itself, the others its neighbours, of which only the rows inside the box
+// [box_lo, box_hi) (the region's extent plus the reach of the pruning) take part.  The local table is assembled
+// here (the merged table and its abs column are not written to), every channel of `channels` is pruned in turn
+// (`chan`: the channel column of the merged table, row pitch chan_ld doubles; NULL: every row belongs to
+// channels[0]) and the region's survivors come back as rows of the merged table with their keys (channel position
+// x n_keys + key) and their averaged coordinates.  Statistics: [n_channels][3][stat_ld].
+extern "C" int mmx_host_prune_parts(const int32_t* zyx, const int32_t* tag, const double* abs_zyx,
+                                    const double* chan, int64_t chan_ld,
+                                    const int64_t* parts, int n_parts, int own_part,
+                                    const int32_t box_lo[3], const int32_t box_hi[3],
+                                    const double* channels, int n_channels,
+                                    const int32_t n_sections[3], const double* const bounds[3],
+                                    const double last_end[3], const int32_t tol[3],
+                                    const double* const nxt_lo[3], const double* const nxt_hi[3], int64_t n_keys,
+                                    int64_t* out_ids, int64_t* out_keys, double* out_abs, int64_t* out_n,
+                                    int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld)
+{
+    if (!parts || n_parts < 1 || own_part < 0 || own_part >= n_parts || !box_lo || !box_hi || !channels || n_channels < 1 ||
+        !n_sections || !bounds || !last_end || !tol || !nxt_lo || !nxt_hi || !out_n || !n_slab || !n_after || !n_next)
+        return MMX_ERR_ARG;
+    // ---- the local table: ids of the merged table's rows, own rows between the neighbours' rows within reach
+    std::vector<int64_t> ids;
+    int64_t own_lo = 0, own_hi = 0, prev_end = -1;
+    for (int p = 0; p < n_parts; ++p) {
+        const int64_t a = parts[2 * p], b = parts[2 * p + 1];
+        if (a < 0 || b < a || a < prev_end) return MMX_ERR_ARG;
+        prev_end = b;
+        if (b > a && (!zyx || !tag || !abs_zyx)) return MMX_ERR_ARG;
+        if (p == own_part) {
+            own_lo = (int64_t)ids.size();
+            for (int64_t r = a; r < b; ++r) ids.push_back(r);
+            own_hi = (int64_t)ids.size();
+        } else {
+            for (int64_t r = a; r < b; ++r) {
+                const int32_t* c = zyx + 3 * r;
+                if (c[0] >= box_lo[0] && c[0] < box_hi[0] && c[1] >= box_lo[1] && c[1] < box_hi[1] &&
+                    c[2] >= box_lo[2] && c[2] < box_hi[2])
+                    ids.push_back(r);
+            }
+        }
     }
-    int64_t k = 0;
+    const int64_t n = (int64_t)ids.size();
+    if (own_hi > own_lo && (!out_ids || !out_keys || !out_abs)) return MMX_ERR_ARG;
+    std::vector<int32_t> lz((size_t)n * 3), lt((size_t)n * 3);
+    std::vector<double> la((size_t)n * 3);
     for (int64_t i = 0; i < n; ++i) {
-        const int64_t row = a_rows[(size_t)i];
-        if (row >= own_lo && row < own_hi) { out_rows[k] = row; out_keys[k] = key[(size_t)row]; ++k; }
+        std::memcpy(lz.data() + 3 * i, zyx + 3 * ids[(size_t)i], 3 * sizeof(int32_t));
+        std::memcpy(lt.data() + 3 * i, tag + 3 * ids[(size_t)i], 3 * sizeof(int32_t));
+        std::memcpy(la.data() + 3 * i, abs_zyx + 3 * ids[(size_t)i], 3 * sizeof(double));
     }
-    *out_n = k;
+    std::vector<int64_t> cur, rows((size_t)n), keys((size_t)n);
+    int64_t k_out = 0;
+    for (int ci = 0; ci < n_channels; ++ci) {
+        cur.clear();
+        for (int64_t i = 0; i < n; ++i)
+            if (!chan || chan[ids[(size_t)i] * chan_ld] == channels[ci]) cur.push_back(i);
+        int64_t k = 0;
+        const int st = prune_region_impl(lz.data(), lt.data(), la.data(), cur.data(), (int64_t)cur.size(), own_lo, own_hi,
+                                         n_sections, bounds, last_end, tol, nxt_lo, nxt_hi, rows.data(), keys.data(), &k,
+                                         n_slab + (int64_t)ci * 3 * stat_ld, n_after + (int64_t)ci * 3 * stat_ld,
+                                         n_next + (int64_t)ci * 3 * stat_ld, stat_ld);
+        if (st != MMX_OK) return st;
+        for (int64_t i = 0; i < k; ++i) {
+            out_ids[k_out] = ids[(size_t)rows[(size_t)i]];
+            out_keys[k_out] = keys[(size_t)i] + (int64_t)ci * n_keys;
+            std::memcpy(out_abs + 3 * k_out, la.data() + 3 * rows[(size_t)i], 3 * sizeof(double));
+            ++k_out;
+        }
+    }
+    *out_n = k_out;
     return MMX_OK;
 }
 

@@ -243,13 +243,21 @@ class _RegionPruner:
             ext = np.array([[s.indices(n)[:2] for s, n in zip(sub_roi_slices[coords[share[k]]], shape3)] for k in ks])
             lo, hi = ext[:, :, 0].min(axis=0), ext[:, :, 1].max(axis=0)
             self.regions.append(dict(k_lo=ks[0], k_hi=ks[-1] + 1, lo=lo - reach, hi=hi + reach, box=(lo, hi)))
+        # neighbours: regions whose extent reaches into this one's box (all pairs at once)
+        box_lo = np.array([r["box"][0] for r in self.regions])
+        box_hi = np.array([r["box"][1] for r in self.regions])
+        lo = np.array([r["lo"] for r in self.regions])
+        hi = np.array([r["hi"] for r in self.regions])
+        touch = np.all(box_lo[None, :, :] < hi[:, None, :], axis=2) & np.all(box_hi[None, :, :] > lo[:, None, :], axis=2)
+        np.fill_diagonal(touch, False)
+        k_hi = np.array([r["k_hi"] for r in self.regions])
         for i, r in enumerate(self.regions):
-            near = [j for j, q in enumerate(self.regions) if j != i and
-                    np.all(q["box"][0] < r["hi"]) and np.all(q["box"][1] > r["lo"])]
-            r["near"] = near
-            r["ready_at"] = max([r["k_hi"]] + [self.regions[j]["k_hi"] for j in near])
+            near = np.flatnonzero(touch[i])
+            r["near"] = [int(j) for j in near]
+            r["ready_at"] = int(max(r["k_hi"], k_hi[near].max(initial=0)))
         self.done = [None] * len(self.regions)
         self.next = 0
+        self._channels = np.ascontiguousarray(self.channels, dtype=np.float64)
 
     def matches(self, arena, plan, channels) -> bool:
         same = arena is self.arena and list(channels) == self.channels and plan["n_keys"] == self.plan["n_keys"]
@@ -269,26 +277,34 @@ class _RegionPruner:
             self.next += 1
 
     def _run(self, i: int) -> None:
+        """One region: its rows and its neighbours' rows within reach, straight from the arena
+        (``mmx_host_prune_parts``: the local table is put together natively)."""
         ar, r = self.arena, self.regions[i]
         ends = ar.row_end
-        own = np.arange(ends[r["k_lo"]], ends[r["k_hi"]], dtype=np.int64)
-        before, after = [], []
-        for j in r["near"]:
-            q = self.regions[j]
-            a, b = ends[q["k_lo"]], ends[q["k_hi"]]
-            ids = a + _rows_within(ar.zyx[a:b], r["lo"], r["hi"])
-            (before if j < i else after).append(ids)
-        ids = np.concatenate(before + [own] + after) if (before or after) else own
-        n_before = sum(len(x) for x in before)
-        zyx = np.ascontiguousarray(ar.zyx[ids])
-        tags = np.ascontiguousarray(ar.tag[ids])
-        abs_l = np.ascontiguousarray(ar.abs[ids])
-        chan = None
-        if not (len(self.channels) == 1 and ar.chan_lo == ar.chan_hi == self.channels[0]):
-            chan = ar.store[ids, 6]
-        rows, keys, counts = StackPruner._prune_table(zyx, tags, abs_l, chan, n_before, n_before + len(own),
-                                                      self.channels, self.plan)
-        self.done[i] = (ids[rows], keys, abs_l[rows], counts)
+        members = sorted(r["near"] + [i])
+        parts = np.array([[ends[self.regions[j]["k_lo"]], ends[self.regions[j]["k_hi"]]] for j in members],
+                         dtype=np.int64)
+        n_own = int(ends[r["k_hi"]] - ends[r["k_lo"]])
+        ids = np.empty(max(1, n_own), dtype=np.int64)
+        keys = np.empty(max(1, n_own), dtype=np.int64)
+        abs_rows = np.empty((max(1, n_own), 3))
+        out_n = ctypes.c_int64(0)
+        ld = self.plan["max_slabs"]
+        stat = np.zeros((3, len(self.channels), 3, ld), dtype=np.int64)        # [kind][channel][axis][slab]
+        one_channel = len(self.channels) == 1 and (ar.chan_lo == ar.chan_hi == self.channels[0] or ar.n == 0)
+        n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi = self.plan["c_args"]
+        lo = np.ascontiguousarray(r["lo"], dtype=np.int32)
+        hi = np.ascontiguousarray(r["hi"], dtype=np.int32)
+        nat.check(nat.lib().mmx_host_prune_parts(
+            ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data,
+            None if one_channel else ar.store.ctypes.data + 6 * 8, ar.store.strides[0] // 8,
+            parts.ctypes.data, len(parts), members.index(i),
+            lo.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), hi.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            self._channels.ctypes.data, len(self.channels), n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi,
+            self.plan["n_keys"], ids.ctypes.data, keys.ctypes.data, abs_rows.ctypes.data, ctypes.byref(out_n),
+            stat[0].ctypes.data, stat[1].ctypes.data, stat[2].ctypes.data, ld), "mmx_host_prune_parts")
+        k = out_n.value
+        self.done[i] = (ids[:k], keys[:k], abs_rows[:k], np.moveaxis(stat, 0, -1))
 
     def finish(self, abs_inds):
         """Whatever is left, then the merge: ``(final table, counts)``."""
@@ -856,7 +872,17 @@ class StackPruner:
         for ax in axes:
             if ax is not None:
                 n_keys *= 3 * ax["n_sections"] - 2
-        return dict(axes=axes, tol=tol3, n_keys=int(n_keys), max_slabs=max([1] + [ax["n_sections"] - 1 for ax in axes if ax]))
+        plan = dict(axes=axes, tol=tol3, n_keys=int(n_keys),
+                    max_slabs=max([1] + [ax["n_sections"] - 1 for ax in axes if ax]))
+
+        def ptrs(name):
+            return (ctypes.c_void_p * 3)(*[None if ax is None else ax[name].ctypes.data for ax in axes])
+
+        # the same constants as the native calls take them (the arrays above stay alive in `axes`)
+        plan["c_args"] = ((ctypes.c_int32 * 3)(*[0 if ax is None else ax["n_sections"] for ax in axes]), ptrs("bounds"),
+                          (ctypes.c_double * 3)(*[0.0 if ax is None else ax["last_end"] for ax in axes]),
+                          tol3.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ptrs("nxt_lo"), ptrs("nxt_hi"))
+        return plan
 
     @classmethod
     def _prune_table(cls, zyx, tags, abs_cur, chan, own_lo, own_hi, channels, plan):
@@ -865,17 +891,10 @@ class StackPruner:
         channel's position in ``channels`` is the most significant part), and the statistics
         ``counts[channel][axis][slab] = (rows in the slab, rows left, rows in the adjacent region)`` over own rows.
         ``abs_cur`` is updated in place.  ``chan``: channel of every row, ``None`` when all belong to ``channels[0]``."""
-        axes = plan["axes"]
         lib = nat.lib()
-        n_sec = (ctypes.c_int32 * 3)(*[0 if ax is None else ax["n_sections"] for ax in axes])
-        last_end = (ctypes.c_double * 3)(*[0.0 if ax is None else ax["last_end"] for ax in axes])
-
-        def ptrs(name):
-            return (ctypes.c_void_p * 3)(*[None if ax is None else ax[name].ctypes.data for ax in axes])
-
-        bounds, nxt_lo, nxt_hi = ptrs("bounds"), ptrs("nxt_lo"), ptrs("nxt_hi")
-        tol3 = plan["tol"].ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+        n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi = plan["c_args"]
         ld = plan["max_slabs"]
+        whole = own_lo == 0 and own_hi == len(zyx)       # one region: the output order is final, no keys needed
         counts = np.zeros((len(channels), 3, ld, 3), dtype=np.int64)
         rows_all, keys_all = [], []
         for ci, chl in enumerate(channels):
@@ -884,20 +903,23 @@ class StackPruner:
             else:
                 cur = np.ascontiguousarray(np.nonzero(np.isin(chan, chl))[0], dtype=np.int64)  # row ids, table order
             out_rows = np.empty(len(cur), dtype=np.int64)
-            out_keys = np.empty(len(cur), dtype=np.int64)
+            out_keys = None if whole else np.empty(len(cur), dtype=np.int64)
             out_n = ctypes.c_int64(0)
             stat = np.zeros((3, 3, ld), dtype=np.int64)       # [kind][axis][slab]
             nat.check(lib.mmx_host_prune_region(
-                zyx.ctypes.data, tags.ctypes.data, abs_cur.ctypes.data, cur.ctypes.data, len(cur), int(own_lo),
-                int(own_hi), n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi, out_rows.ctypes.data,
-                out_keys.ctypes.data, ctypes.byref(out_n), stat[0].ctypes.data, stat[1].ctypes.data,
-                stat[2].ctypes.data, ld), "mmx_host_prune_region")
+                zyx.ctypes.data, tags.ctypes.data, abs_cur.ctypes.data, cur.ctypes.data, len(cur),
+                -(1 << 63) if whole else int(own_lo), (1 << 63) - 1 if whole else int(own_hi), n_sec, bounds, last_end,
+                tol3, nxt_lo, nxt_hi, out_rows.ctypes.data, None if whole else out_keys.ctypes.data,
+                ctypes.byref(out_n), stat[0].ctypes.data, stat[1].ctypes.data, stat[2].ctypes.data, ld),
+                "mmx_host_prune_region")
             counts[ci] = np.moveaxis(stat, 0, -1)
             rows_all.append(out_rows[:out_n.value])
-            keys_all.append(out_keys[:out_n.value] + ci * plan["n_keys"])
+            if not whole:
+                keys_all.append(out_keys[:out_n.value] + ci * plan["n_keys"])
         rows = rows_all[0] if len(rows_all) == 1 else np.concatenate(rows_all)
-        keys = keys_all[0] if len(keys_all) == 1 else np.concatenate(keys_all)
-        return np.ascontiguousarray(rows, dtype=np.int64), np.ascontiguousarray(keys, dtype=np.int64), counts
+        keys = None if whole else (keys_all[0] if len(keys_all) == 1 else np.concatenate(keys_all))
+        return (np.ascontiguousarray(rows, dtype=np.int64),
+                None if keys is None else np.ascontiguousarray(keys, dtype=np.int64), counts)
 
     @staticmethod
     def _ratios_from_counts(counts, plan):

@@ -26,7 +26,7 @@ RES = np.array([[1.0, 1.0, 1.0]])
 def gpu():
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
     return torch.device("cuda", 0)
 
 
@@ -94,11 +94,12 @@ def test_two_blocks_of_the_benchmark_geometry(gpu):
     np.testing.assert_array_equal(got, want)
 
 
-def _run_bench(tmp_path, ranks, *extra, timeout=900):
+def _run_bench(tmp_path, ranks, *extra, timeout=900, launcher=True):
+    """``launcher=False``: plain ``python bench.py --gpus N`` -- the script starts its ranks itself."""
     env = dict(os.environ, MMX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0",
            "--no-cpu-baseline", *extra]
-    if ranks > 1:
+    if ranks > 1 and launcher:
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -137,7 +138,7 @@ def test_c5_shaped_two_channel_coloc_over_ranks(gpu, tmp_path, ranks):
     vol = _host_volume(shape, 3, channels=2)
     np.save(tmp_path / "c5.npy", vol)
     line = _run_bench(tmp_path, ranks, "--config", "c5", "--segment-size", "64", "--volume", str(tmp_path / "c5.npy"),
-                      "--dump", str(tmp_path / "c5.npz"))
+                      "--dump", str(tmp_path / "c5.npz"), launcher=ranks != 3)     # (3 ranks: bench.py launches them itself)
     assert line["n_gpus"] == ranks and len(line["ranks"]) == ranks
     assert sum(r["blocks"] for r in line["ranks"]) == 9                 # 1 x 3 x 3 blocks, uneven over 2 ranks
     profile = _bench_profile(denoise_size=25, segment_size=64)

@@ -20,7 +20,7 @@ if "--real" in sys.argv:          # tables (and their arena) from a real detecti
     import torch
     from magellanmapper_amd import blob_log as _bl, synth as _synth
     import bench as _bench
-    config.setup_roi_profiles(None); config.roi_profile.update(_bench.PROFILE)
+    config.setup_roi_profiles(None); config.roi_profile.update(_bench._BASE_PROFILE)
     bl = stack_detect.setup_blocks(config.roi_profile, shape)
     _dv = _bl.DeviceVolume(_synth.make_volume_device(shape, 3, torch.device("cuda", 0)))
     seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, _dv, bl.sub_roi_slices, bl.sub_rois_offsets, None, None, False, [0])

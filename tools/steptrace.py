@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--budget-gb", type=float, default=16.0)
 ap.add_argument("--keep-heap", action="store_true", help="mallopt: big arrays from the heap, freed memory stays mapped")
 ap.add_argument("--profile", action="store_true", help="cProfile one more step: where the host time goes")
+ap.add_argument("--no-plan", action="store_true", help="no StackDetector.plan_pruning: the whole table is pruned after the detection")
 a = ap.parse_args()
 if a.keep_heap:
     from magellanmapper_amd import _native
@@ -51,11 +52,15 @@ wrap(bl, "_enqueue_detect", "enqueue batch")
 wrap(bl, "_finish_detect", "finish batch (candidates -> peaks)")
 wrap(bl, "_prune_batch", "per-block overlap prune")
 wrap(bl, "_prune_batch_native", "per-block overlap prune (native)")
-wrap(stack_detect._ArenaSink, "__call__", "tables -> arena (native)")
+wrap(stack_detect._ArenaSink, "__call__", "tables -> arena (native) + regions that became ready")
+wrap(stack_detect._RegionPruner, "__init__", "region pruner set-up")
+wrap(stack_detect._RegionPruner, "finish", "remaining regions + merge")
 orig_prune = stack_detect.StackPruner.prune_blobs_mp.__func__
 
 
 def step():
+    if not a.no_plan:
+        stack_detect.StackDetector.plan_pruning(blocks.overlap, blocks.tol, blocks.overlap_padding, [0])
     seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, dvol, blocks.sub_roi_slices, blocks.sub_rois_offsets,
                                                            None, None, False, [0])
     t = time.perf_counter()
