@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 11
+#define MMX_ABI_VERSION 12
 
 typedef enum {
     MMX_OK = 0,
@@ -75,7 +75,10 @@ typedef struct {
 typedef struct {
     const void* d_data;
     int32_t dtype;     /* mmx_dtype */
-    int32_t _pad;
+    float value_range; /* float voxels only, what the caller knows about them (integer voxels: ignored, their range is
+                          the type's): > 0: every voxel lies in [0, value_range]; < 0: |voxel| <= -value_range;
+                          0: unknown.  A known range lets MMX_ZX_AUTO take the tiled matrix-core path for float
+                          voxels (their float16 pieces need |v| < 65504), a non-negative one also its 16-bit tiles. */
     int64_t stride_z, stride_y, stride_x; /* in elements */
 } mmx_volume;
 
@@ -133,9 +136,9 @@ int mmx_device_count(void);
  *   zx_mode    : how the Z and X passes run (a per-call argument: the library keeps no mode).
  *                MMX_ZX_AUTO (default): the fastest kernel that takes the geometry (MMX_ZX_TILED for integer
  *                voxels, else MMX_ZX_PACKED, else the separate passes); the others exist for cross-checks and
- *                measurements.  Float voxels take MMX_ZX_TILED when it is asked for BY NAME: its copy holds
- *                every voxel as two float16 pieces (22 significant bits, like the weights), which covers
- *                |v| < 65504 and thins out below ~2^-10 -- the caller knows the value range, the library does not.  All agree within float32 rounding, and the peak decisions are taken on exact
+ *                measurements.  Float voxels take the tiled path when the volume states its value range
+ *                (mmx_volume.value_range) or when MMX_ZX_TILED is asked for by name: its copy holds every voxel as
+ *                two float16 pieces (22 significant bits, like the weights), which covers |v| < 65504.  All agree within float32 rounding, and the peak decisions are taken on exact
  *                float64 values either way (mmx_rescore_f64).  With entries requested and nms_eps at least four times
  *                mmx_tiled_q16_error_bound(), AUTO hands the intermediates over as 16-bit fixed point
  *                (MMX_ZX_TILED_Q16).  MMX_ZX_TILED works from an operand-ordered copy of
@@ -167,7 +170,7 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
                       int* h_mask_written, int zx_mode, int* h_zx_path, void* stream);
 
 /* Largest deviation of an MMX_ZX_TILED_Q16 LoG value from the float32 paths' (which are within a few 1e-7 of the
- * exact value), in units of the image's value scale, for voxels in [0, 1] (uint8 / uint16 after img_as_float): a
+ * exact value), for voxels in [0, 1] (uint8 / uint16 after img_as_float; float voxels in [0, m]: times m): a
  * function of the weights alone (4.6e-5 for any sigma >= 1).  A true maximum is nominated as long as the NMS band is four
  * times this (mmx_rescore_f64 then decides on exact values as always).  < 0 on bad arguments. */
 double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 11
+MMX_ABI_VERSION = 12
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -59,7 +59,7 @@ assert RESIZE_DTYPE.itemsize == 48
 
 class Volume(Structure):
     """``mmx_volume``."""
-    _fields_ = [("d_data", c_void_p), ("dtype", c_int32), ("_pad", c_int32),
+    _fields_ = [("d_data", c_void_p), ("dtype", c_int32), ("value_range", c_float),
                 ("stride_z", c_int64), ("stride_y", c_int64), ("stride_x", c_int64)]
 
 

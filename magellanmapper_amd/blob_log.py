@@ -72,8 +72,9 @@ LAST_ZX_PATH = None
 #: ``mmx_host_overlap_prune``: threaded, outside the GIL, no second device round trip) or "numpy" (the same rules as
 #: array expressions; kept as a cross-check -- tests run both -- and for ``exact_values=False``)
 HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
-#: value scales (largest |voxel|) for which float voxels take the tiled matrix-core path (float16 pieces: exponent range)
-FLOAT_TILED_RANGE = (2.0 ** -6, 2.0 ** 12)
+#: value scales (largest |voxel|, at least 1) up to which float voxels take the tiled matrix-core path: its float16
+#: pieces overflow at 65504 (faint images are no problem: the nomination band never shrinks below EPS_REL x 1)
+FLOAT_TILED_RANGE = (0.0, 2.0 ** 12)
 #: candidate-table entries copied to pinned host memory together with the counts, before the host knows how many
 #: there are (a batch of the benchmark volume holds ~3e4; more entries cost a second, synchronous copy)
 _PREFIX_ENTRIES = 1 << 16
@@ -131,6 +132,7 @@ class DeviceVolume:
         self.n_channels = self.shape[3] if self.tensor.ndim == 4 else 1
         self._f32 = None
         self._scale = None
+        self._ranges = {}
 
     @property
     def multichannel(self) -> bool:
@@ -145,6 +147,20 @@ class DeviceVolume:
             else:
                 self._scale = 1.0
         return self._scale
+
+    def value_range(self, channel: int = 0) -> Tuple[float, float]:
+        """``(min, max)`` of one channel's voxels after ``img_as_float`` (``(0, 1)`` for integer images)."""
+        if self.np_dtype.kind != "f":
+            return 0.0, 1.0
+        key = int(channel) if self.multichannel else 0
+        if key not in self._ranges:
+            t = self.tensor[..., key] if self.multichannel else self.tensor
+            if t.numel() == 0:
+                self._ranges[key] = (0.0, 1.0)
+            else:
+                lo, hi = torch.aminmax(t)
+                self._ranges[key] = (float(lo.item()), float(hi.item()))
+        return self._ranges[key]
 
     def _strides(self, t) -> Tuple[int, int, int]:
         st = t.stride()
@@ -510,9 +526,14 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     bufs = _buffers_for(dvol.tensor.device)
     vscale = float(dvol.value_scale() if pre is None else pre.value_scale([channel]))
     eps = EPS_REL * vscale
-    if (pre is None and dvol.np_dtype in (np.uint8, np.uint16) and EPS_REL_Q16 > EPS_REL
+    # what is known about the voxels the passes will read: raw integer images [0, 1]; float images their measured
+    # range; preprocessed / unmixed / rescaled blocks the bounds their arithmetic implies
+    vrange = dvol.value_range(channel) if pre is None else pre.value_range([channel])
+    # volumes whose voxels are known to be non-negative and of ordinary magnitude take 16-bit intermediates: the
+    # band must cover their rounding error fourfold
+    if (vrange is not None and vrange[0] >= 0.0 and vrange[1] <= FLOAT_TILED_RANGE[1] and EPS_REL_Q16 > EPS_REL
             and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)):
-        eps = EPS_REL_Q16 * dvol.value_scale()
+        eps = EPS_REL_Q16 * vscale
     d_w0 = torch.from_numpy(space.w0_tab).to(dvol.tensor.device)
     d_w2 = torch.from_numpy(space.w2_tab).to(dvol.tensor.device)
     batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
@@ -544,7 +565,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             jobs[enq] = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
                                         space, float(threshold), eps, bufs, enq % (ahead + 1), d_w0, d_w2, pre=pre,
                                         exact=exact, prepared=None if prepared is None else prepared[enq],
-                                        vscale=vscale)
+                                        vscale=vscale, vrange=vrange)
             jobs[enq]["batch"] = batch
             enq += 1
         pending, jobs[k] = jobs[k], None
@@ -571,7 +592,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
 # --------------------------------------------------------------------------- A0-A4
 def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
                     bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None,
-                    exact: bool = False, prepared=None, vscale: Optional[float] = None):
+                    exact: bool = False, prepared=None, vscale: Optional[float] = None, vrange=None):
     """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU.
     ``exact``: also re-score every candidate in float64 (otherwise ``_resolve_peaks`` re-scores the few
     whose decision depends on it)."""
@@ -614,12 +635,17 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
         tiled_mode = nat.MMX_ZX_TILED
         is_float = vol32.dtype == nat.MMX_F32
         # float voxels (float images, preprocessed blocks): the tiled path holds each as two float16 pieces, which
-        # suits values of ordinary magnitude -- the range is known here, not in the library (include/mmx.h: zx_mode)
-        float_ok = is_float and vscale is not None and FLOAT_TILED_RANGE[0] <= vscale <= FLOAT_TILED_RANGE[1]
-        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16) and not is_float:
+        # suits values of ordinary magnitude -- the range is known here, not in the library (mmx_volume.value_range)
+        float_ok = is_float and vrange is not None and max(abs(vrange[0]), abs(vrange[1])) <= FLOAT_TILED_RANGE[1]
+        nonneg = not is_float or (float_ok and vrange[0] >= 0.0)
+        if is_float:
+            vol32.value_range = 0.0 if not float_ok else (max(vrange[1], 1e-30) if vrange[0] >= 0.0
+                                                          else -max(abs(vrange[0]), abs(vrange[1])))
+        if mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16) and nonneg:
             # 16-bit intermediates when the band covers their rounding error fourfold (or when asked for by name)
             bound = max(float(L.mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
                                                           int(space.radii[s]), float(space.norms[s]))) for s in range(ns))
+            bound *= 1.0 if not is_float else float(vol32.value_range)
             if mode == nat.MMX_ZX_TILED_Q16 or (0 <= 4.0 * bound <= eps):
                 tiled_mode = nat.MMX_ZX_TILED_Q16
         if (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16) and not is_float) or \
@@ -682,7 +708,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     done.record()
     return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
                 nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
-                vol_exact=vol_exact, pre=pre, exact=exact, eps=eps, native=native, vscale=vscale)
+                vol_exact=vol_exact, pre=pre, exact=exact, eps=eps, native=native, vscale=vscale, vrange=vrange)
 
 
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
@@ -709,7 +735,7 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
             torch.cuda.current_stream().synchronize()
             redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr,
                                    eps, bufs, which, d_w0, d_w2, cap=count + 1024, pre=job.get("pre"),
-                                   exact=job.get("exact", False), vscale=job.get("vscale"))
+                                   exact=job.get("exact", False), vscale=job.get("vscale"), vrange=job.get("vrange"))
             redo["batch"] = job.get("batch")
             return _finish_detect(redo, dvol, space, thr, eps, bufs, d_w0, d_w2, stats)
     with torch.cuda.stream(bufs.side):
@@ -744,7 +770,7 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
     stats.n_band_retries += 1
     torch.cuda.current_stream().synchronize()
     redo = _enqueue_detect(dvol, job["channel"], job["origins"], job["shapes"], space, thr, wider, bufs, which,
-                           d_w0, d_w2, cap=None, pre=job.get("pre"), exact=True, vscale=job.get("vscale"))
+                           d_w0, d_w2, cap=None, pre=job.get("pre"), exact=True, vscale=job.get("vscale"), vrange=job.get("vrange"))
     redo["batch"] = job.get("batch")
     redo["retries"] = job.get("retries", 0) + 1
     return _finish_detect(redo, dvol, space, thr, wider, bufs, d_w0, d_w2, stats)

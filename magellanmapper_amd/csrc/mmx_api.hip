@@ -270,12 +270,16 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         // (the condition under which every true maximum is still nominated)
         double q_bp = 0, q_bq = 0, q_err = 0;
         q16_bounds(h_w0, h_w2, radius, norm, &q_bp, &q_bq, &q_err);
-        // (float voxels: the tiled path when asked for by name -- its float16 pieces cover |v| < 65504 and lose
-        //  precision below ~2^-10, the caller knows the range -- with float32 tiles: the 16-bit bounds assume [0, 1])
+        // float voxels: the tiled path when the volume states its value range (or when asked for by name: the float16
+        // pieces of its copy cover |v| < 65504), 16-bit tiles when that range is [0, m]: their bounds scale with m
         const bool integer = vol->dtype == MMX_U8 || vol->dtype == MMX_U16;
-        const bool q16 = integer && (zx_mode == MMX_ZX_TILED_Q16 ||
+        const bool ranged = vol->dtype == MMX_F32 && vol->value_range != 0.f && fabsf(vol->value_range) < 60000.f;
+        const bool nonneg = integer || (ranged && vol->value_range > 0.f);
+        if (!integer && nonneg) { q_bp *= vol->value_range; q_bq *= vol->value_range; q_err *= vol->value_range; }
+        const bool q16 = nonneg && (zx_mode == MMX_ZX_TILED_Q16 ||
                          (zx_mode == MMX_ZX_AUTO && d_nms_mask && h_mask_written && (double)nms_eps >= 4.0 * q_err));
-        bool tiled = (zx_mode == MMX_ZX_TILED || ((zx_mode == MMX_ZX_TILED_Q16 || zx_mode == MMX_ZX_AUTO) && integer)) &&
+        bool tiled = (zx_mode == MMX_ZX_TILED || (zx_mode == MMX_ZX_TILED_Q16 && nonneg) ||
+                      (zx_mode == MMX_ZX_AUTO && (integer || ranged))) &&
                      mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, vol->dtype, &plan) == MMX_OK;
         if (tiled && !prepacked) {
             mmx_timed_scope ts(MMX_K_ZXPACK, s);

@@ -385,7 +385,17 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // at minus what the offsets add -- (offset x column sum of the fragments), the same for the four rows a lane holds.
     // The sums come from the matrix cores themselves: an A operand of ones.  Their float32 rounding (values of ~5
     // instead of <= 1: 5e-7) is inside what mmx_tiled_q16_error_bound states.
-    constexpr bool BIASED = TILED && Q16;
+#ifdef ZX4_NO_BIAS
+    constexpr bool BIASED = false;
+#else
+    // (radius > 16: the eight start registers would push the kernel past three waves per SIMD)
+    constexpr bool BIASED = TILED && Q16 && !is_f32_4<InT>::value && LA == 1;
+#endif
+#ifdef ZX4_NO_MIX
+    constexpr bool MIXSPLIT = false;
+#else
+    constexpr bool MIXSPLIT = Q16;
+#endif
     f4_4 a_start = {0.f, 0.f, 0.f, 0.f}, b_start = a_start;
     if constexpr (BIASED) {
         const u4_4 ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
@@ -522,6 +532,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             else if (t + PF < ntz) load_tile(t + PF, rw);
             __builtin_amdgcn_sched_barrier(0);
             f4_4 a0 = a_start, a1 = {0.f, 0.f, 0.f, 0.f}, b0 = b_start, b1 = a1;
+#ifdef ZX4_PRIO
+            __builtin_amdgcn_s_setprio(ZX4_PRIO);
+#endif
 #pragma unroll
             for (int m = 0; m < NKX; ++m) {
                 a0 = mfma16(dh[m], xw[m][0][0], a0);
@@ -543,6 +556,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                     }
                 }
             }
+#ifdef ZX4_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             // combine the two accumulators and split into float16 pieces: v = acc0 + acc1 / 2048
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
@@ -550,22 +566,18 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 const float bv0 = __builtin_fmaf(b1[r], kLoInv, b0[r]), bv1 = __builtin_fmaf(b1[r + 1], kLoInv, b0[r + 1]);
                 const f2_4 av = {av0, av1}, bv = {bv0, bv1};
                 const h2_4 ah = __builtin_convertvector(av, h2_4), bh = __builtin_convertvector(bv, h2_4);
-                if constexpr (Q16) {
+                if constexpr (MIXSPLIT) {
                     // 16-bit tiles: the low piece is the plain residual v - half(v), not scaled by 2048 -- values are
                     // <= 1 here (the fragments carry 1 / bound), so the residual is below 2^-12 and float16 keeps it to
-                    // 2^-24 absolute, a 250th of the 16-bit quantum; v_fma_mix{lo,hi}_f16 makes it in ONE instruction per
-                    // value (f32 - f16 -> f16, written into one half of the register) instead of convert, subtract,
-                    // scale, convert.  The Z pass below adds it at full weight.
-                    const unsigned ahp = __builtin_bit_cast(unsigned, ah), bhp = __builtin_bit_cast(unsigned, bh);
-                    unsigned alp, blp;
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(alp) : "v"(av0), "v"(ahp));
-                    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(alp) : "v"(av1), "v"(ahp));
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(blp) : "v"(bv0), "v"(bhp));
-                    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(blp) : "v"(bv1), "v"(bhp));
-                    win[0][2 * LA][r >> 1] = ahp;
-                    win[1][2 * LA][r >> 1] = alp;
-                    win[2][2 * LA][r >> 1] = bhp;
-                    win[3][2 * LA][r >> 1] = blp;
+                    // 2^-24 absolute, a 250th of the 16-bit quantum; the Z pass below adds it at full weight.
+                    // (v_fma_mix{lo,hi}_f16 would make it in one instruction per value, but only as inline assembly,
+                    //  whose register writes the compiler's hazard recogniser does not see: one landed right behind an
+                    //  MFMA that still read the register as its C operand -- wrong results for radius <= 8.)
+                    const f2_4 ar = {av0 - (float)ah.x, av1 - (float)ah.y}, br = {bv0 - (float)bh.x, bv1 - (float)bh.y};
+                    win[0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
+                    win[1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
+                    win[2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
+                    win[3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
                     continue;
                 }
                 const f2_4 ar = {__builtin_fmaf((float)ah.x, -kLoScale, av0 * kLoScale), __builtin_fmaf((float)ah.y, -kLoScale, av1 * kLoScale)};
@@ -596,6 +608,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 }
             }
             f4_4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, q0 = p0, q1 = p0;
+#ifdef ZX4_PRIO
+            __builtin_amdgcn_s_setprio(ZX4_PRIO);
+#endif
 #pragma unroll
             for (int ks = 0; ks < NKZ; ++ks) {
                 const u4_4 ah = {win[0][2 * ks][0], win[0][2 * ks][1], win[0][2 * ks + 1][0], win[0][2 * ks + 1][1]};
@@ -616,7 +631,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 q0 = mfma16(bh, z00, q0);
                 p1 = mfma16(ah, z01, p1);
                 q1 = mfma16(bh, z01, q1);
-                if constexpr (Q16) {          // (unscaled low pieces: into the full-weight accumulators)
+                if constexpr (MIXSPLIT) {          // (unscaled low pieces: into the full-weight accumulators)
                     p0 = mfma16(al, z00, p0);
                     q0 = mfma16(bl, z00, q0);
                 } else {
@@ -625,15 +640,20 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 }
                 q0 = mfma16(ah, z10, q0);
                 q1 = mfma16(ah, z11, q1);
-                if constexpr (Q16) q0 = mfma16(al, z10, q0);
+                if constexpr (MIXSPLIT) q0 = mfma16(al, z10, q0);
                 else q1 = mfma16(al, z10, q1);
                 if constexpr (ZLDS && !STEADY) __builtin_amdgcn_sched_barrier(0);    // one k-step's fragments at a time
             }
+#ifdef ZX4_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef ZX4_NO_STORE
             asm volatile("" ::"v"(p0), "v"(p1), "v"(q0), "v"(q1));
             if (false) {
 #else
+#ifndef ZX4_FREE
             __builtin_amdgcn_sched_barrier(0);
+#endif
             asm volatile("" ::"v"(P), "v"(Q));       // the slot's previous results stayed in these registers until now
             if (STEADY || TILED || 16 * U + li < nz) {     // (a tile is stored whole: its padding belongs to it)
 #endif
@@ -684,7 +704,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #ifdef ZX4_LOCKSTEP
         __syncthreads();
 #endif
+#ifndef ZX4_FREE
         __builtin_amdgcn_sched_barrier(0);
+#endif
     };
     // tiles [0, tA): generic steps up to the first interior output tile (U = t - LA >= u_lo), rounded up to a
     // multiple of the ring; [tA, tB): steady steps (U in [u_lo, u_hi], t < ntz), whole rings; the rest generic.
@@ -1148,15 +1170,31 @@ zx6_pack_f32_kernel(const float* __restrict__ vol, int64_t stride_z, int64_t str
     const int y = yt / ntz, t = yt - y * ntz;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* src = vol + bd.src_off + (int64_t)y * stride_y;
+    auto pieces = [](float v) __attribute__((always_inline)) {
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)((v - (float)h) * kLoScale);
+        return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+    };
+    // rows that start on 16-byte boundaries (preprocessed slot buffers, most float images): 4 voxels per lane and load
+    const bool quads = stride_x == 1 && ((bd.src_off | stride_y | stride_z) & 3) == 0 && (reinterpret_cast<uintptr_t>(vol) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 4 * wave + i, z = 16 * t + r;
-        for (int x = lane; x < 8 * nch8; x += 64) {
-            float v = 0.f;
-            if (z < bd.nz && x < bd.nx) v = src[(int64_t)z * stride_z + (int64_t)x * stride_x];
-            const _Float16 h = (_Float16)v;
-            const _Float16 l = (_Float16)((v - (float)h) * kLoScale);
-            tile[r][x] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+        if (quads && z < bd.nz) {
+            const float* row = src + (int64_t)z * stride_z;
+            for (int x = lane * 4; x < 8 * nch8; x += 256) {
+                f4_4 v = {0.f, 0.f, 0.f, 0.f};
+                if (x + 3 < bd.nx) v = *reinterpret_cast<const f4_4*>(row + x);
+                else
+                    for (int j = 0; j < 4; ++j) v[j] = x + j < bd.nx ? row[x + j] : 0.f;
+                *reinterpret_cast<u4_4*>(&tile[r][x]) = (u4_4){pieces(v[0]), pieces(v[1]), pieces(v[2]), pieces(v[3])};
+            }
+        } else {
+            for (int x = lane; x < 8 * nch8; x += 64) {
+                float v = 0.f;
+                if (z < bd.nz && x < bd.nx) v = src[(int64_t)z * stride_z + (int64_t)x * stride_x];
+                tile[r][x] = pieces(v);
+            }
         }
     }
     __syncthreads();
@@ -1217,11 +1255,16 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     hipLaunchKernelGGL((zx4_setup<NKX, LA>), dim3((nx_entries + nz_entries + 3) / 4), dim3(256), 0, s, cfg, xtab, ztab);
     dim3 grid((((max_waves + 3) / 4) + 7) & ~7, n_blocks);        // (a multiple of 8: the XCD-aware order in the kernel)
     if (vol->dtype == MMX_F32) {
-        if (qp > 0.f) return MMX_ERR_UNSUPPORTED;                 // (16-bit tiles need voxels in [0, 1])
-        hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true, false>), grid, dim3(256), 0, s,
-                           reinterpret_cast<const float*>(w + plan.pack_off), plan.pack_stride / 2, (int64_t)0, d_blocks,
-                           plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
-                           xtab, ztab, cfg);
+        if (qp > 0.f)          // (16-bit tiles: the caller's bounds cover the voxels' range, mmx_volume.value_range)
+            hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true, true>), grid, dim3(256), 0, s,
+                               reinterpret_cast<const float*>(w + plan.pack_off), plan.pack_stride / 2, (int64_t)0, d_blocks,
+                               plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
+                               xtab, ztab, cfg);
+        else
+            hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true, false>), grid, dim3(256), 0, s,
+                               reinterpret_cast<const float*>(w + plan.pack_off), plan.pack_stride / 2, (int64_t)0, d_blocks,
+                               plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
+                               xtab, ztab, cfg);
     } else if (qp > 0.f)
         hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, true>), grid, dim3(256), 0, s,
                            reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,

@@ -141,6 +141,23 @@ class Preprocessor:
             m = max(m, 2 * c + abs(float(s["unsharp_strength"] or 0.0)) * c)
         return m
 
+    def value_range(self, channels: Sequence[int]):
+        """``(lo, hi)`` bounds on the preprocessed voxels: ``clip`` puts them into [clip_min, clip_max], the unsharp
+        mask ``den + (den - s * blur)`` (blur a convex mean of ``den``) into [2 clip_min - s clip_max, 2 clip_max -
+        s clip_min], the erosion takes minima.  ``None`` with total-variation denoising on (its iterate may leave the
+        clipped range by a rounding)."""
+        lo, hi = np.inf, -np.inf
+        for chl in channels:
+            s = config.get_roi_profile(chl)
+            if s["tot_var_denoise"]:
+                return None
+            c_lo, c_hi = float(s["clip_min"]), float(s["clip_max"])
+            k = float(s["unsharp_strength"] or 0.0)
+            if k:
+                c_lo, c_hi = 2 * c_lo - max(k * c_hi, k * c_lo), 2 * c_hi - min(k * c_lo, k * c_hi)
+            lo, hi = min(lo, c_lo), max(hi, c_hi)
+        return (float(lo), float(hi)) if lo <= hi else None
+
     def _grid(self, shape):
         shape = tuple(int(v) for v in shape)
         if shape not in self._tiles:
@@ -371,6 +388,12 @@ class Unmixer:
             return Preprocessor(self.dms).value_scale(involved)
         return self._raw_scale
 
+    def value_range(self, channels: Sequence[int]):
+        """The subtraction is clipped at 0: ``[0, largest voxel]`` whatever is subtracted (negative factors add)."""
+        if any(f < 0 for _, f in self.subtract):
+            return None
+        return 0.0, float(self.value_scale(channels))
+
     _buffer = Preprocessor._buffer
 
     def run(self, dvol, channel: int, origins, shapes, which: int = 0):
@@ -551,6 +574,12 @@ class Rescaler:
         if self.dms is not None:
             return Preprocessor(self.dms).value_scale(self.channels)
         return self._scale
+
+    def value_range(self, channels: Sequence[int]):
+        """Interpolation and the anti-aliasing Gaussian are convex combinations: the source's range."""
+        if self.dms is not None:
+            return Preprocessor(self.dms).value_range(self.channels)
+        return None
 
     _buffer = Preprocessor._buffer
 

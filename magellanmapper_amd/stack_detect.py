@@ -256,7 +256,8 @@ class _RegionPruner:
             r["near"] = [int(j) for j in near]
             r["ready_at"] = int(max(r["k_hi"], k_hi[near].max(initial=0)))
         self.done = [None] * len(self.regions)
-        self.next = 0
+        self.pending = list(range(len(self.regions)))
+        self._pool = None
         self._channels = np.ascontiguousarray(self.channels, dtype=np.float64)
 
     def matches(self, arena, plan, channels) -> bool:
@@ -270,11 +271,23 @@ class _RegionPruner:
         return bool(same)
 
     def advance(self) -> None:
-        """Prune every region whose blocks and neighbours have all landed (``arena.row_end`` tells)."""
+        """Prune every region whose blocks and neighbours have all landed (``arena.row_end`` tells), in whatever
+        order they become ready; several at once on a few threads (the native call releases the GIL)."""
         landed = len(self.arena.row_end) - 1
-        while self.next < len(self.regions) and self.regions[self.next]["ready_at"] <= landed:
-            self._run(self.next)
-            self.next += 1
+        ready = [i for i in self.pending if self.regions[i]["ready_at"] <= landed]
+        if not ready:
+            return
+        self.pending = [i for i in self.pending if self.regions[i]["ready_at"] > landed]
+        if len(ready) == 1:
+            self._run(ready[0])
+        else:
+            list(self._workers().map(self._run, ready))
+
+    def _workers(self):
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=min(8, max(1, (os.cpu_count() or 2) // 2)))
+        return self._pool
 
     def _run(self, i: int) -> None:
         """One region: its rows and its neighbours' rows within reach, straight from the arena
@@ -308,9 +321,12 @@ class _RegionPruner:
 
     def finish(self, abs_inds):
         """Whatever is left, then the merge: ``(final table, counts)``."""
-        for i in range(self.next, len(self.regions)):
-            self._run(i)
-        self.next = len(self.regions)
+        if self.pending:            # (everything has landed by now)
+            todo, self.pending = self.pending, []
+            list(self._workers().map(self._run, todo)) if len(todo) > 1 else self._run(todo[0])
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)
+            self._pool = None
         ar = self.arena
         ids = np.ascontiguousarray(np.concatenate([d[0] for d in self.done]), dtype=np.int64)
         keys = np.ascontiguousarray(np.concatenate([d[1] for d in self.done]), dtype=np.int64)
@@ -445,7 +461,9 @@ class StackDetector:
             return cls._exclude_matrix(coords[mine[k]], last_coord, exclude_border)
 
         pruner = None
-        if regular and dist.world_size() == 1 and mine and os.environ.get("MMX_PRUNE_AHEAD", "1") != "0":
+        # (opt-in: measured on the benchmark volume it moves ~4 ms of pruning under the GPU's last batches but adds as
+        #  much in the merge -- 124.9 against 124.6 ms per volume -- and costs small stacks 0.6 ms: DESIGN.md)
+        if regular and dist.world_size() == 1 and mine and os.environ.get("MMX_PRUNE_AHEAD", "0") == "1":
             ov, tl, pad, prune_channels = hint
             pruner = _RegionPruner(arena, StackPruner._axis_plan(shape3, ov, tl, tl if pad is None else pad,
                                                                  sub_roi_slices, sub_rois_offsets),

@@ -832,7 +832,7 @@ def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
     bound = max(nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(k1.gaussian_half_kernel(s_, 0, k1.kernel_radius(s_))),
                                                     nat.as_double_ptr(k1.gaussian_half_kernel(s_, 2, k1.kernel_radius(s_))),
                                                     k1.kernel_radius(s_), s_ * s_) for s_ in sig)
-    assert 4e-5 < bound < 4.6e-5
+    assert 4e-5 < bound < 4.9e-5
     pos = {tuple(r): i for i, r in enumerate(k7)}
     idx = [pos.get(tuple(r), -1) for r in k2]
     assert min(idx) >= 0
@@ -841,8 +841,10 @@ def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
 
 
 def test_zx_pack_refuses_what_the_tiled_path_cannot_take(gpu):
-    """Float voxels have no exact float16 split: ``mmx_zx_pack`` says unsupported (nothing written) and the log call
-    falls back to the packed kernel and its row entries."""
+    """``mmx_zx_pack`` through the ABI: float64 voxels are refused (nothing written; callers hand the float32 copy),
+    float32 voxels are split into float16 pieces; the log call takes the tiled path for them when it is asked for by
+    name or when the volume states its value range (``mmx_volume.value_range``), and keeps the packed kernel when the
+    library knows nothing about the values."""
     import ctypes
     import torch
     from magellanmapper_amd import _native as nat, blob_log as bl, synth
@@ -852,16 +854,39 @@ def test_zx_pack_refuses_what_the_tiled_path_cannot_take(gpu):
     ws = torch.zeros(5 * slot, dtype=torch.float32, device=dvol.tensor.device)
     d_blocks = bl._to_device_bytes(blocks, dvol.tensor.device)
     v32 = dvol.view(0, True)
-    rc = nat.lib().mmx_zx_pack(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, 1, slot, ws.data_ptr(), None)
+    assert nat.lib().mmx_zx_pack(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, 1, slot, ws.data_ptr(), None) == 0
+    v64 = bl.DeviceVolume(vol.astype(np.float64)).view(0, False)
+    assert v64.dtype == nat.MMX_F64
+    rc = nat.lib().mmx_zx_pack(ctypes.byref(v64), d_blocks.data_ptr(), blocks.ctypes.data, 1, slot, ws.data_ptr(), None)
     assert rc == 5                                  # MMX_ERR_UNSUPPORTED
     assert nat.lib().mmx_zx_pack(None, None, None, 1, slot, None, None) == 1      # MMX_ERR_ARG
     space = bl.ScaleSpace.make(3.0, 3.0, 1)
-    default, bl.ZX_MODE = bl.ZX_MODE, nat.MMX_ZX_TILED
+    want = None
+    default = bl.ZX_MODE
     try:
-        bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [vol.shape], space)
-        assert bl.LAST_ZX_PATH == nat.MMX_ZX_PACKED
+        for mode, path in ((nat.MMX_ZX_PACKED, nat.MMX_ZX_PACKED), (nat.MMX_ZX_AUTO, nat.MMX_ZX_PACKED),
+                           (nat.MMX_ZX_TILED, nat.MMX_ZX_TILED)):
+            bl.ZX_MODE = mode
+            cube = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [vol.shape], space)[0]
+            assert bl.LAST_ZX_PATH == path, (mode, bl.LAST_ZX_PATH)
+            want = cube if want is None else want
+            assert np.abs(cube - want).max() < 2e-6
     finally:
         bl.ZX_MODE = default
+    # the range stated in the volume: AUTO takes the tiled path, with 16-bit tiles once the band covers their error
+    ws2 = torch.zeros(6 * slot + 64, dtype=torch.float32, device=dvol.tensor.device)
+    mask = torch.zeros(slot // 2 + 64, dtype=torch.uint8, device=dvol.tensor.device)
+    written, path = ctypes.c_int(0), ctypes.c_int(0)
+    for rng_, eps, expect in ((1.0, 2e-5, nat.MMX_ZX_TILED), (1.0, 2e-4, nat.MMX_ZX_TILED_Q16), (-1.0, 2e-4, nat.MMX_ZX_TILED),
+                              (0.0, 2e-4, nat.MMX_ZX_PACKED)):
+        v32.value_range = rng_
+        nat.check(nat.lib().mmx_log_batch_f32(
+            ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, 1, slot, nat.as_double_ptr(space.w0[0]),
+            nat.as_double_ptr(space.w2[0]), int(space.radii[0]), float(space.norms[0]), ws2.data_ptr() + 4 * slot * 4,
+            ws2.data_ptr(), mask.data_ptr(), 0.1 - eps, eps, ctypes.byref(written), nat.MMX_ZX_AUTO,
+            ctypes.byref(path), None), "mmx_log_batch_f32")
+        torch.cuda.synchronize()
+        assert path.value == expect, (rng_, eps, path.value)
 
 
 def test_tiled_path_geometry_limits_and_interleaved_channels(gpu):
@@ -928,8 +953,8 @@ def test_plateau_of_contested_candidates_in_one_batch(gpu, tmp_path, monkeypatch
 def test_float_voxels_take_the_tiled_path(gpu):
     """Float images of ordinary magnitude (and every preprocessed block) run the matrix-core Z+X kernel on a copy that
     holds each voxel as two float16 pieces: every kernel radius against the float64 oracle cube, blob_log identical
-    to the oracle with the path reported; a float image whose values do not suit float16 pieces keeps the packed
-    kernel."""
+    to the oracle with the path reported (also for a faint image: the nomination band is absolute, never below 2e-5);
+    a float image whose values exceed what float16 pieces hold keeps the packed kernel."""
     from magellanmapper_amd import _native as nat, blob_log as bl, synth
     from oracle import blob_log_oracle as blo
     rng = np.random.default_rng(41)
@@ -947,7 +972,7 @@ def test_float_voxels_take_the_tiled_path(gpu):
             assert np.abs(got - want).max() < LOG_TOL * 1e-2 * 1.3, R
     finally:
         bl.ZX_MODE = default
-    for scale, path in ((1.0, nat.MMX_ZX_TILED), (3.0e5, nat.MMX_ZX_PACKED), (1.0e-4, nat.MMX_ZX_PACKED)):
+    for scale, path in ((1.0, nat.MMX_ZX_TILED), (3.0e5, nat.MMX_ZX_PACKED), (1.0e-4, nat.MMX_ZX_TILED)):
         img = (vol * np.float32(scale)).astype(np.float32)
         want, st = blo.blob_log(img, 3, 5, 3, 0.1 * scale, 0.5, return_stages=True)
         stats = bl.BatchStats()

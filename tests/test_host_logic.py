@@ -982,7 +982,7 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case):
         seg = np.zeros(grid, dtype=object).view(sd._SegRois)
         for k in share:
             if pruner is not None and k == share[-1]:
-                before_last.append(pruner.next)
+                before_last.append(len(pruner.regions) - len(pruner.pending))
             tbl = tables[coords[k]]
             if tbl is not None:
                 arena.add(coords[k], tbl)
@@ -1003,7 +1003,7 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case):
     seg_b, pruner = build(True)
     got, df_got = sd.StackPruner.prune_blobs_mp(Img, seg_b, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                  blocks.sub_rois_offsets, channels, blocks.overlap_padding)
-    assert pruner.next == len(pruner.regions) and all(d is not None for d in pruner.done)      # (it was used)
+    assert not pruner.pending and all(d is not None for d in pruner.done)      # (it was used)
     if len(pruner.regions) > 4:
         assert 0 < before_last[0] < len(pruner.regions)      # some regions early, the last ones once everything landed
     assert len(want) < sum(len(t) for t in tables.values() if t is not None)                    # duplicates were removed
