@@ -75,6 +75,8 @@ HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
 #: value scales (largest |voxel|, at least 1) up to which float voxels take the tiled matrix-core path: its float16
 #: pieces overflow at 65504 (faint images are no problem: the nomination band never shrinks below EPS_REL x 1)
 FLOAT_TILED_RANGE = (0.0, 2.0 ** 12)
+#: per-block preprocessing on a stream of its own (beside the previous batch's LoG kernels)
+PRE_STREAM = os.environ.get("MMX_PRE_STREAM", "1") != "0"
 #: candidate-table entries copied to pinned host memory together with the counts, before the host knows how many
 #: there are (a batch of the benchmark volume holds ~3e4; more entries cost a second, synchronous copy)
 _PREFIX_ENTRIES = 1 << 16
@@ -238,9 +240,33 @@ class ScaleSpace:
     w2: List[np.ndarray]
     w0_tab: np.ndarray = field(default=None)
     w2_tab: np.ndarray = field(default=None)
+    _dev: Optional[dict] = field(default=None, repr=False)
 
     @classmethod
     def make(cls, min_sigma: float, max_sigma: float, num_sigma: int) -> "ScaleSpace":
+        """The filter parameters of ``blob_log(min_sigma, max_sigma, num_sigma)``: a pure function of the three
+        numbers, so the last few are kept (the PROFILE is re-read at every call; what its numbers imply is not)."""
+        if np.isscalar(min_sigma) and np.isscalar(max_sigma):
+            key = (float(min_sigma), float(max_sigma), int(num_sigma))
+            hit = _SPACES.get(key)
+            if hit is None:
+                if len(_SPACES) > 64:
+                    _SPACES.clear()
+                hit = _SPACES[key] = cls._make(min_sigma, max_sigma, num_sigma)
+            return hit
+        return cls._make(min_sigma, max_sigma, num_sigma)
+
+    def device_tables(self, dev):
+        """``(w0, w2)`` half-kernel tables on ``dev`` (for the exact re-score), uploaded once per device."""
+        key = str(dev)
+        if self._dev is None:
+            self._dev = {}
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.w0_tab).to(dev), torch.from_numpy(self.w2_tab).to(dev))
+        return self._dev[key]
+
+    @classmethod
+    def _make(cls, min_sigma: float, max_sigma: float, num_sigma: int) -> "ScaleSpace":
         if not (np.isscalar(min_sigma) and np.isscalar(max_sigma)):
             raise NotImplementedError("per-axis sigmas are not on the reference's path "
                                       "(detector.py:926-927 passes scalars)")
@@ -261,6 +287,9 @@ class ScaleSpace:
             tab0[i, :r + 1] = a
             tab2[i, :r + 1] = b
         return cls(sigmas, norms, radii, w0, w2, tab0, tab2)
+
+
+_SPACES: Dict[tuple, ScaleSpace] = {}
 
 
 @dataclass
@@ -390,6 +419,9 @@ class _Buffers:
         self.host_counts = []
         self.host_tabs = []
         self.side = torch.cuda.Stream(device=dev, priority=-1)
+        # per-block preprocessing (float64 vector arithmetic) of batch k + 1 runs here, beside the LoG kernels of
+        # batch k (bound by memory requests) on the caller's stream
+        self.pre_stream = torch.cuda.Stream(device=dev)
         self.slots(2)
 
     def slots(self, n: int):
@@ -534,8 +566,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     if (vrange is not None and vrange[0] >= 0.0 and vrange[1] <= FLOAT_TILED_RANGE[1] and EPS_REL_Q16 > EPS_REL
             and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)):
         eps = EPS_REL_Q16 * vscale
-    d_w0 = torch.from_numpy(space.w0_tab).to(dvol.tensor.device)
-    d_w2 = torch.from_numpy(space.w2_tab).to(dvol.tensor.device)
+    d_w0, d_w2 = space.device_tables(dvol.tensor.device)
     batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
                            0 if pre is None else pre.bytes_per_voxel())
     exact = bool(True if exact_values is None else exact_values)
@@ -558,6 +589,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             bufs.workspace(max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, len(space.sigmas), 1)) // 4)
                                for blk, slot, _ in prepared))
     jobs: List[Optional[dict]] = [None] * n_b
+    done_events: List = []
     enq = 0
     for k in range(n_b):
         while enq < min(n_b, k + 1 + ahead):           # batch k itself and `ahead` batches behind it
@@ -565,7 +597,10 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             jobs[enq] = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
                                         space, float(threshold), eps, bufs, enq % (ahead + 1), d_w0, d_w2, pre=pre,
                                         exact=exact, prepared=None if prepared is None else prepared[enq],
-                                        vscale=vscale, vrange=vrange)
+                                        vscale=vscale, vrange=vrange,
+                                        buffer_free=(None if enq < ahead + 1 else done_events[enq - (ahead + 1)])
+                                        if pre is not None else False)
+            done_events.append(jobs[enq]["done"])
             jobs[enq]["batch"] = batch
             enq += 1
         pending, jobs[k] = jobs[k], None
@@ -592,7 +627,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
 # --------------------------------------------------------------------------- A0-A4
 def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
                     bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None,
-                    exact: bool = False, prepared=None, vscale: Optional[float] = None, vrange=None):
+                    exact: bool = False, prepared=None, vscale: Optional[float] = None, vrange=None,
+                    buffer_free=False):
     """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU.
     ``exact``: also re-score every candidate in float64 (otherwise ``_resolve_peaks`` re-scores the few
     whose decision depends on it)."""
@@ -608,7 +644,18 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
         vol_exact = dvol.view(channel, False)
         store_f32 = 1 if dvol.np_dtype == np.float32 else 0
     else:
-        blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
+        if PRE_STREAM and buffer_free is not False:
+            # on its own stream: it may start as soon as the batch that last used this buffer set is done
+            # (`buffer_free`: that batch's completion event), i.e. while the batch before this one is still filtering
+            main = torch.cuda.current_stream()
+            bufs.pre_stream.wait_stream(main) if buffer_free is None else bufs.pre_stream.wait_event(buffer_free)
+            with torch.cuda.stream(bufs.pre_stream):
+                blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
+                ready = torch.cuda.Event()
+                ready.record()
+            main.wait_event(ready)
+        else:
+            blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
         store_f32 = int(getattr(pre, "store_f32", 0))
     nb, ns = len(blocks), len(space.sigmas)
     if slot >= (1 << 29):

@@ -57,8 +57,33 @@ _last_gather_ms = 0.0
 
 
 def last_gather_ms() -> float:
-    """Wall milliseconds the most recent :func:`gather_tables` of this process spent (0 without a group)."""
-    return _last_gather_ms
+    """Wall milliseconds this process spent exchanging tables since the last call: the most recent
+    :func:`gather_tables`, or the collectives of a distributed pruning (:func:`all_gather_rows`,
+    :func:`all_reduce_sum`); 0 without a group.  Reading resets the exchange clock."""
+    global _exchange_ms
+    out = _last_gather_ms + _exchange_ms
+    _exchange_ms = 0.0
+    return out
+
+
+_exchange_ms = 0.0
+
+
+def _timed(fn):
+    """Add the wall time of a collective helper to the exchange clock."""
+    import functools
+    import time
+
+    @functools.wraps(fn)
+    def inner(*args, **kwargs):
+        global _exchange_ms
+        t0 = time.perf_counter()
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            if _active() and world_size() > 1:
+                _exchange_ms += (time.perf_counter() - t0) * 1e3
+    return inner
 
 
 def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: int, decode_on: Optional[int] = None,
@@ -172,6 +197,7 @@ def raise_together(failure: Optional[BaseException], what: str = "a rank") -> No
         raise failure
 
 
+@_timed
 def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.ndarray]:
     """Every rank's ``(n_r, c)`` float64 array, in rank order (two collectives: the row counts, then the rows padded
     to the largest count).  Ranks without rows may pass ``n_cols=None`` / a ``(0, 0)`` array: the width is agreed on
@@ -194,15 +220,43 @@ def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.n
     most = int(metas[:, 0].max())
     if most == 0 or width == 0:
         return [np.zeros((0, width)) for _ in range(n_ranks)]
-    padded = np.zeros((most, width))
-    padded[:rows.shape[0], :rows.shape[1]] = rows
-    send = torch.from_numpy(padded).to(dev)
-    recv = [torch.empty_like(send) for _ in range(n_ranks)]
-    tdist.all_gather(recv, send)
-    bufs = torch.stack(recv).cpu().numpy()                       # one device -> host copy
-    return [bufs[r, :int(metas[r, 0])] for r in range(n_ranks)]
+    if dev.type == "cpu":
+        padded = np.zeros((most, width))
+        padded[:rows.shape[0], :rows.shape[1]] = rows
+        send = torch.from_numpy(padded)
+        recv = torch.empty((n_ranks * most, width), dtype=torch.float64)      # (concatenated along the rows)
+        tdist.all_gather_into_tensor(recv, send)
+        bufs = recv.numpy().reshape(n_ranks, most, width)
+    else:
+        # device collectives (RCCL): pinned staging both ways -- pageable copies of tens of MB would cost more than
+        # the exchange itself -- and one gather into one tensor
+        stage = _pinned("send", most * width)
+        host = stage.numpy()[:most * width].reshape(most, width)
+        host[:rows.shape[0], :rows.shape[1]] = rows
+        host[rows.shape[0]:] = 0.0
+        send = torch.empty((most, width), dtype=torch.float64, device=dev)
+        send.copy_(stage[:most * width].view(most, width), non_blocking=True)
+        recv = torch.empty((n_ranks * most, width), dtype=torch.float64, device=dev)
+        tdist.all_gather_into_tensor(recv, send)
+        back = _pinned("recv", n_ranks * most * width)
+        back[:n_ranks * most * width].view(n_ranks * most, width).copy_(recv, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        bufs = back.numpy()[:n_ranks * most * width].reshape(n_ranks, most, width)
+    return [np.array(bufs[r, :int(metas[r, 0])]) for r in range(n_ranks)]
 
 
+_pinned_bufs = {}
+
+
+def _pinned(name: str, n: int):
+    """A pinned float64 staging buffer of at least ``n`` elements (kept between calls)."""
+    buf = _pinned_bufs.get(name)
+    if buf is None or buf.numel() < n:
+        buf = _pinned_bufs[name] = torch.empty(max(int(n * 1.25), 1024), dtype=torch.float64).pin_memory()
+    return buf
+
+
+@_timed
 def all_reduce_sum(values: np.ndarray) -> np.ndarray:
     """Element-wise sum of an int64 array over the ranks (the array itself without a process group)."""
     values = np.ascontiguousarray(values, dtype=np.int64)

@@ -113,7 +113,7 @@ class Preprocessor:
         self.near_max = near_max
         self.want_info = want_info
         self._out64 = [None, None]
-        self._out32 = None
+        self._out32 = [None, None]
         self._scratch = None
         self._weights = None
         self._tmpl_key = None
@@ -281,7 +281,7 @@ class Preprocessor:
             offs = np.concatenate([[0], np.cumsum((7 if tv_on else 2) * gen_n)])
             subs["scratch_off"][n_fast:] = offs[:-1]
             scratch = self._buffer("_scratch", None, int(offs[-1]), torch.float64, dev)
-        out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)
+        out32 = self._buffer("_out32", which, nb * slot_pre, torch.float32, dev)
         out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
         d_subs = torch.empty(max(1, total) * item, dtype=torch.uint8, device=dev)
         d_subs[:total * item].copy_(self._stage[:total * item], non_blocking=True)
@@ -371,7 +371,7 @@ class Unmixer:
         self._blocks_args = None
         self._pres: Dict[int, Preprocessor] = {}
         self._out64 = [None, None]
-        self._out32 = None
+        self._out32 = [None, None]
 
     def set_blocks(self, origins, shapes, new_shapes) -> None:
         self._blocks_args = (origins, shapes, new_shapes)
@@ -433,7 +433,7 @@ class Unmixer:
         sx = int(-(-shp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
         dst_sy, dst_sz = sx, sx * int(shp[:, 1].max())
         slot_pre = dst_sz * int(shp[:, 0].max())
-        out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)
+        out32 = self._buffer("_out32", which, nb * slot_pre, torch.float32, dev)
         out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
         d_src = torch.from_numpy(blocks_src.view(np.uint8).reshape(-1)).to(dev)
         sub_arr = (nat.Volume * max(1, len(subs)))(*subs)
@@ -550,7 +550,7 @@ class Rescaler:
         self._pres: Dict[int, Preprocessor] = {}
         self._orig: Dict[Tuple[Tuple[int, ...], Tuple[int, ...]], Tuple[int, int, int]] = {}
         self._out = [None, None]
-        self._out32 = None
+        self._out32 = [None, None]
         self._aa0 = self._aa1 = None          # ping-pong buffers of the anti-aliasing passes
         self._scale = 1.0
 
@@ -690,7 +690,7 @@ class Rescaler:
         slot_pre = dst_sz * int(new_shp[:, 0].max())
         if out_code == nat.MMX_F64:
             out = self._buffer("_out", which, nb * slot_pre, torch.float64, dev)
-            out32 = self._buffer("_out32", None, nb * slot_pre, torch.float32, dev)
+            out32 = self._buffer("_out32", which, nb * slot_pre, torch.float32, dev)
             vol32 = nat.Volume(out32.data_ptr(), nat.MMX_F32, 0, dst_sz, dst_sy, 1)
             vol_exact = nat.Volume(out.data_ptr(), nat.MMX_F64, 0, dst_sz, dst_sy, 1)
             o32 = out32.data_ptr()

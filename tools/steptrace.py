@@ -14,17 +14,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--budget-gb", type=float, default=16.0)
 ap.add_argument("--keep-heap", action="store_true", help="mallopt: big arrays from the heap, freed memory stays mapped")
 ap.add_argument("--profile", action="store_true", help="cProfile one more step: where the host time goes")
+ap.add_argument("--config", default="c3", choices=["c2", "c3"])
 ap.add_argument("--no-plan", action="store_true", help="no StackDetector.plan_pruning: the whole table is pruned after the detection")
 a = ap.parse_args()
 if a.keep_heap:
     from magellanmapper_amd import _native
     _native.keep_host_heap()
-cfg = bench.CONFIGS["c3"]
+cfg = bench.CONFIGS[a.config]
 shape = cfg["shape"]
 dev = torch.device("cuda", 0)
 config.resolutions = bench.RESOLUTIONS; config.filename = "p"
-config.setup_roi_profiles(None); config.roi_profile.update(bench._BASE_PROFILE)
-vol = synth.make_volume_device(shape, 3, dev)
+config.setup_roi_profiles(None); config.roi_profile.update(dict(bench._BASE_PROFILE, **cfg["profile"]))
+vol = synth.make_volume_device(shape, cfg["seed"], dev)
 dvol = bl.DeviceVolume(vol)
 blocks = stack_detect.setup_blocks(config.roi_profile, shape)
 bl.blob_log_blocks = functools.partial(bl.blob_log_blocks, budget_bytes=int(a.budget_gb * (1 << 30)))
