@@ -105,6 +105,9 @@ typedef struct {
 
 /* ---- library / device ---------------------------------------------------- */
 int mmx_abi_version(void);
+/* 1 when the library was built with `make EXPERIMENTS=1`: zx_mode 3 / 4 / 5 then run their kernels (the measured
+ * matrix-core experiments kept for cross-checks); a stock build runs MMX_ZX_PACKED for them. */
+int mmx_has_experiments(void);
 const char* mmx_strerror(int status);
 const char* mmx_last_hip_error(void);
 /* number of visible devices whose arch is gfx950; <0 on HIP error */
@@ -150,6 +153,7 @@ typedef enum {
     MMX_ZX_AUTO = -1,
     MMX_ZX_SEPARATE = 0,  /* three separate passes (register-ring column kernels + LDS row kernel)          */
     MMX_ZX_PACKED = 2,    /* zx2_kernel: fused Z+X, wave-specialised, packed float32 VALU math              */
+    /* 3, 4, 5: only in a library built with `make EXPERIMENTS=1` (mmx_has_experiments()); otherwise MMX_ZX_PACKED runs */
     MMX_ZX_MFMA_F32 = 3,  /* zx3_kernel: Z on the VALU, X on v_mfma_f32_16x16x4_f32 (measured experiment)   */
     MMX_ZX_MFMA_F16 = 4,  /* zx4_kernel: X+Z on v_mfma_f32_16x16x32_f16 with split-float16 operands,
                              register resident (integer voxels; measured experiment)                       */
@@ -412,7 +416,10 @@ int mmx_resize_batch_as(const mmx_volume* vol, const mmx_resize_block* d_blocks,
  * float64 correlate1d pass along `axis` for every block; block b uses d_weights[b * w_pitch + 0..d_radius[b]]
  * (half kernel, weight at distance k) -- a truncated block has its own zoom factor.  vol: uint8 / uint16 /
  * float64 at any strides (d_blocks[b].src_off) -> d_out float64 [n_blocks][dst_slot], strides (dst_sz, dst_sy,
- * 1); a float32 volume -> float32 d_out (SciPy rounds every pass of a float32 image to float32). */
+ * 1); a float32 volume -> float32 d_out (SciPy rounds every pass of a float32 image to float32).
+ * nearest: 0 = every block extends its lines by mirroring, 1 = by repeating the edge sample ('nearest': the
+ * reference's mode for blocks with an axis of length 1, cv_nd.py:1095-1101), 2 = per block: those whose
+ * mmx_block._pad has bit 0 set repeat the edge sample, the others mirror. */
 int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
                          int n_blocks, int axis, const double* d_weights, const int32_t* d_radius,
                          int w_pitch, int nearest, int64_t dst_slot, int64_t dst_sy, int64_t dst_sz,

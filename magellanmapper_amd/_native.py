@@ -78,7 +78,7 @@ _lib = None
 
 #: every symbol ``include/mmx.h`` declares
 SYMBOLS = (
-    "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
+    "mmx_abi_version", "mmx_has_experiments", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
     "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_zx_pack", "mmx_tiled_q16_error_bound", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
@@ -105,6 +105,7 @@ def lib() -> ctypes.CDLL:
     L = ctypes.CDLL(LIB_PATH)
     vp = c_void_p
     L.mmx_abi_version.restype = c_int
+    L.mmx_has_experiments.restype = c_int
     L.mmx_strerror.restype = c_char_p
     L.mmx_strerror.argtypes = [c_int]
     L.mmx_last_hip_error.restype = c_char_p

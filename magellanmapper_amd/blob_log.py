@@ -350,11 +350,11 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     def fits(batch):
         slot = max(int(shapes[i][0]) * int(shapes[i][1]) * (-(-int(shapes[i][2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
                    for i in batch)
-        return len(batch) == 1 or len(batch) * slot * per_vox <= budget_bytes
+        return len(batch) == 1 or (len(batch) * slot * per_vox <= budget_bytes and len(batch) <= _MAX_BATCH)
 
     full = max(len(b_) for b_ in batches)
     tail = batches.pop()
-    while batches and len(tail) < 2 * full:
+    while batches and len(tail) < 2 * full and _MAX_BATCH >= (1 << 30):      # (a capped batch size: no re-merging)
         tail = batches.pop() + tail
     # (only where there is real work: below ~64 Mvoxel a batch is a few hundred microseconds of kernels)
     if taper > 0 and len(tail) > taper and sum(vox[i] for i in tail) > (64 << 20):

@@ -100,6 +100,14 @@ int mmx_timing_read(double* ms, int64_t* launches, int n)
 }
 
 int mmx_abi_version(void) { return MMX_ABI_VERSION; }
+int mmx_has_experiments(void)
+{
+#ifdef MMX_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 size_t mmx_workspace_bytes(int n_blocks, int64_t slot_elems, int n_sigma, int with_masks)
 {
@@ -295,7 +303,9 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
               rc = mmx_launch_zx6(vol, d_blocks, h_blocks, n_blocks, plan, txx, radius, d_work,
                                   q16 ? (float)(1.0 / q_bp) : 0.f, q16 ? (float)(1.0 / q_bq) : 0.f, s);
               tiled = rc == MMX_OK;
-          } else if (mfma16) {    // integer voxels, aligned rows; geometries it does not take: the packed kernel
+          }
+#ifdef MMX_EXPERIMENTS    // (make EXPERIMENTS=1; a stock build runs the packed kernel for these modes)
+          else if (mfma16) {    // integer voxels, aligned rows; geometries it does not take: the packed kernel
               path = zx_mode == MMX_ZX_MFMA_F16_LDS ? MMX_ZX_MFMA_F16_LDS : MMX_ZX_MFMA_F16;
               rc = mmx_launch_zx4(vol, d_blocks, h_blocks, n_blocks, slot_elems, txx, radius, t0, t1, t2,
                                   (size_t)(2 * n_slots * slot_elems) * sizeof(float), path == MMX_ZX_MFMA_F16_LDS, s);
@@ -303,6 +313,9 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
               path = MMX_ZX_MFMA_F32;
               rc = mmx_launch_zx3(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);
           }
+#else
+          (void)mfma16;
+#endif
           if (rc == MMX_ERR_UNSUPPORTED) {
               path = MMX_ZX_PACKED;
               rc = mmx_launch_zx2(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);

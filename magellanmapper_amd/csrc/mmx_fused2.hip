@@ -147,18 +147,12 @@ __device__ __forceinline__ void zx2_producer(const InT* __restrict__ vol, int64_
             for (int j = 0; j < kG; ++j)
                 pf[u][j] = load_plane(reflect_clamped(u * kG + R + kG + j + zs, nz), 0);
     }
-#ifdef ZX2_PROFILE
-    long long tw = 0, t_start = wall_clock64(), tb;
-#endif
 #pragma unroll 1
     for (int g0 = 0; g0 <= ngroups; g0 += kPF) {
 #pragma unroll
         for (int u = 0; u < kPF; ++u) {
             const int g = g0 + u;
             if (g > ngroups) break;
-#ifdef ZX2_PROFILE
-            tb = wall_clock64();
-#endif
             if (g < ngroups && lane_on) {
                 v2f* rows = tile + (g & 1) * (kG * PW) + row0 * PW;
                 const int z0 = g * kG;
@@ -167,13 +161,11 @@ __device__ __forceinline__ void zx2_producer(const InT* __restrict__ vol, int64_
                 for (int s = 0; s < NS; ++s) {
                     const float c = w[R + S0 + s];
                     v2f a = (v2f){c, c} * T.zw[0];
-#ifndef ZX2_SKIP_PROD
 #pragma unroll
                     for (int k = 1; k <= R; ++k) {
                         const float p = w[R + S0 + s - k] + w[R + S0 + s + k];
                         a = __builtin_elementwise_fma((v2f){p, p}, T.zw[k], a);
                     }
-#endif
                     if (!TAIL || col_real) rows[s * PW + qmain] = a;   // (pitch lanes write past the right halo: no branch)
                     av[s] = a;
                     __builtin_amdgcn_sched_barrier(0);
@@ -208,16 +200,9 @@ __device__ __forceinline__ void zx2_producer(const InT* __restrict__ vol, int64_
                     }
                 }
             }
-#ifdef ZX2_PROFILE
-            tw += wall_clock64() - tb;
-#endif
             __syncthreads();
         }
     }
-#ifdef ZX2_PROFILE
-    if (!TAIL && xlane == 0) { gp[sbase + 0] = (float)tw; gp[sbase + 2] = (float)(wall_clock64() - t_start); }
-    if (TAIL && lane == 0) gp[sbase + 4] = (float)tw;
-#endif
 }
 
 // Wave roles.  A workgroup is one block row: ceil(px / 64) producer waves and 9 consumer waves.  The
@@ -250,17 +235,9 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
     const int64_t sbase = (int64_t)bd.slot * slot_elems + (int64_t)y * px;
     const int64_t plane = (int64_t)bd.ny * px;
     // tail producer: the last producer wave would hold <= 8 real columns
-#ifdef ZX2_NO_TAIL
-    const bool tailmode = false;
-#else
     const bool tailmode = (W & 63) != 0 && (W & 63) <= 8 && ((W + 63) >> 6) == npw;
-#endif
     int role, ord;
-#ifdef ZX2_NO_ROLEMAP
-    if (false) {
-#else
     if (tailmode && npw == 5 && nwaves == 14) {
-#endif
         role = (int)((kRole14 >> (2 * wv)) & 3);
         ord = (int)((kOrd14 >> (4 * wv)) & 15);
     } else {
@@ -268,12 +245,6 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
         ord = wv < npw ? wv : wv - npw;
     }
 
-#ifdef ZX2_PROFILE
-    if ((t & 63) == 0) {   // which SIMD hosts this wave (HW_ID bits 5:4)
-        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        gp[sbase + 8 + (t >> 6)] = (float)((hw >> 4) & 3);
-    }
-#endif
     if (role == 0) {
         zx2_producer<R, InT, false>(vol, stride_z, stride_y, stride_x, bd, y, ord * 64 + (t & 63), tile, T, gp, sbase);
     } else if (role == 1) {
@@ -285,9 +256,6 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
         const int nitems = kG * CH;
         const float inv_ch = 1.0f / (float)CH;
         const int lane = t & 63;
-#ifdef ZX2_PROFILE
-        long long tw = 0, tb;
-#endif
         // this lane's item of the first round is the same in every group: its row, tile offset and output
         // offset are computed once (one round per wave is the common case: 576 items, 9 waves) -- the 64-bit
         // address products are quarter-rate instructions
@@ -299,9 +267,6 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
         constexpr int kB0 = (xg::S - R - xg::LEAD) & 3;              // chunks start at multiples of 4 columns:
 #pragma unroll 1                                                     // pad2(base + i) - pad2(base) is a constant
         for (int g = 0; g <= ngroups; ++g) {
-#ifdef ZX2_PROFILE
-            tb = wall_clock64();
-#endif
             if (g >= 1) {
                 const v2f* rows = tile + ((g - 1) & 1) * (kG * PW);
                 const int z0 = (g - 1) * kG;
@@ -330,14 +295,12 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
                         const v2f cc = win[xg::LEAD + oo + R];
                         v2f ps = cc * T.xw0[0];                 // (G(x) Gz, G(x) Gzz)
                         float q = cc.x * T.xw2[0];              // G''(x) Gz
-#ifndef ZX2_SKIP_CONS
 #pragma unroll
                         for (int k = 1; k <= R; ++k) {
                             const v2f sm = win[xg::LEAD + oo + R - k] + win[xg::LEAD + oo + R + k];
                             ps = __builtin_elementwise_fma(sm, T.xw0[k], ps);
                             q = fmaf(sm.x, T.xw2[k], q);
                         }
-#endif
                         P[oo] = ps.x;
                         Q[oo] = ps.y + q;
                     }
@@ -347,15 +310,8 @@ zx2_kernel(const InT* __restrict__ vol, int64_t stride_z, int stride_y, int stri
                 }
                 o0 += (int64_t)kG * plane;
             }
-#ifdef ZX2_PROFILE
-            tw += wall_clock64() - tb;
-#endif
             __syncthreads();
         }
-#ifdef ZX2_PROFILE
-        if (ord == 0 && lane == 0) gp[sbase + 1] = (float)tw;
-        if (ord == nwaves - npw - 1 && lane == 0) gp[sbase + 3] = (float)tw;
-#endif
     }
 }
 

@@ -219,9 +219,6 @@ template <> struct pieces4<uint16_t> {
     using raw_t = u4_4;
     static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off, unsigned soff = 0)
     {
-#ifdef ZX4_NO_LOAD
-        return (u4_4){off, off * 3u, off * 5u, off * 7u};
-#endif
         return __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, ZX4_LD_AUX));
     }
     static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo)
@@ -306,9 +303,6 @@ template <> struct lo_scaled4<float> { static constexpr bool value = true; };
 
 __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4& c)
 {
-#ifdef ZX4_NO_MFMA
-    f4_4 r = c; r[0] += __uint_as_float(a[0] ^ b[1]); r[3] += __uint_as_float(a[3] ^ b[2]); return r;
-#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_4, a), __builtin_bit_cast(h8_4, b), c, 0, 0, 0);
 }
 
@@ -385,17 +379,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // at minus what the offsets add -- (offset x column sum of the fragments), the same for the four rows a lane holds.
     // The sums come from the matrix cores themselves: an A operand of ones.  Their float32 rounding (values of ~5
     // instead of <= 1: 5e-7) is inside what mmx_tiled_q16_error_bound states.
-#ifdef ZX4_NO_BIAS
-    constexpr bool BIASED = false;
-#else
     // (radius > 16: the eight start registers would push the kernel past three waves per SIMD)
     constexpr bool BIASED = TILED && Q16 && !is_f32_4<InT>::value && LA == 1;
-#endif
-#ifdef ZX4_NO_MIX
-    constexpr bool MIXSPLIT = false;
-#else
     constexpr bool MIXSPLIT = Q16;
-#endif
     f4_4 a_start = {0.f, 0.f, 0.f, 0.f}, b_start = a_start;
     if constexpr (BIASED) {
         const u4_4 ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
@@ -419,11 +405,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     int zset = -1;
 
     // voxel rows: plane z0 + li, chunk of 8 x at xl[m] (clamped into the block; the fragments know)
-#ifdef ZX4_ROWS_Y      // access-pattern experiment (wrong results): tile rows = 16 rows of ONE plane, march along y
-    const InT* in = vol + bd.src_off + (int64_t)y * stride_z;
-#else
     const InT* in = TILED ? vol + (int64_t)bd.slot * stride_z : vol + bd.src_off + (int64_t)y * stride_y;
-#endif
     const int nch8 = (W + 7) >> 3;                               // TILED: 256-byte units (8 columns x 16 planes) per row tile
     unsigned xoff[NKX];
 #pragma unroll
@@ -440,26 +422,15 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         }
     }
     const rsrc4_t rin = make_rsrc4(in);
-#ifdef ZX4_ROWS_Y
-    const unsigned zstride_b = (unsigned)(stride_y * (int64_t)sizeof(InT));
-#else
     const unsigned zstride_b = (unsigned)(stride_z * (int64_t)sizeof(InT));
-#endif
     auto load_tile = [&](int t, typename pc::raw_t (&raw)[NKX]) __attribute__((always_inline)) {
-#ifdef ZX5_LD_SMALL
-        t = 0;
-#endif
         if constexpr (TILED) {
             const unsigned so = (unsigned)((y * ntz + t) * nch8) * (unsigned)kUnit;      // wave-uniform: the row tile
 #pragma unroll
             for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rin, xoff[m], so);
             return;
         }
-#ifdef ZX4_ROWS_Y
-        const rsrc4_t rs = make_rsrc4(in + (int64_t)(16 * t) * stride_y);
-#else
         const rsrc4_t rs = make_rsrc4(in + (int64_t)(16 * t) * stride_z);
-#endif
         int zr = nz - 1 - 16 * t;                                // last real plane relative to the tile
         zr = li < zr ? li : zr;
         const unsigned zo = (unsigned)zr * zstride_b;
@@ -483,12 +454,8 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // the same ntx ntz KiB at any time.  (Measured against the (c, U, y) order: no difference in either kernel; both
     // run at the request rate the memory system sustains)
     const unsigned plane_b = TILED ? 64u : (unsigned)bd.ny * row_b;
-#ifdef ZX4_ROWS_Y
-    unsigned obase = (unsigned)li * row_b + (unsigned)y * plane_b + (unsigned)(16 * c + 4 * kq) * 4u;
-#else
     unsigned obase = TILED ? (unsigned)(((y * ntx + c) * ntz) * 1024 + (4 * li + kq) * 16)
                            : (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
-#endif
 
     // voxels of the next ZX4_PF z tiles, in flight.  vmcnt counts loads and stores together and in issue order:
     // a tile loaded only one step ahead could not be used before the stores of the step in between have been
@@ -532,9 +499,6 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             else if (t + PF < ntz) load_tile(t + PF, rw);
             __builtin_amdgcn_sched_barrier(0);
             f4_4 a0 = a_start, a1 = {0.f, 0.f, 0.f, 0.f}, b0 = b_start, b1 = a1;
-#ifdef ZX4_PRIO
-            __builtin_amdgcn_s_setprio(ZX4_PRIO);
-#endif
 #pragma unroll
             for (int m = 0; m < NKX; ++m) {
                 a0 = mfma16(dh[m], xw[m][0][0], a0);
@@ -556,9 +520,6 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                     }
                 }
             }
-#ifdef ZX4_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
             // combine the two accumulators and split into float16 pieces: v = acc0 + acc1 / 2048
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
@@ -608,9 +569,6 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 }
             }
             f4_4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, q0 = p0, q1 = p0;
-#ifdef ZX4_PRIO
-            __builtin_amdgcn_s_setprio(ZX4_PRIO);
-#endif
 #pragma unroll
             for (int ks = 0; ks < NKZ; ++ks) {
                 const u4_4 ah = {win[0][2 * ks][0], win[0][2 * ks][1], win[0][2 * ks + 1][0], win[0][2 * ks + 1][1]};
@@ -644,19 +602,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 else q1 = mfma16(al, z10, q1);
                 if constexpr (ZLDS && !STEADY) __builtin_amdgcn_sched_barrier(0);    // one k-step's fragments at a time
             }
-#ifdef ZX4_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-#ifdef ZX4_NO_STORE
-            asm volatile("" ::"v"(p0), "v"(p1), "v"(q0), "v"(q1));
-            if (false) {
-#else
-#ifndef ZX4_FREE
             __builtin_amdgcn_sched_barrier(0);
-#endif
             asm volatile("" ::"v"(P), "v"(Q));       // the slot's previous results stayed in these registers until now
             if (STEADY || TILED || 16 * U + li < nz) {     // (a tile is stored whole: its padding belongs to it)
-#endif
                 // the results reach the slot's registers through opaque moves: the stores then read registers
                 // that nothing else may be allocated to before the slot comes round again
                 if constexpr (Q16) {
@@ -686,27 +634,13 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                     P[r] = pr;
                     Q[r] = qr;
                 }
-#ifdef ZX5_ST_SMALL
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P), rp, obase & 0xFFFF0u, 0, ZX4_ST_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, Q), rq, obase & 0xFFFF0u, 0, ZX4_ST_AUX);
-#else
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P), rp, obase, 0, ZX4_ST_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, Q), rq, obase, 0, ZX4_ST_AUX);
-#endif
                 }
             }
-#ifdef ZX4_ROWS_Y
-            obase += 16u * row_b;
-#else
             obase += 16u * plane_b;
-#endif
         }
-#ifdef ZX4_LOCKSTEP
-        __syncthreads();
-#endif
-#ifndef ZX4_FREE
         __builtin_amdgcn_sched_barrier(0);
-#endif
     };
     // tiles [0, tA): generic steps up to the first interior output tile (U = t - LA >= u_lo), rounded up to a
     // multiple of the ring; [tA, tB): steady steps (U in [u_lo, u_hi], t < ntz), whole rings; the rest generic.
@@ -752,6 +686,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 }
 
 
+#ifdef MMX_EXPERIMENTS    // (make EXPERIMENTS=1: zx_mode 4 / 5, the measured experiments that led to the tiled form)
 // ------------------------------------------------------------------------------- staged variant (default)
 // Same arithmetic, but the voxels and the results cross LDS so that every global access is a long contiguous
 // piece of one plane.  zx4_kernel above loads 16 planes x 64 bytes per instruction, four times over (each wave
@@ -839,9 +774,6 @@ zx5_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             if (p < 16) {
                 int z = 16 * t + p;
                 z = z < nz ? z : nz - 1;
-#ifdef ZX5_LD_SMALL
-                z &= 1;
-#endif
                 // descriptor = this plane's block row, W voxels long: chunks beyond either end read as zero (the range
                 // check is per dword: the length is rounded up to 4 bytes, whatever follows the row meets zero weights)
                 const rsrc4_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<InT*>(in + (int64_t)z * stride_z), 0, (W * ESZ + 3) & ~3, 0x00020000);
@@ -906,13 +838,8 @@ zx5_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             const u4_4 pv = *reinterpret_cast<const u4_4*>(src);
             const u4_4 qv = *reinterpret_cast<const u4_4*>(src + st::OUT_ARR);
             if (16 * Up + srow < nz && scol_ok) {
-#ifdef ZX5_ST_SMALL
-                __builtin_amdgcn_raw_buffer_store_b128(pv, rp, sbase & 0xFFFF0u, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(qv, rq, sbase & 0xFFFF0u, 0, 0);
-#else
                 __builtin_amdgcn_raw_buffer_store_b128(pv, rp, sbase, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(qv, rq, sbase, 0, 0);
-#endif
             }
             sbase += 16u * plane_b;
         }
@@ -1094,6 +1021,8 @@ int launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
 #undef MMX_ZX5_LAUNCH
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
+
+#endif  // MMX_EXPERIMENTS
 
 // ------------------------------------------------------------------------------- tiled variant (zx_mode 6)
 // Operand-ordered copy of the blocks' voxels, made once per batch: for every block row y and z tile t the row
@@ -1348,6 +1277,7 @@ int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_b
     return launch_zx6<2, 2>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, qp, qq, stream);
 }
 
+#ifdef MMX_EXPERIMENTS
 // tx: the PLAIN half kernels (no input scale, no norm); d_scratch: device memory the fused path does not
 // otherwise use (the fragment tables: a few hundred KB)
 int mmx_launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
@@ -1361,3 +1291,4 @@ int mmx_launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_b
     if (radius <= 16) return launch_zx4<2, 1>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, staged != 0, stream);
     return launch_zx4<2, 2>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, staged != 0, stream);
 }
+#endif  // MMX_EXPERIMENTS

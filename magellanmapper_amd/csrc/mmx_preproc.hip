@@ -306,12 +306,7 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     uint16_t* raw = (uint16_t*)(hist + PP_HIST);  // the voxels themselves, dense index
     const InT* src = vol + sb.src_off;
     const float inv_nx = 1.0f / (float)nx, inv_ny = 1.0f / (float)ny;
-#ifdef PP_PROFILE
-    long long stamp[8]; int ns_ = 0;
-#define PP_STAMP() do { __syncthreads(); stamp[ns_++] = wall_clock64(); } while (0)
-#else
 #define PP_STAMP() do {} while (0)
-#endif
     PP_STAMP();
 
     for (int i = tid; i < PP_HIST; i += WG) hist[i] = 0;
@@ -441,13 +436,11 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     }
     __syncthreads();
     const int flags = s_flags;
-#ifndef PP_PROFILE
     if (info && tid == 0) {
         mmx_subblock_info o;
         o.vmin = info_vmin; o.vmax = info_vmax; o.mean = s_mean; o.flags = flags; o._pad = 0;
         info[sub_id] = o;
     }
-#endif
     PP_STAMP();
 
     // 4. Gaussian blur, axis 0, 1, 2 in place (scipy gaussian_filter order)
@@ -516,16 +509,6 @@ pp_fast_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
             }
         }
     }
-#ifdef PP_PROFILE
-    PP_STAMP();
-    if (info && tid == 0) {   // 100 MHz ticks per stage: load, select, saturate, blur, write
-        mmx_subblock_info o;
-        o.vmin = (double)(stamp[1] - stamp[0]) + 1e-6 * (double)(stamp[2] - stamp[1]);
-        o.vmax = (double)(stamp[3] - stamp[2]) + 1e-6 * (double)(stamp[4] - stamp[3]);
-        o.mean = (double)(stamp[5] - stamp[4]); o.flags = flags; o._pad = 0;
-        info[sub_id] = o;
-    }
-#endif
     if (!erode) return;
     __syncthreads();
     for (int row = r0; row < nrows; row += rpi) {

@@ -579,7 +579,7 @@ gauss_axis_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
     const int period = 2 * n - 2;
     auto ext = [&](int i) {
         if (n == 1) return 0;
-        if (nearest) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+        if (nearest == 1 || (nearest == 2 && (bd._pad & 1))) return i < 0 ? 0 : (i >= n ? n - 1 : i);
         int m = i % period;
         if (m < 0) m += period;
         return m >= n ? period - m : m;

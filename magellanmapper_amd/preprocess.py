@@ -642,8 +642,13 @@ class Rescaler:
                                              else [1.0])
                 edge = np.array([min(orig[i]) == 1 or (dvol.multichannel and dvol.n_channels == 1)
                                  for i in range(nb)])
-                if edge.any() and not edge.all():
-                    raise NotImplementedError("anti-aliasing of a batch mixing unit-thick and regular blocks")
+                # (a batch may mix unit-thick remainder blocks -- 'nearest' -- with regular ones -- 'mirror': the
+                #  block table carries the choice per block)
+                mixed = bool(edge.any() and not edge.all())
+                if mixed:
+                    cur_blocks = cur_blocks.copy()
+                    cur_blocks["_pad"] = edge.astype(np.int32)
+                    cur_dblocks = torch.from_numpy(cur_blocks.view(np.uint8).reshape(-1)).to(dev)
                 buf = self._buffer("_aa%d" % (len(keep) & 1), None, nb * a_slot,
                                    torch.float32 if f32 else torch.float64, dev)
                 if buf.dtype != (torch.float32 if f32 else torch.float64):
@@ -652,7 +657,7 @@ class Rescaler:
                 d_w = torch.from_numpy(wts.reshape(-1)).to(dev)
                 d_r = torch.from_numpy(radii).to(dev)
                 nat.check(L.mmx_gauss_axis_batch(ctypes.byref(cur_vol), cur_dblocks.data_ptr(), cur_blocks.ctypes.data,
-                                                 nb, a, d_w.data_ptr(), d_r.data_ptr(), pitch, int(edge.all()),
+                                                 nb, a, d_w.data_ptr(), d_r.data_ptr(), pitch, 2 if mixed else int(edge.all()),
                                                  a_slot, a_sy, a_sz, buf.data_ptr(), stream), "mmx_gauss_axis_batch")
                 nxt = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
                 for i in range(nb):

@@ -528,6 +528,8 @@ def main():
         return main_isotropic()
     if sys.argv[1:] == ["tv"]:            # only the total-variation denoising fixtures (added later)
         return main_tv()
+    if sys.argv[1:] == ["overlap"]:       # only the _prune_blobs fixtures (pair-order pinning; added later)
+        return main_overlap()
     if sys.argv[1:] == ["match"]:         # only the match-based co-localisation fixtures (added later)
         return main_match()
     if sys.argv[1:] == ["grouping"]:      # only the channel-grouping fixtures of detect_blobs_stack (added later)
@@ -831,6 +833,27 @@ def match_cases():
 
 def main_match():
     match_cases()
+
+
+def main_overlap():
+    """skimage.feature.blob._prune_blobs itself on crowded random tables (several scales, many blobs that both win and
+    lose an over-limit pair): its outcome then depends on the order cKDTree.query_pairs' set is iterated in."""
+    from skimage.feature import blob as sk_blob
+    rng = np.random.default_rng(91)
+    sigmas = np.array([3.0, 3.5, 4.0, 4.5, 5.0])
+    out = {"sigmas": sigmas, "versions": np.array(repr(VERSIONS))}
+    specs = [(60, 30, 0.5), (300, 60, 0.5), (1200, 110, 0.5), (500, 60, 0.3), (800, 90, 0.7), (40, 12, 0.5)]
+    for k, (n, box, overlap) in enumerate(specs):
+        coords = rng.integers(0, box, (n, 3))
+        sidx = rng.integers(0, len(sigmas), n)
+        table = np.hstack((coords.astype(float), sigmas[sidx][:, None]))
+        kept = sk_blob._prune_blobs(table.copy(), overlap)
+        out["case%d_coords" % k] = np.hstack((coords, sidx[:, None])).astype(np.int32)
+        out["case%d_overlap" % k] = np.array(overlap)
+        out["case%d_kept" % k] = kept
+        print("overlap prune case %d: %d blobs -> %d" % (k, n, len(kept)))
+    out["n_cases"] = np.array(len(specs))
+    np.savez_compressed(os.path.join(HERE, "overlap_prune.npz"), **out)
 
 
 def main_tv():

@@ -504,6 +504,8 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
     odd radii (undefined behaviour that showed as NaNs for R = 3..11)."""
     from magellanmapper_amd import _native as nat, blob_log as bl, synth
     from oracle import blob_log_oracle as blo
+    if fused in (3, 4, 5) and not nat.lib().mmx_has_experiments():
+        pytest.skip("zx_mode 3 / 4 / 5 are built with `make EXPERIMENTS=1` only (a stock library runs the packed kernel)")
     vol = synth.make_volume(3, (35, 42, 48), 12)
     dvol = bl.DeviceVolume(vol)
     img = blo.img_as_float(vol)

@@ -224,6 +224,19 @@ def test_isotropic_z_only_single_channel_matches_scipy_zoom(gpu):
                                   isotropic_oracle.make_isotropic(f, (1, 1, 1), np.array((3.3, 1.0, 1.0))))
 
 
+@pytest.mark.parametrize("case", ["2ch_z", "2ch_f64", "2ch_slight"])
+def test_isotropic_z_only_single_channel_equals_each_channel_of_the_fixtures(gpu, case):
+    """The device rescale of ONE channel along z (the stock ``lightsheet`` shape) against the real reference's
+    two-channel results, channel by channel: the interpolation never mixes channels, and for two-channel blocks
+    scikit-image 0.18.3 runs the pinned release's code path (see the oracle test of the same name)."""
+    from magellanmapper_amd import preprocess
+    roi, want = ISO[case + "_roi"], ISO[case + "_out"]
+    for c in range(roi.shape[3]):
+        got = preprocess.make_isotropic(np.ascontiguousarray(roi[..., c]), ISO[case + "_scale"], ISO[case + "_res"])
+        assert got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want[..., c])
+
+
 def test_stock_anisotropic_lightsheet_geometry_matches_oracle(gpu, env, tmp_path, monkeypatch):
     """The geometry real light-sheet data gives the default profile: 6.6 x 1.1 x 1.1 um voxels (the
     reference's own test resolution) -> 4 x 23 x 23-voxel denoise tiles (256-lane small-tile kernel),
@@ -350,6 +363,32 @@ def test_isotropic_anti_aliased_down_sampling(gpu):
             want = isotropic_oracle.make_isotropic(roi, scale, np.array(res))
             assert got.shape == want.shape and got.dtype == want.dtype
             np.testing.assert_array_equal(got, want, err_msg=str((shape, scale, res, kind)))
+
+
+def test_anti_aliasing_of_a_batch_mixing_unit_thick_and_regular_blocks(gpu):
+    """One batch with a regular block and a one-plane remainder block, both down-sampled (anti-aliased) along y / x:
+    the reference resizes the former in 'reflect' mode and the latter in 'edge' mode (cv_nd.py:1095-1101); the
+    anti-aliasing pass takes the mode per block.  Each block against the oracle's SciPy calls, bit for bit."""
+    from magellanmapper_amd import blob_log as bl, preprocess
+    from oracle import isotropic_oracle
+    rng = np.random.default_rng(23)
+    for dtype in (np.uint16, np.float64):
+        vol = (rng.integers(0, 65535, (14, 40, 44)).astype(np.uint16) if dtype == np.uint16
+               else rng.random((14, 40, 44)) * 3 - 0.5)
+        scale, res = (1, 0.6, 0.7), np.array((1.0, 1.0, 1.0))
+        factor = preprocess.calc_isotropic_factor(scale, res)
+        origins = [(0, 0, 0), (13, 0, 0), (2, 5, 4), (12, 3, 0)]
+        shapes = [(13, 40, 44), (1, 40, 44), (9, 30, 33), (1, 5, 40)]
+        new = [preprocess.isotropic_shape(s_, factor) for s_ in shapes]
+        dvol = bl.DeviceVolume(vol)
+        rs = preprocess.Rescaler(factor, [0], None)
+        rs.set_blocks(origins, shapes, new)
+        rs.run(dvol, 0, origins, new, 0)
+        for o, s_, got in zip(origins, shapes, rs.fetch(new)):
+            sub = vol[o[0]:o[0] + s_[0], o[1]:o[1] + s_[1], o[2]:o[2] + s_[2]]
+            want = isotropic_oracle.make_isotropic(sub, scale, res)
+            assert got.shape == want.shape and got.dtype == want.dtype, (o, s_)
+            np.testing.assert_array_equal(got, want, err_msg=str((o, s_, dtype)))
 
 
 # ------------------------------------------------------------------------------- total-variation denoising

@@ -273,6 +273,22 @@ def test_colocalize_blobs_matches_reference(case):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("case", ["2ch_z", "2ch_f64", "2ch_slight"])
+def test_single_channel_z_only_rescale_is_tied_to_the_multichannel_fixtures(case):
+    """The stock ``lightsheet`` shape -- ONE channel rescaled along z only -- cannot be pinned by a fixture from this
+    container (scikit-image 0.18.3 sends exactly that shape through its 2-D warp; the release the reference pins does
+    not).  What can be shown: the interpolation is separable and never mixes channels, so the single-channel
+    restatement (``scipy.ndimage.zoom``, the pinned release's call) applied to EACH channel of a two-channel block
+    must give that channel of the real reference's two-channel result -- which 0.18.3 does compute on the pinned
+    release's code path (fixtures ``2ch_*`` of isotropic.npz: up-sampling, float64, anti-aliased down-sampling)."""
+    roi, want = ISO[case + "_roi"], ISO[case + "_out"]
+    assert roi.ndim == 4 and want.shape[1:3] == roi.shape[1:3] and want.shape[0] != roi.shape[0]     # z only
+    for c in range(roi.shape[3]):
+        got = isotropic_oracle.make_isotropic(np.ascontiguousarray(roi[..., c]), ISO[case + "_scale"], ISO[case + "_res"])
+        assert got.dtype == want.dtype
+        np.testing.assert_array_equal(got, want[..., c])
+
+
 def test_remove_close_blobs_matches_reference():
     g = load_golden("prune.npz")
     for k in range(int(g["n_rc"])):
