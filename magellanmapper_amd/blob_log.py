@@ -619,8 +619,9 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         for i, pk, res in zip(pending["batch"], peaks, pruned):
             results[i] = res
             peaks_out[i] = pk
-        if on_batch is not None:    # caller's per-block post-processing, still overlapped
-            on_batch(pending["batch"], pruned)
+        if on_batch is not None:    # caller's per-block post-processing, still overlapped: whatever it launches
+            with torch.cuda.stream(bufs.side):           # (co-localisation means) runs beside the next batch's kernels
+                on_batch(pending["batch"], pruned)
     return (results, peaks_out) if return_peaks else results
 
 

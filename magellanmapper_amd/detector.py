@@ -417,9 +417,15 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
     isotropic = first["isotropic"]
     iso_factor = None
     pre = None
+    keeper = None
     if denoise_max_shape is not None:
         from . import preprocess
         pre = preprocess.Preprocessor(denoise_max_shape)
+        if coloc and isotropic is None and dvol.multichannel and \
+                not any(getattr(config.get_roi_profile(c), "spectral_unmixing", None) for c in channels):
+            # the co-localisation reads every channel's preprocessed blocks: keep them instead of making them twice
+            if pre.retain(dvol, origins, shapes, channels):
+                keeper = pre
     log_shapes = shapes
     if isotropic is not None:
         # interpolate every block to (near) isotropy for the detection, first channel's profile
@@ -489,7 +495,7 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                     tbls.append(tbl)
                 if coloc:
                     tbls = _append_colocs(dvol, channels, [origins[i] for i in indices],
-                                          [shapes[i] for i in indices], tbls, denoise_max_shape)
+                                          [shapes[i] for i in indices], tbls, denoise_max_shape, keeper)
                 for i, tbl in zip(indices, tbls):
                     done[i] = on_block(i, tbl) if on_block is not None else tbl
 
@@ -508,7 +514,7 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
     return done
 
 
-def _append_colocs(dvol, channels, origins, shapes, tables, denoise_max_shape):
+def _append_colocs(dvol, channels, origins, shapes, tables, denoise_max_shape, keeper=None):
     """``np.hstack((table, colocalize_blobs(block, table)))`` for the blocks of one batch
     (reference stack_detect.py:159-162).  The image the reference hands to ``colocalize_blobs`` is
     the block as detection saw it: preprocessed when ``denoise_max_shape`` is set."""
@@ -538,7 +544,11 @@ def _append_colocs(dvol, channels, origins, shapes, tables, denoise_max_shape):
             _coloc_pre = preprocess.Preprocessor(denoise_max_shape)
         flags = None
         for c in channels:
-            blocks, _, _, vol64 = _coloc_pre.run(dvol, c, origins, shapes, 0)
+            kept = None if keeper is None else keeper.retained_view(c, origins, shapes)
+            if kept is not None:           # what detection preprocessed is still there (Preprocessor.retain)
+                blocks, vol64 = kept
+            else:
+                blocks, _, _, vol64 = _coloc_pre.run(dvol, c, origins, shapes, 0)
             d_blocks = bl._to_device_bytes(blocks, dev)
             part = colocalizer.colocalize_blocks_device({c: vol64}, blocks, d_blocks, shapes, tables,
                                                         dvol.n_channels, dev, means_only=True)

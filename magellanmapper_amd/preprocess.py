@@ -123,6 +123,47 @@ class Preprocessor:
         self._tiles: Dict[Tuple[int, int, int], Tuple[np.ndarray, np.ndarray]] = {}
         self.last_info: Optional[np.ndarray] = None
         self.last_subs: Optional[np.ndarray] = None
+        self._retain = None
+
+    def retain(self, dvol, origins, shapes, channels, budget_fraction: float = 0.45) -> bool:
+        """Keep the preprocessed float64 blocks of ``channels`` resident for the whole call (every block its own slot)
+        instead of recycling two batch-sized buffers: the intensity co-localisation, which the reference runs on the
+        image detection saw (stack_detect.py:159-162), then reads them instead of preprocessing every channel a
+        second time.  MI355X's 288 GB make that affordable for whole tiles (2 channels x 128 blocks of 261^3:
+        40 GB + 10 GB of float32); returns False -- nothing kept, callers preprocess again -- when the free HBM does not."""
+        nb = len(shapes)
+        if nb == 0:
+            return False
+        shp = np.asarray(shapes, dtype=np.int64).reshape(nb, 3)
+        sx = int(-(-shp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
+        sy_rows = int(shp[:, 1].max())
+        slot = sx * sy_rows * int(shp[:, 0].max())
+        need = nb * slot * (8 * len(channels) + 4)
+        free_b, _ = torch.cuda.mem_get_info(dvol.tensor.device)
+        if need > budget_fraction * free_b:
+            return False
+        dev = dvol.tensor.device
+        self._retain = dict(
+            gid={(tuple(int(v) for v in o), tuple(int(v) for v in s_)): i for i, (o, s_) in enumerate(zip(origins, shapes))},
+            sx=sx, sy_rows=sy_rows, slot=slot, nb=nb,
+            out64={int(c): torch.empty(nb * slot, dtype=torch.float64, device=dev) for c in channels},
+            out32=torch.empty(nb * slot, dtype=torch.float32, device=dev))
+        return True
+
+    def retained_view(self, channel: int, origins, shapes):
+        """``(blocks, vol64)`` of already preprocessed blocks of ``channel`` (``None`` when nothing is retained)."""
+        r = self._retain
+        if r is None or int(channel) not in r["out64"]:
+            return None
+        blocks = np.zeros(len(shapes), dtype=nat.BLOCK_DTYPE)
+        for i, (o, s_) in enumerate(zip(origins, shapes)):
+            g = r["gid"].get((tuple(int(v) for v in o), tuple(int(v) for v in s_)))
+            if g is None:
+                return None
+            px = -(-int(s_[2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN
+            blocks[i] = (g * r["slot"], s_[0], s_[1], s_[2], i, px, 0)
+        dst_sy, dst_sz = r["sx"], r["sx"] * r["sy_rows"]
+        return blocks, nat.Volume(r["out64"][int(channel)].data_ptr(), nat.MMX_F64, 0, dst_sz, dst_sy, 1)
 
     # ---- geometry
     @staticmethod
@@ -232,6 +273,17 @@ class Preprocessor:
         sy_rows = int(shp[:, 1].max())
         dst_sy, dst_sz = sx, sx * sy_rows
         slot_pre = dst_sz * int(shp[:, 0].max())
+        # retained blocks (retain()): every block of the call has its own slot, batch after batch
+        slots_of = np.arange(nb, dtype=np.int64)
+        kept = self._retain if (self._retain is not None and int(channel) in self._retain["out64"]) else None
+        if kept is not None:
+            try:
+                slots_of = np.array([kept["gid"][(tuple(int(v) for v in o), tuple(int(v) for v in s_))]
+                                     for o, s_ in zip(org, shp)], dtype=np.int64)
+                sx, sy_rows, slot_pre = kept["sx"], kept["sy_rows"], kept["slot"]
+                dst_sy, dst_sz = sx, sx * sy_rows
+            except KeyError:
+                kept = None
         t = dvol.tensor
         vsz, vsy, vsx = (int(v) for v in t.stride()[:3])
         # sub-block table: per distinct block shape a cached template (tile extents, offsets relative
@@ -273,7 +325,7 @@ class Preprocessor:
             view[...] = tmpl[None, :]
             idx = np.asarray(members, dtype=np.int64)
             view["src_off"] += base_src_all[idx][:, None]
-            view["dst_off"] += (idx * slot_pre)[:, None]
+            view["dst_off"] += (slots_of[idx] * slot_pre)[:, None]
             at[cls] += m * nt
         qc = np.array(self._qc_rows, dtype=nat.QCLASS_DTYPE)
         if n_gen:
@@ -281,8 +333,11 @@ class Preprocessor:
             offs = np.concatenate([[0], np.cumsum((7 if tv_on else 2) * gen_n)])
             subs["scratch_off"][n_fast:] = offs[:-1]
             scratch = self._buffer("_scratch", None, int(offs[-1]), torch.float64, dev)
-        out32 = self._buffer("_out32", which, nb * slot_pre, torch.float32, dev)
-        out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
+        if kept is not None:
+            out32, out64 = kept["out32"], kept["out64"][int(channel)]
+        else:
+            out32 = self._buffer("_out32", which, nb * slot_pre, torch.float32, dev)
+            out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
         d_subs = torch.empty(max(1, total) * item, dtype=torch.uint8, device=dev)
         d_subs[:total * item].copy_(self._stage[:total * item], non_blocking=True)
         self._stage_free = torch.cuda.Event()
@@ -324,11 +379,11 @@ class Preprocessor:
         slot = 1
         for i in range(nb):
             px = -(-int(shp[i, 2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN
-            blocks[i] = (i * slot_pre, shp[i, 0], shp[i, 1], shp[i, 2], i, px, 0)
+            blocks[i] = (int(slots_of[i]) * slot_pre, shp[i, 0], shp[i, 1], shp[i, 2], i, px, 0)
             slot = max(slot, int(shp[i, 0]) * int(shp[i, 1]) * px)
         vol32 = nat.Volume(out32.data_ptr(), nat.MMX_F32, 0, dst_sz, dst_sy, 1)
         vol64 = nat.Volume(out64.data_ptr(), nat.MMX_F64, 0, dst_sz, dst_sy, 1)
-        self.last_geometry = (slot_pre, dst_sz, dst_sy, out64, out32)
+        self.last_geometry = (slot_pre, dst_sz, dst_sy, out64, out32) if kept is None else None
         return blocks, slot, vol32, vol64
 
     def info(self) -> np.ndarray:
