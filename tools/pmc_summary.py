@@ -75,4 +75,42 @@ for k in ("preproc", "zxpack", "zxpass", "y2pass", "zpass", "ypass", "xpass", "p
     wr = w[k] / max(1, wc[k]) * write_cal[k]
     res[k] = dict(launches=fc[k], read_GB=rd / 1e9, write_GB=wr / 1e9, total_GB=(rd + wr) / 1e9)
     print(f"  {k:6s} launches {fc[k]:4d}  read {rd/1e9:8.3f} GB  write {wr/1e9:8.3f} GB  total {(rd+wr)/1e9:8.3f} GB")
-print(json.dumps(res))
+# ---- issue-side counters of the same command (separate pass): busy fractions of the vector and matrix pipes
+# MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles, GRBM_GUI_ACTIVE the sum over
+# the 8 XCDs; the chip has 256 CUs x 4 SIMDs
+busy = {}
+sq = {}
+for cname in ("SQ_ACTIVE_INST_VALU", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAIT_ANY"):
+    tot, cnt = per_kernel(load_counter(os.path.join(root, "pmc_sq"), cname))
+    for k in tot:
+        sq.setdefault(k, {})[cname] = tot[k] / max(1, cnt[k])
+tcp = {}
+for cname in ("TCP_PENDING_STALL_CYCLES", "TCP_TCC_READ_REQ", "TCP_TCC_WRITE_REQ", "SQ_WAVE_CYCLES"):
+    tot, cnt = per_kernel(load_counter(os.path.join(root, "pmc_tcp"), cname))
+    for k in tot:
+        tcp.setdefault(k, {})[cname] = tot[k] / max(1, cnt[k])
+print("issue side per launch (fractions of the SIMD cycles of the launch):")
+for k, c in sq.items():
+    cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if cyc <= 0:
+        continue
+    simd = cyc * 1024
+    busy[k] = dict(valu_busy=round(4 * c.get("SQ_ACTIVE_INST_VALU", 0) / simd, 4),
+                   mfma_busy=round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd, 4),
+                   cycles_per_xcd=round(cyc))
+    t = tcp.get(k, {})
+    if t:
+        busy[k]["tcp_pending_stall"] = round(t.get("TCP_PENDING_STALL_CYCLES", 0) / (cyc * 256), 4)
+        busy[k]["l2_read_requests"] = round(t.get("TCP_TCC_READ_REQ", 0))
+        busy[k]["l2_write_requests"] = round(t.get("TCP_TCC_WRITE_REQ", 0))
+    print(f"  {k:8s} {busy[k]}")
+import hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+out = {"source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ / TCP, one "
+                 "counter set per pass) of python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub-records; "
+                 "HBM bytes calibrated on tools/pmc_calib.py streams; averages over all launches of a kernel family",
+       "source_digest": bench.source_digest(), "per_launch_GB": res, "busy": busy}
+with open(os.path.join(root, "pmc_counters.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(json.dumps(out))
