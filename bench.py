@@ -468,7 +468,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                             "note": "float16 MFMA flops the kernel issues (split-float16 products: 3 MFMAs per float32 "
                                     "product) over its duration, against the dense float16 peak"}
     gpu_ms = sum(ms for ms, n in ktimes.values()) / steps
-    main_ms = sum(ms for k, (ms, n) in ktimes.items() if k in MAIN_STREAM) / steps
+    # (per-block preprocessing runs on a stream of its own beside the LoG kernels: its spans overlap theirs)
+    overlapped = ("preproc",) if (PROFILE["denoise_size"] and bl.PRE_STREAM) else ()
+    main_ms = sum(ms for k, (ms, n) in ktimes.items() if k in MAIN_STREAM and k not in overlapped) / steps
     b_alg = B_ALG_PER_SIGMA * ns * n_chl
     vol_bytes = nvox * n_chl * 2
     frac_kernels = b_alg * (nvox / world) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -511,8 +513,10 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             "achieved_GBps_wall": round(frac_wall * HBM_PEAK_GBS * world, 1),
             "frac_wall": round(frac_wall, 4),
             # wall clock not covered by a kernel on the stream the LoG passes run on: start-up before the first
-            # launch, launch gaps, and the tail after the last kernel (last batch's host work, pruning, final columns)
-            "host_exposed_ms_per_step": round(elapsed / steps * 1e3 - main_ms, 2) if world == 1 else None},
+            # launch, launch gaps, waits for the preprocessing stream, and the tail after the last kernel (last
+            # batch's host work, pruning, final columns)
+            "host_exposed_ms_per_step": round(elapsed / steps * 1e3 - main_ms, 2) if world == 1 else None,
+            "overlapped_streams": list(overlapped) or None},
         "above_contract_roofline": flags or None,
         "above_contract_roofline_note": None if not flags else (
             "fractions above 1 are quoted on SURVEY.md 8d's byte count (50 B per voxel and sigma: three unfused passes "

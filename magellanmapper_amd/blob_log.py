@@ -461,8 +461,61 @@ def _buffers_for(dev) -> _Buffers:
     cost ~25 ms to set up (pinned allocations, stream creation), a tenth of a whole benchmark volume."""
     key = str(dev)
     if key not in _BUFFERS:
+        if os.environ.get("MMX_SELF_TEST", "1") != "0":
+            self_test(dev)
         _BUFFERS[key] = _Buffers(dev)
     return _BUFFERS[key]
+
+
+_SELF_TESTED = set()
+
+
+def self_test(dev) -> None:
+    """Known-answer check of the matrix-core kernels, once per process and device (~30 ms): a small block tall
+    enough for their steady-state loop through ``MMX_ZX_TILED`` and ``MMX_ZX_TILED_Q16`` (integer and float voxels,
+    one radius per kernel geometry class) against the library's generic one-thread-per-voxel kernels.
+
+    Why it exists: the exactness machinery compares float32 with float64 values AT THE CANDIDATES a batch
+    nominates -- a kernel that is wrong everywhere nominates nothing and the batch comes back empty without an
+    error.  That happened during development (an inline-assembly instruction behind an MFMA that still read its
+    destination register: zeros for radius <= 8); the parity tests caught it, and this makes a production process
+    fail as loudly should a compiler or driver ever produce it again."""
+    key = str(dev)
+    if key in _SELF_TESTED:
+        return
+    L = nat.lib()
+    rng = np.random.default_rng(1234)
+    vol = rng.integers(0, 65536, (70, 12, 80)).astype(np.uint16)
+    vol[20:50, 3:9, 30:60] //= 16
+    shape = vol.shape
+    for dtype in (np.uint16, np.float32):
+        dv = DeviceVolume(vol if dtype == np.uint16 else (vol.astype(np.float32) / np.float32(65535.0)), dev)
+        blocks, slot = _make_blocks(dv, 0, [(0, 0, 0)], [shape])
+        d_blocks = _to_device_bytes(blocks, dev)
+        v32 = dv.view(0, True)
+        v32.value_range = 1.0 if dtype == np.float32 else 0.0
+        ws = torch.zeros(6 * slot, dtype=torch.float32, device=dev)
+        for sigma in (1.6, 3.2, 4.6):                      # radii 6, 13, 18: the three kernel geometry classes
+            space = ScaleSpace.make(sigma, sigma, 1)
+            args = (ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, 1, slot, nat.as_double_ptr(space.w0[0]),
+                    nat.as_double_ptr(space.w2[0]), int(space.radii[0]), float(space.norms[0]))
+            nat.check(L.mmx_log_batch_f32_generic(*args, ws.data_ptr() + 5 * slot * 4, ws.data_ptr(), _stream_ptr()),
+                      "mmx_log_batch_f32_generic")
+            want = ws[5 * slot:6 * slot].clone()
+            for mode, tol in ((nat.MMX_ZX_TILED, 2e-6), (nat.MMX_ZX_TILED_Q16, 6e-5)):
+                path = ctypes.c_int(0)
+                nat.check(L.mmx_log_batch_f32(*args, ws.data_ptr() + 4 * slot * 4, ws.data_ptr(), None, 0.0, 0.0, None,
+                                              mode, ctypes.byref(path), _stream_ptr()), "mmx_log_batch_f32")
+                got = ws[4 * slot:5 * slot]
+                n = shape[0] * shape[1] * int(blocks["px"][0])
+                g = got[:n].view(shape[0], shape[1], -1)[..., :shape[2]]
+                w = want[:n].view(shape[0], shape[1], -1)[..., :shape[2]]
+                err = float((g - w).abs().max().item())
+                if path.value == mode and not err < tol:
+                    raise nat.MmxError(f"self-test of the device kernels failed (zx_mode {mode}, radius "
+                                       f"{int(space.radii[0])}, {np.dtype(dtype).name} voxels: off by {err:.3g}); "
+                                       "this build of libmmx_hip.so must not be used")
+    _SELF_TESTED.add(key)
 
 
 def release_buffers() -> None:
