@@ -165,6 +165,8 @@ typedef enum {
                              only when entries are asked for with nms_eps >= 4 x that bound                     */
 } mmx_zx_mode;
 #define MMX_ZX_PREPACKED 0x100   /* or-ed into MMX_ZX_TILED / MMX_ZX_TILED_Q16: mmx_zx_pack ran on this d_work for these blocks */
+#define MMX_ZX_Y_VALU    0x200   /* or-ed into MMX_ZX_TILED_Q16 (any zx_mode >= 0 accepts it): the Y pass of the 16-bit tiles on the
+                                    VALU (y6_kernel) instead of the matrix cores (ym_kernel, the default); for cross-checks */
 #define MMX_MASK_ROWS 1
 #define MMX_MASK_QUADS 2
 int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks,
@@ -175,7 +177,7 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
 
 /* Largest deviation of an MMX_ZX_TILED_Q16 LoG value from the float32 paths' (which are within a few 1e-7 of the
  * exact value), for voxels in [0, 1] (uint8 / uint16 after img_as_float; float voxels in [0, m]: times m): a
- * function of the weights alone (4.6e-5 for any sigma >= 1).  A true maximum is nominated as long as the NMS band is four
+ * function of the weights alone (5.1e-5 for any sigma >= 1).  A true maximum is nominated as long as the NMS band is four
  * times this (mmx_rescore_f64 then decides on exact values as always).  < 0 on bad arguments. */
 double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm);
 

@@ -26,7 +26,7 @@ MMX_CAND_BAND = 2
 MMX_CAND_PROBE = 4
 #: ``mmx_zx_mode``: how mmx_log_batch_f32 runs its Z and X passes (a per-call argument)
 MMX_ZX_AUTO, MMX_ZX_SEPARATE, MMX_ZX_PACKED, MMX_ZX_MFMA_F32, MMX_ZX_MFMA_F16, MMX_ZX_MFMA_F16_LDS = -1, 0, 2, 3, 4, 5
-MMX_ZX_TILED, MMX_ZX_TILED_Q16, MMX_ZX_PREPACKED = 6, 7, 0x100
+MMX_ZX_TILED, MMX_ZX_TILED_Q16, MMX_ZX_PREPACKED, MMX_ZX_Y_VALU = 6, 7, 0x100, 0x200
 #: NMS entry layouts ``mmx_log_batch_f32`` reports and ``mmx_peaks_batch`` takes
 MMX_MASK_ROWS, MMX_MASK_QUADS = 1, 2
 MMX_MAX_BLOCKS = 65535

@@ -59,13 +59,16 @@ except Exception as exc:  # pragma: no cover
 #: half-width of the float32 "contested" band, relative to the input's value scale
 EPS_REL = float(os.environ.get("MMX_EPS_REL", 2e-5))
 #: the band for raw integer volumes, whose default kernels hand the Z+X results to the Y pass as 16-bit fixed point
-#: (``MMX_ZX_TILED_Q16``: error <= 4.3e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
-EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2e-4))
+#: (``MMX_ZX_TILED_Q16``: error <= 5.2e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
+EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2.5e-4))
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
 #: default for kernel experiments; tests set it to cross-check the kernels against each other)
 ZX_MODE = int(os.environ.get("MMX_FUSE", nat.MMX_ZX_AUTO))
+#: flags or-ed into the mode of the tiled calls: ``MMX_Y_VALU=1`` runs the Y pass of the 16-bit tiles on the VALU
+#: (``y6_kernel``) instead of the matrix cores (``ym_kernel``) -- cross-checks and A/B timing
+ZX_FLAGS = nat.MMX_ZX_Y_VALU if os.environ.get("MMX_Y_VALU", "0") == "1" else 0
 #: the ``mmx_zx_mode`` the most recent ``mmx_log_batch_f32`` call of this process actually ran
 LAST_ZX_PATH = None
 #: who takes the per-batch decisions on the re-scored candidates: "native" (``mmx_host_resolve_peaks`` /
@@ -762,7 +765,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                 nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]), int(space.radii[s]),
                 float(space.norms[s]), log_base + s * nb * slot * 4, ws.data_ptr(),
                 (mask_base + s * mask_words * 16) if with_mask else None, thr - eps, eps,
-                ctypes.byref(written), (tiled_mode | nat.MMX_ZX_PREPACKED) if packed else mode,
+                ctypes.byref(written), (tiled_mode | nat.MMX_ZX_PREPACKED | ZX_FLAGS) if packed else mode,
                 ctypes.byref(path), stream),
                 "mmx_log_batch_f32")
             LAST_ZX_PATH = path.value

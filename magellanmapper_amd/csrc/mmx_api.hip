@@ -156,7 +156,9 @@ int mmx_device_count(void)
 // i.e. 3.7e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7, the product
 // term the 16-bit kernel leaves out (0.55e-5) and the rounding of its X accumulators, which run with the voxel
 // pieces' exponent offsets still in them (values up to 8 instead of 1: four roundings of 2^-22 each, 0.3e-5):
-// 4.6e-5 in all.
+// 4.6e-5; the Y pass on the matrix cores (mmx_ymfma.hip) leaves out its own low x low product -- low byte of a count x
+// (weight - float16(weight)): 255 x 2^-12 = 0.062 counts per unit of weight against the 0.5 of the rounding -- which adds an
+// eighth: 5.1e-5 in all.
 static void q16_bounds(const double* w0, const double* w2, int radius, double norm, double* bp, double* bq, double* err)
 {
     double s0 = w0[0], s2 = fabs(w2[0]);
@@ -169,8 +171,10 @@ static void q16_bounds(const double* w0, const double* w2, int radius, double no
     // ... and the float32 rounding of X accumulators that carry the pieces' offsets (<= 8: ulp 2^-21, half of it per
     // MFMA, four MFMAs into each; relative to the bounds, the fragments carry 1 / bound)
     const double biased = 4.0 * 0x1p-22;
-    *err = norm * (s2 * (*bp / 65535.0 / 2.0 + drop * s0 * s0 + biased * *bp) +
-                   s0 * (*bq / 32767.0 / 2.0 + drop * 2.0 * s2 * s0 + biased * *bq)) + 1e-6;
+    // ... and the Y pass's dropped product, in counts of P and of Q
+    const double ydrop = 255.0 / 4096.0;
+    *err = norm * (s2 * (*bp / 65535.0 * (0.5 + ydrop) + drop * s0 * s0 + biased * *bp) +
+                   s0 * (*bq / 32767.0 * (0.5 + ydrop) + drop * 2.0 * s2 * s0 + biased * *bq)) + 1e-6;
 }
 
 double mmx_tiled_q16_error_bound(const double* h_w0, const double* h_w2, int radius, double norm)
@@ -189,6 +193,8 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
 {
     if (h_mask_written) *h_mask_written = 0;
     if (h_zx_path) *h_zx_path = MMX_ZX_SEPARATE;
+    const bool y_valu = zx_mode >= 0 && (zx_mode & MMX_ZX_Y_VALU);
+    if (y_valu) zx_mode &= ~MMX_ZX_Y_VALU;
     const bool prepacked = zx_mode == (MMX_ZX_TILED | MMX_ZX_PREPACKED) || zx_mode == (MMX_ZX_TILED_Q16 | MMX_ZX_PREPACKED);
     if (prepacked) zx_mode &= ~MMX_ZX_PREPACKED;
     if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_TILED_Q16 || zx_mode == 1) return MMX_ERR_ARG;
@@ -331,7 +337,13 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
                                            : (int64_t)hb.ny * (((int64_t)hb.nz * hb.px + 63) >> 6);
                 if (need > (slot_elems >> 5) - 1) want_mask = false;
             }
-            if (tiled)
+            rc = MMX_ERR_UNSUPPORTED;
+            if (tiled && q16 && !y_valu)
+                rc = mmx_launch_ym(d_blocks, n_blocks, plan, slot_elems, tyy, radius, d_work,
+                                   (float)(q_bp / 65535.0), (float)(q_bq / 32767.0), d_log,
+                                   want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s);
+            if (rc != MMX_ERR_UNSUPPORTED) ;
+            else if (tiled)
                 rc = mmx_launch_y6(d_blocks, n_blocks, plan, slot_elems, tyy, radius, d_work,
                                    reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_work) + plan.q_off),
                                    q16 ? (float)(q_bp / 65535.0) : 0.f, q16 ? (float)(q_bq / 32767.0) : 0.f, d_log,

@@ -70,6 +70,10 @@ int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_b
 int mmx_launch_y6(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q, float cp, float cq,
                   float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);
+// the same on the matrix cores (mmx_ymfma.hip): 16-bit tiles only, radius <= 24; MMX_ERR_UNSUPPORTED otherwise
+int mmx_launch_ym(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
+                  const mmx_taps_f32& taps, int radius, const float* d_p, float cp, float cq,
+                  float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);
 int mmx_launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slot_elems,
                   const mmx_taps_f32& taps, int radius, const float* d_p, const float* d_q,
                   float* d_log, unsigned long long* d_mask, float nms_lo, float nms_eps, hipStream_t stream);

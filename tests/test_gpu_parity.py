@@ -103,7 +103,7 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
             # the fused kernels really ran (wherever the geometry lets any register-resident pass run)
             assert kinds["zxpass"][1] > 0 or kinds["generic"][1] > 0 or kinds["zpass"][1] > 0
             assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL, (mode, bl.LAST_ZX_PATH)
-            # (mode 7 hands 16-bit intermediates to the Y pass: error <= 4.3e-5 of the value scale)
+            # (mode 7 hands 16-bit intermediates to the Y pass: error <= 5.1e-5 of the value scale)
             assert np.max(np.abs(fused - sep)) < (4.5e-5 if bl.LAST_ZX_PATH == 7 else 2e-6) * max(1.0, float(np.abs(sep).max()))
     finally:
         bl.ZX_MODE = default
@@ -131,7 +131,7 @@ def test_blob_log_identical_to_reference(gpu, case, host_path):
     np.testing.assert_array_equal(res[0], res_o)
     if stats.n_candidates:
         # a quarter of the nomination band: 5e-6 for the float32 paths, 5e-5 where the default path hands 16-bit
-        # intermediates to the Y pass (raw integer volumes, radii <= 24; their bound is 4.3e-5)
+        # intermediates to the Y pass (raw integer volumes, radii <= 24; their bound is 5.1e-5)
         q16 = bl.LAST_ZX_PATH == 7
         assert stats.max_f32_error < (4.4e-5 if q16 else 5e-6) * max(1.0, float(np.abs(g["volume"]).max())
                                                                      if g["volume"].dtype.kind == "f" else 1.0)
@@ -521,7 +521,7 @@ def test_every_kernel_radius_matches_oracle(gpu, fused):
             if fused == 7:      # 16-bit intermediates: the bound the library states for these weights
                 tol = nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[0]), nat.as_double_ptr(space.w2[0]),
                                                           R, float(space.norms[0]))
-                assert 3.5e-5 < tol < 7e-5
+                assert 3.5e-5 < tol < 8e-5
             assert np.abs(got - want).max() < tol, R
             # the kernel asked for is the kernel that ran (its geometry conditions hold for this volume)
             if fused in (2, 3) and 1 <= R <= 24:
@@ -746,7 +746,7 @@ def test_a_band_narrower_than_the_float32_error_widens_itself(gpu, monkeypatch):
                              int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]), stats=stats)[0]
     assert stats.n_band_retries >= 1 and stats.n_blocks == 1
     np.testing.assert_array_equal(got, g["pruned"])
-    # the 16-bit intermediates forced under a band their error (<= 4.3e-5) does not fit: same way out
+    # the 16-bit intermediates forced under a band their error (<= 5.1e-5) does not fit: same way out
     monkeypatch.setattr(bl, "EPS_REL_Q16", 2e-5)
     monkeypatch.setattr(bl, "ZX_MODE", nat.MMX_ZX_TILED_Q16)
     stats = bl.BatchStats()
@@ -828,13 +828,13 @@ def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
     assert np.array_equal(k6, ka) and np.array_equal(v6, va)
     # 16-bit intermediates: what AUTO picks once the band covers their rounding error fourfold.  Every candidate of the
     # narrow band is still nominated, its value within the bound the library states for these weights.
-    p7, l7, k7, v7, f7 = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_AUTO, True, eps=2e-4)
+    p7, l7, k7, v7, f7 = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_AUTO, True, eps=2.5e-4)
     assert (p7, l7) == (nat.MMX_ZX_TILED_Q16, nat.MMX_MASK_QUADS)
     from magellanmapper_amd import kernels1d as k1
     bound = max(nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(k1.gaussian_half_kernel(s_, 0, k1.kernel_radius(s_))),
                                                     nat.as_double_ptr(k1.gaussian_half_kernel(s_, 2, k1.kernel_radius(s_))),
                                                     k1.kernel_radius(s_), s_ * s_) for s_ in sig)
-    assert 4e-5 < bound < 4.9e-5
+    assert 4e-5 < bound < 5.3e-5
     pos = {tuple(r): i for i, r in enumerate(k7)}
     idx = [pos.get(tuple(r), -1) for r in k2]
     assert min(idx) >= 0
@@ -879,8 +879,8 @@ def test_zx_pack_refuses_what_the_tiled_path_cannot_take(gpu):
     ws2 = torch.zeros(6 * slot + 64, dtype=torch.float32, device=dvol.tensor.device)
     mask = torch.zeros(slot // 2 + 64, dtype=torch.uint8, device=dvol.tensor.device)
     written, path = ctypes.c_int(0), ctypes.c_int(0)
-    for rng_, eps, expect in ((1.0, 2e-5, nat.MMX_ZX_TILED), (1.0, 2e-4, nat.MMX_ZX_TILED_Q16), (-1.0, 2e-4, nat.MMX_ZX_TILED),
-                              (0.0, 2e-4, nat.MMX_ZX_PACKED)):
+    for rng_, eps, expect in ((1.0, 2e-5, nat.MMX_ZX_TILED), (1.0, 2.5e-4, nat.MMX_ZX_TILED_Q16), (-1.0, 2.5e-4, nat.MMX_ZX_TILED),
+                              (0.0, 2.5e-4, nat.MMX_ZX_PACKED)):
         v32.value_range = rng_
         nat.check(nat.lib().mmx_log_batch_f32(
             ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, 1, slot, nat.as_double_ptr(space.w0[0]),

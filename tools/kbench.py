@@ -58,7 +58,7 @@ for rep in range(a.reps + 1):
         nat.check(fn(ctypes.byref(v32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
                      nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, s * s,
                      log_base + i * nb * slot * 4, ws.data_ptr(), *(() if a.generic else ((masks.data_ptr() + i * mask_words * 16) if a.mask else None, 0.1 - 2e-5, 2e-5,
-                                                    ctypes.byref(written), ((ZX if ZX in (6, 7) else 6) | 0x100) if packed else ZX, ctypes.byref(zxp))), stream), "log")
+                                                    ctypes.byref(written), ((ZX if ZX in (6, 7) else 6) | 0x100 | (0x200 if os.environ.get('MMX_Y_VALU') == '1' else 0)) if packed else ZX, ctypes.byref(zxp))), stream), "log")
         assert not a.mask or written.value in (1, 2)
         layout = written.value
         if rep >= 1:

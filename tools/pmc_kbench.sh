@@ -18,7 +18,7 @@ for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         k = ("pack" if "pack_kernel" in k else "zx" if ("zx" in k and "setup" not in k) else
-             "y2" if "y2_kernel" in k else "y6" if "y6_kernel" in k else None)
+             "y2" if "y2_kernel" in k else "y6" if "y6_kernel" in k else "ym" if "ym_kernel" in k else None)
         if k:
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 for k in tot:
