@@ -447,8 +447,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                 "frac_of_copy": None if not ctx.get("copy_gbps") else round(stream_k[dom]["alg_GBps"] / ctx["copy_gbps"], 4),
                 "note": "achieved = SURVEY.md 8d's algorithmic bytes of this pass (zxpass: 2 B voxels in + 8 B "
                         "intermediates out per volume voxel and sigma) / its HIP-event time; the kernel itself moves "
-                        "fewer bytes than that ('traffic'): its intermediates are 16-bit fixed point and it is bound by "
-                        "instruction issue, not by HBM (DESIGN.md section 4b)" if dom == "zxpass" else None}
+                        "fewer bytes than that ('traffic'): its intermediates are 16-bit fixed point, and with the VALU and "
+                        "the MFMA pipe each about half busy it waits for its L2 requests, not for HBM (DESIGN.md section 4b)"
+                        if dom == "zxpass" else None}
         if dom == "zxpass" and zx_path in (nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16):
             # the same kernel against the matrix-core roofline: MFMAs it issues (16 x 16 x 32 float16, 16 384 flop
             # each) per 16 x 16 tile step -- X pass 12 (16-bit tiles) or 16 per two k-steps, 6 / 8 for radius <= 8;
@@ -489,6 +490,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         "dtype": ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate") if PROFILE["denoise_size"] is None
                  else "f64 preprocessing; " + ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate"),
         "zx_path": zx_path, "host_path": bl.HOST_PATH,
+        "y_kernel": (None if zx_path != nat.MMX_ZX_TILED_Q16 else
+                     "y6_kernel (VALU taps)" if bl.ZX_FLAGS & nat.MMX_ZX_Y_VALU else "ym_kernel (matrix cores)"),
         "data": "synthetic" if use_vol is None else args.volume,
         "config": {"workload": f"{name}: {shape[2]}x{shape[1]}x{shape[0]} (x,y,z) uint16 Gaussian-blob volume, "
                                f"seed {seed}, {n_blocks} blocks (segment_size {PROFILE['segment_size']}, overlap 5), {cfg['what']}, "

@@ -550,7 +550,7 @@ def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: Sc
                      nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
                      int(space.radii[s]), float(space.norms[s]),
                      log_base + s * nb * slot * 4, ws.data_ptr(),
-                     *(() if generic else (None, 0.0, 0.0, None, ZX_MODE, ctypes.byref(path))),
+                     *(() if generic else (None, 0.0, 0.0, None, ZX_MODE | ZX_FLAGS if ZX_MODE >= 0 else ZX_MODE, ctypes.byref(path))),
                      _stream_ptr()), "mmx_log_batch_f32")
         LAST_ZX_PATH = None if generic else path.value
     torch.cuda.synchronize()

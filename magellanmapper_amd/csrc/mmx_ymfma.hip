@@ -244,8 +244,12 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     };
 
     // ---- k-blocks of 32 input rows: block b holds rows -RB + 32 b + [0, 32), lane row 8 kq + i
-    u4_y raw[8];
-    auto load_block = [&](int b) __attribute__((always_inline)) {
+#ifndef YM_PFD
+#define YM_PFD 1
+#endif
+    constexpr int PFD = YM_PFD;                     // k-blocks of loads in flight per wave
+    u4_y rawA[8], rawB[PFD == 2 ? 8 : 1];
+    auto load_block = [&](int b, u4_y (&raw)[8]) __attribute__((always_inline)) {
         const int r0 = -RB + 32 * b;
         if (r0 >= 0 && r0 + 32 <= n) {
 #pragma unroll
@@ -334,16 +338,13 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
         __builtin_amdgcn_wave_barrier();
     };
 
-    load_block(0);
-#pragma unroll 1
-    for (int b = 0; b <= nKB; ++b) {
-        // -- rows of the tiles the previous block finished (before this block's operands take their registers; their
-        //    stores are older than the loads issued below, so waiting for those does not wait for these)
-#ifndef YM_NOROWS
+    // one k-block: rows of the tiles the previous block finished, this block's pieces, the next loads, the MFMAs
+    auto iter = [&](int b, u4_y (&raw)[8]) __attribute__((always_inline)) {
+        // -- rows first (before this block's operands take their registers; their stores are older than the loads
+        //    issued below, so waiting for those does not wait for these)
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) rows_of(2 * (b - 1) - NB + 2 + h, h, h ? any1 : any0);
-#endif
-        if (b == nKB) break;
+        if (b == nKB) return false;
         __builtin_amdgcn_sched_barrier(0);
         // -- the four float16 pieces of every dword, one byte permute each
 #pragma unroll
@@ -358,9 +359,22 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
                 pc[j][3][p] = __builtin_amdgcn_perm(d1, d0, 0x0c060c02u);
             }
         __builtin_amdgcn_sched_barrier(0);
-        if (b + 1 < nKB) load_block(b + 1);
+        if (b + PFD < nKB) load_block(b + PFD, raw);
         __builtin_amdgcn_sched_barrier(0);
         mfma_phase();
+        return true;
+    };
+    load_block(0, rawA);
+    if constexpr (PFD == 2) {
+        if (nKB > 1) load_block(1, reinterpret_cast<u4_y (&)[8]>(rawB));
+#pragma unroll 1
+        for (int b = 0;; b += 2) {
+            if (!iter(b, rawA)) break;
+            if (!iter(b + 1, reinterpret_cast<u4_y (&)[8]>(rawB))) break;
+        }
+    } else {
+#pragma unroll 1
+        for (int b = 0; iter(b, rawA); ++b) {}
     }
     if constexpr (MASK) {     // the last row has no successor
         unsigned long long m = 0;

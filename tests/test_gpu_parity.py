@@ -497,13 +497,17 @@ def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
         detector.Blobs(np.ones((1, 4))).format_blobs()
 
 
-@pytest.mark.parametrize("fused", [0, 2, 3, 4, 5, 6, 7])
-def test_every_kernel_radius_matches_oracle(gpu, fused):
+@pytest.mark.parametrize("fused", [0, 2, 3, 4, 5, 6, 7, "7 + Y on the VALU"])
+def test_every_kernel_radius_matches_oracle(gpu, fused, monkeypatch):
     """Each compiled radius (1..24 register-resident, 25 generic) of the separable passes against the
     float64 oracle cube.  Regression: the X pass read its register window in pairs but sized it odd for
-    odd radii (undefined behaviour that showed as NaNs for R = 3..11)."""
+    odd radii (undefined behaviour that showed as NaNs for R = 3..11).  Mode 7 runs its Y pass on the matrix cores
+    (ym_kernel: three row tiles here, both mirrored ends inside one k-block) and, with MMX_ZX_Y_VALU, on the VALU."""
     from magellanmapper_amd import _native as nat, blob_log as bl, synth
     from oracle import blob_log_oracle as blo
+    if fused == "7 + Y on the VALU":
+        fused = 7
+        monkeypatch.setattr(bl, "ZX_FLAGS", nat.MMX_ZX_Y_VALU)
     if fused in (3, 4, 5) and not nat.lib().mmx_has_experiments():
         pytest.skip("zx_mode 3 / 4 / 5 are built with `make EXPERIMENTS=1` only (a stock library runs the packed kernel)")
     vol = synth.make_volume(3, (35, 42, 48), 12)
@@ -840,6 +844,32 @@ def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
     assert min(idx) >= 0
     assert np.max(np.abs(v7[idx] - v2)) < bound
     assert np.all(f7 & nat.MMX_CAND_BAND)
+
+
+def test_y_pass_on_the_matrix_cores_agrees_with_the_valu_kernel(gpu):
+    """``MMX_ZX_TILED_Q16`` runs its Y pass on the matrix cores (``ym_kernel``); ``| MMX_ZX_Y_VALU`` asks for ``y6_kernel``
+    on the same 16-bit tiles.  Both read the same tiles, so their values differ only by the float32 arithmetic and the low
+    x low product the MFMA form leaves out (0.062 counts per unit of weight: under 1e-5 here); the candidates of either are
+    those of the other up to the few whose value sits at the edge of the band.  Blocks whose y extent is below one k-block,
+    not a multiple of 16, and long; radii of both fragment classes (R <= 16: 4 block offsets, R <= 24: 6)."""
+    from magellanmapper_amd import _native as nat, synth
+    vol = synth.make_volume(9, (60, 140, 120), 60)
+    origins = [(0, 0, 0), (5, 3, 40), (11, 20, 7), (30, 0, 50)]
+    shapes = [(40, 29, 64), (50, 37, 70), (33, 120, 37), (30, 140, 26)]
+    for sig in ([2.0, 3.5], [4.25, 5.0, 6.0]):
+        pm, lm, km, vm, fm = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED_Q16, False, eps=2.5e-4)
+        pv, lv, kv, vv, fv = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED_Q16 | nat.MMX_ZX_Y_VALU, False, eps=2.5e-4)
+        pp, lp, kp, vp, fp = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED_Q16, True, eps=2.5e-4)
+        assert (pm, lm) == (pv, lv) == (pp, lp) == (nat.MMX_ZX_TILED_Q16, nat.MMX_MASK_QUADS)
+        assert np.array_equal(km, kp) and np.array_equal(vm, vp) and np.array_equal(fm, fp)      # same kernel, prepacked copy
+        a = {tuple(r): i for i, r in enumerate(km)}
+        common = [(a[tuple(r)], i) for i, r in enumerate(kv) if tuple(r) in a]
+        assert len(km) >= 30 and len(common) >= 0.97 * max(len(km), len(kv)), (len(km), len(kv), len(common))
+        ia, ib = np.array(common).T
+        assert np.max(np.abs(vm[ia] - vv[ib])) < 1e-5
+        # whatever one nominates and the other does not is at the edge of the band: within 1e-5 of a limit either could
+        # have put it on the other side of (checked on the values of the kernel that did nominate it)
+        assert len(set(map(tuple, km)) ^ set(map(tuple, kv))) <= 0.03 * len(km) + 2
 
 
 def test_zx_pack_refuses_what_the_tiled_path_cannot_take(gpu):
