@@ -64,24 +64,39 @@ __device__ __forceinline__ f4_y mfma_y(const u4_y& a, const u4_y& b, const f4_y&
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_y, a), __builtin_bit_cast(h8_y, b), c, 0, 0, 0);
 }
 
+// Workgroup = four waves = one tile column.  NB == 4 (R <= 16): 164 registers and 48 KiB of LDS, three workgroups per
+// CU; NB == 6 (R <= 24): 195 registers and 56 KiB, two.  (Measured for NB == 6 and kept as the YM6_* switches: pieces
+// built for two column sets at a time -- 32 registers less, the fragments read twice -- with TWELVE waves = three tile
+// columns sharing one fragment table, i.e. three waves per SIMD too: 2.42 against 1.99 ms per 64 blocks -- the LDS then
+// carries as many cycles of fragment reads as the matrix pipe has MFMAs.)
+#ifndef YM5_OCC
+#define YM5_OCC 2
+#endif
+#ifndef YM6_WAVES
+#define YM6_WAVES 4
+#define YM6_JH 4
+#define YM6_NF 4
+#endif
 template <int NB, bool MASK>
-__global__ void __launch_bounds__(256, NB == 4 ? 3 : 2)
+__global__ void __launch_bounds__(NB <= 4 ? 256 : YM6_WAVES * 64, NB <= 4 ? 3 : (YM6_WAVES == 4 ? YM5_OCC : 1))
 ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile_stride,
           const unsigned* __restrict__ gt, float* __restrict__ out, ym_cfg cfg,
           unsigned long long* __restrict__ mask)
 {
     constexpr int RB = 8 * (NB - 2);            // rows a k-block starts before the first output tile it feeds
-    __shared__ u4_y frag[NB * 4 * 64];          // [t][kernel: G'' (P), G (Q)][piece: wh, wl][lane]  (256 wh is made from wh)
-    __shared__ float tr[4 * 2 * 1024];          // per wave: two finished tiles of 16 rows x 64 columns
+    constexpr int NF = NB <= 4 ? 4 : YM6_NF;    // fragments per tile: [kernel: G'' (P), G (Q)][piece: wh, wl(, 256 wh)]
+    __shared__ u4_y frag[NB * NF * 64];         // (NF == 4: 256 wh is made from wh -- 16 KiB instead of 24: the third workgroup)
+    constexpr int WAVES = NB <= 4 ? 4 : YM6_WAVES;     // per workgroup: WAVES / 4 tile columns
+    constexpr int JH = NB <= 4 ? 4 : YM6_JH;           // column sets whose pieces are held at a time
+    __shared__ float tr[WAVES * 2 * 1024];      // per wave: two finished tiles of 16 rows x 64 columns
 
     const mmx_block bd = blocks[blockIdx.y];
     const int ntx = (bd.nx + 15) >> 4, ntz = (bd.nz + 15) >> 4;
-    const int tile = blockIdx.x;
-    if (tile >= ntx * ntz) return;              // (the whole workgroup)
+    if ((int)blockIdx.x * (WAVES / 4) >= ntx * ntz) return;     // (the whole workgroup)
     // ---- Toeplitz fragments: A[m][k] = w[|k - m + delta_t|], lane = (m = l & 15, k = 8 (l >> 4) + i)
-    for (int e = threadIdx.x; e < NB * 4 * 64; e += 256) {
+    for (int e = threadIdx.x; e < NB * NF * 64; e += WAVES * 64) {
         const int ln = e & 63, f = e >> 6;
-        const int piece = f & 1, kern = (f >> 1) & 1, t = f >> 2;
+        const int piece = (f % NF) % (NF / 2), kern = (f % NF) / (NF / 2), t = f / NF;
         const int m = ln & 15, kq = ln >> 4;
         const int delta = RB - 16 * t;
         unsigned pk[4];
@@ -94,7 +109,7 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
                 d = d < 0 ? -d : d;
                 const float ws = d <= cfg.radius ? (kern ? cfg.w0[d] : cfg.w2[d]) : 0.f;
                 const float h = (float)(_Float16)ws;
-                v[u] = piece == 0 ? h : (ws - h) * 256.f;
+                v[u] = piece == 0 ? h : (piece == 1 ? (ws - h) * 256.f : h * 256.f);
             }
             pk[i >> 1] = pack_h2y(v[0], v[1]);
         }
@@ -102,9 +117,12 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     }
     __syncthreads();
 
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = (int)blockIdx.x * (WAVES / 4) + (wv >> 2);
+    if (tile >= ntx * ntz) return;                              // (whole waves; no barriers below)
     const int c = tile / ntz, U = tile - c * ntz;
-    const int zq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (16 * U + 4 * zq >= bd.nz) return;                       // whole wave past the block (no barriers below)
+    const int zq = wv & 3;
+    if (16 * U + 4 * zq >= bd.nz) return;                       // whole wave past the block
     const int lane = threadIdx.x & 63;
     const int n = bd.ny;
     const float nms_lo = cfg.lo, nms_eps = cfg.eps, us = cfg.unscale;
@@ -130,7 +148,7 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     const bool has_l = xi > 0, has_r = xi < 15 && x + 1 < bd.nx;
     float prev1 = -INFINITY, prev2 = -INFINITY, nbx_prev = -INFINITY;
     int ydone = 0;
-    float* trw = tr + zq * 2048;
+    float* trw = tr + wv * 2048;
 
     // one output row (y6_kernel's step after its taps; values and thresholds in accumulator units)
     auto row = [&](float acc, int y) __attribute__((always_inline)) {
@@ -277,57 +295,88 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     bool any0 = false, any1 = false;                // of the two tiles waiting in LDS
 
     const _Float16 k256 = (_Float16)256.f;
-    // the MFMAs of one k-block
-    u4_y pc[4][4];                                  // float16 pieces of the block: [j][Phi, Plo, Qhi, Qlo], k pairs (2p, 2p + 1)
-    auto mfma_phase = [&]() __attribute__((always_inline)) {
-        // output tile T = 2 b - NB + 2 + t.  Tiles t = 0, 1 get their last block here and leave for LDS at once (their
-        // registers are free for the two tiles that start with this block: t = NB - 2, NB - 1)
-        auto tile_mfmas = [&](int t, f4_y (&a)[4], bool fresh) __attribute__((always_inline)) {
-#ifdef YM_NOMFMA
-            if (t >= 0) { for (int j = 0; j < 4; ++j) a[j] = fresh ? __builtin_bit_cast(f4_y, pc[j][t & 3]) : a[j] + __builtin_bit_cast(f4_y, pc[j][t & 3]); return; }
-#endif
-            const u4_y* fr = frag + (t * 4) * 64 + lane;
-            const u4_y ah = fr[0], al = fr[64], bh = fr[128], bl = fr[192];
-            // (x 256: an exponent shift, exact)
-            const u4_y a256 = __builtin_bit_cast(u4_y, __builtin_bit_cast(h8_y, ah) * k256);
-            const u4_y b256 = __builtin_bit_cast(u4_y, __builtin_bit_cast(h8_y, bh) * k256);
+    // one k-block: rows of the tiles the previous block finished, then per group of JH column sets: this block's pieces,
+    // (last group: the next block's loads,) the MFMAs, the hand-off of the two tiles that are complete
+    auto iter = [&](int b, u4_y (&raw)[8]) __attribute__((always_inline)) {
+        // -- rows first (before this block's operands take their registers; their stores are older than the loads
+        //    issued below, so waiting for those does not wait for these)
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) rows_of(2 * (b - 1) - NB + 2 + h, h, h ? any1 : any0);
+        if (b == nKB) return false;
+        if constexpr (JH < 4) { any0 = !MASK; any1 = !MASK; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = mfma_y(a256, pc[j][0], fresh ? start : a[j]);
+        for (int j0 = 0; j0 < 4; j0 += JH) {
+            __builtin_amdgcn_sched_barrier(0);
+            // -- the four float16 pieces of every dword, one byte permute each: [j][Phi, Plo, Qhi, Qlo], k pairs (2p, 2p + 1)
+            u4_y pc[JH][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = mfma_y(ah, pc[j][1], a[j]);
+            for (int j = 0; j < JH; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = mfma_y(al, pc[j][0], a[j]);
+                for (int p = 0; p < 4; ++p) {
+                    const unsigned d0 = raw[2 * p][j0 + j], d1 = raw[2 * p + 1][j0 + j];
+                    // v_perm_b32 {S0 = d1, S1 = d0}: selector 0-3 = bytes of d0, 4-7 = bytes of d1, 0x0c = 0x00
+                    pc[j][0][p] = __builtin_amdgcn_perm(d1, d0, 0x0c050c01u);
+                    pc[j][1][p] = __builtin_amdgcn_perm(d1, d0, 0x0c040c00u);
+                    pc[j][2][p] = __builtin_amdgcn_perm(d1, d0, 0x0c070c03u) ^ 0x00800080u;
+                    pc[j][3][p] = __builtin_amdgcn_perm(d1, d0, 0x0c060c02u);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j0 + JH == 4 && b + PFD < nKB) load_block(b + PFD, raw);
+            __builtin_amdgcn_sched_barrier(0);
+            // -- output tile T = 2 b - NB + 2 + t.  Tiles t = 0, 1 get their last block here and leave for LDS at once
+            //    (their registers are free for the two tiles that start with this block: t = NB - 2, NB - 1)
+            auto tile_mfmas = [&](int t, bool fresh) __attribute__((always_inline)) {
+                f4_y* a = &acc[t][j0];
+                const u4_y* fr = frag + (t * NF) * 64 + lane;
+                const u4_y ah = fr[0], al = fr[64], bh = fr[(NF / 2) * 64], bl = fr[(NF / 2 + 1) * 64];
+                // (x 256: an exponent shift, exact)
+                const u4_y a256 = NF == 6 ? fr[128] : __builtin_bit_cast(u4_y, __builtin_bit_cast(h8_y, ah) * k256);
+                const u4_y b256 = NF == 6 ? fr[320] : __builtin_bit_cast(u4_y, __builtin_bit_cast(h8_y, bh) * k256);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = mfma_y(b256, pc[j][2], a[j]);
+                for (int j = 0; j < JH; ++j) a[j] = mfma_y(a256, pc[j][0], fresh ? start : a[j]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = mfma_y(bh, pc[j][3], a[j]);
+                for (int j = 0; j < JH; ++j) a[j] = mfma_y(ah, pc[j][1], a[j]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = mfma_y(bl, pc[j][2], a[j]);
-        };
+                for (int j = 0; j < JH; ++j) a[j] = mfma_y(al, pc[j][0], a[j]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) tile_mfmas(t, acc[t], false);
-        // (accumulator register r of lane (g, n16) is row 4 g + r, column 4 n16 + j of the wave's 64)
+                for (int j = 0; j < JH; ++j) a[j] = mfma_y(b256, pc[j][2], a[j]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f4_y (&a)[4] = acc[t];
-            float mx = -INFINITY;
+                for (int j = 0; j < JH; ++j) a[j] = mfma_y(bh, pc[j][3], a[j]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < JH; ++j) a[j] = mfma_y(bl, pc[j][2], a[j]);
+            };
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, a[j][r]);
-            const bool any = MASK ? __ballot(mx > nms_lo) != 0ull : true;
-            if (t == 0) any0 = any; else any1 = any;
-            if (any) {
-                f4_y* dst = reinterpret_cast<f4_y*>(trw + t * 1024) + (4 * kq) * 16 + n16;
+            for (int t = 0; t < 2; ++t) tile_mfmas(t, t >= NB - 2);      // (NB == 3: tile 1 starts and ends in this block)
+            // (accumulator register r of lane (g, n16) is row 4 g + r, column 4 n16 + j of the wave's 64)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r * 16] = (f4_y){a[0][r], a[1][r], a[2][r], a[3][r]};
+            for (int t = 0; t < 2; ++t) {
+                const f4_y* a = &acc[t][j0];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < JH; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, a[j][r]);
+                const bool any = MASK ? __ballot(mx > nms_lo) != 0ull : true;
+                if constexpr (JH == 4) {
+                    if (t == 0) any0 = any; else any1 = any;
+                    if (any) {
+                        f4_y* dst = reinterpret_cast<f4_y*>(trw + t * 1024) + (4 * kq) * 16 + n16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[r * 16] = (f4_y){a[0][r], a[1][r], a[2][r], a[3][r]};
+                    }
+                } else {        // (half a tile: the other half may be what is above the threshold)
+                    if (t == 0) any0 |= any; else any1 |= any;
+                    f2_y* dst = reinterpret_cast<f2_y*>(trw + t * 1024) + (4 * kq) * 32 + 2 * n16 + (j0 >> 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r * 32] = (f2_y){a[0][r], a[1][r]};
+                }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);     // (the finished tiles' registers are free from here on)
+            __builtin_amdgcn_sched_barrier(0);     // (the finished tiles' registers are free from here on)
 #pragma unroll
-        for (int t = 2; t < NB; ++t) {
-            tile_mfmas(t, acc[t], t >= NB - 2);
-            if constexpr (NB > 4) __builtin_amdgcn_sched_barrier(0);       // one tile's fragments at a time: 6 x 4 registers
+            for (int t = 2; t < NB; ++t) {
+                tile_mfmas(t, t >= NB - 2);
+                if constexpr (NB > 4) __builtin_amdgcn_sched_barrier(0);       // one tile's fragments at a time
+            }
         }
         // the window moves on by two tiles (a rotation by renaming needs the loop unrolled NB / 2 times with the row code in
         // every copy -- 70 KiB of instructions --, or a switch, after which the compiler keeps every set alive: 251 registers)
@@ -336,32 +385,6 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t][j] = acc[t + 2][j];
         __builtin_amdgcn_wave_barrier();
-    };
-
-    // one k-block: rows of the tiles the previous block finished, this block's pieces, the next loads, the MFMAs
-    auto iter = [&](int b, u4_y (&raw)[8]) __attribute__((always_inline)) {
-        // -- rows first (before this block's operands take their registers; their stores are older than the loads
-        //    issued below, so waiting for those does not wait for these)
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) rows_of(2 * (b - 1) - NB + 2 + h, h, h ? any1 : any0);
-        if (b == nKB) return false;
-        __builtin_amdgcn_sched_barrier(0);
-        // -- the four float16 pieces of every dword, one byte permute each
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const unsigned d0 = raw[2 * p][j], d1 = raw[2 * p + 1][j];
-                // v_perm_b32 {S0 = d1, S1 = d0}: selector 0-3 = bytes of d0, 4-7 = bytes of d1, 0x0c = 0x00
-                pc[j][0][p] = __builtin_amdgcn_perm(d1, d0, 0x0c050c01u);
-                pc[j][1][p] = __builtin_amdgcn_perm(d1, d0, 0x0c040c00u);
-                pc[j][2][p] = __builtin_amdgcn_perm(d1, d0, 0x0c070c03u) ^ 0x00800080u;
-                pc[j][3][p] = __builtin_amdgcn_perm(d1, d0, 0x0c060c02u);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        if (b + PFD < nKB) load_block(b + PFD, raw);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_phase();
         return true;
     };
     load_block(0, rawA);
@@ -390,12 +413,13 @@ template <int NB>
 int launch_ym(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& plan, int64_t slot_elems,
               const ym_cfg& cfg, const float* d_p, float* d_log, unsigned long long* d_mask, hipStream_t s)
 {
-    dim3 grid(plan.max_tiles, n_blocks);
+    constexpr int TPW = NB <= 4 ? 1 : YM6_WAVES / 4;        // tile columns per workgroup
+    dim3 grid((plan.max_tiles + TPW - 1) / TPW, n_blocks);
     if (d_mask)
-        hipLaunchKernelGGL((ym_kernel<NB, true>), grid, dim3(256), 0, s, d_blocks, slot_elems, plan.tile_stride,
+        hipLaunchKernelGGL((ym_kernel<NB, true>), grid, dim3(256 * TPW), 0, s, d_blocks, slot_elems, plan.tile_stride,
                            reinterpret_cast<const unsigned*>(d_p), d_log, cfg, d_mask);
     else
-        hipLaunchKernelGGL((ym_kernel<NB, false>), grid, dim3(256), 0, s, d_blocks, slot_elems, plan.tile_stride,
+        hipLaunchKernelGGL((ym_kernel<NB, false>), grid, dim3(256 * TPW), 0, s, d_blocks, slot_elems, plan.tile_stride,
                            reinterpret_cast<const unsigned*>(d_p), d_log, cfg, d_mask);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
 }
@@ -433,6 +457,9 @@ int mmx_launch_ym(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& p
     cfg.lo = nms_lo / cfg.unscale;
     cfg.eps = nms_eps / cfg.unscale;
     cfg.radius = radius;
-    return radius <= 16 ? launch_ym<4>(d_blocks, n_blocks, plan, slot_elems, cfg, d_p, d_log, d_mask, stream)
-                        : launch_ym<6>(d_blocks, n_blocks, plan, slot_elems, cfg, d_p, d_log, d_mask, stream);
+    // NB block offsets cover every tap when the first offset beyond either end, RB + 16 - 15 and 16 NB - RB - 31 rows away,
+    // is out of reach: R <= 8 (NB - 2) with RB = 8 (NB - 2)
+    if (radius <= 8) return launch_ym<3>(d_blocks, n_blocks, plan, slot_elems, cfg, d_p, d_log, d_mask, stream);
+    if (radius <= 16) return launch_ym<4>(d_blocks, n_blocks, plan, slot_elems, cfg, d_p, d_log, d_mask, stream);
+    return launch_ym<5>(d_blocks, n_blocks, plan, slot_elems, cfg, d_p, d_log, d_mask, stream);
 }
