@@ -470,7 +470,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                                     "product) over its duration, against the dense float16 peak"}
     gpu_ms = sum(ms for ms, n in ktimes.values()) / steps
     # (per-block preprocessing runs on a stream of its own beside the LoG kernels: its spans overlap theirs)
-    overlapped = ("preproc",) if (PROFILE["denoise_size"] and bl.PRE_STREAM) else ()
+    overlapped = ("preproc",) if (PROFILE["denoise_size"] and bl.PRE_STREAM) else (
+        ("peaks", "rescore") if (bl.RESCORE_STREAM and not PROFILE["denoise_size"]) else ())
     main_ms = sum(ms for k, (ms, n) in ktimes.items() if k in MAIN_STREAM and k not in overlapped) / steps
     b_alg = B_ALG_PER_SIGMA * ns * n_chl
     vol_bytes = nvox * n_chl * 2

@@ -300,8 +300,13 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     auto iter = [&](int b, u4_y (&raw)[8]) __attribute__((always_inline)) {
         // -- rows first (before this block's operands take their registers; their stores are older than the loads
         //    issued below, so waiting for those does not wait for these)
+#ifndef YM_ROWS_LATE
+#define YM_ROWS_LATE 1
+#endif
+        if (!YM_ROWS_LATE || b == nKB) {
 #pragma unroll 1
-        for (int h = 0; h < 2; ++h) rows_of(2 * (b - 1) - NB + 2 + h, h, h ? any1 : any0);
+            for (int h = 0; h < 2; ++h) rows_of(2 * (b - 1) - NB + 2 + h, h, h ? any1 : any0);
+        }
         if (b == nKB) return false;
         if constexpr (JH < 4) { any0 = !MASK; any1 = !MASK; }
 #pragma unroll
@@ -323,6 +328,11 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
             __builtin_amdgcn_sched_barrier(0);
             if (j0 + JH == 4 && b + PFD < nKB) load_block(b + PFD, raw);
             __builtin_amdgcn_sched_barrier(0);
+            if (YM_ROWS_LATE && JH == 4) {
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) rows_of(2 * (b - 1) - NB + 2 + h, h, h ? any1 : any0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // -- output tile T = 2 b - NB + 2 + t.  Tiles t = 0, 1 get their last block here and leave for LDS at once
             //    (their registers are free for the two tiles that start with this block: t = NB - 2, NB - 1)
             auto tile_mfmas = [&](int t, bool fresh) __attribute__((always_inline)) {

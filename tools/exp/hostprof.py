@@ -10,7 +10,7 @@ config.setup_roi_profiles(None); config.roi_profile.update(bench.PROFILE)
 vol = synth.make_volume_device(shape, 3, dev)
 dvol = bl.DeviceVolume(vol)
 blocks = stack_detect.setup_blocks(config.roi_profile, shape)
-bl.blob_log_blocks = functools.partial(bl.blob_log_blocks, budget_bytes=64 << 30)
+bl.blob_log_blocks = functools.partial(bl.blob_log_blocks, budget_bytes=16 << 30)
 def step():
     seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, dvol, blocks.sub_roi_slices, blocks.sub_rois_offsets, None, None, False, [0])
     out = stack_detect.StackPruner.prune_blobs_mp(dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices, blocks.sub_rois_offsets, [0], blocks.overlap_padding)

@@ -1,3 +1,4 @@
+import os
 #!/usr/bin/env python3
 """Host timeline of one full-volume step (c3): when each batch is enqueued, when the host starts / ends finishing
 it, when the GPU goes idle, how long the tail after the last kernel is and what it consists of.
@@ -50,6 +51,17 @@ def wrap(mod, name, tag):
 
 evs = []
 wrap(bl, "_enqueue_detect", "enqueue batch")
+if os.environ.get("TRACE_PROLOGUE"):
+    wrap(bl, "_make_blocks", "  block records of a batch")
+    wrap(bl, "_to_device_bytes", "  block records -> device")
+    wrap(bl, "plan_batches", "  plan_batches")
+    wrap(bl, "_buffers_for", "  _buffers_for")
+    wrap(bl.DeviceVolume, "value_range", "  value_range")
+    wrap(bl.DeviceVolume, "value_scale", "  value_scale")
+    wrap(bl.ScaleSpace, "device_tables", "  scale-space tables -> device")
+    wrap(stack_detect.StackDetector, "plan_pruning", "  plan_pruning")
+    wrap(bl._Buffers, "workspace", "  workspace")
+    wrap(bl._Buffers, "slots", "  slots")
 wrap(bl, "_finish_detect", "finish batch (candidates -> peaks)")
 wrap(bl, "_prune_batch", "per-block overlap prune")
 wrap(bl, "_prune_batch_native", "per-block overlap prune (native)")
