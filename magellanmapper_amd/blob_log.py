@@ -87,6 +87,7 @@ PRE_STREAM = os.environ.get("MMX_PRE_STREAM", "1") != "0"
 #: 4.5 ms and the Z+X kernel 59 instead of 53 when they run beside each other; the re-score alone on the side stream,
 #: one workspace: -2.8 ms)
 RESCORE_STREAM = os.environ.get("MMX_RESCORE_STREAM", "1") != "0"
+PACK_STREAM = os.environ.get("MMX_PACK_STREAM", "0") == "1"
 #: candidate-table entries copied to pinned host memory together with the counts, before the host knows how many
 #: there are (a batch of the benchmark volume holds ~3e4; more entries cost a second, synchronous copy)
 _PREFIX_ENTRIES = 1 << 16
@@ -435,6 +436,7 @@ class _Buffers:
         # batch k (bound by memory requests) on the caller's stream
         self.pre_stream = torch.cuda.Stream(device=dev)
         self.rescore_stream = torch.cuda.Stream(device=dev, priority=-1)
+        self.pack_stream = torch.cuda.Stream(device=dev)
         self.slots(2)
 
     def slots(self, n: int):
@@ -744,8 +746,10 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     side_tail = bool(RESCORE_STREAM and exact and pre is None and prepared is not None)
     ws_i = (which & 1) if (side_tail and bufs.ws2 is not None) else 0
     ws = bufs.workspace(-(-int(L.mmx_workspace_bytes(nb, slot, ns, 1)) // 4), ws_i)
+    # ... and the voxel copy of the tiled path, the first kernel of a batch, on a third: it only needs the workspace
+    pack_side = side_tail and PACK_STREAM and bufs.ws2 is not None
     if bufs.ws_free[ws_i] is not None:       # (also a batch that is nominated again, on the main stream: same workspace)
-        torch.cuda.current_stream().wait_event(bufs.ws_free[ws_i])
+        (bufs.pack_stream if pack_side else torch.cuda.current_stream()).wait_event(bufs.ws_free[ws_i])
     if d_blocks is None:
         d_blocks = _to_device_bytes(blocks, dev)
     stream = _stream_ptr()
@@ -781,8 +785,16 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                 tiled_mode = nat.MMX_ZX_TILED_Q16
         if (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16) and not is_float) or \
                 (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED) and float_ok):
-            rc = L.mmx_zx_pack(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
-                               ws.data_ptr(), stream)
+            nonlocal pack_side
+            if pack_side:
+                with torch.cuda.stream(bufs.pack_stream):
+                    rc = L.mmx_zx_pack(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
+                                       ws.data_ptr(), bufs.pack_stream.cuda_stream)
+                torch.cuda.current_stream().wait_stream(bufs.pack_stream)
+                pack_side = False                # (a second round of passes, should one be needed: in stream order)
+            else:
+                rc = L.mmx_zx_pack(ctypes.byref(vol32), d_blocks.data_ptr(), blocks.ctypes.data, nb, slot,
+                                   ws.data_ptr(), stream)
             if rc not in (0, 5):                 # MMX_OK, MMX_ERR_UNSUPPORTED (float voxels, workspace shape)
                 nat.check(rc, "mmx_zx_pack")
             packed = rc == 0

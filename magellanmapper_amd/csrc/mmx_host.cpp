@@ -63,7 +63,10 @@ private:
     pool()
     {
         const unsigned hw = std::thread::hardware_concurrency();
-        const int n = (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+        // (MMX_HOST_THREADS: 1 .. 64; the default of 16 is where the tables of the benchmark volume stop gaining)
+        const char* env = getenv("MMX_HOST_THREADS");
+        const unsigned cap = env ? (unsigned)std::max(1, std::min(64, atoi(env))) : 16u;
+        const int n = (int)std::max(1u, std::min(cap, hw ? hw : 1u));
         owner_ = getpid();
         for (int t = 1; t < n; ++t) workers_.emplace_back([this, t] { loop(t); });
     }

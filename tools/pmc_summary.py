@@ -25,7 +25,7 @@ def short(name):
         return "zxpack"
     if "zx2_kernel" in name or "zx_kernel" in name or "zx4_kernel" in name:
         return "zxpass"
-    if "y2_kernel" in name or "y6_kernel" in name:
+    if "y2_kernel" in name or "y6_kernel" in name or "ym_kernel" in name:
         return "y2pass"
     if "peaks_sparse_kernel" in name:
         return "peaks"
