@@ -402,9 +402,14 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                 per_kernel[k]["alg_GBps"] = round(gbs, 1)
                 if gbs > HBM_PEAK_GBS:
                     flags.append(f"kernels.{k}.alg_GBps")
-                    per_kernel[k]["note"] = ("above the 8 TB/s peak: quoted on the contract's byte count (peaks: 4 B per "
-                                             "voxel and sigma), while the kernel reads the sparse NMS entries the Y pass "
-                                             "leaves (16 B per 64 voxels and sigma plus the lines of the set bits)")
+                    per_kernel[k]["note"] = (
+                        "above the 8 TB/s peak: quoted on the contract's byte count (peaks: 4 B per voxel and sigma), while "
+                        "the kernel reads the sparse NMS entries the Y pass leaves (16 B per 64 voxels and sigma plus the "
+                        "lines of the set bits)" if k == "peaks" else
+                        "above the 8 TB/s peak: quoted on the contract's byte count (Y pass: 8 B in + 4 B out per voxel and "
+                        "sigma), while the kernel reads 16-bit tiles (4.35 B per voxel) and stores the LoG only where "
+                        "something is above the threshold (~1.2 B per voxel): see roofline.traffic / DESIGN.md section 4"
+                        if k == "y2pass" else "above the 8 TB/s peak on the contract's byte count: the kernel moves fewer bytes")
             elif k == "preproc":      # once per voxel (not per sigma): 2 B in, 8 + 4 B out; fp64-VALU bound
                 per_kernel[k]["alg_GBps"] = round(14 * my_vox * steps / (ms * 1e-3) / 1e9, 1)
     stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
@@ -449,6 +454,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                         "intermediates out per volume voxel and sigma) / its HIP-event time; the kernel itself moves "
                         "fewer bytes than that ('traffic'): its intermediates are 16-bit fixed point, and with the VALU and "
                         "the MFMA pipe each about half busy it waits for its L2 requests, not for HBM (DESIGN.md section 4b)"
+                        + ("; its HIP-event time includes sharing the GPU with the NMS and re-score kernels of the previous "
+                           "batch on the second stream (alone: ~10 % less, MMX_RESCORE_STREAM=0)"
+                           if (bl.RESCORE_STREAM and not PROFILE["denoise_size"]) else "")
                         if dom == "zxpass" else None}
         if dom == "zxpass" and zx_path in (nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16):
             # the same kernel against the matrix-core roofline: MFMAs it issues (16 x 16 x 32 float16, 16 384 flop

@@ -21,8 +21,9 @@
 // is six MFMAs per (output tile of 16 rows, k-block of 32 rows, column set): Phi x 256 wh, Plo x wh, Phi x wl
 // (wl = 256 (W - wh); the Plo x (W - wh) term, <= 2^-12 of 255 / 65535 of the sum, is dropped and counted in
 // mmx_tiled_q16_error_bound), the same for Q.  The A operands are Toeplitz fragments w[|k - m + delta|] for the NB
-// block offsets delta = RB - 16 t (RB = 16, NB = 4 for R <= 16; RB = 32, NB = 6 for R <= 24), built once per workgroup
-// in LDS.  SciPy's "reflect" boundary is taken by the loads (rows mirrored, rows beyond reach clamped: zero weights).
+// block offsets delta = RB - 16 t, t = 0 .. NB - 1, of a k-block that starts RB = 8 (NB - 2) rows before the first tile
+// it feeds: NB = 3 / 4 / 5 offsets reach every tap of radius <= 8 / 16 / 24 (the next offset at either end starts
+// 8 (NB - 2) + 1 rows away).  Built once per workgroup in LDS.  SciPy's "reflect" boundary is taken by the loads (rows mirrored, rows beyond reach clamped: zero weights).
 // An output tile is complete after NB / 2 k-blocks; its accumulators (four consecutive y per lane) go through LDS
 // (4 KiB per wave and tile) to come back as one row of 64 columns per step, lane = column as in y6_kernel, whose
 // ballot / sparse store / entry code then runs unchanged -- except that a tile with nothing above the threshold (a
@@ -64,11 +65,13 @@ __device__ __forceinline__ f4_y mfma_y(const u4_y& a, const u4_y& b, const f4_y&
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_y, a), __builtin_bit_cast(h8_y, b), c, 0, 0, 0);
 }
 
-// Workgroup = four waves = one tile column.  NB == 4 (R <= 16): 164 registers and 48 KiB of LDS, three workgroups per
-// CU; NB == 6 (R <= 24): 195 registers and 56 KiB, two.  (Measured for NB == 6 and kept as the YM6_* switches: pieces
-// built for two column sets at a time -- 32 registers less, the fragments read twice -- with TWELVE waves = three tile
-// columns sharing one fragment table, i.e. three waves per SIMD too: 2.42 against 1.99 ms per 64 blocks -- the LDS then
-// carries as many cycles of fragment reads as the matrix pipe has MFMAs.)
+// Workgroup = four waves = one tile column.  NB <= 4 (R <= 16): 164 registers and 44 / 48 KiB of LDS, three workgroups
+// per CU; NB == 5 (R <= 24): 180 registers and 52 KiB, two (held to 168 registers it spills 20 and is slower: 2.10
+// against 1.72 ms per 64 blocks).  Measured with six offsets (RB = 32, what R <= 24 took before the five-offset
+// alignment was found: 1.99 ms) and kept as the YM6_* switches: pieces built for two column sets at a time -- 32
+// registers less, the fragments read twice -- with TWELVE waves = three tile columns sharing one fragment table, i.e.
+// three waves per SIMD too: 2.42 ms -- the LDS then carries as many cycles of fragment reads as the matrix pipe has
+// MFMAs.
 #ifndef YM5_OCC
 #define YM5_OCC 2
 #endif
