@@ -658,7 +658,12 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         # block tables of every batch go to the device BEFORE the first kernel: a pageable host -> device copy
         # waits for everything queued on the stream before it
         prepared = [_make_blocks(dvol, channel, [origins[i] for i in b], [shapes[i] for i in b]) for b in batches]
-        prepared = [(blk, slot, _to_device_bytes(blk, dvol.tensor.device)) for blk, slot in prepared]
+        if prepared:        # (one upload for all of them: fourteen small copies were 0.4 ms of idle GPU at the start of a step)
+            sizes = [blk.nbytes for blk, _ in prepared]
+            allrec = _to_device_bytes(np.concatenate([blk.view(np.uint8).reshape(-1) for blk, _ in prepared]),
+                                      dvol.tensor.device)
+            offs = np.concatenate([[0], np.cumsum(sizes)])
+            prepared = [(blk, slot, allrec[int(offs[i]):int(offs[i + 1])]) for i, (blk, slot) in enumerate(prepared)]
         # ... and the shared workspace has its final size before anything is queued on it
         if prepared:
             need = max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, len(space.sigmas), 1)) // 4)

@@ -441,9 +441,14 @@ class StackDetector:
         origins, shapes = [], []
         for i in mine:
             slc = sub_roi_slices[coords[i]]
-            rng = [s.indices(n) for s, n in zip(slc, shape3)]
-            origins.append(tuple(r[0] for r in rng))
-            shapes.append(tuple(r[1] - r[0] for r in rng))
+            a = [s.start for s in slc]
+            b = [s.stop for s in slc]
+            if any(v is None or v < 0 for v in a + b) or any(s.step not in (None, 1) for s in slc) or \
+                    any(q > n for q, n in zip(b, shape3)):
+                rng = [s.indices(n) for s, n in zip(slc, shape3)]      # (open-ended or negative bounds: Python's rules)
+                a, b = [r[0] for r in rng], [r[1] for r in rng]
+            origins.append((int(a[0]), int(a[1]), int(a[2])))
+            shapes.append((int(b[0] - a[0]), int(b[1] - a[1]), int(b[2] - a[2])))
         stats = bl.BatchStats()
         tables = []
         n_extra = (img.shape[3] if len(img.shape) > 3 else 0) if coloc else 0
@@ -461,9 +466,11 @@ class StackDetector:
             return cls._exclude_matrix(coords[mine[k]], last_coord, exclude_border)
 
         pruner = None
-        # (opt-in: measured on the benchmark volume it moves ~4 ms of pruning under the GPU's last batches but adds as
-        #  much in the merge -- 124.9 against 124.6 ms per volume -- and costs small stacks 0.6 ms: DESIGN.md)
-        if regular and dist.world_size() == 1 and mine and os.environ.get("MMX_PRUNE_AHEAD", "0") == "1":
+        # (MMX_PRUNE_AHEAD = 1 / 0 / unset: always / never / for stacks of 64 blocks and more.  On the benchmark volume it
+        #  moves ~4 ms of pruning under the GPU's last batches and adds most of that in the merge: 0.8-1.0 ms per volume
+        #  in four alternating pairs of bench.py runs; it costs small stacks 0.6 ms: DESIGN.md)
+        ahead = os.environ.get("MMX_PRUNE_AHEAD", "")
+        if regular and dist.world_size() == 1 and mine and (ahead == "1" or (ahead != "0" and len(mine) >= 64)):
             ov, tl, pad, prune_channels = hint
             pruner = _RegionPruner(arena, StackPruner._axis_plan(shape3, ov, tl, tl if pad is None else pad,
                                                                  sub_roi_slices, sub_rois_offsets),
