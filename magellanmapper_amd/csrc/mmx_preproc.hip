@@ -64,6 +64,13 @@ __device__ __forceinline__ double pp_clip(double x, double lo, double hi)
 }
 
 // numpy _lerp (numpy/lib/_function_base_impl.py): a + (b-a)*t, or b - (b-a)*(1-t) for t >= 0.5
+__device__ __forceinline__ double pp_lerp(double a, double b, double t)      // (float64 images: the same NumPy formula)
+{
+    const double d = b - a;
+    double r = a + d * t;
+    if (t >= 0.5) r = b - d * (1.0 - t);
+    return r;
+}
 __device__ __forceinline__ double pp_lerp(int a, int b, double t)
 {
     const double d = (double)(b - a);
@@ -803,51 +810,101 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
     const InT* src = vol + sb.src_off;
     double* bufA = scratch + sb.scratch_off;
     double* bufB = bufA + n;
+    constexpr bool F64 = std::is_same<InT, double>::value;
     auto raw = [&](int64_t i) {
         const int64_t t = i / nx, x = i - t * nx, z = t / ny, y = t - z * ny;
-        return (int)src[z * sz + y * sy + x * sx];
+        if constexpr (F64) return (double)src[z * sz + y * sy + x * sx];
+        else return (int)src[z * sz + y * sy + x * sx];
     };
-
-    for (int i = tid; i < PP_HIST; i += PP_WG_GENERIC) hist[i] = 0;
-    __syncthreads();
-    for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
-        const int v = raw(i);
-        bufA[i] = (double)v;
-        atomicAdd(&hist[v >> 8], 1u);
-    }
-    __syncthreads();
     const mmx_quantile_class qc = qcs[sb.qclass];
-    if (wave < 4) {
-        const uint32_t rank = wave == 0 ? qc.lo_prev : wave == 1 ? qc.lo_next : wave == 2 ? qc.hi_prev : qc.hi_next;
-        int b; uint32_t r;
-        pp_select(hist, rank, b, r);
-        if (lane == 0) { s_bin[wave] = b; s_res[wave] = r; }
-    }
-    __syncthreads();
-    {
-        const int b0 = s_bin[0], b1 = s_bin[1], b2 = s_bin[2], b3 = s_bin[3];
-        for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
-            const int v = (int)bufA[i];
-            const int hi = v >> 8, lo = v & 255;
-            if (hi == b0) atomicAdd(&hist[256 + lo], 1u);
-            if (hi == b1) atomicAdd(&hist[512 + lo], 1u);
-            if (hi == b2) atomicAdd(&hist[768 + lo], 1u);
-            if (hi == b3) atomicAdd(&hist[1024 + lo], 1u);
+    double q_val[4];                        // the four order statistics np.percentile interpolates between
+    if constexpr (F64) {
+        // float64 voxels: an eight-level radix select on the order-preserving bit pattern of the doubles (sign bit
+        // flipped for positives, all bits for negatives), the four ranks side by side -- one 256-bin histogram each
+        // per level, counted over the voxels that share the rank's prefix so far
+        __shared__ unsigned long long s_pre[4];
+        auto key = [](double v) {
+            const unsigned long long u = (unsigned long long)__double_as_longlong(v + 0.0);     // (-0.0 sorts as +0.0)
+            return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+        };
+        for (int64_t i = tid; i < n; i += PP_WG_GENERIC) bufA[i] = raw(i);
+        if (tid < 4) {
+            s_pre[tid] = 0ull;
+            s_res[tid] = tid == 0 ? qc.lo_prev : tid == 1 ? qc.lo_next : tid == 2 ? qc.hi_prev : qc.hi_next;
         }
+        __syncthreads();
+        for (int level = 7; level >= 0; --level) {
+            for (int i = tid; i < PP_HIST; i += PP_WG_GENERIC) hist[i] = 0;
+            __syncthreads();
+            const unsigned long long p0 = s_pre[0], p1 = s_pre[1], p2 = s_pre[2], p3 = s_pre[3];
+            const int sh = 8 * level;
+            for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+                const unsigned long long k = key(bufA[i]);
+                const unsigned long long up = level == 7 ? 0ull : k >> (sh + 8);
+                const unsigned b8 = (unsigned)(k >> sh) & 255u;
+                if (up == p0) atomicAdd(&hist[256 + b8], 1u);
+                if (up == p1) atomicAdd(&hist[512 + b8], 1u);
+                if (up == p2) atomicAdd(&hist[768 + b8], 1u);
+                if (up == p3) atomicAdd(&hist[1024 + b8], 1u);
+            }
+            __syncthreads();
+            if (wave < 4) {
+                int b; uint32_t r;
+                pp_select(hist + 256 * (1 + wave), s_res[wave], b, r);
+                if (lane == 0) { s_pre[wave] = (s_pre[wave] << 8) | (unsigned long long)b; s_res[wave] = r; }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned long long k = s_pre[w];
+            const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+            q_val[w] = __longlong_as_double((long long)u);
+        }
+    } else {
+
+        for (int i = tid; i < PP_HIST; i += PP_WG_GENERIC) hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+            const int v = raw(i);
+            bufA[i] = (double)v;
+            atomicAdd(&hist[v >> 8], 1u);
+        }
+        __syncthreads();
+        if (wave < 4) {
+            const uint32_t rank = wave == 0 ? qc.lo_prev : wave == 1 ? qc.lo_next : wave == 2 ? qc.hi_prev : qc.hi_next;
+            int b; uint32_t r;
+            pp_select(hist, rank, b, r);
+            if (lane == 0) { s_bin[wave] = b; s_res[wave] = r; }
+        }
+        __syncthreads();
+        {
+            const int b0 = s_bin[0], b1 = s_bin[1], b2 = s_bin[2], b3 = s_bin[3];
+            for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
+                const int v = (int)bufA[i];
+                const int hi = v >> 8, lo = v & 255;
+                if (hi == b0) atomicAdd(&hist[256 + lo], 1u);
+                if (hi == b1) atomicAdd(&hist[512 + lo], 1u);
+                if (hi == b2) atomicAdd(&hist[768 + lo], 1u);
+                if (hi == b3) atomicAdd(&hist[1024 + lo], 1u);
+            }
+        }
+        __syncthreads();
+        if (wave < 4) {
+            int b; uint32_t r;
+            pp_select(hist + 256 * (1 + wave), s_res[wave], b, r);
+            if (lane == 0) s_val[wave] = (s_bin[wave] << 8) | b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) q_val[w] = (double)s_val[w];
     }
-    __syncthreads();
-    if (wave < 4) {
-        int b; uint32_t r;
-        pp_select(hist + 256 * (1 + wave), s_res[wave], b, r);
-        if (lane == 0) s_val[wave] = (s_bin[wave] << 8) | b;
-    }
-    __syncthreads();
 
     pp_sat S;
     double info_vmin, info_vmax;
     {
-        const double vmin = pp_lerp(s_val[0], s_val[1], qc.lo_gamma);
-        double vmax = pp_lerp(s_val[2], s_val[3], qc.hi_gamma);
+        const double vmin = pp_lerp(q_val[0], q_val[1], qc.lo_gamma);
+        double vmax = pp_lerp(q_val[2], q_val[3], qc.hi_gamma);
         S.identity = vmin == vmax;
         if (vmax < A.max_thresh) vmax = A.max_thresh;
         S.vmin = vmin; S.vmax = vmax; S.span = vmax - vmin;
@@ -855,9 +912,12 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
         S.finish();
     }
 
+    // (an identity tile -- vmin == vmax: the reference leaves the voxels alone -- of a float64 image may hold negative
+    //  values, which the vmin = 0 stand-in of pp_sat would clip)
+    auto sat = [&](double v) { return (F64 && S.identity) ? v : S.plain(v); };
     double part = 0.;
     for (int64_t i = tid; i < n; i += PP_WG_GENERIC) {
-        const double s = S.plain(bufA[i]);
+        const double s = sat(bufA[i]);
         part += s;
         bufA[i] = pp_clip(s, A.clip_min, A.clip_max);
     }
@@ -872,7 +932,7 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
         if (A.do_erosion) {
             const double tol = 1e-9 * (fabs(A.ero_thr) > 1. ? fabs(A.ero_thr) : 1.);
             if (!S.identity && fabs(mean - A.ero_thr) <= tol && n < (1ll << 31)) {
-                auto val = [&](int i) { return S.plain((double)raw(i)); };
+                auto val = [&](int i) { return sat((double)raw(i)); };
                 mean = pp_pairwise(val, (int)n, &s_stack) / (double)n;
                 flags |= MMX_PP_EXACT_MEAN;
             }
@@ -1011,7 +1071,7 @@ pp_generic_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t s
         double o;
         if (A.do_unsharp) {
             const double den = tv ? den_buf[i]
-                                  : pp_clip(S.plain((double)(int)src[z * sz + y * sy + x * sx]), A.clip_min, A.clip_max);
+                                  : pp_clip(sat((double)raw(i)), A.clip_min, A.clip_max);
             const double m = A.strength * cur[i];
             const double hp = den - m;
             o = den + hp;
@@ -1077,7 +1137,9 @@ static int pp_check(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx
         !d_out32 || !d_out64)
         return MMX_ERR_ARG;
     if (p->radius != PP_R) return MMX_ERR_UNSUPPORTED;
-    if (vol->dtype != MMX_U8 && vol->dtype != MMX_U16) return MMX_ERR_UNSUPPORTED;
+    // (float64 images: the one-output-per-lane kernel of the generic entry only; float32 images compute in float32 in
+    //  the reference -- another arithmetic, not built)
+    if (vol->dtype != MMX_U8 && vol->dtype != MMX_U16 && vol->dtype != MMX_F64) return MMX_ERR_UNSUPPORTED;
     for (int i = 0; i < n_subs; ++i) {
         const mmx_subblock& b = h_subs[i];
         if (b.nz < 1 || b.ny < 1 || b.nx < 1 || b.qclass < 0 || b.qclass >= n_qc || b.src_off < 0 || b.dst_off < 0)
@@ -1095,6 +1157,7 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
     const int st = pp_check(vol, d_subs, h_subs, n_subs, d_qclasses, n_qclasses, params, d_weights, d_out32, d_out64);
     if (st != MMX_OK) return st;
     if (params->tv_weight != 0.0) return MMX_ERR_UNSUPPORTED;      // total-variation denoising: the generic entry
+    if (vol->dtype == MMX_F64) return MMX_ERR_UNSUPPORTED;         // float64 voxels: the generic entry
     if (n_subs == 0) return MMX_OK;
     int64_t lds = 0;
     for (int i = 0; i < n_subs; ++i) {
@@ -1150,7 +1213,7 @@ int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_su
     hipStream_t s = (hipStream_t)stream;
     mmx_timed_scope ts(MMX_K_PREPROC, s);
     // every side <= 64: register-resident lines over the scratch (pp_mid_kernel); else one output per lane
-    bool mid = params->tv_weight == 0.0;       // (the iteration lives in the one-output-per-lane kernel only)
+    bool mid = params->tv_weight == 0.0 && vol->dtype != MMX_F64;   // (the iteration, and float64 voxels, live in the one-output-per-lane kernel only)
     int max_nx = 1;
     for (int i = 0; i < n_subs; ++i) {
         const mmx_subblock& b = h_subs[i];
@@ -1176,7 +1239,11 @@ int mmx_preprocess_batch_generic(const mmx_volume* vol, const mmx_subblock* d_su
         }
         return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
     }
-    if (vol->dtype == MMX_U16)
+    if (vol->dtype == MMX_F64)
+        hipLaunchKernelGGL(pp_generic_kernel<double>, dim3(n_subs), dim3(PP_WG_GENERIC), 0, s,
+                           (const double*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_subs,
+                           d_qclasses, d_weights, A, d_out32, d_out64, d_info, d_scratch);
+    else if (vol->dtype == MMX_U16)
         hipLaunchKernelGGL(pp_generic_kernel<uint16_t>, dim3(n_subs), dim3(PP_WG_GENERIC), 0, s,
                            (const uint16_t*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_subs,
                            d_qclasses, d_weights, A, d_out32, d_out64, d_info, d_scratch);

@@ -15,7 +15,8 @@ device, all O(number of distinct tile sizes)):
 * the sigma-8 Gaussian weights, built like ``scipy.ndimage._filters._gaussian_kernel1d``
   (:mod:`kernels1d`).
 
-Scope: uint8 / uint16 voxels (what microscopes write); ``tot_var_denoise`` profiles raise
+Scope: uint8 / uint16 voxels (what microscopes write) and float64 images (the same float64 arithmetic once the
+order statistics are found); float32 images, which the reference keeps in float32 throughout, raise
 ``NotImplementedError``.  scikit-image < 0.19 treats a 3-D array whose last axis has length 3
 as RGB inside ``filters.gaussian``; the reference pins 0.25 (no such guess), :data:`RGB_GUESS`
 switches the old behaviour on for the golden fixtures made with 0.18.3.
@@ -258,9 +259,13 @@ class Preprocessor:
         ``mmx_volume`` views (float32 for the passes, float64 for the exact re-score)."""
         L = nat.lib()
         dev = dvol.tensor.device
-        if dvol.np_dtype not in (np.dtype(np.uint8), np.dtype(np.uint16)):
+        # float64 images: the reference's arithmetic is the same float64 arithmetic once np.percentile has found its
+        # order statistics (a radix select on the doubles, in the one-output-per-lane kernel).  float32 images stay in
+        # float32 all the way in the reference (NumPy keeps the array's type): a different arithmetic, not built.
+        f64_voxels = dvol.np_dtype == np.dtype(np.float64)
+        if dvol.np_dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float64)):
             raise NotImplementedError(
-                f"device preprocessing reads uint8 / uint16 voxels, not {dvol.np_dtype}")
+                f"device preprocessing reads uint8 / uint16 / float64 voxels, not {dvol.np_dtype}")
         params, pct_lo, pct_hi = channel_params(int(channel), self.near_max)
         nb = len(shapes)
         shp = np.asarray(shapes, dtype=np.int64).reshape(nb, 3)
@@ -290,7 +295,7 @@ class Preprocessor:
         # to the block, quantile class, fast / generic split); a block only adds its two base offsets
         # total-variation denoising iterates in the one-output-per-lane kernel over a global scratch
         tv_on = params.tv_weight != 0.0
-        force = "big" if tv_on else FORCE_GENERIC
+        force = "big" if (tv_on or f64_voxels) else FORCE_GENERIC
         key = (pct_lo, pct_hi, force)
         if self._tmpl_key != key:
             self._tmpl_key, self._tmpl, self._qc_rows, self._qc_index = key, {}, [], {}

@@ -22,6 +22,8 @@ Fixtures (all ``np.savez_compressed``):
 * ``stack_<case>.npz``     -- ``detect_blobs_blocks``: per-block tables, final table.
 * ``prune.npz``            -- ``remove_close_blobs`` / ``StackPruner.prune_blobs_mp``
   on hand-made tables (multi-matches, half-even averages, >1000-row chunking).
+* ``preproc_f64.npz``      -- the same two functions on FLOAT64 sub-blocks (values in [0, 1], negative and
+  fractional values, ties, a constant tile) + ``stack_denoise_f64.npz`` (a float64 stack end to end)
 * ``preproc.npz``          -- ``plot_3d.saturate_roi`` / ``plot_3d.denoise_roi`` on denoise
   sub-blocks (sparse, dense/eroded, constant, ragged, x-size-3, uint8, near_max, 2 channels).
 * ``stack_denoise*.npz``   -- ``detect_blobs_blocks`` with the profile's ``denoise_size`` on.
@@ -516,6 +518,8 @@ def main():
     print("versions:", VERSIONS)
     if sys.argv[1:] == ["preproc"]:       # only the preprocessing fixtures (added later)
         return main_preproc()
+    if sys.argv[1:] == ["preproc_f64"]:   # only the float64-image preprocessing fixtures (added later)
+        return main_preproc_f64()
     if sys.argv[1:] == ["coloc_cases"]:   # only coloc.npz (percentile cases added later)
         return coloc_cases()
     if sys.argv[1:] == ["coloc"]:         # only the co-localisation fixtures (added later)
@@ -914,6 +918,47 @@ def main_coloc():
                segment_size=36, num_sigma=3, coloc=True)
     stack_case("coloc_denoise", make_coloc_volume(55, (48, 66, 64), 26), None, segment_size=34,
                num_sigma=3, denoise_size=25, near_max=(-1.0, -1.0), coloc=True)
+
+
+def main_preproc_f64():
+    """saturate_roi / denoise_roi of the real reference on FLOAT64 sub-blocks, and one float64 stack end to end."""
+    from magmap.plot import plot_3d
+    out, names = {}, []
+
+    def case(name, roi, near_max=(-1.0,), **over):
+        assert roi.dtype == np.float64
+        setup_profile(None, **over)
+        config.near_max = list(near_max)
+        sat = quiet(plot_3d.saturate_roi, roi, channel=None)
+        den = quiet(plot_3d.denoise_roi, sat, channel=None)
+        out[name + "_roi"] = roi
+        out[name + "_near_max"] = np.array(near_max, dtype=float)
+        out[name + "_over"] = repr(over)
+        out[name + "_sat"] = sat
+        out[name + "_den"] = den
+        names.append(name)
+        print("preproc_f64 %-10s %s -> sat %s mean %.4f, den %s [%.4f, %.4f]" % (
+            name, roi.shape, sat.dtype, float(np.mean(sat)), den.dtype, float(den.min()), float(den.max())))
+
+    sparse = make_volume(41, (25, 25, 25), 3, margin=4)
+    densev = make_volume(42, (25, 25, 25), 40, amp=6000.0, blob_sigma=3.5, bg_mean=3000.0, bg_sd=800.0, margin=0)
+    case("unit", sparse / 65535.0)                           # what img_as_float would have made of the uint16 tile
+    case("neg", densev * 0.37 - 1500.25)                     # negative and fractional values
+    case("const", np.full((25, 25, 25), -2.5))               # identity tile (vmin == vmax) of negative values
+    case("ragged", make_volume(43, (14, 25, 9), 2, margin=3) * 1e-3)
+    case("tiny", make_volume(46, (2, 1, 5), 0, margin=0) / 7.0)
+    rng = np.random.default_rng(48)
+    case("ties", rng.integers(-3, 4, (20, 25, 25)) * 0.1)    # many ties around the percentile ranks, both signs
+    case("nearmax", sparse / 65535.0, near_max=(0.9,))
+    case("clipvals", densev / 65535.0, clip_vmin=2, clip_vmax=90.5, clip_min=0.1, clip_max=0.8,
+         unsharp_strength=0.45, erosion_threshold=0.1)
+    case("big", make_volume(49, (32, 40, 36), 10, margin=4) / 65535.0)
+    config.near_max = [-1.0]
+    out["names"] = np.array(names)
+    out["versions"] = repr(VERSIONS)
+    np.savez_compressed(os.path.join(HERE, "preproc_f64.npz"), **out)
+    stack_case("denoise_f64", make_volume(35, (64, 96, 96), 60) / 65535.0, None, segment_size=40, num_sigma=5,
+               denoise_size=25)
 
 
 def main_preproc():

@@ -75,6 +75,42 @@ def test_tile_matches_reference(gpu, env, case):
             assert abs(info["mean"][0] - np.mean(sat)) < 1e-12
 
 
+PREPROC_F64 = load_golden("preproc_f64.npz")
+
+
+@pytest.mark.parametrize("case", [str(n) for n in PREPROC_F64["names"]])
+def test_float64_tile_matches_reference(gpu, env, case):
+    """FLOAT64 images (the part that raised until round 3): the order statistics come from
+    an eight-level radix select on the doubles' bit patterns, an identity tile of negative values is left alone."""
+    from magellanmapper_amd import _native as nat, preprocess
+    g = PREPROC_F64
+    roi = g[case + "_roi"]
+    over = ast.literal_eval(str(g[case + "_over"]))
+    prof = _set_profiles(over)[0]
+    near_max = list(g[case + "_near_max"])
+    got, infos = preprocess.preprocess_roi(roi, roi.shape[:3], near_max=near_max, return_info=True)
+    assert got.dtype == np.float64
+    np.testing.assert_array_equal(got, g[case + "_den"])
+    (subs, info), = infos
+    vmin, vmax = np.percentile(roi, (prof["clip_vmin"], prof["clip_vmax"]))
+    assert len(info) == 1 and info["vmin"][0] == vmin
+    assert bool(info["flags"][0] & nat.MMX_PP_IDENTITY) == (vmin == vmax)
+    if vmin != vmax:
+        assert info["vmax"][0] == max(vmax, near_max[0] * prof["max_thresh_factor"])
+
+
+def test_float64_block_tiles_match_oracle(gpu, env):
+    """A float64 block of several ragged tiles against the oracle's tile loop, bit for bit."""
+    from magellanmapper_amd import preprocess
+    from oracle import preprocess_oracle as ppo
+    g = load_golden("stack_denoise_f64.npz")
+    roi = np.ascontiguousarray(g["roi"][:40, :45, :52]) * 3.0 - 0.4
+    profs = _set_profiles({})
+    got = preprocess.preprocess_roi(roi, (25, 20, 30), near_max=[-1.0])
+    want = ppo.preprocess_block(roi, (25, 20, 30), profs, [-1.0])
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("dms", [(25, 25, 25), (13, 25, 30), (7, 40, 9), (50, 64, 33), (64, 96, 96)])
 def test_tiled_block_matches_oracle(gpu, env, dms):
     """A whole block, tiled like chunking.stack_splitter does: fast (LDS) and generic tiles mixed."""

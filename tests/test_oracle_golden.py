@@ -216,6 +216,24 @@ def test_preprocessing_matches_reference(case, golden_gauss_weights):
     np.testing.assert_array_equal(den, g[case + "_den"])
 
 
+PREPROC_F64 = load_golden("preproc_f64.npz")
+
+
+@pytest.mark.parametrize("case", [str(n) for n in PREPROC_F64["names"]])
+def test_preprocessing_of_float64_tiles_matches_reference(case, golden_gauss_weights):
+    """The same two functions on FLOAT64 sub-blocks (values in [0, 1], negative and fractional values, ties of both
+    signs, a constant tile of negative values): ``np.percentile`` interpolates between doubles, everything after it is
+    the arithmetic of the integer images."""
+    g = PREPROC_F64
+    roi = g[case + "_roi"]
+    assert roi.dtype == np.float64
+    profs = _profiles(ast.literal_eval(str(g[case + "_over"])), 1)
+    near_max = list(g[case + "_near_max"])
+    sat = ppo.saturate_roi(roi, profs, near_max)
+    np.testing.assert_array_equal(sat, g[case + "_sat"])
+    np.testing.assert_array_equal(ppo.denoise_roi(sat, profs), g[case + "_den"])
+
+
 def test_preprocess_block_tiles_like_the_reference_loop():
     g = load_golden("stack_denoise.npz")
     roi = g["roi"][:40, :45, :52]

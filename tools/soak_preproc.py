@@ -26,8 +26,14 @@ for trial in range(a.trials):
     shape = (int(rng.integers(16, 50)), int(rng.integers(16, 72)), int(rng.integers(16, 72)))
     vol = synth.make_volume(int(rng.integers(1 << 30)), shape, int(rng.integers(3, 80)),
                             blob_sigma=float(rng.uniform(1.0, 4.0)), amp=float(rng.uniform(2000, 60000)))
-    if rng.random() < 0.2:
+    kind = rng.random()
+    if kind < 0.2:
         vol = (vol >> 8).astype(np.uint8)
+    elif kind < 0.4:          # float64 images: scaled, shifted below zero, or coarse (ties)
+        f = vol.astype(np.float64)
+        vol = (f / 65535.0 if rng.random() < 0.4 else
+               f * float(rng.uniform(1e-3, 3.0)) - float(rng.uniform(0.0, 4000.0)) if rng.random() < 0.6 else
+               np.round(f / 4096.0) * 0.25 - 1.0)
     dms = tuple(int(v) for v in rng.choice([5, 7, 13, 23, 25, 30, 40, 64], 3))
     over = dict(clip_vmin=float(rng.choice([0, 2, 5, 10])), clip_vmax=float(rng.choice([95, 99, 99.5, 100])),
                 clip_min=float(rng.choice([0.0, 0.1, 0.2, 0.3])), clip_max=float(rng.choice([0.6, 0.8, 1.0])),
@@ -38,7 +44,7 @@ for trial in range(a.trials):
     for k, v in over.items():
         config.roi_profiles[0][k] = v
     profs = [dict(p) for p in config.roi_profiles]
-    nm = [float(rng.choice([-1.0, 5000.0, 30000.0]))]
+    nm = [float(rng.choice([-1.0, 5000.0, 30000.0]))] if vol.dtype.kind == "u" else [float(rng.choice([-1.0, 0.5, 2.0]))]
     want = ppo.preprocess_block(vol, dms, profs, nm)
     got = preprocess.preprocess_roi(vol, dms, near_max=nm)
     vox += vol.size
