@@ -16,7 +16,7 @@ device, all O(number of distinct tile sizes)):
   (:mod:`kernels1d`).
 
 Scope: uint8 / uint16 voxels (what microscopes write) and float64 images (the same float64 arithmetic once the
-order statistics are found); float32 images, which the reference keeps in float32 throughout, raise
+order statistics are found); float32 images, whose result in the reference depends on the NumPy release, raise
 ``NotImplementedError``.  scikit-image < 0.19 treats a 3-D array whose last axis has length 3
 as RGB inside ``filters.gaussian``; the reference pins 0.25 (no such guess), :data:`RGB_GUESS`
 switches the old behaviour on for the golden fixtures made with 0.18.3.
@@ -260,8 +260,9 @@ class Preprocessor:
         L = nat.lib()
         dev = dvol.tensor.device
         # float64 images: the reference's arithmetic is the same float64 arithmetic once np.percentile has found its
-        # order statistics (a radix select on the doubles, in the one-output-per-lane kernel).  float32 images stay in
-        # float32 all the way in the reference (NumPy keeps the array's type): a different arithmetic, not built.
+        # order statistics (a radix select on the doubles, in the one-output-per-lane kernel).  float32 images: what the
+        # reference computes depends on the NumPy release (float32 throughout under 1.26, float64 after the clip under
+        # 2.2: DESIGN.md section 6) -- not built.
         f64_voxels = dvol.np_dtype == np.dtype(np.float64)
         if dvol.np_dtype not in (np.dtype(np.uint8), np.dtype(np.uint16), np.dtype(np.float64)):
             raise NotImplementedError(
