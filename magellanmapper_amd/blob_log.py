@@ -435,7 +435,7 @@ class _Buffers:
         # per-block preprocessing (float64 vector arithmetic) of batch k + 1 runs here, beside the LoG kernels of
         # batch k (bound by memory requests) on the caller's stream
         self.pre_stream = torch.cuda.Stream(device=dev)
-        self.rescore_stream = torch.cuda.Stream(device=dev, priority=-1)
+        self.rescore_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MMX_SIDE_PRIORITY", "0")))
         self.pack_stream = torch.cuda.Stream(device=dev)
         self.slots(2)
 
