@@ -23,8 +23,9 @@
 // mmx_tiled_q16_error_bound), the same for Q.  The A operands are Toeplitz fragments w[|k - m + delta|] for the NB
 // block offsets delta = RB - 16 t, t = 0 .. NB - 1, of a k-block that starts RB = 8 (NB - 2) rows before the first tile
 // it feeds: NB = 3 / 4 / 5 offsets reach every tap of radius <= 8 / 16 / 24 (the next offset at either end starts
-// 8 (NB - 2) + 1 rows away).  Built once per workgroup in LDS.  SciPy's "reflect" boundary is taken by the loads (rows mirrored, rows beyond reach clamped: zero weights).
-// An output tile is complete after NB / 2 k-blocks; its accumulators (four consecutive y per lane) go through LDS
+// 8 (NB - 2) + 1 rows away).  Built once per workgroup in LDS.  SciPy's "reflect" boundary is taken by the loads (rows
+// mirrored, rows beyond reach clamped: zero weights).
+// Two output tiles are complete after every k-block; their accumulators (four consecutive y per lane) go through LDS
 // (4 KiB per wave and tile) to come back as one row of 64 columns per step, lane = column as in y6_kernel, whose
 // ballot / sparse store / entry code then runs unchanged -- except that a tile with nothing above the threshold (a
 // ballot over the accumulators) skips all of it and writes its sixteen zero entries with one store.
