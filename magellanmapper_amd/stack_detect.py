@@ -159,8 +159,11 @@ class _ArenaSink:
         self.shapes = shapes
         self.exclude_of = exclude_of
         self.pruner = None
+        self.pruner_factory = None      # () -> _RegionPruner, called when the first batch lands
 
     def __call__(self, indices, pb, chl):
+        if self.pruner is None and self.pruner_factory is not None:
+            self.pruner, self.pruner_factory = self.pruner_factory(), None
         ar = self.arena
         idx = np.asarray(indices, dtype=np.int64)
         nb = len(idx)
@@ -439,16 +442,19 @@ class StackDetector:
         mine = dist.my_share(len(coords))            # all of them without torch.distributed
         shape3 = img.shape[:3]
         origins, shapes = [], []
+        n0, n1, n2 = (int(v) for v in shape3)
+        flat = sub_roi_slices.reshape(-1)            # (C order: the order of np.ndindex)
         for i in mine:
-            slc = sub_roi_slices[coords[i]]
-            a = [s.start for s in slc]
-            b = [s.stop for s in slc]
-            if any(v is None or v < 0 for v in a + b) or any(s.step not in (None, 1) for s in slc) or \
-                    any(q > n for q, n in zip(b, shape3)):
-                rng = [s.indices(n) for s, n in zip(slc, shape3)]      # (open-ended or negative bounds: Python's rules)
-                a, b = [r[0] for r in rng], [r[1] for r in rng]
-            origins.append((int(a[0]), int(a[1]), int(a[2])))
-            shapes.append((int(b[0] - a[0]), int(b[1] - a[1]), int(b[2] - a[2])))
+            z, y, x = flat[i]
+            a0, a1, a2, b0, b1, b2 = z.start, y.start, x.start, z.stop, y.stop, x.stop
+            if (a0 is None or a1 is None or a2 is None or b0 is None or b1 is None or b2 is None
+                    or a0 < 0 or a1 < 0 or a2 < 0 or b0 < 0 or b1 < 0 or b2 < 0 or b0 > n0 or b1 > n1 or b2 > n2
+                    or z.step not in (None, 1) or y.step not in (None, 1) or x.step not in (None, 1)):
+                a0, b0, _ = z.indices(n0)             # (open-ended or negative bounds: Python's rules)
+                a1, b1, _ = y.indices(n1)
+                a2, b2, _ = x.indices(n2)
+            origins.append((int(a0), int(a1), int(a2)))
+            shapes.append((int(b0 - a0), int(b1 - a1), int(b2 - a2)))
         stats = bl.BatchStats()
         tables = []
         n_extra = (img.shape[3] if len(img.shape) > 3 else 0) if coloc else 0
@@ -470,11 +476,14 @@ class StackDetector:
         #  moves ~4 ms of pruning under the GPU's last batches and adds most of that in the merge: 0.8-1.0 ms per volume
         #  in four alternating pairs of bench.py runs; it costs small stacks 0.6 ms: DESIGN.md)
         ahead = os.environ.get("MMX_PRUNE_AHEAD", "")
+        make_pruner = None
         if regular and dist.world_size() == 1 and mine and (ahead == "1" or (ahead != "0" and len(mine) >= 64)):
             ov, tl, pad, prune_channels = hint
-            pruner = _RegionPruner(arena, StackPruner._axis_plan(shape3, ov, tl, tl if pad is None else pad,
-                                                                 sub_roi_slices, sub_rois_offsets),
-                                   prune_channels, sub_roi_slices, shape3, mine)
+
+            def make_pruner():
+                return _RegionPruner(arena, StackPruner._axis_plan(shape3, ov, tl, tl if pad is None else pad,
+                                                                   sub_roi_slices, sub_rois_offsets),
+                                     prune_channels, sub_roi_slices, shape3, mine)
 
         def finish(k, tbl):
             # shift to ROI coordinates as soon as the block's batch is done (border exclusion and
@@ -495,10 +504,16 @@ class StackDetector:
             if arena is not None and n_extra == 0:
                 sink = _ArenaSink(arena, [coords[i] for i in mine], [sub_rois_offsets[coords[i]] for i in mine],
                                   shapes, exclude_of if exclude_border is not None else None)
-                sink.pruner = pruner
+                # (the pruner's set-up -- 0.7 ms for 256 blocks -- waits until the first batch has landed: by then every
+                #  batch is queued and the GPU busy)
+                sink.pruner_factory = make_pruner
+            elif make_pruner is not None:
+                pruner = make_pruner()
             tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
                                                          denoise_max_shape=denoise_max_shape,
                                                          exclude=exclude_of, coloc=coloc, sink=sink)
+            if sink is not None and sink.pruner is not None:
+                pruner = sink.pruner
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
         seg_rois = cls.assemble_seg_rois(local, grid, n_extra, arena, local_only=local_only)
