@@ -584,18 +584,22 @@ def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: Sc
 
 
 def _make_blocks(dvol: DeviceVolume, channel: int, origins, shapes):
+    """``mmx_block`` records of one batch (block i owns slot i) and the workspace slot size they need."""
     t = dvol.tensor
-    sz, sy, sx = t.stride()[0], t.stride()[1], t.stride()[2]
+    strides = np.array([t.stride()[0], t.stride()[1], t.stride()[2]], dtype=np.int64)
     blocks = np.zeros(len(shapes), dtype=nat.BLOCK_DTYPE)
-    slot = 1
-    for i, (o, shp) in enumerate(zip(origins, shapes)):
-        for ax in range(3):
-            if o[ax] < 0 or shp[ax] < 1 or o[ax] + shp[ax] > dvol.shape[ax]:
-                raise ValueError("block outside the volume")
-        px = -(-int(shp[2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN   # 128-B aligned rows
-        blocks[i] = (int(o[0]) * sz + int(o[1]) * sy + int(o[2]) * sx, shp[0], shp[1], shp[2], i, px, 0)
-        slot = max(slot, int(shp[0]) * int(shp[1]) * px)
-    return blocks, slot
+    if not len(shapes):
+        return blocks, 1
+    o = np.asarray(origins, dtype=np.int64).reshape(-1, 3)
+    shp = np.asarray(shapes, dtype=np.int64).reshape(-1, 3)
+    if (o < 0).any() or (shp < 1).any() or (o + shp > np.asarray(dvol.shape[:3], dtype=np.int64)).any():
+        raise ValueError("block outside the volume")
+    px = -(-shp[:, 2] // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN      # 128-B aligned rows
+    blocks["src_off"] = o @ strides
+    blocks["nz"], blocks["ny"], blocks["nx"] = shp[:, 0], shp[:, 1], shp[:, 2]
+    blocks["slot"] = np.arange(len(shp))
+    blocks["px"] = px
+    return blocks, max(1, int((shp[:, 0] * shp[:, 1] * px).max()))
 
 
 def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence[int]],
