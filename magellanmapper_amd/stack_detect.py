@@ -472,12 +472,14 @@ class StackDetector:
             return cls._exclude_matrix(coords[mine[k]], last_coord, exclude_border)
 
         pruner = None
-        # (MMX_PRUNE_AHEAD = 1 / 0 / unset: always / never / for stacks of 64 blocks and more.  On the benchmark volume it
+        # (MMX_PRUNE_AHEAD = 1 / 0 / unset: always / never / for raw stacks of 64 blocks and more -- with per-block
+        #  preprocessing on it measured 218.9 against 216.6 ms per volume: nothing to gain.  On the benchmark volume it
         #  moves ~4 ms of pruning under the GPU's last batches and adds most of that in the merge: 0.8-1.0 ms per volume
         #  in four alternating pairs of bench.py runs; it costs small stacks 0.6 ms: DESIGN.md)
         ahead = os.environ.get("MMX_PRUNE_AHEAD", "")
         make_pruner = None
-        if regular and dist.world_size() == 1 and mine and (ahead == "1" or (ahead != "0" and len(mine) >= 64)):
+        if regular and dist.world_size() == 1 and mine and (
+                ahead == "1" or (ahead != "0" and len(mine) >= 64 and denoise_max_shape is None)):
             ov, tl, pad, prune_channels = hint
 
             def make_pruner():
@@ -507,7 +509,9 @@ class StackDetector:
                 # (the pruner's set-up -- 0.7 ms for 256 blocks -- waits until the first batch has landed: by then every
                 #  batch is queued and the GPU busy)
                 sink.pruner_factory = make_pruner
-            elif make_pruner is not None:
+            elif make_pruner is not None and ahead == "1":
+                # (tables with co-localisation columns land block by block through finish(): pruning ahead there costs
+                #  the two-channel C5 run 35-55 ms per volume -- only on request)
                 pruner = make_pruner()
             tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
                                                          denoise_max_shape=denoise_max_shape,
