@@ -427,8 +427,10 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             with open(os.path.join(ROOT, PMC_FILE)) as f:
                 pmc = json.load(f)
             fresh = pmc.get("source_digest") == source_digest()
+            # (the counter passes ran the DEFAULT command: same volume, raw voxels, default batches, one rank)
             usable = (fresh and name == "c3" and tuple(shape) == cfg["shape"] and world == 1 and
-                      dom in pmc.get("per_launch_GB", {}))
+                      not PROFILE["denoise_size"] and use_vol is None and not args.budget_gb and
+                      not args.segment_size and dom in pmc.get("per_launch_GB", {}))
             if usable:
                 traffic = round(pmc["per_launch_GB"][dom]["total_GB"] * 1e9)
                 actual_frac = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
