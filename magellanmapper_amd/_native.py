@@ -102,6 +102,14 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} not found: the HIP extension has not been built "
             "(run __graft_entry__.build() or make -C magellanmapper_amd/csrc). "
             "There is no CPU fallback for this path.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64: when this library is loaded first, the loader binds it to the
+    # system's copy and a process that imports torch afterwards ends up with two HIP runtimes -- every launch on a torch
+    # stream then fails with "HIP runtime error" (seen with __graft_entry__.build() followed by smoke() in one
+    # process).  With torch imported first the runtime already in the process satisfies the dependency.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp = c_void_p
     L.mmx_abi_version.restype = c_int
