@@ -622,7 +622,11 @@ def main():
             baselines[name] = run_cpu_baseline(name, args, host_vol)
     # one rank per GPU; MMX_DIST_BACKEND=gloo + fewer GPUs than ranks is only for functional tests
     backend = os.environ.get("MMX_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
-    local_dev = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: --gpus {world} needs one GPU per rank, this node shows {n_dev} "
+                         "(a functional run of the N-rank path on fewer GPUs: MMX_DIST_BACKEND=gloo)")
+    local_dev = local_rank % max(1, n_dev) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:

@@ -1011,6 +1011,15 @@ class StackPruner:
         from . import dist
         ar = seg_rois.arena
         world, me = dist.world_size(), dist.rank()
+        from time import perf_counter
+        _prof = os.environ.get("MMX_PRUNE_PROF") and me == 0
+        _t = [perf_counter()]
+
+        def _lap(what):
+            if _prof:
+                now = perf_counter()
+                print(f"distributed prune, rank 0: {what}: {(now - _t[0]) * 1e3:.2f} ms", file=sys.stderr)
+                _t[0] = now
         grid = sub_roi_slices.shape
         coords = list(np.ndindex(*grid))
         n = ar.n
@@ -1034,14 +1043,22 @@ class StackPruner:
         zyx, tags, abs_own = ar.zyx[:n], ar.tag[:n], ar.abs[:n]
         chan_own = ar.store[:n, 6]
         near = np.zeros(n, dtype=bool)
+        own = boxes[me]
         for q, box in enumerate(boxes):
-            if q != me and box is not None and n:
-                near |= np.all((zyx >= box[0]) & (zyx < box[1]), axis=1)
+            if q == me or box is None or own is None or not n:
+                continue
+            # (both boxes carry the reach: a rank whose blocks are further away than twice that cannot hold a row in it)
+            if np.any(own[0] + reach >= box[1]) or np.any(own[1] - reach <= box[0]):
+                continue
+            near |= ((zyx[:, 0] >= box[0][0]) & (zyx[:, 0] < box[1][0]) & (zyx[:, 1] >= box[0][1]) &
+                     (zyx[:, 1] < box[1][1]) & (zyx[:, 2] >= box[0][2]) & (zyx[:, 2] < box[1][2]))
         sel = np.flatnonzero(near)
         payload = np.empty((len(sel), 10))
         payload[:, 0:3], payload[:, 3:6] = zyx[sel], tags[sel]
         payload[:, 6:9], payload[:, 9] = abs_own[sel], chan_own[sel]
+        _lap("rows near the other ranks' blocks")
         parts = dist.all_gather_rows(payload, 10)
+        _lap("exchange 1 (seam rows)")
         mine_box = boxes[me]
         before, after = [], []
         for q, part in enumerate(parts):
@@ -1056,7 +1073,9 @@ class StackPruner:
         abs_l = np.ascontiguousarray(np.concatenate((halo_b[:, 6:9], abs_own, halo_a[:, 6:9])), dtype=np.float64)
         chan_l = np.concatenate((halo_b[:, 9], chan_own, halo_a[:, 9]))
         own_lo = len(halo_b)
+        _lap("own + halo tables")
         rows, keys, counts = cls._prune_table(zyx_l, tag_l, abs_l, chan_l, own_lo, own_lo + n, channels, plan)
+        _lap("three passes on own + halo rows")
         # own survivors in their final form + the key that places them
         mine = np.empty((len(rows), ncol - 2))
         if len(rows):
@@ -1070,7 +1089,9 @@ class StackPruner:
                 ncol - 3, abs_rows.ctypes.data, cols3, body.ctypes.data), "mmx_host_gather_by_key")
             mine[:, :ncol - 3] = body
             mine[:, ncol - 3] = keys
+        _lap("own survivors in final form")
         everyone = dist.all_gather_rows(mine, ncol - 2)
+        _lap("exchange 2 (survivors)")
         table = np.concatenate(everyone) if len(everyone) > 1 else everyone[0]
         table = np.ascontiguousarray(table)
         out = np.empty((len(table), ncol - 3))
@@ -1079,7 +1100,9 @@ class StackPruner:
             nat.check(nat.lib().mmx_host_merge_by_key(
                 table.ctypes.data, ncol - 2, all_keys.ctypes.data, len(table), plan["n_keys"] * len(channels),
                 ncol - 3, out.ctypes.data), "mmx_host_merge_by_key")
+        _lap("merge by key")
         counts = dist.all_reduce_sum(counts.reshape(-1)).reshape(counts.shape)
+        _lap("counts all_reduce")
         return out, counts
 
     @classmethod
