@@ -3,10 +3,10 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
 import numpy as np, torch
 from magellanmapper_amd import blob_log as bl, config, stack_detect, synth, _native as nat
 import bench, functools
-shape = bench.SHAPE
+shape = bench.CONFIGS["c3"]["shape"]
 dev = torch.device("cuda", 0)
 config.resolutions = bench.RESOLUTIONS; config.filename = "p"
-config.setup_roi_profiles(None); config.roi_profile.update(bench.PROFILE)
+config.setup_roi_profiles(None); config.roi_profile.update(dict(bench._BASE_PROFILE, **bench.CONFIGS["c3"]["profile"]))
 vol = synth.make_volume_device(shape, 3, dev)
 dvol = bl.DeviceVolume(vol)
 blocks = stack_detect.setup_blocks(config.roi_profile, shape)
