@@ -261,6 +261,7 @@ class _RegionPruner:
         self.done = [None] * len(self.regions)
         self.pending = list(range(len(self.regions)))
         self._pool = None
+        self._futures = []
         self._channels = np.ascontiguousarray(self.channels, dtype=np.float64)
 
     def matches(self, arena, plan, channels) -> bool:
@@ -281,10 +282,10 @@ class _RegionPruner:
         if not ready:
             return
         self.pending = [i for i in self.pending if self.regions[i]["ready_at"] > landed]
-        if len(ready) == 1:
-            self._run(ready[0])
-        else:
-            list(self._workers().map(self._run, ready))
+        # (not waited for: towards the end of a stack the batches are small and the host thread is what the step waits
+        #  for -- 1.5 ms per batch when the regions ran inside this call; finish() collects them)
+        pool = self._workers()
+        self._futures.extend(pool.submit(self._run, i) for i in ready)
 
     def _workers(self):
         if self._pool is None:
@@ -296,6 +297,9 @@ class _RegionPruner:
         """One region: its rows and its neighbours' rows within reach, straight from the arena
         (``mmx_host_prune_parts``: the local table is put together natively)."""
         ar, r = self.arena, self.regions[i]
+        # (this may run beside the arena growing: the rows it reads have landed and never change, and these references
+        #  keep the arrays it reads them from alive should the arena move to larger ones meanwhile)
+        a_zyx, a_tag, a_abs, a_store = ar.zyx, ar.tag, ar.abs, ar.store
         ends = ar.row_end
         members = sorted(r["near"] + [i])
         parts = np.array([[ends[self.regions[j]["k_lo"]], ends[self.regions[j]["k_hi"]]] for j in members],
@@ -312,8 +316,8 @@ class _RegionPruner:
         lo = np.ascontiguousarray(r["lo"], dtype=np.int32)
         hi = np.ascontiguousarray(r["hi"], dtype=np.int32)
         nat.check(nat.lib().mmx_host_prune_parts(
-            ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data,
-            None if one_channel else ar.store.ctypes.data + 6 * 8, ar.store.strides[0] // 8,
+            a_zyx.ctypes.data, a_tag.ctypes.data, a_abs.ctypes.data,
+            None if one_channel else a_store.ctypes.data + 6 * 8, a_store.strides[0] // 8,
             parts.ctypes.data, len(parts), members.index(i),
             lo.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), hi.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
             self._channels.ctypes.data, len(self.channels), n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi,
@@ -326,7 +330,11 @@ class _RegionPruner:
         """Whatever is left, then the merge: ``(final table, counts)``."""
         if self.pending:            # (everything has landed by now)
             todo, self.pending = self.pending, []
-            list(self._workers().map(self._run, todo)) if len(todo) > 1 else self._run(todo[0])
+            pool = self._workers()
+            self._futures.extend(pool.submit(self._run, i) for i in todo)
+        for f in self._futures:     # (an exception of a region surfaces here)
+            f.result()
+        self._futures = []
         if self._pool is not None:
             self._pool.shutdown(wait=False)
             self._pool = None

@@ -953,7 +953,7 @@ def _synthetic_block_tables(rng, shape, blocks, n_blobs, channels=(0,), jitter=3
 
 
 @pytest.mark.parametrize("case", ["one_channel", "two_channels_extra_columns", "thin_last_blocks", "one_axis"])
-def test_region_wise_pruning_equals_the_whole_table_passes(case):
+def test_region_wise_pruning_equals_the_whole_table_passes(case, monkeypatch):
     """The three passes run region by region (own rows + a halo of neighbouring rows) as blocks land, then merged
     by key, against the same passes over the whole table: identical rows in identical order, identical averaged
     coordinates, identical pruning-ratio statistics."""
@@ -993,6 +993,13 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case):
             seg[coords[k]] = tbl
             if pruner is not None:
                 pruner.advance()
+        # (the arena moves to larger arrays as it grows: the views are taken once everything has landed, as
+        #  StackDetector.assemble_seg_rois does -- otherwise prune_blobs_mp finds the arena no longer intact and prunes
+        #  the whole table, which is not what this test is about)
+        for k in share:
+            if seg[coords[k]] is not None:
+                seg[coords[k]] = arena.view(coords[k])
+        assert arena.intact(seg)
         seg.arena, seg.pruner = arena, pruner
         return seg, pruner
 
@@ -1003,9 +1010,12 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case):
     want, df_want = sd.StackPruner.prune_blobs_mp(Img, seg_a, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                    blocks.sub_rois_offsets, channels, blocks.overlap_padding)
     seg_b, pruner = build(True)
+    merges = []
+    merge = sd._RegionPruner.finish
+    monkeypatch.setattr(sd._RegionPruner, "finish", lambda self, cols: (merges.append(self), merge(self, cols))[1])
     got, df_got = sd.StackPruner.prune_blobs_mp(Img, seg_b, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                  blocks.sub_rois_offsets, channels, blocks.overlap_padding)
-    assert not pruner.pending and all(d is not None for d in pruner.done)      # (it was used)
+    assert merges == [pruner] and not pruner.pending and all(d is not None for d in pruner.done)      # (it was used)
     if len(pruner.regions) > 4:
         assert 0 < before_last[0] < len(pruner.regions)      # some regions early, the last ones once everything landed
     assert len(want) < sum(len(t) for t in tables.values() if t is not None)                    # duplicates were removed

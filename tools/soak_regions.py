@@ -58,6 +58,10 @@ for trial in range(n_trials):
             segr[coords[k]] = tbl
             if pruner is not None:
                 pruner.advance()
+        for k in share:          # (views taken once everything has landed, as assemble_seg_rois does: the arena stays "intact")
+            if segr[coords[k]] is not None:
+                segr[coords[k]] = arena.view(coords[k])
+        assert arena.intact(segr)
         segr.arena, segr.pruner = arena, pruner
         return segr
 
@@ -69,7 +73,9 @@ for trial in range(n_trials):
         skipped += 1
         continue
     want, df_want = sd.StackPruner.prune_blobs_mp(Img, build(False), *args)
-    got, df_got = sd.StackPruner.prune_blobs_mp(Img, build(True), *args)
+    seg_b = build(True)
+    got, df_got = sd.StackPruner.prune_blobs_mp(Img, seg_b, *args)
+    assert all(d is not None for d in seg_b.pruner.done), "the regions were not merged"
     ok = np.array_equal(got, want) and np.array_equal(df_got.to_numpy(), df_want.to_numpy())
     done += 1
     if not ok:
