@@ -198,15 +198,9 @@ def raise_together(failure: Optional[BaseException], what: str = "a rank") -> No
 
 
 @_timed
-def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.ndarray]:
-    """Every rank's ``(n_r, c)`` float64 array, in rank order (two collectives: the row counts, then the rows padded
-    to the largest count).  Ranks without rows may pass ``n_cols=None`` / a ``(0, 0)`` array: the width is agreed on
-    first.  Without a process group: ``[rows]``."""
-    rows = np.ascontiguousarray(rows, dtype=np.float64)
-    if rows.ndim != 2:
-        rows = rows.reshape(len(rows), -1) if rows.size else np.zeros((0, 0))
-    if not _active() or world_size() == 1:
-        return [rows]
+def _gather_rows(rows: np.ndarray, n_cols: Optional[int]):
+    """``(buffers (n_ranks, most, width) or None, per-rank row counts, width)``: every rank's rows, padded to the
+    largest count (two collectives: the counts, then the rows)."""
     dev = _device_for_collectives()
     n_ranks = world_size()
     meta = torch.tensor([rows.shape[0], rows.shape[1] if rows.shape[0] else int(n_cols or 0)], dtype=torch.int64, device=dev)
@@ -217,9 +211,10 @@ def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.n
     have = metas[metas[:, 0] > 0, 1]
     if len(have) and not np.all(have == have[0]):
         raise ValueError(f"ranks hold rows of different widths: {sorted(set(int(v) for v in have))}")
-    most = int(metas[:, 0].max())
+    counts = [int(v) for v in metas[:, 0]]
+    most = max(counts)
     if most == 0 or width == 0:
-        return [np.zeros((0, width)) for _ in range(n_ranks)]
+        return None, counts, width
     if dev.type == "cpu":
         padded = np.zeros((most, width))
         padded[:rows.shape[0], :rows.shape[1]] = rows
@@ -242,7 +237,39 @@ def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.n
         back[:n_ranks * most * width].view(n_ranks * most, width).copy_(recv, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         bufs = back.numpy()[:n_ranks * most * width].reshape(n_ranks, most, width)
-    return [np.array(bufs[r, :int(metas[r, 0])]) for r in range(n_ranks)]
+    return bufs, counts, width
+
+
+def _as_rows(rows: np.ndarray) -> np.ndarray:
+    rows = np.ascontiguousarray(rows, dtype=np.float64)
+    if rows.ndim != 2:
+        rows = rows.reshape(len(rows), -1) if rows.size else np.zeros((0, 0))
+    return rows
+
+
+def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.ndarray]:
+    """Every rank's ``(n_r, c)`` float64 array, in rank order (two collectives: the row counts, then the rows padded
+    to the largest count).  Ranks without rows may pass ``n_cols=None`` / a ``(0, 0)`` array: the width is agreed on
+    first.  Without a process group: ``[rows]``."""
+    rows = _as_rows(rows)
+    if not _active() or world_size() == 1:
+        return [rows]
+    bufs, counts, width = _gather_rows(rows, n_cols)
+    if bufs is None:
+        return [np.zeros((0, width)) for _ in counts]
+    return [np.array(bufs[r, :n]) for r, n in enumerate(counts)]
+
+
+def all_gather_rows_concat(rows: np.ndarray, n_cols: Optional[int] = None) -> np.ndarray:
+    """The same exchange with every rank's rows back to back in ONE array, rank after rank (one copy out of the
+    receive buffer instead of a copy per rank and a concatenation: 2 ms for the 21 MB of a pruned benchmark table)."""
+    rows = _as_rows(rows)
+    if not _active() or world_size() == 1:
+        return rows
+    bufs, counts, width = _gather_rows(rows, n_cols)
+    if bufs is None:
+        return np.zeros((0, width))
+    return np.concatenate([bufs[r, :n] for r, n in enumerate(counts)])
 
 
 _pinned_bufs = {}

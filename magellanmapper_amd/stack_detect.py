@@ -1098,10 +1098,8 @@ class StackPruner:
             mine[:, :ncol - 3] = body
             mine[:, ncol - 3] = keys
         _lap("own survivors in final form")
-        everyone = dist.all_gather_rows(mine, ncol - 2)
+        table = dist.all_gather_rows_concat(mine, ncol - 2)
         _lap("exchange 2 (survivors)")
-        table = np.concatenate(everyone) if len(everyone) > 1 else everyone[0]
-        table = np.ascontiguousarray(table)
         out = np.empty((len(table), ncol - 3))
         if len(table):
             all_keys = np.ascontiguousarray(table[:, ncol - 3], dtype=np.int64)
