@@ -57,6 +57,34 @@ def _worker(rank, world, port, n_items, out_dir):
         td.destroy_process_group()
 
 
+def _worker_rows(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from magellanmapper_amd import dist as d
+
+        def rows_of(r):          # rank 1 holds nothing; the others different numbers of rows
+            n = 0 if r == 1 else 3 + 2 * r
+            return (np.arange(n * 5, dtype=np.float64).reshape(n, 5) + 1000.0 * r) if n else np.zeros((0, 0))
+        parts = d.all_gather_rows(rows_of(rank), 5)
+        joined = d.all_gather_rows_concat(rows_of(rank), 5)
+        assert len(parts) == world
+        for r, p in enumerate(parts):
+            want = rows_of(r)
+            assert p.shape == ((0, 5) if want.size == 0 else want.shape)
+            if want.size:
+                np.testing.assert_array_equal(p, want)
+        np.testing.assert_array_equal(joined, np.concatenate([p for p in parts]))
+        assert joined.flags["C_CONTIGUOUS"] and joined.shape[1] == 5
+        # nobody holds anything: an empty table of the agreed width
+        assert d.all_gather_rows_concat(np.zeros((0, 0)), 7).shape == (0, 7)
+        open(os.path.join(out_dir, f"rows{rank}"), "w").write("ok")
+    finally:
+        td.destroy_process_group()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -275,3 +303,11 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
         assert got.shape == want.shape
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(ratios.reshape(df.shape), df.to_numpy())
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rows_of_all_ranks_back_to_back(tmp_path, world):
+    """``dist.all_gather_rows`` / ``all_gather_rows_concat``: uneven shares, a rank without rows, nobody with rows -- the
+    concatenated form is the per-rank form back to back (what the distributed pruning merges by key)."""
+    tmp.spawn(_worker_rows, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"rows{r}").exists() for r in range(world))
