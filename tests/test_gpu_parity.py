@@ -195,6 +195,32 @@ def test_multi_block_batch_equals_per_block(gpu):
         np.testing.assert_array_equal(a, b)
 
 
+def test_the_tail_of_a_batch_on_its_own_stream_changes_nothing(gpu, monkeypatch):
+    """Raw volumes: NMS, probe expansion and exact re-score of a batch run on a second stream beside the next batch's
+    LoG kernels, the batches alternating between two workspaces (``blob_log.RESCORE_STREAM``).  Several batches of
+    different sizes, with and without it: identical peaks, values included."""
+    from magellanmapper_amd import blob_log as bl, synth
+    vol = synth.make_volume(23, (70, 150, 160), 140)
+    dvol = bl.DeviceVolume(vol)
+    origins = [(z, y, x) for z in (0, 30) for y in (0, 50, 100) for x in (0, 55, 110)]
+    shapes = [(40, 50, 50)] * len(origins)
+    runs = []
+    for on in (True, False, True):
+        monkeypatch.setattr(bl, "RESCORE_STREAM", on)
+        st = bl.BatchStats()
+        res, peaks = bl.blob_log_blocks(dvol, 0, origins, shapes, 2, 4, 3, 0.08, 0.5, budget_bytes=24 << 20,
+                                        stats=st, return_peaks=True)
+        runs.append((res, peaks, st))
+    assert runs[0][2].n_blobs > 100
+    for res, peaks, st in runs[1:]:
+        assert st.n_candidates == runs[0][2].n_candidates and st.n_blobs == runs[0][2].n_blobs
+        for a, b in zip(res, runs[0][0]):
+            np.testing.assert_array_equal(a, b)
+        for (ca, va), (cb, vb) in zip(peaks, runs[0][1]):
+            np.testing.assert_array_equal(ca, cb)
+            np.testing.assert_array_equal(va, vb)
+
+
 def test_large_sigma_takes_generic_path(gpu):
     """sigma 7.5 -> radius 30 > MMX_MAX_RADIUS_FAST: generic kernels, same exactness."""
     from magellanmapper_amd import blob_log as bl
