@@ -81,7 +81,7 @@ def _timed(fn):
         try:
             return fn(*args, **kwargs)
         finally:
-            if _active() and world_size() > 1:
+            if _multi_rank():
                 _exchange_ms += (time.perf_counter() - t0) * 1e3
     return inner
 
@@ -100,7 +100,7 @@ def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: in
     """
     global _last_gather_ms
     _last_gather_ms = 0.0
-    if not _active() or world_size() == 1:
+    if not _multi_rank():
         return sorted(local, key=lambda e: e[0])
     import time
     t_start = time.perf_counter()
@@ -188,7 +188,7 @@ def raise_together(failure: Optional[BaseException], what: str = "a rank") -> No
     """Agree on whether any rank failed before the next collective: re-raises ``failure`` on the rank that holds it
     and raises ``RuntimeError`` on all the others, instead of leaving them waiting in a collective the failed rank
     never enters (one tiny all_reduce; nothing without a process group beyond re-raising)."""
-    if _active() and world_size() > 1:
+    if _multi_rank():
         flag = torch.tensor([0 if failure is None else 1], dtype=torch.int64, device=_device_for_collectives())
         tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
         if int(flag.item()) and failure is None:
@@ -197,16 +197,34 @@ def raise_together(failure: Optional[BaseException], what: str = "a rank") -> No
         raise failure
 
 
+def _multi_rank() -> bool:
+    """True when collectives have somebody to talk to.  ``_force_collectives`` (a test hook, never set by the
+    product) sends a ONE-rank group through the collective code as well, so that a single GPU can execute the RCCL
+    branches: pinned staging, ``all_gather_into_tensor`` on device tensors, the stream ordering around them."""
+    return _active() and (world_size() > 1 or _force_collectives)
+
+
+_force_collectives = False
+
+
 @_timed
-def _gather_rows(rows: np.ndarray, n_cols: Optional[int]):
+def _gather_rows(rows: np.ndarray, n_cols: Optional[int], failure: Optional[BaseException] = None,
+                 what: str = "a rank"):
     """``(buffers (n_ranks, most, width) or None, per-rank row counts, width)``: every rank's rows, padded to the
-    largest count (two collectives: the counts, then the rows)."""
+    largest count (two collectives: the counts, then the rows).  ``failure``: what this rank's preparation of the
+    rows raised, if anything -- it travels with the counts, so that every rank raises before the second collective
+    instead of waiting in it for a rank that never comes."""
     dev = _device_for_collectives()
     n_ranks = world_size()
-    meta = torch.tensor([rows.shape[0], rows.shape[1] if rows.shape[0] else int(n_cols or 0)], dtype=torch.int64, device=dev)
+    meta = torch.tensor([rows.shape[0], rows.shape[1] if rows.shape[0] else int(n_cols or 0),
+                         0 if failure is None else 1], dtype=torch.int64, device=dev)
     metas = [torch.zeros_like(meta) for _ in range(n_ranks)]
     tdist.all_gather(metas, meta)
     metas = torch.stack(metas).cpu().numpy()
+    if failure is not None:
+        raise failure
+    if metas[:, 2].any():
+        raise RuntimeError(f"{what} failed on rank {int(np.flatnonzero(metas[:, 2])[0])}; see its log")
     width = int(metas[:, 1].max())
     have = metas[metas[:, 0] > 0, 1]
     if len(have) and not np.all(have == have[0]):
@@ -247,26 +265,33 @@ def _as_rows(rows: np.ndarray) -> np.ndarray:
     return rows
 
 
-def all_gather_rows(rows: np.ndarray, n_cols: Optional[int] = None) -> List[np.ndarray]:
+def all_gather_rows(rows: Optional[np.ndarray], n_cols: Optional[int] = None,
+                    failure: Optional[BaseException] = None, what: str = "a rank") -> List[np.ndarray]:
     """Every rank's ``(n_r, c)`` float64 array, in rank order (two collectives: the row counts, then the rows padded
     to the largest count).  Ranks without rows may pass ``n_cols=None`` / a ``(0, 0)`` array: the width is agreed on
-    first.  Without a process group: ``[rows]``."""
-    rows = _as_rows(rows)
-    if not _active() or world_size() == 1:
+    first.  ``failure``: an exception this rank met while making ``rows`` (which may then be ``None``); every rank
+    raises.  Without a process group: ``[rows]``."""
+    rows = _as_rows(np.zeros((0, 0)) if rows is None else rows)
+    if not _multi_rank():
+        if failure is not None:
+            raise failure
         return [rows]
-    bufs, counts, width = _gather_rows(rows, n_cols)
+    bufs, counts, width = _gather_rows(rows, n_cols, failure, what)
     if bufs is None:
         return [np.zeros((0, width)) for _ in counts]
     return [np.array(bufs[r, :n]) for r, n in enumerate(counts)]
 
 
-def all_gather_rows_concat(rows: np.ndarray, n_cols: Optional[int] = None) -> np.ndarray:
+def all_gather_rows_concat(rows: Optional[np.ndarray], n_cols: Optional[int] = None,
+                           failure: Optional[BaseException] = None, what: str = "a rank") -> np.ndarray:
     """The same exchange with every rank's rows back to back in ONE array, rank after rank (one copy out of the
     receive buffer instead of a copy per rank and a concatenation: 2 ms for the 21 MB of a pruned benchmark table)."""
-    rows = _as_rows(rows)
-    if not _active() or world_size() == 1:
+    rows = _as_rows(np.zeros((0, 0)) if rows is None else rows)
+    if not _multi_rank():
+        if failure is not None:
+            raise failure
         return rows
-    bufs, counts, width = _gather_rows(rows, n_cols)
+    bufs, counts, width = _gather_rows(rows, n_cols, failure, what)
     if bufs is None:
         return np.zeros((0, width))
     return np.concatenate([bufs[r, :n] for r, n in enumerate(counts)])
@@ -287,7 +312,7 @@ def _pinned(name: str, n: int):
 def all_reduce_sum(values: np.ndarray) -> np.ndarray:
     """Element-wise sum of an int64 array over the ranks (the array itself without a process group)."""
     values = np.ascontiguousarray(values, dtype=np.int64)
-    if not _active() or world_size() == 1:
+    if not _multi_rank():
         return values
     t = torch.from_numpy(values.copy()).to(_device_for_collectives())
     tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
@@ -296,7 +321,7 @@ def all_reduce_sum(values: np.ndarray) -> np.ndarray:
 
 def broadcast_table(table: Optional[np.ndarray], src: int = 0) -> Optional[np.ndarray]:
     """``table`` of rank ``src`` (a float64 2-D array or ``None``) on every rank."""
-    if not _active() or world_size() == 1:
+    if not _multi_rank():
         return table
     dev = _device_for_collectives()
     is_src = rank() == src

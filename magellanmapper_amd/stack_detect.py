@@ -144,7 +144,21 @@ class _TableArena:
             if span is None or span[0] != at or not np.shares_memory(tbl, self.store):
                 return False
             at = span[1]
-        return at == self.n
+        return at == self.n and self._columns_unedited()
+
+    def _columns_unedited(self) -> bool:
+        """The compact columns the pruning reads (``zyx``, ``abs``: copies made when the rows landed) still say what
+        the tables say, on a sample of the rows (every 61st and the last: 50 us for 3 x 10^5 rows).  Tables handed
+        out by ``detect_blobs_sub_rois`` are views of the arena and the reference's API lets a caller edit them in
+        place before ``prune_blobs_mp`` (shift them, say); such an edit is meant to be seen, and the arena's
+        shortcuts would not see it -- ``prune_blobs_mp`` then works from the tables themselves."""
+        n = self.n
+        if n == 0:
+            return True
+        pick = np.append(np.arange(0, n, 61), n - 1)
+        return bool(np.array_equal(self.store[pick, :3], self.zyx[pick]) and
+                    np.array_equal(self.store[pick, 7:10], self.abs[pick]) and
+                    np.array_equal(self.store[pick, self.n_cols:], self.tag[pick]))
 
 
 class _ArenaSink:
@@ -326,6 +340,19 @@ class _RegionPruner:
         k = out_n.value
         self.done[i] = (ids[:k], keys[:k], abs_rows[:k], np.moveaxis(stat, 0, -1))
 
+    def cancel(self) -> None:
+        """Give up on pruning ahead (``prune_blobs_mp`` was called with other parameters, the arena is no longer
+        intact, the detection failed): regions not started are dropped, running ones are waited for, the worker
+        threads end, and an exception a region raised surfaces here instead of vanishing with its future."""
+        self.pending = []
+        futures, self._futures = self._futures, []
+        if self._pool is not None:
+            self._pool.shutdown(wait=True, cancel_futures=True)
+            self._pool = None
+        for f in futures:
+            if not f.cancelled():
+                f.result()
+
     def finish(self, abs_inds):
         """Whatever is left, then the merge: ``(final table, counts)``."""
         if self.pending:            # (everything has landed by now)
@@ -381,7 +408,10 @@ class StackDetector:
         """Tell the next :meth:`detect_blobs_sub_rois` call what ``StackPruner.prune_blobs_mp`` will be called
         with, so that finished regions of the stack are pruned while the GPU is still busy with later blocks
         (the host idles through most of a detection).  One shot; purely an optimisation: ``prune_blobs_mp`` checks
-        that its own arguments are the ones planned for and otherwise prunes the whole table as always."""
+        that its own arguments are the ones planned for and that the block tables are still the ones that landed
+        (they are views of one arena: editing them IN PLACE between the two calls is allowed, as in the reference, and
+        is detected on a sample of rows -- a caller that does so should not plan ahead) and otherwise cancels the
+        regions pruned ahead and prunes the whole table as always."""
         cls.prune_hint = (np.asarray(overlap), np.asarray(tol),
                           None if overlap_padding is None else np.asarray(overlap_padding), list(channels))
 
@@ -521,9 +551,19 @@ class StackDetector:
                 # (tables with co-localisation columns land block by block through finish(): pruning ahead there costs
                 #  the two-channel C5 run 35-55 ms per volume -- only on request)
                 pruner = make_pruner()
-            tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
-                                                         denoise_max_shape=denoise_max_shape,
-                                                         exclude=exclude_of, coloc=coloc, sink=sink)
+            try:
+                tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
+                                                             denoise_max_shape=denoise_max_shape,
+                                                             exclude=exclude_of, coloc=coloc, sink=sink)
+            except BaseException:
+                # the detection failed: the regions pruned ahead have nobody to collect them
+                for p_ in (pruner, None if sink is None else sink.pruner):
+                    if p_ is not None:
+                        try:
+                            p_.cancel()
+                        except Exception:       # (the detection's own exception is the one to report)
+                            pass
+                raise
             if sink is not None and sink.pruner is not None:
                 pruner = sink.pruner
         cls.last_stats = stats
@@ -641,94 +681,141 @@ def _prepare_subimg(image5d, offset, size):
     return image5d[0][sl]
 
 
+class _StackRun:
+    """One whole-image detection from ROI to ``Blobs`` (what ``detect_blobs_blocks`` does, reference :338-517, as four
+    steps over shared state): :meth:`resolve_roi` (which voxels, which channels, where results are written),
+    :meth:`detect` (blocks -> per-block tables), :meth:`prune` (the overlap de-duplication, on one rank or as a
+    collective) and :meth:`finish` (final columns, metadata, the side files the reference writes)."""
+
+    def __init__(self, filename_base, img5d, save_dfs: bool):
+        self.t0 = time()
+        self.base = filename_base
+        self.volume = img5d.img
+        self.img5d = img5d
+        self.save_dfs = save_dfs
+        self.seconds = {}
+
+    def resolve_roi(self, offset, size, channels, full_roi: bool, coloc: bool):
+        """ROI voxels (the whole first time point or a sub-image), output paths, channels, co-localisation only
+        with two channels and more (:374-397)."""
+        vol = self.volume
+        self.path_base = self.base
+        if offset is None or size is None:
+            offset, size = (0, 0, 0), vol.shape[1:4]
+        else:
+            self.path_base = _subimage_name(self.base, offset, size)
+        self.offset, self.size = offset, size
+        self.roi = vol[0] if full_roi else _prepare_subimg(vol, offset, size)
+        self.n_roi_channels = self.roi.shape[3] if self.roi.ndim > 3 else 1
+        self.coloc = bool(coloc) and self.n_roi_channels > 1
+        self.channels = (detector._channels_of(self.roi.ndim, self.n_roi_channels, None)[1]
+                         if channels is None else channels)
+        return self
+
+    def _timed(self, key, fn):
+        start = time()
+        out = fn()
+        self.seconds[key] = time() - start
+        return out
+
+    def detect(self):
+        """Block geometry from the FIRST channel's profile (:399-404), then every block of this rank's share; the
+        pruning parameters are announced first so that finished regions can be pruned while the GPU is busy."""
+        def run():
+            self.blocks = bk = setup_blocks(config.get_roi_profile(self.channels[0]), self.roi.shape)
+            StackDetector.plan_pruning(bk.overlap, bk.tol, bk.overlap_padding, self.channels)
+            return StackDetector.detect_blobs_sub_rois(
+                self.img5d, self.roi, bk.sub_roi_slices, bk.sub_rois_offsets, bk.denoise_max_shape,
+                bk.exclude_border, self.coloc, self.channels)
+        self.seg_rois = self._timed(StackTimes.DETECTION, run)
+        return self
+
+    def _prune_here(self):
+        bk = self.blocks
+        return StackPruner.prune_blobs_mp(self.roi, self.seg_rois, bk.overlap, bk.tol, bk.sub_roi_slices,
+                                          bk.sub_rois_offsets, self.channels, bk.overlap_padding)
+
+    def prune(self):
+        """The merged, pruned table on every rank.  One rank: a plain call.  Several ranks: either the tables stayed
+        on their ranks and the pruning is a collective, or they were gathered on rank 0, which prunes and broadcasts
+        (telling the others first if it failed: they are about to wait for the table)."""
+        from . import dist
+
+        def run():
+            if getattr(self.seg_rois, "local_only", False):
+                return self._prune_here()
+            table, frame, failure = None, None, None
+            if dist.rank() == 0:
+                try:
+                    table, frame = self._prune_here()
+                except Exception as exc:
+                    failure = exc
+            dist.raise_together(failure, "pruning on rank 0")
+            return dist.broadcast_table(table), frame
+        self.table, self.ratios = self._timed(StackTimes.PRUNING, run)
+        return self
+
+    def finish(self):
+        """``Blobs`` in the reference's final form (:455-498): rel <- abs, co-localisation flags read from column 10
+        on (the reference's own off-by-one, kept: DESIGN.md section 2c), abs columns dropped; metadata; the CSVs and
+        the optional sub-image file, on rank 0 only."""
+        from . import dist
+        root = dist.rank() == 0
+        if root and self.save_dfs and self.ratios is not None and len(self.ratios):
+            _save_pruning_ratios(self.ratios)
+        blobs = detector.Blobs(self.table, path=_combine_paths(self.path_base, config.SUFFIX_BLOBS))
+        final, flags = self.table, None
+        if final is not None:
+            blobs.replace_rel_with_abs_blob_coords(final)
+            blobs.blobs = final
+            if self.coloc:
+                flags = final[:, 10:10 + self.n_roi_channels].astype(np.uint8)
+            final = blobs.remove_abs_blob_coords(True)
+        if config.save_subimg and root:
+            _save_subimage(_combine_paths(self.path_base, config.SUFFIX_SUBIMG), self.volume, self.roi)
+        blobs.blobs, blobs.colocalizations = final, flags
+        blobs.resolutions = config.resolutions
+        blobs.basename = os.path.basename(config.filename) if config.filename else None
+        blobs.roi_offset, blobs.roi_size = self.offset, self.size
+        blobs.times = {StackTimes.DETECTION: [self.seconds[StackTimes.DETECTION]],
+                       StackTimes.PRUNING: [self.seconds[StackTimes.PRUNING]], StackTimes.TOTAL: time() - self.t0}
+        if self.save_dfs and root:
+            import pandas as pd
+            pd.DataFrame({k.value: v for k, v in blobs.times.items()}).to_csv("stack_detection_times.csv", index=False)
+        _logger.info("No blobs detected" if final is None else f"Total blobs found: {len(final)}")
+        return blobs
+
+
+def _save_subimage(path: str, volume, roi) -> None:
+    """``config.save_subimg``: the ROI as a ``.npy`` file next to the blobs archive (reference :477-489); skipped with
+    a warning when the image itself is a memory map of that very file (saving would truncate what is being read)."""
+    if isinstance(volume, np.memmap) and getattr(volume, "filename", None) == os.path.abspath(path):
+        _logger.warning("%s is currently open, cannot save sub-image", path)
+        return
+    if not isinstance(roi, np.ndarray):
+        # an image already resident in HBM (a DeviceVolume / a tensor): its voxels as they are there -- the
+        # caller's own for the voxel types the kernels read in place (uint8 / uint16 / float32 / float64)
+        tensor = getattr(roi, "tensor", roi)
+        if not hasattr(tensor, "cpu"):
+            raise TypeError(f"config.save_subimg: cannot save a ROI of type {type(roi).__name__}")
+        roi = tensor.cpu().numpy()
+    with open(path, "wb") as f:
+        np.save(f, roi)
+
+
 def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, channels=None,
                         verify: bool = False, save_dfs: bool = True, full_roi: bool = False,
                         coloc: bool = False):
-    """Detect blobs in a large image block by block -> ``(stats, fdbk, Blobs)``."""
-    time_start = time()
+    """Detect blobs in a large image block by block -> ``(stats, fdbk, Blobs)`` (reference :338-517).
+
+    Several ranks (``torch.distributed``): every rank detects its share of the blocks and all return the same
+    table; only rank 0 writes ``blob_ratios*.csv``, ``stack_detection_times.csv`` and the sub-image."""
     if img5d.img is None:
         raise ValueError("Image data is None")
     if verify:
         raise NotImplementedError("truth-set verification is outside this path's scope")
-    image5d = img5d.img
-    subimg_path_base = filename_base
-    if size is None or offset is None:
-        size = image5d.shape[1:4]
-        offset = (0, 0, 0)
-    else:
-        subimg_path_base = _subimage_name(filename_base, offset, size)
-    filename_blobs = _combine_paths(subimg_path_base, config.SUFFIX_BLOBS)
-
-    roi = image5d[0] if full_roi else _prepare_subimg(image5d, offset, size)
-    num_chls_roi = 1 if len(roi.shape) < 4 else roi.shape[3]
-    if num_chls_roi < 2:
-        coloc = False
-
-    time_detection_start = time()
-    if channels is None:
-        channels = detector._channels_of(roi.ndim, num_chls_roi, None)[1]
-    settings = config.get_roi_profile(channels[0])       # first channel's block settings
-    blocks = setup_blocks(settings, roi.shape)
-    StackDetector.plan_pruning(blocks.overlap, blocks.tol, blocks.overlap_padding, channels)
-    seg_rois = StackDetector.detect_blobs_sub_rois(
-        img5d, roi, blocks.sub_roi_slices, blocks.sub_rois_offsets, blocks.denoise_max_shape,
-        blocks.exclude_border, coloc, channels)
-    detection_time = time() - time_detection_start
-
-    # Several ranks (torch.distributed): the gathered tables are unpacked on rank 0 only, rank 0 prunes and
-    # writes the CSVs, every rank returns the same final table (one broadcast).
-    from . import dist
-    is_root = dist.rank() == 0
-    time_pruning_start = time()
-    segments_all, df_pruning = (None, None)
-    if getattr(seg_rois, "local_only", False):
-        # every rank holds its own blocks' tables: the pruning is a collective and leaves the table on all of them
-        segments_all, df_pruning = StackPruner.prune_blobs_mp(
-            roi, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
-            blocks.sub_rois_offsets, channels, blocks.overlap_padding)
-    else:
-        failure = None
-        if is_root:
-            try:
-                segments_all, df_pruning = StackPruner.prune_blobs_mp(
-                    roi, seg_rois, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
-                    blocks.sub_rois_offsets, channels, blocks.overlap_padding)
-            except Exception as exc:      # the other ranks are about to wait for the table: tell them first
-                failure = exc
-        dist.raise_together(failure, "pruning on rank 0")
-        segments_all = dist.broadcast_table(segments_all)
-    pruning_time = time() - time_pruning_start
-
-    if is_root and df_pruning is not None and save_dfs and len(df_pruning):
-        _save_pruning_ratios(df_pruning)
-
-    blobs = detector.Blobs(segments_all, path=filename_blobs)
-    colocs = None
-    if segments_all is not None:
-        blobs.replace_rel_with_abs_blob_coords(segments_all)
-        blobs.blobs = segments_all
-        if coloc:
-            colocs = segments_all[:, 10:10 + num_chls_roi].astype(np.uint8)
-        segments_all = blobs.remove_abs_blob_coords(True)
-
-    blobs.blobs = segments_all
-    blobs.colocalizations = colocs
-    blobs.resolutions = config.resolutions
-    blobs.basename = os.path.basename(config.filename) if config.filename else None
-    blobs.roi_offset = offset
-    blobs.roi_size = size
-
-    times = {StackTimes.DETECTION: [detection_time], StackTimes.PRUNING: [pruning_time],
-             StackTimes.TOTAL: time() - time_start}
-    blobs.times = times
-    if save_dfs and is_root:
-        import pandas as pd
-        pd.DataFrame({k.value: v for k, v in times.items()}).to_csv(
-            "stack_detection_times.csv", index=False)
-    if segments_all is None:
-        _logger.info("No blobs detected")
-    else:
-        _logger.info("Total blobs found: %s", len(segments_all))
+    run = _StackRun(filename_base, img5d, save_dfs)
+    blobs = run.resolve_roi(offset, size, channels, full_roi, coloc).detect().prune().finish()
     return None, None, blobs
 
 
@@ -937,16 +1024,20 @@ class StackPruner:
         return plan
 
     @classmethod
-    def _prune_table(cls, zyx, tags, abs_cur, chan, own_lo, own_hi, channels, plan):
+    def _prune_table(cls, zyx, tags, abs_cur, chan, own_lo, own_hi, channels, plan, need_keys: bool = False):
         """The three passes over one table (``mmx_host_prune_region``), channel by channel: ``(rows, keys, counts)``
         -- the ids of the surviving rows among ``[own_lo, own_hi)`` in their final order, the key of each (the
         channel's position in ``channels`` is the most significant part), and the statistics
         ``counts[channel][axis][slab] = (rows in the slab, rows left, rows in the adjacent region)`` over own rows.
-        ``abs_cur`` is updated in place.  ``chan``: channel of every row, ``None`` when all belong to ``channels[0]``."""
+        ``abs_cur`` is updated in place.  ``chan``: channel of every row, ``None`` when all belong to ``channels[0]``.
+        ``need_keys``: the survivors will be merged with other tables' (several ranks), so the keys are computed even
+        when the own rows happen to be the whole table -- a rank that received no halo rows (the other ranks have no
+        blobs, or none near the seam) still needs them; without it the keyless shortcut is taken for one region."""
         lib = nat.lib()
         n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi = plan["c_args"]
         ld = plan["max_slabs"]
-        whole = own_lo == 0 and own_hi == len(zyx)       # one region: the output order is final, no keys needed
+        # one region whose output order is final: no keys needed
+        whole = own_lo == 0 and own_hi == len(zyx) and not need_keys
         counts = np.zeros((len(channels), 3, ld, 3), dtype=np.int64)
         rows_all, keys_all = [], []
         for ci, chl in enumerate(channels):
@@ -1028,26 +1119,81 @@ class StackPruner:
                 now = perf_counter()
                 print(f"distributed prune, rank 0: {what}: {(now - _t[0]) * 1e3:.2f} ms", file=sys.stderr)
                 _t[0] = now
+        # Every rank-local stage runs under try / except and its failure travels with the NEXT collective (a status
+        # word in the all_reduce, in the row counts of the two exchanges): a rank that fails -- a native error, tables
+        # of the wrong width -- makes every rank raise at that collective instead of leaving the others waiting in it.
         grid = sub_roi_slices.shape
         coords = list(np.ndindex(*grid))
         n = ar.n
         ncol = ar.store.shape[1]
-        has_table = any(seg_rois[c] is not None and not isinstance(seg_rois[c], (int, np.integer)) for c in coords)
-        flags = dist.all_reduce_sum(np.array([1 if has_table else 0, n], dtype=np.int64))
+        failure, payload, boxes, reach, abs_inds = None, None, None, None, None
+        has_table = False
+        try:
+            has_table = any(seg_rois[c] is not None and not isinstance(seg_rois[c], (int, np.integer)) for c in coords)
+            abs_inds = detector.Blobs._get_abs_inds()
+            reach = _region_reach(plan["tol"])
+            boxes = cls._rank_boxes(len(coords), world, coords, sub_roi_slices, shape3, reach)
+            payload = cls._seam_rows(ar, boxes, me, reach)
+        except Exception as exc:
+            failure = exc
+        flags = dist.all_reduce_sum(np.array([1 if has_table else 0, n, 0 if failure is None else 1], dtype=np.int64))
+        if failure is not None:
+            raise failure
+        if flags[2]:
+            raise RuntimeError("distributed pruning failed on another rank before the first exchange; see its log")
         if flags[0] == 0:
             return None, None
-        abs_inds = detector.Blobs._get_abs_inds()
-        reach = _region_reach(plan["tol"])
-        # the extent of every rank's blocks
+        _lap("rows near the other ranks' blocks")
+        parts = dist.all_gather_rows(payload, 10)
+        _lap("exchange 1 (seam rows)")
+        mine, counts = None, None
+        try:
+            mine, counts = cls._prune_own_rows(ar, parts, boxes[me], me, channels, plan, abs_inds, _lap)
+        except Exception as exc:
+            failure = exc
+        table = dist.all_gather_rows_concat(mine, ncol - 2, failure, "distributed pruning (own rows)")
+        _lap("exchange 2 (survivors)")
+        out = None
+        try:
+            out = np.empty((len(table), ncol - 3))
+            if len(table):
+                all_keys = np.ascontiguousarray(table[:, ncol - 3], dtype=np.int64)
+                nat.check(nat.lib().mmx_host_merge_by_key(
+                    table.ctypes.data, ncol - 2, all_keys.ctypes.data, len(table), plan["n_keys"] * len(channels),
+                    ncol - 3, out.ctypes.data), "mmx_host_merge_by_key")
+        except Exception as exc:
+            failure = exc
+        _lap("merge by key")
+        summed = dist.all_reduce_sum(np.append(counts.reshape(-1), 0 if failure is None else 1))
+        if failure is not None:
+            raise failure
+        if summed[-1]:
+            raise RuntimeError("distributed pruning: the merge failed on another rank; see its log")
+        counts = summed[:-1].reshape(counts.shape)
+        _lap("counts all_reduce")
+        return out, counts
+
+    @staticmethod
+    def _rank_boxes(n_blocks, world, coords, sub_roi_slices, shape3, reach):
+        """The extent of every rank's blocks, widened by the reach of the pruning (``None`` for a rank without
+        blocks)."""
+        from . import dist
         boxes = []
         for q in range(world):
-            lo_b, hi_b = dist.share_bounds(len(coords), q, world)
+            lo_b, hi_b = dist.share_bounds(n_blocks, q, world)
             if hi_b <= lo_b:
                 boxes.append(None)
                 continue
             ext = np.array([[s.indices(m)[:2] for s, m in zip(sub_roi_slices[coords[i]], shape3)]
                             for i in range(lo_b, hi_b)])
             boxes.append((ext[:, :, 0].min(axis=0) - reach, ext[:, :, 1].max(axis=0) + reach))
+        return boxes
+
+    @staticmethod
+    def _seam_rows(ar, boxes, me, reach):
+        """The rows of this rank's arena that lie within reach of another rank's blocks, ten values a row:
+        detection coordinates, block tags, absolute coordinates, channel."""
+        n = ar.n
         zyx, tags, abs_own = ar.zyx[:n], ar.tag[:n], ar.abs[:n]
         chan_own = ar.store[:n, 6]
         near = np.zeros(n, dtype=bool)
@@ -1064,10 +1210,16 @@ class StackPruner:
         payload = np.empty((len(sel), 10))
         payload[:, 0:3], payload[:, 3:6] = zyx[sel], tags[sel]
         payload[:, 6:9], payload[:, 9] = abs_own[sel], chan_own[sel]
-        _lap("rows near the other ranks' blocks")
-        parts = dist.all_gather_rows(payload, 10)
-        _lap("exchange 1 (seam rows)")
-        mine_box = boxes[me]
+        return payload
+
+    @classmethod
+    def _prune_own_rows(cls, ar, parts, mine_box, me, channels, plan, abs_inds, _lap=lambda what: None):
+        """The three passes on this rank's rows between the seam rows received from the ranks before and after it:
+        ``(own survivors in their final form + one column with the key that places them, statistics)``."""
+        n = ar.n
+        ncol = ar.store.shape[1]
+        zyx, tags, abs_own = ar.zyx[:n], ar.tag[:n], ar.abs[:n]
+        chan_own = ar.store[:n, 6]
         before, after = [], []
         for q, part in enumerate(parts):
             if q == me or mine_box is None or not len(part):
@@ -1082,7 +1234,10 @@ class StackPruner:
         chan_l = np.concatenate((halo_b[:, 9], chan_own, halo_a[:, 9]))
         own_lo = len(halo_b)
         _lap("own + halo tables")
-        rows, keys, counts = cls._prune_table(zyx_l, tag_l, abs_l, chan_l, own_lo, own_lo + n, channels, plan)
+        # (need_keys: a rank that received no halo rows -- nobody else has blobs, or none near the seam -- holds
+        #  "the whole table" and would otherwise take the keyless single-process shortcut)
+        rows, keys, counts = cls._prune_table(zyx_l, tag_l, abs_l, chan_l, own_lo, own_lo + n, channels, plan,
+                                              need_keys=True)
         _lap("three passes on own + halo rows")
         # own survivors in their final form + the key that places them
         mine = np.empty((len(rows), ncol - 2))
@@ -1098,18 +1253,7 @@ class StackPruner:
             mine[:, :ncol - 3] = body
             mine[:, ncol - 3] = keys
         _lap("own survivors in final form")
-        table = dist.all_gather_rows_concat(mine, ncol - 2)
-        _lap("exchange 2 (survivors)")
-        out = np.empty((len(table), ncol - 3))
-        if len(table):
-            all_keys = np.ascontiguousarray(table[:, ncol - 3], dtype=np.int64)
-            nat.check(nat.lib().mmx_host_merge_by_key(
-                table.ctypes.data, ncol - 2, all_keys.ctypes.data, len(table), plan["n_keys"] * len(channels),
-                ncol - 3, out.ctypes.data), "mmx_host_merge_by_key")
-        _lap("merge by key")
-        counts = dist.all_reduce_sum(counts.reshape(-1)).reshape(counts.shape)
-        _lap("counts all_reduce")
-        return out, counts
+        return mine, counts
 
     @classmethod
     def prune_blobs_mp(cls, img, seg_rois, overlap, tol, sub_roi_slices, sub_rois_offsets,
@@ -1150,8 +1294,18 @@ class StackPruner:
         arena = getattr(seg_rois, "arena", None)
         if arena is not None and not arena.intact(seg_rois):
             arena = None
-        merged = arena.store[:arena.n] if arena is not None and arena.n else chunking.merge_blobs(seg_rois)
+        early = getattr(seg_rois, "pruner", None)
+        if early is not None:
+            seg_rois.pruner = None        # one shot: used below or cancelled
+        try:
+            merged = arena.store[:arena.n] if arena is not None and arena.n else chunking.merge_blobs(seg_rois)
+        except Exception:
+            if early is not None:
+                early.cancel()
+            raise
         if merged is None:
+            if early is not None:
+                early.cancel()
             return None, None
         grid = sub_roi_slices.shape
         coord_last = tuple(np.subtract(grid, 1))
@@ -1159,6 +1313,8 @@ class StackPruner:
         ratios_all = {}
         if not all(cls._axis_geometry(a, shape3, overlap, overlap_padding, sub_roi_slices, sub_rois_offsets)[1]
                    for a in range(3) if sub_rois_offsets.shape[a] > 1):
+            if early is not None:
+                early.cancel()
             out, ratios_all = cls._prune_blobs_general(merged, shape3, overlap, tol, sub_roi_slices,
                                                        sub_rois_offsets, channels, overlap_padding)
             return out, pd.DataFrame(ratios_all)
@@ -1167,11 +1323,12 @@ class StackPruner:
         abs_inds = detector.Blobs._get_abs_inds()
         plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
         # regions of this very call finished while the GPU was still detecting (StackDetector.plan_pruning)
-        early = getattr(seg_rois, "pruner", None)
         if early is not None and arena is not None and early.matches(arena, plan, channels):
             out, counts = early.finish(abs_inds)
             _lap("regions pruned during detection: the rest + merge")
         else:
+            if early is not None:       # other parameters than planned for, or tables edited since: not usable
+                early.cancel()
             chan = detector.Blobs.get_blobs_channel(merged)
             # compact columns for the native step (libmmx_hip.so: mmx_host_prune_region)
             if arena is not None:                 # filled while the GPU was busy

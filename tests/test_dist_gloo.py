@@ -253,6 +253,8 @@ def _dist_case(case):
     shape, seg, channels, n_extra, n_blobs = (96, 150, 170), 40, [0], 0, 6000
     if case == "extra_columns_two_channels":
         channels, n_extra = [0, 1], 2
+    elif case == "far_from_seam":
+        shape, n_blobs = (150, 100, 120), 12000         # four z-layers of blocks: one or two per rank
     elif case == "flat":
         shape, seg, n_blobs = (30, 200, 260), 50, 3000
     config.roi_profile.update(segment_size=seg, denoise_size=None)
@@ -264,6 +266,24 @@ def _dist_case(case):
         tables[3] = np.zeros((0, 11 + n_extra))          # all blobs excluded: EMPTY
         tables[5] = None
         tables[len(tables) - 1] = None
+    elif case == "second_half_none":
+        # only the first rank(s) hold blobs: they receive no halo rows and their own rows ARE the whole local table
+        for k in range(len(tables) // 2, len(tables)):
+            tables[k] = None
+    elif case == "one_rank_all_empty":
+        # the last third of the blocks found blobs and excluded them all: EMPTY tables, no rows
+        for k in range(2 * len(tables) // 3, len(tables)):
+            tables[k] = np.zeros((0, 11))
+    elif case == "far_from_seam":
+        # no blob within reach of another rank's blocks: nobody sends or receives a halo row
+        reach = 4 * int(np.max(blocks.tol)) + int(np.max(blocks.overlap)) + 2
+        grid = blocks.sub_roi_slices.shape
+        z_seams = [int(blocks.sub_rois_offsets[(j, 0, 0)][0]) for j in range(1, grid[0])]
+        for k, tbl in enumerate(tables):
+            if tbl is None:
+                continue
+            keep = np.all([np.abs(tbl[:, 0] - zs) > reach for zs in z_seams], axis=0)
+            tables[k] = tbl[keep] if keep.any() else None
     elif case == "all_empty":
         tables = [np.zeros((0, 11)) if k % 2 else None for k in range(len(tables))]
     elif case == "nothing":
@@ -272,7 +292,9 @@ def _dist_case(case):
 
 
 @pytest.mark.parametrize("world,case", [(2, "plain"), (3, "holes"), (4, "extra_columns_two_channels"), (4, "flat"),
-                                        (3, "all_empty"), (2, "nothing")])
+                                        (3, "all_empty"), (2, "nothing"), (2, "second_half_none"),
+                                        (3, "second_half_none"), (3, "one_rank_all_empty"), (2, "far_from_seam"),
+                                        (4, "far_from_seam")])
 def test_distributed_pruning_equals_one_process(tmp_path, world, case):
     """Every rank holds the tables of its own blocks only, prunes its own rows (three passes on its rows plus the
     other ranks' rows within reach of its blocks) and merges everybody's survivors by key: the table -- rows, order,
@@ -291,6 +313,8 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
         assert want is None
     elif case == "all_empty":
         assert want.shape == (0, 11)
+    elif case == "far_from_seam":
+        assert 300 < len(want)
     else:
         assert 1000 < len(want) < sum(len(t) for t in tables if t is not None)
     tmp.spawn(_worker_dist_prune, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
@@ -311,3 +335,57 @@ def test_rows_of_all_ranks_back_to_back(tmp_path, world):
     concatenated form is the per-rank form back to back (what the distributed pruning merges by key)."""
     tmp.spawn(_worker_rows, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"rows{r}").exists() for r in range(world))
+
+
+# ---------------------------------------------------------------- a rank-local failure inside the collective pruning
+def _worker_dist_failure(rank, world, port, stage, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    from datetime import timedelta
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+    try:
+        from magellanmapper_amd import dist as d, stack_detect as sd
+        blocks, tables, shape, channels, n_extra = _dist_case("plain")
+        grid = blocks.sub_roi_slices.shape
+        coords = list(np.ndindex(*grid))
+        mine = d.my_share(len(coords))
+        arena = sd._TableArena(11, len(mine))
+        local = []
+        for i in mine:
+            if tables[i] is not None and len(tables[i]):
+                arena.add(coords[i], tables[i])
+            arena.landed()
+            local.append((i, tables[i]))
+        seg = sd.StackDetector.assemble_seg_rois(local, grid, 0, arena, local_only=True)
+        if rank == 1:           # this rank alone fails, in the stage before the given collective
+            def boom(*a, **k):
+                raise sd.nat.MmxError("injected failure")
+            setattr(sd.StackPruner, {"seam": "_seam_rows", "own": "_prune_own_rows"}[stage], staticmethod(boom))
+
+        class Img:
+            pass
+        Img.shape = shape
+        try:
+            sd.StackPruner.prune_blobs_mp(Img, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                          blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+            verdict = "returned"
+        except sd.nat.MmxError as exc:
+            verdict = f"own:{exc}"
+        except RuntimeError as exc:
+            verdict = f"peer:{exc}"
+        open(os.path.join(out_dir, f"verdict{rank}"), "w").write(verdict)
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage", ["seam", "own"])
+def test_a_failing_rank_makes_every_rank_raise(tmp_path, stage):
+    """One rank fails inside the collective pruning -- before the first exchange, before the second: every rank
+    raises at the next collective (the failed rank its own exception, the others a RuntimeError naming the cause)
+    instead of waiting in a collective the failed rank never enters."""
+    world = 3
+    tmp.spawn(_worker_dist_failure, args=(world, _free_port(), stage, str(tmp_path)), nprocs=world, join=True)
+    verdicts = [open(tmp_path / f"verdict{r}").read() for r in range(world)]
+    assert verdicts[1].startswith("own:") and "injected failure" in verdicts[1]
+    assert verdicts[0].startswith("peer:") and verdicts[2].startswith("peer:")

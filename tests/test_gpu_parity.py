@@ -385,6 +385,16 @@ def test_subimage_offset_and_archive(gpu, tmp_path, monkeypatch):
     assert want is not None and len(want) > 0
     np.testing.assert_array_equal(lexsorted(blobs.blobs), lexsorted(want))
     assert os.path.exists("stack_detection_times.csv")
+    # config.save_subimg: the ROI next to the archive, named as the reference names it (x,y,z in the file name)
+    assert not os.path.exists(tmp_path / "sample_region_(30,30,8)x(70,70,10)_subimg.npy")
+    monkeypatch.setattr(config, "save_subimg", True)
+    _, _, again = stack_detect.detect_blobs_blocks(config.filename, img5d, offset, size, None,
+                                                   False, False, False, False)
+    monkeypatch.setattr(config, "save_subimg", False)
+    np.testing.assert_array_equal(again.blobs, blobs.blobs)
+    saved = np.load(tmp_path / "sample_region_(30,30,8)x(70,70,10)_subimg.npy")
+    assert saved.dtype == vol.dtype
+    np.testing.assert_array_equal(saved, sub)
     stats, fdbk, all_blobs = stack_detect.detect_blobs_stack(config.filename, img5d, offset, size)
     assert os.path.exists(all_blobs.path)
     loaded = detector.Blobs().load_blobs(all_blobs.path)

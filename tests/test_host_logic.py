@@ -1030,6 +1030,59 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case, monkeypatch):
     want2, _ = sd.StackPruner.prune_blobs_mp(Img, build(False)[0], blocks.overlap, tol2, blocks.sub_roi_slices,
                                              blocks.sub_rois_offsets, channels, blocks.overlap_padding)
     np.testing.assert_array_equal(got2, want2)
+    assert pruner_c._pool is None and not pruner_c._futures          # cancelled: no worker threads left behind
+    # tables edited IN PLACE between detection and pruning (the reference's API allows it: they are plain arrays):
+    # neither the regions pruned ahead nor the arena's compact columns may be used -- the result is that of pruning
+    # the edited tables
+    seg_d, pruner_d = build(True)
+    for k in share:
+        if seg_d[coords[k]] is not None:
+            seg_d[coords[k]][:, [0, 7]] += 2.0           # every blob two planes deeper, rel and abs
+    got3, _ = sd.StackPruner.prune_blobs_mp(Img, seg_d, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                            blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    seg_e = np.zeros(grid, dtype=object)
+    for k in share:
+        t = tables[coords[k]]
+        if t is not None:
+            t = t.copy()
+            t[:, [0, 7]] += 2.0
+        seg_e[coords[k]] = t
+    want3, _ = sd.StackPruner.prune_blobs_mp(Img, seg_e, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                             blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    np.testing.assert_array_equal(got3, want3)
+    assert pruner_d._pool is None and not np.array_equal(got3, want)
+
+
+def test_cancelled_region_pruner_surfaces_a_region_failure(monkeypatch):
+    """A region that raised while pruning ahead is not lost with its future: ``cancel`` (what ``prune_blobs_mp`` calls
+    when it cannot use the regions) re-raises it, and ends the worker threads either way."""
+    from magellanmapper_amd import _native as nat, stack_detect as sd
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(segment_size=32, denoise_size=None)
+    shape = (70, 70, 70)
+    blocks = sd.setup_blocks(config.roi_profile, shape)
+    tables = _synthetic_block_tables(np.random.default_rng(5), shape, blocks, 800)
+    grid = blocks.sub_roi_slices.shape
+    coords = list(np.ndindex(*grid))
+    plan = sd.StackPruner._axis_plan(shape, blocks.overlap, blocks.tol, blocks.overlap_padding, blocks.sub_roi_slices,
+                                     blocks.sub_rois_offsets)
+    arena = sd._TableArena(11, len(coords))
+    pruner = sd._RegionPruner(arena, plan, [0], blocks.sub_roi_slices, shape, list(range(len(coords))))
+
+    def boom(self, i):
+        raise nat.MmxError("region %d failed" % i)
+    monkeypatch.setattr(sd._RegionPruner, "_run", boom)
+    for c in coords:
+        if tables[c] is not None:
+            arena.add(c, tables[c])
+        arena.landed()
+        pruner.advance()
+    assert pruner._futures
+    with pytest.raises(nat.MmxError, match="region"):
+        pruner.cancel()
+    assert pruner._pool is None and not pruner._futures and not pruner.pending
+    pruner.cancel()         # idempotent
 
 
 def test_overlap_prune_reproduces_scikit_image_on_every_fixture():
@@ -1069,3 +1122,21 @@ def test_overlap_prune_reproduces_scikit_image_on_every_fixture():
         np.testing.assert_array_equal(pb.blobs(0), g["case%d_kept" % k], err_msg="case %d" % k)
         n_chain += stats.n_order_fallbacks
     assert n_chain >= 3
+
+
+def test_save_subimage_writes_the_roi_unless_it_is_the_open_memmap(tmp_path, caplog):
+    """``config.save_subimg`` (reference stack_detect.py:477-489): the ROI as ``<base>_subimg.npy``; when the image is
+    a memory map of that very file it is left alone with a warning."""
+    roi = np.arange(2 * 3 * 4, dtype=np.uint16).reshape(2, 3, 4)
+    path = str(tmp_path / "img_subimg.npy")
+    stack_detect._save_subimage(path, roi[None], roi)
+    np.testing.assert_array_equal(np.load(path), roi)
+    mapped = np.load(path, mmap_mode="r+")
+    assert isinstance(mapped, np.memmap)
+    before = os.path.getmtime(path)
+    with caplog.at_level("WARNING", logger="magellanmapper_amd"):
+        stack_detect._save_subimage(path, mapped, np.zeros((1, 1, 1), dtype=np.uint16))
+    assert "currently open" in caplog.text and os.path.getmtime(path) == before
+    np.testing.assert_array_equal(np.load(path), roi)
+    with pytest.raises(TypeError):
+        stack_detect._save_subimage(str(tmp_path / "x.npy"), roi[None], object())
