@@ -375,7 +375,7 @@ int prune_region_impl(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
     }
     int64_t k = 0;
     if (own_lo == INT64_MIN && own_hi == INT64_MAX && !out_keys) {       // the whole table: every survivor, no keys
-        std::memcpy(out_rows, a_rows.data(), (size_t)n * sizeof(int64_t));
+        if (n) std::memcpy(out_rows, a_rows.data(), (size_t)n * sizeof(int64_t));      // (an empty vector's data() may be null)
         k = n;
     } else {
         for (int64_t i = 0; i < n; ++i) {
