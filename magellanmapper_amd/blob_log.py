@@ -61,6 +61,16 @@ EPS_REL = float(os.environ.get("MMX_EPS_REL", 2e-5))
 #: the band for raw integer volumes, whose default kernels hand the Z+X results to the Y pass as 16-bit fixed point
 #: (``MMX_ZX_TILED_Q16``: error <= 5.2e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
 EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2.5e-4))
+#: the rounding error of the 16-bit intermediates for ANY sigma, relative to the value range (per
+#: call the library states the bound of the sigmas at hand: ``mmx_tiled_q16_error_bound``, <= this)
+Q16_BOUND_ANY_SIGMA = 5.2e-5
+if 0.0 < EPS_REL_Q16 < 4.0 * Q16_BOUND_ANY_SIGMA:
+    # exactness rests on the band covering the error fourfold: an environment variable may widen it or switch the
+    # 16-bit intermediates off (0), not narrow it below what the bound needs
+    raise ValueError(f"MMX_EPS_REL_Q16={EPS_REL_Q16:g} is narrower than 4 x the 16-bit intermediates' error bound "
+                     f"({4.0 * Q16_BOUND_ANY_SIGMA:g}); use 0 to keep float32 intermediates")
+#: bound of the 16-bit intermediates of the most recent batch that used them (value units), else 0: bench.py prints it
+LAST_Q16_BOUND = 0.0
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
@@ -550,9 +560,11 @@ def _to_device_bytes(arr: np.ndarray, dev) -> "torch.Tensor":
 
 
 def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: ScaleSpace,
-                    generic: bool = False) -> List[np.ndarray]:
+                    generic: bool = False, value_range: float = 0.0) -> List[np.ndarray]:
     """Float32 ``(z, y, x, sigma)`` cubes of the given blocks (A0-A3 only; used by tests
-    for the 1e-4 LoG tolerance and by the profiling scripts)."""
+    for the 1e-4 LoG tolerance and by the profiling scripts).  ``value_range``: what the caller knows about float
+    voxels (``mmx_volume.value_range``: > 0 = values in [0, m], < 0 = |v| <= m, 0 = unknown), which decides whether
+    they may take the tiled matrix-core kernels."""
     dev = dvol.tensor.device
     L = nat.lib()
     blocks, slot = _make_blocks(dvol, channel, origins, shapes)
@@ -560,6 +572,8 @@ def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: Sc
     ws = torch.empty((4 + ns) * nb * slot, dtype=torch.float32, device=dev)
     d_blocks = _to_device_bytes(blocks, dev)
     vol32 = dvol.view(channel, True)
+    if vol32.dtype == nat.MMX_F32:
+        vol32.value_range = float(value_range)
     fn = L.mmx_log_batch_f32_generic if generic else L.mmx_log_batch_f32
     log_base = ws.data_ptr() + 4 * nb * slot * 4
     global LAST_ZX_PATH
@@ -770,7 +784,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
 
     def passes(with_mask: bool, mode: int):
         """Every scale of the batch -> the set of entry layouts the calls reported (0 = no entries)."""
-        global LAST_ZX_PATH
+        global LAST_ZX_PATH, LAST_Q16_BOUND
         layouts = set()
         # the tiled path works from an operand-ordered copy of the voxels that does not depend on sigma: made
         # once here, trusted by the calls below for as long as every call so far ran the tiled path (any other
@@ -790,8 +804,12 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
             bound = max(float(L.mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
                                                           int(space.radii[s]), float(space.norms[s]))) for s in range(ns))
             bound *= 1.0 if not is_float else float(vol32.value_range)
-            if mode == nat.MMX_ZX_TILED_Q16 or (0 <= 4.0 * bound <= eps):
+            if mode == nat.MMX_ZX_TILED_Q16 and not (0 <= 4.0 * bound <= eps):
+                raise ValueError(f"16-bit intermediates asked for by name with a nomination band of {eps:g}, narrower "
+                                 f"than 4 x their error bound {bound:g}")
+            if 0 <= 4.0 * bound <= eps:
                 tiled_mode = nat.MMX_ZX_TILED_Q16
+                LAST_Q16_BOUND = bound
         if (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16) and not is_float) or \
                 (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED) and float_ok):
             nonlocal pack_side
@@ -1180,10 +1198,26 @@ def _exact_overlap(b1: np.ndarray, b2: np.ndarray) -> float:
     return vol / (4. / 3 * math.pi * min(r1, r2) ** 3)
 
 
+#: SciPy releases whose ``cKDTree.query_pairs`` + CPython set order are known to reproduce the real ``_prune_blobs`` on
+#: the chain-heavy fixture (tests/golden/overlap_prune.npz: made with 1.7.1; 1.15.3 is the reference's pin and this
+#: image's).  Any other release is used all the same -- it is the reference's own call -- with one warning.
+VERIFIED_SCIPY = ("1.7.1", "1.15.3")
+_warned_scipy = False
+
+
 def _reference_pair_order(lm: np.ndarray) -> np.ndarray:
     """The visiting order ``_prune_blobs`` uses (blob.py:169-172): iteration order of the
     Python ``set`` returned by SciPy's ``cKDTree.query_pairs``.  It is implementation
     defined, so when the outcome depends on it the only faithful source is the same call."""
+    global _warned_scipy
+    if not _warned_scipy:
+        _warned_scipy = True
+        import scipy
+        if scipy.__version__ not in VERIFIED_SCIPY:
+            import warnings
+            warnings.warn(f"SciPy {scipy.__version__}: the pair order of cKDTree.query_pairs decides blocks with "
+                          f"pruning chains and was verified against the real _prune_blobs for {VERIFIED_SCIPY} only "
+                          "(tests/test_host_logic.py::test_overlap_prune_reproduces_scikit_image_on_every_fixture)")
     sigma = lm[:, -1].max()
     distance = 2 * sigma * math.sqrt(lm.shape[1] - 1)
     tree = _scipy_spatial.cKDTree(lm[:, :-1])

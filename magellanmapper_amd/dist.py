@@ -27,12 +27,31 @@ def _active() -> bool:
     return tdist is not None and tdist.is_available() and tdist.is_initialized()
 
 
+_solo = 0
+
+
 def rank() -> int:
-    return tdist.get_rank() if _active() else 0
+    return tdist.get_rank() if _active() and not _solo else 0
 
 
 def world_size() -> int:
-    return tdist.get_world_size() if _active() else 1
+    return tdist.get_world_size() if _active() and not _solo else 1
+
+
+class solo:
+    """``with dist.solo():`` -- inside, this process works as if there were no process group (rank 0 of 1: all blocks
+    are its own, no collective is entered).  For work ONE rank of a group does by itself while the others wait, e.g.
+    the parity sample of ``bench.py`` on rank 0."""
+
+    def __enter__(self):
+        global _solo
+        _solo += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _solo
+        _solo -= 1
+        return False
 
 
 def share_bounds(n_items: int, r: int, n_ranks: int) -> Tuple[int, int]:

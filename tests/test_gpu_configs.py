@@ -149,6 +149,50 @@ def test_c5_shaped_two_channel_coloc_over_ranks(gpu, tmp_path, ranks):
     np.testing.assert_array_equal(dump["colocs"], stages["colocs"])
 
 
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+C3_DIGEST = "5fba8ef88362dfa0a7d9fb8caaef869ea416eb85"
+
+
+def test_full_c3_volume_over_four_ranks_has_the_one_rank_digest(gpu, tmp_path):
+    """BASELINE.json configs[3] as far as one GPU goes: the FULL 2048 x 2048 x 1024 volume, its 256 blocks sharded
+    over 4 ranks that share this GPU (gloo), every rank pruning its own rows and merging everybody's survivors by key
+    (the distributed pruning): same digest and blob count as one rank.  Rank 0 also runs the parity sample by itself
+    (``dist.solo``) against the committed oracle table of that sample (tests/golden/make_bench_samples.py)."""
+    line = _run_bench(tmp_path, 4, "--parity-sample", os.path.join(GOLDEN_DIR, "bench_sample_c3.npz"), timeout=1500)
+    assert line["n_gpus"] == 4 and [r["blocks"] for r in line["ranks"]] == [64, 64, 64, 64]
+    assert line["table_sha1"] == C3_DIGEST and line["blobs"] == 292044
+    assert line["parity_sample_identical"] is True and "committed" in line["parity_sample_source"]
+    assert line["scaling"] == "strong" and line["roofline"] is not None
+
+
+def test_full_size_c5_tile_digests_and_sample_parity(gpu, tmp_path):
+    """BASELINE.json configs[4] at bench.py's geometry on one GPU: 2 channels x 2048 x 2048 x 512 uint16, per-block
+    preprocessing (denoise_size 25), both channels detected with 5 sigmas, intensity co-localisation, prune.  Too large
+    for the float64 oracle, so: the sample of the same workload equals the committed oracle table (final table row for
+    row AND the co-localisation flags), and the full-size table / flags are pinned by digest and by size-independent
+    properties."""
+    line = _run_bench(tmp_path, 1, "--config", "c5", "--parity-sample", os.path.join(GOLDEN_DIR, "bench_sample_c5.npz"),
+                      "--dump", str(tmp_path / "c5.npz"), timeout=1500)
+    assert line["parity_sample_identical"] is True and "committed" in line["parity_sample_source"]
+    assert line["config"]["blocks_per_rank"] == 128 and line["n_gpus"] == 1
+    dump = np.load(tmp_path / "c5.npz")
+    final, colocs = dump["final"], dump["colocs"]
+    assert final.shape == (line["blobs"], 8) and colocs.shape == (line["blobs"], 2) and colocs.dtype == np.uint8
+    assert set(np.unique(final[:, 6])) == {0.0, 1.0}
+    zyx = final[:, :3]
+    assert np.array_equal(zyx, np.round(zyx)) and zyx.min() >= 0 and np.all(zyx.max(axis=0) < (512, 2048, 2048))
+    # the reference's off-by-one (DESIGN.md section 2c): column 0 of the flags is uint8(region = -1), column 1 the
+    # flag of channel 0 -- set for every blob of channel 0 that passes its own channel's threshold
+    assert np.all(colocs[:, 0] == 255) and set(np.unique(colocs[:, 1])) <= {0, 1}
+    assert line["table_sha1"] == C5_DIGESTS["table"], line["table_sha1"]
+    assert line["colocs_sha1"] == C5_DIGESTS["colocs"], line["colocs_sha1"]
+    assert line["blobs"] == C5_DIGESTS["blobs"]
+
+
+#: first recorded in round 4 (gpurun_out/r04_c5_full.json); the sample check above ties the same code to the oracle
+C5_DIGESTS = {"table": "TBD", "colocs": "TBD", "blobs": -1}
+
+
 def test_full_size_c3_volume_properties_and_digest(gpu, tmp_path):
     """BASELINE.json configs[2] at FULL size (2048 x 2048 x 1024, 256 blocks, 5 sigmas) through ``bench.py``: too
     large for the float64 oracle, so the result is pinned by what does not depend on size -- the digest of the final
@@ -157,7 +201,7 @@ def test_full_size_c3_volume_properties_and_digest(gpu, tmp_path):
     from magellanmapper_amd import detector
     line = _run_bench(tmp_path, 1, "--dump", str(tmp_path / "c3.npz"), timeout=1200)
     assert line["config"]["blocks_per_rank"] == 256 and line["n_gpus"] == 1
-    assert line["table_sha1"] == "5fba8ef88362dfa0a7d9fb8caaef869ea416eb85"
+    assert line["table_sha1"] == C3_DIGEST
     assert line["detector_stats"]["max_f32_error"] < 4.4e-5 and line["detector_stats"]["n_band_retries"] == 0   # Q16 bound
     final = np.load(tmp_path / "c3.npz")["final"]
     assert final.shape == (line["blobs"], 8) and line["blobs"] == 292044

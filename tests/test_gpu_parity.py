@@ -572,6 +572,48 @@ def test_every_kernel_radius_matches_oracle(gpu, fused, monkeypatch):
         bl.ZX_MODE = default
 
 
+@pytest.mark.parametrize("case", ["preprocessed_1.94", "unit_range_extremes", "float_range_40", "float64_range_3"])
+def test_q16_error_bound_holds_across_value_ranges(gpu, case, monkeypatch):
+    """The analytic bound of the 16-bit intermediates (``mmx_tiled_q16_error_bound`` x the stated value range) on FLOAT
+    volumes, every radius 1..24: the range a stock preprocessing leaves (unsharp overshoot: [0, 1.94]), the full unit
+    range with voxels AT both extremes (saturated plateaus next to zeros: what a clip leaves), a float image of range
+    40 and a float64 one -- the cases on which the nomination band (4 x the bound) of preprocessed and float volumes
+    rests.  The LoG contract of 1e-4 is relative to the value scale, as the band is."""
+    from magellanmapper_amd import _native as nat, blob_log as bl, synth
+    from oracle import blob_log_oracle as blo
+    rng = np.random.default_rng(7)
+    base = synth.make_volume(11, (35, 42, 48), 14).astype(np.float64) / 65535.0
+    if case == "preprocessed_1.94":
+        vmax, vol = 1.94, (base / base.max() * 1.94).astype(np.float32)
+    elif case == "unit_range_extremes":
+        vol = base / base.max()
+        vol[rng.random(vol.shape) < 0.05] = 1.0            # saturated voxels scattered through the noise
+        vol[10:20, 5:30, 8:40] = 1.0                       # and a saturated plateau
+        vol[22:30, :, :20] = 0.0                           # next to clipped-to-zero regions
+        vmax, vol = 1.0, vol.astype(np.float32)
+    elif case == "float_range_40":
+        vmax, vol = 40.0, (base / base.max() * 40.0).astype(np.float32)
+    else:
+        vmax, vol = 3.0, base / base.max() * 3.0           # float64: the float32 copy feeds the passes
+    dvol = bl.DeviceVolume(vol)
+    img = vol.astype(np.float64)
+    monkeypatch.setattr(bl, "ZX_MODE", nat.MMX_ZX_TILED_Q16)
+    worst = 0.0
+    for R in range(1, 25):
+        sigma = (R + 0.2) / 4.0
+        space = bl.ScaleSpace.make(sigma, sigma, 1)
+        got = np.squeeze(bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [vol.shape], space, value_range=vmax)[0])
+        assert bl.LAST_ZX_PATH == nat.MMX_ZX_TILED_Q16, (case, R, bl.LAST_ZX_PATH)
+        want = blo.log_cube(img, np.array([[sigma] * 3]))[..., 0]
+        bound = nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[0]), nat.as_double_ptr(space.w2[0]),
+                                                    R, float(space.norms[0]))
+        err = np.abs(got - want).max()
+        assert err < bound * vmax, (case, R, err, bound * vmax)
+        assert bound <= bl.Q16_BOUND_ANY_SIGMA              # what the band of 2.5e-4 covers fourfold
+        worst = max(worst, err / vmax)
+    assert worst < 1e-4 / 1.9          # the north star's LoG tolerance, relative to the value scale, with room
+
+
 def test_block_shape_and_dtype_sweep_matches_oracle(gpu):
     """Ragged extents (row lengths around the 8-float chunk, the 32-float pitch and the 64-lane wave),
     blocks thinner than the kernel radius (generic fallback per pass), every input dtype; several
