@@ -71,6 +71,8 @@ if 0.0 < EPS_REL_Q16 < 4.0 * Q16_BOUND_ANY_SIGMA:
                      f"({4.0 * Q16_BOUND_ANY_SIGMA:g}); use 0 to keep float32 intermediates")
 #: bound of the 16-bit intermediates of the most recent batch that used them (value units), else 0: bench.py prints it
 LAST_Q16_BOUND = 0.0
+#: nomination band (value units) of that batch
+LAST_NMS_BAND = 0.0
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
@@ -784,7 +786,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
 
     def passes(with_mask: bool, mode: int):
         """Every scale of the batch -> the set of entry layouts the calls reported (0 = no entries)."""
-        global LAST_ZX_PATH, LAST_Q16_BOUND
+        global LAST_ZX_PATH, LAST_Q16_BOUND, LAST_NMS_BAND
         layouts = set()
         # the tiled path works from an operand-ordered copy of the voxels that does not depend on sigma: made
         # once here, trusted by the calls below for as long as every call so far ran the tiled path (any other
@@ -809,7 +811,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                                  f"than 4 x their error bound {bound:g}")
             if 0 <= 4.0 * bound <= eps:
                 tiled_mode = nat.MMX_ZX_TILED_Q16
-                LAST_Q16_BOUND = bound
+                LAST_Q16_BOUND, LAST_NMS_BAND = bound, eps
         if (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16) and not is_float) or \
                 (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED) and float_ok):
             nonlocal pack_side

@@ -301,6 +301,52 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
             if (rc == MMX_ERR_HIP) return hip_fail(hipGetLastError(), "voxel copy of the tiled path");
             tiled = rc == MMX_OK;
         }
+        // the mask rows of a block (ny rows of ceil(nz * px / 64) words) must fit its slot / 32 words
+        auto mask_fits = [&](bool tiles) {
+            bool ok = d_nms_mask != nullptr && h_mask_written != nullptr;
+            for (int b = 0; ok && b < n_blocks; ++b) {
+                const mmx_block& hb = h_blocks[b];
+                const int64_t need = tiles ? (int64_t)hb.ny * ((hb.nz + 3) >> 2) * ((hb.nx + 15) >> 4)
+                                           : (int64_t)hb.ny * (((int64_t)hb.nz * hb.px + 63) >> 6);
+                if (need > (slot_elems >> 5) - 1) ok = false;
+            }
+            return ok;
+        };
+        // MMX_SUBBATCH = n (tiled path with the Y pass on the matrix cores only): the Z+X and the Y kernel run per group
+        // of n blocks instead of once per batch each, so that a group's P / Q tiles (38 MB a block) are read back while
+        // they may still sit in the 256 MiB memory-side cache.  An experiment switch (DESIGN.md section 4b has the
+        // measurement); blocks address their workspace by slot, so a launch over a sub-range of the block table is the
+        // same work.
+        static const int sub_env = getenv("MMX_SUBBATCH") ? atoi(getenv("MMX_SUBBATCH")) : 0;
+        const int sub = (tiled && q16 && !y_valu && sub_env > 0 && sub_env < n_blocks) ? sub_env : n_blocks;
+        bool sub_done = false;
+        if (sub < n_blocks) {
+            const bool want_mask = mask_fits(true);
+            rc = MMX_OK;
+            int groups_done = 0;
+            for (int g0 = 0; g0 < n_blocks && rc == MMX_OK; g0 += sub) {
+                const int cnt = n_blocks - g0 < sub ? n_blocks - g0 : sub;
+                { mmx_timed_scope ts(MMX_K_ZX, s);
+                  rc = mmx_launch_zx6(vol, d_blocks + g0, h_blocks + g0, cnt, plan, txx, radius, d_work,
+                                      (float)(1.0 / q_bp), (float)(1.0 / q_bq), s); }
+                if (rc != MMX_OK) break;
+                { mmx_timed_scope ts(MMX_K_Y2, s);
+                  rc = mmx_launch_ym(d_blocks + g0, cnt, plan, slot_elems, tyy, radius, d_work,
+                                     (float)(q_bp / 65535.0), (float)(q_bq / 32767.0), d_log,
+                                     want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s); }
+                if (rc == MMX_OK) ++groups_done;
+            }
+            if (rc == MMX_ERR_HIP) return hip_fail(hipGetLastError(), "fused passes (sub-batches)");
+            // (a geometry the kernels do not take shows at the first group: the whole-batch form below then falls back
+            //  as always; later groups cannot differ -- the plan and the radius are the batch's)
+            if (rc != MMX_OK && !(rc == MMX_ERR_UNSUPPORTED && groups_done == 0)) return rc;
+            sub_done = rc == MMX_OK;
+            if (sub_done) {
+                if (h_zx_path) *h_zx_path = MMX_ZX_TILED_Q16;
+                if (want_mask) *h_mask_written = MMX_MASK_QUADS;
+                return MMX_OK;
+            }
+        }
         { mmx_timed_scope ts(MMX_K_ZX, s);
           rc = MMX_ERR_UNSUPPORTED;
           const bool mfma16 = zx_mode == MMX_ZX_MFMA_F16 || zx_mode == MMX_ZX_MFMA_F16_LDS;
@@ -329,14 +375,7 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         if (rc == MMX_OK && h_zx_path) *h_zx_path = path;
         if (rc == MMX_OK) {
             mmx_timed_scope ts(MMX_K_Y2, s);
-            // the mask rows of a block (ny rows of ceil(nz * px / 64) words) must fit its slot / 32 words
-            bool want_mask = d_nms_mask != nullptr && h_mask_written != nullptr;
-            for (int b = 0; want_mask && b < n_blocks; ++b) {
-                const mmx_block& hb = h_blocks[b];
-                const int64_t need = tiled ? (int64_t)hb.ny * ((hb.nz + 3) >> 2) * ((hb.nx + 15) >> 4)
-                                           : (int64_t)hb.ny * (((int64_t)hb.nz * hb.px + 63) >> 6);
-                if (need > (slot_elems >> 5) - 1) want_mask = false;
-            }
+            const bool want_mask = mask_fits(tiled);      // (after the Z+X launch: `tiled` says which kernel ran)
             rc = MMX_ERR_UNSUPPORTED;
             if (tiled && q16 && !y_valu)
                 rc = mmx_launch_ym(d_blocks, n_blocks, plan, slot_elems, tyy, radius, d_work,

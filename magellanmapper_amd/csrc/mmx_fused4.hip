@@ -77,6 +77,7 @@ struct mmx_zx4_cfg {
     int maxcol, maxu;                      // table extents: columns per width class, z tiles per depth class
     float qp, qq;                          // Q16 tiles: P / bound(P) and Q / bound(Q) land in [0, 1] and [-1, 1]
     int staged;                            // 0: chunks clamped into the row (zx4); 1: at their natural position (zx5); 2: same, windows at 16 c - R8 (zx6)
+    int ntw;                               // column tiles per wave (tiled form): 2 = tiles (2 p, 2 p + 1) share the window of tile 2 p
 };
 
 namespace {
@@ -163,7 +164,9 @@ zx4_setup(mmx_zx4_cfg cfg, u4_4* __restrict__ xtab, u4_4* __restrict__ ztab)
         const float* w = kern ? cfg.w2 : cfg.w0;
         const int xo = 16 * c + col;
         // natural start of this lane's chunk (tiled form, staged == 2: windows start at 16 c - R8, any multiple of 8)
-        const int xc = (cfg.staged == 2 ? 16 * c - cg::R8 : cg::xstart(c)) + 32 * m + 8 * kq;
+        // (two tiles per wave: the odd tile of a pair reads the even one's window, 16 columns further left)
+        const int cwin = cfg.ntw == 2 ? (c & ~1) : c;
+        const int xc = (cfg.staged == 2 ? 16 * cwin - cg::R8 : cg::xstart(c)) + 32 * m + 8 * kq;
         int xl = xc < 0 ? 0 : xc;
         xl = xl > W - 8 ? W - 8 : xl;                               // where the kernel loads it from
         if (cfg.staged) xl = xc;
@@ -313,8 +316,16 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
 // Q16 (zx_mode 7): the tile holds one dword per voxel, P as unorm16 of P / bound(P) in the low half and Q as snorm16
 // of Q / bound(Q) in the high half (the bounds follow from the weights alone: mmx_tiled_q16_error_bound) -- half
 // the bytes for the Y pass to read and for this kernel to write, at a known error that the caller's band must cover.
-template <int NKX, int LA, typename InT, bool TILED = false, bool Q16 = false>
-__global__ void __launch_bounds__(256, (TILED && (LA == 1 || Q16) && !is_f32_4<InT>::value) ? 3 : 2)   // (float32 tiles, LA == 2: 232 registers)
+// NTW = 2 (TILED, Q16, 8 < radius <= 16): a wave owns TWO adjacent column tiles (2 p, 2 p + 1).  Their windows -- 48
+// of the 64 columns two k-steps load -- overlap by two thirds, and the 64 columns from 16 c - 16 on hold both: the
+// same two loads per z step now feed two output tiles (half the L2 read requests per tile: the counters had shown
+// 4.3 x as many bytes requested from L2 as read from HBM, neighbouring waves re-reading each other's windows), and
+// the voxels are unpacked into float16 pieces once for both (-16 of ~92 VALU instructions per tile step).  The second
+// tile's X fragments and window are another 64 registers: two waves per SIMD instead of three, each with twice the
+// independent work per step.  An odd tile count leaves the last wave of a row one tile: it computes the second with
+// zero weights and its stores are dropped by a zero-length buffer descriptor (no branch in the march).
+template <int NKX, int LA, typename InT, bool TILED = false, bool Q16 = false, int NTW = 1>
+__global__ void __launch_bounds__(256, (NTW == 1 && TILED && (LA == 1 || Q16) && !is_f32_4<InT>::value) ? 3 : 2)   // (float32 tiles, LA == 2: 232 registers)
 zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
            float* __restrict__ gp, float* __restrict__ gq,
@@ -326,6 +337,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     constexpr int kUnit = std::is_same<InT, float>::value ? 512 : 256;      // bytes of a unit of the voxel copy
     constexpr bool LO_SCALED = lo_scaled4<InT>::value;
     static_assert(TILED || !std::is_same<InT, float>::value, "float voxels: tiled form only");
+    static_assert(NTW == 1 || (NTW == 2 && TILED && Q16 && NKX == 2 && LA == 1), "two tiles per wave: 16-bit tiles, 8 < radius <= 16");
     // TILED, radius <= 16: the Z fragments of the interior z tiles live in LDS, shared by the workgroup's waves, and
     // two z tiles are in flight instead of three: 154 registers, three waves per SIMD.  (Radius > 16 has three
     // k-steps of Z fragments: with float32 tiles, which are bound by their stores, fetching them from LDS every step
@@ -342,8 +354,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // workgroups one XCD gets (every 8th) are made neighbours: its L2 then serves the overlap (gridDim.x % 8 == 0)
     const int bx = TILED ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int gw = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of this block: (y, column)
-    const int y = gw / ntx;
-    const int c = gw - y * ntx;
+    const int ntp = (ntx + NTW - 1) / NTW;                      // waves per row: one per tile, or per pair of tiles
+    const int y = gw / ntp;
+    const int c = (gw - y * ntp) * NTW;                         // (first) column tile of this wave
     const int lane = threadIdx.x & 63;
     const int li = lane & 15, kq = lane >> 4;
     int cw = 0, cz = 0;
@@ -363,16 +376,19 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     }
     if (y >= bd.ny) return;                                   // whole wave (no barriers below)
 
-    // X fragments of this column: [m][kernel][piece]
-    u4_4 xw[NKX][2][2];
-    {
-        const u4_4* xt = xtab + ((size_t)(cw * cfg.maxcol + c) * NKX * 2) * 128 + lane;
+    // X fragments of this wave's column tile(s): [tile][m][kernel][piece]
+    u4_4 xw[NTW][NKX][2][2];
+    const bool has2 = NTW == 2 && c + 1 < ntx;                 // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        // (a pair's missing second tile: any column's fragments -- its results are never stored)
+        const u4_4* xt = xtab + ((size_t)(cw * cfg.maxcol + (i && !has2 ? c : c + i)) * NKX * 2) * 128 + lane;
 #pragma unroll
         for (int m = 0; m < NKX; ++m)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                xw[m][k][0] = xt[(m * 2 + k) * 128];
-                xw[m][k][1] = xt[(m * 2 + k) * 128 + 64];
+                xw[i][m][k][0] = xt[(m * 2 + k) * 128];
+                xw[i][m][k][1] = xt[(m * 2 + k) * 128 + 64];
             }
     }
     // 16-bit tiles: the voxel pieces keep their exponent offsets (pieces4::split_biased) and the X accumulators start
@@ -382,22 +398,28 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // (radius > 16: the eight start registers would push the kernel past three waves per SIMD)
     constexpr bool BIASED = TILED && Q16 && !is_f32_4<InT>::value && LA == 1;
     constexpr bool MIXSPLIT = Q16;
-    f4_4 a_start = {0.f, 0.f, 0.f, 0.f}, b_start = a_start;
+    const f4_4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4_4 a_start[NTW], b_start[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { a_start[i] = zero4; b_start[i] = zero4; }
     if constexpr (BIASED) {
         const u4_4 ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
-        f4_4 sh[2] = {a_start, a_start}, sl[2] = {a_start, a_start};
 #pragma unroll
-        for (int m = 0; m < NKX; ++m)
+        for (int i = 0; i < NTW; ++i) {
+            f4_4 sh[2] = {zero4, zero4}, sl[2] = {zero4, zero4};
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                sh[k] = mfma16(ones, xw[m][k][0], sh[k]);
-                sl[k] = mfma16(ones, xw[m][k][1], sl[k]);
-            }
-        // a0 takes (hi + lo pieces) x high fragments, a1 hi pieces x low fragments (scaled by 2048), v = a0 + a1 / 2048
-        const float ca = -((pc::kBiasHi + (pc::NP == 2 ? pc::kBiasLo : 0.f)) * sh[0][0] + pc::kBiasHi * sl[0][0] * kLoInv);
-        const float cb = -((pc::kBiasHi + (pc::NP == 2 ? pc::kBiasLo : 0.f)) * sh[1][0] + pc::kBiasHi * sl[1][0] * kLoInv);
-        a_start = (f4_4){ca, ca, ca, ca};
-        b_start = (f4_4){cb, cb, cb, cb};
+            for (int m = 0; m < NKX; ++m)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    sh[k] = mfma16(ones, xw[i][m][k][0], sh[k]);
+                    sl[k] = mfma16(ones, xw[i][m][k][1], sl[k]);
+                }
+            // a0 takes (hi + lo pieces) x high fragments, a1 hi pieces x low fragments (scaled by 2048), v = a0 + a1 / 2048
+            const float ca = -((pc::kBiasHi + (pc::NP == 2 ? pc::kBiasLo : 0.f)) * sh[0][0] + pc::kBiasHi * sl[0][0] * kLoInv);
+            const float cb = -((pc::kBiasHi + (pc::NP == 2 ? pc::kBiasLo : 0.f)) * sh[1][0] + pc::kBiasHi * sl[1][0] * kLoInv);
+            a_start[i] = (f4_4){ca, ca, ca, ca};
+            b_start[i] = (f4_4){cb, cb, cb, cb};
+        }
     }
     // Z fragments: [ks][kernel][piece], of the z tile being produced (reloaded when its class changes);
     // interior z tiles share one set: the first tile whose taps all fall inside the block
@@ -438,15 +460,19 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rs, zo + xoff[m]);
     };
 
-    // window of X results as float16 pieces: [array: A hi, A lo, B hi, B lo][tile][2 dwords]
-    unsigned win[4][NT][2];
+    // window of X results as float16 pieces: [column tile][array: A hi, A lo, B hi, B lo][z tile][2 dwords]
+    unsigned win[NTW][4][NT][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int w = 0; w < NTW; ++w)
 #pragma unroll
-        for (int i = 0; i < NT; ++i) { win[a][i][0] = 0u; win[a][i][1] = 0u; }
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) { win[w][a][i][0] = 0u; win[w][a][i][1] = 0u; }
 
     const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
     const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
+    // (second tile of a pair: the same array, 0 records when the row has no such tile -- its stores are dropped)
+    const rsrc4_t rp2 = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems, 0, has2 ? 0x7fffffff : 0, 0x00020000);
     const unsigned row_b = (unsigned)px * 4u;
     // TILED: tile (y, c, U) of 16 z x 16 x floats, row-major, at ((y ntx + c) ntz + U) KiB: what a wave writes
     // during its march is contiguous, the waves of a workgroup and the workgroups of a row follow each other --
@@ -473,16 +499,22 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // Results on their way to memory: a store reads its data registers asynchronously, so the compiler makes the
     // next writer of those registers wait (vmcnt) until the store has completed.  Each ring slot therefore has
     // its own result registers, kept allocated (an empty asm "use") until the slot comes round again.
-    f4_4 outP[PF], outQ[PF];
+    f4_4 outP[PF][NTW], outQ[PF];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) { outP[u] = (f4_4){0.f, 0.f, 0.f, 0.f}; outQ[u] = outP[u]; }
-    auto step = [&](int t, auto steady_tag, typename pc::raw_t (&rw)[NKX], f4_4& P, f4_4& Q) __attribute__((always_inline)) {
+    for (int u = 0; u < PF; ++u) {
+#pragma unroll
+        for (int w = 0; w < NTW; ++w) outP[u][w] = zero4;
+        outQ[u] = zero4;
+    }
+    auto step = [&](int t, auto steady_tag, typename pc::raw_t (&rw)[NKX], f4_4 (&P)[NTW], f4_4& Q) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         // shift the window by one z tile
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int w = 0; w < NTW; ++w)
 #pragma unroll
-            for (int i = 0; i < 2 * LA; ++i) { win[a][i][0] = win[a][i + 1][0]; win[a][i][1] = win[a][i + 1][1]; }
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int i = 0; i < 2 * LA; ++i) { win[w][a][i][0] = win[w][a][i + 1][0]; win[w][a][i][1] = win[w][a][i + 1][1]; }
         if (STEADY || t < ntz) {
             // ---- X pass of z tile t
             u4_4 dh[NKX], dl[NKX];
@@ -498,59 +530,64 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
             if (STEADY) load_tile(t + PF < ntz ? t + PF : ntz - 1, rw);
             else if (t + PF < ntz) load_tile(t + PF, rw);
             __builtin_amdgcn_sched_barrier(0);
-            f4_4 a0 = a_start, a1 = {0.f, 0.f, 0.f, 0.f}, b0 = b_start, b1 = a1;
 #pragma unroll
-            for (int m = 0; m < NKX; ++m) {
-                a0 = mfma16(dh[m], xw[m][0][0], a0);
-                b0 = mfma16(dh[m], xw[m][1][0], b0);
-                a1 = mfma16(dh[m], xw[m][0][1], a1);
-                b1 = mfma16(dh[m], xw[m][1][1], b1);
-                if constexpr (LO_SCALED) {
-                    // (float voxels: the low piece carries x 2048 like the low fragments; low x low is 2^-22 of a product)
-                    a1 = mfma16(dl[m], xw[m][0][0], a1);
-                    b1 = mfma16(dl[m], xw[m][1][0], b1);
-                } else if constexpr (pc::NP == 2) {
-                    a0 = mfma16(dl[m], xw[m][0][0], a0);
-                    b0 = mfma16(dl[m], xw[m][1][0], b0);
-                    // (low voxel byte x low weight piece: <= 2^-19 of a product.  The float32 tiles keep it; the 16-bit
-                    //  tiles' error bound has room for it: mmx_tiled_q16_error_bound counts 1.9e-6 per X sum)
-                    if constexpr (!Q16) {
-                        a1 = mfma16(dl[m], xw[m][0][1], a1);
-                        b1 = mfma16(dl[m], xw[m][1][1], b1);
+            for (int w = 0; w < NTW; ++w) {
+                f4_4 a0 = a_start[w], a1 = zero4, b0 = b_start[w], b1 = zero4;
+#pragma unroll
+                for (int m = 0; m < NKX; ++m) {
+                    a0 = mfma16(dh[m], xw[w][m][0][0], a0);
+                    b0 = mfma16(dh[m], xw[w][m][1][0], b0);
+                    a1 = mfma16(dh[m], xw[w][m][0][1], a1);
+                    b1 = mfma16(dh[m], xw[w][m][1][1], b1);
+                    if constexpr (LO_SCALED) {
+                        // (float voxels: the low piece carries x 2048 like the low fragments; low x low is 2^-22 of a product)
+                        a1 = mfma16(dl[m], xw[w][m][0][0], a1);
+                        b1 = mfma16(dl[m], xw[w][m][1][0], b1);
+                    } else if constexpr (pc::NP == 2) {
+                        a0 = mfma16(dl[m], xw[w][m][0][0], a0);
+                        b0 = mfma16(dl[m], xw[w][m][1][0], b0);
+                        // (low voxel byte x low weight piece: <= 2^-19 of a product.  The float32 tiles keep it; the 16-bit
+                        //  tiles' error bound has room for it: mmx_tiled_q16_error_bound counts 1.9e-6 per X sum)
+                        if constexpr (!Q16) {
+                            a1 = mfma16(dl[m], xw[w][m][0][1], a1);
+                            b1 = mfma16(dl[m], xw[w][m][1][1], b1);
+                        }
                     }
                 }
-            }
-            // combine the two accumulators and split into float16 pieces: v = acc0 + acc1 / 2048
+                // combine the two accumulators and split into float16 pieces: v = acc0 + acc1 / 2048
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const float av0 = __builtin_fmaf(a1[r], kLoInv, a0[r]), av1 = __builtin_fmaf(a1[r + 1], kLoInv, a0[r + 1]);
-                const float bv0 = __builtin_fmaf(b1[r], kLoInv, b0[r]), bv1 = __builtin_fmaf(b1[r + 1], kLoInv, b0[r + 1]);
-                const f2_4 av = {av0, av1}, bv = {bv0, bv1};
-                const h2_4 ah = __builtin_convertvector(av, h2_4), bh = __builtin_convertvector(bv, h2_4);
-                if constexpr (MIXSPLIT) {
-                    // 16-bit tiles: the low piece is the plain residual v - half(v), not scaled by 2048 -- values are
-                    // <= 1 here (the fragments carry 1 / bound), so the residual is below 2^-12 and float16 keeps it to
-                    // 2^-24 absolute, a 250th of the 16-bit quantum; the Z pass below adds it at full weight.
-                    // (v_fma_mix{lo,hi}_f16 would make it in one instruction per value, but only as inline assembly,
-                    //  whose register writes the compiler's hazard recogniser does not see: one landed right behind an
-                    //  MFMA that still read the register as its C operand -- wrong results for radius <= 8.)
-                    const f2_4 ar = {av0 - (float)ah.x, av1 - (float)ah.y}, br = {bv0 - (float)bh.x, bv1 - (float)bh.y};
-                    win[0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
-                    win[1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
-                    win[2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
-                    win[3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
-                    continue;
+                for (int r = 0; r < 4; r += 2) {
+                    const float av0 = __builtin_fmaf(a1[r], kLoInv, a0[r]), av1 = __builtin_fmaf(a1[r + 1], kLoInv, a0[r + 1]);
+                    const float bv0 = __builtin_fmaf(b1[r], kLoInv, b0[r]), bv1 = __builtin_fmaf(b1[r + 1], kLoInv, b0[r + 1]);
+                    const f2_4 av = {av0, av1}, bv = {bv0, bv1};
+                    const h2_4 ah = __builtin_convertvector(av, h2_4), bh = __builtin_convertvector(bv, h2_4);
+                    if constexpr (MIXSPLIT) {
+                        // 16-bit tiles: the low piece is the plain residual v - half(v), not scaled by 2048 -- values are
+                        // <= 1 here (the fragments carry 1 / bound), so the residual is below 2^-12 and float16 keeps it to
+                        // 2^-24 absolute, a 250th of the 16-bit quantum; the Z pass below adds it at full weight.
+                        // (v_fma_mix{lo,hi}_f16 would make it in one instruction per value, but only as inline assembly,
+                        //  whose register writes the compiler's hazard recogniser does not see: one landed right behind an
+                        //  MFMA that still read the register as its C operand -- wrong results for radius <= 8.)
+                        const f2_4 ar = {av0 - (float)ah.x, av1 - (float)ah.y}, br = {bv0 - (float)bh.x, bv1 - (float)bh.y};
+                        win[w][0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
+                        win[w][1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
+                        win[w][2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
+                        win[w][3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
+                        continue;
+                    }
+                    const f2_4 ar = {__builtin_fmaf((float)ah.x, -kLoScale, av0 * kLoScale), __builtin_fmaf((float)ah.y, -kLoScale, av1 * kLoScale)};
+                    const f2_4 br = {__builtin_fmaf((float)bh.x, -kLoScale, bv0 * kLoScale), __builtin_fmaf((float)bh.y, -kLoScale, bv1 * kLoScale)};
+                    win[w][0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
+                    win[w][1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
+                    win[w][2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
+                    win[w][3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
                 }
-                const f2_4 ar = {__builtin_fmaf((float)ah.x, -kLoScale, av0 * kLoScale), __builtin_fmaf((float)ah.y, -kLoScale, av1 * kLoScale)};
-                const f2_4 br = {__builtin_fmaf((float)bh.x, -kLoScale, bv0 * kLoScale), __builtin_fmaf((float)bh.y, -kLoScale, bv1 * kLoScale)};
-                win[0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
-                win[1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
-                win[2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
-                win[3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
             }
         } else {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) { win[a][2 * LA][0] = 0u; win[a][2 * LA][1] = 0u; }
+            for (int w = 0; w < NTW; ++w)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { win[w][a][2 * LA][0] = 0u; win[w][a][2 * LA][1] = 0u; }
         }
         const int U = t - LA;
         if (STEADY || U >= 0) {
@@ -568,13 +605,11 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                         }
                 }
             }
-            f4_4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, q0 = p0, q1 = p0;
+            f4_4 p0[NTW], p1[NTW], q0[NTW], q1[NTW];
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) { p0[w] = zero4; p1[w] = zero4; q0[w] = zero4; q1[w] = zero4; }
 #pragma unroll
             for (int ks = 0; ks < NKZ; ++ks) {
-                const u4_4 ah = {win[0][2 * ks][0], win[0][2 * ks][1], win[0][2 * ks + 1][0], win[0][2 * ks + 1][1]};
-                const u4_4 al = {win[1][2 * ks][0], win[1][2 * ks][1], win[1][2 * ks + 1][0], win[1][2 * ks + 1][1]};
-                const u4_4 bh = {win[2][2 * ks][0], win[2][2 * ks][1], win[2][2 * ks + 1][0], win[2][2 * ks + 1][1]};
-                const u4_4 bl = {win[3][2 * ks][0], win[3][2 * ks][1], win[3][2 * ks + 1][0], win[3][2 * ks + 1][1]};
                 u4_4 z00, z01, z10, z11;          // [kernel][piece]
                 if constexpr (!ZLDS) {
                     z00 = zw[ks][0][0]; z01 = zw[ks][0][1]; z10 = zw[ks][1][0]; z11 = zw[ks][1][1];
@@ -585,56 +620,70 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                     const u4_4* zp = zt + ((size_t)(want * NKZ + ks) * 2) * 128;
                     z00 = zp[0]; z01 = zp[64]; z10 = zp[128]; z11 = zp[192];
                 }
-                p0 = mfma16(ah, z00, p0);
-                q0 = mfma16(bh, z00, q0);
-                p1 = mfma16(ah, z01, p1);
-                q1 = mfma16(bh, z01, q1);
-                if constexpr (MIXSPLIT) {          // (unscaled low pieces: into the full-weight accumulators)
-                    p0 = mfma16(al, z00, p0);
-                    q0 = mfma16(bl, z00, q0);
-                } else {
-                    p1 = mfma16(al, z00, p1);
-                    q1 = mfma16(bl, z00, q1);
+#pragma unroll
+                for (int w = 0; w < NTW; ++w) {
+                    const u4_4 ah = {win[w][0][2 * ks][0], win[w][0][2 * ks][1], win[w][0][2 * ks + 1][0], win[w][0][2 * ks + 1][1]};
+                    const u4_4 al = {win[w][1][2 * ks][0], win[w][1][2 * ks][1], win[w][1][2 * ks + 1][0], win[w][1][2 * ks + 1][1]};
+                    const u4_4 bh = {win[w][2][2 * ks][0], win[w][2][2 * ks][1], win[w][2][2 * ks + 1][0], win[w][2][2 * ks + 1][1]};
+                    const u4_4 bl = {win[w][3][2 * ks][0], win[w][3][2 * ks][1], win[w][3][2 * ks + 1][0], win[w][3][2 * ks + 1][1]};
+                    p0[w] = mfma16(ah, z00, p0[w]);
+                    q0[w] = mfma16(bh, z00, q0[w]);
+                    p1[w] = mfma16(ah, z01, p1[w]);
+                    q1[w] = mfma16(bh, z01, q1[w]);
+                    if constexpr (MIXSPLIT) {          // (unscaled low pieces: into the full-weight accumulators)
+                        p0[w] = mfma16(al, z00, p0[w]);
+                        q0[w] = mfma16(bl, z00, q0[w]);
+                    } else {
+                        p1[w] = mfma16(al, z00, p1[w]);
+                        q1[w] = mfma16(bl, z00, q1[w]);
+                    }
+                    q0[w] = mfma16(ah, z10, q0[w]);
+                    q1[w] = mfma16(ah, z11, q1[w]);
+                    if constexpr (MIXSPLIT) q0[w] = mfma16(al, z10, q0[w]);
+                    else q1[w] = mfma16(al, z10, q1[w]);
                 }
-                q0 = mfma16(ah, z10, q0);
-                q1 = mfma16(ah, z11, q1);
-                if constexpr (MIXSPLIT) q0 = mfma16(al, z10, q0);
-                else q1 = mfma16(al, z10, q1);
                 if constexpr (ZLDS && !STEADY) __builtin_amdgcn_sched_barrier(0);    // one k-step's fragments at a time
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" ::"v"(P), "v"(Q));       // the slot's previous results stayed in these registers until now
+#pragma unroll
+            for (int w = 0; w < NTW; ++w) asm volatile("" ::"v"(P[w]));     // the slot's previous results stayed in these registers until now
+            asm volatile("" ::"v"(Q));
             if (STEADY || TILED || 16 * U + li < nz) {     // (a tile is stored whole: its padding belongs to it)
                 // the results reach the slot's registers through opaque moves: the stores then read registers
                 // that nothing else may be allocated to before the slot comes round again
                 if constexpr (Q16) {
 #pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        const float pa = __builtin_fmaf(p1[r], kLoInv, p0[r]), pb = __builtin_fmaf(p1[r + 1], kLoInv, p0[r + 1]);
-                        const float qa = __builtin_fmaf(q1[r], kLoInv, q0[r]), qb = __builtin_fmaf(q1[r + 1], kLoInv, q0[r + 1]);
-                        const unsigned pu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(pa, pb));   // [Pa | Pb]
-                        const unsigned qs = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_i16(qa, qb));   // [Qa | Qb]
-                        const unsigned da = __builtin_amdgcn_perm(qs, pu, 0x05040100u);     // [Pa | Qa]
-                        const unsigned db = __builtin_amdgcn_perm(qs, pu, 0x07060302u);     // [Pb | Qb]
-                        float ra, rb;
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(ra) : "v"(__uint_as_float(da)));
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(rb) : "v"(__uint_as_float(db)));
-                        P[r] = ra;
-                        P[r + 1] = rb;
+                    for (int w = 0; w < NTW; ++w) {
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            const float pa = __builtin_fmaf(p1[w][r], kLoInv, p0[w][r]), pb = __builtin_fmaf(p1[w][r + 1], kLoInv, p0[w][r + 1]);
+                            const float qa = __builtin_fmaf(q1[w][r], kLoInv, q0[w][r]), qb = __builtin_fmaf(q1[w][r + 1], kLoInv, q0[w][r + 1]);
+                            const unsigned pu = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(pa, pb));   // [Pa | Pb]
+                            const unsigned qs = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_i16(qa, qb));   // [Qa | Qb]
+                            const unsigned da = __builtin_amdgcn_perm(qs, pu, 0x05040100u);     // [Pa | Qa]
+                            const unsigned db = __builtin_amdgcn_perm(qs, pu, 0x07060302u);     // [Pb | Qb]
+                            float ra, rb;
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(ra) : "v"(__uint_as_float(da)));
+                            asm volatile("v_mov_b32 %0, %1" : "=v"(rb) : "v"(__uint_as_float(db)));
+                            P[w][r] = ra;
+                            P[w][r + 1] = rb;
+                        }
+                        // (tile (y, c + w, U) lies ntz KiB after tile (y, c, U))
+                        if (w == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P[w]), rp, obase, 0, ZX4_ST_AUX);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P[w]), rp2, obase, (unsigned)ntz * 1024u, ZX4_ST_AUX);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P), rp, obase, 0, ZX4_ST_AUX);
                 } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_fmaf(p1[r], kLoInv, p0[r]);
-                    const float qv = __builtin_fmaf(q1[r], kLoInv, q0[r]);
+                    const float pv = __builtin_fmaf(p1[0][r], kLoInv, p0[0][r]);
+                    const float qv = __builtin_fmaf(q1[0][r], kLoInv, q0[0][r]);
                     float pr, qr;
                     asm volatile("v_mov_b32 %0, %1" : "=v"(pr) : "v"(pv));
                     asm volatile("v_mov_b32 %0, %1" : "=v"(qr) : "v"(qv));
-                    P[r] = pr;
+                    P[0][r] = pr;
                     Q[r] = qr;
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P), rp, obase, 0, ZX4_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P[0]), rp, obase, 0, ZX4_ST_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, Q), rq, obase, 0, ZX4_ST_AUX);
                 }
             }
@@ -804,6 +853,8 @@ zx5_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const int scol = 16 * g * WPG + 4 * schunk;
     const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
     const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
+    // (second tile of a pair: the same array, 0 records when the row has no such tile -- its stores are dropped)
+    const rsrc4_t rp2 = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems, 0, has2 ? 0x7fffffff : 0, 0x00020000);
     const unsigned row_b = (unsigned)px * 4u;
     const unsigned plane_b = (unsigned)bd.ny * row_b;
     unsigned sbase = (unsigned)srow * plane_b + (unsigned)y * row_b + (unsigned)scol * 4u;
@@ -974,7 +1025,8 @@ int launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
         const int ntx = (b.nx + 15) / 16, ntz = (b.nz + 15) / 16;
         if (ntx > cfg.maxcol) cfg.maxcol = ntx;
         if (ntz > cfg.maxu) cfg.maxu = ntz;
-        if (b.ny * ntx > max_waves) max_waves = b.ny * ntx;
+        const int per_row = pair ? (ntx + 1) / 2 : ntx;
+        if (b.ny * per_row > max_waves) max_waves = b.ny * per_row;
     }
     for (int j = cfg.ncw; j < MMX_ZX4_MAXCLS; ++j) cfg.wcls[j] = -1;
     for (int j = cfg.ncz; j < MMX_ZX4_MAXCLS; ++j) cfg.zcls[j] = -1;
@@ -1157,6 +1209,11 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     cfg.staged = 2;
     cfg.qp = qp; cfg.qq = qq;
     cfg.maxcol = cfg.maxu = 0;
+    // two column tiles per wave (zx4_kernel's NTW): 16-bit tiles of integer voxels, 8 < radius <= 16.  MMX_ZX_PAIR=0
+    // keeps one tile per wave (A/B runs).
+    static const bool pair_env = !(getenv("MMX_ZX_PAIR") && atoi(getenv("MMX_ZX_PAIR")) == 0);
+    const bool pair = pair_env && NKX == 2 && LA == 1 && qp > 0.f && vol->dtype != MMX_F32;
+    cfg.ntw = pair ? 2 : 1;
     int max_waves = 0;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
@@ -1169,7 +1226,8 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
         const int ntx = (b.nx + 15) / 16, ntz = (b.nz + 15) / 16;
         if (ntx > cfg.maxcol) cfg.maxcol = ntx;
         if (ntz > cfg.maxu) cfg.maxu = ntz;
-        if (b.ny * ntx > max_waves) max_waves = b.ny * ntx;
+        const int per_row = pair ? (ntx + 1) / 2 : ntx;
+        if (b.ny * per_row > max_waves) max_waves = b.ny * per_row;
     }
     for (int j = cfg.ncw; j < MMX_ZX4_MAXCLS; ++j) cfg.wcls[j] = -1;
     for (int j = cfg.ncz; j < MMX_ZX4_MAXCLS; ++j) cfg.zcls[j] = -1;
@@ -1192,6 +1250,12 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
         else
             hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true, false>), grid, dim3(256), 0, s,
                                reinterpret_cast<const float*>(w + plan.pack_off), plan.pack_stride / 2, (int64_t)0, d_blocks,
+                               plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
+                               xtab, ztab, cfg);
+    } else if (pair) {
+        if constexpr (NKX == 2 && LA == 1)
+            hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, true, 2>), grid, dim3(256), 0, s,
+                               reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
                                plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
                                xtab, ztab, cfg);
     } else if (qp > 0.f)

@@ -189,8 +189,9 @@ def test_full_size_c5_tile_digests_and_sample_parity(gpu, tmp_path):
     assert line["blobs"] == C5_DIGESTS["blobs"]
 
 
-#: first recorded in round 4 (gpurun_out/r04_c5_full.json); the sample check above ties the same code to the oracle
-C5_DIGESTS = {"table": "TBD", "colocs": "TBD", "blobs": -1}
+#: first recorded in round 4 (profiles/r04_bench_c5_first.json); the sample check above ties the same code to the oracle
+C5_DIGESTS = {"table": "4cea549b4ccf64e812dd75171aaf9505125a5a67", "colocs": "946996fd9817e988835dfcafc0d68fb79af3f543",
+              "blobs": 427167}
 
 
 def test_full_size_c3_volume_properties_and_digest(gpu, tmp_path):
