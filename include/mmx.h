@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 12
+#define MMX_ABI_VERSION 13
 
 typedef enum {
     MMX_OK = 0,
@@ -241,6 +241,68 @@ int mmx_rescore_f64(const mmx_volume* vol, const mmx_block* d_blocks, int n_bloc
  * neighbours inside the cube. */
 int mmx_expand_probes(mmx_cand* d_cands, uint32_t cap, uint32_t* d_count, uint32_t* d_n_cands,
                       const mmx_block* d_blocks, int n_blocks, int n_sigma, void* stream);
+
+/* ---- A0-A4 of one batch of blocks in ONE call (the fused `mmx_detect_block`)
+ * replaces: everything between the reference's call `blob_log(roi, min_sigma, max_sigma, num_sigma, threshold, overlap)`
+ * (magmap/cv/detector.py:931-933 -> skimage/feature/blob.py:470-504, peak.py:28-50) and the comparison of float64 cube
+ * values: the voxel copy of the tiled path, (Z+X, Y) per sigma -- with the rules that keep all scales on one kernel path
+ * and one NMS entry layout --, the counter reset, mmx_peaks_batch, mmx_expand_probes, mmx_rescore_f64 and the copies of
+ * the counters and of the head of the candidate table to pinned host memory, all enqueued by native code.  Nothing
+ * waits for the GPU; the caller synchronises on `ev_done` and then owns h_count / h_cands.
+ *   vol32 / vol_exact : what the float32 passes read (uint8 / uint16 / float32; float voxels state their range in
+ *                 value_range) and what the exact re-score reads (the same volume, or its float64 original)
+ *   h_w0, h_w2 / d_w0, d_w2 : [n_sigma][MMX_MAX_RADIUS_GENERIC + 1] float64 half kernels on the host and on the device
+ *   d_work / work_bytes : >= mmx_workspace_bytes(n_blocks, slot_elems, n_sigma, 1)
+ *   thr, eps    : threshold and nomination band (candidates: v >= nbr_max - eps and v > thr - eps)
+ *   d_cands / cap / d_count : candidate table; d_count[0] = entries (keeps counting past cap: the caller retries with
+ *                 a larger table), d_count[1] = candidates among them (the rest are probes)
+ *   h_count, h_cands / h_prefix : pinned host copies of d_count[0..1] and of the first h_prefix entries (NULL: no copy)
+ *   zx_mode / zx_flags : as for mmx_log_batch_f32 (flags: MMX_ZX_Y_VALU)
+ *   exact       : re-score every candidate (and probe) in float64;  expand : append the probes (mmx_expand_probes)
+ *   stream      : the LoG passes;  tail_stream (NULL = stream): NMS, probes, re-score, copies -- beside the next batch's
+ *                 passes when it is another stream;  pack_stream (NULL = stream): the voxel copy
+ *   ev_work_free: NULL or an event to wait for before d_work is written (its previous reader);
+ *   ev_work_read: NULL or an event recorded once the NMS has read d_work;  ev_done: NULL or recorded at the very end. */
+typedef struct {
+    const mmx_volume* vol32;
+    const mmx_volume* vol_exact;
+    const mmx_block* d_blocks;
+    const mmx_block* h_blocks;
+    int32_t n_blocks, n_sigma;
+    int64_t slot_elems;
+    const double* h_w0; const double* h_w2;
+    const double* d_w0; const double* d_w2;
+    const int32_t* h_radius;
+    const double* h_norm;
+    float* d_work;
+    size_t work_bytes;
+    float thr, eps;
+    mmx_cand* d_cands;
+    uint32_t cap, h_prefix;
+    uint32_t* d_count;
+    uint32_t* h_count;
+    mmx_cand* h_cands;
+    int32_t zx_mode, zx_flags, store_f32, exact, expand, _pad;
+    void* stream; void* tail_stream; void* pack_stream;
+    void* ev_work_free; void* ev_work_read; void* ev_done;
+} mmx_detect_args;
+typedef struct {
+    int32_t zx_path;        /* mmx_zx_mode the last scale ran */
+    int32_t mask_layout;    /* 0 = the NMS read the full cube, MMX_MASK_ROWS / MMX_MASK_QUADS */
+    int32_t n_pass_rounds;  /* 1, or more when the scales had to be computed again on another path */
+    int32_t _pad;
+    double q16_bound;       /* error bound of the 16-bit intermediates in value units (0: not used) */
+} mmx_detect_info;
+int mmx_detect_batch(const mmx_detect_args* args, mmx_detect_info* info);
+const char* mmx_detect_last_error(void);
+/* the same launches captured as a hipGraph (every argument frozen; refused with MMX_ERR_UNSUPPORTED while per-kernel
+ * timing is on: its events cannot live inside a capture) and replayed with one launch on `stream` */
+int mmx_detect_batch_capture(const mmx_detect_args* args, mmx_detect_info* info, void** graph);
+int mmx_graph_launch(void* graph, void* stream, void* ev_done, mmx_detect_info* info);
+int mmx_graph_destroy(void* graph);
+int mmx_event_synchronize(void* ev);
+int mmx_stream_wait_event(void* stream, void* ev);
+int mmx_timing_is_enabled(void);
 
 /* ---- A5 support: all blob pairs of one block whose sphere-overlap fraction exceeds
  * `overlap` (skimage/feature/blob.py:84-187: _blob_overlap / _prune_blobs)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 12
+MMX_ABI_VERSION = 13
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -63,6 +63,26 @@ class Volume(Structure):
                 ("stride_z", c_int64), ("stride_y", c_int64), ("stride_x", c_int64)]
 
 
+class DetectArgs(Structure):
+    """``mmx_detect_args`` (one batch from voxels to the re-scored candidate table: ``mmx_detect_batch``)."""
+    _fields_ = [("vol32", POINTER(Volume)), ("vol_exact", POINTER(Volume)), ("d_blocks", c_void_p),
+                ("h_blocks", c_void_p), ("n_blocks", c_int32), ("n_sigma", c_int32), ("slot_elems", c_int64),
+                ("h_w0", c_void_p), ("h_w2", c_void_p), ("d_w0", c_void_p), ("d_w2", c_void_p),
+                ("h_radius", c_void_p), ("h_norm", c_void_p), ("d_work", c_void_p), ("work_bytes", ctypes.c_size_t),
+                ("thr", c_float), ("eps", c_float), ("d_cands", c_void_p), ("cap", c_uint32), ("h_prefix", c_uint32),
+                ("d_count", c_void_p), ("h_count", c_void_p), ("h_cands", c_void_p),
+                ("zx_mode", c_int32), ("zx_flags", c_int32), ("store_f32", c_int32), ("exact", c_int32),
+                ("expand", c_int32), ("_pad", c_int32),
+                ("stream", c_void_p), ("tail_stream", c_void_p), ("pack_stream", c_void_p),
+                ("ev_work_free", c_void_p), ("ev_work_read", c_void_p), ("ev_done", c_void_p)]
+
+
+class DetectInfo(Structure):
+    """``mmx_detect_info``."""
+    _fields_ = [("zx_path", c_int32), ("mask_layout", c_int32), ("n_pass_rounds", c_int32), ("_pad", c_int32),
+                ("q16_bound", c_double)]
+
+
 class PreprocParams(Structure):
     """``mmx_preproc_params``."""
     _fields_ = [("clip_min", c_double), ("clip_max", c_double), ("max_thresh", c_double),
@@ -79,6 +99,8 @@ _lib = None
 #: every symbol ``include/mmx.h`` declares
 SYMBOLS = (
     "mmx_abi_version", "mmx_has_experiments", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
+    "mmx_detect_batch", "mmx_detect_batch_capture", "mmx_graph_launch", "mmx_graph_destroy", "mmx_detect_last_error",
+    "mmx_event_synchronize", "mmx_stream_wait_event", "mmx_timing_is_enabled",
     "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_zx_pack", "mmx_tiled_q16_error_bound", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
@@ -133,6 +155,13 @@ def lib() -> ctypes.CDLL:
                                   POINTER(c_int32), POINTER(c_double), c_int, c_int, vp]
     L.mmx_overlap_pairs.argtypes = [vp, vp, c_int, c_double, c_double, c_double, vp, vp, c_uint32, vp, vp]
     L.mmx_close_pairs.argtypes = [vp, c_int, vp, c_int, POINTER(c_int32), vp, vp, vp]
+    L.mmx_detect_batch.argtypes = [POINTER(DetectArgs), POINTER(DetectInfo)]
+    L.mmx_detect_batch_capture.argtypes = [POINTER(DetectArgs), POINTER(DetectInfo), POINTER(vp)]
+    L.mmx_graph_launch.argtypes = [vp, vp, vp, POINTER(DetectInfo)]
+    L.mmx_graph_destroy.argtypes = [vp]
+    L.mmx_detect_last_error.restype = c_char_p
+    L.mmx_event_synchronize.argtypes = [vp]
+    L.mmx_stream_wait_event.argtypes = [vp, vp]
     L.mmx_event_create.argtypes = [POINTER(vp)]
     L.mmx_event_destroy.argtypes = [vp]
     L.mmx_event_record.argtypes = [vp, vp]

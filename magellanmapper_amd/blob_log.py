@@ -69,6 +69,13 @@ if 0.0 < EPS_REL_Q16 < 4.0 * Q16_BOUND_ANY_SIGMA:
     # 16-bit intermediates off (0), not narrow it below what the bound needs
     raise ValueError(f"MMX_EPS_REL_Q16={EPS_REL_Q16:g} is narrower than 4 x the 16-bit intermediates' error bound "
                      f"({4.0 * Q16_BOUND_ANY_SIGMA:g}); use 0 to keep float32 intermediates")
+#: raw volumes on the native host path: one ``mmx_detect_batch`` call enqueues a whole batch (voxel copy, the passes of
+#: every scale, NMS, probes, exact re-score, copies) instead of a dozen calls from here (``MMX_NATIVE_BATCH=0``: the
+#: call-by-call form, kept for cross-checks)
+NATIVE_BATCH = os.environ.get("MMX_NATIVE_BATCH", "1") != "0"
+#: batches of at most this many blocks that come back with the very same arguments (a small volume detected step
+#: after step) are captured as a hipGraph and replayed with one launch (``MMX_GRAPH_BLOCKS=0``: never)
+GRAPH_BLOCKS = int(os.environ.get("MMX_GRAPH_BLOCKS", "8"))
 #: bound of the 16-bit intermediates of the most recent batch that used them (value units), else 0: bench.py prints it
 LAST_Q16_BOUND = 0.0
 #: nomination band (value units) of that batch
@@ -92,6 +99,9 @@ HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
 FLOAT_TILED_RANGE = (0.0, 2.0 ** 12)
 #: per-block preprocessing on a stream of its own (beside the previous batch's LoG kernels)
 PRE_STREAM = os.environ.get("MMX_PRE_STREAM", "1") != "0"
+#: ... and this many batches ahead of the one the host is finishing (``preprocess.N_BUFFER_SETS`` - 1 buffer sets allow
+#: it): the first batch is then the only one whose LoG passes wait for their preprocessing
+PRE_AHEAD = max(1, min(2, int(os.environ.get("MMX_PRE_AHEAD", "2"))))
 #: raw volumes: everything after a batch's last LoG kernel -- NMS, probe expansion, exact re-score, the copies of the
 #: results to the host -- on a stream of its own, beside the LoG kernels of the next batch, which then work in a second
 #: workspace (``_Buffers.workspace(n, 1)``: +16 GiB with the default budget).  Measured on the benchmark volume,
@@ -424,6 +434,35 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     return batches
 
 
+class _NativeEvent:
+    """A HIP event the library records (``mmx_detect_batch``: ``ev_done`` / ``ev_work_read``); what this host needs of
+    ``torch.cuda.Event``: ``synchronize`` and being waited for by a stream (:func:`_stream_wait`)."""
+    __slots__ = ("handle",)
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        nat.check(nat.lib().mmx_event_create(ctypes.byref(h)), "mmx_event_create")
+        self.handle = h.value
+
+    def synchronize(self) -> None:
+        nat.check(nat.lib().mmx_event_synchronize(self.handle), "mmx_event_synchronize")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                nat.lib().mmx_event_destroy(self.handle)
+        except Exception:       # (interpreter shutdown)
+            pass
+
+
+def _stream_wait(stream, event) -> None:
+    """``stream.wait_event(event)`` for torch events and for the library's own."""
+    if isinstance(event, _NativeEvent):
+        nat.check(nat.lib().mmx_stream_wait_event(stream.cuda_stream, event.handle), "mmx_stream_wait_event")
+    else:
+        stream.wait_event(event)
+
+
 class _Buffers:
     """Device scratch that is reused across the batches of one call.
 
@@ -449,6 +488,8 @@ class _Buffers:
         self.pre_stream = torch.cuda.Stream(device=dev)
         self.rescore_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MMX_SIDE_PRIORITY", "0")))
         self.pack_stream = torch.cuda.Stream(device=dev)
+        self.native_events = []            # per candidate-table slot: (workspace read, batch done)
+        self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
         self.slots(2)
 
     def slots(self, n: int):
@@ -459,6 +500,7 @@ class _Buffers:
             self.counts.append(torch.zeros(2, dtype=torch.int32, device=self.dev))
             self.host_counts.append(torch.zeros(2, dtype=torch.int32).pin_memory())
             self.host_tabs.append(None)
+            self.native_events.append(None)
 
     def workspace(self, n_floats: int, which: int = 0):
         """Workspace ``which`` (0: the only one of most paths; 1: the second of the two that batches of a raw volume
@@ -472,6 +514,19 @@ class _Buffers:
             self.ws2 = None
             self.ws2 = torch.empty(n_floats, dtype=torch.float32, device=self.dev)
         return self.ws2
+
+    def events(self, which: int):
+        """``(workspace read, batch done)`` events of slot ``which`` (made once, recorded again by every batch that takes
+        the slot -- which happens only after the previous holder has been waited for)."""
+        if self.native_events[which] is None:
+            self.native_events[which] = (_NativeEvent(), _NativeEvent())
+        return self.native_events[which]
+
+    def drop_graphs(self) -> None:
+        for hit in self.graphs.values():
+            if hit:
+                nat.lib().mmx_graph_destroy(hit[0])
+        self.graphs = {}
 
     def host_table(self, which: int):
         """Pinned staging for the first ``_PREFIX_ENTRIES`` entries of slot ``which``'s candidate table."""
@@ -553,12 +608,63 @@ def self_test(dev) -> None:
 
 
 def release_buffers() -> None:
-    """Drop the cached device scratch (workspace, candidate tables) of every device."""
+    """Drop the cached device scratch (workspace, candidate tables, captured graphs) of every device."""
+    for b in _BUFFERS.values():
+        b.drop_graphs()
     _BUFFERS.clear()
+    from . import preprocess
+    preprocess.release_retained()
+
+
+class _UploadRing:
+    """Small host -> device uploads (block tables, quantile classes, row offsets) that do not stall the host: a
+    pageable ``tensor.to(device)`` waits for everything queued on the stream before it -- with kernels of a few
+    milliseconds queued that is a few milliseconds per table, a dozen times per batch on the preprocessing and
+    co-localisation paths, and the GPU then idles while the host catches up.  Here the bytes go through a ring of
+    pinned slots and an asynchronous copy on the current stream; a slot is reused only after its copy has completed."""
+    SLOTS, SLOT_BYTES = 64, 1 << 17
+
+    def __init__(self):
+        self.stage = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
+        self.host = self.stage.numpy()
+        self.busy = [None] * self.SLOTS
+        self.at = 0
+
+    def put(self, raw: np.ndarray, dev) -> "torch.Tensor":
+        n = raw.size
+        k = self.at
+        self.at = (k + 1) % self.SLOTS
+        if self.busy[k] is not None:
+            self.busy[k].synchronize()
+        lo = k * self.SLOT_BYTES
+        self.host[lo:lo + n] = raw
+        out = torch.empty(n, dtype=torch.uint8, device=dev)
+        out.copy_(self.stage[lo:lo + n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.busy[k] = ev
+        return out
+
+
+_UPLOAD: Optional[_UploadRing] = None
 
 
 def _to_device_bytes(arr: np.ndarray, dev) -> "torch.Tensor":
-    return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(dev)
+    """``arr``'s bytes as a uint8 device tensor, uploaded on the current stream."""
+    global _UPLOAD
+    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    if 0 < raw.size <= _UploadRing.SLOT_BYTES and getattr(dev, "type", str(dev)[:4]) == "cuda":
+        if _UPLOAD is None:
+            _UPLOAD = _UploadRing()
+        return _UPLOAD.put(raw, dev)
+    return torch.from_numpy(raw).to(dev)
+
+
+def to_device(arr: np.ndarray, dev) -> "torch.Tensor":
+    """``torch.from_numpy(arr).to(dev)`` without the stall of a pageable copy (small arrays: :class:`_UploadRing`)."""
+    arr = np.ascontiguousarray(arr)
+    t = _to_device_bytes(arr, dev)
+    return t.view(getattr(torch, str(arr.dtype))).view(arr.shape) if arr.size else torch.from_numpy(arr).to(dev)
 
 
 def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: ScaleSpace,
@@ -671,7 +777,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     # batch k + 1 only after the host work of batch k - 1 left the GPU idle ~4 ms per batch once the host work of
     # a batch outlasted the kernels of the next).  Each batch in flight owns a candidate table; the workspace is
     # shared (stream order).  With preprocessing the float64 tiles are double-buffered, so one batch ahead.
-    ahead = n_b if pre is None else 1
+    ahead = n_b if pre is None else PRE_AHEAD
     bufs.slots(ahead + 1)
     prepared = None
     if pre is None:
@@ -773,14 +879,66 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     ws = bufs.workspace(-(-int(L.mmx_workspace_bytes(nb, slot, ns, 1)) // 4), ws_i)
     # ... and the voxel copy of the tiled path, the first kernel of a batch, on a third: it only needs the workspace
     pack_side = side_tail and PACK_STREAM and bufs.ws2 is not None
-    if bufs.ws_free[ws_i] is not None:       # (also a batch that is nominated again, on the main stream: same workspace)
-        (bufs.pack_stream if pack_side else torch.cuda.current_stream()).wait_event(bufs.ws_free[ws_i])
+    native_batch = bool(NATIVE_BATCH and pre is None and exact and HOST_PATH == "native")
+    if bufs.ws_free[ws_i] is not None and not native_batch:   # (also a batch that is nominated again, on the main stream: same workspace)
+        _stream_wait(bufs.pack_stream if pack_side else torch.cuda.current_stream(), bufs.ws_free[ws_i])
     if d_blocks is None:
         d_blocks = _to_device_bytes(blocks, dev)
     stream = _stream_ptr()
     log_base = ws.data_ptr() + 4 * nb * slot * 4
     # NMS pre-filter masks, [ns][nb][slot / 32] uint64: written by the Y pass of the fused path
     mask_base = (log_base + ns * nb * slot * 4 + 15) & ~15
+    if native_batch:
+        # ---- the whole batch in one native call (mmx_detect_batch): voxel copy, every scale, NMS, probes, re-score, copies
+        global LAST_ZX_PATH, LAST_Q16_BOUND, LAST_NMS_BAND
+        is_float = vol32.dtype == nat.MMX_F32
+        if is_float:
+            float_ok = vrange is not None and max(abs(vrange[0]), abs(vrange[1])) <= FLOAT_TILED_RANGE[1]
+            vol32.value_range = 0.0 if not float_ok else (max(vrange[1], 1e-30) if vrange[0] >= 0.0
+                                                          else -max(abs(vrange[0]), abs(vrange[1])))
+        n_vox = int(sum(int(np.prod(s)) for s in shapes))
+        if cap is None:
+            cap = max(4096, min(n_vox * ns, n_vox // 2000 * ns + 65536))
+        table = bufs.cand_table(which, cap)
+        count = bufs.counts[which]
+        ev_read, ev_done = bufs.events(which)
+        side = bufs.rescore_stream if side_tail else None
+        a = nat.DetectArgs()
+        a.vol32, a.vol_exact = ctypes.pointer(vol32), ctypes.pointer(vol_exact)
+        a.d_blocks, a.h_blocks = d_blocks.data_ptr(), blocks.ctypes.data
+        a.n_blocks, a.n_sigma, a.slot_elems = nb, ns, slot
+        a.h_w0, a.h_w2 = space.w0_tab.ctypes.data, space.w2_tab.ctypes.data
+        a.d_w0, a.d_w2 = d_w0.data_ptr(), d_w2.data_ptr()
+        a.h_radius, a.h_norm = space.radii.ctypes.data, space.norms.ctypes.data
+        a.d_work, a.work_bytes = ws.data_ptr(), ws.numel() * 4
+        a.thr, a.eps = thr, eps
+        a.d_cands, a.cap, a.d_count = table.data_ptr(), cap, count.data_ptr()
+        a.h_count = bufs.host_counts[which].data_ptr()
+        a.h_cands, a.h_prefix = bufs.host_table(which).data_ptr(), min(cap, _PREFIX_ENTRIES)
+        a.zx_mode, a.zx_flags, a.store_f32, a.exact, a.expand = ZX_MODE, ZX_FLAGS, store_f32, 1, 1
+        a.stream = stream
+        a.tail_stream = side.cuda_stream if side is not None else stream
+        a.pack_stream = bufs.pack_stream.cuda_stream if pack_side else stream
+        prev = bufs.ws_free[ws_i]
+        if prev is not None and not isinstance(prev, _NativeEvent):     # (left by the call-by-call form)
+            _stream_wait(bufs.pack_stream if pack_side else torch.cuda.current_stream(), prev)
+            prev = None
+        a.ev_work_free = prev.handle if prev is not None else None
+        a.ev_work_read = ev_read.handle if side_tail else None
+        a.ev_done = ev_done.handle
+        info = nat.DetectInfo()
+        rc = _launch_batch(L, a, info, bufs, nb, blocks, space, vol32, vol_exact)
+        if rc != 0:
+            detail = L.mmx_detect_last_error().decode()
+            nat.check(rc, "mmx_detect_batch" + (f" [{detail}]" if detail and rc == 2 else ""))
+        LAST_ZX_PATH = info.zx_path
+        if info.zx_path == nat.MMX_ZX_TILED_Q16:
+            LAST_Q16_BOUND, LAST_NMS_BAND = info.q16_bound, eps
+        if side_tail:
+            bufs.ws_free[ws_i] = ev_read
+        return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
+                    nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=ev_done, store_f32=store_f32,
+                    vol_exact=vol_exact, pre=pre, exact=exact, eps=eps, native=True, vscale=vscale, vrange=vrange)
     written = ctypes.c_int(0)
     path = ctypes.c_int(0)
 
@@ -806,10 +964,9 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
             bound = max(float(L.mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[s]), nat.as_double_ptr(space.w2[s]),
                                                           int(space.radii[s]), float(space.norms[s]))) for s in range(ns))
             bound *= 1.0 if not is_float else float(vol32.value_range)
-            if mode == nat.MMX_ZX_TILED_Q16 and not (0 <= 4.0 * bound <= eps):
-                raise ValueError(f"16-bit intermediates asked for by name with a nomination band of {eps:g}, narrower "
-                                 f"than 4 x their error bound {bound:g}")
-            if 0 <= 4.0 * bound <= eps:
+            # (by name: taken whatever the band -- kernel experiments and the band-retry tests ask for it with narrow
+            #  bands; the run-time check |float32 - float64| < eps / 4 on every re-scored candidate then widens the band)
+            if mode == nat.MMX_ZX_TILED_Q16 or (0 <= 4.0 * bound <= eps):
                 tiled_mode = nat.MMX_ZX_TILED_Q16
                 LAST_Q16_BOUND, LAST_NMS_BAND = bound, eps
         if (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16) and not is_float) or \
@@ -895,6 +1052,41 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     return dict(blocks=blocks, d_blocks=d_blocks, shapes=shapes, origins=origins, channel=channel,
                 nb=nb, ns=ns, n_vox=n_vox, cap=cap, which=which, done=done, store_f32=store_f32,
                 vol_exact=vol_exact, pre=pre, exact=exact, eps=eps, native=native, vscale=vscale, vrange=vrange)
+
+
+def _launch_batch(L, a, info, bufs: _Buffers, nb: int, blocks, space, vol32, vol_exact) -> int:
+    """``mmx_detect_batch(a)`` -- or, for a small batch that has come by with the very same arguments before (a small
+    volume detected step after step: same buffers, geometry, scales, band), the replay of its captured hipGraph: one
+    launch instead of a dozen.  The second sighting of a key captures, later ones replay; a capture is refused while
+    per-kernel timing is on (its events cannot live inside one) and the plain call is made instead."""
+    if not (0 < nb <= GRAPH_BLOCKS) or a.ev_work_free or not a.stream:
+        return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))
+    # everything a node of the graph would freeze (the two volume records by content: their addresses change per call)
+    key = (bytes(vol32), bytes(vol_exact), blocks.tobytes(), space.sigmas.tobytes(), a.d_blocks, a.slot_elems, a.d_w0,
+           a.d_w2, a.d_work, a.work_bytes, a.thr, a.eps, a.d_cands, a.cap, a.h_prefix, a.d_count, a.h_count, a.h_cands,
+           a.zx_mode, a.zx_flags, a.store_f32, a.stream, a.tail_stream, a.pack_stream)
+    hit = bufs.graphs.get(key)
+    if hit is None:                                 # first sighting: remember it, run it plainly
+        if len(bufs.graphs) >= 16:
+            bufs.drop_graphs()
+        bufs.graphs[key] = ()
+        return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))
+    if L.mmx_timing_is_enabled():                   # (a replay would hide the kernels from the per-kernel timing, and
+        return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))      # a capture cannot hold its events)
+    if not hit:
+        # second sighting: capture (this only records the launches; the replay below runs them)
+        graph = ctypes.c_void_p()
+        rc = L.mmx_detect_batch_capture(ctypes.byref(a), ctypes.byref(info), ctypes.byref(graph))
+        if rc != 0:
+            return rc
+        hit = bufs.graphs[key] = (graph.value, nat.DetectInfo.from_buffer_copy(info), (blocks, space))
+    graph, saved, _ = hit
+    ctypes.memmove(ctypes.byref(info), ctypes.byref(saved), ctypes.sizeof(info))
+    rc = L.mmx_graph_launch(graph, a.stream, a.ev_done, None)
+    if rc == 0 and a.ev_work_read:
+        # (the graph is ordered as a whole on `stream`: "the NMS has read the workspace" holds once it is through)
+        rc = L.mmx_event_record(a.ev_work_read, a.stream)
+    return rc
 
 
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,

@@ -91,8 +91,9 @@ def colocalize_blocks_device(volumes: Dict[int, nat.Volume], blocks: np.ndarray,
         rows[a:a + len(t), 0] = i
         rows[a:a + len(t), 1:4] = t[:, :3].astype(int)          # the reference's .astype(int)
         rows[a:a + len(t), 4] = t[:, 6].astype(int)
-    d_rows = torch.from_numpy(rows.reshape(-1)).to(dev)
-    d_off = torch.from_numpy(offsets).to(dev)
+    from . import blob_log as _bl
+    d_rows = _bl.to_device(rows.reshape(-1), dev)
+    d_off = _bl.to_device(offsets, dev)
     d_mean = torch.empty(n, dtype=torch.float64, device=dev)
     d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
     means = np.full((n, n_channels), np.nan)

@@ -79,6 +79,12 @@ int mmx_timing_enable(int on)
     return MMX_OK;
 }
 
+int mmx_timing_is_enabled(void)
+{
+    std::lock_guard<std::mutex> lk(g_tm);
+    return g_timing ? 1 : 0;
+}
+
 int mmx_timing_read(double* ms, int64_t* launches, int n)
 {
     if (!ms || !launches || n < MMX_K_COUNT) return MMX_ERR_ARG;

@@ -102,6 +102,18 @@ def channel_params(chl: int, near_max: Optional[Sequence[float]] = None) -> Tupl
     return p, settings["clip_vmin"], settings["clip_vmax"]
 
 
+#: output buffer sets a preprocessing stage cycles through (``run(..., which)``): batch k + 2 may be preprocessed while
+#: batch k + 1 waits for its LoG passes and batch k's results are still being re-scored (``blob_log``: two batches ahead)
+N_BUFFER_SETS = 3
+#: device -> {"f64_<channel>" / "f32": tensor}: the resident preprocessed blocks of `Preprocessor.retain`
+_RETAINED: Dict[str, Dict[str, "torch.Tensor"]] = {}
+
+
+def release_retained() -> None:
+    """Drop the preprocessed blocks `Preprocessor.retain` keeps between calls (tens of GB for a whole tile)."""
+    _RETAINED.clear()
+
+
 class Preprocessor:
     """Preprocesses the blocks of a batch into uniform-stride float32 / float64 slots."""
 
@@ -113,8 +125,8 @@ class Preprocessor:
         self.dms = dms
         self.near_max = near_max
         self.want_info = want_info
-        self._out64 = [None, None]
-        self._out32 = [None, None]
+        self._out64 = [None] * N_BUFFER_SETS
+        self._out32 = [None] * N_BUFFER_SETS
         self._scratch = None
         self._weights = None
         self._tmpl_key = None
@@ -141,14 +153,29 @@ class Preprocessor:
         slot = sx * sy_rows * int(shp[:, 0].max())
         need = nb * slot * (8 * len(channels) + 4)
         free_b, _ = torch.cuda.mem_get_info(dvol.tensor.device)
-        if need > budget_fraction * free_b:
-            return False
         dev = dvol.tensor.device
+        held = sum(t.numel() * t.element_size() for t in _RETAINED.get(str(dev), {}).values() if t is not None)
+        if need > budget_fraction * (free_b + held):        # (what an earlier call left here is ours to reuse)
+            return False
+        # The buffers outlive this object: a stack detected step after step (or channel group after channel group)
+        # takes the same tens of GB every time, and handing them back to the caching allocator in between lets smaller
+        # requests carve pieces out of them -- the next call then pays a fresh hipMalloc of 50 GB (measured: 160 ms of
+        # a 305 ms step of the two-channel benchmark tile).  `release_retained()` drops them.
+        pool = _RETAINED.setdefault(str(dev), {})
+
+        def take(name, dtype):
+            t = pool.get(name)
+            if t is None or t.numel() < nb * slot or t.dtype != dtype:
+                pool[name] = None
+                t = pool[name] = torch.empty(nb * slot, dtype=dtype, device=dev)
+            return t[:nb * slot]
+        for name in [k for k in pool if k != "f32" and k not in {f"f64_{int(c)}" for c in channels}]:
+            del pool[name]                  # (channels of an earlier call that this one does not keep)
         self._retain = dict(
             gid={(tuple(int(v) for v in o), tuple(int(v) for v in s_)): i for i, (o, s_) in enumerate(zip(origins, shapes))},
             sx=sx, sy_rows=sy_rows, slot=slot, nb=nb,
-            out64={int(c): torch.empty(nb * slot, dtype=torch.float64, device=dev) for c in channels},
-            out32=torch.empty(nb * slot, dtype=torch.float32, device=dev))
+            out64={int(c): take(f"f64_{int(c)}", torch.float64) for c in channels},
+            out32=take("f32", torch.float32))
         return True
 
     def retained_view(self, channel: int, origins, shapes):
@@ -348,7 +375,8 @@ class Preprocessor:
         d_subs[:total * item].copy_(self._stage[:total * item], non_blocking=True)
         self._stage_free = torch.cuda.Event()
         self._stage_free.record()
-        d_qc = torch.from_numpy(qc.view(np.uint8).reshape(-1)).to(dev)
+        from . import blob_log as _bl
+        d_qc = _bl._to_device_bytes(qc, dev)
         d_info = None
         if self.want_info:
             d_info = torch.zeros(len(subs) * nat.SUBINFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
@@ -431,8 +459,8 @@ class Unmixer:
         self._rs: Dict[int, "Rescaler"] = {}
         self._blocks_args = None
         self._pres: Dict[int, Preprocessor] = {}
-        self._out64 = [None, None]
-        self._out32 = [None, None]
+        self._out64 = [None] * N_BUFFER_SETS
+        self._out32 = [None] * N_BUFFER_SETS
 
     def set_blocks(self, origins, shapes, new_shapes) -> None:
         self._blocks_args = (origins, shapes, new_shapes)
@@ -610,8 +638,8 @@ class Rescaler:
         self.near_max = near_max
         self._pres: Dict[int, Preprocessor] = {}
         self._orig: Dict[Tuple[Tuple[int, ...], Tuple[int, ...]], Tuple[int, int, int]] = {}
-        self._out = [None, None]
-        self._out32 = [None, None]
+        self._out = [None] * N_BUFFER_SETS
+        self._out32 = [None] * N_BUFFER_SETS
         self._aa0 = self._aa1 = None          # ping-pong buffers of the anti-aliasing passes
         self._scale = 1.0
 

@@ -1094,3 +1094,143 @@ def test_float_voxels_take_the_tiled_path(gpu):
         np.testing.assert_array_equal(peaks[0][1], st["peak_values"].astype(np.float64))
         np.testing.assert_array_equal(res[0], want)
         assert stats.max_f32_error < 5e-6 * max(1.0, scale * 1.3)
+
+
+# ---------------------------------------------------------------- mmx_detect_batch: one native call per batch
+def _peaks_of(bl, dvol, g, stats=None):
+    res, peaks = bl.blob_log_blocks(
+        dvol, 0, [(0, 0, 0)], [g["volume"].shape], float(g["min_sigma"]), float(g["max_sigma"]),
+        int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]), stats=stats, return_peaks=True)
+    return res[0], peaks[0]
+
+
+@pytest.mark.parametrize("case", ["u16_5sigma", "u8_3sigma", "f32_2sigma", "f64_2sigma", "u16_thin", "u16_empty"])
+def test_one_native_call_per_batch_equals_the_call_by_call_form(gpu, case, monkeypatch):
+    """``mmx_detect_batch`` (SURVEY.md 8b's fused A0-A4 entry: voxel copy, every scale, NMS, probes, exact re-score and
+    the copies enqueued by native code) against the same launches made one ctypes call at a time from Python, and
+    against the real scikit-image: ordered peaks, bit-equal float64 values, pruned blobs."""
+    from magellanmapper_amd import blob_log as bl
+    g = load_golden("bloblog_%s.npz" % case)
+    dvol = bl.DeviceVolume(g["volume"])
+    monkeypatch.setattr(bl, "GRAPH_BLOCKS", 0)
+    monkeypatch.setattr(bl, "NATIVE_BATCH", False)
+    res_a, (coords_a, vals_a) = _peaks_of(bl, dvol, g)
+    path_a = bl.LAST_ZX_PATH
+    monkeypatch.setattr(bl, "NATIVE_BATCH", True)
+    st = bl.BatchStats()
+    res_b, (coords_b, vals_b) = _peaks_of(bl, dvol, g, st)
+    assert bl.LAST_ZX_PATH == path_a
+    np.testing.assert_array_equal(coords_b, coords_a)
+    np.testing.assert_array_equal(vals_b, vals_a)
+    np.testing.assert_array_equal(res_b, res_a)
+    np.testing.assert_array_equal(coords_b, g["peaks"].reshape(-1, 4))            # real skimage
+    np.testing.assert_array_equal(res_b, g["pruned"])
+
+
+def test_small_batches_replay_a_captured_graph(gpu, monkeypatch):
+    """A small volume detected again and again with the same buffers (``bench.py --config c2``'s step): the second
+    sighting of a batch captures its launches as a hipGraph, later ones replay it -- same peaks every time, and the
+    replay refuses to hide kernels from the per-kernel timing."""
+    from magellanmapper_amd import _native as nat, blob_log as bl
+    g = load_golden("bloblog_u16_5sigma.npz")
+    dvol = bl.DeviceVolume(g["volume"])
+    bl.release_buffers()
+    monkeypatch.setattr(bl, "GRAPH_BLOCKS", 8)
+    monkeypatch.setattr(bl, "NATIVE_BATCH", True)
+    runs = [_peaks_of(bl, dvol, g) for _ in range(4)]
+    bufs = bl._buffers_for(dvol.tensor.device)
+    captured = [hit for hit in bufs.graphs.values() if hit]
+    assert len(captured) == 1 and captured[0][0]                # one key, seen, captured, replayed twice
+    for res, (coords, vals) in runs:
+        np.testing.assert_array_equal(coords, g["peaks"].reshape(-1, 4))
+        np.testing.assert_array_equal(vals, runs[0][1][1])
+        np.testing.assert_array_equal(res, g["pruned"])
+    # another band is another key: no stale replay
+    monkeypatch.setattr(bl, "EPS_REL_Q16", 3e-4)
+    res, (coords, _) = _peaks_of(bl, dvol, g)
+    np.testing.assert_array_equal(coords, g["peaks"].reshape(-1, 4))
+    assert len(bufs.graphs) == 2
+    # with the per-kernel timing on the launches are made one by one (and show up in it)
+    monkeypatch.setattr(bl, "EPS_REL_Q16", 2.5e-4)
+    nat.timing_enable(True)
+    try:
+        _peaks_of(bl, dvol, g)
+        assert nat.timing_read()["zxpass"][1] == int(g["num_sigma"])
+    finally:
+        nat.timing_enable(False)
+    bl.release_buffers()
+
+
+def test_detect_batch_through_the_abi(gpu):
+    """``mmx_detect_batch`` driven from raw pointers, as a foreign binding would (no blob_log): two ragged uint16 blocks,
+    three scales; the table it leaves in pinned host memory holds every peak of the real scikit-image with bit-equal
+    float64 values; a too small table reports its overflow in the counters; bad arguments are refused."""
+    import ctypes
+    import torch
+    from magellanmapper_amd import _native as nat, blob_log as bl
+    from oracle import blob_log_oracle as blo
+    L = nat.lib()
+    g = load_golden("bloblog_u16_5sigma.npz")
+    vol = g["volume"]
+    dev = torch.device("cuda", 0)
+    dvol = bl.DeviceVolume(vol)
+    space = bl.ScaleSpace.make(float(g["min_sigma"]), float(g["max_sigma"]), 3)
+    origins, shapes = [(0, 0, 0), (3, 2, 5)], [vol.shape, (vol.shape[0] - 3, vol.shape[1] - 4, vol.shape[2] - 9)]
+    blocks, slot = bl._make_blocks(dvol, 0, origins, shapes)
+    d_blocks = bl._to_device_bytes(blocks, dev)
+    nb, ns = 2, 3
+    ws = torch.empty(-(-int(L.mmx_workspace_bytes(nb, slot, ns, 1)) // 4), dtype=torch.float32, device=dev)
+    d_w0, d_w2 = space.device_tables(dev)
+    cap = 20000
+    table = torch.zeros(cap * nat.CAND_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    count = torch.zeros(2, dtype=torch.int32, device=dev)
+    h_count = torch.zeros(2, dtype=torch.int32).pin_memory()
+    h_table = torch.zeros(cap * nat.CAND_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+    v32, vex = dvol.view(0, True), dvol.view(0, False)
+    thr, eps = float(g["threshold"]), 2.5e-4
+    ev = bl._NativeEvent()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def args(cap_now):
+        a = nat.DetectArgs()
+        a.vol32, a.vol_exact = ctypes.pointer(v32), ctypes.pointer(vex)
+        a.d_blocks, a.h_blocks, a.n_blocks, a.n_sigma, a.slot_elems = d_blocks.data_ptr(), blocks.ctypes.data, nb, ns, slot
+        a.h_w0, a.h_w2, a.d_w0, a.d_w2 = space.w0_tab.ctypes.data, space.w2_tab.ctypes.data, d_w0.data_ptr(), d_w2.data_ptr()
+        a.h_radius, a.h_norm = space.radii.ctypes.data, space.norms.ctypes.data
+        a.d_work, a.work_bytes, a.thr, a.eps = ws.data_ptr(), ws.numel() * 4, thr, eps
+        a.d_cands, a.cap, a.h_prefix, a.d_count = table.data_ptr(), cap_now, cap_now, count.data_ptr()
+        a.h_count, a.h_cands = h_count.data_ptr(), h_table.data_ptr()
+        a.zx_mode, a.zx_flags, a.store_f32, a.exact, a.expand = nat.MMX_ZX_AUTO, 0, 0, 1, 1
+        a.stream = a.tail_stream = a.pack_stream = stream
+        a.ev_done = ev.handle
+        return a
+    info = nat.DetectInfo()
+    nat.check(L.mmx_detect_batch(ctypes.byref(args(cap)), ctypes.byref(info)), "mmx_detect_batch")
+    ev.synchronize()
+    assert info.zx_path == nat.MMX_ZX_TILED_Q16 and info.mask_layout == nat.MMX_MASK_QUADS and info.n_pass_rounds == 1
+    assert 0 < info.q16_bound <= 5.2e-5
+    n_all, n_cands = (int(v) for v in h_count.numpy().view(np.uint32))
+    assert 0 < n_cands <= n_all <= cap
+    cands = h_table.numpy()[:n_all * nat.CAND_DTYPE.itemsize].view(nat.CAND_DTYPE)
+    for b, (o, shp) in enumerate(zip(origins, shapes)):
+        sub = vol[o[0]:o[0] + shp[0], o[1]:o[1] + shp[1], o[2]:o[2] + shp[2]]
+        cube = blo.log_cube(blo.img_as_float(sub), np.stack([space.sigmas] * 3, axis=1))
+        want = blo.peak_coords(cube, blo.peak_mask(cube, thr))       # the real rule on the float64 cube
+        mine = cands[:n_cands][cands["slot"][:n_cands] == b]
+        have = {(int(c["z"]), int(c["y"]), int(c["x"]), int(c["s"])): float(c["v64"]) for c in mine}
+        assert len(want) > 20
+        for z, y, x, s_ in want:
+            assert (z, y, x, s_) in have                              # every true peak was nominated ...
+            assert have[(z, y, x, s_)] == cube[z, y, x, s_]          # ... and re-scored bit for bit
+    # a table too small: the counters say how many entries there would have been
+    nat.check(L.mmx_detect_batch(ctypes.byref(args(8)), ctypes.byref(info)), "mmx_detect_batch")
+    ev.synchronize()
+    assert int(h_count.numpy().view(np.uint32)[0]) > 8
+    # refused: no workspace, a workspace too small
+    bad = args(cap)
+    bad.d_work = None
+    assert L.mmx_detect_batch(ctypes.byref(bad), ctypes.byref(info)) == 1
+    bad = args(cap)
+    bad.work_bytes = 1024
+    assert L.mmx_detect_batch(ctypes.byref(bad), ctypes.byref(info)) == 4      # MMX_ERR_WORKSPACE
+    torch.cuda.synchronize()
