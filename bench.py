@@ -396,6 +396,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     # per-kernel timing, as a caller's step does, and the per-kernel times come from extra steps after it.
     replayed = world == 1 and 0 < n_blocks <= bl.GRAPH_BLOCKS and bl.NATIVE_BATCH and not PROFILE["denoise_size"]
     nat.timing_enable(not replayed)
+    replays0 = bl.GRAPH_REPLAYS
     barrier()
     t0 = time.perf_counter()
     final = colocs = None
@@ -404,6 +405,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         final, colocs, stats = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    n_replays = bl.GRAPH_REPLAYS - replays0
     if replayed:
         extra = max(1, min(steps, 10))
         nat.timing_enable(True)
@@ -547,9 +549,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         "dtype": ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate") if PROFILE["denoise_size"] is None
                  else "f64 preprocessing; " + ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate"),
         "zx_path": zx_path, "host_path": bl.HOST_PATH,
-        "graph_replay": bool(replayed) or None,
+        "graph_replay": (n_replays if replayed else None),
         "graph_replay_note": None if not replayed else (
-            "the volume's single batch is replayed as a captured hipGraph in the timed region (no per-kernel events inside "
+            "graph_replay = batches of the timed region that were replayed from a captured hipGraph (no per-kernel events inside "
             "it); `kernels` and `roofline` come from extra steps run after it with the launches made one by one"),
         "y_kernel": (None if zx_path != nat.MMX_ZX_TILED_Q16 else
                      "y6_kernel (VALU taps)" if bl.ZX_FLAGS & nat.MMX_ZX_Y_VALU else "ym_kernel (matrix cores)"),

@@ -61,8 +61,9 @@ EPS_REL = float(os.environ.get("MMX_EPS_REL", 2e-5))
 #: the band for raw integer volumes, whose default kernels hand the Z+X results to the Y pass as 16-bit fixed point
 #: (``MMX_ZX_TILED_Q16``: error <= 5.2e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
 EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2.5e-4))
-#: the rounding error of the 16-bit intermediates for ANY sigma, relative to the value range (per
-#: call the library states the bound of the sigmas at hand: ``mmx_tiled_q16_error_bound``, <= this)
+#: the rounding error of the 16-bit intermediates for sigma >= 1, relative to the value range (per
+#: call the library states the bound of the sigmas at hand, ``mmx_tiled_q16_error_bound``: <= this from radius 4 on, up to
+#: 5.7e-5 for the few-tap kernels below -- whose batches then keep float32 intermediates under ``MMX_ZX_AUTO``)
 Q16_BOUND_ANY_SIGMA = 5.2e-5
 if 0.0 < EPS_REL_Q16 < 4.0 * Q16_BOUND_ANY_SIGMA:
     # exactness rests on the band covering the error fourfold: an environment variable may widen it or switch the
@@ -76,6 +77,8 @@ NATIVE_BATCH = os.environ.get("MMX_NATIVE_BATCH", "1") != "0"
 #: batches of at most this many blocks that come back with the very same arguments (a small volume detected step
 #: after step) are captured as a hipGraph and replayed with one launch (``MMX_GRAPH_BLOCKS=0``: never)
 GRAPH_BLOCKS = int(os.environ.get("MMX_GRAPH_BLOCKS", "8"))
+#: batches replayed from a captured graph so far (bench.py reports the count of its timed region)
+GRAPH_REPLAYS = 0
 #: bound of the 16-bit intermediates of the most recent batch that used them (value units), else 0: bench.py prints it
 LAST_Q16_BOUND = 0.0
 #: nomination band (value units) of that batch
@@ -490,6 +493,7 @@ class _Buffers:
         self.pack_stream = torch.cuda.Stream(device=dev)
         self.native_events = []            # per candidate-table slot: (workspace read, batch done)
         self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
+        self.graph_stream = None           # where they run when the caller is on the (uncapturable) default stream
         self.slots(2)
 
     def slots(self, n: int):
@@ -1059,8 +1063,30 @@ def _launch_batch(L, a, info, bufs: _Buffers, nb: int, blocks, space, vol32, vol
     volume detected step after step: same buffers, geometry, scales, band), the replay of its captured hipGraph: one
     launch instead of a dozen.  The second sighting of a key captures, later ones replay; a capture is refused while
     per-kernel timing is on (its events cannot live inside one) and the plain call is made instead."""
-    if not (0 < nb <= GRAPH_BLOCKS) or a.ev_work_free or not a.stream:
+    if not (0 < nb <= GRAPH_BLOCKS) or a.ev_work_free:
         return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))
+    if L.mmx_timing_is_enabled():                   # (a replay would hide the kernels from the per-kernel timing, and
+        return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))      # a capture cannot hold its events)
+    caller = None
+    if not a.stream:
+        # the caller works on the default stream, which cannot be captured: the batch runs on a stream of this module's
+        # instead, ordered after what the caller has queued and before what it queues next
+        caller = torch.cuda.current_stream()
+        if bufs.graph_stream is None:
+            bufs.graph_stream = torch.cuda.Stream(device=bufs.dev)
+        gs = bufs.graph_stream
+        origin = a.stream
+        for name in ("stream", "tail_stream", "pack_stream"):
+            if getattr(a, name) == origin:
+                setattr(a, name, gs.cuda_stream)
+        gs.wait_stream(caller)
+    rc = _launch_batch_graph(L, a, info, bufs, blocks, space, vol32, vol_exact)
+    if caller is not None:
+        caller.wait_stream(bufs.graph_stream)
+    return rc
+
+
+def _launch_batch_graph(L, a, info, bufs: _Buffers, blocks, space, vol32, vol_exact) -> int:
     # everything a node of the graph would freeze (the two volume records by content: their addresses change per call)
     key = (bytes(vol32), bytes(vol_exact), blocks.tobytes(), space.sigmas.tobytes(), a.d_blocks, a.slot_elems, a.d_w0,
            a.d_w2, a.d_work, a.work_bytes, a.thr, a.eps, a.d_cands, a.cap, a.h_prefix, a.d_count, a.h_count, a.h_cands,
@@ -1071,8 +1097,6 @@ def _launch_batch(L, a, info, bufs: _Buffers, nb: int, blocks, space, vol32, vol
             bufs.drop_graphs()
         bufs.graphs[key] = ()
         return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))
-    if L.mmx_timing_is_enabled():                   # (a replay would hide the kernels from the per-kernel timing, and
-        return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))      # a capture cannot hold its events)
     if not hit:
         # second sighting: capture (this only records the launches; the replay below runs them)
         graph = ctypes.c_void_p()
@@ -1081,6 +1105,8 @@ def _launch_batch(L, a, info, bufs: _Buffers, nb: int, blocks, space, vol32, vol
             return rc
         hit = bufs.graphs[key] = (graph.value, nat.DetectInfo.from_buffer_copy(info), (blocks, space))
     graph, saved, _ = hit
+    global GRAPH_REPLAYS
+    GRAPH_REPLAYS += 1
     ctypes.memmove(ctypes.byref(info), ctypes.byref(saved), ctypes.sizeof(info))
     rc = L.mmx_graph_launch(graph, a.stream, a.ev_done, None)
     if rc == 0 and a.ev_work_read:

@@ -155,10 +155,11 @@ class _TableArena:
         n = self.n
         if n == 0:
             return True
-        pick = np.append(np.arange(0, n, 61), n - 1)
-        return bool(np.array_equal(self.store[pick, :3], self.zyx[pick]) and
-                    np.array_equal(self.store[pick, 7:10], self.abs[pick]) and
-                    np.array_equal(self.store[pick, self.n_cols:], self.tag[pick]))
+        st, zyx, ab, tg = self.store[:n], self.zyx[:n], self.abs[:n], self.tag[:n]
+        nc = self.n_cols
+        return bool((st[::61, :3] == zyx[::61]).all() and (st[::61, 7:10] == ab[::61]).all() and
+                    (st[::61, nc:] == tg[::61]).all() and (st[n - 1, :3] == zyx[n - 1]).all() and
+                    (st[n - 1, 7:10] == ab[n - 1]).all() and (st[n - 1, nc:] == tg[n - 1]).all())
 
 
 class _ArenaSink:
@@ -497,9 +498,8 @@ class StackDetector:
         tables = []
         n_extra = (img.shape[3] if len(img.shape) > 3 else 0) if coloc else 0
         hint, cls.prune_hint = cls.prune_hint, None
-        regular = hint is not None and all(
-            StackPruner._axis_geometry(a, shape3, hint[0], hint[1] if hint[2] is None else hint[2], sub_roi_slices,
-                                       sub_rois_offsets)[1] for a in range(3) if sub_rois_offsets.shape[a] > 1)
+        regular = hint is not None and StackPruner._geometry(
+            shape3, hint[0], hint[1], hint[1] if hint[2] is None else hint[2], sub_roi_slices, sub_rois_offsets)[1]
         # several ranks: with the pruning planned (plan_pruning) and a regular block geometry every rank keeps its
         # own tables and the pruning itself is distributed; otherwise the tables are gathered on rank 0
         local_only = dist.world_size() > 1 and regular and os.environ.get("MMX_DIST_PRUNE", "1") != "0"
@@ -968,6 +968,28 @@ class StackPruner:
             blobs_all.append(blobs)
         return np.vstack(blobs_all)[:, :-3], ratios_all
 
+    #: the last few block geometries: (ids of the slice / offset arrays, shape, overlap, tol, padding) -> (plan, regular).
+    #: A stack detected again and again (a step loop, channel groups) hands over the very same ``Blocks`` arrays; the
+    #: entry keeps them alive, so an id cannot come back as another array.  (Editing a ``Blocks`` array in place between
+    #: calls is not supported -- the reference builds them once per call and never writes to them.)
+    _geometry_cache: dict = {}
+
+    @classmethod
+    def _geometry(cls, shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets):
+        """``(plan, regular)``: :meth:`_axis_plan` and whether every axis with more than one section is tiled by the
+        reference's regions (:meth:`_axis_geometry`), remembered per block geometry."""
+        key = (id(sub_roi_slices), id(sub_rois_offsets), tuple(int(v) for v in shape3),
+               np.asarray(overlap).tobytes(), np.asarray(tol).tobytes(), np.asarray(overlap_padding).tobytes())
+        hit = cls._geometry_cache.get(key)
+        if hit is None:
+            regular = all(cls._axis_geometry(a, shape3, overlap, overlap_padding, sub_roi_slices, sub_rois_offsets)[1]
+                          for a in range(3) if sub_rois_offsets.shape[a] > 1)
+            plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets) if regular else None
+            if len(cls._geometry_cache) >= 8:
+                cls._geometry_cache.clear()
+            hit = cls._geometry_cache[key] = (plan, regular, sub_roi_slices, sub_rois_offsets)
+        return hit[0], hit[1]
+
     @classmethod
     def _axis_plan(cls, shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets):
         """The constants of the three passes (regular geometry): per axis ``None`` (one section: no pass) or the
@@ -1290,7 +1312,7 @@ class StackPruner:
             out, counts = cls._prune_distributed(seg_rois, shape3, plan, sub_roi_slices, channels)
             if out is None:
                 return None, None
-            return out, pd.DataFrame(cls._ratios_from_counts(counts, plan))
+            return out, cls._ratio_frame(cls._ratios_from_counts(counts, plan))
         arena = getattr(seg_rois, "arena", None)
         if arena is not None and not arena.intact(seg_rois):
             arena = None
@@ -1311,8 +1333,8 @@ class StackPruner:
         coord_last = tuple(np.subtract(grid, 1))
         ratio_cols = ("blobs", "ratio_pruning", "ratio_adjacent")
         ratios_all = {}
-        if not all(cls._axis_geometry(a, shape3, overlap, overlap_padding, sub_roi_slices, sub_rois_offsets)[1]
-                   for a in range(3) if sub_rois_offsets.shape[a] > 1):
+        plan, regular = cls._geometry(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
+        if not regular:
             if early is not None:
                 early.cancel()
             out, ratios_all = cls._prune_blobs_general(merged, shape3, overlap, tol, sub_roi_slices,
@@ -1321,7 +1343,6 @@ class StackPruner:
         ncol = merged.shape[1]
         detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
         abs_inds = detector.Blobs._get_abs_inds()
-        plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
         # regions of this very call finished while the GPU was still detecting (StackDetector.plan_pruning)
         if early is not None and arena is not None and early.matches(arena, plan, channels):
             out, counts = early.finish(abs_inds)
@@ -1348,6 +1369,14 @@ class StackPruner:
             _lap("three axis passes")
             out = cls._take_rows(merged, rows, abs_cur, abs_inds)
             _lap("gather of the output table")
-        df = pd.DataFrame(cls._ratios_from_counts(counts, plan))
+        df = cls._ratio_frame(cls._ratios_from_counts(counts, plan))
         _lap("ratio frame")
         return out, df
+
+    @staticmethod
+    def _ratio_frame(ratios):
+        """The pruning-ratio data frame (reference :836-838, 859) from the column lists, without the per-element type
+        inference of the dict-of-lists constructor: half the time of a small stack's whole pruning step."""
+        import pandas as pd
+        cols = {k: np.asarray(v, dtype=np.int64 if k == "blobs" else np.float64) for k, v in ratios.items()}
+        return pd.DataFrame(cols, copy=False)
