@@ -611,9 +611,9 @@ def test_q16_error_bound_holds_across_value_ranges(gpu, case, monkeypatch):
         assert err < bound * vmax, (case, R, err, bound * vmax)
         # what the band of 2.5e-4 covers fourfold (the few-tap kernels of sigma < 1 carry a little more, and AUTO then
         # keeps float32 intermediates for them)
-        assert bound <= (bl.Q16_BOUND_ANY_SIGMA if R >= 4 else 6e-5), (R, bound)
+        assert bound <= (bl.Q16_BOUND_ANY_SIGMA if R >= 4 else 7.6e-5), (R, bound)
         worst = max(worst, err / vmax)
-    assert worst < 6e-5                # the north star's LoG tolerance of 1e-4, relative to the value scale, with room
+    assert worst < 7.6e-5              # the north star's LoG tolerance of 1e-4, relative to the value scale, with room
 
 
 def test_block_shape_and_dtype_sweep_matches_oracle(gpu):

@@ -698,6 +698,20 @@ def test_q16_error_bound_is_a_function_of_the_weights():
         assert abs(got - want) < 1e-12, sigma
         assert 3.5e-5 < got < 5.5e-5 and 4 * got <= bl.EPS_REL_Q16, (sigma, got)
     assert lib.mmx_tiled_q16_error_bound(None, None, 3, 1.0) < 0
+    # every radius the fast kernels take, sigma swept across each: the constant the host quotes holds from radius 4 on,
+    # and where the bound is larger (radii 1..3) four times it no longer fits the band: AUTO keeps float32 intermediates
+    worst = {}
+    for R in range(1, nat.MMX_MAX_RADIUS_FAST + 1):
+        for sigma in np.linspace(max(0.06, (R - 0.5) / 4.0), (R + 0.5) / 4.0, 40):
+            if k1.kernel_radius(sigma) != R:
+                continue
+            w0, w2 = k1.gaussian_half_kernel(sigma, 0, R), k1.gaussian_half_kernel(sigma, 2, R)
+            b = lib.mmx_tiled_q16_error_bound(nat.as_double_ptr(w0), nat.as_double_ptr(w2), R, sigma * sigma)
+            worst[R] = max(worst.get(R, 0.0), b)
+    assert len(worst) == nat.MMX_MAX_RADIUS_FAST
+    assert all(b <= bl.Q16_BOUND_ANY_SIGMA for R, b in worst.items() if R >= 4), worst
+    assert all(4 * b <= bl.EPS_REL_Q16 for R, b in worst.items() if R >= 4)
+    assert max(worst.values()) < 8e-5
 
 
 # ---------------------------------------------------------------- native per-batch host work (mmx_host.cpp)
