@@ -560,6 +560,23 @@ int mmx_host_prune_parts(const int32_t* zyx, const int32_t* tag, const double* a
                          const int32_t tol[3], const double* const nxt_lo[3], const double* const nxt_hi[3],
                          int64_t n_keys, int64_t* out_ids, int64_t* out_keys, double* out_abs, int64_t* out_n,
                          int64_t* n_slab, int64_t* n_after, int64_t* n_next, int64_t stat_ld);
+/* the distributed pruning's table plumbing (stack_detect.StackPruner._prune_distributed), native:
+ * mmx_host_rows_in_boxes: the rows of a rank's table inside any of the other ranks' (widened) boxes, ten float64 values a
+ *   row (zyx, block tag, abs zyx, channel) -- the payload of the first exchange; *out_n keeps counting past cap;
+ * mmx_host_append_rows: the rows of a received payload inside this rank's box, appended to its compact columns from row
+ *   `at` on (MMX_ERR_WORKSPACE when they do not fit `cap` rows; *out_n says how many there are);
+ * mmx_host_emit_survivors: rows ids[i] of the merged table with their averaged abs columns and their sort key as an
+ *   extra last column -- the payload of the second exchange.
+ * (mmx_host_prune_parts takes its parts in LOCAL order: a rank lists the halo rows of earlier ranks, its own rows, the
+ *  halo rows of later ranks, wherever they sit in its arrays.) */
+int mmx_host_rows_in_boxes(const int32_t* zyx, const int32_t* tag, const double* abs_zyx, const double* chan,
+                           int64_t chan_ld, int64_t n, const int32_t* box_lo, const int32_t* box_hi, int n_boxes,
+                           double* out, int64_t cap, int64_t* out_n);
+int mmx_host_append_rows(const double* payload, int64_t n, const int32_t lo[3], const int32_t hi[3], int32_t* zyx,
+                         int32_t* tag, double* abs_zyx, double* chan, int64_t chan_ld, int64_t at, int64_t cap,
+                         int64_t* out_n);
+int mmx_host_emit_survivors(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
+                            int64_t n_cols, const double* abs_rows, const int32_t abs_cols[3], double* out);
 int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
                           int64_t n_cols, double* out);
 int mmx_host_gather_by_key(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,

@@ -495,6 +495,7 @@ class _Buffers:
         self.native_events = []            # per candidate-table slot: (workspace read, batch done)
         self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
         self.graph_stream = None           # where they run when the caller is on the (uncapturable) default stream
+        self.plans = {}                    # batch plans + uploaded block tables of recent (block lists, volume layout)
         self.slots(2)
 
     def slots(self, n: int):
@@ -773,8 +774,22 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)):
         eps = EPS_REL_Q16 * vscale
     d_w0, d_w2 = space.device_tables(dvol.tensor.device)
-    batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
-                           0 if pre is None else pre.bytes_per_voxel())
+    # the batches and their block tables on the device: remembered for the very same block lists, volume layout and
+    # budget (a stack detected step after step hands over the SAME lists, stack_detect.StackDetector._block_extents) --
+    # a millisecond of planning, record building and upload per step otherwise, before the first kernel can start
+    plan_key = None
+    planned = None
+    if pre is None:
+        t_ = dvol.tensor
+        # (block records hold element offsets, not addresses: any volume of this layout can use them)
+        plan_key = (id(origins), id(shapes), len(shapes), tuple(t_.stride()), tuple(t_.shape), str(t_.dtype),
+                    len(space.sigmas), int(budget_bytes), _MAX_BATCH, os.environ.get("MMX_RAMP"))
+        planned = bufs.plans.get(plan_key)
+    if planned is not None:
+        batches = planned[0]
+    else:
+        batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
+                               0 if pre is None else pre.bytes_per_voxel())
     exact = bool(True if exact_values is None else exact_values)
     n_b = len(batches)
     # How far the GPU queue runs ahead of the host.  Raw volumes: EVERY batch is enqueued before the host looks at
@@ -785,7 +800,9 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     ahead = n_b if pre is None else PRE_AHEAD
     bufs.slots(ahead + 1)
     prepared = None
-    if pre is None:
+    if planned is not None:
+        prepared = planned[1]
+    elif pre is None:
         # block tables of every batch go to the device BEFORE the first kernel: a pageable host -> device copy
         # waits for everything queued on the stream before it
         prepared = [_make_blocks(dvol, channel, [origins[i] for i in b], [shapes[i] for i in b]) for b in batches]
@@ -795,7 +812,10 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                                       dvol.tensor.device)
             offs = np.concatenate([[0], np.cumsum(sizes)])
             prepared = [(blk, slot, allrec[int(offs[i]):int(offs[i + 1])]) for i, (blk, slot) in enumerate(prepared)]
-        # ... and the shared workspace has its final size before anything is queued on it
+        if len(bufs.plans) >= 8:
+            bufs.plans.clear()
+        bufs.plans[plan_key] = (batches, prepared, origins, shapes)     # (the lists stay alive: their ids are the key)
+    if pre is None:        # ... and the shared workspace has its final size before anything is queued on it
         if prepared:
             need = max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, len(space.sigmas), 1)) // 4)
                        for blk, slot, _ in prepared)

@@ -425,12 +425,15 @@ extern "C" int mmx_host_prune_parts(const int32_t* zyx, const int32_t* tag, cons
         !n_sections || !bounds || !last_end || !tol || !nxt_lo || !nxt_hi || !out_n || !n_slab || !n_after || !n_next)
         return MMX_ERR_ARG;
     // ---- the local table: ids of the merged table's rows, own rows between the neighbours' rows within reach
+    // (the parts come in the order of the LOCAL table -- for regions of one arena that is ascending row order; a rank's
+    //  table keeps the halo rows it received from other ranks behind its own rows and lists them before / after)
     std::vector<int64_t> ids;
-    int64_t own_lo = 0, own_hi = 0, prev_end = -1;
+    int64_t own_lo = 0, own_hi = 0;
     for (int p = 0; p < n_parts; ++p) {
         const int64_t a = parts[2 * p], b = parts[2 * p + 1];
-        if (a < 0 || b < a || a < prev_end) return MMX_ERR_ARG;
-        prev_end = b;
+        if (a < 0 || b < a) return MMX_ERR_ARG;
+        for (int q = 0; q < p; ++q)          // no row twice
+            if (a < parts[2 * q + 1] && parts[2 * q] < b && b > a && parts[2 * q + 1] > parts[2 * q]) return MMX_ERR_ARG;
         if (b > a && (!zyx || !tag || !abs_zyx)) return MMX_ERR_ARG;
         if (p == own_part) {
             own_lo = (int64_t)ids.size();
@@ -526,6 +529,89 @@ extern "C" int mmx_host_gather_by_key(const double* table, int64_t ld, const int
             double* o = out + dst[(size_t)i] * n_cols;
             std::memcpy(o, table + ids[i] * ld, (size_t)n_cols * sizeof(double));
             for (int a = 0; a < 3; ++a) o[abs_cols[a]] = abs_rows[3 * i + a];
+        }
+    });
+    return MMX_OK;
+}
+
+// Rows of a table that lie inside ANY of `n_boxes` boxes [lo, hi): what a rank sends to the ranks whose blocks its
+// rows can influence (the distributed pruning's first exchange), ten values a row -- detection coordinates, block
+// tags, absolute coordinates, channel.  out: [cap][10] float64; *out_n keeps counting past cap.
+extern "C" int mmx_host_rows_in_boxes(const int32_t* zyx, const int32_t* tag, const double* abs_zyx, const double* chan,
+                                      int64_t chan_ld, int64_t n, const int32_t* box_lo, const int32_t* box_hi,
+                                      int n_boxes, double* out, int64_t cap, int64_t* out_n)
+{
+    if (n < 0 || n_boxes < 0 || !out_n || (n && (!zyx || !tag || !abs_zyx || !chan)) || (n_boxes && (!box_lo || !box_hi)) ||
+        (cap && !out) || cap < 0)
+        return MMX_ERR_ARG;
+    int64_t k = 0;
+    for (int64_t i = 0; i < n && n_boxes; ++i) {
+        const int32_t* c = zyx + 3 * i;
+        bool in = false;
+        for (int b = 0; b < n_boxes && !in; ++b) {
+            const int32_t* lo = box_lo + 3 * b; const int32_t* hi = box_hi + 3 * b;
+            in = c[0] >= lo[0] && c[0] < hi[0] && c[1] >= lo[1] && c[1] < hi[1] && c[2] >= lo[2] && c[2] < hi[2];
+        }
+        if (!in) continue;
+        if (k < cap) {
+            double* o = out + 10 * k;
+            o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
+            o[3] = tag[3 * i]; o[4] = tag[3 * i + 1]; o[5] = tag[3 * i + 2];
+            o[6] = abs_zyx[3 * i]; o[7] = abs_zyx[3 * i + 1]; o[8] = abs_zyx[3 * i + 2];
+            o[9] = chan[i * chan_ld];
+        }
+        ++k;
+    }
+    *out_n = k;
+    return MMX_OK;
+}
+
+// The reverse on the receiving rank: rows of such a payload inside the box [lo, hi) appended to the compact columns
+// of a table from row `at` on (capacity `cap` rows): zyx / tag as int32, abs as float64, the channel into `chan`.
+extern "C" int mmx_host_append_rows(const double* payload, int64_t n, const int32_t lo[3], const int32_t hi[3],
+                                    int32_t* zyx, int32_t* tag, double* abs_zyx, double* chan, int64_t chan_ld,
+                                    int64_t at, int64_t cap, int64_t* out_n)
+{
+    if (n < 0 || at < 0 || cap < at || !lo || !hi || !out_n || (n && (!payload || !zyx || !tag || !abs_zyx || !chan)))
+        return MMX_ERR_ARG;
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double* r = payload + 10 * i;
+        const int32_t z = (int32_t)r[0], y = (int32_t)r[1], x = (int32_t)r[2];
+        if (z < lo[0] || z >= hi[0] || y < lo[1] || y >= hi[1] || x < lo[2] || x >= hi[2]) continue;
+        const int64_t row = at + k;
+        if (row < cap) {
+            zyx[3 * row] = z; zyx[3 * row + 1] = y; zyx[3 * row + 2] = x;
+            tag[3 * row] = (int32_t)r[3]; tag[3 * row + 1] = (int32_t)r[4]; tag[3 * row + 2] = (int32_t)r[5];
+            abs_zyx[3 * row] = r[6]; abs_zyx[3 * row + 1] = r[7]; abs_zyx[3 * row + 2] = r[8];
+            chan[row * chan_ld] = r[9];
+        }
+        ++k;
+    }
+    *out_n = k;
+    return at + k <= cap ? MMX_OK : MMX_ERR_WORKSPACE;
+}
+
+// Survivors of a rank in the form the second exchange carries: row ids[i] of `table` (its first n_cols columns), the
+// three abs columns replaced by abs_rows[i], the sort key appended as column n_cols -- in the order given.
+//   out : [n][n_cols + 1]
+extern "C" int mmx_host_emit_survivors(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys,
+                                       int64_t n, int64_t n_cols, const double* abs_rows, const int32_t abs_cols[3],
+                                       double* out)
+{
+    if (n < 0 || n_cols < 1 || n_cols > ld || !abs_cols || (n && (!table || !ids || !keys || !out || !abs_rows)))
+        return MMX_ERR_ARG;
+    for (int a = 0; a < 3; ++a)
+        if (abs_cols[a] < 0 || abs_cols[a] >= n_cols) return MMX_ERR_ARG;
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[i] < 0) return MMX_ERR_ARG;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            double* o = out + i * (n_cols + 1);
+            std::memcpy(o, table + ids[i] * ld, (size_t)n_cols * sizeof(double));
+            for (int a = 0; a < 3; ++a) o[abs_cols[a]] = abs_rows[3 * i + a];
+            o[n_cols] = (double)keys[i];
         }
     });
     return MMX_OK;

@@ -462,6 +462,38 @@ class StackDetector:
             detector.Blobs.shift_blob_abs_coords(segments, offset)
         return coord, segments
 
+    _extent_cache: dict = {}
+
+    @classmethod
+    def _block_extents(cls, sub_roi_slices, shape3, mine):
+        """``(origins, shapes)`` of the blocks ``mine`` (indices in C order of the grid): every slice resolved against the
+        ROI with Python's rules.  Remembered per slice array and share (the entry keeps the array alive): a stack
+        detected step after step pays the 256-block loop once, and the device pipeline recognises the SAME lists and
+        reuses the block tables it uploaded for them."""
+        key = (id(sub_roi_slices), tuple(int(v) for v in shape3), len(mine), mine[0] if mine else -1,
+               mine[-1] if mine else -1)
+        hit = cls._extent_cache.get(key)
+        if hit is not None:
+            return hit[0], hit[1]
+        origins, shapes = [], []
+        n0, n1, n2 = (int(v) for v in shape3)
+        flat = sub_roi_slices.reshape(-1)            # (C order: the order of np.ndindex)
+        for i in mine:
+            z, y, x = flat[i]
+            a0, a1, a2, b0, b1, b2 = z.start, y.start, x.start, z.stop, y.stop, x.stop
+            if (a0 is None or a1 is None or a2 is None or b0 is None or b1 is None or b2 is None
+                    or a0 < 0 or a1 < 0 or a2 < 0 or b0 < 0 or b1 < 0 or b2 < 0 or b0 > n0 or b1 > n1 or b2 > n2
+                    or z.step not in (None, 1) or y.step not in (None, 1) or x.step not in (None, 1)):
+                a0, b0, _ = z.indices(n0)             # (open-ended or negative bounds: Python's rules)
+                a1, b1, _ = y.indices(n1)
+                a2, b2, _ = x.indices(n2)
+            origins.append((int(a0), int(a1), int(a2)))
+            shapes.append((int(b0 - a0), int(b1 - a1), int(b2 - a2)))
+        if len(cls._extent_cache) >= 8:
+            cls._extent_cache.clear()
+        cls._extent_cache[key] = (origins, shapes, sub_roi_slices)
+        return origins, shapes
+
     @classmethod
     def detect_blobs_sub_rois(cls, img5d, img, sub_roi_slices, sub_rois_offsets,
                               denoise_max_shape, exclude_border, coloc, channel):
@@ -480,20 +512,7 @@ class StackDetector:
         coords = list(np.ndindex(*grid))
         mine = dist.my_share(len(coords))            # all of them without torch.distributed
         shape3 = img.shape[:3]
-        origins, shapes = [], []
-        n0, n1, n2 = (int(v) for v in shape3)
-        flat = sub_roi_slices.reshape(-1)            # (C order: the order of np.ndindex)
-        for i in mine:
-            z, y, x = flat[i]
-            a0, a1, a2, b0, b1, b2 = z.start, y.start, x.start, z.stop, y.stop, x.stop
-            if (a0 is None or a1 is None or a2 is None or b0 is None or b1 is None or b2 is None
-                    or a0 < 0 or a1 < 0 or a2 < 0 or b0 < 0 or b1 < 0 or b2 < 0 or b0 > n0 or b1 > n1 or b2 > n2
-                    or z.step not in (None, 1) or y.step not in (None, 1) or x.step not in (None, 1)):
-                a0, b0, _ = z.indices(n0)             # (open-ended or negative bounds: Python's rules)
-                a1, b1, _ = y.indices(n1)
-                a2, b2, _ = x.indices(n2)
-            origins.append((int(a0), int(a1), int(a2)))
-            shapes.append((int(b0 - a0), int(b1 - a1), int(b2 - a2)))
+        origins, shapes = cls._block_extents(sub_roi_slices, shape3, mine)
         stats = bl.BatchStats()
         tables = []
         n_extra = (img.shape[3] if len(img.shape) > 3 else 0) if coloc else 0
@@ -1195,11 +1214,18 @@ class StackPruner:
         _lap("counts all_reduce")
         return out, counts
 
-    @staticmethod
-    def _rank_boxes(n_blocks, world, coords, sub_roi_slices, shape3, reach):
+    _rank_box_cache: dict = {}
+
+    @classmethod
+    def _rank_boxes(cls, n_blocks, world, coords, sub_roi_slices, shape3, reach):
         """The extent of every rank's blocks, widened by the reach of the pruning (``None`` for a rank without
-        blocks)."""
+        blocks); remembered per block geometry like :meth:`_geometry` (256 blocks: a millisecond of slice arithmetic
+        per call otherwise)."""
         from . import dist
+        key = (id(sub_roi_slices), int(n_blocks), int(world), tuple(int(v) for v in shape3), np.asarray(reach).tobytes())
+        hit = cls._rank_box_cache.get(key)
+        if hit is not None:
+            return hit[0]
         boxes = []
         for q in range(world):
             lo_b, hi_b = dist.share_bounds(n_blocks, q, world)
@@ -1209,71 +1235,98 @@ class StackPruner:
             ext = np.array([[s.indices(m)[:2] for s, m in zip(sub_roi_slices[coords[i]], shape3)]
                             for i in range(lo_b, hi_b)])
             boxes.append((ext[:, :, 0].min(axis=0) - reach, ext[:, :, 1].max(axis=0) + reach))
+        if len(cls._rank_box_cache) >= 8:
+            cls._rank_box_cache.clear()
+        cls._rank_box_cache[key] = (boxes, sub_roi_slices)
         return boxes
 
     @staticmethod
     def _seam_rows(ar, boxes, me, reach):
         """The rows of this rank's arena that lie within reach of another rank's blocks, ten values a row:
-        detection coordinates, block tags, absolute coordinates, channel."""
+        detection coordinates, block tags, absolute coordinates, channel (``mmx_host_rows_in_boxes``)."""
         n = ar.n
-        zyx, tags, abs_own = ar.zyx[:n], ar.tag[:n], ar.abs[:n]
-        chan_own = ar.store[:n, 6]
-        near = np.zeros(n, dtype=bool)
         own = boxes[me]
+        near = []
         for q, box in enumerate(boxes):
             if q == me or box is None or own is None or not n:
                 continue
             # (both boxes carry the reach: a rank whose blocks are further away than twice that cannot hold a row in it)
             if np.any(own[0] + reach >= box[1]) or np.any(own[1] - reach <= box[0]):
                 continue
-            near |= ((zyx[:, 0] >= box[0][0]) & (zyx[:, 0] < box[1][0]) & (zyx[:, 1] >= box[0][1]) &
-                     (zyx[:, 1] < box[1][1]) & (zyx[:, 2] >= box[0][2]) & (zyx[:, 2] < box[1][2]))
-        sel = np.flatnonzero(near)
-        payload = np.empty((len(sel), 10))
-        payload[:, 0:3], payload[:, 3:6] = zyx[sel], tags[sel]
-        payload[:, 6:9], payload[:, 9] = abs_own[sel], chan_own[sel]
-        return payload
+            near.append(box)
+        if not near:
+            return np.empty((0, 10))
+        lo = np.ascontiguousarray([b[0] for b in near], dtype=np.int32)
+        hi = np.ascontiguousarray([b[1] for b in near], dtype=np.int32)
+        payload = np.empty((n, 10))
+        k = ctypes.c_int64(0)
+        nat.check(nat.lib().mmx_host_rows_in_boxes(
+            ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data, ar.store.ctypes.data + 6 * 8,
+            ar.store.strides[0] // 8, n, lo.ctypes.data, hi.ctypes.data, len(near), payload.ctypes.data, n,
+            ctypes.byref(k)), "mmx_host_rows_in_boxes")
+        return payload[:k.value]
 
     @classmethod
     def _prune_own_rows(cls, ar, parts, mine_box, me, channels, plan, abs_inds, _lap=lambda what: None):
         """The three passes on this rank's rows between the seam rows received from the ranks before and after it:
-        ``(own survivors in their final form + one column with the key that places them, statistics)``."""
+        ``(own survivors in their final form + one column with the key that places them, statistics)``.
+
+        The received rows are appended to the arena's compact columns behind the rank's own rows
+        (``mmx_host_append_rows``) and ``mmx_host_prune_parts`` is told the order of the local table -- earlier
+        ranks' halo, own rows, later ranks' halo: what the whole-table passes would see of them -- so that no table is
+        put together in Python; the survivors leave through ``mmx_host_emit_survivors``."""
+        lib = nat.lib()
         n = ar.n
         ncol = ar.store.shape[1]
-        zyx, tags, abs_own = ar.zyx[:n], ar.tag[:n], ar.abs[:n]
-        chan_own = ar.store[:n, 6]
-        before, after = [], []
-        for q, part in enumerate(parts):
-            if q == me or mine_box is None or not len(part):
-                continue
-            keep = _rows_within(part[:, :3], mine_box[0], mine_box[1])
-            (before if q < me else after).append(part[keep])
-        halo_b = np.concatenate(before) if before else np.zeros((0, 10))
-        halo_a = np.concatenate(after) if after else np.zeros((0, 10))
-        zyx_l = np.ascontiguousarray(np.concatenate((halo_b[:, 0:3], zyx, halo_a[:, 0:3])), dtype=np.int32)
-        tag_l = np.ascontiguousarray(np.concatenate((halo_b[:, 3:6], tags, halo_a[:, 3:6])), dtype=np.int32)
-        abs_l = np.ascontiguousarray(np.concatenate((halo_b[:, 6:9], abs_own, halo_a[:, 6:9])), dtype=np.float64)
-        chan_l = np.concatenate((halo_b[:, 9], chan_own, halo_a[:, 9]))
-        own_lo = len(halo_b)
+        halo = [(q, p) for q, p in enumerate(parts) if q != me and mine_box is not None and len(p)]
+        room = n + sum(len(p) for _, p in halo)
+        if room > ar.cap:
+            ar._grow(room)
+        lo = np.ascontiguousarray(mine_box[0] if mine_box is not None else (0, 0, 0), dtype=np.int32)
+        hi = np.ascontiguousarray(mine_box[1] if mine_box is not None else (0, 0, 0), dtype=np.int32)
+        lo_p, hi_p = (v.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) for v in (lo, hi))
+        at = n
+        edges = [n]
+        for side in (lambda q: q < me, lambda q: q > me):
+            for q, p in halo:
+                if not side(q):
+                    continue
+                p = np.ascontiguousarray(p, dtype=np.float64)
+                k = ctypes.c_int64(0)
+                nat.check(lib.mmx_host_append_rows(
+                    p.ctypes.data, len(p), lo_p, hi_p, ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data,
+                    ar.store.ctypes.data + 6 * 8, ar.store.strides[0] // 8, at, ar.cap, ctypes.byref(k)),
+                    "mmx_host_append_rows")
+                at += k.value
+            edges.append(at)
+        # local order: halo of the ranks before, own rows, halo of the ranks after
+        local = np.array([[edges[0], edges[1]], [0, n], [edges[1], edges[2]]], dtype=np.int64)
         _lap("own + halo tables")
-        # (need_keys: a rank that received no halo rows -- nobody else has blobs, or none near the seam -- holds
-        #  "the whole table" and would otherwise take the keyless single-process shortcut)
-        rows, keys, counts = cls._prune_table(zyx_l, tag_l, abs_l, chan_l, own_lo, own_lo + n, channels, plan,
-                                              need_keys=True)
+        ids = np.empty(max(1, n), dtype=np.int64)
+        keys = np.empty(max(1, n), dtype=np.int64)
+        abs_rows = np.empty((max(1, n), 3))
+        out_n = ctypes.c_int64(0)
+        ld = plan["max_slabs"]
+        stat = np.zeros((3, len(channels), 3, ld), dtype=np.int64)        # [kind][channel][axis][slab]
+        n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi = plan["c_args"]
+        chans = np.ascontiguousarray(channels, dtype=np.float64)
+        # (every row takes part that lies inside the box: append_rows has filtered the halo already, the own rows are
+        #  the own part, which is never filtered)
+        nat.check(lib.mmx_host_prune_parts(
+            ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data, ar.store.ctypes.data + 6 * 8,
+            ar.store.strides[0] // 8, local.ctypes.data, 3, 1, lo_p, hi_p, chans.ctypes.data, len(channels),
+            n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi, plan["n_keys"], ids.ctypes.data, keys.ctypes.data,
+            abs_rows.ctypes.data, ctypes.byref(out_n), stat[0].ctypes.data, stat[1].ctypes.data, stat[2].ctypes.data,
+            ld), "mmx_host_prune_parts")
+        k = out_n.value
+        counts = np.ascontiguousarray(np.moveaxis(stat, 0, -1))
         _lap("three passes on own + halo rows")
-        # own survivors in their final form + the key that places them
-        mine = np.empty((len(rows), ncol - 2))
-        if len(rows):
-            ids = np.ascontiguousarray(rows - own_lo, dtype=np.int64)
-            abs_rows = np.ascontiguousarray(abs_l[rows])
+        mine = np.empty((k, ncol - 2))
+        if k:
             cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
-            ident = np.zeros(len(rows), dtype=np.int64)          # (one key: keeps the order, replaces the abs columns)
-            body = np.empty((len(rows), ncol - 3))
-            nat.check(nat.lib().mmx_host_gather_by_key(
-                ar.store.ctypes.data, ar.store.strides[0] // 8, ids.ctypes.data, ident.ctypes.data, len(rows), 1,
-                ncol - 3, abs_rows.ctypes.data, cols3, body.ctypes.data), "mmx_host_gather_by_key")
-            mine[:, :ncol - 3] = body
-            mine[:, ncol - 3] = keys
+            nat.check(lib.mmx_host_emit_survivors(
+                ar.store.ctypes.data, ar.store.strides[0] // 8, ids.ctypes.data, keys.ctypes.data, k, ncol - 3,
+                abs_rows.ctypes.data, cols3, mine.ctypes.data), "mmx_host_emit_survivors")
         _lap("own survivors in final form")
         return mine, counts
 
