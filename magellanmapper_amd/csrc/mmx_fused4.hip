@@ -1102,25 +1102,44 @@ zx6_pack_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     bool quads = false;
     if constexpr (sizeof(InT) == 2)
         quads = stride_x == 1 && ((bd.src_off | stride_y | stride_z) & 3) == 0 && (reinterpret_cast<uintptr_t>(vol) & 7) == 0;
+    if (quads) {
+        // All of a wave's loads -- four planes x (up to) two 4-voxel groups per lane -- are issued before the first
+        // LDS write: a workgroup moves 8 KiB in and 8 KiB out and nothing else hides its load latency (the loop form
+        // had one or two loads in flight per wave: 2.8 TB/s).
+        u2_4 v[4][2];
+        bool have[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int z = 16 * t + 4 * wave + i;
+            const InT* row = src + (int64_t)(z < bd.nz ? z : 0) * stride_z;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int x = lane * 4 + 256 * h;
+                have[i][h] = x < 8 * nch8;
+                v[i][h] = (u2_4){0u, 0u};
+                if (have[i][h] && z < bd.nz) {
+                    if (x + 3 < bd.nx) {
+                        v[i][h] = *reinterpret_cast<const u2_4*>(row + x);
+                    } else {
+                        unsigned e[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e[j] = x + j < bd.nx ? (unsigned)row[x + j] : 0u;
+                        v[i][h] = (u2_4){e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (have[i][h]) *reinterpret_cast<u2_4*>(&tile[4 * wave + i][lane * 4 + 256 * h]) = v[i][h];
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 4 * wave + i, z = 16 * t + r;
         if (z >= bd.nz) {
             for (int x = lane * 4; x < 8 * nch8; x += 256) *reinterpret_cast<u2_4*>(&tile[r][x]) = (u2_4){0u, 0u};
-        } else if (quads) {
-            const InT* row = src + (int64_t)z * stride_z;
-            for (int x = lane * 4; x < 8 * nch8; x += 256) {
-                u2_4 v = {0u, 0u};
-                if (x + 3 < bd.nx) {
-                    v = *reinterpret_cast<const u2_4*>(row + x);
-                } else {
-                    unsigned e[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) e[j] = x + j < bd.nx ? (unsigned)row[x + j] : 0u;
-                    v = (u2_4){e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
-                }
-                *reinterpret_cast<u2_4*>(&tile[r][x]) = v;
-            }
         } else {
             for (int x = lane; x < 8 * nch8; x += 64)
                 tile[r][x] = x < bd.nx ? (uint16_t)((unsigned)src[(int64_t)z * stride_z + (int64_t)x * stride_x] << (sizeof(InT) == 1 ? 8 : 0))

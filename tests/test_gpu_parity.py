@@ -1137,12 +1137,17 @@ def test_small_batches_replay_a_captured_graph(gpu, monkeypatch):
     g = load_golden("bloblog_u16_5sigma.npz")
     dvol = bl.DeviceVolume(g["volume"])
     bl.release_buffers()
+    nat.timing_enable(False)            # (another test's timing window must not be open: a replay would hide from it)
     monkeypatch.setattr(bl, "GRAPH_BLOCKS", 8)
     monkeypatch.setattr(bl, "NATIVE_BATCH", True)
+    monkeypatch.setattr(bl, "HOST_PATH", "native")
+    replays0 = bl.GRAPH_REPLAYS
     runs = [_peaks_of(bl, dvol, g) for _ in range(4)]
     bufs = bl._buffers_for(dvol.tensor.device)
     captured = [hit for hit in bufs.graphs.values() if hit]
-    assert len(captured) == 1 and captured[0][0]                # one key, seen, captured, replayed twice
+    # one key: seen, captured, replayed twice
+    assert len(captured) == 1 and captured[0][0], (len(bufs.graphs), nat.lib().mmx_timing_is_enabled())
+    assert bl.GRAPH_REPLAYS - replays0 == 3
     for res, (coords, vals) in runs:
         np.testing.assert_array_equal(coords, g["peaks"].reshape(-1, 4))
         np.testing.assert_array_equal(vals, runs[0][1][1])
