@@ -496,6 +496,7 @@ class _Buffers:
         self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
         self.graph_stream = None           # where they run when the caller is on the (uncapturable) default stream
         self.plans = {}                    # batch plans + uploaded block tables of recent (block lists, volume layout)
+        self.plan_lists = {}               # (id(origins), id(shapes)) -> (the lists, their content key)
         self.slots(2)
 
     def slots(self, n: int):
@@ -774,16 +775,31 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)):
         eps = EPS_REL_Q16 * vscale
     d_w0, d_w2 = space.device_tables(dvol.tensor.device)
-    # the batches and their block tables on the device: remembered for the very same block lists, volume layout and
-    # budget (a stack detected step after step hands over the SAME lists, stack_detect.StackDetector._block_extents) --
-    # a millisecond of planning, record building and upload per step otherwise, before the first kernel can start
+    # the batches and their block tables on the device: remembered for the same block lists, volume layout and budget (a
+    # stack detected step after step) -- a millisecond of planning, record building and upload per step otherwise, before
+    # the first kernel can start
     plan_key = None
     planned = None
     if pre is None:
         t_ = dvol.tensor
-        # (block records hold element offsets, not addresses: any volume of this layout can use them)
-        plan_key = (id(origins), id(shapes), len(shapes), tuple(t_.stride()), tuple(t_.shape), str(t_.dtype),
-                    len(space.sigmas), int(budget_bytes), _MAX_BATCH, os.environ.get("MMX_RAMP"))
+        # (block records hold element offsets, not addresses: any volume of this layout can use them; the block lists
+        #  are compared by content -- 256 blocks hash in ~30 us -- so that a caller who builds them afresh finds the
+        #  same device tables, which is also what lets a small batch's captured graph be found again)
+        # ... and the very same list objects (stack_detect hands its cached lists over step after step) skip the hashing
+        # (tuples only: a list could have been edited in place since)
+        immutable = type(origins) is tuple and type(shapes) is tuple
+        seen = bufs.plan_lists.get((id(origins), id(shapes))) if immutable else None
+        if seen is not None and seen[0] is origins and seen[1] is shapes:
+            lists_key = seen[2]
+        else:
+            lists_key = (tuple(tuple(int(v) for v in o) for o in origins),
+                         tuple(tuple(int(v) for v in s_) for s_ in shapes))
+            if immutable:
+                if len(bufs.plan_lists) >= 8:
+                    bufs.plan_lists.clear()
+                bufs.plan_lists[(id(origins), id(shapes))] = (origins, shapes, lists_key)    # (kept alive: ids stay theirs)
+        plan_key = (lists_key, tuple(t_.stride()), tuple(t_.shape), str(t_.dtype), len(space.sigmas),
+                    int(budget_bytes), _MAX_BATCH, os.environ.get("MMX_RAMP"))
         planned = bufs.plans.get(plan_key)
     if planned is not None:
         batches = planned[0]
@@ -814,7 +830,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             prepared = [(blk, slot, allrec[int(offs[i]):int(offs[i + 1])]) for i, (blk, slot) in enumerate(prepared)]
         if len(bufs.plans) >= 8:
             bufs.plans.clear()
-        bufs.plans[plan_key] = (batches, prepared, origins, shapes)     # (the lists stay alive: their ids are the key)
+        bufs.plans[plan_key] = (batches, prepared)
     if pre is None:        # ... and the shared workspace has its final size before anything is queued on it
         if prepared:
             need = max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, len(space.sigmas), 1)) // 4)

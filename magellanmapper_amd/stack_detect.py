@@ -489,6 +489,7 @@ class StackDetector:
                 a2, b2, _ = x.indices(n2)
             origins.append((int(a0), int(a1), int(a2)))
             shapes.append((int(b0 - a0), int(b1 - a1), int(b2 - a2)))
+        origins, shapes = tuple(origins), tuple(shapes)       # (immutable: the device pipeline may remember them by identity)
         if len(cls._extent_cache) >= 8:
             cls._extent_cache.clear()
         cls._extent_cache[key] = (origins, shapes, sub_roi_slices)
