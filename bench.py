@@ -396,6 +396,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     # per-kernel timing, as a caller's step does, and the per-kernel times come from extra steps after it.
     replayed = world == 1 and 0 < n_blocks <= bl.GRAPH_BLOCKS and bl.NATIVE_BATCH and not PROFILE["denoise_size"]
     nat.timing_enable(not replayed)
+    bl.PRE_WAITS.clear()
     replays0 = bl.GRAPH_REPLAYS
     barrier()
     t0 = time.perf_counter()
@@ -406,6 +407,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     barrier()
     elapsed = time.perf_counter() - t0
     n_replays = bl.GRAPH_REPLAYS - replays0
+    pre_wait_ms = sum(a.elapsed_time(b) for a, b in bl.PRE_WAITS) / steps if bl.PRE_WAITS else None
+    bl.PRE_WAITS.clear()
     if replayed:
         extra = max(1, min(steps, 10))
         nat.timing_enable(True)
@@ -460,6 +463,11 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                         if k == "y2pass" else "above the 8 TB/s peak on the contract's byte count: the kernel moves fewer bytes")
             elif k == "preproc":      # once per voxel (not per sigma): 2 B in, 8 + 4 B out; fp64-VALU bound
                 per_kernel[k]["alg_GBps"] = round(14 * my_vox * steps / (ms * 1e-3) / 1e9, 1)
+                # ~220 float64 operations per voxel (three sigma-8 passes of 68 + stretch, unsharp, erosion), none
+                # fused (SciPy's arithmetic has no FMA), against 256 CUs x 64 lanes x 2.4 GHz = 39.3 Top/s
+                top = 220.0 * my_vox * steps / (ms * 1e-3) / 1e12
+                per_kernel[k]["f64_Tops"] = round(top, 2)
+                per_kernel[k]["frac_of_f64_vector_rate_no_fma"] = round(top / 39.3, 3)
     stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
     dom = max(stream_k, key=lambda k: stream_k[k]["ms_per_step"]) if stream_k else None
     zx_path = bl.LAST_ZX_PATH
@@ -582,6 +590,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             # launch, launch gaps, waits for the preprocessing stream, and the tail after the last kernel (last
             # batch's host work, pruning, final columns)
             "host_exposed_ms_per_step": round(elapsed / steps * 1e3 - main_ms, 2) if world == 1 else None,
+            # of which: the LoG stream waiting for a batch's preprocessing on the other stream (HIP events around the waits)
+            "pre_stream_wait_ms": None if pre_wait_ms is None else round(pre_wait_ms, 2),
             "overlapped_streams": list(overlapped) or None},
         "above_contract_roofline": flags or None,
         "above_contract_roofline_note": None if not flags else (

@@ -78,6 +78,8 @@ NATIVE_BATCH = os.environ.get("MMX_NATIVE_BATCH", "1") != "0"
 #: batches of at most this many blocks that come back with the very same arguments (a small volume detected step
 #: after step) are captured as a hipGraph and replayed with one launch (``MMX_GRAPH_BLOCKS=0``: never)
 GRAPH_BLOCKS = int(os.environ.get("MMX_GRAPH_BLOCKS", "8"))
+#: with the per-kernel timing on: (before, after) event pairs around the LoG stream's wait for a batch's preprocessing
+PRE_WAITS: list = []
 #: batches replayed from a captured graph so far (bench.py reports the count of its timed region)
 GRAPH_REPLAYS = 0
 #: bound of the 16-bit intermediates of the most recent batch that used them (value units), else 0: bench.py prints it
@@ -905,7 +907,15 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                 blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
                 ready = torch.cuda.Event()
                 ready.record()
+            timed = bool(L.mmx_timing_is_enabled())
+            if timed:       # how long the LoG stream waits for this batch's preprocessing (bench.py: pre_stream_wait_ms)
+                before = torch.cuda.Event(enable_timing=True)
+                before.record()
             main.wait_event(ready)
+            if timed:
+                after = torch.cuda.Event(enable_timing=True)
+                after.record()
+                PRE_WAITS.append((before, after))
         else:
             blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
         store_f32 = int(getattr(pre, "store_f32", 0))
