@@ -252,7 +252,7 @@ class _RegionPruner:
     def __init__(self, arena: _TableArena, plan, channels, sub_roi_slices, shape3, share):
         self.arena, self.plan, self.channels = arena, plan, list(channels)
         grid = sub_roi_slices.shape
-        coords = list(np.ndindex(*grid))
+        coords = StackDetector._grid_coords(grid)
         run = max(1, int(grid[2]))
         reach = _region_reach(plan["tol"])
         self.regions = []
@@ -463,6 +463,18 @@ class StackDetector:
         return coord, segments
 
     _extent_cache: dict = {}
+    _coords_cache: dict = {}
+
+    @classmethod
+    def _grid_coords(cls, grid):
+        """``list(np.ndindex(*grid))``, remembered per grid shape (a tuple of tuples: nobody writes to it)."""
+        grid = tuple(int(v) for v in grid)
+        hit = cls._coords_cache.get(grid)
+        if hit is None:
+            if len(cls._coords_cache) >= 16:
+                cls._coords_cache.clear()
+            hit = cls._coords_cache[grid] = tuple(np.ndindex(*grid))
+        return hit
 
     @classmethod
     def _block_extents(cls, sub_roi_slices, shape3, mine):
@@ -510,7 +522,7 @@ class StackDetector:
         grid = sub_roi_slices.shape
         last_coord = np.subtract(grid, 1)
         cls.last_coord = last_coord
-        coords = list(np.ndindex(*grid))
+        coords = cls._grid_coords(grid)
         mine = dist.my_share(len(coords))            # all of them without torch.distributed
         shape3 = img.shape[:3]
         origins, shapes = cls._block_extents(sub_roi_slices, shape3, mine)
@@ -562,7 +574,9 @@ class StackDetector:
             dvol = img if isinstance(img, bl.DeviceVolume) else bl.DeviceVolume(img)
             sink = None
             if arena is not None and n_extra == 0:
-                sink = _ArenaSink(arena, [coords[i] for i in mine], [sub_rois_offsets[coords[i]] for i in mine],
+                flat_offsets = np.asarray(sub_rois_offsets, dtype=np.float64).reshape(-1, 3)    # (C order: coords' order)
+                sink = _ArenaSink(arena, np.asarray(coords, dtype=np.int32)[mine[0]:mine[-1] + 1],
+                                  flat_offsets[mine[0]:mine[-1] + 1],
                                   shapes, exclude_of if exclude_border is not None else None)
                 # (the pruner's set-up -- 0.7 ms for 256 blocks -- waits until the first batch has landed: by then every
                 #  batch is queued and the GPU busy)
@@ -601,7 +615,7 @@ class StackDetector:
         rank keeps the tables of its own blocks (``None`` for the others) and ``StackPruner.prune_blobs_mp`` prunes
         them as a collective."""
         from . import dist
-        coords = list(np.ndindex(*grid))
+        coords = StackDetector._grid_coords(grid)
         seg_rois = np.zeros(grid, dtype=object).view(_SegRois)
         if dist.world_size() > 1 and local_only:
             for coord in coords:
@@ -1165,7 +1179,7 @@ class StackPruner:
         # word in the all_reduce, in the row counts of the two exchanges): a rank that fails -- a native error, tables
         # of the wrong width -- makes every rank raise at that collective instead of leaving the others waiting in it.
         grid = sub_roi_slices.shape
-        coords = list(np.ndindex(*grid))
+        coords = StackDetector._grid_coords(grid)
         n = ar.n
         ncol = ar.store.shape[1]
         failure, payload, boxes, reach, abs_inds = None, None, None, None, None

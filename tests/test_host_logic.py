@@ -1161,3 +1161,103 @@ def test_save_subimage_writes_the_roi_unless_it_is_the_open_memmap(tmp_path, cap
     np.testing.assert_array_equal(np.load(path), roi)
     with pytest.raises(TypeError):
         stack_detect._save_subimage(str(tmp_path / "x.npy"), roi[None], object())
+
+
+def test_rank_table_plumbing_natives():
+    """``mmx_host_rows_in_boxes`` / ``mmx_host_append_rows`` / ``mmx_host_emit_survivors`` (the table plumbing of the
+    distributed pruning, host code only) against their NumPy statements, incl. the overflow counts and bad arguments."""
+    from magellanmapper_amd import _native as nat
+    lib = nat.lib()
+    rng = np.random.default_rng(3)
+    n, ncol = 5000, 14
+    store = rng.normal(size=(n, ncol))
+    zyx = rng.integers(0, 200, (n, 3)).astype(np.int32)
+    tag = rng.integers(0, 5, (n, 3)).astype(np.int32)
+    ab = zyx + rng.integers(-2, 3, (n, 3)).astype(np.float64)
+    store[:, 6] = rng.integers(0, 2, n)
+    lo = np.array([[0, 0, 0], [150, 20, 30]], dtype=np.int32)
+    hi = np.array([[40, 200, 200], [200, 90, 160]], dtype=np.int32)
+    inside = np.zeros(n, dtype=bool)
+    for b in range(2):
+        inside |= np.all((zyx >= lo[b]) & (zyx < hi[b]), axis=1)
+    want = np.column_stack((zyx[inside], tag[inside], ab[inside], store[inside, 6])).astype(np.float64)
+    out = np.empty((n, 10))
+    k = ctypes.c_int64(0)
+    nat.check(lib.mmx_host_rows_in_boxes(zyx.ctypes.data, tag.ctypes.data, ab.ctypes.data, store.ctypes.data + 48,
+                                         ncol, n, lo.ctypes.data, hi.ctypes.data, 2, out.ctypes.data, n,
+                                         ctypes.byref(k)), "rows_in_boxes")
+    assert k.value == len(want) > 100
+    np.testing.assert_array_equal(out[:k.value], want)
+    small = np.empty((7, 10))                   # too small: filled to its capacity, the count keeps counting
+    nat.check(lib.mmx_host_rows_in_boxes(zyx.ctypes.data, tag.ctypes.data, ab.ctypes.data, store.ctypes.data + 48,
+                                         ncol, n, lo.ctypes.data, hi.ctypes.data, 2, small.ctypes.data, 7,
+                                         ctypes.byref(k)), "rows_in_boxes")
+    assert k.value == len(want)
+    np.testing.assert_array_equal(small, want[:7])
+    assert lib.mmx_host_rows_in_boxes(None, None, None, None, ncol, n, lo.ctypes.data, hi.ctypes.data, 2,
+                                      out.ctypes.data, n, ctypes.byref(k)) == 1
+    # ... and back into compact columns behind `at` rows, filtered by the receiver's box
+    box_lo = np.array([10, 0, 0], dtype=np.int32)
+    box_hi = np.array([180, 150, 150], dtype=np.int32)
+    keep = np.all((want[:, :3] >= box_lo) & (want[:, :3] < box_hi), axis=1)
+    at, cap = 11, 11 + int(keep.sum())
+    z2 = np.zeros((cap, 3), dtype=np.int32)
+    t2 = np.zeros((cap, 3), dtype=np.int32)
+    a2 = np.zeros((cap, 3))
+    st2 = np.zeros((cap, ncol))
+    p32 = ctypes.POINTER(ctypes.c_int32)
+    nat.check(lib.mmx_host_append_rows(want.ctypes.data, len(want), box_lo.ctypes.data_as(p32), box_hi.ctypes.data_as(p32),
+                                       z2.ctypes.data, t2.ctypes.data, a2.ctypes.data, st2.ctypes.data + 48, ncol, at, cap,
+                                       ctypes.byref(k)), "append_rows")
+    assert k.value == keep.sum() > 50
+    np.testing.assert_array_equal(z2[at:], want[keep, :3])
+    np.testing.assert_array_equal(t2[at:], want[keep, 3:6])
+    np.testing.assert_array_equal(a2[at:], want[keep, 6:9])
+    np.testing.assert_array_equal(st2[at:, 6], want[keep, 9])
+    assert not z2[:at].any()
+    assert lib.mmx_host_append_rows(want.ctypes.data, len(want), box_lo.ctypes.data_as(p32), box_hi.ctypes.data_as(p32),
+                                    z2.ctypes.data, t2.ctypes.data, a2.ctypes.data, st2.ctypes.data + 48, ncol, at,
+                                    cap - 1, ctypes.byref(k)) == 4            # MMX_ERR_WORKSPACE, the count still right
+    assert k.value == keep.sum()
+    # survivors: rows by id, abs columns replaced, key appended
+    ids = np.ascontiguousarray(rng.permutation(n)[:30000 % n + 700], dtype=np.int64)
+    keys = rng.integers(0, 99, len(ids)).astype(np.int64)
+    abs_rows = rng.normal(size=(len(ids), 3))
+    got = np.empty((len(ids), 12))
+    cols3 = (ctypes.c_int32 * 3)(7, 8, 9)
+    nat.check(lib.mmx_host_emit_survivors(store.ctypes.data, ncol, ids.ctypes.data, keys.ctypes.data, len(ids), 11,
+                                          abs_rows.ctypes.data, cols3, got.ctypes.data), "emit_survivors")
+    ref = store[ids, :11].copy()
+    ref[:, 7:10] = abs_rows
+    np.testing.assert_array_equal(got[:, :11], ref)
+    np.testing.assert_array_equal(got[:, 11], keys)
+    assert lib.mmx_host_emit_survivors(store.ctypes.data, ncol, ids.ctypes.data, keys.ctypes.data, len(ids), 15,
+                                       abs_rows.ctypes.data, cols3, got.ctypes.data) == 1
+
+
+def test_geometry_memo_and_ratio_frame():
+    """``StackPruner._geometry`` remembers a block geometry by the identity of its arrays (and recomputes for other
+    arrays, tolerances or shapes); ``_ratio_frame`` builds the data frame the dict-of-lists constructor would."""
+    import pandas as pd
+    from magellanmapper_amd import stack_detect as sd
+    config.setup_roi_profiles(None)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.roi_profile.update(segment_size=40, denoise_size=None)
+    shape = (96, 150, 170)
+    b1, b2 = sd.setup_blocks(config.roi_profile, shape), sd.setup_blocks(config.roi_profile, shape)
+    args = lambda b, tol=None: (shape, b.overlap, b.tol if tol is None else tol, b.overlap_padding, b.sub_roi_slices,
+                                b.sub_rois_offsets)
+    p1, r1 = sd.StackPruner._geometry(*args(b1))
+    assert r1 and sd.StackPruner._geometry(*args(b1))[0] is p1                 # remembered
+    p2, _ = sd.StackPruner._geometry(*args(b2))
+    assert p2 is not p1 and p2["n_keys"] == p1["n_keys"]                      # other arrays: computed again, same answer
+    p3, _ = sd.StackPruner._geometry(*args(b1, np.asarray(b1.tol) - 1))
+    assert p3 is not p1 and not np.array_equal(p3["tol"], p1["tol"])
+    fresh = sd.StackPruner._axis_plan(*args(b1))
+    for a, b in zip(p1["axes"], fresh["axes"]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            np.testing.assert_array_equal(a["bounds"], b["bounds"])
+    ratios = {"blobs": [12, 7, 30], "ratio_pruning": [0.5, 1.0, 0.25], "ratio_adjacent": [1.5, 0.75, 2.0]}
+    pd.testing.assert_frame_equal(sd.StackPruner._ratio_frame(ratios), pd.DataFrame(ratios))
+    assert sd.StackPruner._ratio_frame({}).shape == pd.DataFrame({}).shape
