@@ -105,6 +105,9 @@ HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
 FLOAT_TILED_RANGE = (0.0, 2.0 ** 12)
 #: per-block preprocessing on a stream of its own (beside the previous batch's LoG kernels)
 PRE_STREAM = os.environ.get("MMX_PRE_STREAM", "1") != "0"
+#: ... with the NMS / re-score tail of a preprocessed batch on the second stream too (``MMX_PRE_SIDE_TAIL=0``: on the
+#: main stream, as before round 4)
+PRE_SIDE_TAIL = os.environ.get("MMX_PRE_SIDE_TAIL", "1") != "0"
 #: ... and this many batches ahead of the one the host is finishing (``preprocess.N_BUFFER_SETS`` - 1 buffer sets allow
 #: it): the first batch is then the only one whose LoG passes wait for their preprocessing
 PRE_AHEAD = max(1, min(2, int(os.environ.get("MMX_PRE_AHEAD", "2"))))
@@ -833,6 +836,17 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         if len(bufs.plans) >= 8:
             bufs.plans.clear()
         bufs.plans[plan_key] = (batches, prepared)
+    if pre is not None and PRE_SIDE_TAIL and RESCORE_STREAM and exact and n_b > 1:
+        # preprocessed batches alternate between two workspaces as well (the tail of a batch on the second stream beside
+        # the next batch's passes): both at their final size before anything is queued on them
+        need = 0
+        for b in batches:
+            slot_b = max(int(shapes[i][0]) * int(shapes[i][1]) * (-(-int(shapes[i][2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
+                         for i in b)
+            need = max(need, -(-int(nat.lib().mmx_workspace_bytes(len(b), slot_b, len(space.sigmas), 1)) // 4))
+        bufs.workspace(need)
+        bufs.workspace(need, 1)
+        bufs.ws_free = [None, None]
     if pre is None:        # ... and the shared workspace has its final size before anything is queued on it
         if prepared:
             need = max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, len(space.sigmas), 1)) // 4)
@@ -852,7 +866,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                                         exact=exact, prepared=None if prepared is None else prepared[enq],
                                         vscale=vscale, vrange=vrange,
                                         buffer_free=(None if enq < ahead + 1 else done_events[enq - (ahead + 1)])
-                                        if pre is not None else False)
+                                        if pre is not None else False, parity=enq)
             done_events.append(jobs[enq]["done"])
             jobs[enq]["batch"] = batch
             enq += 1
@@ -882,7 +896,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
 def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: float, eps: float,
                     bufs: _Buffers, which: int, d_w0, d_w2, cap: Optional[int] = None, pre=None,
                     exact: bool = False, prepared=None, vscale: Optional[float] = None, vrange=None,
-                    buffer_free=False):
+                    buffer_free=False, parity: Optional[int] = None):
     """Enqueue (P1-P3,) A0-A4 of one batch on the current stream; nothing here waits for the GPU.
     ``exact``: also re-score every candidate in float64 (otherwise ``_resolve_peaks`` re-scores the few
     whose decision depends on it)."""
@@ -925,8 +939,11 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     mask_words = (nb * slot) >> 5            # 16-byte entries per sigma (include/mmx.h: d_nms_mask)
     # raw volumes: the batches alternate between two workspaces, and everything after a batch's last LoG kernel -- NMS,
     # probe expansion, exact re-score, copies -- runs on a second stream beside the next batch's LoG kernels
-    side_tail = bool(RESCORE_STREAM and exact and pre is None and prepared is not None)
-    ws_i = (which & 1) if (side_tail and bufs.ws2 is not None) else 0
+    # (preprocessed batches too since round 4 -- PRE_SIDE_TAIL: there the tail is 35 of 270 ms on the critical path of the
+    #  two-channel benchmark tile; their two workspaces are sized by blob_log_blocks before anything is queued)
+    side_tail = bool(RESCORE_STREAM and exact and ((pre is None and prepared is not None) or
+                                                   (pre is not None and PRE_SIDE_TAIL and bufs.ws2 is not None)))
+    ws_i = ((which if parity is None else parity) & 1) if (side_tail and bufs.ws2 is not None) else 0
     ws = bufs.workspace(-(-int(L.mmx_workspace_bytes(nb, slot, ns, 1)) // 4), ws_i)
     # ... and the voxel copy of the tiled path, the first kernel of a batch, on a third: it only needs the workspace
     pack_side = side_tail and PACK_STREAM and bufs.ws2 is not None
