@@ -105,9 +105,10 @@ HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
 FLOAT_TILED_RANGE = (0.0, 2.0 ** 12)
 #: per-block preprocessing on a stream of its own (beside the previous batch's LoG kernels)
 PRE_STREAM = os.environ.get("MMX_PRE_STREAM", "1") != "0"
-#: ... with the NMS / re-score tail of a preprocessed batch on the second stream too (``MMX_PRE_SIDE_TAIL=0``: on the
-#: main stream, as before round 4)
-PRE_SIDE_TAIL = os.environ.get("MMX_PRE_SIDE_TAIL", "1") != "0"
+#: ... with the NMS / re-score tail of a preprocessed batch on the second stream too (``MMX_PRE_SIDE_TAIL=1``).  Off:
+#: measured on the box it LOSES -- 283.6 against 278.9 ms (two-channel tile), 214.6 against 212.4 ms (--denoise 25): the
+#: preprocessing kernel already fills every CU it can, a third stream only adds to the time-sharing
+PRE_SIDE_TAIL = os.environ.get("MMX_PRE_SIDE_TAIL", "0") == "1"
 #: ... and this many batches ahead of the one the host is finishing (``preprocess.N_BUFFER_SETS`` - 1 buffer sets allow
 #: it): the first batch is then the only one whose LoG passes wait for their preprocessing
 PRE_AHEAD = max(1, min(2, int(os.environ.get("MMX_PRE_AHEAD", "2"))))
@@ -939,8 +940,8 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     mask_words = (nb * slot) >> 5            # 16-byte entries per sigma (include/mmx.h: d_nms_mask)
     # raw volumes: the batches alternate between two workspaces, and everything after a batch's last LoG kernel -- NMS,
     # probe expansion, exact re-score, copies -- runs on a second stream beside the next batch's LoG kernels
-    # (preprocessed batches too since round 4 -- PRE_SIDE_TAIL: there the tail is 35 of 270 ms on the critical path of the
-    #  two-channel benchmark tile; their two workspaces are sized by blob_log_blocks before anything is queued)
+    # (preprocessed batches too with PRE_SIDE_TAIL -- measured and left off; their two workspaces are sized by
+    #  blob_log_blocks before anything is queued)
     side_tail = bool(RESCORE_STREAM and exact and ((pre is None and prepared is not None) or
                                                    (pre is not None and PRE_SIDE_TAIL and bufs.ws2 is not None)))
     ws_i = ((which if parity is None else parity) & 1) if (side_tail and bufs.ws2 is not None) else 0
