@@ -32,6 +32,8 @@
 
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "mmx_common.h"
 
 typedef _Float16 h2_y __attribute__((ext_vector_type(2)));
@@ -47,6 +49,7 @@ struct ym_cfg {
     float start;                            // accumulators start here: minus what the 128 of Q's high byte adds
     float lo, eps;                          // nms_lo, nms_eps in accumulator units (/ unscale: a power of two, exact)
     int radius;
+    int reverse;                            // 1: blockIdx.y = n - 1 takes the first block (the launch walks the batch backwards)
 };
 
 namespace {
@@ -94,7 +97,9 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     constexpr int JH = NB <= 4 ? 4 : YM6_JH;           // column sets whose pieces are held at a time
     __shared__ float tr[WAVES * 2 * 1024];      // per wave: two finished tiles of 16 rows x 64 columns
 
-    const mmx_block bd = blocks[blockIdx.y];
+    // (reverse: the Z+X kernel has just written the batch's P / Q tiles block after block; walking the batch from its
+    //  last block back starts with the tiles written last -- what the 256 MiB memory-side cache still holds)
+    const mmx_block bd = blocks[cfg.reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y];
     const int ntx = (bd.nx + 15) >> 4, ntz = (bd.nz + 15) >> 4;
     if ((int)blockIdx.x * (WAVES / 4) >= ntx * ntz) return;     // (the whole workgroup)
     // ---- Toeplitz fragments: A[m][k] = w[|k - m + delta_t|], lane = (m = l & 15, k = 8 (l >> 4) + i)
@@ -471,6 +476,8 @@ int mmx_launch_ym(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& p
     cfg.lo = nms_lo / cfg.unscale;
     cfg.eps = nms_eps / cfg.unscale;
     cfg.radius = radius;
+    static const bool rev_env = !(getenv("MMX_YM_REVERSE") && atoi(getenv("MMX_YM_REVERSE")) == 0);
+    cfg.reverse = rev_env ? 1 : 0;
     // NB block offsets cover every tap when the first offset beyond either end, RB + 16 - 15 and 16 NB - RB - 31 rows away,
     // is out of reach: R <= 8 (NB - 2) with RB = 8 (NB - 2)
     if (radius <= 8) return launch_ym<3>(d_blocks, n_blocks, plan, slot_elems, cfg, d_p, d_log, d_mask, stream);
