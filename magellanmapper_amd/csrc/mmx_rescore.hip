@@ -14,7 +14,7 @@
 // oracle/ndfilters.c states the same arithmetic on the CPU and is pinned to SciPy bit for
 // bit; tests/test_gpu_parity.py checks this kernel against it.
 //
-// Design (gfx950): one 256-thread workgroup per point.  The point needs a (2R+1)^2 window
+// Design (gfx950): a 256-thread workgroup per point, a fixed number of workgroups walking the table.  The point needs a (2R+1)^2 window
 // of axis-0 sums (two kernels sharing their loads), staged in LDS in column strips, then
 // 3(2R+1) axis-1 sums, then 3 axis-2 sums.  Loads are L2/MALL hits (the block's voxels were
 // just streamed by the float32 passes); the work is ~1e5 float64 operations per point and
@@ -66,15 +66,21 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     extern __shared__ double smem[];
     uint32_t n = cap;
     if (count) { const uint32_t c = *count; n = c < cap ? c : cap; }
-    // (one workgroup per point; the grid is two-dimensional because grid.x * 256 threads must stay below 2^32:
-    //  a batch whose candidates sit on a plateau -- spectral unmixing clips whole regions to 0 -- asks for the
-    //  80 neighbours of several 10^5 candidates, > 16.7 M points in one call)
-    const uint64_t idx64 = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;      // (cap near 2^32: no 32-bit wrap)
-    if (idx64 >= cap) return;
+    // A fixed number of workgroups walks the table (round 4).  One workgroup per table ENTRY used to be launched --
+    // the table's capacity, ~10^6, for the ~3 x 10^4 points a batch really has: 97 % of the workgroups read the count and
+    // left, which still cost each a wave slot for a few hundred cycles (~0.1 ms per launch).
+    for (uint64_t idx64 = blockIdx.x; idx64 < n; idx64 += gridDim.x) {
     const uint32_t idx = (uint32_t)idx64;
-    if (idx >= n) return;
-    const mmx_cand pt = pts[idx];
-    if (pt.slot < 0 || pt.slot >= prm.n_blocks) return;
+    // (the point is the same for every lane: readfirstlane tells the compiler, so that the weight tables -- indexed by
+    //  the point's scale -- are read by scalar loads next to their use instead of two vector loads per tap)
+    const mmx_cand ptv = pts[idx];
+    mmx_cand pt;
+    pt.slot = __builtin_amdgcn_readfirstlane(ptv.slot);
+    pt.s = __builtin_amdgcn_readfirstlane(ptv.s);
+    pt.z = __builtin_amdgcn_readfirstlane(ptv.z);
+    pt.y = __builtin_amdgcn_readfirstlane(ptv.y);
+    pt.x = __builtin_amdgcn_readfirstlane(ptv.x);
+    if (pt.slot < 0 || pt.slot >= prm.n_blocks || pt.s < 0 || pt.s >= MMX_MAX_SIGMAS) continue;     // (whole workgroup)
     const mmx_block bd = blocks[pt.slot];
     const int R = prm.radius[pt.s];
     const int N = 2 * R + 1;
@@ -90,9 +96,9 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
     // multiply per load would cost as much issue time as the float64 arithmetic of the tap)
     int64_t* zr = (int64_t*)(yp + 3 * (size_t)N);
 
+    __syncthreads();                    // (the previous point's last reads of this memory)
     for (int k = threadIdx.x; k < N; k += MMX_WG) zr[k] = (int64_t)mmx_reflect(pt.z + k - R, bd.nz) * sz;
     __syncthreads();
-
     for (int dx0 = 0; dx0 < N; dx0 += SW) {
         const int sw = (N - dx0) < SW ? (N - dx0) : SW;
         // ---- axis 0 (z): two kernels share every load
@@ -157,6 +163,7 @@ rescore_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx,
         const StoreT cube = (-sum) * (StoreT)prm.norm[pt.s];
         pts[idx].v64 = (double)cube;
     }
+    }       // next point
 }
 
 template <typename InT, typename StoreT>
@@ -164,10 +171,9 @@ int launch(const mmx_volume* vol, const mmx_block* d_blocks, mmx_cand* d_pts, ui
            const uint32_t* d_count, const double* d_w0, const double* d_w2,
            const mmx_rescore_params& prm, size_t lds, hipStream_t s)
 {
-    const uint32_t gx = cap < (1u << 22) ? cap : (1u << 22);
-    const uint64_t gy = ((uint64_t)cap + gx - 1) / gx;
-    if (gy > 65535u) return MMX_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((rescore_kernel<InT, StoreT>), dim3(gx, (uint32_t)gy), dim3(MMX_WG), lds, s,
+    // (256 CUs x the workgroups a CU holds at 60 KiB of LDS each, a few times over: the points' costs differ with sigma)
+    const uint32_t gx = cap < 8192u ? cap : 8192u;
+    hipLaunchKernelGGL((rescore_kernel<InT, StoreT>), dim3(gx), dim3(MMX_WG), lds, s,
                        (const InT*)vol->d_data, vol->stride_z, vol->stride_y, vol->stride_x, d_blocks,
                        d_pts, cap, d_count, d_w0, d_w2, prm);
     return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
