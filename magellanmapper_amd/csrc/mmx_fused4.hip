@@ -78,6 +78,7 @@ struct mmx_zx4_cfg {
     float qp, qq;                          // Q16 tiles: P / bound(P) and Q / bound(Q) land in [0, 1] and [-1, 1]
     int staged;                            // 0: chunks clamped into the row (zx4); 1: at their natural position (zx5); 2: same, windows at 16 c - R8 (zx6)
     int ntw;                               // column tiles per wave (tiled form): 2 = tiles (2 p, 2 p + 1) share the window of tile 2 p
+    int keep_pad;                          // 1: store the planes of the last z tile past the block too (A/B switch)
 };
 
 namespace {
@@ -469,10 +470,18 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #pragma unroll
             for (int i = 0; i < NT; ++i) { win[w][a][i][0] = 0u; win[w][a][i][1] = 0u; }
 
-    const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
-    const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
-    // (second tile of a pair: the same array, 0 records when the row has no such tile -- its stores are dropped)
-    const rsrc4_t rp2 = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems, 0, has2 ? 0x7fffffff : 0, 0x00020000);
+    // TILED: one descriptor per wave, over the tile column (y, c, all U) it writes -- ntz KiB -- and ENDING where the
+    // block's planes end: the rows of the last z tile past the block (11 of 16 at 261 planes) fall outside it and the
+    // hardware drops their part of the store, 4 % of the kernel's write requests, without a branch or an exec mask.
+    // Nothing reads them: the Y pass works within a plane and discards the planes past the block (ym_kernel: `real`).
+    // (Second tile of a pair: the next ntz KiB, 0 records when the row has no such tile -- its stores are dropped.)
+    const unsigned col_b = (unsigned)ntz * 1024u;                                        // bytes of one tile column
+    const unsigned live_b = TILED ? col_b - (cfg.keep_pad ? 0u : (unsigned)(16 * ntz - nz) * 64u) : 0x7fffffffu;
+    const int64_t wave_e = TILED ? (int64_t)((y * ntx + c) * ntz) * 256 : 0;             // elements before this wave's tiles
+    const rsrc4_t rp = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems + wave_e, 0, (int)live_b, 0x00020000);
+    const rsrc4_t rq = __builtin_amdgcn_make_buffer_rsrc(gq + (int64_t)bd.slot * slot_elems + wave_e, 0, (int)live_b, 0x00020000);
+    const rsrc4_t rp2 = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems + wave_e + (int64_t)ntz * 256, 0,
+                                                          has2 ? (int)live_b : 0, 0x00020000);
     const unsigned row_b = (unsigned)px * 4u;
     // TILED: tile (y, c, U) of 16 z x 16 x floats, row-major, at ((y ntx + c) ntz + U) KiB: what a wave writes
     // during its march is contiguous, the waves of a workgroup and the workgroups of a row follow each other --
@@ -480,7 +489,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // the same ntx ntz KiB at any time.  (Measured against the (c, U, y) order: no difference in either kernel; both
     // run at the request rate the memory system sustains)
     const unsigned plane_b = TILED ? 64u : (unsigned)bd.ny * row_b;
-    unsigned obase = TILED ? (unsigned)(((y * ntx + c) * ntz) * 1024 + (4 * li + kq) * 16)
+    unsigned obase = TILED ? (unsigned)((4 * li + kq) * 16)          // (relative to the wave's tile column)
                            : (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
 
     // voxels of the next ZX4_PF z tiles, in flight.  vmcnt counts loads and stores together and in issue order:
@@ -668,9 +677,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                             P[w][r] = ra;
                             P[w][r + 1] = rb;
                         }
-                        // (tile (y, c + w, U) lies ntz KiB after tile (y, c, U))
+                        // (tile (y, c + w, U) lies ntz KiB after tile (y, c, U): rp2's base)
                         if (w == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P[w]), rp, obase, 0, ZX4_ST_AUX);
-                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P[w]), rp2, obase, (unsigned)ntz * 1024u, ZX4_ST_AUX);
+                        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_4, P[w]), rp2, obase, 0, ZX4_ST_AUX);
                     }
                 } else {
 #pragma unroll
@@ -853,8 +862,6 @@ zx5_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const int scol = 16 * g * WPG + 4 * schunk;
     const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
     const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
-    // (second tile of a pair: the same array, 0 records when the row has no such tile -- its stores are dropped)
-    const rsrc4_t rp2 = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems, 0, has2 ? 0x7fffffff : 0, 0x00020000);
     const unsigned row_b = (unsigned)px * 4u;
     const unsigned plane_b = (unsigned)bd.ny * row_b;
     unsigned sbase = (unsigned)srow * plane_b + (unsigned)y * row_b + (unsigned)scol * 4u;
@@ -1233,6 +1240,8 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     static const bool pair_env = !(getenv("MMX_ZX_PAIR") && atoi(getenv("MMX_ZX_PAIR")) == 0);
     const bool pair = pair_env && NKX == 2 && LA == 1 && qp > 0.f && vol->dtype != MMX_F32;
     cfg.ntw = pair ? 2 : 1;
+    static const bool keep_pad_env = getenv("MMX_ZX_KEEP_PAD") && atoi(getenv("MMX_ZX_KEEP_PAD")) != 0;
+    cfg.keep_pad = keep_pad_env ? 1 : 0;
     int max_waves = 0;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
