@@ -153,19 +153,19 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 C3_DIGEST = "5fba8ef88362dfa0a7d9fb8caaef869ea416eb85"
 
 
-def test_full_c3_volume_over_three_ranks_has_the_one_rank_digest(gpu, tmp_path):
+def test_full_c3_volume_over_two_ranks_has_the_one_rank_digest(gpu, tmp_path):
     """BASELINE.json configs[3] as far as one GPU goes: the FULL 2048 x 2048 x 1024 volume, its 256 blocks sharded
-    over 3 ranks that share this GPU (gloo; uneven shares, seams inside z-layers of the block grid), every rank
-    pruning its own rows and merging everybody's survivors by key (the distributed pruning): same digest and blob
-    count as one rank.  Rank 0 also runs the parity sample by itself (``dist.solo``) against the committed oracle table
-    of that sample (tests/golden/make_bench_samples.py).
+    over 2 ranks that share this GPU (gloo), every rank pruning its own rows and merging everybody's survivors by key
+    (the distributed pruning): same digest and blob count as one rank.  Rank 0 also runs the parity sample by itself
+    (``dist.solo``) against the committed oracle table of that sample (tests/golden/make_bench_samples.py).
 
-    Three ranks, not four: FOUR processes on one MI355X of this pool run pathologically slowly -- their slabs of the
-    synthetic volume take 262 s to generate instead of 0.6 s with two or three (tools/exp/gen4.py: all four finish at
-    the same moment; a limit on concurrently scheduled compute processes, not this code) -- so the four-rank run, which
-    returns the same digest (profiles/r04_ranks4_gloo.txt), takes 8 minutes and stays a tool, not a test."""
-    line = _run_bench(tmp_path, 3, "--parity-sample", os.path.join(GOLDEN_DIR, "bench_sample_c3.npz"), timeout=1500)
-    assert line["n_gpus"] == 3 and [r["blocks"] for r in line["ranks"]] == [86, 85, 85]
+    Two ranks, not four: THREE or more processes on one MI355X of this pool are time-sliced in quanta of seconds --
+    four processes take 262 s to generate their slabs of the synthetic volume instead of 0.6 s with two
+    (tools/exp/gen4.py: all four finish at the same moment), the three-rank form of this test 275 s, the four-rank form
+    515 s -- a property of the box, not of this code.  The four-rank run returns the same digest
+    (profiles/r04_ranks4_gloo.txt) and stays a tool: ``MMX_DIST_BACKEND=gloo python bench.py --gpus 4``."""
+    line = _run_bench(tmp_path, 2, "--parity-sample", os.path.join(GOLDEN_DIR, "bench_sample_c3.npz"), timeout=1500)
+    assert line["n_gpus"] == 2 and [r["blocks"] for r in line["ranks"]] == [128, 128]
     assert line["table_sha1"] == C3_DIGEST and line["blobs"] == 292044
     assert line["parity_sample_identical"] is True and "committed" in line["parity_sample_source"]
     assert line["scaling"] == "strong" and line["roofline"] is not None
