@@ -147,12 +147,13 @@ def physical_cores() -> int:
 
 
 def source_digest() -> str:
-    """SHA-1 over the kernel sources the library is built from: the committed counter passes name the digest they
-    were taken with, and a line only quotes them while the sources are still those."""
+    """SHA-1 over the DEVICE sources the library is built from (kernels, their headers, the Makefile's flags; not
+    the host-only table code ``mmx_host.cpp``, which no counter of a kernel depends on): the committed counter
+    passes name the digest they were taken with, and a line only quotes them while the sources are still those."""
     h = hashlib.sha1()
     src = os.path.join(ROOT, "magellanmapper_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".inc", ".h", ".cpp")) or name == "Makefile":
+        if (name.endswith((".hip", ".inc", ".h", ".cpp")) and name != "mmx_host.cpp") or name == "Makefile":
             h.update(name.encode())
             h.update(open(os.path.join(src, name), "rb").read())
     return h.hexdigest()
@@ -316,6 +317,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     def finish(pruned):
         if pruned is None:
             return None, None
+        if isinstance(pruned, stack_detect._FinalTable):       # the pruning step wrote the final columns itself
+            detector.Blobs(None).cols = list(pruned.col_names)
+            return pruned.view(np.ndarray), None
         bb = detector.Blobs(pruned)              # the table's final form (reference stack_detect.py:458-467)
         bb.replace_rel_with_abs_blob_coords(pruned)
         colocs = pruned[:, 10:10 + n_chl].astype(np.uint8) if coloc else None
@@ -334,9 +338,10 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         t_b = time.perf_counter()
         final = colocs = None
         if rank == 0 or getattr(seg, "local_only", False):
+            # (final_form: as stack_detect._StackRun asks for it -- one process, no co-localisation columns)
             pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
                 vol, seg, blk.overlap, blk.tol, blk.sub_roi_slices, blk.sub_rois_offsets,
-                channels, blk.overlap_padding)
+                channels, blk.overlap_padding, final_form=not coloc and dist.world_size() == 1)
             if rank == 0:
                 final, colocs = finish(pruned)
         t_c = time.perf_counter()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 13
+#define MMX_ABI_VERSION 14
 
 typedef enum {
     MMX_OK = 0,
@@ -527,6 +527,16 @@ int mmx_host_prune_axis(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
  * `blobs_all[:, :-3]` after pruning, stack_detect.py:858-861).  table: float64, row pitch ld. */
 int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int64_t n,
                        int64_t n_cols, const double* abs_zyx, const int32_t abs_cols[3], double* out);
+/* ... and with the reference's last two steps on the pruned table folded in (magmap/cv/stack_detect.py:455-470:
+ * `replace_rel_with_abs_blob_coords`, `remove_abs_blob_coords(True)` -- two more passes over the whole table when made
+ * afterwards): out[i][j] = table[rows[i]][src_cols[j]], j < n_out (3..64), then out[i][abs_dst0 .. abs_dst0 + 3] =
+ * abs_zyx[rows[i]].  mmx_host_gather_by_key_final: the same for mmx_host_gather_by_key (abs_rows[i]). */
+int mmx_host_take_rows_final(const double* table, int64_t ld, const int64_t* rows, int64_t n,
+                             const int32_t* src_cols, int32_t n_out, const double* abs_zyx, int32_t abs_dst0,
+                             double* out);
+int mmx_host_gather_by_key_final(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
+                                 int64_t n_keys, const int32_t* src_cols, int32_t n_out, const double* abs_rows,
+                                 int32_t abs_dst0, double* out);
 
 /* All three axis passes of the pruning for one REGION of the stack (the whole stack, one rank's blocks, or a group
  * of blocks pruned while the GPU still works on later ones): a table holding the region's own rows (ids
@@ -594,9 +604,10 @@ int mmx_host_map_columns(const double* table, int64_t ld, int64_t n, const int32
  *   replaces: `image == maximum_filter(image)` & `image > threshold`, np.nonzero, argsort(-values) of
  *   skimage.feature.peak_local_max (skimage/feature/peak.py:9-50) for the candidates of one batch.
  *   cands[0, n_cands) candidates, cands[n_cands, n_total) probes (mmx_expand_probes), all re-scored.
- *   out_nz_coords/out_nz_vals: per block the peaks in np.nonzero order ([z, y, x, sigma index] int32, float64);
- *   out_coords/out_vals: the same rows by descending value, equal values in nonzero order; offsets[n_blocks + 1];
+ *   out_coords/out_vals: per block the peaks ([z, y, x, sigma index] int32, float64) by descending value, equal
+ *   values in np.nonzero order; offsets[n_blocks + 1];
  *   ties[b] = 1 when block b holds two equal values (np.argsort's order of equal keys is its own: ask NumPy);
+ *   out_nz_coords/out_nz_vals: the same rows in np.nonzero order -- written for the blocks with ties[b] == 1 only;
  *   stats[4]: contested candidates, peaks, max |float32 - float64| (inf when a value is not finite: nothing else
  *   is then written), blocks dropped as constant cubes (peak.py:41-43).
  * mmx_host_overlap_prune: skimage.feature.blob._prune_blobs (blob.py:84-187) on those peaks: `alive` per row, final

@@ -17,6 +17,7 @@
 //   check rows, each group in the current table order.
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -40,6 +41,11 @@ namespace {
 // fork(): the child inherits the pool object but none of its threads (the reference's default start method is
 // "fork"), so a parallel section there would wait for workers that do not exist.  The pool remembers the pid it
 // was built in; in any other process every section runs on the calling thread.
+// Waking: a small stack's sections are 20-100 us of work each and come in chains (resolve, overlap prune, tables,
+// pruning: half a dozen within a few hundred microseconds), and a condition-variable wake-up of sixteen sleepers cost
+// as much as the section (measured on a 4-block stack: the resolve step 0.20 ms with 16 threads, 0.13 with 4).  The
+// workers therefore keep polling the section counter for `spin_us_` (150 us where there are cores to spare) after their last section before they go to sleep,
+// and the caller polls the completion counter for as long before it does.
 class pool {
 public:
     static pool& get() { static pool p; return p; }
@@ -49,17 +55,41 @@ public:
     {
         if (n <= 1) { fn(0, 1); return; }
         std::unique_lock<std::mutex> serial(serial_);          // one section at a time
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn; n_ = n; pending_ = n - 1; ++epoch_;
+        fn_.store(&fn);
+        pending_.store(n - 1);
+        // (section number and thread count change together: a worker always pairs a section with ITS thread count)
+        state_.store(((state_.load() >> 8) + 1) << 8 | (uint64_t)n);
+        if (sleepers_.load() > 0) {
+            // (a worker that has counted itself a sleeper holds m_ until it waits: taking the lock orders this
+            //  notification after its wait has begun)
+            { std::lock_guard<std::mutex> lk(m_); }
+            cv_.notify_all();
         }
-        cv_.notify_all();
         fn(0, n);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = nullptr;
+        if (pending_.load() != 0) {
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_);
+            for (int k = 0; spin_us_ && pending_.load() != 0; ++k) {
+                relax();
+                if ((k & 63) == 63 && std::chrono::steady_clock::now() > until) break;
+            }
+            if (pending_.load() != 0) {
+                std::unique_lock<std::mutex> lk(m_);
+                caller_sleeps_.store(true);
+                done_.wait(lk, [&] { return pending_.load() == 0; });
+                caller_sleeps_.store(false);
+            }
+        }
+        fn_.store(nullptr);
     }
 private:
+    static void relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     pool()
     {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -68,6 +98,11 @@ private:
         const unsigned cap = env ? (unsigned)std::max(1, std::min(64, atoi(env))) : 16u;
         const int n = (int)std::max(1u, std::min(cap, hw ? hw : 1u));
         owner_ = getpid();
+        // (polling needs cores to spare: with as many pool threads as cores -- an 8-core container -- any other runnable
+        //  thread preempts a poller or a worker and the section waits a scheduler slice for it: measured 3.2 against
+        //  0.5 ms per back-to-back section there; MMX_HOST_SPIN_US overrides, 0 = always sleep)
+        const char* spin = getenv("MMX_HOST_SPIN_US");
+        spin_us_ = spin ? std::max(0, std::min(10000, atoi(spin))) : (hw >= 2u * (unsigned)n ? 150 : 0);
         for (int t = 1; t < n; ++t) workers_.emplace_back([this, t] { loop(t); });
     }
     ~pool()
@@ -76,38 +111,52 @@ private:
             for (auto& w : workers_) w.detach();
             return;
         }
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
+        stop_.store(true);
+        state_.store(((state_.load() >> 8) + 1) << 8);          // (a section for nobody)
+        { std::lock_guard<std::mutex> lk(m_); }
         cv_.notify_all();
         for (auto& w : workers_) w.join();
     }
     void loop(int t)
     {
-        uint64_t seen = 0;
+        uint64_t seen = 0;              // the last section number this worker has looked at
         for (;;) {
-            const std::function<void(int, int)>* fn = nullptr;
-            int n = 0;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return epoch_ != seen; });
-                seen = epoch_;
-                if (stop_) return;
-                if (t < n_) { fn = fn_; n = n_; }
+            // ---- the next section: poll for a while, then sleep
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_);
+            for (int k = 0; spin_us_ && (state_.load() >> 8) == seen; ++k) {
+                relax();
+                if ((k & 63) == 63 && std::chrono::steady_clock::now() > until) break;
             }
-            if (fn) {
-                (*fn)(t, n);
-                std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) done_.notify_one();
+            if ((state_.load() >> 8) == seen) {
+                std::unique_lock<std::mutex> lk(m_);
+                sleepers_.fetch_add(1);
+                cv_.wait(lk, [&] { return (state_.load() >> 8) != seen; });
+                sleepers_.fetch_sub(1);
+            }
+            const uint64_t st = state_.load();
+            seen = st >> 8;
+            if (stop_.load()) return;
+            const int n = (int)(st & 0xff);
+            // (a section this worker has no part in may be over already -- it then finds the next one at once; a
+            //  section that counts on it cannot end, nor fn_ change, before it has reported)
+            if (t >= n) continue;
+            const std::function<void(int, int)>* fn = fn_.load();
+            (*fn)(t, n);
+            if (pending_.fetch_sub(1) == 1 && caller_sleeps_.load()) {
+                { std::lock_guard<std::mutex> lk(m_); }
+                done_.notify_one();
             }
         }
     }
     std::vector<std::thread> workers_;
     pid_t owner_ = 0;
+    int spin_us_ = 0;
     std::mutex m_, serial_;
     std::condition_variable cv_, done_;
-    const std::function<void(int, int)>* fn_ = nullptr;
-    int n_ = 0, pending_ = 0;
-    uint64_t epoch_ = 0;
-    bool stop_ = false;
+    std::atomic<const std::function<void(int, int)>*> fn_{nullptr};
+    std::atomic<int> pending_{0}, sleepers_{0};
+    std::atomic<uint64_t> state_{0};                // section number << 8 | threads of the section
+    std::atomic<bool> stop_{false}, caller_sleeps_{false};
 };
 
 template <typename F>
@@ -534,6 +583,39 @@ extern "C" int mmx_host_gather_by_key(const double* table, int64_t ld, const int
     return MMX_OK;
 }
 
+// The same merge with the table leaving in the caller's FINAL column layout (the reference's last two steps on the
+// pruned table, magmap/cv/stack_detect.py:455-470: rel <- abs, abs and unnamed columns dropped -- two more passes over
+// a 3e5-row table when done afterwards): out[k][j] = table[ids][src_cols[j]], then out[k][abs_dst0 .. +3] = abs_rows.
+extern "C" int mmx_host_gather_by_key_final(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys,
+                                            int64_t n, int64_t n_keys, const int32_t* src_cols, int32_t n_out,
+                                            const double* abs_rows, int32_t abs_dst0, double* out)
+{
+    if (n < 0 || n_keys < 1 || n_out < 3 || n_out > 64 || !src_cols || abs_dst0 < 0 || abs_dst0 + 3 > n_out ||
+        (n && (!table || !ids || !keys || !out || !abs_rows)))
+        return MMX_ERR_ARG;
+    if (n_keys > (int64_t(1) << 26)) return MMX_ERR_UNSUPPORTED;
+    for (int j = 0; j < n_out; ++j)
+        if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
+    std::vector<int64_t> at((size_t)n_keys + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (keys[i] < 0 || keys[i] >= n_keys || ids[i] < 0) return MMX_ERR_ARG;
+        ++at[(size_t)keys[i] + 1];
+    }
+    for (int64_t k = 0; k < n_keys; ++k) at[(size_t)k + 1] += at[(size_t)k];
+    std::vector<int64_t> dst((size_t)n);
+    for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = at[(size_t)keys[i]]++;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            double* o = out + dst[(size_t)i] * n_out;
+            const double* src = table + ids[i] * ld;
+            for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
+            for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_rows[3 * i + a];
+        }
+    });
+    return MMX_OK;
+}
+
 // Rows of a table that lie inside ANY of `n_boxes` boxes [lo, hi): what a rank sends to the ranks whose blocks its
 // rows can influence (the distributed pruning's first exchange), ten values a row -- detection coordinates, block
 // tags, absolute coordinates, channel.  out: [cap][10] float64; *out_n keeps counting past cap.
@@ -663,6 +745,30 @@ extern "C" int mmx_host_take_rows(const double* table, int64_t ld, const int64_t
     return MMX_OK;
 }
 
+// mmx_host_take_rows with the table leaving in the caller's final column layout (see mmx_host_gather_by_key_final):
+// out[i][j] = table[rows[i]][src_cols[j]], then out[i][abs_dst0 .. +3] = abs_zyx[rows[i]].
+extern "C" int mmx_host_take_rows_final(const double* table, int64_t ld, const int64_t* rows, int64_t n,
+                                        const int32_t* src_cols, int32_t n_out, const double* abs_zyx,
+                                        int32_t abs_dst0, double* out)
+{
+    if (!table || (!rows && n) || !out || n < 0 || n_out < 3 || n_out > 64 || !src_cols || !abs_zyx || abs_dst0 < 0 ||
+        abs_dst0 + 3 > n_out)
+        return MMX_ERR_ARG;
+    for (int j = 0; j < n_out; ++j)
+        if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t r = rows[i];
+            double* o = out + i * n_out;
+            const double* src = table + r * ld;
+            for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
+            for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_zyx[3 * r + a];
+        }
+    });
+    return MMX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // mmx_host_lsap -- rectangular linear sum assignment (minimum total cost, every row of the shorter side assigned),
 // what the reference's match-based co-localisation gets from scipy.optimize.linear_sum_assignment
@@ -787,7 +893,8 @@ static_assert(sizeof(cand_rec) == 48 && sizeof(cand_rec) == sizeof(mmx_cand), "m
 
 // Exact peak membership and the reference's two orders.
 //   cands[0, n_cands): candidates; cands[n_cands, n_total): probes (band = index of the candidate they may out-vote)
-//   out_nz_* : the peaks of every block in np.nonzero order (C order of the (z, y, x, sigma) cube)
+//   out_nz_* : the peaks in np.nonzero order (C order of the (z, y, x, sigma) cube) -- filled for the blocks whose
+//              `ties` flag is set only (nobody else needs that order)
 //   out_*    : the same rows per block by descending value (stable: equal values keep the nonzero order)
 //   offsets  : [n_blocks + 1] row ranges of the blocks in both
 //   ties     : [n_blocks] 1 when two peaks of the block have EQUAL values -- np.argsort's order of equal keys is
@@ -889,30 +996,43 @@ extern "C" int mmx_host_resolve_peaks(const mmx_cand* cands_, uint32_t n_cands, 
             rows[(size_t)at[(size_t)b]++] = std::make_pair(key[i], i);
         }
     }
+    // per block: ONE sort, by descending value and -- for equal values -- ascending cube position, which is what a stable
+    // sort of the np.nonzero rows by value gives; the np.nonzero order itself is only needed where values tie (the
+    // caller then asks NumPy for its order of them): that block is sorted a second time
     parallel(std::min(T, n_blocks), [&](int t, int nt) {
-        std::vector<uint32_t> order;
+        struct row { double v; int64_t key; uint32_t cand; };
+        std::vector<row> rs;
         for (int b = t; b < n_blocks; b += nt) {
             const int64_t lo = offsets[b], hi = offsets[b + 1];
             if (lo == hi) continue;
-            std::sort(rows.begin() + lo, rows.begin() + hi);          // a voxel appears once: keys are unique
-            order.resize((size_t)(hi - lo));
+            rs.resize((size_t)(hi - lo));
             for (int64_t r = lo; r < hi; ++r) {
-                const cand_rec& c = cands[rows[(size_t)r].second];
-                int32_t* o = out_nz_coords + 4 * r;
-                o[0] = c.z; o[1] = c.y; o[2] = c.x; o[3] = c.s;
-                out_nz_vals[r] = c.v64;
-                order[(size_t)(r - lo)] = (uint32_t)(r - lo);
+                const uint32_t ci = rows[(size_t)r].second;
+                rs[(size_t)(r - lo)] = row{cands[ci].v64, rows[(size_t)r].first, ci};
             }
-            const double* v = out_nz_vals + lo;
-            std::stable_sort(order.begin(), order.end(), [v](uint32_t a, uint32_t b2) { return v[a] > v[b2]; });
+            std::sort(rs.begin(), rs.end(), [](const row& a, const row& b2) {
+                return a.v > b2.v || (a.v == b2.v && a.key < b2.key);          // a voxel appears once: keys are unique
+            });
             uint8_t tie = 0;
             for (int64_t r = lo; r < hi; ++r) {
-                const int64_t src = lo + order[(size_t)(r - lo)];
-                std::memcpy(out_coords + 4 * r, out_nz_coords + 4 * src, 4 * sizeof(int32_t));
-                out_vals[r] = out_nz_vals[src];
-                if (r > lo && out_vals[r] == out_vals[r - 1]) tie = 1;
+                const row& q = rs[(size_t)(r - lo)];
+                const cand_rec& c = cands[q.cand];
+                int32_t* o = out_coords + 4 * r;
+                o[0] = c.z; o[1] = c.y; o[2] = c.x; o[3] = c.s;
+                out_vals[r] = q.v;
+                if (r > lo && q.v == rs[(size_t)(r - lo - 1)].v) tie = 1;
             }
             ties[b] = tie;
+            if (tie) {
+                std::sort(rs.begin(), rs.end(), [](const row& a, const row& b2) { return a.key < b2.key; });
+                for (int64_t r = lo; r < hi; ++r) {
+                    const row& q = rs[(size_t)(r - lo)];
+                    const cand_rec& c = cands[q.cand];
+                    int32_t* o = out_nz_coords + 4 * r;
+                    o[0] = c.z; o[1] = c.y; o[2] = c.x; o[3] = c.s;
+                    out_nz_vals[r] = q.v;
+                }
+            }
         }
     });
     return MMX_OK;
@@ -953,10 +1073,15 @@ extern "C" int mmx_host_overlap_prune(const int32_t* coords, const int32_t* offs
     const int T = n < 2000 ? 1 : std::min(pool::get().size(), 16);
     struct found { int32_t i, j; double f; };
     std::vector<std::vector<found>> per_thread((size_t)T);
-    parallel(std::min(T, n_blocks), [&](int t, int nt) {
+    // (few blocks -- a small stack -- : each block's blobs are dealt to `parts` threads, every one of which builds the
+    //  block's cell lists for itself: ~5 % of the pair search it shares)
+    const int parts = T > n_blocks ? std::min(8, T / n_blocks) : 1;
+    const int n_items = n_blocks * parts;
+    parallel(std::min(T, n_items), [&](int t, int nt) {
         std::vector<int32_t> cell_of, start, sorted;
         auto& out = per_thread[(size_t)t];
-        for (int b = t; b < n_blocks; b += nt) {
+        for (int item = t; item < n_items; item += nt) {
+            const int b = item / parts, part = item % parts;
             const int32_t lo = offsets[b], hi = offsets[b + 1];
             const int m = hi - lo;
             if (m < 2) continue;
@@ -983,7 +1108,7 @@ extern "C" int mmx_host_overlap_prune(const int32_t* coords, const int32_t* offs
                 std::vector<int32_t> at(start.begin(), start.end() - 1);
                 for (int k = 0; k < m; ++k) sorted[(size_t)at[(size_t)cell_of[(size_t)k]]++] = k;
             }
-            for (int i = 0; i < m; ++i) {
+            for (int i = part; i < m; i += parts) {          // (interleaved: blob i meets only the blobs after it)
                 const int32_t* ci = coords + 4 * (int64_t)(lo + i);
                 const double zi = ci[0], yi = ci[1], xi = ci[2], si = sigmas[ci[3]];
                 const int cz = (int)(ci[0] / cell), cy = (int)(ci[1] / cell), cx = (int)(ci[2] / cell);
@@ -1095,7 +1220,8 @@ extern "C" int mmx_host_emit_tables(const int32_t* coords, const uint8_t* alive,
     }
     if (first[(size_t)n_blocks] > capacity) return MMX_ERR_WORKSPACE;
     const double root3 = std::sqrt(3.0);
-    const int T = n < 4000 ? 1 : std::min(pool::get().size(), 16);
+    // (block b on thread b mod T, as in the resolve step that wrote its rows: they are in that core's cache)
+    const int T = n < 2000 ? 1 : std::min(pool::get().size(), 16);
     parallel(std::min(T, n_blocks), [&](int t, int nt) {
         for (int b = t; b < n_blocks; b += nt) {
             int64_t at = first[(size_t)b];

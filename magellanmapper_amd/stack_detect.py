@@ -354,8 +354,9 @@ class _RegionPruner:
             if not f.cancelled():
                 f.result()
 
-    def finish(self, abs_inds):
-        """Whatever is left, then the merge: ``(final table, counts)``."""
+    def finish(self, abs_inds, final=None):
+        """Whatever is left, then the merge: ``(final table, counts)``.  ``final = (source columns, place of the abs
+        coordinates)``: the table in those columns (``StackPruner._final_columns``)."""
         if self.pending:            # (everything has landed by now)
             todo, self.pending = self.pending, []
             pool = self._workers()
@@ -372,6 +373,14 @@ class _RegionPruner:
         abs_rows = np.ascontiguousarray(np.concatenate([d[2] for d in self.done]), dtype=np.float64)
         counts = sum(d[3] for d in self.done)
         ncol = ar.store.shape[1] - 3
+        if final is not None:
+            src, dst0 = final
+            out = np.empty((len(ids), len(src)))
+            nat.check(nat.lib().mmx_host_gather_by_key_final(
+                ar.store.ctypes.data, ar.store.strides[0] // 8, ids.ctypes.data, keys.ctypes.data, len(ids),
+                self.plan["n_keys"] * len(self.channels), (ctypes.c_int32 * len(src))(*src), len(src),
+                abs_rows.ctypes.data, dst0, out.ctypes.data), "mmx_host_gather_by_key_final")
+            return out, counts
         out = np.empty((len(ids), ncol))
         cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
         nat.check(nat.lib().mmx_host_gather_by_key(
@@ -379,6 +388,12 @@ class _RegionPruner:
             self.plan["n_keys"] * len(self.channels), ncol, abs_rows.ctypes.data, cols3, out.ctypes.data),
             "mmx_host_gather_by_key")
         return out, counts
+
+
+class _FinalTable(np.ndarray):
+    """A pruned table that left ``StackPruner.prune_blobs_mp(..., final_form=True)`` already in the reference's final
+    columns (rel <- abs, abs and unnamed columns dropped): ``col_names`` are the columns it holds."""
+    col_names = None
 
 
 class _SegRois(np.ndarray):
@@ -766,8 +781,11 @@ class _StackRun:
 
     def _prune_here(self):
         bk = self.blocks
+        from . import dist
+        # (one process, no co-localisation columns: the table may come back in its final columns, see finish())
         return StackPruner.prune_blobs_mp(self.roi, self.seg_rois, bk.overlap, bk.tol, bk.sub_roi_slices,
-                                          bk.sub_rois_offsets, self.channels, bk.overlap_padding)
+                                          bk.sub_rois_offsets, self.channels, bk.overlap_padding,
+                                          final_form=not self.coloc and dist.world_size() == 1)
 
     def prune(self):
         """The merged, pruned table on every rank.  One rank: a plain call.  Several ranks: either the tables stayed
@@ -797,14 +815,21 @@ class _StackRun:
         root = dist.rank() == 0
         if root and self.save_dfs and self.ratios is not None and len(self.ratios):
             _save_pruning_ratios(self.ratios)
-        blobs = detector.Blobs(self.table, path=_combine_paths(self.path_base, config.SUFFIX_BLOBS))
         final, flags = self.table, None
-        if final is not None:
-            blobs.replace_rel_with_abs_blob_coords(final)
-            blobs.blobs = final
-            if self.coloc:
-                flags = final[:, 10:10 + self.n_roi_channels].astype(np.uint8)
-            final = blobs.remove_abs_blob_coords(True)
+        path = _combine_paths(self.path_base, config.SUFFIX_BLOBS)
+        if isinstance(final, _FinalTable):
+            # the pruning step wrote the final columns itself; the column registry ends as the two steps below leave it
+            blobs = detector.Blobs(None, path=path)
+            blobs.cols = list(final.col_names)
+            final = final.view(np.ndarray)
+        else:
+            blobs = detector.Blobs(final, path=path)
+            if final is not None:
+                blobs.replace_rel_with_abs_blob_coords(final)
+                blobs.blobs = final
+                if self.coloc:
+                    flags = final[:, 10:10 + self.n_roi_channels].astype(np.uint8)
+                final = blobs.remove_abs_blob_coords(True)
         if config.save_subimg and root:
             _save_subimage(_combine_paths(self.path_base, config.SUFFIX_SUBIMG), self.volume, self.roi)
         blobs.blobs, blobs.colocalizations = final, flags
@@ -1140,9 +1165,42 @@ class StackPruner:
         return ratios_all
 
     @staticmethod
-    def _take_rows(merged, rows, abs_cur, abs_inds):
-        """``merged[rows][:, :-3]`` with the three abs columns taken from ``abs_cur[rows]``."""
+    def _final_columns(merged, abs_inds):
+        """What the reference's last two steps on the pruned table (``replace_rel_with_abs_blob_coords``, then
+        ``remove_abs_blob_coords(True)``, :455-470) leave of the merged table's columns, for the gather to write
+        directly: ``(source columns, place of the abs coordinates among them, their names)`` -- or ``None`` where the
+        two steps do not reduce to that (co-localisation columns behind the named ones, an unusual registry, a table
+        the native gather does not take)."""
+        if not (merged.dtype == np.float64 and merged.strides[1] == 8 and merged.strides[0] % 8 == 0):
+            return None
+        registry = detector.Blobs._col_inds
+        named = [(c, i) for c, i in registry.items() if i is not None]
+        if merged.shape[1] - 3 != len(named) or sorted(i for _, i in named) != list(range(len(named))):
+            return None                 # (columns beyond the named ones: the co-localisation flags are read from them)
+        rel = detector.Blobs._get_rel_inds()
+        drop = set(abs_inds)
+        keep = [(c, i) for c, i in named if i not in drop]
+        src = [i for _, i in keep]
+        if any(r is None for r in rel) or rel[0] not in src:
+            return None
+        dst0 = src.index(rel[0])
+        if src[dst0:dst0 + 3] != list(rel):
+            return None
+        return src, dst0, [c.value for c, _ in keep]
+
+    @staticmethod
+    def _take_rows(merged, rows, abs_cur, abs_inds, final=None):
+        """``merged[rows][:, :-3]`` with the three abs columns taken from ``abs_cur[rows]``; with ``final = (source
+        columns, place of the abs coordinates)`` the table in those columns instead (:meth:`_final_columns`)."""
         ncol = merged.shape[1]
+        if final is not None:
+            src, dst0 = final
+            out = np.empty((len(rows), len(src)))
+            nat.check(nat.lib().mmx_host_take_rows_final(
+                merged.ctypes.data, merged.strides[0] // 8, rows.ctypes.data, len(rows),
+                (ctypes.c_int32 * len(src))(*src), len(src), abs_cur.ctypes.data, dst0, out.ctypes.data),
+                "mmx_host_take_rows_final")
+            return out
         if merged.dtype == np.float64 and merged.strides[1] == 8 and merged.strides[0] % 8 == 0:
             out = np.empty((len(rows), ncol - 3))
             cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
@@ -1347,14 +1405,16 @@ class StackPruner:
 
     @classmethod
     def prune_blobs_mp(cls, img, seg_rois, overlap, tol, sub_roi_slices, sub_rois_offsets,
-                       channels, overlap_padding=None):
+                       channels, overlap_padding=None, final_form: bool = False):
         """Prune duplicates in the overlap slabs, per channel, axis by axis (:679-861).
 
         For every axis with more than one block, every block boundary ``j | j+1`` defines a
         slab ``[end_j - (overlap + pad), end_j + pad)`` spanning the whole plane; blobs in it
         are de-duplicated between the two block generations (:meth:`prune_overlap`),
         everything else passes through, and the recombined table goes on to the next axis.
-        Returns ``(table, DataFrame)`` or ``(None, None)``.
+        Returns ``(table, DataFrame)`` or ``(None, None)``.  ``final_form`` (not in the reference; ``_StackRun`` asks
+        for it): where possible the table comes back as a :class:`_FinalTable`, already in the columns the reference's
+        next two steps would leave (rel <- abs, abs dropped) -- two passes over the whole table less.
 
         Same results and row order as the reference, but rows are tracked as indices into the
         merged table (only the 3 abs columns ever change), so the big table is gathered once, and
@@ -1411,9 +1471,11 @@ class StackPruner:
         ncol = merged.shape[1]
         detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
         abs_inds = detector.Blobs._get_abs_inds()
+        final = cls._final_columns(merged, abs_inds) if final_form else None
+        gather_as = None if final is None else final[:2]
         # regions of this very call finished while the GPU was still detecting (StackDetector.plan_pruning)
         if early is not None and arena is not None and early.matches(arena, plan, channels):
-            out, counts = early.finish(abs_inds)
+            out, counts = early.finish(abs_inds, gather_as)
             _lap("regions pruned during detection: the rest + merge")
         else:
             if early is not None:       # other parameters than planned for, or tables edited since: not usable
@@ -1435,11 +1497,16 @@ class StackPruner:
             rows, _, counts = cls._prune_table(zyx, tags, abs_cur, None if one_channel else chan, 0, len(zyx),
                                                channels, plan)
             _lap("three axis passes")
-            out = cls._take_rows(merged, rows, abs_cur, abs_inds)
+            out = cls._take_rows(merged, rows, abs_cur, abs_inds, gather_as)
             _lap("gather of the output table")
+        if final is not None:
+            out = out.view(_FinalTable)
+            out.col_names = final[2]
         df = cls._ratio_frame(cls._ratios_from_counts(counts, plan))
         _lap("ratio frame")
         return out, df
+
+    _frame_names: dict = {}
 
     @staticmethod
     def _ratio_frame(ratios):
@@ -1447,4 +1514,16 @@ class StackPruner:
         inference of the dict-of-lists constructor: half the time of a small stack's whole pruning step."""
         import pandas as pd
         cols = {k: np.asarray(v, dtype=np.int64 if k == "blobs" else np.float64) for k, v in ratios.items()}
+        # (the frame from ready-made columns: a third of the dict constructor's time, which in turn is what a small
+        #  stack's pruning step spends most on; a pandas without that constructor takes the public one)
+        n_rows = {len(v) for v in cols.values()}
+        if len(n_rows) == 1:
+            names = StackPruner._frame_names.get(tuple(cols))
+            if names is None:           # (the column index is immutable: made once per set of names)
+                names = StackPruner._frame_names[tuple(cols)] = pd.Index(list(cols))
+            try:
+                return pd.DataFrame._from_arrays(list(cols.values()), names, pd.RangeIndex(n_rows.pop()),
+                                                 verify_integrity=False)
+            except (AttributeError, TypeError):
+                pass
         return pd.DataFrame(cols, copy=False)

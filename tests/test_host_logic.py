@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import math
 import numpy as np
 import pytest
 
@@ -518,6 +519,51 @@ def test_map_columns_native_matches_numpy():
     assert lib.mmx_host_map_columns(t.ctypes.data, 4, 4, cols, 2, t.ctypes.data, 4, 0) == 1     # bad column
 
 
+def test_native_gathers_in_final_columns():
+    """mmx_host_take_rows_final / mmx_host_gather_by_key_final: out[i][j] = table[row][src_cols[j]], the abs
+    coordinates written at abs_dst0 -- against NumPy, on a table large enough for the threaded path; bad arguments
+    are refused."""
+    from magellanmapper_amd import _native as nat
+    L = nat.lib()
+    rng = np.random.default_rng(21)
+    n_table, n, ld = 50000, 30000, 14
+    table = rng.random((n_table, ld))
+    rows = rng.permutation(n_table)[:n].astype(np.int64)
+    absz = rng.random((n_table, 3))
+    src = [0, 1, 2, 3, 4, 5, 6, 10]
+    csrc = (ctypes.c_int32 * len(src))(*src)
+    out = np.empty((n, len(src)))
+    nat.check(L.mmx_host_take_rows_final(table.ctypes.data, ld, rows.ctypes.data, n, csrc, len(src), absz.ctypes.data, 0,
+                                         out.ctypes.data), "take_rows_final")
+    want = table[rows][:, src]
+    want[:, 0:3] = absz[rows]
+    np.testing.assert_array_equal(out, want)
+    # by key: rows land in key order, equal keys in input order; abs_rows run with the input
+    keys = rng.integers(0, 97, n).astype(np.int64)
+    abs_rows = rng.random((n, 3))
+    out2 = np.empty((n, len(src)))
+    nat.check(L.mmx_host_gather_by_key_final(table.ctypes.data, ld, rows.ctypes.data, keys.ctypes.data, n, 97, csrc,
+                                             len(src), abs_rows.ctypes.data, 0, out2.ctypes.data), "gather_by_key_final")
+    order = np.argsort(keys, kind="stable")
+    want2 = table[rows[order]][:, src]
+    want2[:, 0:3] = abs_rows[order]
+    np.testing.assert_array_equal(out2, want2)
+    # ... and equal to the two-step form: gather in the table's columns, then the column shuffles
+    cols3 = (ctypes.c_int32 * 3)(7, 8, 9)
+    full = np.empty((n, ld - 3))
+    nat.check(L.mmx_host_gather_by_key(table.ctypes.data, ld, rows.ctypes.data, keys.ctypes.data, n, 97, ld - 3,
+                                       abs_rows.ctypes.data, cols3, full.ctypes.data), "gather_by_key")
+    full[:, 0:3] = full[:, 7:10]
+    np.testing.assert_array_equal(out2, full[:, src])
+    bad = (ctypes.c_int32 * 3)(0, 1, 99)
+    assert L.mmx_host_take_rows_final(table.ctypes.data, ld, rows.ctypes.data, n, bad, 3, absz.ctypes.data, 0,
+                                      out.ctypes.data) == 1
+    assert L.mmx_host_take_rows_final(table.ctypes.data, ld, rows.ctypes.data, n, csrc, len(src), absz.ctypes.data, 6,
+                                      out.ctypes.data) == 1                    # abs columns past the row
+    assert L.mmx_host_gather_by_key_final(table.ctypes.data, ld, rows.ctypes.data, keys.ctypes.data, n, 5, csrc,
+                                          len(src), abs_rows.ctypes.data, 0, out2.ctypes.data) == 1       # key >= n_keys
+
+
 def test_native_prune_works_in_a_forked_child():
     """The host thread pool lives in the dlopen'd library; after fork() its threads are gone (the reference's
     default start method is 'fork').  A table large enough for the threaded path must still prune in the child."""
@@ -877,6 +923,86 @@ def test_native_overlap_prune_matches_brute_force():
     assert n_open > 0          # (the trials do exercise the order-dependent case)
 
 
+def _big_peak_batch(rng, sizes, extent=110):
+    from magellanmapper_amd import blob_log as bl
+    offsets = np.concatenate(([0], np.cumsum(sizes))).astype(np.int32)
+    n = int(offsets[-1])
+    coords = np.empty((n, 4), dtype=np.int32)
+    coords[:, :3] = rng.integers(0, extent, (n, 3))
+    coords[:, 3] = rng.integers(0, 4, n)
+    return bl.PeakBatch(coords, rng.random(n), offsets)
+
+
+def test_native_overlap_prune_of_few_big_blocks_splits_each_block_over_threads():
+    """A small stack's batch (2 blocks, thousands of peaks each): every block's pair search is dealt to several
+    threads (mmx_host.cpp: `parts`).  The pairs found equal those of SciPy's cKDTree + the reference's overlap
+    formula, and the flags are the sequential rule's on them."""
+    from scipy.spatial import cKDTree
+    from magellanmapper_amd import blob_log as bl
+    rng = np.random.default_rng(77)
+    space = bl.ScaleSpace.make(2.0, 5.0, 4)
+    pb = _big_peak_batch(rng, [2600, 0, 3100])
+    stats = bl.BatchStats()
+    pb = bl._prune_batch_native(pb, space, 0.5, stats)
+    allb = pb.coords.astype(np.float64)
+    allb[:, 3] = space.sigmas[pb.coords[:, 3]]
+    sig = allb[:, 3].copy()
+    n_over = 0
+    found = []
+    for b in range(len(pb)):
+        lo, hi = pb.offsets[b], pb.offsets[b + 1]
+        if hi - lo < 2:
+            continue
+        for i, j in cKDTree(allb[lo:hi, :3]).query_pairs(2 * 5.0 * math.sqrt(3)):
+            f = bl._exact_overlap(allb[lo + i], allb[lo + j])
+            if f > 0.5 - bl.OVERLAP_BAND:
+                found.append((lo + min(i, j), lo + max(i, j), f))
+                n_over += 1
+    assert n_over > 200 and stats.n_overlap_pairs == n_over
+    pairs = np.array([(i, j) for i, j, _ in found], dtype=np.int64)
+    frac = np.array([f for _, _, f in found])
+    bl._apply_pairs(allb, sig, pb.offsets, pairs, frac, 0.5, bl.BatchStats())
+    np.testing.assert_array_equal(pb.alive.astype(bool), sig > 0)
+
+
+def test_host_thread_pool_gives_the_same_answer_whether_its_workers_poll_or_sleep():
+    """The pool's workers poll for ~150 us after a section and sleep afterwards; the caller does the same while it
+    waits.  Sections spaced from back-to-back to a millisecond apart, from two Python threads at once: every call
+    returns what the first one did."""
+    import threading
+    import time as _time
+    from magellanmapper_amd import blob_log as bl
+    space = bl.ScaleSpace.make(2.0, 5.0, 4)
+    base = _big_peak_batch(np.random.default_rng(5), [1300, 1200], extent=200)      # (sparse: no order-dependent blocks)
+    want = bl._prune_batch_native(bl.PeakBatch(base.coords, base.vals, base.offsets), space, 0.5, bl.BatchStats())
+    want_alive = want.alive.copy()
+    assert 0 < want_alive.sum() < len(want_alive)
+    errors = []
+
+    def work(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for k in range(400):
+                st = bl.BatchStats()
+                got = bl._prune_batch_native(bl.PeakBatch(base.coords, base.vals, base.offsets), space, 0.5, st)
+                if not np.array_equal(got.alive, want_alive):
+                    errors.append(f"call {k} of thread {seed}")
+                    return
+                pause = (0.0, 0.0, 5e-5, 2e-4, 1e-3)[int(rng.integers(0, 5))]
+                if pause:
+                    _time.sleep(pause)
+        except Exception as exc:            # noqa: BLE001 -- reported below
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(s,)) for s in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not any(t.is_alive() for t in threads), "a parallel section never finished"
+    assert not errors, errors
+
+
 def test_native_table_emit_matches_the_python_tables():
     """mmx_host_emit_tables: 11 columns + tags + compact copies, block offsets, border exclusion, capacity check --
     against the table building of detector.detect_blobs_blocks_device + StackDetector._finish_block."""
@@ -1026,7 +1152,7 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case, monkeypatch):
     seg_b, pruner = build(True)
     merges = []
     merge = sd._RegionPruner.finish
-    monkeypatch.setattr(sd._RegionPruner, "finish", lambda self, cols: (merges.append(self), merge(self, cols))[1])
+    monkeypatch.setattr(sd._RegionPruner, "finish", lambda self, cols, final=None: (merges.append(self), merge(self, cols, final))[1])
     got, df_got = sd.StackPruner.prune_blobs_mp(Img, seg_b, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                  blocks.sub_rois_offsets, channels, blocks.overlap_padding)
     assert merges == [pruner] and not pruner.pending and all(d is not None for d in pruner.done)      # (it was used)
@@ -1036,6 +1162,26 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case, monkeypatch):
     np.testing.assert_array_equal(got, want)
     assert list(df_got.columns) == list(df_want.columns)
     np.testing.assert_array_equal(df_got.to_numpy(), df_want.to_numpy())
+    # final_form: the table comes back in the columns the reference's last two steps leave (rel <- abs, abs dropped),
+    # from the whole-table gather and from the regions' merge alike -- except with co-localisation columns behind the
+    # named ones, which those steps still have to read
+    def final_of(table):
+        bb = detector.Blobs(table.copy())
+        bb.replace_rel_with_abs_blob_coords(bb.blobs)
+        return bb.remove_abs_blob_coords(True), list(bb.cols)
+    want_final, want_cols = final_of(want)
+    for with_pruner in (False, True):
+        seg_f, _ = build(with_pruner)
+        got_f, df_f = sd.StackPruner.prune_blobs_mp(Img, seg_f, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                     blocks.sub_rois_offsets, channels, blocks.overlap_padding,
+                                                     final_form=True)
+        np.testing.assert_array_equal(df_f.to_numpy(), df_want.to_numpy())
+        if n_extra:
+            assert not isinstance(got_f, sd._FinalTable)
+            np.testing.assert_array_equal(got_f, want)
+        else:
+            assert isinstance(got_f, sd._FinalTable) and got_f.col_names == want_cols
+            np.testing.assert_array_equal(got_f.view(np.ndarray), want_final)
     # other parameters than planned for: the regions are ignored, the whole table is pruned
     seg_c, pruner_c = build(True)
     tol2 = np.asarray(blocks.tol) - 1
