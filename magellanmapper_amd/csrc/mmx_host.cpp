@@ -189,7 +189,8 @@ int prune_axis_impl(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
     if ((n_cur && (!zyx || !tag || !abs_zyx || !cur || !out_cur)) || !bounds || !tol || !out_n ||
         !n_slab || !n_after || !n_next || axis < 0 || axis > 2 || n_sections < 2 || n_cur < 0)
         return MMX_ERR_ARG;
-    static const bool prof = getenv("MMX_PRUNE_PROF") != nullptr;
+    // (MMX_PRUNE_PROF=2: the split of every axis step on stderr; any other value only turns the Python-side laps on)
+    static const bool prof = getenv("MMX_PRUNE_PROF") != nullptr && atoi(getenv("MMX_PRUNE_PROF")) >= 2;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto t0 = tnow();
     const int n_regions = 2 * n_sections - 1;

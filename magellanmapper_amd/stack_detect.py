@@ -354,7 +354,7 @@ class _RegionPruner:
             if not f.cancelled():
                 f.result()
 
-    def finish(self, abs_inds, final=None):
+    def finish(self, abs_inds, final=None, _lap=lambda what: None):
         """Whatever is left, then the merge: ``(final table, counts)``.  ``final = (source columns, place of the abs
         coordinates)``: the table in those columns (``StackPruner._final_columns``)."""
         if self.pending:            # (everything has landed by now)
@@ -364,6 +364,7 @@ class _RegionPruner:
         for f in self._futures:     # (an exception of a region surfaces here)
             f.result()
         self._futures = []
+        _lap("  regions: the last ones done")
         if self._pool is not None:
             self._pool.shutdown(wait=False)
             self._pool = None
@@ -372,6 +373,7 @@ class _RegionPruner:
         keys = np.ascontiguousarray(np.concatenate([d[1] for d in self.done]), dtype=np.int64)
         abs_rows = np.ascontiguousarray(np.concatenate([d[2] for d in self.done]), dtype=np.float64)
         counts = sum(d[3] for d in self.done)
+        _lap("  regions: survivors concatenated")
         ncol = ar.store.shape[1] - 3
         if final is not None:
             src, dst0 = final
@@ -1475,7 +1477,8 @@ class StackPruner:
         gather_as = None if final is None else final[:2]
         # regions of this very call finished while the GPU was still detecting (StackDetector.plan_pruning)
         if early is not None and arena is not None and early.matches(arena, plan, channels):
-            out, counts = early.finish(abs_inds, gather_as)
+            _lap("set-up (arena check, geometry, registry)")
+            out, counts = early.finish(abs_inds, gather_as, _lap)
             _lap("regions pruned during detection: the rest + merge")
         else:
             if early is not None:       # other parameters than planned for, or tables edited since: not usable

@@ -1152,7 +1152,7 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case, monkeypatch):
     seg_b, pruner = build(True)
     merges = []
     merge = sd._RegionPruner.finish
-    monkeypatch.setattr(sd._RegionPruner, "finish", lambda self, cols, final=None: (merges.append(self), merge(self, cols, final))[1])
+    monkeypatch.setattr(sd._RegionPruner, "finish", lambda self, cols, final=None, lap=lambda what: None: (merges.append(self), merge(self, cols, final, lap))[1])
     got, df_got = sd.StackPruner.prune_blobs_mp(Img, seg_b, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                  blocks.sub_rois_offsets, channels, blocks.overlap_padding)
     assert merges == [pruner] and not pruner.pending and all(d is not None for d in pruner.done)      # (it was used)

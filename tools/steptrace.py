@@ -78,10 +78,14 @@ def step():
                                                            None, None, False, [0])
     t = time.perf_counter()
     pruned, _ = stack_detect.StackPruner.prune_blobs_mp(dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
-                                                        blocks.sub_rois_offsets, [0], blocks.overlap_padding)
+                                                        blocks.sub_rois_offsets, [0], blocks.overlap_padding,
+                                                        final_form=True)
     log.append((t - T0[0], time.perf_counter() - T0[0], "StackPruner.prune_blobs_mp", ""))
     t = time.perf_counter()
-    bb = detector.Blobs(pruned); bb.replace_rel_with_abs_blob_coords(pruned); final = bb.remove_abs_blob_coords(True)
+    if isinstance(pruned, stack_detect._FinalTable):
+        detector.Blobs(None).cols = list(pruned.col_names); final = pruned.view(np.ndarray)
+    else:
+        bb = detector.Blobs(pruned); bb.replace_rel_with_abs_blob_coords(pruned); final = bb.remove_abs_blob_coords(True)
     log.append((t - T0[0], time.perf_counter() - T0[0], "final columns", ""))
     return final
 
