@@ -338,10 +338,11 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         t_b = time.perf_counter()
         final = colocs = None
         if rank == 0 or getattr(seg, "local_only", False):
-            # (final_form: as stack_detect._StackRun asks for it -- one process, no co-localisation columns)
+            # (final_form, untouched: as stack_detect._StackRun calls it -- one process and no co-localisation columns;
+            #  the tables come straight from the call above)
             pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
                 vol, seg, blk.overlap, blk.tol, blk.sub_roi_slices, blk.sub_rois_offsets,
-                channels, blk.overlap_padding, final_form=not coloc and dist.world_size() == 1)
+                channels, blk.overlap_padding, final_form=not coloc and dist.world_size() == 1, untouched=True)
             if rank == 0:
                 final, colocs = finish(pruned)
         t_c = time.perf_counter()
@@ -392,15 +393,28 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             tdist.barrier()
         torch.cuda.synchronize()
 
+    nat.timing_enable(True)             # (the warm-up tells which kernel family dominates: the one the roofline is about)
     for _ in range(warmup):
         one_step()
+    torch.cuda.synchronize()
+    warm = {k: ms for k, (ms, n) in nat.timing_read().items() if n and k in ALG_BYTES}
+    nat.timing_enable(False)
     for k in timers:
         timers[k] = 0.0
     # Volumes of a few blocks (c2): their one batch is replayed as a captured hipGraph (blob_log.GRAPH_BLOCKS), which the
     # per-kernel event timing would prevent -- a capture cannot hold its events.  The timed region then runs WITHOUT the
     # per-kernel timing, as a caller's step does, and the per-kernel times come from extra steps after it.
     replayed = world == 1 and 0 < n_blocks <= bl.GRAPH_BLOCKS and bl.NATIVE_BATCH and not PROFILE["denoise_size"]
-    nat.timing_enable(not replayed)
+    # Larger volumes: every kernel family records its HIP events inside the timed region (--kernel-events all, the
+    # default; `roofline` is the dominant family's live measurement over that region).  What those ~400 events per step
+    # cost was measured with --kernel-events dominant | none (only the dominant family's events inside the region |
+    # none, the other families timed in extra steps after it): 102.2 / 102.8 ms with all, 103.3 / 102.7 with the
+    # dominant family's, 102.2 / 102.1 with none, alternating on one box -- nothing beyond the run-to-run spread.
+    events = "none" if replayed else args.kernel_events
+    if events == "dominant" and not warm:
+        events = "all"                  # (no warm-up step to tell the dominant family from)
+    dominant = max(warm, key=warm.get) if events == "dominant" else None
+    nat.timing_enable(events != "none", kinds=None if events != "dominant" else [dominant])
     bl.PRE_WAITS.clear()
     replays0 = bl.GRAPH_REPLAYS
     barrier()
@@ -414,13 +428,16 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     n_replays = bl.GRAPH_REPLAYS - replays0
     pre_wait_ms = sum(a.elapsed_time(b) for a, b in bl.PRE_WAITS) / steps if bl.PRE_WAITS else None
     bl.PRE_WAITS.clear()
-    if replayed:
+    if events != "all":
+        timed = nat.timing_read() if events == "dominant" else {}
         extra = max(1, min(steps, 10))
         nat.timing_enable(True)
         for _ in range(extra):
             one_step()
         torch.cuda.synchronize()
         ktimes = {k: (ms * steps / extra, n * steps // extra) for k, (ms, n) in nat.timing_read().items()}
+        if dominant is not None and timed.get(dominant, (0.0, 0))[1]:
+            ktimes[dominant] = timed[dominant]          # (the timed region's own events)
     else:
         ktimes = nat.timing_read()
     nat.timing_enable(False)
@@ -562,6 +579,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         "dtype": ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate") if PROFILE["denoise_size"] is None
                  else "f64 preprocessing; " + ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate"),
         "zx_path": zx_path, "host_path": bl.HOST_PATH,
+        "kernel_events": {"in_timed_region": events if events != "dominant" else [dominant],
+                          "note": "kernel families whose HIP events were recorded inside the timed region (--kernel-events; "
+                                  "families not timed there are timed in extra steps after it)"},
         "graph_replay": (n_replays if replayed else None),
         "graph_replay_note": None if not replayed else (
             "graph_replay = batches of the timed region that were replayed from a captured hipGraph (no per-kernel events inside "
@@ -658,6 +678,9 @@ def main():
     ap.add_argument("--no-sub-records", action="store_true", help="default command: c3 only")
     ap.add_argument("--shape", type=int, nargs=3, default=None, help="z y x (default: the named config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-events", choices=("all", "dominant", "none"), default="all",
+                    help="which kernel families record HIP events inside the timed region (default: all; dominant / none: "
+                         "the roofline's kernel only / none, the others timed in extra steps after it)")
     ap.add_argument("--budget-gb", type=float, default=0.0,
                     help="workspace budget per batch (default: 16 GiB = 22 blocks of the benchmark geometry, less when "
                          "the free HBM of this rank's GPU does not allow it; larger batches are SLOWER: the host starts "

@@ -495,7 +495,9 @@ int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const
  * events, returns summed milliseconds and launch counts per kernel family (index =
  * MMX_K_*: 0 z pass, 1 y pass, 2 x pass, 3 generic passes, 4 peaks, 5 rescore,
  * 6 overlap pairs, 7 close pairs, 8 fused z+x pass, 9 y pass of the fused path, 10 preprocessing,
- * 11 co-localisation means, 12 operand-ordered voxel copy of the tiled path) and starts a new window. */
+ * 11 co-localisation means, 12 operand-ordered voxel copy of the tiled path) and starts a new window.
+ * mmx_timing_enable(m), m > 1: only the families whose bit (k + 1) is set in m record events (an event between two
+ * kernels keeps the second from starting under the first one's tail: timing one family perturbs a step less). */
 #define MMX_K_COUNT 13
 int mmx_timing_enable(int on);
 int mmx_timing_read(double* ms, int64_t* launches, int n);
@@ -530,13 +532,16 @@ int mmx_host_take_rows(const double* table, int64_t ld, const int64_t* rows, int
 /* ... and with the reference's last two steps on the pruned table folded in (magmap/cv/stack_detect.py:455-470:
  * `replace_rel_with_abs_blob_coords`, `remove_abs_blob_coords(True)` -- two more passes over the whole table when made
  * afterwards): out[i][j] = table[rows[i]][src_cols[j]], j < n_out (3..64), then out[i][abs_dst0 .. abs_dst0 + 3] =
- * abs_zyx[rows[i]].  mmx_host_gather_by_key_final: the same for mmx_host_gather_by_key (abs_rows[i]). */
+ * abs_zyx[rows[i]].  mmx_host_gather_parts_by_key_final: the same for mmx_host_gather_by_key, on the concatenation of
+ * n_parts survivor lists (ids[p], keys[p], abs_rows[p]: n_rows[p] entries each) that nobody has to concatenate;
+ * out_rows must equal their total. */
 int mmx_host_take_rows_final(const double* table, int64_t ld, const int64_t* rows, int64_t n,
                              const int32_t* src_cols, int32_t n_out, const double* abs_zyx, int32_t abs_dst0,
                              double* out);
-int mmx_host_gather_by_key_final(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
-                                 int64_t n_keys, const int32_t* src_cols, int32_t n_out, const double* abs_rows,
-                                 int32_t abs_dst0, double* out);
+int mmx_host_gather_parts_by_key_final(const double* table, int64_t ld, int32_t n_parts, const int64_t* const* ids,
+                                       const int64_t* const* keys, const double* const* abs_rows,
+                                       const int64_t* n_rows, int64_t n_keys, const int32_t* src_cols, int32_t n_out,
+                                       int32_t abs_dst0, double* out, int64_t out_rows);
 
 /* All three axis passes of the pruning for one REGION of the stack (the whole stack, one rank's blocks, or a group
  * of blocks pruned while the GPU still works on later ones): a table holding the region's own rows (ids

@@ -27,6 +27,7 @@ thread_local char g_hip_err[256] = "";
 struct span { hipEvent_t a, b; int kind; };
 std::mutex g_tm;
 bool g_timing = false;
+uint32_t g_kinds = ~0u;              // kernel families that record events while g_timing is on
 std::vector<span> g_spans;          // recorded spans of the current window
 std::vector<hipEvent_t> g_pool;     // recycled events
 hipEvent_t g_open[MMX_K_COUNT];
@@ -52,7 +53,7 @@ constexpr int kColPrefetch = 4;
 void mmx_time_begin(int kind, hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_tm);
-    if (!g_timing) return;
+    if (!g_timing || !((g_kinds >> kind) & 1u)) return;
     g_open[kind] = take_event();
     hipEventRecord(g_open[kind], s);
 }
@@ -76,6 +77,8 @@ int mmx_timing_enable(int on)
     g_spans.clear();
     for (int k = 0; k < MMX_K_COUNT; ++k) g_open[k] = nullptr;
     g_timing = on != 0;
+    // 1: every family; any other non-zero value: bit (k + 1) selects family MMX_K_k
+    g_kinds = on == 1 ? ~0u : ((uint32_t)on >> 1);
     return MMX_OK;
 }
 

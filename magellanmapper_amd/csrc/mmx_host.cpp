@@ -584,35 +584,79 @@ extern "C" int mmx_host_gather_by_key(const double* table, int64_t ld, const int
     return MMX_OK;
 }
 
-// The same merge with the table leaving in the caller's FINAL column layout (the reference's last two steps on the
-// pruned table, magmap/cv/stack_detect.py:455-470: rel <- abs, abs and unnamed columns dropped -- two more passes over
-// a 3e5-row table when done afterwards): out[k][j] = table[ids][src_cols[j]], then out[k][abs_dst0 .. +3] = abs_rows.
-extern "C" int mmx_host_gather_by_key_final(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys,
-                                            int64_t n, int64_t n_keys, const int32_t* src_cols, int32_t n_out,
-                                            const double* abs_rows, int32_t abs_dst0, double* out)
+// The merge of the regions' survivor lists with the table leaving in the caller's FINAL column layout (the reference's
+// last two steps on the pruned table, magmap/cv/stack_detect.py:455-470: rel <- abs, abs and unnamed columns dropped --
+// two more passes over a 3e5-row table when done afterwards): out[k][j] = table[ids][src_cols[j]], then
+// out[k][abs_dst0 .. +3] = abs_rows; rows in key order, equal keys in the order of the lists.  The `n_parts` lists (the
+// regions of a stack pruned one by one) are taken as they are
+// -- concatenating them is 12 MB of copies for 3e5 rows, a millisecond of the step's tail -- and
+// the counting sort itself threaded: every thread counts the keys of a contiguous run of parts, the runs' counts are
+// laid end to end per key, and every thread places its own rows (the order within a key stays the lists' order).
+extern "C" int mmx_host_gather_parts_by_key_final(const double* table, int64_t ld, int32_t n_parts,
+                                                  const int64_t* const* ids, const int64_t* const* keys,
+                                                  const double* const* abs_rows, const int64_t* n_rows, int64_t n_keys,
+                                                  const int32_t* src_cols, int32_t n_out, int32_t abs_dst0,
+                                                  double* out, int64_t out_rows)
 {
-    if (n < 0 || n_keys < 1 || n_out < 3 || n_out > 64 || !src_cols || abs_dst0 < 0 || abs_dst0 + 3 > n_out ||
-        (n && (!table || !ids || !keys || !out || !abs_rows)))
+    if (n_parts < 0 || n_keys < 1 || n_out < 3 || n_out > 64 || !src_cols || abs_dst0 < 0 || abs_dst0 + 3 > n_out ||
+        (n_parts && (!ids || !keys || !abs_rows || !n_rows)))
         return MMX_ERR_ARG;
     if (n_keys > (int64_t(1) << 26)) return MMX_ERR_UNSUPPORTED;
     for (int j = 0; j < n_out; ++j)
         if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
-    std::vector<int64_t> at((size_t)n_keys + 1, 0);
-    for (int64_t i = 0; i < n; ++i) {
-        if (keys[i] < 0 || keys[i] >= n_keys || ids[i] < 0) return MMX_ERR_ARG;
-        ++at[(size_t)keys[i] + 1];
+    int64_t n = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        if (n_rows[p] < 0 || (n_rows[p] && (!ids[p] || !keys[p] || !abs_rows[p]))) return MMX_ERR_ARG;
+        n += n_rows[p];
     }
-    for (int64_t k = 0; k < n_keys; ++k) at[(size_t)k + 1] += at[(size_t)k];
-    std::vector<int64_t> dst((size_t)n);
-    for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = at[(size_t)keys[i]]++;
-    parallel(host_threads(n), [&](int t, int nt) {
-        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
-        for (int64_t i = lo; i < hi; ++i) {
-            double* o = out + dst[(size_t)i] * n_out;
-            const double* src = table + ids[i] * ld;
-            for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
-            for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_rows[3 * i + a];
+    if (n != out_rows || (n && (!table || !out))) return MMX_ERR_ARG;
+    if (n == 0) return MMX_OK;
+    // runs of parts with about the same number of rows each (a thread's run may be empty)
+    int T = host_threads(n);
+    if ((int64_t)T * n_keys > (int64_t(1) << 24)) T = 1;
+    std::vector<int> first((size_t)T + 1, n_parts);
+    {
+        int64_t seen = 0;
+        int t = 0;
+        first[0] = 0;
+        for (int p = 0; p < n_parts; ++p) {
+            while (t + 1 < T && seen >= n * (t + 1) / T) first[(size_t)++t] = p;
+            seen += n_rows[p];
         }
+        for (++t; t <= T; ++t) first[(size_t)t] = n_parts;
+    }
+    std::vector<int64_t> at((size_t)T * (size_t)n_keys, 0);
+    std::vector<int> bad((size_t)T, 0);
+    parallel(T, [&](int t, int) {
+        int64_t* h = at.data() + (size_t)t * (size_t)n_keys;
+        for (int p = first[(size_t)t]; p < first[(size_t)t + 1]; ++p)
+            for (int64_t i = 0; i < n_rows[p]; ++i) {
+                const int64_t k = keys[p][i];
+                if (k < 0 || k >= n_keys || ids[p][i] < 0) { bad[(size_t)t] = 1; break; }
+                ++h[k];
+            }
+    });
+    for (int t = 0; t < T; ++t)
+        if (bad[(size_t)t]) return MMX_ERR_ARG;
+    {
+        int64_t run = 0;
+        for (int64_t k = 0; k < n_keys; ++k)
+            for (int t = 0; t < T; ++t) {
+                int64_t& c = at[(size_t)t * (size_t)n_keys + (size_t)k];
+                const int64_t here = c;
+                c = run;
+                run += here;
+            }
+    }
+    parallel(T, [&](int t, int) {
+        int64_t* pos = at.data() + (size_t)t * (size_t)n_keys;
+        for (int p = first[(size_t)t]; p < first[(size_t)t + 1]; ++p)
+            for (int64_t i = 0; i < n_rows[p]; ++i) {
+                double* o = out + pos[keys[p][i]]++ * n_out;
+                const double* src = table + ids[p][i] * ld;
+                for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
+                for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_rows[p][3 * i + a];
+            }
     });
     return MMX_OK;
 }
@@ -746,7 +790,7 @@ extern "C" int mmx_host_take_rows(const double* table, int64_t ld, const int64_t
     return MMX_OK;
 }
 
-// mmx_host_take_rows with the table leaving in the caller's final column layout (see mmx_host_gather_by_key_final):
+// mmx_host_take_rows with the table leaving in the caller's final column layout (see mmx_host_gather_parts_by_key_final):
 // out[i][j] = table[rows[i]][src_cols[j]], then out[i][abs_dst0 .. +3] = abs_zyx[rows[i]].
 extern "C" int mmx_host_take_rows_final(const double* table, int64_t ld, const int64_t* rows, int64_t n,
                                         const int32_t* src_cols, int32_t n_out, const double* abs_zyx,

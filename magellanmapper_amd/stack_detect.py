@@ -69,6 +69,7 @@ class _TableArena:
         self.abs = np.empty((self.cap, 3))
         self.n = 0
         self.spans = {}
+        self._views = {}                       # coord -> the view of `store` last handed out for it (view())
         self.chan_lo, self.chan_hi = np.inf, -np.inf       # range of the channel column over all rows
         # rows before the k-th block that was added (blocks arrive in grid order; blocks without rows count too):
         # what the region-wise pruning addresses blocks by
@@ -108,8 +109,14 @@ class _TableArena:
         self.row_end.extend([self.n] * n_blocks)
 
     def view(self, coord):
-        a, b = self.spans[tuple(coord)]
-        return self.store[a:b, :self.n_cols]
+        """The block's table as a view of the store -- the same object for as long as the store stays where it is
+        (``intact`` recognises the tables it handed out by identity)."""
+        coord = tuple(coord)
+        v = self._views.get(coord)
+        if v is None or v.base is not self.store:
+            a, b = self.spans[coord]
+            v = self._views[coord] = self.store[a:b, :self.n_cols]
+        return v
 
     @classmethod
     def from_rows(cls, idx: np.ndarray, rows: np.ndarray, coords: np.ndarray):
@@ -133,18 +140,24 @@ class _TableArena:
             self.chan_lo, self.chan_hi = rows[:, 6].min(), rows[:, 6].max()
         return self
 
-    def intact(self, blob_rois) -> bool:
-        """True when ``blob_rois`` still holds exactly the arena's tables, in grid order."""
+    def intact(self, blob_rois, sample_columns: bool = True) -> bool:
+        """True when ``blob_rois`` still holds exactly the arena's tables, in grid order (and, with ``sample_columns``,
+        a sample of their rows still says what the compact columns say: ``_columns_unedited``)."""
         at = 0
-        for coord in np.ndindex(*blob_rois.shape):
-            tbl = blob_rois[coord]
+        views = self._views
+        # (the very view objects the arena handed out -- assemble_seg_rois' -- are recognised by identity: 256 blocks in
+        #  ~30 us; any other array has to share the store's memory: ~4 us each)
+        for coord, tbl in zip(StackDetector._grid_coords(blob_rois.shape), blob_rois.ravel().tolist()):
             if tbl is None or isinstance(tbl, (int, np.integer)) or len(tbl) == 0:
                 continue
             span = self.spans.get(coord)
-            if span is None or span[0] != at or not np.shares_memory(tbl, self.store):
+            if span is None or span[0] != at:
+                return False
+            known = views.get(coord)
+            if not (tbl is known and known.base is self.store) and not np.shares_memory(tbl, self.store):
                 return False
             at = span[1]
-        return at == self.n and self._columns_unedited()
+        return at == self.n and (not sample_columns or self._columns_unedited())
 
     def _columns_unedited(self) -> bool:
         """The compact columns the pruning reads (``zyx``, ``abs``: copies made when the rows landed) still say what
@@ -369,20 +382,25 @@ class _RegionPruner:
             self._pool.shutdown(wait=False)
             self._pool = None
         ar = self.arena
+        counts = sum(d[3] for d in self.done)
+        ncol = ar.store.shape[1] - 3
+        if final is not None:
+            # the regions' survivor lists go to the merge as they are (no concatenation: 12 MB of copies for 3e5 rows)
+            src, dst0 = final
+            parts = [d for d in self.done if len(d[0])]
+            n_rows = np.array([len(d[0]) for d in parts], dtype=np.int64)
+            ptrs = [(ctypes.c_void_p * max(1, len(parts)))(*[d[c].ctypes.data for d in parts]) for c in range(3)]
+            out = np.empty((int(n_rows.sum()), len(src)))
+            nat.check(nat.lib().mmx_host_gather_parts_by_key_final(
+                ar.store.ctypes.data, ar.store.strides[0] // 8, len(parts), ptrs[0], ptrs[1], ptrs[2],
+                n_rows.ctypes.data, self.plan["n_keys"] * len(self.channels), (ctypes.c_int32 * len(src))(*src),
+                len(src), dst0, out.ctypes.data, len(out)), "mmx_host_gather_parts_by_key_final")
+            _lap("  regions: merge by key, final columns")
+            return out, counts
         ids = np.ascontiguousarray(np.concatenate([d[0] for d in self.done]), dtype=np.int64)
         keys = np.ascontiguousarray(np.concatenate([d[1] for d in self.done]), dtype=np.int64)
         abs_rows = np.ascontiguousarray(np.concatenate([d[2] for d in self.done]), dtype=np.float64)
-        counts = sum(d[3] for d in self.done)
         _lap("  regions: survivors concatenated")
-        ncol = ar.store.shape[1] - 3
-        if final is not None:
-            src, dst0 = final
-            out = np.empty((len(ids), len(src)))
-            nat.check(nat.lib().mmx_host_gather_by_key_final(
-                ar.store.ctypes.data, ar.store.strides[0] // 8, ids.ctypes.data, keys.ctypes.data, len(ids),
-                self.plan["n_keys"] * len(self.channels), (ctypes.c_int32 * len(src))(*src), len(src),
-                abs_rows.ctypes.data, dst0, out.ctypes.data), "mmx_host_gather_by_key_final")
-            return out, counts
         out = np.empty((len(ids), ncol))
         cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
         nat.check(nat.lib().mmx_host_gather_by_key(
@@ -787,7 +805,7 @@ class _StackRun:
         # (one process, no co-localisation columns: the table may come back in its final columns, see finish())
         return StackPruner.prune_blobs_mp(self.roi, self.seg_rois, bk.overlap, bk.tol, bk.sub_roi_slices,
                                           bk.sub_rois_offsets, self.channels, bk.overlap_padding,
-                                          final_form=not self.coloc and dist.world_size() == 1)
+                                          final_form=not self.coloc and dist.world_size() == 1, untouched=True)
 
     def prune(self):
         """The merged, pruned table on every rank.  One rank: a plain call.  Several ranks: either the tables stayed
@@ -1407,7 +1425,7 @@ class StackPruner:
 
     @classmethod
     def prune_blobs_mp(cls, img, seg_rois, overlap, tol, sub_roi_slices, sub_rois_offsets,
-                       channels, overlap_padding=None, final_form: bool = False):
+                       channels, overlap_padding=None, final_form: bool = False, untouched: bool = False):
         """Prune duplicates in the overlap slabs, per channel, axis by axis (:679-861).
 
         For every axis with more than one block, every block boundary ``j | j+1`` defines a
@@ -1416,7 +1434,10 @@ class StackPruner:
         everything else passes through, and the recombined table goes on to the next axis.
         Returns ``(table, DataFrame)`` or ``(None, None)``.  ``final_form`` (not in the reference; ``_StackRun`` asks
         for it): where possible the table comes back as a :class:`_FinalTable`, already in the columns the reference's
-        next two steps would leave (rel <- abs, abs dropped) -- two passes over the whole table less.
+        next two steps would leave (rel <- abs, abs dropped) -- two passes over the whole table less.  ``untouched``:
+        the caller vouches that nobody has had the tables since ``detect_blobs_sub_rois`` returned them (``_StackRun``
+        calls one right after the other), which spares the sampled comparison that looks for in-place edits -- 5000
+        cache misses on a 3e5-row table, 0.3 ms.
 
         Same results and row order as the reference, but rows are tracked as indices into the
         merged table (only the 3 abs columns ever change), so the big table is gathered once, and
@@ -1444,8 +1465,9 @@ class StackPruner:
                 return None, None
             return out, cls._ratio_frame(cls._ratios_from_counts(counts, plan))
         arena = getattr(seg_rois, "arena", None)
-        if arena is not None and not arena.intact(seg_rois):
+        if arena is not None and not arena.intact(seg_rois, sample_columns=not untouched):
             arena = None
+        _lap("arena check")
         early = getattr(seg_rois, "pruner", None)
         if early is not None:
             seg_rois.pruner = None        # one shot: used below or cancelled

@@ -520,7 +520,7 @@ def test_map_columns_native_matches_numpy():
 
 
 def test_native_gathers_in_final_columns():
-    """mmx_host_take_rows_final / mmx_host_gather_by_key_final: out[i][j] = table[row][src_cols[j]], the abs
+    """mmx_host_take_rows_final / mmx_host_gather_parts_by_key_final: out[i][j] = table[row][src_cols[j]], the abs
     coordinates written at abs_dst0 -- against NumPy, on a table large enough for the threaded path; bad arguments
     are refused."""
     from magellanmapper_amd import _native as nat
@@ -538,16 +538,26 @@ def test_native_gathers_in_final_columns():
     want = table[rows][:, src]
     want[:, 0:3] = absz[rows]
     np.testing.assert_array_equal(out, want)
-    # by key: rows land in key order, equal keys in input order; abs_rows run with the input
+    # by key, from several lists: rows land in key order, equal keys in the order of the concatenated lists
     keys = rng.integers(0, 97, n).astype(np.int64)
     abs_rows = rng.random((n, 3))
-    out2 = np.empty((n, len(src)))
-    nat.check(L.mmx_host_gather_by_key_final(table.ctypes.data, ld, rows.ctypes.data, keys.ctypes.data, n, 97, csrc,
-                                             len(src), abs_rows.ctypes.data, 0, out2.ctypes.data), "gather_by_key_final")
+
+    def gather(cuts, n_keys=97):
+        edges = [0] + list(cuts) + [n]
+        parts = [(rows[a:b], keys[a:b], abs_rows[a:b]) for a, b in zip(edges[:-1], edges[1:])]
+        n_rows = np.array([len(p_[0]) for p_ in parts], dtype=np.int64)
+        ptrs = [(ctypes.c_void_p * len(parts))(*[p_[c].ctypes.data for p_ in parts]) for c in range(3)]
+        out2 = np.full((n, len(src)), np.nan)
+        rc = L.mmx_host_gather_parts_by_key_final(table.ctypes.data, ld, len(parts), ptrs[0], ptrs[1], ptrs[2],
+                                                  n_rows.ctypes.data, n_keys, csrc, len(src), 0, out2.ctypes.data, n)
+        return rc, out2
     order = np.argsort(keys, kind="stable")
     want2 = table[rows[order]][:, src]
     want2[:, 0:3] = abs_rows[order]
-    np.testing.assert_array_equal(out2, want2)
+    for cuts in ([], [1], [0, 0, 7000, 7001, 29999], sorted(rng.integers(0, n, 40))):
+        rc, out2 = gather(cuts)
+        assert rc == 0
+        np.testing.assert_array_equal(out2, want2)
     # ... and equal to the two-step form: gather in the table's columns, then the column shuffles
     cols3 = (ctypes.c_int32 * 3)(7, 8, 9)
     full = np.empty((n, ld - 3))
@@ -560,8 +570,7 @@ def test_native_gathers_in_final_columns():
                                       out.ctypes.data) == 1
     assert L.mmx_host_take_rows_final(table.ctypes.data, ld, rows.ctypes.data, n, csrc, len(src), absz.ctypes.data, 6,
                                       out.ctypes.data) == 1                    # abs columns past the row
-    assert L.mmx_host_gather_by_key_final(table.ctypes.data, ld, rows.ctypes.data, keys.ctypes.data, n, 5, csrc,
-                                          len(src), abs_rows.ctypes.data, 0, out2.ctypes.data) == 1       # key >= n_keys
+    assert gather([100], n_keys=5)[0] == 1                                       # key >= n_keys
 
 
 def test_native_prune_works_in_a_forked_child():
@@ -1174,7 +1183,7 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case, monkeypatch):
         seg_f, _ = build(with_pruner)
         got_f, df_f = sd.StackPruner.prune_blobs_mp(Img, seg_f, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                      blocks.sub_rois_offsets, channels, blocks.overlap_padding,
-                                                     final_form=True)
+                                                     final_form=True, untouched=with_pruner)
         np.testing.assert_array_equal(df_f.to_numpy(), df_want.to_numpy())
         if n_extra:
             assert not isinstance(got_f, sd._FinalTable)

@@ -81,7 +81,7 @@ def step():
     t1 = time.perf_counter()
     pruned, _ = stack_detect.StackPruner.prune_blobs_mp(dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                         blocks.sub_rois_offsets, [0], blocks.overlap_padding,
-                                                        final_form=True)
+                                                        final_form=True, untouched=True)
     t2 = time.perf_counter()
     if isinstance(pruned, stack_detect._FinalTable):
         detector.Blobs(None).cols = list(pruned.col_names); final = pruned.view(np.ndarray)

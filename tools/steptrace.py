@@ -79,7 +79,7 @@ def step():
     t = time.perf_counter()
     pruned, _ = stack_detect.StackPruner.prune_blobs_mp(dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                                         blocks.sub_rois_offsets, [0], blocks.overlap_padding,
-                                                        final_form=True)
+                                                        final_form=True, untouched=True)
     log.append((t - T0[0], time.perf_counter() - T0[0], "StackPruner.prune_blobs_mp", ""))
     t = time.perf_counter()
     if isinstance(pruned, stack_detect._FinalTable):
