@@ -338,11 +338,12 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         t_b = time.perf_counter()
         final = colocs = None
         if rank == 0 or getattr(seg, "local_only", False):
-            # (final_form, untouched: as stack_detect._StackRun calls it -- one process and no co-localisation columns;
-            #  the tables come straight from the call above)
+            # (final_form, untouched: as stack_detect._StackRun calls it -- no co-localisation columns, one process or
+            #  every rank pruning its own rows; the tables come straight from the call above)
             pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
                 vol, seg, blk.overlap, blk.tol, blk.sub_roi_slices, blk.sub_rois_offsets,
-                channels, blk.overlap_padding, final_form=not coloc and dist.world_size() == 1, untouched=True)
+                channels, blk.overlap_padding, untouched=True,
+                final_form=not coloc and (dist.world_size() == 1 or getattr(seg, "local_only", False)))
             if rank == 0:
                 final, colocs = finish(pruned)
         t_c = time.perf_counter()

@@ -592,6 +592,10 @@ int mmx_host_append_rows(const double* payload, int64_t n, const int32_t lo[3], 
                          int64_t* out_n);
 int mmx_host_emit_survivors(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
                             int64_t n_cols, const double* abs_rows, const int32_t abs_cols[3], double* out);
+/* ... in the final columns (src_cols / abs_dst0 as for mmx_host_take_rows_final): out[i][n_out + 1], the key last. */
+int mmx_host_emit_survivors_final(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
+                                  const int32_t* src_cols, int32_t n_out, const double* abs_rows, int32_t abs_dst0,
+                                  double* out);
 int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
                           int64_t n_cols, double* out);
 int mmx_host_gather_by_key(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,

@@ -744,6 +744,33 @@ extern "C" int mmx_host_emit_survivors(const double* table, int64_t ld, const in
     return MMX_OK;
 }
 
+// mmx_host_emit_survivors with the rows leaving in the caller's final column layout (see
+// mmx_host_gather_parts_by_key_final): out[i] = table[ids[i]][src_cols[0 .. n_out)], abs_rows[i] at abs_dst0, then the
+// key -- what travels in the distributed pruning's second exchange is a quarter smaller, and so is the merge after it.
+extern "C" int mmx_host_emit_survivors_final(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys,
+                                             int64_t n, const int32_t* src_cols, int32_t n_out, const double* abs_rows,
+                                             int32_t abs_dst0, double* out)
+{
+    if (n < 0 || n_out < 3 || n_out > 64 || !src_cols || abs_dst0 < 0 || abs_dst0 + 3 > n_out ||
+        (n && (!table || !ids || !keys || !out || !abs_rows)))
+        return MMX_ERR_ARG;
+    for (int j = 0; j < n_out; ++j)
+        if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[i] < 0) return MMX_ERR_ARG;
+    parallel(host_threads(n), [&](int t, int nt) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; ++i) {
+            double* o = out + i * (n_out + 1);
+            const double* src = table + ids[i] * ld;
+            for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
+            for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_rows[3 * i + a];
+            o[n_out] = (double)keys[i];
+        }
+    });
+    return MMX_OK;
+}
+
 // out[i][dst_col0 + j] = table[i][src_cols[j]] for every row: the column shuffles that end a stack
 // detection (Blobs.replace_rel_with_abs_blob_coords: out = table, columns 7..9 -> 0..2;
 // Blobs.remove_abs_blob_coords: the kept columns into a new table).  `out` may be `table` itself (a row is

@@ -802,10 +802,12 @@ class _StackRun:
     def _prune_here(self):
         bk = self.blocks
         from . import dist
-        # (one process, no co-localisation columns: the table may come back in its final columns, see finish())
+        # (no co-localisation columns, and either one process or every rank pruning its own rows: the table may come
+        #  back in its final columns, see finish(); a table pruned on rank 0 and broadcast keeps the merged columns)
+        own = dist.world_size() == 1 or getattr(self.seg_rois, "local_only", False)
         return StackPruner.prune_blobs_mp(self.roi, self.seg_rois, bk.overlap, bk.tol, bk.sub_roi_slices,
                                           bk.sub_rois_offsets, self.channels, bk.overlap_padding,
-                                          final_form=not self.coloc and dist.world_size() == 1, untouched=True)
+                                          final_form=not self.coloc and own, untouched=True)
 
     def prune(self):
         """The merged, pruned table on every rank.  One rank: a plain call.  Several ranks: either the tables stayed
@@ -1233,7 +1235,7 @@ class StackPruner:
         return out
 
     @classmethod
-    def _prune_distributed(cls, seg_rois, shape3, plan, sub_roi_slices, channels):
+    def _prune_distributed(cls, seg_rois, shape3, plan, sub_roi_slices, channels, final=None):
         """Several ranks, each holding the tables of its own blocks (``seg_rois.local_only``): every rank prunes
         its own rows -- the three passes on its rows plus the other ranks' rows within reach of its blocks
         (``mmx_host_prune_region``) -- and the survivors are merged by key on every rank.  Collective: all ranks
@@ -1282,19 +1284,20 @@ class StackPruner:
         _lap("exchange 1 (seam rows)")
         mine, counts = None, None
         try:
-            mine, counts = cls._prune_own_rows(ar, parts, boxes[me], me, channels, plan, abs_inds, _lap)
+            mine, counts = cls._prune_own_rows(ar, parts, boxes[me], me, channels, plan, abs_inds, _lap, final)
         except Exception as exc:
             failure = exc
-        table = dist.all_gather_rows_concat(mine, ncol - 2, failure, "distributed pruning (own rows)")
+        width = (ncol - 3) if final is None else len(final[0])          # columns of a survivor's row; its key follows
+        table = dist.all_gather_rows_concat(mine, width + 1, failure, "distributed pruning (own rows)")
         _lap("exchange 2 (survivors)")
         out = None
         try:
-            out = np.empty((len(table), ncol - 3))
+            out = np.empty((len(table), width))
             if len(table):
-                all_keys = np.ascontiguousarray(table[:, ncol - 3], dtype=np.int64)
+                all_keys = np.ascontiguousarray(table[:, width], dtype=np.int64)
                 nat.check(nat.lib().mmx_host_merge_by_key(
-                    table.ctypes.data, ncol - 2, all_keys.ctypes.data, len(table), plan["n_keys"] * len(channels),
-                    ncol - 3, out.ctypes.data), "mmx_host_merge_by_key")
+                    table.ctypes.data, width + 1, all_keys.ctypes.data, len(table), plan["n_keys"] * len(channels),
+                    width, out.ctypes.data), "mmx_host_merge_by_key")
         except Exception as exc:
             failure = exc
         _lap("merge by key")
@@ -1360,7 +1363,7 @@ class StackPruner:
         return payload[:k.value]
 
     @classmethod
-    def _prune_own_rows(cls, ar, parts, mine_box, me, channels, plan, abs_inds, _lap=lambda what: None):
+    def _prune_own_rows(cls, ar, parts, mine_box, me, channels, plan, abs_inds, _lap=lambda what: None, final=None):
         """The three passes on this rank's rows between the seam rows received from the ranks before and after it:
         ``(own survivors in their final form + one column with the key that places them, statistics)``.
 
@@ -1414,6 +1417,16 @@ class StackPruner:
         k = out_n.value
         counts = np.ascontiguousarray(np.moveaxis(stat, 0, -1))
         _lap("three passes on own + halo rows")
+        if final is not None:       # (the survivors leave in the table's final columns: fewer values to exchange and merge)
+            src, dst0 = final
+            mine = np.empty((k, len(src) + 1))
+            if k:
+                nat.check(lib.mmx_host_emit_survivors_final(
+                    ar.store.ctypes.data, ar.store.strides[0] // 8, ids.ctypes.data, keys.ctypes.data, k,
+                    (ctypes.c_int32 * len(src))(*src), len(src), abs_rows.ctypes.data, dst0, mine.ctypes.data),
+                    "mmx_host_emit_survivors_final")
+            _lap("own survivors in final form")
+            return mine, counts
         mine = np.empty((k, ncol - 2))
         if k:
             cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
@@ -1460,9 +1473,15 @@ class StackPruner:
             # several ranks, each with the tables of its own blocks: a collective (every rank calls this)
             detector.Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry
             plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
-            out, counts = cls._prune_distributed(seg_rois, shape3, plan, sub_roi_slices, channels)
+            # (the same decision on every rank: it follows from the arena's width and the registry alone)
+            final = cls._final_columns(seg_rois.arena.store, detector.Blobs._get_abs_inds()) if final_form else None
+            out, counts = cls._prune_distributed(seg_rois, shape3, plan, sub_roi_slices, channels,
+                                                 None if final is None else final[:2])
             if out is None:
                 return None, None
+            if final is not None:
+                out = out.view(_FinalTable)
+                out.col_names = final[2]
             return out, cls._ratio_frame(cls._ratios_from_counts(counts, plan))
         arena = getattr(seg_rois, "arena", None)
         if arena is not None and not arena.intact(seg_rois, sample_columns=not untouched):

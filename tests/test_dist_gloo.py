@@ -238,6 +238,15 @@ def _worker_dist_prune(rank, world, port, case, out_dir):
                                                    blocks.sub_rois_offsets, channels, blocks.overlap_padding)
         np.save(os.path.join(out_dir, f"pruned{rank}.npy"), np.zeros((0, 0)) if pruned is None else pruned)
         np.save(os.path.join(out_dir, f"ratios{rank}.npy"), np.zeros((0, 0)) if df is None else df.to_numpy())
+        # the same collective with the table asked for in its final columns (what stack_detect._StackRun asks for)
+        final, df2 = sd.StackPruner.prune_blobs_mp(Img, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                   blocks.sub_rois_offsets, channels, blocks.overlap_padding,
+                                                   final_form=True, untouched=True)
+        assert (df2 is None) == (df is None) and (df is None or np.array_equal(df2.to_numpy(), df.to_numpy()))
+        is_final = isinstance(final, sd._FinalTable)
+        np.save(os.path.join(out_dir, f"final{rank}.npy"), np.zeros((0, 0)) if final is None else np.asarray(final))
+        with open(os.path.join(out_dir, f"final{rank}.txt"), "w") as f:
+            f.write(",".join(final.col_names) if is_final else "")
     finally:
         td.destroy_process_group()
 
@@ -327,6 +336,19 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
         assert got.shape == want.shape
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(ratios.reshape(df.shape), df.to_numpy())
+        # final_form: the reference's last two steps folded into the exchange (not with co-localisation columns)
+        final = np.load(tmp_path / f"final{r}.npy")
+        names = (tmp_path / f"final{r}.txt").read_text()
+        if n_extra:
+            assert names == ""
+            np.testing.assert_array_equal(final, want)
+        else:
+            from magellanmapper_amd import detector
+            bb = detector.Blobs(want.copy())
+            bb.replace_rel_with_abs_blob_coords(bb.blobs)
+            want_final = bb.remove_abs_blob_coords(True)
+            assert names.split(",") == list(bb.cols)
+            np.testing.assert_array_equal(final, want_final.reshape(final.shape) if not len(want_final) else want_final)
 
 
 @pytest.mark.parametrize("world", [2, 4])
