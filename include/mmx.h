@@ -554,7 +554,8 @@ int mmx_host_gather_parts_by_key_final(const double* table, int64_t ld, int32_t 
  *   bounds / nxt_lo / nxt_hi / last_end / tol: as for mmx_host_prune_axis, per axis
  *   out_rows / out_keys / *out_n: own survivors in final order; abs_zyx updated in place
  *   n_slab / n_after / n_next: [3][stat_ld] statistics over OWN rows
- * mmx_host_merge_by_key: out = the stable sort by key of rows[n][ld] (first n_cols columns), keys < n_keys.
+ * mmx_host_merge_by_key: out = the stable sort by key of rows[n][ld] (first n_cols columns), keys < n_keys; keys == NULL:
+ *   a row's key is the value in its column n_cols.
  * mmx_host_gather_by_key: the same for survivors still in the merged table: row ids[i], its three abs columns
  *   replaced by abs_rows[i][3]. */
 int mmx_host_prune_region(const int32_t* zyx, const int32_t* tag, double* abs_zyx, const int64_t* cur, int64_t n_cur,

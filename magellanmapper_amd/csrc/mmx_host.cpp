@@ -536,20 +536,47 @@ extern "C" int mmx_host_prune_parts(const int32_t* zyx, const int32_t* tag, cons
 extern "C" int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
                                      int64_t n_cols, double* out)
 {
-    if (n < 0 || n_keys < 1 || n_cols < 1 || n_cols > ld || (n && (!rows || !keys || !out))) return MMX_ERR_ARG;
+    // keys == nullptr: a row's key is the value in its column n_cols (how the ranks' survivors arrive: the key rides
+    // behind the columns) -- no separate key array has to be pulled out of the table first
+    if (n < 0 || n_keys < 1 || n_cols < 1 || n_cols > ld || (!keys && n_cols >= ld) || (n && (!rows || !out)))
+        return MMX_ERR_ARG;
     if (n_keys > (int64_t(1) << 26)) return MMX_ERR_UNSUPPORTED;
-    std::vector<int64_t> at((size_t)n_keys + 1, 0);
-    for (int64_t i = 0; i < n; ++i) {
-        if (keys[i] < 0 || keys[i] >= n_keys) return MMX_ERR_ARG;
-        ++at[(size_t)keys[i] + 1];
+    if (n == 0) return MMX_OK;
+    // threaded counting sort: every thread counts the keys of one contiguous run of rows, the runs' counts are laid end
+    // to end per key, every thread places its own rows (rows of one key keep their order)
+    int T = host_threads(n);
+    if ((int64_t)T * n_keys > (int64_t(1) << 24)) T = 1;
+    std::vector<int64_t> at((size_t)T * (size_t)n_keys, 0);
+    std::vector<int> bad((size_t)T, 0);
+    auto key_of = [&](int64_t i) -> int64_t {
+        if (keys) return keys[i];
+        const double v = rows[i * ld + n_cols];
+        return (v >= 0.0 && v < 9.0e15) ? (int64_t)v : -1;
+    };
+    parallel(T, [&](int t, int) {
+        int64_t* h = at.data() + (size_t)t * (size_t)n_keys;
+        for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+            const int64_t k = key_of(i);
+            if (k < 0 || k >= n_keys) { bad[(size_t)t] = 1; break; }
+            ++h[k];
+        }
+    });
+    for (int t = 0; t < T; ++t)
+        if (bad[(size_t)t]) return MMX_ERR_ARG;
+    {
+        int64_t run = 0;
+        for (int64_t k = 0; k < n_keys; ++k)
+            for (int t = 0; t < T; ++t) {
+                int64_t& c = at[(size_t)t * (size_t)n_keys + (size_t)k];
+                const int64_t here = c;
+                c = run;
+                run += here;
+            }
     }
-    for (int64_t k = 0; k < n_keys; ++k) at[(size_t)k + 1] += at[(size_t)k];
-    std::vector<int64_t> dst((size_t)n);
-    for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = at[(size_t)keys[i]]++;
-    parallel(host_threads(n), [&](int t, int nt) {
-        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
-        for (int64_t i = lo; i < hi; ++i)
-            std::memcpy(out + dst[(size_t)i] * n_cols, rows + i * ld, (size_t)n_cols * sizeof(double));
+    parallel(T, [&](int t, int) {
+        int64_t* pos = at.data() + (size_t)t * (size_t)n_keys;
+        for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i)
+            std::memcpy(out + pos[key_of(i)]++ * n_cols, rows + i * ld, (size_t)n_cols * sizeof(double));
     });
     return MMX_OK;
 }

@@ -1293,10 +1293,9 @@ class StackPruner:
         out = None
         try:
             out = np.empty((len(table), width))
-            if len(table):
-                all_keys = np.ascontiguousarray(table[:, width], dtype=np.int64)
+            if len(table):          # (keys: the column behind the table's own, read in place)
                 nat.check(nat.lib().mmx_host_merge_by_key(
-                    table.ctypes.data, width + 1, all_keys.ctypes.data, len(table), plan["n_keys"] * len(channels),
+                    table.ctypes.data, width + 1, None, len(table), plan["n_keys"] * len(channels),
                     width, out.ctypes.data), "mmx_host_merge_by_key")
         except Exception as exc:
             failure = exc

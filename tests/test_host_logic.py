@@ -573,6 +573,32 @@ def test_native_gathers_in_final_columns():
     assert gather([100], n_keys=5)[0] == 1                                       # key >= n_keys
 
 
+def test_native_merge_by_key_reads_keys_in_place():
+    """mmx_host_merge_by_key: the stable sort of rows by key (threaded counting sort), keys from an array or from the
+    column behind the rows' own (how the ranks' survivors arrive); keys out of range are refused."""
+    from magellanmapper_amd import _native as nat
+    L = nat.lib()
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 777, 60000):
+        n_cols, n_keys = 8, 500
+        rows = rng.random((n, n_cols + 1))
+        keys = rng.integers(0, n_keys, n).astype(np.int64)
+        rows[:, n_cols] = keys
+        want = rows[np.argsort(keys, kind="stable"), :n_cols]
+        for kp in (keys.ctypes.data, None):
+            out = np.full((n, n_cols), np.nan)
+            assert L.mmx_host_merge_by_key(rows.ctypes.data, n_cols + 1, kp, n, n_keys, n_cols, out.ctypes.data) == 0
+            np.testing.assert_array_equal(out, want)
+    out = np.empty((n, n_cols))
+    assert L.mmx_host_merge_by_key(rows.ctypes.data, n_cols + 1, None, n, 100, n_cols, out.ctypes.data) == 1     # key >= n_keys
+    rows[5, n_cols] = -1.0
+    assert L.mmx_host_merge_by_key(rows.ctypes.data, n_cols + 1, None, n, n_keys, n_cols, out.ctypes.data) == 1
+    rows[5, n_cols] = np.nan
+    assert L.mmx_host_merge_by_key(rows.ctypes.data, n_cols + 1, None, n, n_keys, n_cols, out.ctypes.data) == 1
+    # (no room for a key column behind the rows' own: a key array is required)
+    assert L.mmx_host_merge_by_key(rows.ctypes.data, n_cols + 1, None, n, n_keys, n_cols + 1, out.ctypes.data) == 1
+
+
 def test_native_prune_works_in_a_forked_child():
     """The host thread pool lives in the dlopen'd library; after fork() its threads are gone (the reference's
     default start method is 'fork').  A table large enough for the threaded path must still prune in the child."""
