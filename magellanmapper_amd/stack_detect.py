@@ -253,6 +253,21 @@ def _rows_within(zyx: np.ndarray, lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
     return np.flatnonzero(np.all((zyx >= lo) & (zyx < hi), axis=1))
 
 
+_REGION_POOL = [None, 0]        # the executor the regions run on, and the process it was made in
+
+
+def _region_workers():
+    """A few threads for pruning regions side by side (the native call releases the GIL), kept for the life of the
+    process: making eight threads costs as much as pruning a region.  A forked child makes its own (an executor does
+    not survive a fork: its threads are gone, and it would wait for them)."""
+    if _REGION_POOL[0] is None or _REGION_POOL[1] != os.getpid():
+        from concurrent.futures import ThreadPoolExecutor
+        _REGION_POOL[0] = ThreadPoolExecutor(max_workers=min(8, max(1, (os.cpu_count() or 2) // 2)),
+                                             thread_name_prefix="mmx-region")
+        _REGION_POOL[1] = os.getpid()
+    return _REGION_POOL[0]
+
+
 class _RegionPruner:
     """The overlap pruning of one process' table done region by region while later blocks are still being detected.
 
@@ -262,8 +277,11 @@ class _RegionPruner:
     Results equal the whole-table passes (``mmx_host_prune_region`` says why); ``StackPruner.prune_blobs_mp`` uses
     them when it is called with the very parameters they were made for, and prunes the whole table otherwise."""
 
-    def __init__(self, arena: _TableArena, plan, channels, sub_roi_slices, shape3, share):
+    def __init__(self, arena: _TableArena, plan, channels, sub_roi_slices, shape3, share, halo=None):
         self.arena, self.plan, self.channels = arena, plan, list(channels)
+        # several ranks: the row ranges (behind the arena's own rows) of the seam rows received from the ranks before
+        # and after this one -- every region sees them as the first and the last part of its local table
+        self.halo = halo
         grid = sub_roi_slices.shape
         coords = StackDetector._grid_coords(grid)
         run = max(1, int(grid[2]))
@@ -288,7 +306,6 @@ class _RegionPruner:
             r["ready_at"] = int(max(r["k_hi"], k_hi[near].max(initial=0)))
         self.done = [None] * len(self.regions)
         self.pending = list(range(len(self.regions)))
-        self._pool = None
         self._futures = []
         self._channels = np.ascontiguousarray(self.channels, dtype=np.float64)
 
@@ -312,14 +329,8 @@ class _RegionPruner:
         self.pending = [i for i in self.pending if self.regions[i]["ready_at"] > landed]
         # (not waited for: towards the end of a stack the batches are small and the host thread is what the step waits
         #  for -- 1.5 ms per batch when the regions ran inside this call; finish() collects them)
-        pool = self._workers()
+        pool = _region_workers()
         self._futures.extend(pool.submit(self._run, i) for i in ready)
-
-    def _workers(self):
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=min(8, max(1, (os.cpu_count() or 2) // 2)))
-        return self._pool
 
     def _run(self, i: int) -> None:
         """One region: its rows and its neighbours' rows within reach, straight from the arena
@@ -330,8 +341,12 @@ class _RegionPruner:
         a_zyx, a_tag, a_abs, a_store = ar.zyx, ar.tag, ar.abs, ar.store
         ends = ar.row_end
         members = sorted(r["near"] + [i])
-        parts = np.array([[ends[self.regions[j]["k_lo"]], ends[self.regions[j]["k_hi"]]] for j in members],
-                         dtype=np.int64)
+        ranges = [[ends[self.regions[j]["k_lo"]], ends[self.regions[j]["k_hi"]]] for j in members]
+        own_at = members.index(i)
+        if self.halo is not None:       # (local order: earlier ranks' seam rows, own regions, later ranks' seam rows)
+            ranges = [list(self.halo[0])] + ranges + [list(self.halo[1])]
+            own_at += 1
+        parts = np.array(ranges, dtype=np.int64)
         n_own = int(ends[r["k_hi"]] - ends[r["k_lo"]])
         ids = np.empty(max(1, n_own), dtype=np.int64)
         keys = np.empty(max(1, n_own), dtype=np.int64)
@@ -346,7 +361,7 @@ class _RegionPruner:
         nat.check(nat.lib().mmx_host_prune_parts(
             a_zyx.ctypes.data, a_tag.ctypes.data, a_abs.ctypes.data,
             None if one_channel else a_store.ctypes.data + 6 * 8, a_store.strides[0] // 8,
-            parts.ctypes.data, len(parts), members.index(i),
+            parts.ctypes.data, len(parts), own_at,
             lo.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), hi.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
             self._channels.ctypes.data, len(self.channels), n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi,
             self.plan["n_keys"], ids.ctypes.data, keys.ctypes.data, abs_rows.ctypes.data, ctypes.byref(out_n),
@@ -356,31 +371,37 @@ class _RegionPruner:
 
     def cancel(self) -> None:
         """Give up on pruning ahead (``prune_blobs_mp`` was called with other parameters, the arena is no longer
-        intact, the detection failed): regions not started are dropped, running ones are waited for, the worker
-        threads end, and an exception a region raised surfaces here instead of vanishing with its future."""
+        intact, the detection failed): regions not started are dropped, running ones are waited for, and an
+        exception a region raised surfaces here instead of vanishing with its future."""
         self.pending = []
         futures, self._futures = self._futures, []
-        if self._pool is not None:
-            self._pool.shutdown(wait=True, cancel_futures=True)
-            self._pool = None
+        for f in futures:
+            f.cancel()
         for f in futures:
             if not f.cancelled():
                 f.result()
 
+    def run_all(self) -> None:
+        """Every region at once (everything has landed), waited for: an exception of a region surfaces here."""
+        if self.pending:
+            todo, self.pending = self.pending, []
+            pool = _region_workers()
+            self._futures.extend(pool.submit(self._run, i) for i in todo)
+        futures, self._futures = self._futures, []
+        failure = None
+        for f in futures:
+            try:
+                f.result()
+            except Exception as exc:        # (the others are still waited for: they read arrays the caller owns)
+                failure = failure or exc
+        if failure is not None:
+            raise failure
+
     def finish(self, abs_inds, final=None, _lap=lambda what: None):
         """Whatever is left, then the merge: ``(final table, counts)``.  ``final = (source columns, place of the abs
         coordinates)``: the table in those columns (``StackPruner._final_columns``)."""
-        if self.pending:            # (everything has landed by now)
-            todo, self.pending = self.pending, []
-            pool = self._workers()
-            self._futures.extend(pool.submit(self._run, i) for i in todo)
-        for f in self._futures:     # (an exception of a region surfaces here)
-            f.result()
-        self._futures = []
+        self.run_all()              # (everything has landed by now)
         _lap("  regions: the last ones done")
-        if self._pool is not None:
-            self._pool.shutdown(wait=False)
-            self._pool = None
         ar = self.arena
         counts = sum(d[3] for d in self.done)
         ncol = ar.store.shape[1] - 3
@@ -1284,7 +1305,8 @@ class StackPruner:
         _lap("exchange 1 (seam rows)")
         mine, counts = None, None
         try:
-            mine, counts = cls._prune_own_rows(ar, parts, boxes[me], me, channels, plan, abs_inds, _lap, final)
+            mine, counts = cls._prune_own_rows(ar, parts, boxes[me], me, channels, plan, abs_inds, _lap, final,
+                                               (sub_roi_slices, shape3, dist.my_share(len(coords))))
         except Exception as exc:
             failure = exc
         width = (ncol - 3) if final is None else len(final[0])          # columns of a survivor's row; its key follows
@@ -1310,6 +1332,8 @@ class StackPruner:
         return out, counts
 
     _rank_box_cache: dict = {}
+    #: own rows from which a rank prunes its blocks region by region (below: one region, no thread hand-offs)
+    REGION_MIN_ROWS = int(os.environ.get("MMX_DIST_REGION_ROWS", 8000))
 
     @classmethod
     def _rank_boxes(cls, n_blocks, world, coords, sub_roi_slices, shape3, reach):
@@ -1362,14 +1386,20 @@ class StackPruner:
         return payload[:k.value]
 
     @classmethod
-    def _prune_own_rows(cls, ar, parts, mine_box, me, channels, plan, abs_inds, _lap=lambda what: None, final=None):
+    def _prune_own_rows(cls, ar, parts, mine_box, me, channels, plan, abs_inds, _lap=lambda what: None, final=None,
+                        geometry=None):
         """The three passes on this rank's rows between the seam rows received from the ranks before and after it:
         ``(own survivors in their final form + one column with the key that places them, statistics)``.
 
         The received rows are appended to the arena's compact columns behind the rank's own rows
         (``mmx_host_append_rows``) and ``mmx_host_prune_parts`` is told the order of the local table -- earlier
         ranks' halo, own rows, later ranks' halo: what the whole-table passes would see of them -- so that no table is
-        put together in Python; the survivors leave through ``mmx_host_emit_survivors``."""
+        put together in Python; the survivors leave through ``mmx_host_emit_survivors``.
+
+        ``geometry = (sub_roi_slices, shape3, this rank's block indices)``: with enough rows the rank's blocks are
+        pruned region by region on a few threads, as one process does while it detects (:class:`_RegionPruner`), every
+        region seeing the seam rows as the first and last part of its table -- one region for the whole rank is a
+        single thread's 4-6 ms at two to four ranks."""
         lib = nat.lib()
         n = ar.n
         ncol = ar.store.shape[1]
@@ -1397,6 +1427,35 @@ class StackPruner:
         # local order: halo of the ranks before, own rows, halo of the ranks after
         local = np.array([[edges[0], edges[1]], [0, n], [edges[1], edges[2]]], dtype=np.int64)
         _lap("own + halo tables")
+        if geometry is not None and mine_box is not None and n >= cls.REGION_MIN_ROWS and \
+                len(ar.row_end) == len(geometry[2]) + 1 and ar.row_end[-1] == n:
+            rp = _RegionPruner(ar, plan, channels, geometry[0], geometry[1], list(geometry[2]),
+                               halo=((edges[0], edges[1]), (edges[1], edges[2])))
+            if len(rp.regions) > 1:
+                rp.run_all()
+                _lap(f"three passes on own + halo rows ({len(rp.regions)} regions)")
+                counts = np.ascontiguousarray(sum(d[3] for d in rp.done))
+                width = (ncol - 3) if final is None else len(final[0])
+                mine = np.empty((sum(len(d[0]) for d in rp.done), width + 1))
+                row = 0
+                csrc = None if final is None else (ctypes.c_int32 * width)(*final[0])
+                cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
+                for r_ids, r_keys, r_abs, _ in rp.done:         # (regions in order: the merge by key is stable)
+                    k = len(r_ids)
+                    if not k:
+                        continue
+                    dst = mine[row:row + k]
+                    if final is not None:
+                        nat.check(lib.mmx_host_emit_survivors_final(
+                            ar.store.ctypes.data, ar.store.strides[0] // 8, r_ids.ctypes.data, r_keys.ctypes.data, k,
+                            csrc, width, r_abs.ctypes.data, final[1], dst.ctypes.data), "mmx_host_emit_survivors_final")
+                    else:
+                        nat.check(lib.mmx_host_emit_survivors(
+                            ar.store.ctypes.data, ar.store.strides[0] // 8, r_ids.ctypes.data, r_keys.ctypes.data, k,
+                            width, r_abs.ctypes.data, cols3, dst.ctypes.data), "mmx_host_emit_survivors")
+                    row += k
+                _lap("own survivors in final form")
+                return mine, counts
         ids = np.empty(max(1, n), dtype=np.int64)
         keys = np.empty(max(1, n), dtype=np.int64)
         abs_rows = np.empty((max(1, n), 3))

@@ -209,10 +209,12 @@ def test_single_process_passthrough():
 
 
 # ---------------------------------------------------------------- distributed pruning: every rank prunes its own rows
-def _worker_dist_prune(rank, world, port, case, out_dir):
+def _worker_dist_prune(rank, world, port, case, out_dir, regions=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as td
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if regions:     # every rank prunes its blocks region by region whatever the number of rows (read at import)
+        os.environ["MMX_DIST_REGION_ROWS"] = "0"
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from magellanmapper_amd import dist as d, stack_detect as sd
@@ -230,6 +232,9 @@ def _worker_dist_prune(rank, world, port, case, out_dir):
             local.append((i, tbl))
         seg = sd.StackDetector.assemble_seg_rois(local, grid, n_extra, arena, local_only=True)
         assert seg.local_only and all(seg[coords[i]] is None for i in range(len(coords)) if i not in mine)
+        region_runs = []
+        run_all = sd._RegionPruner.run_all
+        sd._RegionPruner.run_all = lambda self: (region_runs.append(len(self.regions)), run_all(self))[1]
 
         class Img:
             pass
@@ -247,6 +252,8 @@ def _worker_dist_prune(rank, world, port, case, out_dir):
         np.save(os.path.join(out_dir, f"final{rank}.npy"), np.zeros((0, 0)) if final is None else np.asarray(final))
         with open(os.path.join(out_dir, f"final{rank}.txt"), "w") as f:
             f.write(",".join(final.col_names) if is_final else "")
+        with open(os.path.join(out_dir, f"regions{rank}.txt"), "w") as f:
+            f.write(" ".join(str(v) for v in region_runs))
     finally:
         td.destroy_process_group()
 
@@ -303,13 +310,17 @@ def _dist_case(case):
 @pytest.mark.parametrize("world,case", [(2, "plain"), (3, "holes"), (4, "extra_columns_two_channels"), (4, "flat"),
                                         (3, "all_empty"), (2, "nothing"), (2, "second_half_none"),
                                         (3, "second_half_none"), (3, "one_rank_all_empty"), (2, "far_from_seam"),
-                                        (4, "far_from_seam")])
+                                        (4, "far_from_seam"), (2, "plain+regions"), (3, "holes+regions"),
+                                        (2, "extra_columns_two_channels+regions"), (2, "flat+regions"),
+                                        (3, "second_half_none+regions"), (2, "far_from_seam+regions")])
 def test_distributed_pruning_equals_one_process(tmp_path, world, case):
     """Every rank holds the tables of its own blocks only, prunes its own rows (three passes on its rows plus the
     other ranks' rows within reach of its blocks) and merges everybody's survivors by key: the table -- rows, order,
     averaged coordinates -- and the pruning-ratio statistics one process gets from the whole table, on every rank;
-    uneven shares, EMPTY / missing blocks, 13-column two-channel tables, nothing at all."""
+    uneven shares, EMPTY / missing blocks, 13-column two-channel tables, nothing at all.  ``+regions``: every rank prunes
+    its blocks region by region on a few threads (what it does from ``StackPruner.REGION_MIN_ROWS`` own rows on)."""
     from magellanmapper_amd import stack_detect as sd
+    case, _, regions = case.partition("+")
     blocks, tables, shape, channels, n_extra = _dist_case(case)
     seg = sd.StackDetector.assemble_seg_rois(list(enumerate(tables)), blocks.sub_roi_slices.shape, n_extra)
 
@@ -326,7 +337,12 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
         assert 300 < len(want)
     else:
         assert 1000 < len(want) < sum(len(t) for t in tables if t is not None)
-    tmp.spawn(_worker_dist_prune, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    tmp.spawn(_worker_dist_prune, args=(world, _free_port(), case, str(tmp_path), bool(regions)), nprocs=world, join=True)
+    runs = [(tmp_path / f"regions{r}.txt").read_text().split() for r in range(world)]
+    if regions:         # (some rank did prune several regions side by side, in both collectives)
+        assert any(len(v) == 2 and int(v[0]) > 1 for v in runs), runs
+    else:
+        assert not any(runs), runs
     for r in range(world):
         got = np.load(tmp_path / f"pruned{r}.npy")
         ratios = np.load(tmp_path / f"ratios{r}.npy")
