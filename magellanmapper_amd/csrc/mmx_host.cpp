@@ -698,25 +698,39 @@ extern "C" int mmx_host_rows_in_boxes(const int32_t* zyx, const int32_t* tag, co
     if (n < 0 || n_boxes < 0 || !out_n || (n && (!zyx || !tag || !abs_zyx || !chan)) || (n_boxes && (!box_lo || !box_hi)) ||
         (cap && !out) || cap < 0)
         return MMX_ERR_ARG;
-    int64_t k = 0;
-    for (int64_t i = 0; i < n && n_boxes; ++i) {
+    *out_n = 0;
+    if (n == 0 || n_boxes == 0) return MMX_OK;
+    auto inside = [&](int64_t i) {
         const int32_t* c = zyx + 3 * i;
-        bool in = false;
-        for (int b = 0; b < n_boxes && !in; ++b) {
+        for (int b = 0; b < n_boxes; ++b) {
             const int32_t* lo = box_lo + 3 * b; const int32_t* hi = box_hi + 3 * b;
-            in = c[0] >= lo[0] && c[0] < hi[0] && c[1] >= lo[1] && c[1] < hi[1] && c[2] >= lo[2] && c[2] < hi[2];
+            if (c[0] >= lo[0] && c[0] < hi[0] && c[1] >= lo[1] && c[1] < hi[1] && c[2] >= lo[2] && c[2] < hi[2]) return true;
         }
-        if (!in) continue;
-        if (k < cap) {
+        return false;
+    };
+    // two passes over contiguous runs of rows: count, then write from each run's offset (the rows keep their order)
+    const int T = host_threads(n);
+    std::vector<int64_t> first((size_t)T + 1, 0);
+    parallel(T, [&](int t, int) {
+        int64_t k = 0;
+        for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) k += inside(i);
+        first[(size_t)t + 1] = k;
+    });
+    for (int t = 0; t < T; ++t) first[(size_t)t + 1] += first[(size_t)t];
+    *out_n = first[(size_t)T];
+    parallel(T, [&](int t, int) {
+        int64_t k = first[(size_t)t];
+        for (int64_t i = n * t / T; i < n * (t + 1) / T && k < cap; ++i) {
+            if (!inside(i)) continue;
+            const int32_t* c = zyx + 3 * i;
             double* o = out + 10 * k;
             o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
             o[3] = tag[3 * i]; o[4] = tag[3 * i + 1]; o[5] = tag[3 * i + 2];
             o[6] = abs_zyx[3 * i]; o[7] = abs_zyx[3 * i + 1]; o[8] = abs_zyx[3 * i + 2];
             o[9] = chan[i * chan_ld];
+            ++k;
         }
-        ++k;
-    }
-    *out_n = k;
+    });
     return MMX_OK;
 }
 

@@ -1440,11 +1440,8 @@ class StackPruner:
                 row = 0
                 csrc = None if final is None else (ctypes.c_int32 * width)(*final[0])
                 cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
-                for r_ids, r_keys, r_abs, _ in rp.done:         # (regions in order: the merge by key is stable)
+                def emit(r_ids, r_keys, r_abs, dst):
                     k = len(r_ids)
-                    if not k:
-                        continue
-                    dst = mine[row:row + k]
                     if final is not None:
                         nat.check(lib.mmx_host_emit_survivors_final(
                             ar.store.ctypes.data, ar.store.strides[0] // 8, r_ids.ctypes.data, r_keys.ctypes.data, k,
@@ -1453,7 +1450,22 @@ class StackPruner:
                         nat.check(lib.mmx_host_emit_survivors(
                             ar.store.ctypes.data, ar.store.strides[0] // 8, r_ids.ctypes.data, r_keys.ctypes.data, k,
                             width, r_abs.ctypes.data, cols3, dst.ctypes.data), "mmx_host_emit_survivors")
-                    row += k
+                # (regions in order: the merge by key is stable; every region writes its own rows of the payload, side
+                #  by side on the region threads -- one region's rows are too few for the native call to thread itself)
+                jobs = []
+                for r_ids, r_keys, r_abs, _ in rp.done:
+                    k = len(r_ids)
+                    if k:
+                        jobs.append(_region_workers().submit(emit, r_ids, r_keys, r_abs, mine[row:row + k]))
+                        row += k
+                failure = None
+                for j in jobs:
+                    try:
+                        j.result()
+                    except Exception as exc:
+                        failure = failure or exc
+                if failure is not None:
+                    raise failure
                 _lap("own survivors in final form")
                 return mine, counts
         ids = np.empty(max(1, n), dtype=np.int64)

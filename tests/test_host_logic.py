@@ -1352,7 +1352,7 @@ def test_rank_table_plumbing_natives():
     from magellanmapper_amd import _native as nat
     lib = nat.lib()
     rng = np.random.default_rng(3)
-    n, ncol = 5000, 14
+    n, ncol = 50000, 14                     # (enough rows for the threaded forms)
     store = rng.normal(size=(n, ncol))
     zyx = rng.integers(0, 200, (n, 3)).astype(np.int32)
     tag = rng.integers(0, 5, (n, 3)).astype(np.int32)
