@@ -599,6 +599,10 @@ int mmx_host_emit_survivors_final(const double* table, int64_t ld, const int64_t
                                   double* out);
 int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
                           int64_t n_cols, double* out);
+/* ... on the concatenation of n_parts row blocks (parts[p]: n_rows[p] rows of pitch ld, the key in column n_cols) that
+ * nobody has to concatenate -- what an all_gather of the ranks' survivors, padded to the longest block, leaves. */
+int mmx_host_merge_parts_by_key(const double* const* parts, const int64_t* n_rows, int32_t n_parts, int64_t ld,
+                                int64_t n_keys, int64_t n_cols, double* out, int64_t out_rows);
 int mmx_host_gather_by_key(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
                            int64_t n_keys, int64_t n_cols, const double* abs_rows, const int32_t abs_cols[3],
                            double* out);

@@ -581,6 +581,78 @@ extern "C" int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64
     return MMX_OK;
 }
 
+// mmx_host_merge_by_key on the CONCATENATION of n_parts row blocks (every rank's survivors as an all_gather leaves
+// them: padded to the longest block, so not contiguous), keys in column n_cols of each row -- without the 20 MB copy
+// that would make them one array.  Blocks are cut into segments so that every thread has work whatever their number.
+extern "C" int mmx_host_merge_parts_by_key(const double* const* parts, const int64_t* n_rows, int32_t n_parts, int64_t ld,
+                                           int64_t n_keys, int64_t n_cols, double* out, int64_t out_rows)
+{
+    if (n_parts < 0 || n_keys < 1 || n_cols < 1 || n_cols >= ld || (n_parts && (!parts || !n_rows))) return MMX_ERR_ARG;
+    if (n_keys > (int64_t(1) << 26)) return MMX_ERR_UNSUPPORTED;
+    int64_t n = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        if (n_rows[p] < 0 || (n_rows[p] && !parts[p])) return MMX_ERR_ARG;
+        n += n_rows[p];
+    }
+    if (n != out_rows || (n && !out)) return MMX_ERR_ARG;
+    if (n == 0) return MMX_OK;
+    int T = host_threads(n);
+    if ((int64_t)T * n_keys > (int64_t(1) << 24)) T = 1;
+    struct seg { const double* rows; int64_t n; };
+    std::vector<seg> segs;
+    const int64_t piece = std::max<int64_t>(1, (n + 4 * T - 1) / (4 * T));
+    for (int p = 0; p < n_parts; ++p)
+        for (int64_t a = 0; a < n_rows[p]; a += piece)
+            segs.push_back(seg{parts[p] + a * ld, std::min(piece, n_rows[p] - a)});
+    const int S = (int)segs.size();
+    std::vector<int> first((size_t)T + 1, S);
+    {
+        int64_t seen = 0;
+        int t = 0;
+        first[0] = 0;
+        for (int q = 0; q < S; ++q) {
+            while (t + 1 < T && seen >= n * (t + 1) / T) first[(size_t)++t] = q;
+            seen += segs[(size_t)q].n;
+        }
+    }
+    auto key_of = [&](const double* row) -> int64_t {
+        const double v = row[n_cols];
+        return (v >= 0.0 && v < 9.0e15) ? (int64_t)v : -1;
+    };
+    std::vector<int64_t> at((size_t)T * (size_t)n_keys, 0);
+    std::vector<int> bad((size_t)T, 0);
+    parallel(T, [&](int t, int) {
+        int64_t* h = at.data() + (size_t)t * (size_t)n_keys;
+        for (int q = first[(size_t)t]; q < first[(size_t)t + 1] && !bad[(size_t)t]; ++q)
+            for (int64_t i = 0; i < segs[(size_t)q].n; ++i) {
+                const int64_t k = key_of(segs[(size_t)q].rows + i * ld);
+                if (k < 0 || k >= n_keys) { bad[(size_t)t] = 1; break; }
+                ++h[k];
+            }
+    });
+    for (int t = 0; t < T; ++t)
+        if (bad[(size_t)t]) return MMX_ERR_ARG;
+    {
+        int64_t run = 0;
+        for (int64_t k = 0; k < n_keys; ++k)
+            for (int t = 0; t < T; ++t) {
+                int64_t& c = at[(size_t)t * (size_t)n_keys + (size_t)k];
+                const int64_t here = c;
+                c = run;
+                run += here;
+            }
+    }
+    parallel(T, [&](int t, int) {
+        int64_t* pos = at.data() + (size_t)t * (size_t)n_keys;
+        for (int q = first[(size_t)t]; q < first[(size_t)t + 1]; ++q)
+            for (int64_t i = 0; i < segs[(size_t)q].n; ++i) {
+                const double* row = segs[(size_t)q].rows + i * ld;
+                std::memcpy(out + pos[key_of(row)]++ * n_cols, row, (size_t)n_cols * sizeof(double));
+            }
+    });
+    return MMX_OK;
+}
+
 // The same for survivors that still live in the merged table: row ids[i] of `table` (its first n_cols columns), the
 // three abs columns replaced by abs_rows[i], written to its place by key.
 extern "C" int mmx_host_gather_by_key(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys,

@@ -1310,15 +1310,19 @@ class StackPruner:
         except Exception as exc:
             failure = exc
         width = (ncol - 3) if final is None else len(final[0])          # columns of a survivor's row; its key follows
-        table = dist.all_gather_rows_concat(mine, width + 1, failure, "distributed pruning (own rows)")
+        blocks_, n_per_rank, _ = dist.all_gather_rows_padded(mine, width + 1, failure, "distributed pruning (own rows)")
         _lap("exchange 2 (survivors)")
         out = None
         try:
-            out = np.empty((len(table), width))
-            if len(table):          # (keys: the column behind the table's own, read in place)
-                nat.check(nat.lib().mmx_host_merge_by_key(
-                    table.ctypes.data, width + 1, None, len(table), plan["n_keys"] * len(channels),
-                    width, out.ctypes.data), "mmx_host_merge_by_key")
+            total = int(sum(n_per_rank)) if blocks_ is not None else 0
+            out = np.empty((total, width))
+            if total:       # (every rank's block as the exchange left it; keys: the column behind the table's own)
+                n_rows = np.ascontiguousarray(n_per_rank, dtype=np.int64)
+                step = blocks_.strides[0]
+                ptrs = (ctypes.c_void_p * len(n_per_rank))(*[blocks_.ctypes.data + r * step for r in range(len(n_per_rank))])
+                nat.check(nat.lib().mmx_host_merge_parts_by_key(
+                    ptrs, n_rows.ctypes.data, len(n_per_rank), blocks_.strides[1] // 8, plan["n_keys"] * len(channels),
+                    width, out.ctypes.data, total), "mmx_host_merge_parts_by_key")
         except Exception as exc:
             failure = exc
         _lap("merge by key")

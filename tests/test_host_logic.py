@@ -599,6 +599,31 @@ def test_native_merge_by_key_reads_keys_in_place():
     assert L.mmx_host_merge_by_key(rows.ctypes.data, n_cols + 1, None, n, n_keys, n_cols + 1, out.ctypes.data) == 1
 
 
+def test_native_merge_of_padded_blocks_by_key():
+    """mmx_host_merge_parts_by_key: the stable sort by key of the CONCATENATION of row blocks that are not contiguous
+    (every rank's survivors in an all_gather's padded receive buffer), from two to many blocks, empty ones included."""
+    from magellanmapper_amd import _native as nat
+    L = nat.lib()
+    rng = np.random.default_rng(9)
+    n_cols, n_keys = 8, 700
+    for counts in ([5], [0, 3, 0], [30000, 41000], [9000, 0, 12000, 7000, 1, 15000, 8000, 11000]):
+        most = max(counts)
+        blocks = rng.random((len(counts), most, n_cols + 1))
+        blocks[:, :, n_cols] = rng.integers(0, n_keys, (len(counts), most))
+        live = np.concatenate([blocks[r, :c] for r, c in enumerate(counts)])
+        want = live[np.argsort(live[:, n_cols].astype(np.int64), kind="stable"), :n_cols]
+        n_rows = np.array(counts, dtype=np.int64)
+        ptrs = (ctypes.c_void_p * len(counts))(*[blocks.ctypes.data + r * blocks.strides[0] for r in range(len(counts))])
+        out = np.full((len(live), n_cols), np.nan)
+        assert L.mmx_host_merge_parts_by_key(ptrs, n_rows.ctypes.data, len(counts), n_cols + 1, n_keys, n_cols,
+                                             out.ctypes.data, len(live)) == 0
+        np.testing.assert_array_equal(out, want)
+    assert L.mmx_host_merge_parts_by_key(ptrs, n_rows.ctypes.data, len(counts), n_cols + 1, n_keys, n_cols,
+                                         out.ctypes.data, len(live) - 1) == 1            # wrong output size
+    assert L.mmx_host_merge_parts_by_key(ptrs, n_rows.ctypes.data, len(counts), n_cols + 1, 100, n_cols,
+                                         out.ctypes.data, len(live)) == 1                # key >= n_keys
+
+
 def test_native_prune_works_in_a_forked_child():
     """The host thread pool lives in the dlopen'd library; after fork() its threads are gone (the reference's
     default start method is 'fork').  A table large enough for the threaded path must still prune in the child."""
