@@ -597,6 +597,10 @@ int mmx_host_emit_survivors(const double* table, int64_t ld, const int64_t* ids,
 int mmx_host_emit_survivors_final(const double* table, int64_t ld, const int64_t* ids, const int64_t* keys, int64_t n,
                                   const int32_t* src_cols, int32_t n_out, const double* abs_rows, int32_t abs_dst0,
                                   double* out);
+/* ... for n_parts survivor lists at once, in order (a rank's regions): out[out_rows][n_out + 1]. */
+int mmx_host_emit_parts_final(const double* table, int64_t ld, int32_t n_parts, const int64_t* const* ids,
+                              const int64_t* const* keys, const double* const* abs_rows, const int64_t* n_rows,
+                              const int32_t* src_cols, int32_t n_out, int32_t abs_dst0, double* out, int64_t out_rows);
 int mmx_host_merge_by_key(const double* rows, int64_t ld, const int64_t* keys, int64_t n, int64_t n_keys,
                           int64_t n_cols, double* out);
 /* ... on the concatenation of n_parts row blocks (parts[p]: n_rows[p] rows of pitch ld, the key in column n_cols) that

@@ -884,6 +884,51 @@ extern "C" int mmx_host_emit_survivors_final(const double* table, int64_t ld, co
     return MMX_OK;
 }
 
+// mmx_host_emit_survivors_final for n_parts survivor lists at once (a rank's regions, in order): one threaded pass over
+// all of them -- a region's few thousand rows are too few for a call of their own to thread itself, and sixteen calls
+// from Python threads cost more in hand-offs than in copying.
+extern "C" int mmx_host_emit_parts_final(const double* table, int64_t ld, int32_t n_parts, const int64_t* const* ids,
+                                         const int64_t* const* keys, const double* const* abs_rows,
+                                         const int64_t* n_rows, const int32_t* src_cols, int32_t n_out, int32_t abs_dst0,
+                                         double* out, int64_t out_rows)
+{
+    if (n_parts < 0 || n_out < 3 || n_out > 64 || !src_cols || abs_dst0 < 0 || abs_dst0 + 3 > n_out ||
+        (n_parts && (!ids || !keys || !abs_rows || !n_rows)))
+        return MMX_ERR_ARG;
+    for (int j = 0; j < n_out; ++j)
+        if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
+    std::vector<int64_t> first((size_t)n_parts + 1, 0);
+    for (int p = 0; p < n_parts; ++p) {
+        if (n_rows[p] < 0 || (n_rows[p] && (!ids[p] || !keys[p] || !abs_rows[p]))) return MMX_ERR_ARG;
+        first[(size_t)p + 1] = first[(size_t)p] + n_rows[p];
+    }
+    const int64_t n = first[(size_t)n_parts];
+    if (n != out_rows || (n && (!table || !out))) return MMX_ERR_ARG;
+    if (n == 0) return MMX_OK;
+    const int T = host_threads(n);
+    std::vector<int> bad((size_t)T, 0);
+    parallel(T, [&](int t, int) {
+        // rows [lo, hi) of the concatenation: walk the parts they fall into
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        int p = (int)(std::upper_bound(first.begin(), first.end(), lo) - first.begin()) - 1;
+        for (int64_t g = lo; g < hi; ++p) {
+            const int64_t end = std::min(hi, first[(size_t)p + 1]);
+            for (; g < end; ++g) {
+                const int64_t i = g - first[(size_t)p];
+                if (ids[p][i] < 0) { bad[(size_t)t] = 1; return; }
+                double* o = out + g * (n_out + 1);
+                const double* src = table + ids[p][i] * ld;
+                for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
+                for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_rows[p][3 * i + a];
+                o[n_out] = (double)keys[p][i];
+            }
+        }
+    });
+    for (int t = 0; t < T; ++t)
+        if (bad[(size_t)t]) return MMX_ERR_ARG;
+    return MMX_OK;
+}
+
 // out[i][dst_col0 + j] = table[i][src_cols[j]] for every row: the column shuffles that end a stack
 // detection (Blobs.replace_rel_with_abs_blob_coords: out = table, columns 7..9 -> 0..2;
 // Blobs.remove_abs_blob_coords: the kept columns into a new table).  `out` may be `table` itself (a row is

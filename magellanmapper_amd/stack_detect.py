@@ -1444,32 +1444,23 @@ class StackPruner:
                 row = 0
                 csrc = None if final is None else (ctypes.c_int32 * width)(*final[0])
                 cols3 = (ctypes.c_int32 * 3)(*[int(v) for v in abs_inds])
-                def emit(r_ids, r_keys, r_abs, dst):
-                    k = len(r_ids)
-                    if final is not None:
-                        nat.check(lib.mmx_host_emit_survivors_final(
-                            ar.store.ctypes.data, ar.store.strides[0] // 8, r_ids.ctypes.data, r_keys.ctypes.data, k,
-                            csrc, width, r_abs.ctypes.data, final[1], dst.ctypes.data), "mmx_host_emit_survivors_final")
-                    else:
+                # (regions in order: the merge by key is stable)
+                live = [d for d in rp.done if len(d[0])]
+                if final is not None:       # one threaded pass over all the regions' lists
+                    if live:
+                        n_rows = np.array([len(d[0]) for d in live], dtype=np.int64)
+                        ptrs = [(ctypes.c_void_p * len(live))(*[d[c].ctypes.data for d in live]) for c in range(3)]
+                        nat.check(lib.mmx_host_emit_parts_final(
+                            ar.store.ctypes.data, ar.store.strides[0] // 8, len(live), ptrs[0], ptrs[1], ptrs[2],
+                            n_rows.ctypes.data, csrc, width, final[1], mine.ctypes.data, len(mine)),
+                            "mmx_host_emit_parts_final")
+                else:                       # (tables with co-localisation columns: region by region)
+                    for r_ids, r_keys, r_abs, _ in live:
+                        k = len(r_ids)
                         nat.check(lib.mmx_host_emit_survivors(
                             ar.store.ctypes.data, ar.store.strides[0] // 8, r_ids.ctypes.data, r_keys.ctypes.data, k,
-                            width, r_abs.ctypes.data, cols3, dst.ctypes.data), "mmx_host_emit_survivors")
-                # (regions in order: the merge by key is stable; every region writes its own rows of the payload, side
-                #  by side on the region threads -- one region's rows are too few for the native call to thread itself)
-                jobs = []
-                for r_ids, r_keys, r_abs, _ in rp.done:
-                    k = len(r_ids)
-                    if k:
-                        jobs.append(_region_workers().submit(emit, r_ids, r_keys, r_abs, mine[row:row + k]))
+                            width, r_abs.ctypes.data, cols3, mine[row:row + k].ctypes.data), "mmx_host_emit_survivors")
                         row += k
-                failure = None
-                for j in jobs:
-                    try:
-                        j.result()
-                    except Exception as exc:
-                        failure = failure or exc
-                if failure is not None:
-                    raise failure
                 _lap("own survivors in final form")
                 return mine, counts
         ids = np.empty(max(1, n), dtype=np.int64)

@@ -624,6 +624,37 @@ def test_native_merge_of_padded_blocks_by_key():
                                          out.ctypes.data, len(live)) == 1                # key >= n_keys
 
 
+def test_native_emit_of_several_survivor_lists_at_once():
+    """mmx_host_emit_parts_final == mmx_host_emit_survivors_final list by list, back to back (threaded over the
+    concatenation: lists of any length, empty ones included)."""
+    from magellanmapper_amd import _native as nat
+    L = nat.lib()
+    rng = np.random.default_rng(10)
+    n_table, ld = 90000, 14
+    table = rng.random((n_table, ld))
+    src = [0, 1, 2, 3, 4, 5, 6, 10]
+    csrc = (ctypes.c_int32 * len(src))(*src)
+    for counts in ([7], [0, 0], [4000, 0, 1, 25000, 9000, 12000]):
+        lists = [(rng.integers(0, n_table, c).astype(np.int64), rng.integers(0, 500, c).astype(np.int64), rng.random((c, 3)))
+                 for c in counts]
+        want = []
+        for ids, keys, ab in lists:
+            o = np.empty((len(ids), len(src) + 1))
+            if len(ids):
+                nat.check(L.mmx_host_emit_survivors_final(table.ctypes.data, ld, ids.ctypes.data, keys.ctypes.data, len(ids),
+                                                          csrc, len(src), ab.ctypes.data, 0, o.ctypes.data), "emit")
+            want.append(o)
+        want = np.concatenate(want)
+        n_rows = np.array(counts, dtype=np.int64)
+        ptrs = [(ctypes.c_void_p * len(lists))(*[(d[c].ctypes.data if len(d[0]) else None) for d in lists]) for c in range(3)]
+        out = np.full((len(want), len(src) + 1), np.nan)
+        assert L.mmx_host_emit_parts_final(table.ctypes.data, ld, len(lists), ptrs[0], ptrs[1], ptrs[2], n_rows.ctypes.data,
+                                           csrc, len(src), 0, out.ctypes.data, len(want)) == 0
+        np.testing.assert_array_equal(out, want)
+    assert L.mmx_host_emit_parts_final(table.ctypes.data, ld, len(lists), ptrs[0], ptrs[1], ptrs[2], n_rows.ctypes.data,
+                                       csrc, len(src), 0, out.ctypes.data, len(want) + 1) == 1
+
+
 def test_native_prune_works_in_a_forked_child():
     """The host thread pool lives in the dlopen'd library; after fork() its threads are gone (the reference's
     default start method is 'fork').  A table large enough for the threaded path must still prune in the child."""
