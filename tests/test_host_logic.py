@@ -687,6 +687,25 @@ def test_native_prune_works_in_a_forked_child():
     assert q.get(timeout=5) is True
 
 
+def test_region_threads_work_in_a_forked_child():
+    """The executor the pruning regions run on is kept for the life of the process; a forked child (the reference's
+    default start method) must not wait for the parent's threads: it makes its own."""
+    import multiprocessing as mp
+    from magellanmapper_amd import stack_detect as sd
+    assert sd._region_workers().submit(lambda: 41 + 1).result(timeout=30) == 42        # threads exist in the parent
+
+    def child(q):
+        q.put(sd._region_workers().submit(lambda: os.getpid()).result(timeout=30))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    p.join(60)
+    assert p.exitcode == 0, "the forked child hung waiting for region threads it does not have"
+    assert q.get(timeout=5) == p.pid
+
+
 def test_get_mp_pool_follows_config():
     from magellanmapper_amd import chunking, config
     config.setup_roi_profiles(None)

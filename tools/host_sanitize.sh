@@ -43,9 +43,9 @@ if [ "$which" = tsan ] || [ "$which" = both ]; then
     # (gloo ranks are separate processes: what TSan can see is the pool inside one process -- test_host_logic drives
     #  every parallel section; MMX_HOST_THREADS=8 makes sure the sections really fan out on a small container and
     #  MMX_HOST_SPIN_US=150 that the workers poll before they sleep as on a machine with cores to spare.
-    #  TSan cannot follow fork() from a process that already has threads -- it deadlocks in the child -- so the two
+    #  TSan cannot follow fork() from a process that already has threads -- it deadlocks in the child -- so the
     #  tests that fork are left to the ASan run)
     run tsan "$tsan_rt" "TSAN_OPTIONS=report_signal_unsafe=0:history_size=4 MMX_HOST_THREADS=8 MMX_HOST_SPIN_US=150" \
-        "tests/test_host_logic.py --deselect tests/test_host_logic.py::test_native_prune_works_in_a_forked_child --deselect tests/test_host_logic.py::test_get_mp_pool_follows_config"
+        "tests/test_host_logic.py --deselect tests/test_host_logic.py::test_native_prune_works_in_a_forked_child --deselect tests/test_host_logic.py::test_get_mp_pool_follows_config --deselect tests/test_host_logic.py::test_region_threads_work_in_a_forked_child"
 fi
 exit $status
