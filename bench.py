@@ -723,6 +723,11 @@ def main():
     # (N > 1: rank 0 still runs it -- the other ranks wait for it in init_process_group, whose timeout allows for that --
     #  so that every line of a scaling run carries the baseline measured on that box)
     baselines = {}
+    # host allocator, before anything large is allocated: the per-step tables (tens of MB) come from the heap and stay
+    # mapped between steps instead of being mmap'd, page-faulted in and unmapped every step (8 ms of a 198 ms step,
+    # tools/steptrace.py)
+    from magellanmapper_amd import _native as nat
+    nat.keep_host_heap()
     if rank == 0 and args.parity_sample:
         got = load_parity_sample(args.parity_sample, args.config, args)
         if got is not None:
@@ -731,6 +736,12 @@ def main():
         for name in [args.config] + subs:
             if name not in baselines:
                 baselines[name] = run_cpu_baseline(name, args, host_vol)
+    if any(b.get("cpu") for b in baselines.values()):
+        # the oracle pools have just ended: a hundred-odd spawned interpreters are still being torn down and the cores
+        # they loaded for a minute are hot.  Two runs of this command on two boxes read 104.3 / 104.9 ms with 10.8 / 11.9
+        # ms of exposed host time when the GPU part followed at once (100.0 without the pools on the same box); with this
+        # pause (and the allocator set up first) 99.1 / 99.3 against 99.8 / 101.0 alternating (tools/exp/ab_baseline.sh)
+        time.sleep(float(os.environ.get("MMX_BENCH_SETTLE_S", 3)))
     # one rank per GPU; MMX_DIST_BACKEND=gloo + fewer GPUs than ranks is only for functional tests
     backend = os.environ.get("MMX_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
     n_dev = torch.cuda.device_count()
@@ -748,12 +759,8 @@ def main():
         else:
             tdist.init_process_group(backend, timeout=wait)
 
-    from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
 
-    # host allocator: the per-step tables (tens of MB) come from the heap and stay mapped between steps instead
-    # of being mmap'd, page-faulted in and unmapped every step (8 ms of a 198 ms step, tools/steptrace.py)
-    nat.keep_host_heap()
     import scipy
     ctx = dict(rank=rank, world=world, dev=dev, backend=backend, blob_log_blocks=bl.blob_log_blocks,
                # the one third-party routine whose implementation-defined order reaches the result (chain blocks of the
