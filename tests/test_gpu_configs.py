@@ -128,6 +128,32 @@ def test_c2_single_sigma_volume_matches_oracle(gpu, tmp_path):
     np.testing.assert_array_equal(got, want)
 
 
+def test_kernel_event_modes_of_the_bench_line(gpu, tmp_path):
+    """``bench.py --kernel-events all | dominant | none``: where the per-kernel HIP events are recorded (inside the timed
+    region, only the roofline's family there, or in extra steps after it) changes neither the table nor what the line
+    reports -- every family has its launches and a time."""
+    shape = (96, 200, 210)
+    vol = _host_volume(shape, 5)
+    np.save(tmp_path / "ke.npy", vol)
+    lines = {}
+    for mode in ("all", "dominant", "none"):
+        lines[mode] = _run_bench(tmp_path, 1, "--config", "c3", "--segment-size", "64", "--volume", str(tmp_path / "ke.npy"),
+                                 "--steps", "2", "--warmup", "1", "--kernel-events", mode)
+    ref = lines["all"]
+    assert ref["config"]["blocks_per_rank"] > 8 and ref["graph_replay"] is None        # (not the small-volume graph path)
+    assert ref["kernel_events"]["in_timed_region"] == "all" and lines["none"]["kernel_events"]["in_timed_region"] == "none"
+    timed = lines["dominant"]["kernel_events"]["in_timed_region"]
+    from magellanmapper_amd import _native
+    # (the warm-up step's longest family -- on these small blocks not necessarily one the later steps launch)
+    assert isinstance(timed, list) and len(timed) == 1 and timed[0] in _native.KERNEL_KINDS
+    for mode, line in lines.items():
+        assert line["table_sha1"] == ref["table_sha1"] and line["blobs"] == ref["blobs"] > 0, mode
+        assert line["roofline"]["kernel"] in ref["kernels"], mode          # (tiny kernels here: which one leads is noise)
+        assert set(line["kernels"]) == set(ref["kernels"]), mode
+        for fam, rec in line["kernels"].items():
+            assert rec["launches_per_step"] == ref["kernels"][fam]["launches_per_step"] and rec["ms_per_step"] > 0, (mode, fam)
+
+
 @pytest.mark.parametrize("ranks", [2, 3])
 def test_c5_shaped_two_channel_coloc_over_ranks(gpu, tmp_path, ranks):
     """BASELINE.json configs[4] in small: 2 channels (30 % of channel 1's blobs of its own), per-block preprocessing
