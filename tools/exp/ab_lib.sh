@@ -1,5 +1,7 @@
 #!/bin/bash
 # A/B of two builds of libmmx_hip.so on one box: bench.py lines (c3 + appended c2 / c5) and the c3 step trace, alternating.
+# The other build goes to magellanmapper_amd/libmmx_old.so first (git stash; make -C magellanmapper_amd/csrc; cp ../libmmx_hip.so
+# ../libmmx_old.so; git stash pop; make again) and is selected through MMX_LIB_PATH.
 OLD=$PWD/magellanmapper_amd/libmmx_old.so
 for rep in 1 2; do
   for lib in old new; do
