@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 14
+#define MMX_ABI_VERSION 15
 
 typedef enum {
     MMX_OK = 0,
@@ -394,6 +394,29 @@ int mmx_preprocess_batch(const mmx_volume* vol, const mmx_subblock* d_subs, cons
                          const mmx_preproc_params* params, const double* d_weights,
                          int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
                          mmx_subblock_info* d_info, void* stream);
+
+/* The same with the kernel choice and the workspace in the caller's hands (tests cross-check the forms; tools time them):
+ *   MMX_PP_AUTO      : what mmx_preprocess_batch does -- tiles of > 4 096 voxels take the pipelined form
+ *                      (mmx_preproc_pipe.hip: tile-major voxel copy, statistics kernel, blur kernel that walks runs
+ *                      of tiles), smaller ones the one-kernel-per-tile form
+ *   MMX_PP_SINGLE    : one kernel per tile whatever its size (pp_fast_kernel)
+ *   MMX_PP_PIPELINED : the pipelined form whatever the size (MMX_ERR_UNSUPPORTED if a tile does not fit)
+ *   tiles_per_wg     : tiles one workgroup of the blur kernel walks (0 = MMX_PP_TILES_PER_WG)
+ *   d_work           : mmx_preprocess_work_bytes(h_subs, n_subs) bytes of device scratch for the pipelined form
+ *                      (2 bytes per voxel + 12 per tile), or NULL: taken from the stream's memory pool for the call;
+ *                      likewise d_info may be NULL in every mode.  MMX_ERR_WORKSPACE when work_bytes is too small.
+ * Results are bit-identical across modes.                                                                     */
+#define MMX_PP_AUTO 0
+#define MMX_PP_SINGLE 1
+#define MMX_PP_PIPELINED 2
+#define MMX_PP_TILES_PER_WG 8
+int64_t mmx_preprocess_work_bytes(const mmx_subblock* h_subs, int n_subs);
+int mmx_preprocess_batch_mode(const mmx_volume* vol, const mmx_subblock* d_subs, const mmx_subblock* h_subs,
+                              int n_subs, const mmx_quantile_class* d_qclasses, int n_qclasses,
+                              const mmx_preproc_params* params, const double* d_weights,
+                              int64_t dst_sy, int64_t dst_sz, float* d_out32, double* d_out64,
+                              mmx_subblock_info* d_info, int mode, int tiles_per_wg,
+                              void* d_work, int64_t work_bytes, void* stream);
 
 /* Same contract for any extent: data in d_scratch (each sub-block owns 2*nz*ny*nx doubles at its
  * scratch_off -- 7*nz*ny*nx with params->tv_weight set), one output per lane and pass. */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: ``MMX_LIB_PATH`` selects an experimental build of the same ABI (kernel tuning only)
 LIB_PATH = os.environ.get("MMX_LIB_PATH") or os.path.join(_HERE, "libmmx_hip.so")
 
-MMX_ABI_VERSION = 14
+MMX_ABI_VERSION = 15
 MMX_U8, MMX_U16, MMX_F32, MMX_F64 = 0, 1, 2, 3
 MMX_MAX_RADIUS_FAST = 24
 MMX_MAX_RADIUS_GENERIC = 255
@@ -50,6 +50,7 @@ SUBINFO_DTYPE = np.dtype([("vmin", "<f8"), ("vmax", "<f8"), ("mean", "<f8"), ("f
                           ("_pad", "<i4")], align=True)
 assert SUBBLOCK_DTYPE.itemsize == 40 and QCLASS_DTYPE.itemsize == 32 and SUBINFO_DTYPE.itemsize == 32
 MMX_PP_IDENTITY, MMX_PP_ERODED, MMX_PP_EXACT_MEAN = 1, 2, 4
+MMX_PP_AUTO, MMX_PP_SINGLE, MMX_PP_PIPELINED = 0, 1, 2     # kernel choice of mmx_preprocess_batch_mode
 #: NumPy mirror of ``mmx_resize_block`` (48 bytes)
 RESIZE_DTYPE = np.dtype([("src_off", "<i8"), ("in_nz", "<i4"), ("in_ny", "<i4"), ("in_nx", "<i4"),
                          ("out_nz", "<i4"), ("out_ny", "<i4"), ("out_nx", "<i4"), ("slot", "<i4"),
@@ -105,7 +106,7 @@ SYMBOLS = (
     "mmx_overlap_pairs", "mmx_close_pairs", "mmx_event_create", "mmx_event_destroy",
     "mmx_event_record", "mmx_event_elapsed_ms", "mmx_timing_enable", "mmx_timing_read",
     "mmx_calib_stream", "mmx_host_prune_axis",
-    "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_generic",
+    "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_mode", "mmx_preprocess_work_bytes", "mmx_preprocess_batch_generic",
     "mmx_coloc_means", "mmx_coloc_voxels", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
     "mmx_cdist_f64", "mmx_host_lsap", "mmx_expand_probes", "mmx_host_resolve_peaks", "mmx_host_overlap_prune",
     "mmx_host_emit_tables", "mmx_host_prune_region", "mmx_host_prune_parts", "mmx_host_rows_in_boxes", "mmx_host_append_rows", "mmx_host_emit_survivors", "mmx_host_merge_by_key", "mmx_host_merge_parts_by_key", "mmx_host_gather_by_key", "mmx_host_take_rows_final", "mmx_host_emit_survivors_final", "mmx_host_emit_parts_final", "mmx_host_gather_parts_by_key_final",
@@ -176,6 +177,9 @@ def lib() -> ctypes.CDLL:
     pre_args = [POINTER(Volume), vp, vp, c_int, vp, c_int, POINTER(PreprocParams), vp,
                 c_int64, c_int64, vp, vp, vp]
     L.mmx_preprocess_batch.argtypes = pre_args + [vp]
+    L.mmx_preprocess_batch_mode.argtypes = pre_args + [c_int, c_int, vp, c_int64, vp]
+    L.mmx_preprocess_work_bytes.argtypes = [vp, c_int]
+    L.mmx_preprocess_work_bytes.restype = c_int64
     L.mmx_preprocess_batch_generic.argtypes = pre_args + [vp, c_int64, vp]
     L.mmx_minmax_batch.argtypes = [POINTER(Volume), vp, vp, c_int, vp, vp]
     L.mmx_minmax_batch.restype = c_int
@@ -228,10 +232,11 @@ def lib() -> ctypes.CDLL:
     L.mmx_host_emit_tables.argtypes = [vp, vp, vp, c_int, vp, c_int, c_double, vp, vp, vp, vp, c_int64, vp, vp, vp,
                                        c_int64, c_int64, vp]
     L.mmx_preprocess_batch.restype = c_int
+    L.mmx_preprocess_batch_mode.restype = c_int
     L.mmx_preprocess_batch_generic.restype = c_int
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name in ("mmx_preprocess_fast_lds", "mmx_workspace_bytes"):
+        if name in ("mmx_preprocess_fast_lds", "mmx_workspace_bytes", "mmx_preprocess_work_bytes"):
             continue
         if fn.restype is None or name.startswith(("mmx_log", "mmx_peaks", "mmx_rescore",
                                                   "mmx_overlap", "mmx_close", "mmx_event", "mmx_timing", "mmx_calib", "mmx_host")):

@@ -45,6 +45,10 @@ GAUSS_WEIGHTS_OVERRIDE: Optional[np.ndarray] = None
 #: test hook: send every tile through the global-scratch kernels (sides <= 64: register-line kernel,
 #: larger: one output per lane) instead of the LDS kernel; "big" forces the one-output-per-lane kernel
 FORCE_GENERIC = False
+#: kernel form of the LDS-resident tiles (``nat.MMX_PP_AUTO`` / ``_SINGLE`` / ``_PIPELINED``) and the tiles one
+#: workgroup of the pipelined blur kernel walks (0 = the library's default): what tests and tools switch
+KERNEL_MODE = nat.MMX_PP_AUTO
+TILES_PER_WG = 0
 
 
 def gauss_weights() -> np.ndarray:
@@ -105,6 +109,8 @@ def channel_params(chl: int, near_max: Optional[Sequence[float]] = None) -> Tupl
 #: output buffer sets a preprocessing stage cycles through (``run(..., which)``): batch k + 2 may be preprocessed while
 #: batch k + 1 waits for its LoG passes and batch k's results are still being re-scored (``blob_log``: two batches ahead)
 N_BUFFER_SETS = 3
+#: bytes per block voxel of one stage's output slots: a float32 and a float64 copy in every buffer set
+_SLOT_BYTES = (4 + 8) * N_BUFFER_SETS
 #: device -> {"f64_<channel>" / "f32": tensor}: the resident preprocessed blocks of `Preprocessor.retain`
 _RETAINED: Dict[str, Dict[str, "torch.Tensor"]] = {}
 
@@ -128,6 +134,8 @@ class Preprocessor:
         self._out64 = [None] * N_BUFFER_SETS
         self._out32 = [None] * N_BUFFER_SETS
         self._scratch = None
+        self._info = [None] * N_BUFFER_SETS
+        self._work = None
         self._weights = None
         self._tmpl_key = None
         self._tmpl, self._qc_rows, self._qc_index = {}, [], {}
@@ -196,10 +204,11 @@ class Preprocessor:
     # ---- geometry
     @staticmethod
     def bytes_per_voxel() -> int:
-        """Extra HBM per block voxel: one float32 slot + two (double-buffered) float64 slots (+ the 7-double
-        scratch of the total-variation iteration when any profile switches it on)."""
+        """Extra HBM per block voxel: a float32 + a float64 slot in each of the ``N_BUFFER_SETS`` buffer sets, the
+        tile-major uint16 copy of the pipelined kernels (+ the 7-double scratch of the total-variation iteration when
+        any profile switches it on)."""
         tv = any(p["tot_var_denoise"] for p in [config.roi_profile, *config.roi_profiles] if p)
-        return 4 + 2 * 8 + (7 * 8 if tv else 0)
+        return _SLOT_BYTES + 2 + (7 * 8 if tv else 0)
 
     def value_scale(self, channels: Sequence[int]) -> float:
         """Bound on |preprocessed voxel|: den + (den - s*blur) with den, blur in [clip_min, clip_max]."""
@@ -377,9 +386,12 @@ class Preprocessor:
         self._stage_free.record()
         from . import blob_log as _bl
         d_qc = _bl._to_device_bytes(qc, dev)
-        d_info = None
+        # per-tile records: the statistics kernel hands them to the blur kernel (and `info()` reads them)
+        n_info = max(1, len(subs)) * nat.SUBINFO_DTYPE.itemsize
         if self.want_info:
-            d_info = torch.zeros(len(subs) * nat.SUBINFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            d_info = torch.zeros(n_info, dtype=torch.uint8, device=dev)
+        else:                       # (reused in stream order: every run of this object is queued on one stream)
+            d_info = self._buffer("_info", int(which) % N_BUFFER_SETS, n_info, torch.uint8, dev)
         weights = gauss_weights()
         if len(weights) != params.radius + 1:
             raise nat.MmxError("Gaussian half kernel has the wrong length")
@@ -392,10 +404,16 @@ class Preprocessor:
         item = nat.SUBBLOCK_DTYPE.itemsize
         info_ptr = d_info.data_ptr() if d_info is not None else None
         if n_fast:
-            nat.check(L.mmx_preprocess_batch(
+            # scratch of the pipelined form (a tile-major uint16 copy of the voxels + per-tile offsets): one buffer,
+            # reused in stream order like the per-tile records
+            wb = int(L.mmx_preprocess_work_bytes(subs.ctypes.data, n_fast)) if KERNEL_MODE != nat.MMX_PP_SINGLE else 0
+            work = self._buffer("_work", None, max(1, wb), torch.uint8, dev)
+            nat.check(L.mmx_preprocess_batch_mode(
                 ctypes.byref(vol), d_subs.data_ptr(), subs.ctypes.data, n_fast, d_qc.data_ptr(), len(qc),
                 ctypes.byref(params), d_w.data_ptr(), dst_sy, dst_sz,
-                out32.data_ptr(), out64.data_ptr(), info_ptr, stream), "mmx_preprocess_batch")
+                out32.data_ptr(), out64.data_ptr(), info_ptr, int(KERNEL_MODE), int(TILES_PER_WG),
+                work.data_ptr() if wb else None, wb, stream),
+                "mmx_preprocess_batch_mode")
         for first, count in ((n_fast, n_mid), (n_fast + n_mid, n_gen - n_mid)):
             if count:      # one call per kernel class: the entry point picks the kernel from the extents
                 nat.check(L.mmx_preprocess_batch_generic(
@@ -406,8 +424,8 @@ class Preprocessor:
                     scratch.data_ptr(), int(scratch.numel()), stream), "mmx_preprocess_batch_generic")
         self.last_subs = subs.copy() if self.want_info else None
         self._keep = (d_subs, d_qc, d_info)
-        if d_info is not None:
-            self.last_info = d_info        # device bytes; see info()
+        if self.want_info:
+            self.last_info = d_info[:len(subs) * nat.SUBINFO_DTYPE.itemsize]        # device bytes; see info()
         # block table over the preprocessed slots
         blocks = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
         slot = 1
@@ -467,9 +485,10 @@ class Unmixer:
 
     def bytes_per_voxel(self) -> int:
         n_src = 1 + len({k for k, _ in self.subtract})
+        pre = _SLOT_BYTES + 2                  # one Preprocessor per source channel (slots + its tile-major copy)
         if self.rescale is not None:
-            return 20 + n_src * (20 + (0 if self.dms is None else 20 * len(self.rescale[1])))
-        return 20 + (0 if self.dms is None else 20 * n_src)
+            return _SLOT_BYTES + n_src * (_SLOT_BYTES + (0 if self.dms is None else pre * len(self.rescale[1])))
+        return _SLOT_BYTES + (0 if self.dms is None else pre * n_src)
 
     def value_scale(self, channels: Sequence[int]) -> float:
         if self.dms is not None:
@@ -656,8 +675,8 @@ class Rescaler:
         return sigma, int(4.0 * sigma + 0.5)
 
     def bytes_per_voxel(self) -> int:
-        # resized copies (2 x float64 + float32, or 2 x uint16) + the preprocessed sources of all channels
-        return 20 + (0 if self.dms is None else 20 * len(self.channels))
+        # resized copies (float64 + float32, or uint16, per buffer set) + the preprocessed sources of all channels
+        return _SLOT_BYTES + (0 if self.dms is None else (_SLOT_BYTES + 2) * len(self.channels))
 
     def value_scale(self, channels: Sequence[int]) -> float:
         if self.dms is not None:

@@ -134,6 +134,102 @@ def test_generic_kernel_equals_fast_kernel(gpu, env, monkeypatch):
         np.testing.assert_array_equal(fast, slow)
 
 
+def _synthetic_block(shape, seed, dtype=np.uint16, flat=()):
+    """Background + blobs like the benchmark volume (tiles with and without erosion); ``flat`` = (z0, y0, x0, n)
+    cubes of one value (vmin == vmax tiles: the reference leaves those voxels alone)."""
+    rng = np.random.default_rng(seed)
+    top = np.iinfo(dtype).max
+    vol = rng.normal(500 * top / 65535, 50 * top / 65535, shape)
+    zz, yy, xx = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    for _ in range(max(3, int(np.prod(shape) * 2e-4))):
+        c = [rng.uniform(0, n) for n in shape]
+        vol = np.maximum(vol, 0.6 * top * np.exp(-((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) / 18.0))
+    vol = np.clip(vol, 0, top).astype(dtype)
+    for z0, y0, x0, n in flat:
+        vol[z0:z0 + n, y0:y0 + n, x0:x0 + n] = 777 % top
+    return vol
+
+
+@pytest.mark.parametrize("tpw", [1, 3, 8])
+@pytest.mark.parametrize("case", ["u16", "u8", "no_unsharp", "no_erosion", "always_eroded", "ragged"])
+def test_pipelined_kernels_equal_the_single_kernel_and_the_oracle(gpu, env, monkeypatch, case, tpw):
+    """The statistics + blur kernels over a tile-major copy (`mmx_preproc_pipe.hip`) against one kernel per tile and the
+    oracle, bit for bit: 25^3 tiles and the ragged ones a 58 x 61 x 83 block leaves, eroded / plain / identity tiles in
+    one run (deferred and immediate output stores), runs of 1 / 3 / 8 tiles per workgroup."""
+    from magellanmapper_amd import _native as nat, preprocess
+    from oracle import preprocess_oracle as ppo
+    shape, dms = ((58, 61, 83), (25, 25, 25)) if case != "ragged" else ((40, 57, 70), (18, 25, 31))
+    roi = _synthetic_block(shape, 11, np.uint8 if case == "u8" else np.uint16, flat=((0, 0, 0, 25), (25, 25, 50, 25)))
+    over = {"no_unsharp": {"unsharp_strength": 0}, "no_erosion": {"erosion_threshold": 0},
+            "always_eroded": {"erosion_threshold": 1e-6}}.get(case, {})
+    profs = _set_profiles(over)
+    want = ppo.preprocess_block(roi, dms, profs, [-1.0])
+    outs, infos = {}, {}
+    for name, mode in (("single", nat.MMX_PP_SINGLE), ("pipelined", nat.MMX_PP_PIPELINED), ("auto", nat.MMX_PP_AUTO)):
+        monkeypatch.setattr(preprocess, "KERNEL_MODE", mode)
+        monkeypatch.setattr(preprocess, "TILES_PER_WG", tpw)
+        outs[name], info = preprocess.preprocess_roi(roi, dms, return_info=True)
+        infos[name] = np.concatenate([i[1] for i in info])
+    np.testing.assert_array_equal(outs["single"], want)
+    np.testing.assert_array_equal(outs["pipelined"], want)
+    np.testing.assert_array_equal(outs["auto"], want)
+    a, b = infos["single"], infos["pipelined"]
+    np.testing.assert_array_equal(a["flags"], b["flags"])
+    np.testing.assert_array_equal(a["vmin"], b["vmin"])
+    np.testing.assert_array_equal(a["vmax"], b["vmax"])
+    np.testing.assert_allclose(a["mean"], b["mean"], rtol=0, atol=1e-12)
+    assert (a["flags"] & nat.MMX_PP_IDENTITY).any() or case in ("u8", "ragged")
+    if case == "always_eroded":
+        assert (a["flags"] & nat.MMX_PP_ERODED).all()
+    if case == "u16":
+        assert 0 < int((a["flags"] & nat.MMX_PP_ERODED != 0).sum()) < len(a)
+
+
+def test_pipelined_kernels_with_caller_and_pool_workspace(gpu, env):
+    """`mmx_preprocess_batch_mode` through the raw ABI: with the caller's workspace and records, with neither (both
+    come from the stream's memory pool), and with a workspace that is too small (MMX_ERR_WORKSPACE)."""
+    import ctypes
+    from magellanmapper_amd import _native as nat, blob_log as bl, preprocess
+    profs = _set_profiles({})
+    roi = _synthetic_block((50, 50, 50), 3)
+    want = preprocess.preprocess_roi(roi, (25, 25, 25))
+    L = nat.lib()
+    dev = torch.device("cuda", 0)
+    dvol = bl.DeviceVolume(roi)
+    pre = preprocess.Preprocessor((25, 25, 25), want_info=True)
+    pre.run(dvol, 0, [(0, 0, 0)], [roi.shape], 0)              # builds the tile table and the outputs once
+    subs = pre.last_subs
+    params, _, _ = preprocess.channel_params(0, None)
+    d_subs = bl._to_device_bytes(subs, dev)
+    qc = np.array(pre._qc_rows, dtype=nat.QCLASS_DTYPE)
+    d_qc = bl._to_device_bytes(qc, dev)
+    d_w = torch.from_numpy(preprocess.gauss_weights()).to(dev)
+    slot_pre, dst_sz, dst_sy, out64, out32 = pre.last_geometry
+    vol = dvol.view(0, False)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def call(work, work_bytes, info):
+        o64, o32 = torch.zeros_like(out64), torch.zeros_like(out32)
+        rc = L.mmx_preprocess_batch_mode(
+            ctypes.byref(vol), d_subs.data_ptr(), subs.ctypes.data, len(subs), d_qc.data_ptr(), len(qc),
+            ctypes.byref(params), d_w.data_ptr(), dst_sy, dst_sz, o32.data_ptr(), o64.data_ptr(), info,
+            nat.MMX_PP_PIPELINED, 0, work, work_bytes, stream)
+        torch.cuda.synchronize()
+        return rc, o64
+
+    need = int(L.mmx_preprocess_work_bytes(subs.ctypes.data, len(subs)))
+    assert need >= 2 * roi.size
+    work = torch.empty(need, dtype=torch.uint8, device=dev)
+    d_info = torch.zeros(len(subs) * nat.SUBINFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    for args in ((work.data_ptr(), need, d_info.data_ptr()), (None, 0, None)):
+        rc, o64 = call(*args)
+        assert rc == 0
+        got = torch.as_strided(o64[:slot_pre], roi.shape, (dst_sz, dst_sy, 1)).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    rc, _ = call(work.data_ptr(), need - 1024, d_info.data_ptr())
+    assert rc == 4          # MMX_ERR_WORKSPACE
+
+
 @pytest.mark.parametrize("force_generic", [False, True, "big"])
 def test_knife_edge_mean_uses_numpys_summation_order(gpu, env, monkeypatch, force_generic):
     """erosion_threshold set exactly AT the tile mean (and one ulp below): the device must

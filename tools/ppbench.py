@@ -17,6 +17,10 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--generic", action="store_true")
 ap.add_argument("--no-unsharp", action="store_true")
 ap.add_argument("--no-erosion", action="store_true")
+ap.add_argument("--mode", choices=("auto", "single", "pipelined"), default="auto")
+ap.add_argument("--tpw", type=int, default=0, help="tiles per workgroup of the pipelined blur kernel")
+ap.add_argument("--profile", action="store_true", help="phase ticks of a -DPP_PROFILE build (MMX_LIB_PATH)")
+ap.add_argument("--check", action="store_true", help="compare the float64 output with the single-kernel form")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 e = a.edge
@@ -34,6 +38,8 @@ if a.no_erosion:
     config.roi_profile["erosion_threshold"] = 0
 dms = a.dms * 3 if len(a.dms) == 1 else a.dms
 preprocess.FORCE_GENERIC = a.generic
+preprocess.KERNEL_MODE = dict(auto=nat.MMX_PP_AUTO, single=nat.MMX_PP_SINGLE, pipelined=nat.MMX_PP_PIPELINED)[a.mode]
+preprocess.TILES_PER_WG = a.tpw
 pre = preprocess.Preprocessor(dms, want_info=True)
 nvox = len(origins) * e ** 3
 times = []
@@ -48,6 +54,26 @@ for rep in range(a.reps + 1):
         t = nat.timing_read()
         times.append((t["preproc"][0], t0.elapsed_time(t1)))
 info = pre.info()
+if a.profile:
+    import ctypes
+    buf = (ctypes.c_ulonglong * 32)()
+    nat.lib().mmx_pp_profile_read(buf, 1)
+    t = np.array(buf[:], dtype=np.float64).reshape(2, 16) / 100.0 / len(info) / (a.reps + 1)       # us per tile
+    print("stats us/tile: load+hist %.2f select %.2f hist2 %.2f select2 %.2f tally+info %.2f" % tuple(t[0, :5]))
+    print("blur  us/tile: first load %.2f setup %.2f z %.2f y %.2f x %.2f unsharp(last part) %.2f erode+end %.2f reload %.2f | issue prefetch %.2f batches %.2f" % tuple(t[1, :10]))
+if a.check:
+    got = [t.copy() for t in pre.fetch(shapes)]
+    got_info = info.copy()
+    preprocess.KERNEL_MODE = nat.MMX_PP_SINGLE
+    ref = preprocess.Preprocessor(dms, want_info=True)
+    ref.run(dvol, 0, origins, shapes, 0)
+    want = ref.fetch(shapes)
+    bad = sum(int((g != w).sum()) for g, w in zip(got, want))
+    wi = ref.info()
+    print("check: %d differing voxels of %d; flags equal %s; vmin/vmax equal %s; max |mean diff| %.3g" % (
+        bad, sum(g.size for g in got), bool((wi["flags"] == got_info["flags"]).all()),
+        bool((wi["vmin"] == got_info["vmin"]).all() and (wi["vmax"] == got_info["vmax"]).all()),
+        float(np.abs(wi["mean"] - got_info["mean"]).max())))
 if os.environ.get("PP_PROFILE"):
     a1 = np.floor(info["vmin"]); a2 = (info["vmin"] - a1) * 1e6
     b1 = np.floor(info["vmax"]); b2 = (info["vmax"] - b1) * 1e6
