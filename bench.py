@@ -638,6 +638,10 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         # detector_stats.max_f32_error -- the largest |float32 - float64| over all re-scored candidates -- must stay
         # under, and the nomination band that covers it fourfold
         "q16_bound": None if zx_path != nat.MMX_ZX_TILED_Q16 else round(bl.LAST_Q16_BOUND, 9),
+        # (the same number under the name the contract uses: error bound of the 16-bit intermediates in VALUE units;
+        #  16-bit tiles are chosen only while it is <= log_abs_tol, MMX_LOG_ABS_TOL)
+        "q16_bound_abs": None if zx_path != nat.MMX_ZX_TILED_Q16 else round(bl.LAST_Q16_BOUND, 9),
+        "log_abs_tol": bl.LOG_ABS_TOL,
         "nms_band": round(bl.LAST_NMS_BAND if zx_path == nat.MMX_ZX_TILED_Q16 else bl.EPS_REL, 9),
         "cpu_baseline": cpu, "parity_sample_identical": parity,
         "parity_sample_source": None if baseline is None else (

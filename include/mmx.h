@@ -175,6 +175,12 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
                       float* d_log, float* d_work, uint64_t* d_nms_mask, float nms_lo, float nms_eps,
                       int* h_mask_written, int zx_mode, int* h_zx_path, void* stream);
 
+/* The LoG contract: nominated (float32 / 16-bit) cube values stay within this ABSOLUTE distance of the reference's
+ * float64 values.  Under MMX_ZX_AUTO 16-bit intermediates are chosen only when their error bound in value units
+ * (mmx_tiled_q16_error_bound x the stated value range) is below it AND the caller's NMS band covers it fourfold;
+ * MMX_ZX_TILED_Q16 by name takes them regardless (tests, experiments). */
+#define MMX_LOG_ABS_TOL 1e-4
+
 /* Largest deviation of an MMX_ZX_TILED_Q16 LoG value from the float32 paths' (which are within a few 1e-7 of the
  * exact value), for voxels in [0, 1] (uint8 / uint16 after img_as_float; float voxels in [0, m]: times m): a
  * function of the weights alone (5.1e-5 for any sigma >= 1).  A true maximum is nominated as long as the NMS band is four

@@ -66,6 +66,8 @@ EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2.5e-4))
 #: of the sigmas at hand (``mmx_tiled_q16_error_bound``); the kernels of radius 1..3 carry up to 7.5e-5, and their
 #: batches then keep float32 intermediates under ``MMX_ZX_AUTO`` (4 x 7.5e-5 exceeds the band).
 Q16_BOUND_ANY_SIGMA = 5.3e-5
+#: ``MMX_LOG_ABS_TOL`` of include/mmx.h: the LoG contract in value units (BASELINE.json: "LoG response within 1e-4")
+LOG_ABS_TOL = 1e-4
 if 0.0 < EPS_REL_Q16 < 4.0 * Q16_BOUND_ANY_SIGMA:
     # exactness rests on the band covering the error fourfold: an environment variable may widen it or switch the
     # 16-bit intermediates off (0), not narrow it below what the bound needs
@@ -284,6 +286,7 @@ class ScaleSpace:
     w0_tab: np.ndarray = field(default=None)
     w2_tab: np.ndarray = field(default=None)
     _dev: Optional[dict] = field(default=None, repr=False)
+    _q16: Optional[float] = field(default=None, repr=False)
 
     @classmethod
     def make(cls, min_sigma: float, max_sigma: float, num_sigma: int) -> "ScaleSpace":
@@ -307,6 +310,15 @@ class ScaleSpace:
         if key not in self._dev:
             self._dev[key] = (torch.from_numpy(self.w0_tab).to(dev), torch.from_numpy(self.w2_tab).to(dev))
         return self._dev[key]
+
+    def q16_bound(self) -> float:
+        """``mmx_tiled_q16_error_bound`` of the worst scale, relative to the value range (cached: the scale space is)."""
+        if self._q16 is None:
+            L = nat.lib()
+            b = [float(L.mmx_tiled_q16_error_bound(nat.as_double_ptr(self.w0[s]), nat.as_double_ptr(self.w2[s]),
+                                                   int(self.radii[s]), float(self.norms[s]))) for s in range(len(self.sigmas))]
+            self._q16 = float("inf") if (not b or min(b) < 0) else max(b)
+        return self._q16
 
     @classmethod
     def _make(cls, min_sigma: float, max_sigma: float, num_sigma: int) -> "ScaleSpace":
@@ -789,10 +801,15 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     # what is known about the voxels the passes will read: raw integer images [0, 1]; float images their measured
     # range; preprocessed / unmixed / rescaled blocks the bounds their arithmetic implies
     vrange = dvol.value_range(channel) if pre is None else pre.value_range([channel])
+    integer_voxels = pre is None and dvol.np_dtype in (np.dtype(np.uint8), np.dtype(np.uint16))
     # volumes whose voxels are known to be non-negative and of ordinary magnitude take 16-bit intermediates: the
     # band must cover their rounding error fourfold
+    # -- and their error in value units must stay inside the LoG contract (a profile whose unsharp / clip settings
+    # stretch the preprocessed range past ~1.9 keeps float32 intermediates and the narrow band)
     if (vrange is not None and vrange[0] >= 0.0 and vrange[1] <= FLOAT_TILED_RANGE[1] and EPS_REL_Q16 > EPS_REL
-            and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)):
+            and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)
+            and (ZX_MODE == nat.MMX_ZX_TILED_Q16 or space.q16_bound() * (vrange[1] if not integer_voxels else 1.0)
+                 <= LOG_ABS_TOL)):
         eps = EPS_REL_Q16 * vscale
     d_w0, d_w2 = space.device_tables(dvol.tensor.device)
     # the batches and their block tables on the device: remembered for the same block lists, volume layout and budget (a
@@ -1036,7 +1053,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
             bound *= 1.0 if not is_float else float(vol32.value_range)
             # (by name: taken whatever the band -- kernel experiments and the band-retry tests ask for it with narrow
             #  bands; the run-time check |float32 - float64| < eps / 4 on every re-scored candidate then widens the band)
-            if mode == nat.MMX_ZX_TILED_Q16 or (0 <= 4.0 * bound <= eps):
+            if mode == nat.MMX_ZX_TILED_Q16 or (0 <= 4.0 * bound <= eps and bound <= LOG_ABS_TOL):
                 tiled_mode = nat.MMX_ZX_TILED_Q16
                 LAST_Q16_BOUND, LAST_NMS_BAND = bound, eps
         if (mode in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED, nat.MMX_ZX_TILED_Q16) and not is_float) or \

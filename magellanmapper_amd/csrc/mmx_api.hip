@@ -289,7 +289,8 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         // and LDS-staged matrix-core kernels are correct and selectable, but no faster than the packed one:
         // DESIGN.md section 4b -- their 16 planes x 64 bytes accesses were the limit, which the tiled form removes.)
         mmx_zx6_plan plan;
-        // Q16 tiles when asked for, or under AUTO when the caller's NMS band covers their rounding error fourfold
+        // Q16 tiles when asked for, or under AUTO when the caller's NMS band covers their rounding error fourfold and
+        // that error, in value units, is inside the LoG contract (MMX_LOG_ABS_TOL)
         // (the condition under which every true maximum is still nominated)
         double q_bp = 0, q_bq = 0, q_err = 0;
         q16_bounds(h_w0, h_w2, radius, norm, &q_bp, &q_bq, &q_err);
@@ -300,7 +301,8 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
         const bool nonneg = integer || (ranged && vol->value_range > 0.f);
         if (!integer && nonneg) { q_bp *= vol->value_range; q_bq *= vol->value_range; q_err *= vol->value_range; }
         const bool q16 = nonneg && (zx_mode == MMX_ZX_TILED_Q16 ||
-                         (zx_mode == MMX_ZX_AUTO && d_nms_mask && h_mask_written && (double)nms_eps >= 4.0 * q_err));
+                         (zx_mode == MMX_ZX_AUTO && d_nms_mask && h_mask_written && (double)nms_eps >= 4.0 * q_err &&
+                          q_err <= MMX_LOG_ABS_TOL));
         bool tiled = (zx_mode == MMX_ZX_TILED || (zx_mode == MMX_ZX_TILED_Q16 && nonneg) ||
                       (zx_mode == MMX_ZX_AUTO && (integer || ranged))) &&
                      mmx_zx6_plan_make(h_blocks, n_blocks, slot_elems, vol->dtype, &plan) == MMX_OK;

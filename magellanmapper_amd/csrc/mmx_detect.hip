@@ -63,7 +63,8 @@ int after(hipStream_t a, hipStream_t b, const char* what)
 // reported (bit 0: none).  The rules are blob_log.py's (round 3), moved here unchanged:
 //   * the tiled path works from an operand-ordered copy of the voxels that does not depend on sigma: made once, trusted
 //     by the calls below for as long as every call so far ran the tiled path;
-//   * 16-bit intermediates when the nomination band covers their rounding error fourfold (or when asked for by name).
+//   * 16-bit intermediates when the nomination band covers their rounding error fourfold and the error in value units
+//     is inside the LoG contract (MMX_LOG_ABS_TOL) -- or when asked for by name.
 int passes(const mmx_detect_args* a, bool with_mask, int mode, float* d_log, uint64_t* d_mask, size_t mask_words,
            unsigned* layouts, int* zx_path, double* q16_bound, bool* pack_side)
 {
@@ -84,7 +85,7 @@ int passes(const mmx_detect_args* a, bool with_mask, int mode, float* d_log, uin
             if (b > bound) bound = b;
         }
         if (is_float) bound *= (double)vol->value_range;
-        const bool covers = bound >= 0.0 && 4.0 * bound <= (double)a->eps;
+        const bool covers = bound >= 0.0 && 4.0 * bound <= (double)a->eps && bound <= MMX_LOG_ABS_TOL;
         // (by name: taken whatever the band; the caller's run-time check of |float32 - float64| against eps / 4 on the
         //  re-scored candidates is what then widens it)
         if (mode == MMX_ZX_TILED_Q16 || covers) { tiled_mode = MMX_ZX_TILED_Q16; if (q16_bound) *q16_bound = bound; }

@@ -616,6 +616,37 @@ def test_q16_error_bound_holds_across_value_ranges(gpu, case, monkeypatch):
     assert worst < 7.6e-5              # the north star's LoG tolerance of 1e-4, relative to the value scale, with room
 
 
+@pytest.mark.parametrize("unsharp,clip_max,expect_q16", [(0.3, 1.0, True), (0.9, 1.0, False), (0.3, 1.6, False)])
+def test_sixteen_bit_tiles_only_inside_the_absolute_log_tolerance(gpu, unsharp, clip_max, expect_q16):
+    """AUTO picks 16-bit intermediates for preprocessed blocks only while their error bound IN VALUE UNITS
+    (``mmx_tiled_q16_error_bound`` x the preprocessed range ``2 clip_max - s clip_min``) stays inside the 1e-4 LoG contract
+    (``MMX_LOG_ABS_TOL``): the stock profile (range 1.94) does, a stronger unsharp mask or a wider clip falls back to
+    float32 tiles with the narrow band -- and the detection equals the oracle either way."""
+    from magellanmapper_amd import _native as nat, blob_log as bl, config, stack_detect, synth
+    from oracle import magmap_oracle as mmo
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(dict(num_sigma=3, denoise_size=25, segment_size=64, unsharp_strength=unsharp,
+                                   clip_max=clip_max))
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "abs_tol"
+    vol = synth.make_volume(21, (40, 56, 60), 30)
+    try:
+        img5d = stack_detect.Image5d(vol[None])
+        _, _, blobs = stack_detect.detect_blobs_blocks("abs_tol", img5d, None, None, None, False, False, True, False)
+        assert (bl.LAST_ZX_PATH == nat.MMX_ZX_TILED_Q16) == expect_q16, (bl.LAST_ZX_PATH, bl.LAST_Q16_BOUND)
+        if expect_q16:
+            assert 0 < bl.LAST_Q16_BOUND <= bl.LOG_ABS_TOL
+        else:
+            assert bl.LAST_ZX_PATH == nat.MMX_ZX_TILED          # float32 tiles of the same kernels
+        want, _ = mmo.detect_blobs_blocks(vol, None, [dict(config.roi_profile)], config.resolutions)
+        got = blobs.blobs
+        assert want is not None and got is not None and got.shape == want.shape
+        key = lambda t: t[np.lexsort(tuple(t[:, i] for i in range(t.shape[1] - 1, -1, -1)))]
+        np.testing.assert_array_equal(key(got), key(want))
+    finally:
+        config.setup_roi_profiles(None)
+
+
 def test_block_shape_and_dtype_sweep_matches_oracle(gpu):
     """Ragged extents (row lengths around the 8-float chunk, the 32-float pitch and the 64-lane wave),
     blocks thinner than the kernel radius (generic fallback per pass), every input dtype; several
