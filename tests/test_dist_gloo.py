@@ -273,6 +273,10 @@ def _dist_case(case):
         shape, n_blobs = (150, 100, 120), 12000         # four z-layers of blocks: one or two per rank
     elif case == "flat":
         shape, seg, n_blobs = (30, 200, 260), 50, 3000
+    elif case.startswith("c4_grid"):
+        # BASELINE.json configs[3]'s partition: a 4 x 8 x 8 grid of blocks over 8 ranks = 32 blocks = HALF a z-layer
+        # per rank, so rank seams run along y as well as z
+        shape, seg, n_blobs = (160, 320, 320), 40, 60000
     config.roi_profile.update(segment_size=seg, denoise_size=None)
     blocks = sd.setup_blocks(config.roi_profile, shape)
     rng = np.random.default_rng(31)
@@ -300,6 +304,9 @@ def _dist_case(case):
                 continue
             keep = np.all([np.abs(tbl[:, 0] - zs) > reach for zs in z_seams], axis=0)
             tables[k] = tbl[keep] if keep.any() else None
+    elif case == "c4_grid_one_rank_without_blobs":
+        for k in range(5 * 32, 6 * 32):                  # rank 5 of 8 finds nothing at all
+            tables[k] = None
     elif case == "all_empty":
         tables = [np.zeros((0, 11)) if k % 2 else None for k in range(len(tables))]
     elif case == "nothing":
@@ -312,7 +319,8 @@ def _dist_case(case):
                                         (3, "second_half_none"), (3, "one_rank_all_empty"), (2, "far_from_seam"),
                                         (4, "far_from_seam"), (2, "plain+regions"), (3, "holes+regions"),
                                         (2, "extra_columns_two_channels+regions"), (2, "flat+regions"),
-                                        (3, "second_half_none+regions"), (2, "far_from_seam+regions")])
+                                        (3, "second_half_none+regions"), (2, "far_from_seam+regions"),
+                                        (8, "c4_grid"), (8, "c4_grid_one_rank_without_blobs"), (8, "c4_grid+regions")])
 def test_distributed_pruning_equals_one_process(tmp_path, world, case):
     """Every rank holds the tables of its own blocks only, prunes its own rows (three passes on its rows plus the
     other ranks' rows within reach of its blocks) and merges everybody's survivors by key: the table -- rows, order,
@@ -329,6 +337,8 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
     Img.shape = shape
     want, df = sd.StackPruner.prune_blobs_mp(Img, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
                                              blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    if case.startswith("c4_grid"):
+        assert blocks.sub_roi_slices.shape == (4, 8, 8)             # 32 blocks a rank: half z-layers
     if case == "nothing":
         assert want is None
     elif case == "all_empty":
@@ -341,7 +351,7 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
     runs = [(tmp_path / f"regions{r}.txt").read_text().split() for r in range(world)]
     if regions:         # (some rank did prune several regions side by side, in both collectives)
         assert any(len(v) == 2 and int(v[0]) > 1 for v in runs), runs
-    else:
+    elif not case.startswith("c4_grid"):      # (tables of that size prune by regions on their own)
         assert not any(runs), runs
     for r in range(world):
         got = np.load(tmp_path / f"pruned{r}.npy")
