@@ -455,6 +455,13 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         tdist.all_gather(allr, mine)
         per_rank = [dict(zip(("kernel_ms", "detect_wall_ms", "gather_ms", "prune_ms", "blocks"),
                              (round(float(v), 2) for v in r.cpu()))) for r in allr]
+    host_run = None
+    if args.from_host and world == 1:
+        host_run = lambda rec: from_host_record(args.from_host, host_src, z0, shape, SlabVolume, detect_and_prune,
+                                                blocks, rec, min(steps, 5), args.tiles)
+        host_src = torch.empty(tuple(slab.shape), dtype=slab.dtype).pin_memory()
+        host_src.copy_(slab)
+        torch.cuda.synchronize()
     del dvol, slab
     bl.release_buffers()
     torch.cuda.empty_cache()
@@ -651,10 +658,85 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         "scipy": ctx.get("scipy"),
         "volume_gen_s": round(t_gen, 2),
     }
+    if host_run is not None:
+        out["from_host"] = host_run(out)
+        bl.release_buffers()
+        torch.cuda.empty_cache()
     if args.dump and name == args.config:
         np.savez(args.dump, final=np.zeros((0, 8)) if final is None else final,
                  colocs=np.zeros((0, n_chl), dtype=np.uint8) if colocs is None else colocs)
     return out
+
+
+def from_host_record(kind, slab, z0, shape, volume_cls, detect_and_prune, blocks, rec, n_steps, n_tiles=1):
+    """End to end from a HOST volume, what a drop-in caller pays per stack (the reference's callers hand a memory-mapped
+    image5d.npy, importer.py:794): every step uploads the volume again -- z-slab by z-slab on a copy stream, the
+    detection starting on the blocks whose slabs have landed (blob_log._SlabUpload) -- detects and prunes.
+    `kind`: pinned (a pinned tensor: the DMA reads it directly), pageable (an ordinary array: staged through pinned
+    buffers by a few host threads) or mmap (a memory-mapped .npy under /dev/shm)."""
+    import tempfile
+    import torch
+    path = None
+    pinned = slab                 # (a pinned host copy of the volume, made before the device one was released)
+    if kind == "pinned":
+        src = pinned
+    elif kind == "pageable":
+        src = np.array(pinned.numpy())
+        del pinned
+    else:
+        fd, path = tempfile.mkstemp(suffix=".npy", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        os.close(fd)
+        np.save(path, pinned.numpy())
+        del pinned
+        src = np.load(path, mmap_mode="r")
+    times, digest, n = [], None, 0
+    tiled = None
+    try:
+        if n_tiles > 1:
+            # consecutive tiles of a tiled stack (configs[4]): tile k + 1 is queued for upload before tile k is detected
+            # (stack_detect.detect_blobs_tiles does the same with Image5d files); every tile here is the same host volume
+            detect_and_prune(volume_cls(src, z0, shape), blocks)          # (staging buffers, retained blocks: warm)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hv, same = volume_cls(src, z0, shape), True
+            for k in range(n_tiles):
+                nxt = volume_cls(src, z0, shape) if k + 1 < n_tiles else None
+                final_k, _, _ = detect_and_prune(hv, blocks)
+                d_k = None if final_k is None else hashlib.sha1(np.ascontiguousarray(final_k).tobytes()).hexdigest()
+                same = same and d_k == rec.get("table_sha1")
+                hv = nxt
+            torch.cuda.synchronize()
+            ms_tile = (time.perf_counter() - t0) * 1e3 / n_tiles
+            h2d_t = (rec.get("h2d") or {}).get("ms_for_volume")
+            tiled = {"tiles": n_tiles, "ms_per_tile": round(ms_tile, 2), "every_tile_same_table_as_resident": same,
+                     "serial_ms_per_tile": None if h2d_t is None else round(h2d_t + rec["ms_per_step"], 2),
+                     "ratio_to_max_of_both": None if h2d_t is None else round(ms_tile / max(h2d_t, rec["ms_per_step"]), 3)}
+        for i in range(n_steps + 1):               # (the first step also pins the staging buffers: not counted)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hv = volume_cls(src, z0, shape)
+            final, _, _ = detect_and_prune(hv, blocks)
+            torch.cuda.synchronize()
+            if i:
+                times.append((time.perf_counter() - t0) * 1e3)
+            digest = None if final is None else hashlib.sha1(np.ascontiguousarray(final).tobytes()).hexdigest()
+            n = 0 if final is None else len(final)
+            del hv
+    finally:
+        del src
+        if path is not None:
+            os.unlink(path)
+    ms = float(np.median(times))
+    h2d = (rec.get("h2d") or {}).get("ms_for_volume")
+    floor = max(h2d or 0.0, rec["ms_per_step"])
+    return {"source": kind, "ms_per_step": round(ms, 2), "steps": len(times),
+            "resident_ms_per_step": rec["ms_per_step"], "h2d_ms_for_volume": h2d,
+            "ratio_to_max_of_both": round(ms / floor, 3) if floor else None,
+            "serial_ms": None if h2d is None else round(h2d + rec["ms_per_step"], 2),
+            "blobs": n, "table_sha1": digest, "same_table_as_resident": digest == rec.get("table_sha1"),
+            "tiled": tiled,
+            "note": "every step: upload of the host volume (z-slabs on a copy stream, one event per slab) + detection of "
+                    "the blocks whose slabs have landed + pruning; `serial_ms` = whole upload, then the resident step"}
 
 
 def compact(rec):
@@ -698,6 +780,11 @@ def main():
     ap.add_argument("--dump", default=None, metavar="NPZ", help="rank 0 writes the final table (and colocs) here")
     ap.add_argument("--segment-size", type=int, default=0, help="profile segment_size (default 256; parity tests use smaller blocks)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="pool size of the CPU baseline (default: all physical cores)")
+    ap.add_argument("--from-host", choices=("pinned", "pageable", "mmap"), default=None,
+                    help="after the timed region: steps that start from a HOST copy of the volume (upload overlapped "
+                         "with the detection), reported as `from_host`")
+    ap.add_argument("--tiles", type=int, default=1,
+                    help="with --from-host: also run this many consecutive tiles, each uploading beside its predecessor's detection")
     ap.add_argument("--parity-sample", default=None, metavar="NPZ",
                     help="check the parity sample against this committed oracle table (tests/golden/make_bench_samples.py) "
                          "instead of running the oracle: no cpu_baseline timing, seconds instead of minutes")

@@ -11,4 +11,13 @@ Modules mirror the reference's names for this one path:
 
 The compute path is ``libmmx_hip.so`` (C ABI in ``include/mmx.h``); there is no CPU fallback.
 """
+import os as _os
+
 __version__ = "0.1.0"
+
+# The batched detection keeps up to seven HIP streams busy (LoG passes, preprocessing, voxel copy, NMS / re-score tail,
+# host-side pruning helpers, and the z-slab upload of a host volume or of the NEXT tile).  ROCm maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin: with the default the upload stream shares a queue with a
+# kernel stream, and the kernels queue behind 150 ms of copies (measured: 302 vs 254 ms per tile of a streamed stack).
+# Read when the HIP runtime starts, so it is set here, before anything touches the GPU; a caller's own value wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

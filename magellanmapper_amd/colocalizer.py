@@ -137,6 +137,7 @@ def colocalize_blobs(roi, blobs: Optional[np.ndarray], thresh=None) -> Optional[
         return None
     percentile = None if thresh is None or (isinstance(thresh, str) and thresh == "min") else float(thresh)
     dvol = roi if isinstance(roi, bl.DeviceVolume) else bl.DeviceVolume(roi)
+    dvol.wait_all()                 # (a volume still on its way up: the whole ROI is read here)
     shape3 = tuple(dvol.shape[:3])
     blocks, _ = bl._make_blocks(dvol, 0, [(0, 0, 0)], [shape3])
     d_blocks = bl._to_device_bytes(blocks, dvol.tensor.device)

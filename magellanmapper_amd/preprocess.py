@@ -51,6 +51,13 @@ KERNEL_MODE = nat.MMX_PP_AUTO
 TILES_PER_WG = 0
 
 
+def _wait_upload(dvol, origins, shapes) -> None:
+    """A volume still on its way to the device (``DeviceVolume.stream_wait``): the current stream waits for the slabs
+    these blocks touch."""
+    if getattr(dvol, "_upload", None) is not None:
+        dvol.stream_wait(max((int(o[0]) + int(s_[0]) for o, s_ in zip(origins, shapes)), default=0))
+
+
 def gauss_weights() -> np.ndarray:
     if GAUSS_WEIGHTS_OVERRIDE is not None:
         return np.ascontiguousarray(GAUSS_WEIGHTS_OVERRIDE, dtype=np.float64)
@@ -293,6 +300,7 @@ class Preprocessor:
         stream.  Returns ``(blocks, slot_elems, vol32, vol64)``: the ``mmx_block`` table whose
         ``src_off`` point into the preprocessed slots, the LoG workspace slot size and the two
         ``mmx_volume`` views (float32 for the passes, float64 for the exact re-score)."""
+        _wait_upload(dvol, origins, shapes)
         L = nat.lib()
         dev = dvol.tensor.device
         # float64 images: the reference's arithmetic is the same float64 arithmetic once np.percentile has found its
@@ -505,6 +513,7 @@ class Unmixer:
     _buffer = Preprocessor._buffer
 
     def run(self, dvol, channel: int, origins, shapes, which: int = 0):
+        _wait_upload(dvol, origins, shapes)
         from . import blob_log as bl
         L = nat.lib()
         dev = dvol.tensor.device
@@ -692,6 +701,7 @@ class Rescaler:
     _buffer = Preprocessor._buffer
 
     def run(self, dvol, channel: int, origins, shapes, which: int = 0):
+        _wait_upload(dvol, origins, shapes)
         from . import blob_log as bl
         L = nat.lib()
         dev = dvol.tensor.device

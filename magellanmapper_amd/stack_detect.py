@@ -51,6 +51,17 @@ class Image5d:
         self.meta = None
         self.rgb = False
         self.is_roi = False
+        #: the first time point already on its way to the device (`prefetch`): what a whole-image detection then reads
+        self.device_volume = None
+
+    def prefetch(self):
+        """Start the upload of the first time point now (``blob_log.DeviceVolume``: z-slabs on a copy stream); a later
+        whole-image ``detect_blobs_blocks`` / ``detect_blobs_stack`` of this image detects on it while the rest is still
+        in flight.  What `detect_blobs_tiles` calls for tile k + 1 before it detects tile k."""
+        from . import blob_log as bl
+        if self.device_volume is None and self.img is not None:
+            self.device_volume = bl.DeviceVolume(self.img[0])
+        return self
 
 
 class _TableArena:
@@ -800,15 +811,20 @@ class _StackRun:
         with two channels and more (:374-397)."""
         vol = self.volume
         self.path_base = self.base
+        whole = full_roi
         if offset is None or size is None:
             offset, size = (0, 0, 0), vol.shape[1:4]
         else:
             self.path_base = _subimage_name(self.base, offset, size)
         self.offset, self.size = offset, size
-        self.roi = vol[0] if full_roi else _prepare_subimg(vol, offset, size)
-        self.n_roi_channels = self.roi.shape[3] if self.roi.ndim > 3 else 1
+        pre = getattr(self.img5d, "device_volume", None)
+        if pre is not None and whole and tuple(pre.shape[:3]) == tuple(vol.shape[1:4]):
+            self.roi = pre                      # (already uploading: Image5d.prefetch)
+        else:
+            self.roi = vol[0] if full_roi else _prepare_subimg(vol, offset, size)
+        self.n_roi_channels = self.roi.shape[3] if len(self.roi.shape) > 3 else 1
         self.coloc = bool(coloc) and self.n_roi_channels > 1
-        self.channels = (detector._channels_of(self.roi.ndim, self.n_roi_channels, None)[1]
+        self.channels = (detector._channels_of(len(self.roi.shape), self.n_roi_channels, None)[1]
                          if channels is None else channels)
         return self
 
@@ -884,7 +900,8 @@ class _StackRun:
                     flags = final[:, 10:10 + self.n_roi_channels].astype(np.uint8)
                 final = blobs.remove_abs_blob_coords(True)
         if config.save_subimg and root:
-            _save_subimage(_combine_paths(self.path_base, config.SUFFIX_SUBIMG), self.volume, self.roi)
+            roi = self.roi if isinstance(self.roi, np.ndarray) else self.volume[0]     # (a prefetched device volume)
+            _save_subimage(_combine_paths(self.path_base, config.SUFFIX_SUBIMG), self.volume, roi)
         blobs.blobs, blobs.colocalizations = final, flags
         blobs.resolutions = config.resolutions
         blobs.basename = os.path.basename(config.filename) if config.filename else None
@@ -929,6 +946,30 @@ def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, chann
     run = _StackRun(filename_base, img5d, save_dfs)
     blobs = run.resolve_roi(offset, size, channels, full_roi, coloc).detect().prune().finish()
     return None, None, blobs
+
+
+def detect_blobs_tiles(filename_bases, tiles, channels=None, coloc: bool = False, save_dfs: bool = False):
+    """Whole-image detection of consecutive tiles of a tiled stack (BASELINE.json configs[4]: a light-sheet stack as
+    tiles), one ``detect_blobs_blocks`` each: the upload of tile k + 1 is queued before tile k is detected and runs
+    beside it, the device buffers of the batched passes and of the per-block preprocessing are reused from tile to
+    tile.  ``tiles``: an iterable of ``Image5d`` (host images: memory-mapped ``image5d.npy`` files, arrays, pinned
+    tensors); yields ``(index, Blobs)`` in order.  Each tile is an image of its own, exactly as the reference treats a
+    file (stack_detect.py:338-517); placing the tables in a common frame is the caller's (the importer's) business."""
+    it = iter(tiles)
+    names = iter(filename_bases) if not isinstance(filename_bases, str) else None
+    cur = next(it, None)
+    if cur is not None:
+        cur.prefetch()
+    k = 0
+    while cur is not None:
+        nxt = next(it, None)
+        if nxt is not None:
+            nxt.prefetch()                          # (its copies are queued on its own stream before tile k's kernels)
+        base = f"{filename_bases}_{k}" if names is None else next(names)
+        _, _, blobs = detect_blobs_blocks(base, cur, None, None, channels, False, save_dfs, True, coloc)
+        cur.device_volume = None                    # (the tile's voxels leave the device with it)
+        yield k, blobs
+        cur, k = nxt, k + 1
 
 
 def _save_pruning_ratios(df):

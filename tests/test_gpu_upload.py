@@ -1,0 +1,136 @@
+"""Host-resident volumes: the z-slab upload that runs beside the detection (``blob_log._SlabUpload``; the reference's
+callers hand a memory-mapped ``image5d.npy``, magmap/io/importer.py:794, magmap/cv/stack_detect.py:386-390)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: torch.cuda.is_available() is False")
+    return torch.device("cuda", 0)
+
+
+def _stack(vol, denoise):
+    from magellanmapper_amd import config, stack_detect
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(dict(num_sigma=3, denoise_size=denoise, segment_size=40))
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "upload"
+    img5d = stack_detect.Image5d(vol[None])
+    _, _, blobs = stack_detect.detect_blobs_blocks("upload", img5d, None, None, None, False, False, True, False)
+    return blobs.blobs
+
+
+@pytest.mark.parametrize("denoise", [None, 25])
+@pytest.mark.parametrize("source", ["pageable", "memmap", "readonly"])
+def test_streamed_upload_gives_the_resident_volumes_table(gpu, monkeypatch, tmp_path, source, denoise):
+    """The same stack detected from a volume that is uploaded in one synchronous copy and from one that goes up in
+    slabs of 9 planes while its first blocks are already being detected (raw and per-block preprocessing): identical
+    tables, and the slab path was really taken."""
+    from magellanmapper_amd import blob_log as bl, config, synth
+    vol = synth.make_volume(17, (100, 72, 80), 60)
+    try:
+        monkeypatch.setattr(bl, "STREAM_UPLOAD", False)
+        want = _stack(vol, denoise)
+        monkeypatch.setattr(bl, "STREAM_UPLOAD", True)
+        monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
+        monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 9 * vol[0].nbytes)
+        made = []
+        init = bl._SlabUpload.__init__
+        monkeypatch.setattr(bl._SlabUpload, "__init__", lambda self, *a: (init(self, *a), made.append(self))[0])
+        if source == "memmap":
+            np.save(tmp_path / "v.npy", vol)
+            src = np.load(tmp_path / "v.npy", mmap_mode="r")
+        elif source == "readonly":
+            src = vol.copy()
+            src.flags.writeable = False
+        else:
+            src = vol
+        got = _stack(src, denoise)
+        assert made and made[0].n_slabs == 12 and made[0].all_queued()
+        assert want is not None and got is not None
+        np.testing.assert_array_equal(got, want)
+    finally:
+        config.setup_roi_profiles(None)
+
+
+def test_pinned_source_is_copied_without_staging_and_partial_waits_work(gpu, monkeypatch):
+    """A pinned tensor: every slab copy is queued at construction (no thread); `stream_wait(z)` orders a stream after the
+    slabs below z only, `wait_all` after everything; the device copy equals the source."""
+    from magellanmapper_amd import blob_log as bl, synth
+    vol = synth.make_volume(3, (64, 48, 56), 10)
+    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 8 * vol[0].nbytes)
+    src = torch.from_numpy(vol.view(np.int16)).pin_memory() if not hasattr(torch, "uint16") else \
+        torch.from_numpy(vol).pin_memory()
+    dv = bl.DeviceVolume(src)
+    up = dv._upload
+    assert up is not None and not hasattr(up, "thread") and up.n_slabs == 8 and up.all_queued()
+    assert up.event_for(1) is up.events[0] and up.event_for(8) is up.events[0] and up.event_for(9) is up.events[1]
+    assert up.event_for(64) is up.events[-1]
+    side = torch.cuda.Stream()
+    dv.stream_wait(20, [side])
+    with torch.cuda.stream(side):
+        head = dv.tensor[:20].clone()
+    dv.wait_all()
+    assert dv._upload is None
+    side.synchronize()
+    np.testing.assert_array_equal(head.cpu().numpy().view(vol.dtype), vol[:20])
+    np.testing.assert_array_equal(dv.tensor.cpu().numpy().view(vol.dtype), vol)
+
+
+def test_a_failing_source_is_reported_by_the_waiter(gpu, monkeypatch):
+    """An exception in the staging thread surfaces where the detection waits for the slab (not as a hang)."""
+    from magellanmapper_amd import _native as nat, blob_log as bl
+
+    class Bad(np.ndarray):
+        def __getitem__(self, item):
+            raise OSError("disk gone")
+    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
+    src = np.zeros((8, 16, 16), dtype=np.uint16).view(Bad)
+    dv = bl.DeviceVolume.__new__(bl.DeviceVolume)
+    dv._upload = bl._SlabUpload(src, torch.device("cuda", 0))
+    dv.shape = (8, 16, 16)
+    with pytest.raises(nat.MmxError, match="upload of the image failed"):
+        dv.stream_wait(8)
+
+
+@pytest.mark.parametrize("denoise", [None, 25])
+def test_three_tiles_streamed_equal_the_oracle_per_tile(gpu, monkeypatch, tmp_path, denoise):
+    """`stack_detect.detect_blobs_tiles`: three tiles of a stack as memory-mapped image5d files, tile k + 1 uploading
+    (in slabs) while tile k is detected, device buffers reused -- every tile's table equals the oracle's for that tile."""
+    from magellanmapper_amd import blob_log as bl, config, stack_detect, synth
+    from oracle import magmap_oracle as mmo
+    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 16 * 64 * 72 * 2)
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(dict(num_sigma=3, denoise_size=denoise, segment_size=40))
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "tiles"
+    vols, tiles = [], []
+    for k in range(3):
+        v = synth.make_volume(40 + k, (70, 64, 72), 40)
+        np.save(tmp_path / f"t{k}.npy", v[None])
+        vols.append(v)
+        tiles.append(stack_detect.Image5d(np.load(tmp_path / f"t{k}.npy", mmap_mode="r")))
+    uploads = []
+    init = bl._SlabUpload.__init__
+    monkeypatch.setattr(bl._SlabUpload, "__init__", lambda self, *a: (init(self, *a), uploads.append(self))[0])
+    key = lambda t: t[np.lexsort(tuple(t[:, i] for i in range(t.shape[1] - 1, -1, -1)))]
+    try:
+        seen = []
+        for k, blobs in stack_detect.detect_blobs_tiles("tiles", tiles):
+            if k < 2:
+                assert len(uploads) == k + 2          # tile k + 1 was queued before tile k's table came back
+            want, _ = mmo.detect_blobs_blocks(vols[k], None, [dict(config.roi_profile)], config.resolutions)
+            assert want is not None and blobs.blobs is not None and blobs.blobs.shape == want.shape
+            np.testing.assert_array_equal(key(blobs.blobs), key(want))
+            seen.append(k)
+        assert seen == [0, 1, 2] and len(uploads) == 3 and all(t.device_volume is None for t in tiles)
+    finally:
+        config.setup_roi_profiles(None)
