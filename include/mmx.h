@@ -105,9 +105,6 @@ typedef struct {
 
 /* ---- library / device ---------------------------------------------------- */
 int mmx_abi_version(void);
-/* 1 when the library was built with `make EXPERIMENTS=1`: zx_mode 3 / 4 / 5 then run their kernels (the measured
- * matrix-core experiments kept for cross-checks); a stock build runs MMX_ZX_PACKED for them. */
-int mmx_has_experiments(void);
 const char* mmx_strerror(int status);
 const char* mmx_last_hip_error(void);
 /* number of visible devices whose arch is gfx950; <0 on HIP error */
@@ -153,11 +150,8 @@ typedef enum {
     MMX_ZX_AUTO = -1,
     MMX_ZX_SEPARATE = 0,  /* three separate passes (register-ring column kernels + LDS row kernel)          */
     MMX_ZX_PACKED = 2,    /* zx2_kernel: fused Z+X, wave-specialised, packed float32 VALU math              */
-    /* 3, 4, 5: only in a library built with `make EXPERIMENTS=1` (mmx_has_experiments()); otherwise MMX_ZX_PACKED runs */
-    MMX_ZX_MFMA_F32 = 3,  /* zx3_kernel: Z on the VALU, X on v_mfma_f32_16x16x4_f32 (measured experiment)   */
-    MMX_ZX_MFMA_F16 = 4,  /* zx4_kernel: X+Z on v_mfma_f32_16x16x32_f16 with split-float16 operands,
-                             register resident (integer voxels; measured experiment)                       */
-    MMX_ZX_MFMA_F16_LDS = 5,/* zx5_kernel: the same arithmetic, voxels and results staged through LDS      */
+    /* 1, 3, 4, 5: retired (the matrix-core experiments that led to the tiled form; measurements in
+       profiles/HISTORY.md): MMX_ERR_ARG */
     MMX_ZX_TILED = 6,     /* zx4's arithmetic on an operand-ordered copy of the voxels (zx6_pack_kernel), P / Q
                              handed to the Y pass (y6_kernel) as 16 x 16 tiles: every access one contiguous KiB */
     MMX_ZX_TILED_Q16 = 7  /* the same with the tiles as 16-bit fixed point (half the intermediate bytes): the LoG

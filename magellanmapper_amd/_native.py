@@ -99,7 +99,7 @@ _lib = None
 
 #: every symbol ``include/mmx.h`` declares
 SYMBOLS = (
-    "mmx_abi_version", "mmx_has_experiments", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
+    "mmx_abi_version", "mmx_strerror", "mmx_last_hip_error", "mmx_device_count",
     "mmx_detect_batch", "mmx_detect_batch_capture", "mmx_graph_launch", "mmx_graph_destroy", "mmx_detect_last_error",
     "mmx_event_synchronize", "mmx_stream_wait_event", "mmx_timing_is_enabled",
     "mmx_log_batch_f32", "mmx_log_batch_f32_generic", "mmx_zx_pack", "mmx_tiled_q16_error_bound", "mmx_workspace_bytes", "mmx_peaks_batch", "mmx_rescore_f64",
@@ -136,7 +136,6 @@ def lib() -> ctypes.CDLL:
     L = ctypes.CDLL(LIB_PATH)
     vp = c_void_p
     L.mmx_abi_version.restype = c_int
-    L.mmx_has_experiments.restype = c_int
     L.mmx_strerror.restype = c_char_p
     L.mmx_strerror.argtypes = [c_int]
     L.mmx_last_hip_error.restype = c_char_p

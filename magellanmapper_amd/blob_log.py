@@ -74,12 +74,12 @@ if 0.0 < EPS_REL_Q16 < 4.0 * Q16_BOUND_ANY_SIGMA:
     raise ValueError(f"MMX_EPS_REL_Q16={EPS_REL_Q16:g} is narrower than 4 x the 16-bit intermediates' error bound "
                      f"({4.0 * Q16_BOUND_ANY_SIGMA:g}); use 0 to keep float32 intermediates")
 #: raw volumes on the native host path: one ``mmx_detect_batch`` call enqueues a whole batch (voxel copy, the passes of
-#: every scale, NMS, probes, exact re-score, copies) instead of a dozen calls from here (``MMX_NATIVE_BATCH=0``: the
-#: call-by-call form, kept for cross-checks)
-NATIVE_BATCH = os.environ.get("MMX_NATIVE_BATCH", "1") != "0"
+#: every scale, NMS, probes, exact re-score, copies) instead of a dozen calls from here (``False``: the call-by-call
+#: form, which tests keep as a cross-check)
+NATIVE_BATCH = True
 #: batches of at most this many blocks that come back with the very same arguments (a small volume detected step
-#: after step) are captured as a hipGraph and replayed with one launch (``MMX_GRAPH_BLOCKS=0``: never)
-GRAPH_BLOCKS = int(os.environ.get("MMX_GRAPH_BLOCKS", "8"))
+#: after step) are captured as a hipGraph and replayed with one launch (0: never)
+GRAPH_BLOCKS = 8
 #: with the per-kernel timing on: (before, after) event pairs around the LoG stream's wait for a batch's preprocessing
 PRE_WAITS: list = []
 #: batches replayed from a captured graph so far (bench.py reports the count of its timed region)
@@ -93,9 +93,9 @@ OVERLAP_BAND = 1e-9
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
 #: default for kernel experiments; tests set it to cross-check the kernels against each other)
 ZX_MODE = int(os.environ.get("MMX_FUSE", nat.MMX_ZX_AUTO))
-#: flags or-ed into the mode of the tiled calls: ``MMX_Y_VALU=1`` runs the Y pass of the 16-bit tiles on the VALU
+#: flags or-ed into the mode of the tiled calls: ``nat.MMX_ZX_Y_VALU`` runs the Y pass of the 16-bit tiles on the VALU
 #: (``y6_kernel``) instead of the matrix cores (``ym_kernel``) -- cross-checks and A/B timing
-ZX_FLAGS = nat.MMX_ZX_Y_VALU if os.environ.get("MMX_Y_VALU", "0") == "1" else 0
+ZX_FLAGS = 0
 #: the ``mmx_zx_mode`` the most recent ``mmx_log_batch_f32`` call of this process actually ran
 LAST_ZX_PATH = None
 #: who takes the per-batch decisions on the re-scored candidates: "native" (``mmx_host_resolve_peaks`` /
@@ -106,22 +106,22 @@ HOST_PATH = os.environ.get("MMX_HOST_PATH", "native")
 #: pieces overflow at 65504 (faint images are no problem: the nomination band never shrinks below EPS_REL x 1)
 FLOAT_TILED_RANGE = (0.0, 2.0 ** 12)
 #: per-block preprocessing on a stream of its own (beside the previous batch's LoG kernels)
-PRE_STREAM = os.environ.get("MMX_PRE_STREAM", "1") != "0"
-#: ... with the NMS / re-score tail of a preprocessed batch on the second stream too (``MMX_PRE_SIDE_TAIL=1``).  Off:
+PRE_STREAM = True
+#: ... with the NMS / re-score tail of a preprocessed batch on the second stream too.  Off:
 #: measured on the box it LOSES -- 283.6 against 278.9 ms (two-channel tile), 214.6 against 212.4 ms (--denoise 25): the
 #: preprocessing kernel already fills every CU it can, a third stream only adds to the time-sharing
-PRE_SIDE_TAIL = os.environ.get("MMX_PRE_SIDE_TAIL", "0") == "1"
+PRE_SIDE_TAIL = False
 #: ... and this many batches ahead of the one the host is finishing (``preprocess.N_BUFFER_SETS`` - 1 buffer sets allow
 #: it): the first batch is then the only one whose LoG passes wait for their preprocessing
-PRE_AHEAD = max(1, min(2, int(os.environ.get("MMX_PRE_AHEAD", "2"))))
+PRE_AHEAD = 2
 #: raw volumes: everything after a batch's last LoG kernel -- NMS, probe expansion, exact re-score, the copies of the
 #: results to the host -- on a stream of its own, beside the LoG kernels of the next batch, which then work in a second
 #: workspace (``_Buffers.workspace(n, 1)``: +16 GiB with the default budget).  Measured on the benchmark volume,
 #: alternating runs on one box: 115.2 / 113.5 ms per volume without, 110.2 / 109.4 with (the NMS takes 8.3 instead of
 #: 4.5 ms and the Z+X kernel 59 instead of 53 when they run beside each other; the re-score alone on the side stream,
 #: one workspace: -2.8 ms)
-RESCORE_STREAM = os.environ.get("MMX_RESCORE_STREAM", "1") != "0"
-PACK_STREAM = os.environ.get("MMX_PACK_STREAM", "0") == "1"
+RESCORE_STREAM = True
+PACK_STREAM = False
 #: candidate-table entries copied to pinned host memory together with the counts, before the host knows how many
 #: there are (a batch of the benchmark volume holds ~3e4; more entries cost a second, synchronous copy)
 _PREFIX_ENTRIES = 1 << 16
@@ -500,7 +500,11 @@ class BatchStats:
 
 
 #: debugging aid: cap on the blocks of one batch (``MMX_MAX_BATCH``; bisecting a batch-size dependent failure)
-_MAX_BATCH = int(os.environ.get("MMX_MAX_BATCH", 1 << 30))
+_MAX_BATCH = 1 << 30
+#: the tail of the block list is re-split into batches that shrink by this factor (nothing hides the host work of the
+#: last batches), the first batch into a ramp that starts at this many blocks (nothing hides its GPU time from the host)
+TAPER = 4
+RAMP = 16
 
 
 def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
@@ -534,7 +538,7 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     # gives the GPU about as much work as the host has left from the batch before.  Measured (tools/steptrace.py):
     # 89 / 89 / 59 / 19 blocks left the host 8 ms behind the GPU at the end and 18 ms of tail, 89 / 89 / 39 / 20 /
     # 10 / 5 / 4 did not; with 22-block batches a tail of 22 / 7 / 7 against 18 / 18 / 11 / 7 / 4.
-    taper = int(os.environ.get("MMX_TAPER", 4))
+    taper = TAPER
     vox = [int(s_[0]) * int(s_[1]) * int(s_[2]) for s_ in shapes]
 
     def fits(batch):
@@ -579,7 +583,7 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     # candidates arrive: with the tiled kernels the host work per block (~0.5 ms) is as long as the kernels'
     # (~0.55 ms), so a first batch of 89 blocks put the host 50 ms behind for the whole step (tail after the last
     # kernel 24 - 38 ms).  The first batch is therefore split into a ramp of `MMX_RAMP`, 2 x, 4 x ... blocks.
-    ramp = int(os.environ.get("MMX_RAMP", 16))
+    ramp = RAMP
     first = batches[0]
     if ramp > 0 and len(batches) > 1 and len(first) > 2 * ramp and sum(vox[i] for i in first) > (64 << 20):
         head = []
@@ -643,7 +647,7 @@ class _Buffers:
         # per-block preprocessing (float64 vector arithmetic) of batch k + 1 runs here, beside the LoG kernels of
         # batch k (bound by memory requests) on the caller's stream
         self.pre_stream = torch.cuda.Stream(device=dev)
-        self.rescore_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MMX_SIDE_PRIORITY", "0")))
+        self.rescore_stream = torch.cuda.Stream(device=dev, priority=0)
         self.pack_stream = torch.cuda.Stream(device=dev)
         self.native_events = []            # per candidate-table slot: (workspace read, batch done)
         self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
@@ -684,7 +688,7 @@ class _Buffers:
 
     def drop_graphs(self) -> None:
         for hit in self.graphs.values():
-            if hit:
+            if hit and hit != "plain":
                 nat.lib().mmx_graph_destroy(hit[0])
         self.graphs = {}
 
@@ -959,7 +963,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         #  are compared by content -- `lists_key` above -- so that a caller who builds them afresh finds the same device
         #  tables, which is also what lets a small batch's captured graph be found again)
         plan_key = (lists_key, tuple(t_.stride()), tuple(t_.shape), str(t_.dtype), len(space.sigmas),
-                    int(budget_bytes), _MAX_BATCH, os.environ.get("MMX_RAMP"))
+                    int(budget_bytes), _MAX_BATCH, RAMP, TAPER)
         planned = bufs.plans.get(plan_key)
     if planned is not None:
         batches = planned[0]
@@ -1323,12 +1327,16 @@ def _launch_batch_graph(L, a, info, bufs: _Buffers, blocks, space, vol32, vol_ex
             bufs.drop_graphs()
         bufs.graphs[key] = ()
         return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))
+    if hit == "plain":                              # a capture of this batch failed once: launched call by call
+        return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))
     if not hit:
         # second sighting: capture (this only records the launches; the replay below runs them)
         graph = ctypes.c_void_p()
         rc = L.mmx_detect_batch_capture(ctypes.byref(a), ctypes.byref(info), ctypes.byref(graph))
         if rc != 0:
-            return rc
+            # not capturable (the library says why in mmx_detect_last_error): never tried again for this key
+            bufs.graphs[key] = "plain"
+            return L.mmx_detect_batch(ctypes.byref(a), ctypes.byref(info))
         hit = bufs.graphs[key] = (graph.value, nat.DetectInfo.from_buffer_copy(info), (blocks, space))
     graph, saved, _ = hit
     global GRAPH_REPLAYS

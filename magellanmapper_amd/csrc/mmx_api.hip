@@ -109,15 +109,6 @@ int mmx_timing_read(double* ms, int64_t* launches, int n)
 }
 
 int mmx_abi_version(void) { return MMX_ABI_VERSION; }
-int mmx_has_experiments(void)
-{
-#ifdef MMX_EXPERIMENTS
-    return 1;
-#else
-    return 0;
-#endif
-}
-
 size_t mmx_workspace_bytes(int n_blocks, int64_t slot_elems, int n_sigma, int with_masks)
 {
     if (n_blocks < 1 || slot_elems < 1 || n_sigma < 1) return 0;
@@ -206,7 +197,8 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     if (y_valu) zx_mode &= ~MMX_ZX_Y_VALU;
     const bool prepacked = zx_mode == (MMX_ZX_TILED | MMX_ZX_PREPACKED) || zx_mode == (MMX_ZX_TILED_Q16 | MMX_ZX_PREPACKED);
     if (prepacked) zx_mode &= ~MMX_ZX_PREPACKED;
-    if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_TILED_Q16 || zx_mode == 1) return MMX_ERR_ARG;
+    if (zx_mode < MMX_ZX_AUTO || zx_mode > MMX_ZX_TILED_Q16 || zx_mode == 1 || (zx_mode >= 3 && zx_mode <= 5))
+        return MMX_ERR_ARG;             // (3, 4, 5: retired experiment kernels)
     if (!vol || !vol->d_data || !d_blocks || !h_blocks || !h_w0 || !h_w2 || !d_log || !d_work)
         return MMX_ERR_ARG;
     if (n_blocks < 1 || radius < 0 || slot_elems < 1) return MMX_ERR_ARG;
@@ -259,12 +251,9 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
     }
     const bool fast_r = radius >= 1 && radius <= MMX_MAX_RADIUS_FAST;
     const bool lane_ok = max_lane_in * 8 < (int64_t(1) << 31);
-    // MMX_DEBUG_GENERIC=zyx (any subset) sends those passes through the generic kernels (bisecting only)
-    static const char* dbg = getenv("MMX_DEBUG_GENERIC");
-    const bool gz = dbg && strchr(dbg, 'z'), gy = dbg && strchr(dbg, 'y'), gx = dbg && strchr(dbg, 'x');
-    const bool fast_z = !gz && fast_r && lane_ok && min_nz >= radius + kColPrefetch && vol->stride_y < (1 << 30);
-    const bool fast_y = !gy && fast_r && min_ny >= radius + kColPrefetch;
-    const bool fast_x = !gx && fast_r && min_nx >= radius;
+    const bool fast_z = fast_r && lane_ok && min_nz >= radius + kColPrefetch && vol->stride_y < (1 << 30);
+    const bool fast_y = fast_r && min_ny >= radius + kColPrefetch;
+    const bool fast_x = fast_r && min_nx >= radius;
     auto taps = [&](const float* a, const float* b) {
         mmx_taps_f32 t;
         for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) {
@@ -323,62 +312,14 @@ int mmx_log_batch_f32(const mmx_volume* vol, const mmx_block* d_blocks, const mm
             }
             return ok;
         };
-        // MMX_SUBBATCH = n (tiled path with the Y pass on the matrix cores only): the Z+X and the Y kernel run per group
-        // of n blocks instead of once per batch each, so that a group's P / Q tiles (38 MB a block) are read back while
-        // they may still sit in the 256 MiB memory-side cache.  An experiment switch (DESIGN.md section 4b has the
-        // measurement); blocks address their workspace by slot, so a launch over a sub-range of the block table is the
-        // same work.
-        static const int sub_env = getenv("MMX_SUBBATCH") ? atoi(getenv("MMX_SUBBATCH")) : 0;
-        const int sub = (tiled && q16 && !y_valu && sub_env > 0 && sub_env < n_blocks) ? sub_env : n_blocks;
-        bool sub_done = false;
-        if (sub < n_blocks) {
-            const bool want_mask = mask_fits(true);
-            rc = MMX_OK;
-            int groups_done = 0;
-            for (int g0 = 0; g0 < n_blocks && rc == MMX_OK; g0 += sub) {
-                const int cnt = n_blocks - g0 < sub ? n_blocks - g0 : sub;
-                { mmx_timed_scope ts(MMX_K_ZX, s);
-                  rc = mmx_launch_zx6(vol, d_blocks + g0, h_blocks + g0, cnt, plan, txx, radius, d_work,
-                                      (float)(1.0 / q_bp), (float)(1.0 / q_bq), s); }
-                if (rc != MMX_OK) break;
-                { mmx_timed_scope ts(MMX_K_Y2, s);
-                  rc = mmx_launch_ym(d_blocks + g0, cnt, plan, slot_elems, tyy, radius, d_work,
-                                     (float)(q_bp / 65535.0), (float)(q_bq / 32767.0), d_log,
-                                     want_mask ? (unsigned long long*)d_nms_mask : nullptr, nms_lo, nms_eps, s); }
-                if (rc == MMX_OK) ++groups_done;
-            }
-            if (rc == MMX_ERR_HIP) return hip_fail(hipGetLastError(), "fused passes (sub-batches)");
-            // (a geometry the kernels do not take shows at the first group: the whole-batch form below then falls back
-            //  as always; later groups cannot differ -- the plan and the radius are the batch's)
-            if (rc != MMX_OK && !(rc == MMX_ERR_UNSUPPORTED && groups_done == 0)) return rc;
-            sub_done = rc == MMX_OK;
-            if (sub_done) {
-                if (h_zx_path) *h_zx_path = MMX_ZX_TILED_Q16;
-                if (want_mask) *h_mask_written = MMX_MASK_QUADS;
-                return MMX_OK;
-            }
-        }
         { mmx_timed_scope ts(MMX_K_ZX, s);
           rc = MMX_ERR_UNSUPPORTED;
-          const bool mfma16 = zx_mode == MMX_ZX_MFMA_F16 || zx_mode == MMX_ZX_MFMA_F16_LDS;
           if (tiled) {
               path = q16 ? MMX_ZX_TILED_Q16 : MMX_ZX_TILED;
               rc = mmx_launch_zx6(vol, d_blocks, h_blocks, n_blocks, plan, txx, radius, d_work,
                                   q16 ? (float)(1.0 / q_bp) : 0.f, q16 ? (float)(1.0 / q_bq) : 0.f, s);
               tiled = rc == MMX_OK;
           }
-#ifdef MMX_EXPERIMENTS    // (make EXPERIMENTS=1; a stock build runs the packed kernel for these modes)
-          else if (mfma16) {    // integer voxels, aligned rows; geometries it does not take: the packed kernel
-              path = zx_mode == MMX_ZX_MFMA_F16_LDS ? MMX_ZX_MFMA_F16_LDS : MMX_ZX_MFMA_F16;
-              rc = mmx_launch_zx4(vol, d_blocks, h_blocks, n_blocks, slot_elems, txx, radius, t0, t1, t2,
-                                  (size_t)(2 * n_slots * slot_elems) * sizeof(float), path == MMX_ZX_MFMA_F16_LDS, s);
-          } else if (zx_mode == MMX_ZX_MFMA_F32) {
-              path = MMX_ZX_MFMA_F32;
-              rc = mmx_launch_zx3(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);
-          }
-#else
-          (void)mfma16;
-#endif
           if (rc == MMX_ERR_UNSUPPORTED) {
               path = MMX_ZX_PACKED;
               rc = mmx_launch_zx2(vol, d_blocks, n_blocks, max_ny, max_px, slot_elems, tzz, txx, radius, t0, t1, s);

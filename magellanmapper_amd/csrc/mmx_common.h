@@ -42,12 +42,6 @@ int mmx_launch_xpass(const mmx_block* d_blocks, int n_blocks, int max_rows, int 
 int mmx_launch_zx2(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_ny, int max_px,
                    int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
                    float* d_p, float* d_q, hipStream_t s);
-int mmx_launch_zx3(const mmx_volume* vol, const mmx_block* d_blocks, int n_blocks, int max_ny, int max_px,
-                   int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
-                   float* d_p, float* d_q, hipStream_t s);
-int mmx_launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
-                   int64_t slot_elems, const mmx_taps_f32& tx, int radius, float* d_p, float* d_q,
-                   void* d_scratch, size_t scratch_bytes, int staged, hipStream_t stream);
 // Tiled fused path (zx_mode 6): where its pieces live inside the four intermediate arrays of d_work
 // (4 n_blocks slot_elems floats).  P and Q as 16 x 16 tiles (mmx_fused4.hip: zx4_kernel<.., TILED>), the Toeplitz
 // fragment tables of the current sigma, and the operand-ordered copy of the blocks' voxels (zx6_pack_kernel),

@@ -246,6 +246,9 @@ int mmx_detect_batch_capture(const mmx_detect_args* a, mmx_detect_info* info, vo
     // inside a capture the caller's cross-call events have no meaning: the graph is ordered as a whole by the stream it
     // is launched on; the side streams join the capture through the fork / join events
     b.ev_work_free = b.ev_work_read = b.ev_done = nullptr;
+    // (the voxel copy's own stream joins a batch through ev_work_free, which a capture does not have: inside the graph
+    //  the copy runs on the main stream)
+    b.pack_stream = nullptr;
     const int rc = mmx_detect_batch(&b, info);
     hipGraph_t g = nullptr;
     if (rc == MMX_OK && b.tail_stream && b.tail_stream != b.stream) {

@@ -744,344 +744,6 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 }
 
 
-#ifdef MMX_EXPERIMENTS    // (make EXPERIMENTS=1: zx_mode 4 / 5, the measured experiments that led to the tiled form)
-// ------------------------------------------------------------------------------- staged variant (default)
-// Same arithmetic, but the voxels and the results cross LDS so that every global access is a long contiguous
-// piece of one plane.  zx4_kernel above loads 16 planes x 64 bytes per instruction, four times over (each wave
-// fetches its own 64-voxel window), and stores 16 planes x 64 bytes: measured, that moves 16.7 GB through L2 per
-// 64 blocks instead of 11.4 and pins the step time at 3.2 us per wave whatever the arithmetic does.  Here a
-// workgroup of WPG waves owns WPG adjacent column tiles of one block row: per step its waves load the 16 planes
-// of the group's window ONCE (one plane per instruction, descriptor bounded by the block row: out-of-row chunks
-// read as zero, no clamping) into a double-buffered LDS tile, every wave takes its A operands from there, the
-// results go to a second LDS tile and leave as whole rows of the group (WPG x 64 bytes per plane).  One
-// workgroup barrier per step.
-template <int WPG, typename InT> struct stage5 {
-    static constexpr int ESZ = (int)sizeof(InT);
-    static constexpr int IPITCH = ESZ == 2 ? 544 : 272;        // bytes; = 32 (mod 256) / 16 (mod 256): conflict-free operand reads
-    static constexpr int OPITCH = 64 * WPG + 16;               // bytes; rows 4 banks apart for the 16-byte tile writes
-    static constexpr int IN_BUF = 16 * IPITCH;
-    static constexpr int OUT_ARR = 16 * OPITCH;
-    static constexpr int LDS_BYTES = 2 * IN_BUF + 4 * OUT_ARR;
-};
-
-template <int NKX, int LA, typename InT, int WPG>
-__global__ void __launch_bounds__(WPG * 64)
-zx5_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
-           const mmx_block* __restrict__ blocks, int64_t slot_elems,
-           float* __restrict__ gp, float* __restrict__ gq,
-           const u4_4* __restrict__ xtab, const u4_4* __restrict__ ztab, mmx_zx4_cfg cfg)
-{
-    using cg = cls4<NKX, LA>;
-    using pc = pieces4<InT>;
-    using st = stage5<WPG, InT>;
-    constexpr int NKZ = cg::NKZ, NT = cg::NT, ESZ = st::ESZ;
-    extern __shared__ __attribute__((aligned(16))) char lds5[];
-    char* const lin = lds5;                              // [2][16][IPITCH]
-    char* const lout = lds5 + 2 * st::IN_BUF;            // [2][P | Q][16][OPITCH]
-    const mmx_block bd = blocks[blockIdx.y];
-    const int W = bd.nx, nz = bd.nz, px = bd.px;
-    const int ntx = (W + 15) >> 4;
-    const int ntg = (ntx + WPG - 1) / WPG;
-    const int y = blockIdx.x / ntg;
-    if (y >= bd.ny) return;                              // whole workgroup
-    const int g = blockIdx.x - y * ntg;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int c = g * WPG + wv;
-    const int ctab = c < ntx ? c : ntx - 1;              // (surplus waves of the last group: any fragments, results unused)
-    const int lane = threadIdx.x & 63;
-    const int li = lane & 15, kq = lane >> 4;
-    int cw = 0, cz = 0;
-    for (int i = 1; i < cfg.ncw; ++i) cw = cfg.wcls[i] == W ? i : cw;
-    for (int i = 1; i < cfg.ncz; ++i) cz = cfg.zcls[i] == nz ? i : cz;
-    const int ntz = (nz + 15) >> 4;
-    const int gx0 = (16 * g * WPG - cg::R8) & ~31;       // first staged column of the group
-
-    u4_4 xw[NKX][2][2];
-    {
-        const u4_4* xt = xtab + ((size_t)(cw * cfg.maxcol + ctab) * NKX * 2) * 128 + lane;
-#pragma unroll
-        for (int m = 0; m < NKX; ++m)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                xw[m][k][0] = xt[(m * 2 + k) * 128];
-                xw[m][k][1] = xt[(m * 2 + k) * 128 + 64];
-            }
-    }
-    u4_4 zw[NKZ][2][2];
-    const u4_4* zt = ztab + ((size_t)cz * cfg.maxu * NKZ * 2) * 128 + lane;
-    const int R = cfg.radius;
-    const int u_lo = (R + 15) >> 4;
-    const int u_hi = (nz - 16 - R) >> 4;
-    int zset = -1;
-
-    // ---- loader: this wave stages planes wv, wv + WPG, ... of each tile; lane = 16-byte chunk of the staged row
-    constexpr int NPL = (16 + WPG - 1) / WPG;
-    const InT* in = vol + bd.src_off + (int64_t)y * stride_y;
-    const unsigned ld_off = (unsigned)(gx0 * ESZ + 16 * lane);          // byte offset in the block row (wraps below 0: out of range)
-    const int need_b = (cg::xstart(g * WPG + WPG - 1) + 32 * NKX - gx0) * ESZ;     // bytes of the row the group reads
-    const bool ld_on = 16 * lane < need_b && 16 * lane < st::IPITCH;
-#ifndef ZX5_PF
-#define ZX5_PF 2
-#endif
-    constexpr int PF = ZX5_PF;                       // tiles of voxels in flight (registers) ahead of the LDS buffers
-    u4_4 stgr[PF][NPL];
-    auto issue_loads = [&](int t, u4_4 (&stg)[NPL]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-            const int p = wv + i * WPG;
-            if (p < 16) {
-                int z = 16 * t + p;
-                z = z < nz ? z : nz - 1;
-                // descriptor = this plane's block row, W voxels long: chunks beyond either end read as zero (the range
-                // check is per dword: the length is rounded up to 4 bytes, whatever follows the row meets zero weights)
-                const rsrc4_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<InT*>(in + (int64_t)z * stride_z), 0, (W * ESZ + 3) & ~3, 0x00020000);
-                stg[i] = ld_on ? __builtin_bit_cast(u4_4, __builtin_amdgcn_raw_buffer_load_b128(rs, ld_off, 0, 0)) : (u4_4){0u, 0u, 0u, 0u};
-            }
-        }
-    };
-    auto stage_tile = [&](int buf, u4_4 (&stg)[NPL]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-            const int p = wv + i * WPG;
-            if (p < 16 && ld_on) *reinterpret_cast<u4_4*>(lin + buf * st::IN_BUF + p * st::IPITCH + 16 * lane) = stg[i];
-        }
-    };
-    // ---- operand reads: plane li, 8 voxels at xstart(c) + 32 m + 8 kq
-    int aoff[NKX];
-#pragma unroll
-    for (int m = 0; m < NKX; ++m) {
-        int o = (cg::xstart(c) + 32 * m + 8 * kq - gx0) * ESZ;
-        o = o < 0 ? 0 : o;
-        o = o > st::IPITCH - 8 * ESZ ? st::IPITCH - 8 * ESZ : o;
-        aoff[m] = li * st::IPITCH + o;
-    }
-    // ---- results: tile write at (plane li, columns 16 wv + 4 kq), row stores by thread (row, 16-byte chunk)
-    const int ooff = li * st::OPITCH + (16 * wv + 4 * kq) * 4;
-    const int tid = threadIdx.x;
-    const int srow = tid / (4 * WPG), schunk = tid - srow * (4 * WPG);
-    const int scol = 16 * g * WPG + 4 * schunk;
-    const rsrc4_t rp = make_rsrc4(gp + (int64_t)bd.slot * slot_elems);
-    const rsrc4_t rq = make_rsrc4(gq + (int64_t)bd.slot * slot_elems);
-    const unsigned row_b = (unsigned)px * 4u;
-    const unsigned plane_b = (unsigned)bd.ny * row_b;
-    unsigned sbase = (unsigned)srow * plane_b + (unsigned)y * row_b + (unsigned)scol * 4u;
-    const bool scol_ok = scol < px;
-
-    unsigned win[4][NT][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int i = 0; i < NT; ++i) { win[a][i][0] = 0u; win[a][i][1] = 0u; }
-
-    // tile 0 goes straight to LDS; tiles 1 .. PF wait in registers (slot (t - 1) % PF)
-    issue_loads(0, stgr[0]);
-    stage_tile(0, stgr[0]);
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (1 + u < ntz) issue_loads(1 + u, stgr[u]);
-    __syncthreads();
-
-    const int t_end = ntz + LA;
-#pragma unroll 1
-    for (int t0 = 0; t0 < t_end; t0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int t = t0 + u;
-        if (t >= t_end) break;
-        const int buf = t & 1;
-        // results of the previous step leave as whole rows (written to LDS before the barrier that ended it)
-        const int Up = t - 1 - LA;
-        if (Up >= 0) {
-            const char* src = lout + ((t - 1) & 1) * 2 * st::OUT_ARR + srow * st::OPITCH + schunk * 16;
-            const u4_4 pv = *reinterpret_cast<const u4_4*>(src);
-            const u4_4 qv = *reinterpret_cast<const u4_4*>(src + st::OUT_ARR);
-            if (16 * Up + srow < nz && scol_ok) {
-                __builtin_amdgcn_raw_buffer_store_b128(pv, rp, sbase, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(qv, rq, sbase, 0, 0);
-            }
-            sbase += 16u * plane_b;
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int i = 0; i < 2 * LA; ++i) { win[a][i][0] = win[a][i + 1][0]; win[a][i][1] = win[a][i + 1][1]; }
-        if (t < ntz) {
-            u4_4 dh[NKX], dl[NKX];
-#pragma unroll
-            for (int m = 0; m < NKX; ++m) {
-                typename pc::raw_t raw;
-                if constexpr (ESZ == 2) raw = *reinterpret_cast<const u4_4*>(lin + buf * st::IN_BUF + aoff[m]);
-                else raw = *reinterpret_cast<const u2_4*>(lin + buf * st::IN_BUF + aoff[m]);
-                pc::split(raw, dh[m], dl[m]);
-            }
-            f4_4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
-#pragma unroll
-            for (int m = 0; m < NKX; ++m) {
-                a0 = mfma16(dh[m], xw[m][0][0], a0);
-                b0 = mfma16(dh[m], xw[m][1][0], b0);
-                a1 = mfma16(dh[m], xw[m][0][1], a1);
-                b1 = mfma16(dh[m], xw[m][1][1], b1);
-                if constexpr (pc::NP == 2) {
-                    a0 = mfma16(dl[m], xw[m][0][0], a0);
-                    b0 = mfma16(dl[m], xw[m][1][0], b0);
-                    a1 = mfma16(dl[m], xw[m][0][1], a1);
-                    b1 = mfma16(dl[m], xw[m][1][1], b1);
-                }
-            }
-            // the next tile's voxels (loaded during the previous step) go to the other buffer; the tile after
-            // that is requested
-            if (t + 1 < ntz) stage_tile(buf ^ 1, stgr[u]);                 // tile t + 1 sits in slot t % PF
-            if (t + 1 + PF < ntz) issue_loads(t + 1 + PF, stgr[u]);
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const float av0 = __builtin_fmaf(a1[r], kLoInv, a0[r]), av1 = __builtin_fmaf(a1[r + 1], kLoInv, a0[r + 1]);
-                const float bv0 = __builtin_fmaf(b1[r], kLoInv, b0[r]), bv1 = __builtin_fmaf(b1[r + 1], kLoInv, b0[r + 1]);
-                const f2_4 av = {av0, av1}, bv = {bv0, bv1};
-                const h2_4 ah = __builtin_convertvector(av, h2_4), bh = __builtin_convertvector(bv, h2_4);
-                const f2_4 ar = {__builtin_fmaf((float)ah.x, -kLoScale, av0 * kLoScale), __builtin_fmaf((float)ah.y, -kLoScale, av1 * kLoScale)};
-                const f2_4 br = {__builtin_fmaf((float)bh.x, -kLoScale, bv0 * kLoScale), __builtin_fmaf((float)bh.y, -kLoScale, bv1 * kLoScale)};
-                win[0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
-                win[1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
-                win[2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
-                win[3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) { win[a][2 * LA][0] = 0u; win[a][2 * LA][1] = 0u; }
-        }
-        const int U = t - LA;
-        if (U >= 0) {
-            const int want = (U >= u_lo && U <= u_hi) ? u_lo : U;
-            if (want != zset) {
-                zset = want;
-#pragma unroll
-                for (int ks = 0; ks < NKZ; ++ks)
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        zw[ks][k][0] = zt[((size_t)(want * NKZ + ks) * 2 + k) * 128];
-                        zw[ks][k][1] = zt[((size_t)(want * NKZ + ks) * 2 + k) * 128 + 64];
-                    }
-            }
-            f4_4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, q0 = p0, q1 = p0;
-#pragma unroll
-            for (int ks = 0; ks < NKZ; ++ks) {
-                const u4_4 ah = {win[0][2 * ks][0], win[0][2 * ks][1], win[0][2 * ks + 1][0], win[0][2 * ks + 1][1]};
-                const u4_4 al = {win[1][2 * ks][0], win[1][2 * ks][1], win[1][2 * ks + 1][0], win[1][2 * ks + 1][1]};
-                const u4_4 bh = {win[2][2 * ks][0], win[2][2 * ks][1], win[2][2 * ks + 1][0], win[2][2 * ks + 1][1]};
-                const u4_4 bl = {win[3][2 * ks][0], win[3][2 * ks][1], win[3][2 * ks + 1][0], win[3][2 * ks + 1][1]};
-                p0 = mfma16(ah, zw[ks][0][0], p0);
-                q0 = mfma16(bh, zw[ks][0][0], q0);
-                p1 = mfma16(ah, zw[ks][0][1], p1);
-                q1 = mfma16(bh, zw[ks][0][1], q1);
-                p1 = mfma16(al, zw[ks][0][0], p1);
-                q1 = mfma16(bl, zw[ks][0][0], q1);
-                q0 = mfma16(ah, zw[ks][1][0], q0);
-                q1 = mfma16(ah, zw[ks][1][1], q1);
-                q1 = mfma16(al, zw[ks][1][0], q1);
-            }
-            f4_4 P, Q;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                P[r] = __builtin_fmaf(p1[r], kLoInv, p0[r]);
-                Q[r] = __builtin_fmaf(q1[r], kLoInv, q0[r]);
-            }
-            char* dst = lout + buf * 2 * st::OUT_ARR + ooff;
-            *reinterpret_cast<f4_4*>(dst) = P;
-            *reinterpret_cast<f4_4*>(dst + st::OUT_ARR) = Q;
-        }
-        __syncthreads();
-      }
-    }
-    // the last tile's results
-    {
-        const int Up = t_end - 1 - LA;
-        const char* src = lout + ((t_end - 1) & 1) * 2 * st::OUT_ARR + srow * st::OPITCH + schunk * 16;
-        const u4_4 pv = *reinterpret_cast<const u4_4*>(src);
-        const u4_4 qv = *reinterpret_cast<const u4_4*>(src + st::OUT_ARR);
-        if (Up >= 0 && 16 * Up + srow < nz && scol_ok) {
-            __builtin_amdgcn_raw_buffer_store_b128(pv, rp, sbase, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(qv, rq, sbase, 0, 0);
-        }
-    }
-}
-
-template <int NKX, int LA>
-int launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
-               int64_t slot_elems, const mmx_taps_f32& tx, int radius, float* d_p, float* d_q,
-               void* d_scratch, size_t scratch_bytes, bool staged, hipStream_t s)
-{
-    using cg = cls4<NKX, LA>;
-    mmx_zx4_cfg cfg{};          // (every field the setup kernel reads has a value: qp = qq = 0 means float32 tiles)
-    for (int k = 0; k <= MMX_MAX_RADIUS_FAST; ++k) { cfg.w0[k] = tx.w0[k]; cfg.w2[k] = tx.w2[k]; }
-    cfg.radius = radius;
-    cfg.xscale = vol->dtype == MMX_U16 ? (float)(65536.0 / 65535.0) : (float)(256.0 / 255.0);
-    cfg.ncw = cfg.ncz = 0;
-    cfg.staged = staged ? 1 : 0;
-    cfg.maxcol = cfg.maxu = 0;
-    int max_waves = 0;
-    const int64_t esz = vol->dtype == MMX_U16 ? 2 : 1;
-    for (int i = 0; i < n_blocks; ++i) {
-        const mmx_block& b = h_blocks[i];
-        if (b.nx < 8 || b.nx < radius || b.nz < radius) return MMX_ERR_UNSUPPORTED;   // single reflection, 8-voxel chunks
-        if ((b.src_off * esz) % 16) return MMX_ERR_UNSUPPORTED;                        // 16-byte chunk loads
-        int j;
-        for (j = 0; j < cfg.ncw && cfg.wcls[j] != b.nx; ++j) {}
-        if (j == cfg.ncw) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; cfg.wcls[cfg.ncw++] = b.nx; }
-        for (j = 0; j < cfg.ncz && cfg.zcls[j] != b.nz; ++j) {}
-        if (j == cfg.ncz) { if (j == MMX_ZX4_MAXCLS) return MMX_ERR_UNSUPPORTED; cfg.zcls[cfg.ncz++] = b.nz; }
-        const int ntx = (b.nx + 15) / 16, ntz = (b.nz + 15) / 16;
-        if (ntx > cfg.maxcol) cfg.maxcol = ntx;
-        if (ntz > cfg.maxu) cfg.maxu = ntz;
-        const int per_row = pair ? (ntx + 1) / 2 : ntx;
-        if (b.ny * per_row > max_waves) max_waves = b.ny * per_row;
-    }
-    for (int j = cfg.ncw; j < MMX_ZX4_MAXCLS; ++j) cfg.wcls[j] = -1;
-    for (int j = cfg.ncz; j < MMX_ZX4_MAXCLS; ++j) cfg.zcls[j] = -1;
-    if ((vol->stride_y * esz) % 16 || (vol->stride_z * esz) % 16) return MMX_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(vol->d_data)) % 16) return MMX_ERR_UNSUPPORTED;
-    if (vol->stride_z * esz * 16 >= (int64_t(1) << 31)) return MMX_ERR_UNSUPPORTED;   // 32-bit row offsets in a tile
-    const int nx_entries = cfg.ncw * cfg.maxcol * NKX * 2;
-    const int nz_entries = cfg.ncz * cfg.maxu * cg::NKZ * 2;
-    const size_t xbytes = (size_t)nx_entries * 2 * 64 * sizeof(u4_4);
-    const size_t zbytes = (size_t)nz_entries * 2 * 64 * sizeof(u4_4);
-    if (xbytes + zbytes > scratch_bytes) return MMX_ERR_UNSUPPORTED;
-    u4_4* xtab = reinterpret_cast<u4_4*>(d_scratch);
-    u4_4* ztab = reinterpret_cast<u4_4*>(reinterpret_cast<char*>(d_scratch) + xbytes);
-    hipLaunchKernelGGL((zx4_setup<NKX, LA>), dim3((nx_entries + nz_entries + 3) / 4), dim3(256), 0, s, cfg, xtab, ztab);
-    if (!staged) {
-    dim3 grid((max_waves + 3) / 4, n_blocks);
-    if (vol->dtype == MMX_U16)
-        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)vol->d_data,
-                           vol->stride_z, vol->stride_y, d_blocks, slot_elems, d_p, d_q, xtab, ztab, cfg);
-    else
-        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint8_t>), grid, dim3(256), 0, s, (const uint8_t*)vol->d_data,
-                           vol->stride_z, vol->stride_y, d_blocks, slot_elems, d_p, d_q, xtab, ztab, cfg);
-    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
-    }
-    constexpr int WPG = 6;
-    int max_groups = 0;
-    for (int i = 0; i < n_blocks; ++i) {
-        const int ntx = (h_blocks[i].nx + 15) / 16;
-        const int ng = h_blocks[i].ny * ((ntx + WPG - 1) / WPG);
-        if (ng > max_groups) max_groups = ng;
-    }
-    dim3 grid(max_groups, n_blocks);
-#define MMX_ZX5_LAUNCH(TT)                                                                                  \
-    do {                                                                                                    \
-        auto k = zx5_kernel<NKX, LA, TT, WPG>;                                                              \
-        const int lds = stage5<WPG, TT>::LDS_BYTES;                                                         \
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) \
-            return MMX_ERR_HIP;                                                                             \
-        hipLaunchKernelGGL(k, grid, dim3(WPG * 64), lds, s, (const TT*)vol->d_data, vol->stride_z, vol->stride_y, \
-                           d_blocks, slot_elems, d_p, d_q, xtab, ztab, cfg);                                \
-    } while (0)
-    if (vol->dtype == MMX_U16) MMX_ZX5_LAUNCH(uint16_t);
-    else MMX_ZX5_LAUNCH(uint8_t);
-#undef MMX_ZX5_LAUNCH
-    return hipGetLastError() == hipSuccess ? MMX_OK : MMX_ERR_HIP;
-}
-
-#endif  // MMX_EXPERIMENTS
 
 // ------------------------------------------------------------------------------- tiled variant (zx_mode 6)
 // Operand-ordered copy of the blocks' voxels, made once per batch: for every block row y and z tile t the row
@@ -1235,13 +897,11 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     cfg.staged = 2;
     cfg.qp = qp; cfg.qq = qq;
     cfg.maxcol = cfg.maxu = 0;
-    // two column tiles per wave (zx4_kernel's NTW): 16-bit tiles of integer voxels, 8 < radius <= 16.  MMX_ZX_PAIR=0
-    // keeps one tile per wave (A/B runs).
-    static const bool pair_env = !(getenv("MMX_ZX_PAIR") && atoi(getenv("MMX_ZX_PAIR")) == 0);
-    const bool pair = pair_env && NKX == 2 && LA == 1 && qp > 0.f && vol->dtype != MMX_F32;
+    // two column tiles per wave (zx4_kernel's NTW): 16-bit tiles of integer voxels, 8 < radius <= 16; tile rows past
+    // the block are not stored (the A/B runs of both: profiles/r04_zx_experiments.txt)
+    const bool pair = NKX == 2 && LA == 1 && qp > 0.f && vol->dtype != MMX_F32;
     cfg.ntw = pair ? 2 : 1;
-    static const bool keep_pad_env = getenv("MMX_ZX_KEEP_PAD") && atoi(getenv("MMX_ZX_KEEP_PAD")) != 0;
-    cfg.keep_pad = keep_pad_env ? 1 : 0;
+    cfg.keep_pad = 0;
     int max_waves = 0;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];
@@ -1369,18 +1029,3 @@ int mmx_launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_b
     return launch_zx6<2, 2>(vol, d_blocks, h_blocks, n_blocks, plan, tx, radius, d_work, qp, qq, stream);
 }
 
-#ifdef MMX_EXPERIMENTS
-// tx: the PLAIN half kernels (no input scale, no norm); d_scratch: device memory the fused path does not
-// otherwise use (the fragment tables: a few hundred KB)
-int mmx_launch_zx4(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block* h_blocks, int n_blocks,
-                   int64_t slot_elems, const mmx_taps_f32& tx, int radius, float* d_p, float* d_q,
-                   void* d_scratch, size_t scratch_bytes, int staged, hipStream_t stream)
-{
-    if (vol->dtype != MMX_U16 && vol->dtype != MMX_U8) return MMX_ERR_UNSUPPORTED;
-    if (vol->stride_x != 1) return MMX_ERR_UNSUPPORTED;
-    if (radius < 1 || radius > MMX_MAX_RADIUS_FAST) return MMX_ERR_UNSUPPORTED;
-    if (radius <= 8) return launch_zx4<1, 1>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, staged != 0, stream);
-    if (radius <= 16) return launch_zx4<2, 1>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, staged != 0, stream);
-    return launch_zx4<2, 2>(vol, d_blocks, h_blocks, n_blocks, slot_elems, tx, radius, d_p, d_q, d_scratch, scratch_bytes, staged != 0, stream);
-}
-#endif  // MMX_EXPERIMENTS

@@ -189,8 +189,7 @@ int prune_axis_impl(const int32_t* zyx, const int32_t* tag, double* abs_zyx,
     if ((n_cur && (!zyx || !tag || !abs_zyx || !cur || !out_cur)) || !bounds || !tol || !out_n ||
         !n_slab || !n_after || !n_next || axis < 0 || axis > 2 || n_sections < 2 || n_cur < 0)
         return MMX_ERR_ARG;
-    // (MMX_PRUNE_PROF=2: the split of every axis step on stderr; any other value only turns the Python-side laps on)
-    static const bool prof = getenv("MMX_PRUNE_PROF") != nullptr && atoi(getenv("MMX_PRUNE_PROF")) >= 2;
+    constexpr bool prof = false;          // (the split of every axis step on stderr: a debugging aid, compiled out)
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto t0 = tnow();
     const int n_regions = 2 * n_sections - 1;

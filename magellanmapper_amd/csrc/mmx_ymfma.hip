@@ -476,8 +476,7 @@ int mmx_launch_ym(const mmx_block* d_blocks, int n_blocks, const mmx_zx6_plan& p
     cfg.lo = nms_lo / cfg.unscale;
     cfg.eps = nms_eps / cfg.unscale;
     cfg.radius = radius;
-    static const bool rev_env = !(getenv("MMX_YM_REVERSE") && atoi(getenv("MMX_YM_REVERSE")) == 0);
-    cfg.reverse = rev_env ? 1 : 0;
+    cfg.reverse = 1;         // (a batch is walked from its last block backwards: the tiles Z+X wrote last)
     // NB block offsets cover every tap when the first offset beyond either end, RB + 16 - 15 and 16 NB - RB - 31 rows away,
     // is out of reach: R <= 8 (NB - 2) with RB = 8 (NB - 2)
     if (radius <= 8) return launch_ym<3>(d_blocks, n_blocks, plan, slot_elems, cfg, d_p, d_log, d_mask, stream);

@@ -37,6 +37,15 @@ class StackTimes(Enum):
     TOTAL = "Total_stack"
 
 
+#: several ranks with a regular block geometry: every rank prunes its own rows (False: gather, rank 0 prunes, broadcast)
+DIST_PRUNE = True
+#: prune finished regions of a raw stack while the GPU is still detecting: "" = stacks of 64 blocks and more, "1" /
+#: "0" = always / never (what tests and tools set; DESIGN.md section 4b has the measurements)
+PRUNE_AHEAD = ""
+#: print the phases of the pruning step to stderr (tools/prune_prof.py)
+PRUNE_PROF = False
+
+
 class Image5d:
     """Minimal stand-in for ``magmap.io.np_io.Image5d`` (reference np_io.py:33-70): the
     ``(t, z, y, x[, c])`` array plus the attributes this path reads."""
@@ -171,19 +180,18 @@ class _TableArena:
         return at == self.n and (not sample_columns or self._columns_unedited())
 
     def _columns_unedited(self) -> bool:
-        """The compact columns the pruning reads (``zyx``, ``abs``: copies made when the rows landed) still say what
-        the tables say, on a sample of the rows (every 61st and the last: 50 us for 3 x 10^5 rows).  Tables handed
-        out by ``detect_blobs_sub_rois`` are views of the arena and the reference's API lets a caller edit them in
-        place before ``prune_blobs_mp`` (shift them, say); such an edit is meant to be seen, and the arena's
-        shortcuts would not see it -- ``prune_blobs_mp`` then works from the tables themselves."""
+        """The compact columns the pruning reads (``zyx``, ``abs``, ``tag``: copies made when the rows landed) still
+        say what the tables say -- every row (an in-place edit of one small block's table must not slip through; a few
+        ms for 3 x 10^5 rows, skipped when ``_StackRun`` vouches for tables nobody else has seen).  Tables handed out by
+        ``detect_blobs_sub_rois`` are views of the arena and the reference's API lets a caller edit them in place
+        before ``prune_blobs_mp`` (shift them, say); such an edit is meant to be seen, and the arena's shortcuts would
+        not see it -- ``prune_blobs_mp`` then works from the tables themselves."""
         n = self.n
         if n == 0:
             return True
-        st, zyx, ab, tg = self.store[:n], self.zyx[:n], self.abs[:n], self.tag[:n]
-        nc = self.n_cols
-        return bool((st[::61, :3] == zyx[::61]).all() and (st[::61, 7:10] == ab[::61]).all() and
-                    (st[::61, nc:] == tg[::61]).all() and (st[n - 1, :3] == zyx[n - 1]).all() and
-                    (st[n - 1, 7:10] == ab[n - 1]).all() and (st[n - 1, nc:] == tg[n - 1]).all())
+        st, nc = self.store[:n], self.n_cols
+        return bool(np.array_equal(st[:, :3], self.zyx[:n]) and np.array_equal(st[:, 7:10], self.abs[:n]) and
+                    np.array_equal(st[:, nc:], self.tag[:n]))
 
 
 class _ArenaSink:
@@ -611,7 +619,7 @@ class StackDetector:
             shape3, hint[0], hint[1], hint[1] if hint[2] is None else hint[2], sub_roi_slices, sub_rois_offsets)[1]
         # several ranks: with the pruning planned (plan_pruning) and a regular block geometry every rank keeps its
         # own tables and the pruning itself is distributed; otherwise the tables are gathered on rank 0
-        local_only = dist.world_size() > 1 and regular and os.environ.get("MMX_DIST_PRUNE", "1") != "0"
+        local_only = dist.world_size() > 1 and regular and DIST_PRUNE
         arena = _TableArena(11 + n_extra, len(mine)) if (dist.world_size() == 1 or local_only) else None
         pos = {i: k for k, i in enumerate(mine)}
 
@@ -619,11 +627,11 @@ class StackDetector:
             return cls._exclude_matrix(coords[mine[k]], last_coord, exclude_border)
 
         pruner = None
-        # (MMX_PRUNE_AHEAD = 1 / 0 / unset: always / never / for raw stacks of 64 blocks and more -- with per-block
+        # (PRUNE_AHEAD "1" / "0" / "": always / never / for raw stacks of 64 blocks and more -- with per-block
         #  preprocessing on it measured 218.9 against 216.6 ms per volume: nothing to gain.  On the benchmark volume it
         #  moves ~4 ms of pruning under the GPU's last batches and adds most of that in the merge: 0.8-1.0 ms per volume
         #  in four alternating pairs of bench.py runs; it costs small stacks 0.6 ms: DESIGN.md)
-        ahead = os.environ.get("MMX_PRUNE_AHEAD", "")
+        ahead = PRUNE_AHEAD
         make_pruner = None
         if regular and dist.world_size() == 1 and mine and (
                 ahead == "1" or (ahead != "0" and len(mine) >= 64 and denoise_max_shape is None)):
@@ -1319,7 +1327,7 @@ class StackPruner:
         ar = seg_rois.arena
         world, me = dist.world_size(), dist.rank()
         from time import perf_counter
-        _prof = os.environ.get("MMX_PRUNE_PROF") and me == 0
+        _prof = PRUNE_PROF and me == 0
         _t = [perf_counter()]
 
         def _lap(what):
@@ -1388,7 +1396,7 @@ class StackPruner:
 
     _rank_box_cache: dict = {}
     #: own rows from which a rank prunes its blocks region by region (below: one region, no thread hand-offs)
-    REGION_MIN_ROWS = int(os.environ.get("MMX_DIST_REGION_ROWS", 8000))
+    REGION_MIN_ROWS = 8000
 
     @classmethod
     def _rank_boxes(cls, n_blocks, world, coords, sub_roi_slices, shape3, reach):
@@ -1574,7 +1582,7 @@ class StackPruner:
         (``mmx_host_prune_axis``; the de-duplication stays on the host as in the reference).
         """
         import pandas as pd
-        _prof = os.environ.get("MMX_PRUNE_PROF")
+        _prof = PRUNE_PROF
         _t = [time()]
 
         def _lap(what):

@@ -213,11 +213,11 @@ def _worker_dist_prune(rank, world, port, case, out_dir, regions=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as td
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    if regions:     # every rank prunes its blocks region by region whatever the number of rows (read at import)
-        os.environ["MMX_DIST_REGION_ROWS"] = "0"
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from magellanmapper_amd import dist as d, stack_detect as sd
+        if regions:     # every rank prunes its blocks region by region whatever the number of rows
+            sd.StackPruner.REGION_MIN_ROWS = 0
         blocks, tables, shape, channels, n_extra = _dist_case(case)
         grid = blocks.sub_roi_slices.shape
         coords = list(np.ndindex(*grid))

@@ -78,9 +78,9 @@ def test_log_cube_within_tolerance(gpu, case):
 
 @pytest.mark.parametrize("case", ["u16_5sigma", "u8_3sigma", "f32_2sigma", "u16_twoscale10"])
 def test_fused_zx_path_gives_the_same_cube(gpu, case):
-    """The fused Z+X kernels (zx_mode 2: wave-specialised packed math, 3: float32 MFMA X pass, 4 / 5: split-float16
-    MFMA X+Z, register resident / staged through LDS, 6: the same on operand-ordered voxels with tiled P / Q and
-    its own Y pass) must reproduce the three-pass result (mode 0)."""
+    """The fused Z+X kernels (zx_mode 2: wave-specialised packed math, 6: split-float16 matrix-core X+Z on operand-ordered
+    voxels with tiled P / Q and its own Y pass, 7: the same with 16-bit tiles) must reproduce the three-pass result
+    (mode 0)."""
     from magellanmapper_amd import _native as nat
     from magellanmapper_amd import blob_log as bl
     g = load_golden("bloblog_%s.npz" % case)
@@ -96,7 +96,7 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
         kinds = nat.timing_read()
         assert kinds["zxpass"][1] == 0 and (kinds["zpass"][1] > 0 or kinds["generic"][1] > 0)
         assert bl.LAST_ZX_PATH == nat.MMX_ZX_SEPARATE
-        for mode in (2, 3, 4, 5, 6, 7):
+        for mode in (2, 6, 7):
             bl.ZX_MODE = mode
             fused = bl.log_cube_blocks(dvol, 0, [(0, 0, 0)], [shape], space)[0]
             kinds = nat.timing_read()
@@ -533,7 +533,7 @@ def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
         detector.Blobs(np.ones((1, 4))).format_blobs()
 
 
-@pytest.mark.parametrize("fused", [0, 2, 3, 4, 5, 6, 7, "7 + Y on the VALU"])
+@pytest.mark.parametrize("fused", [0, 2, 6, 7, "7 + Y on the VALU"])
 def test_every_kernel_radius_matches_oracle(gpu, fused, monkeypatch):
     """Each compiled radius (1..24 register-resident, 25 generic) of the separable passes against the
     float64 oracle cube.  Regression: the X pass read its register window in pairs but sized it odd for
@@ -544,8 +544,6 @@ def test_every_kernel_radius_matches_oracle(gpu, fused, monkeypatch):
     if fused == "7 + Y on the VALU":
         fused = 7
         monkeypatch.setattr(bl, "ZX_FLAGS", nat.MMX_ZX_Y_VALU)
-    if fused in (3, 4, 5) and not nat.lib().mmx_has_experiments():
-        pytest.skip("zx_mode 3 / 4 / 5 are built with `make EXPERIMENTS=1` only (a stock library runs the packed kernel)")
     vol = synth.make_volume(3, (35, 42, 48), 12)
     dvol = bl.DeviceVolume(vol)
     img = blo.img_as_float(vol)
