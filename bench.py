@@ -215,6 +215,8 @@ def run_cpu_baseline(name, args, host_vol):
     bx = max(1, min(shape[2] // 256, -(-want_blocks // (bz * by))))
     sz = min(shape[0], 320 if bz == 2 else (96 if n_chl > 1 else 256))
     sshape = (sz, min(shape[1], 256 * by), min(shape[2], 256 * bx))
+    if args.cpu_full and name == args.config:
+        sshape = tuple(shape)               # the SAME volume (minutes of CPU work: not the default)
     use_vol = host_vol if name == args.config else None
     sample = make_host_sample(sshape, cfg["seed"], n_chl) if use_vol is None else np.ascontiguousarray(
         use_vol[:sshape[0], :sshape[1], :sshape[2]])
@@ -224,6 +226,7 @@ def run_cpu_baseline(name, args, host_vol):
            "cores": min(cores, n_jobs), "kind": "port",
            "cpu_count": os.cpu_count(), "physical_cores": phys,
            "detection_s": round(t_det, 2), "pruning_s": round(t_tot - t_det, 2),
+           "whole_volume": tuple(sshape) == tuple(shape),
            "sample": f"{sshape[0]}x{sshape[1]}x{sshape[2]} (z,y,x){' x %d channels' % n_chl if n_chl > 1 else ''} "
                      f"volume from the same generator (seed, blob density, profile, segment_size as the GPU run), "
                      f"{n_jobs} blocks over a pool of {min(cores, n_jobs)} processes "
@@ -779,6 +782,8 @@ def main():
                     help="a (z, y, x[, c]) uint16 host volume to detect instead of the generated one (parity tests)")
     ap.add_argument("--dump", default=None, metavar="NPZ", help="rank 0 writes the final table (and colocs) here")
     ap.add_argument("--segment-size", type=int, default=0, help="profile segment_size (default 256; parity tests use smaller blocks)")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="CPU baseline (and the parity check) on the WHOLE volume of --config instead of the bounded sample")
     ap.add_argument("--cpu-cores", type=int, default=0, help="pool size of the CPU baseline (default: all physical cores)")
     ap.add_argument("--from-host", choices=("pinned", "pageable", "mmap"), default=None,
                     help="after the timed region: steps that start from a HOST copy of the volume (upload overlapped "
