@@ -315,7 +315,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             return v
 
     dvol = SlabVolume(slab, z0, shape)
-    timers = {"gather_ms": 0.0, "prune_ms": 0.0, "detect_ms": 0.0}
+    timers = {"gather_ms": 0.0, "prune_ms": 0.0, "detect_ms": 0.0, "tail_ms": 0.0, "tail_exchange_ms": 0.0}
 
     def finish(pruned):
         if pruned is None:
@@ -357,6 +357,10 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         timers["gather_ms"] += exchange
         timers["detect_ms"] += (t_b - t_a) * 1e3 - (exchange - in_prune)
         timers["prune_ms"] += (t_c - t_b) * 1e3 - in_prune
+        # what this rank still did after its last kernel had finished: the last batch's host work, the pruning (its
+        # exchanges included) and the final columns
+        timers["tail_ms"] += (t_c - bl.LAST_BATCH_DONE_T) * 1e3 if bl.LAST_BATCH_DONE_T >= t_a else 0.0
+        timers["tail_exchange_ms"] += in_prune
         return final, colocs, st
 
     def one_step():
@@ -452,11 +456,13 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
         mine = torch.tensor([sum(ms for ms, n in ktimes.values()) / steps, timers["detect_ms"] / steps,
-                             timers["gather_ms"] / steps, timers["prune_ms"] / steps, float(hi - lo)],
+                             timers["gather_ms"] / steps, timers["prune_ms"] / steps, float(hi - lo),
+                             timers["tail_ms"] / steps, (timers["tail_ms"] - timers["tail_exchange_ms"]) / steps],
                             dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         tdist.all_gather(allr, mine)
-        per_rank = [dict(zip(("kernel_ms", "detect_wall_ms", "gather_ms", "prune_ms", "blocks"),
+        per_rank = [dict(zip(("kernel_ms", "detect_wall_ms", "gather_ms", "prune_ms", "blocks",
+                              "tail_after_last_kernel_ms", "tail_without_exchanges_ms"),
                              (round(float(v), 2) for v in r.cpu()))) for r in allr]
     host_run = None
     if args.from_host and world == 1:
@@ -626,6 +632,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             # launch, launch gaps, waits for the preprocessing stream, and the tail after the last kernel (last
             # batch's host work, pruning, final columns)
             "host_exposed_ms_per_step": round(elapsed / steps * 1e3 - main_ms, 2) if world == 1 else None,
+            # rank 0: from the moment its last batch's kernels were seen done to the end of the step (the last batch's
+            # host work, the pruning with its exchanges, the final columns); per rank in `ranks`
+            "tail_after_last_kernel_ms": round(timers["tail_ms"] / steps, 2),
             # of which: the LoG stream waiting for a batch's preprocessing on the other stream (HIP events around the waits)
             "pre_stream_wait_ms": None if pre_wait_ms is None else round(pre_wait_ms, 2),
             "overlapped_streams": list(overlapped) or None},

@@ -32,6 +32,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import time
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -88,6 +89,8 @@ GRAPH_REPLAYS = 0
 LAST_Q16_BOUND = 0.0
 #: nomination band (value units) of that batch
 LAST_NMS_BAND = 0.0
+#: host clock (time.perf_counter) at which the most recent batch's last kernel was seen complete
+LAST_BATCH_DONE_T = 0.0
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
@@ -1354,6 +1357,8 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
     """Wait for one batch's candidates and turn them into ordered raw peaks
     ``(coords int64 (n, 4), values float64 (n,))`` per block."""
     job["done"].synchronize()
+    global LAST_BATCH_DONE_T
+    LAST_BATCH_DONE_T = time.perf_counter()      # (bench.py: what a step still does after its last kernel)
     eps = job.get("eps", eps)
     which, cap, ns = job["which"], job["cap"], job["ns"]
     native = job.get("native", False)

@@ -283,7 +283,16 @@ pp_stats_kernel(const uint16_t* __restrict__ copy, const int64_t* __restrict__ c
     for (int i = tid; i < PP_HIST; i += PPS_WG) hist[i] = 0;
     __syncthreads();
 
+#ifdef PPS_REGS
     const bool regs = n <= NV * PPS_WG;                // every lane's voxels fit its registers
+#else
+    // (measured: with 64 voxels in registers the fully unrolled passes keep 128 compare masks alive in scalar registers
+    //  and spill them lane by lane; re-reading the tile from L2 in chunks of 8 for each of the three passes is faster:
+    //  0.97 -> 0.65 ms per 27 blocks.  Also measured and dropped: a constant-line shortcut in the blur kernel's first
+    //  pass -- lines of background voxels all stretch to clip_min, their outputs are one chain -- which fired for a
+    //  quarter of the waves and still lost 9 % to its spills, ballots and second LDS read)
+    const bool regs = false;
+#endif
     int v[NV];
     if (regs) {
 #pragma unroll
