@@ -162,7 +162,9 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
     // one output row (y6_kernel's step after its taps; values and thresholds in accumulator units)
     auto row = [&](float acc, int y) __attribute__((always_inline)) {
         const unsigned long long ab = MASK ? __ballot(real & (acc > nms_lo)) : ~0ull;
+#ifndef YM_NOSTORE
         if (ab && real) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc * us), rsw, ooff, (unsigned)y * row_b, 0);
+#endif
         if constexpr (MASK) {
             float nbx = -INFINITY;
             if (ab) {
@@ -243,7 +245,9 @@ ym_kernel(const mmx_block* __restrict__ blocks, int64_t slot_elems, int64_t tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (ab[r]) {
+#ifndef YM_NOSTORE
                     if (real) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r] * us), rsw, ooff, (unsigned)(16 * T + r) * row_b, 0);
+#endif
                     const float l = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
                         (int)__float_as_uint(v[r]), (int)__float_as_uint(v[r]), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
                     const float rr = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(
