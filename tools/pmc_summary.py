@@ -19,7 +19,8 @@ def load_counter(d, counter):
     return rows
 
 def short(name):
-    if "pp_fast_kernel" in name or "pp_generic_kernel" in name or "pp_mid_kernel" in name:
+    if any(k in name for k in ("pp_fast_kernel", "pp_generic_kernel", "pp_mid_kernel", "pp_blur_kernel", "pp_stats_kernel",
+                               "pp_retile_kernel", "pp_offsets")):
         return "preproc"
     if "zx6_pack_kernel" in name:
         return "zxpack"
