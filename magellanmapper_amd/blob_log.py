@@ -45,18 +45,6 @@ try:  # torch is the device-memory / stream plumbing
     import torch
 except Exception as exc:  # pragma: no cover
     raise ImportError("magellanmapper_amd needs PyTorch-ROCm for device memory") from exc
-try:
-    # A declared dependency of the product path (not of the kernels): when two overlapping blobs of a block
-    # each win one pair and lose another, scikit-image's outcome depends on the order in which
-    # ``cKDTree.query_pairs`` returns the pairs (skimage/feature/blob.py:169-172) -- implementation defined, so
-    # the only faithful source is the same call (``_reference_pair_order``; 13 of the 256 benchmark blocks).
-    # Fixtures were made with SciPy 1.7.1, the reference pins 1.15.3 (envs/requirements.txt:47); both agree on
-    # every golden case.  SciPy is the reference's own dependency, so it is present wherever this drops in.
-    from scipy import spatial as _scipy_spatial
-except Exception as exc:  # pragma: no cover
-    raise ImportError("magellanmapper_amd needs SciPy (scipy.spatial.cKDTree) for the reference's pair "
-                      "order in chained overlap prunes") from exc
-
 #: half-width of the float32 "contested" band, relative to the input's value scale
 EPS_REL = float(os.environ.get("MMX_EPS_REL", 2e-5))
 #: the band for raw integer volumes, whose default kernels hand the Z+X results to the Y pass as 16-bit fixed point
@@ -91,8 +79,6 @@ LAST_Q16_BOUND = 0.0
 LAST_NMS_BAND = 0.0
 #: host clock (time.perf_counter) at which the most recent batch's last kernel was seen complete
 LAST_BATCH_DONE_T = 0.0
-#: band around the overlap limit inside which the host re-evaluates the fraction exactly
-OVERLAP_BAND = 1e-9
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
 #: default for kernel experiments; tests set it to cross-check the kernels against each other)
 ZX_MODE = int(os.environ.get("MMX_FUSE", nat.MMX_ZX_AUTO))
@@ -125,291 +111,14 @@ PRE_AHEAD = 2
 #: one workspace: -2.8 ms)
 RESCORE_STREAM = True
 PACK_STREAM = False
-#: candidate-table entries copied to pinned host memory together with the counts, before the host knows how many
-#: there are (a batch of the benchmark volume holds ~3e4; more entries cost a second, synchronous copy)
-_PREFIX_ENTRIES = 1 << 16
 
-_NP_TO_MMX = {np.dtype(np.uint8): nat.MMX_U8, np.dtype(np.uint16): nat.MMX_U16,
-              np.dtype(np.float32): nat.MMX_F32, np.dtype(np.float64): nat.MMX_F64}
-_TORCH_DTYPES = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16,
-                 np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
-
-
-def _require_gpu() -> "torch.device":
-    if not torch.cuda.is_available():
-        raise nat.MmxError("no GPU visible: the blob-detection path is HIP-only (no CPU fallback)")
-    return torch.device("cuda", torch.cuda.current_device())
-
-
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
-class DeviceVolume:
-    """A ``(z, y, x[, c])`` image resident in HBM.
-
-    Integer images other than uint8/uint16 and float16 are converted like
-    ``skimage.img_as_float`` would (to float64) on the host first.  For a float64 image a
-    float32 copy feeds the float32 passes; the exact re-score reads the float64 original.
-    """
-
-    _upload = None          # the z-slab upload still in flight (`_SlabUpload`), if any
-
-    def __init__(self, image, device: Optional["torch.device"] = None):
-        dev = device or _require_gpu()
-        if isinstance(image, torch.Tensor):
-            t = image
-            np_dtype = np.dtype(str(t.dtype).replace("torch.", ""))
-        else:
-            arr = np.asarray(image)
-            if arr.dtype not in _NP_TO_MMX:
-                arr = _img_as_float_host(arr)
-            np_dtype = arr.dtype
-            if np_dtype not in _NP_TO_MMX:
-                raise TypeError(f"unsupported voxel type {np_dtype}")
-            if arr.ndim not in (3, 4):
-                raise ValueError("image must be (z, y, x) or (z, y, x, c)")
-            if arr.nbytes > _STREAM_MIN_BYTES and STREAM_UPLOAD:
-                # large host images (the reference's callers hand a memory-mapped image5d.npy, importer.py:794) go up
-                # z-slab by z-slab on a copy stream; detection starts on the blocks whose slabs have landed
-                t = None
-                self._upload = _SlabUpload(arr, dev)
-                self.tensor = self._upload.out
-            else:
-                t = torch.from_numpy(np.array(arr) if not arr.flags.writeable else np.ascontiguousarray(arr))
-        if np_dtype not in _NP_TO_MMX:
-            raise TypeError(f"unsupported voxel type {np_dtype}")
-        if t is not None and t.device.type == "cpu" and t.is_pinned() and STREAM_UPLOAD and \
-                t.numel() * t.element_size() > _STREAM_MIN_BYTES and t.is_contiguous():
-            self._upload = _SlabUpload(t, dev)          # (pinned source: DMA straight from it, no staging thread)
-            self.tensor = self._upload.out
-            t = None
-        if t is not None:
-            if t.ndim not in (3, 4):
-                raise ValueError("image must be (z, y, x) or (z, y, x, c)")
-            self.tensor = t.to(dev).contiguous()
-        elif self.tensor.ndim not in (3, 4):
-            raise ValueError("image must be (z, y, x) or (z, y, x, c)")
-        self.np_dtype = np_dtype
-        self.shape = tuple(self.tensor.shape)
-        self.n_channels = self.shape[3] if self.tensor.ndim == 4 else 1
-        self._f32 = None
-        self._scale = None
-        self._ranges = {}
-
-    @property
-    def multichannel(self) -> bool:
-        return self.tensor.ndim == 4
-
-    def stream_wait(self, z_hi: Optional[int] = None, streams=None) -> None:
-        """Order ``streams`` (default: the current one) after the upload of planes ``[0, z_hi)`` (all planes when
-        ``None``).  Nothing to do for a resident volume.  With a staging thread behind the upload the host waits until
-        that slab's copy has been QUEUED (its event recorded), never for the copy itself."""
-        up = self._upload
-        if up is None:
-            return
-        ev = up.event_for(self.shape[0] if z_hi is None else int(z_hi) - getattr(self, "z_off", 0))
-        for st in (streams or [torch.cuda.current_stream()]):
-            if st is not None:
-                st.wait_event(ev)
-        if up.all_queued() and up.events[-1].query():
-            self._upload = None             # everything has landed: later calls cost nothing
-
-    def wait_all(self) -> None:
-        """Host-side wait for the whole upload (readers of the voxels outside the batched detection)."""
-        up = self._upload
-        if up is not None:
-            up.event_for(self.shape[0]).synchronize()
-            self._upload = None
-
-    def value_scale(self) -> float:
-        """Magnitude of the image values after ``img_as_float`` (1 for integer images)."""
-        if self._scale is None:
-            if self.np_dtype.kind == "f":
-                self.wait_all()
-                m = float(self.tensor.abs().max().item()) if self.tensor.numel() else 1.0
-                self._scale = max(1.0, m)
-            else:
-                self._scale = 1.0
-        return self._scale
-
-    def value_range(self, channel: int = 0) -> Tuple[float, float]:
-        """``(min, max)`` of one channel's voxels after ``img_as_float`` (``(0, 1)`` for integer images)."""
-        if self.np_dtype.kind != "f":
-            return 0.0, 1.0
-        key = int(channel) if self.multichannel else 0
-        if key not in self._ranges:
-            self.wait_all()
-            t = self.tensor[..., key] if self.multichannel else self.tensor
-            if t.numel() == 0:
-                self._ranges[key] = (0.0, 1.0)
-            else:
-                lo, hi = torch.aminmax(t)
-                self._ranges[key] = (float(lo.item()), float(hi.item()))
-        return self._ranges[key]
-
-    def _strides(self, t) -> Tuple[int, int, int]:
-        st = t.stride()
-        return st[0], st[1], st[2]
-
-    def view(self, channel: int, for_f32_passes: bool) -> nat.Volume:
-        t = self.tensor
-        if for_f32_passes and self.np_dtype == np.float64:
-            if self._f32 is None:
-                self.wait_all()
-                self._f32 = t.to(torch.float32)
-            t = self._f32
-            code = nat.MMX_F32
-        else:
-            code = _NP_TO_MMX[self.np_dtype]
-        sz, sy, sx = self._strides(t)
-        ptr = int(t.data_ptr()) + (int(channel) if self.multichannel else 0) * t.element_size()
-        return nat.Volume(ptr, code, 0, int(sz), int(sy), int(sx))
-
-
-#: host images above this size go to the device z-slab by z-slab on a copy stream (`_SlabUpload`); 0 / False keeps
-#: the one synchronous copy (tests compare the two)
-_STREAM_MIN_BYTES = 64 << 20
-_STREAM_CHUNK_BYTES = 128 << 20
-STREAM_UPLOAD = True
-#: threads that fill a pinned staging buffer from a pageable / memory-mapped source (one memcpy stream reads ~10 GB/s,
-#: the link takes 57)
-_STAGE_THREADS = 4
-_UPLOAD_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
-_STAGING: Dict[Tuple[str, int], list] = {}          # (dtype, elements) -> free pairs of pinned staging buffers
-import threading as _threading          # noqa: E402
-_STAGING_LOCK = _threading.Lock()
-
-
-class _SlabUpload:
-    """A host ``(z, y, x[, c])`` image on its way to the device, z-slab by z-slab, on a stream of its own: one event
-    per slab, so that the detection of the blocks a slab completes can start while the rest is still in flight (blocks
-    are consumed in z-major order).  A pinned source is read by the DMA engine directly -- every copy is queued at once;
-    a pageable or memory-mapped one goes through two pinned staging buffers filled by a few host threads."""
-
-    def __init__(self, src, dev):
-        import threading
-        if isinstance(src, torch.Tensor):
-            shape, tdtype, itemsize = tuple(src.shape), src.dtype, src.element_size()
-        else:
-            shape, tdtype, itemsize = tuple(src.shape), getattr(torch, str(src.dtype)), src.dtype.itemsize
-        self.out = torch.empty(shape, dtype=tdtype, device=dev)
-        self.dev = dev
-        self.nz = shape[0]
-        plane = max(1, int(np.prod(shape[1:])) * itemsize)
-        self.slab = max(1, min(self.nz, _STREAM_CHUNK_BYTES // plane))
-        self.bounds: List[int] = []          # z end of every queued slab
-        self.events: List = []
-        self.n_slabs = -(-self.nz // self.slab) if self.nz else 0
-        self.cv = threading.Condition()
-        self.error: Optional[BaseException] = None
-        # ONE copy stream per device for every upload: streams are dealt to the hardware queues round-robin as they are
-        # made, so a stream per volume would sooner or later share a queue with a kernel stream (magellanmapper_amd/__init__)
-        self.stream = _UPLOAD_STREAMS.get(str(dev))
-        if self.stream is None:
-            self.stream = _UPLOAD_STREAMS[str(dev)] = torch.cuda.Stream(dev)
-        self.stream.wait_stream(torch.cuda.current_stream(dev))        # (the allocation above)
-        if self.nz == 0:
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-            self.bounds.append(0)
-            self.events.append(ev)
-        elif isinstance(src, torch.Tensor) and src.is_pinned():
-            with torch.cuda.stream(self.stream):
-                for z0 in range(0, self.nz, self.slab):
-                    z1 = min(z0 + self.slab, self.nz)
-                    self.out[z0:z1].copy_(src[z0:z1], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    self.bounds.append(z1)
-                    self.events.append(ev)
-            self._keep = src                       # (the source must outlive the copies)
-        else:
-            arr = src.numpy() if isinstance(src, torch.Tensor) else src
-            self.thread = threading.Thread(target=self._stage, args=(arr, tdtype), daemon=True)
-            self.thread.start()
-
-    def all_queued(self) -> bool:
-        return len(self.events) >= max(1, self.n_slabs)
-
-    def _stage(self, arr, tdtype):
-        from concurrent.futures import ThreadPoolExecutor
-        try:
-            torch.cuda.set_device(self.dev)
-            shape1 = (self.slab,) + tuple(arr.shape[1:])
-            key = (str(tdtype), int(np.prod(shape1)))
-            # (pinning 128 MiB takes tens of ms: a pair of buffers is kept for the next volume; two uploads at once --
-            #  tile k + 1 behind tile k -- each take their own pair)
-            with _STAGING_LOCK:
-                free = _STAGING.setdefault(key, [])
-                stage = free.pop() if free else None
-            if stage is None:
-                stage = [torch.empty(key[1], dtype=tdtype).pin_memory() for _ in range(2)]
-            done = [None, None]
-            with ThreadPoolExecutor(_STAGE_THREADS) as pool:
-                for k, z0 in enumerate(range(0, self.nz, self.slab)):
-                    z1 = min(z0 + self.slab, self.nz)
-                    buf = stage[k & 1][:(z1 - z0) * int(np.prod(arr.shape[1:]))].view((z1 - z0,) + tuple(arr.shape[1:]))
-                    if done[k & 1] is not None:
-                        done[k & 1].synchronize()          # the DMA that last used this buffer
-                    host = buf.numpy()
-                    cuts = np.linspace(0, z1 - z0, min(_STAGE_THREADS, z1 - z0) + 1).astype(int)
-                    list(pool.map(lambda ab: np.copyto(host[ab[0]:ab[1]], arr[z0 + ab[0]:z0 + ab[1]]),
-                                  zip(cuts[:-1], cuts[1:])))
-                    with torch.cuda.stream(self.stream):
-                        self.out[z0:z1].copy_(buf, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                    done[k & 1] = ev
-                    with self.cv:
-                        self.bounds.append(z1)
-                        self.events.append(ev)
-                        self.cv.notify_all()
-            for ev in done:
-                if ev is not None:
-                    ev.synchronize()               # (the buffers go back only when the DMA has read them)
-            with _STAGING_LOCK:
-                if len(_STAGING) > 4:
-                    _STAGING.clear()
-                if len(_STAGING.setdefault(key, [])) < 2:
-                    _STAGING[key].append(stage)
-        except BaseException as exc:               # (reported by whoever waits for a slab)
-            with self.cv:
-                self.error = exc
-                self.cv.notify_all()
-
-    def event_for(self, z_hi: int):
-        """The event after which planes ``[0, z_hi)`` are on the device (waits until its copy has been queued)."""
-        import bisect
-        z_hi = max(0, min(int(z_hi), self.nz))
-        with self.cv:
-            while True:
-                if self.error is not None:
-                    raise nat.MmxError(f"upload of the image failed: {self.error!r}") from self.error
-                i = bisect.bisect_left(self.bounds, z_hi)
-                if i < len(self.events):
-                    return self.events[i]
-                if self.all_queued():
-                    return self.events[-1]
-                self.cv.wait(0.5)
-
-
-def _img_as_float_host(arr: np.ndarray) -> np.ndarray:
-    """``skimage.util.img_as_float`` for the dtypes the device path does not read natively
-    (skimage/util/dtype.py:310-328)."""
-    kind = arr.dtype.kind
-    if kind == "b":
-        return arr.astype(np.float64)
-    if kind == "u":
-        return np.multiply(arr, 1.0 / np.iinfo(arr.dtype).max, dtype=np.float64)
-    if kind == "i":
-        info = np.iinfo(arr.dtype)
-        out = np.add(arr, 0.5, dtype=np.float64)
-        out *= 2 / (float(info.max) - float(info.min))
-        return out
-    if kind == "f":
-        return arr.astype(np.float32 if arr.dtype.itemsize < 4 else arr.dtype)
-    raise TypeError(f"cannot use {arr.dtype} as an image")
+from .volume import (DeviceVolume, _SlabUpload, _img_as_float_host, _require_gpu, _stream_ptr,   # noqa: F401,E402
+                     _NP_TO_MMX, _TORCH_DTYPES)
+from .buffers import (_Buffers, _NativeEvent, _UploadRing, _buffers_for, _stream_wait, _to_device_bytes,   # noqa: F401,E402
+                      release_buffers, to_device, _PREFIX_ENTRIES)
+from .host_resolve import (OVERLAP_BAND, PeakBatch, VERIFIED_SCIPY, _BandTooNarrow, _apply_pairs,   # noqa: F401,E402
+                           _check_f32_error, _exact_overlap, _prune_batch, _prune_batch_native,
+                           _reference_pair_order, _resolve_peaks, _resolve_peaks_native)
 
 
 @dataclass
@@ -598,131 +307,6 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     return batches
 
 
-class _NativeEvent:
-    """A HIP event the library records (``mmx_detect_batch``: ``ev_done`` / ``ev_work_read``); what this host needs of
-    ``torch.cuda.Event``: ``synchronize`` and being waited for by a stream (:func:`_stream_wait`)."""
-    __slots__ = ("handle",)
-
-    def __init__(self):
-        h = ctypes.c_void_p()
-        nat.check(nat.lib().mmx_event_create(ctypes.byref(h)), "mmx_event_create")
-        self.handle = h.value
-
-    def synchronize(self) -> None:
-        nat.check(nat.lib().mmx_event_synchronize(self.handle), "mmx_event_synchronize")
-
-    def __del__(self):
-        try:
-            if self.handle:
-                nat.lib().mmx_event_destroy(self.handle)
-        except Exception:       # (interpreter shutdown)
-            pass
-
-
-def _stream_wait(stream, event) -> None:
-    """``stream.wait_event(event)`` for torch events and for the library's own."""
-    if isinstance(event, _NativeEvent):
-        nat.check(nat.lib().mmx_stream_wait_event(stream.cuda_stream, event.handle), "mmx_stream_wait_event")
-    else:
-        stream.wait_event(event)
-
-
-class _Buffers:
-    """Device scratch that is reused across the batches of one call.
-
-    ``main`` is the caller's stream: the float32 passes, the NMS and the bulk re-score of
-    batch k are enqueued there back to back.  ``side`` is a high-priority stream for the
-    small follow-up work of batch k-1 (copying its candidates out, re-scoring the neighbours
-    of contested candidates, the overlap-pair search), which therefore overlaps the heavy
-    kernels of batch k instead of queueing behind them.
-    """
-
-    def __init__(self, dev):
-        self.dev = dev
-        self.ws = None
-        self.ws2 = None
-        self.ws_free = [None, None]        # events: the last reader of each workspace (the NMS of a batch) is done
-        self.cands = []
-        self.counts = []
-        self.host_counts = []
-        self.host_tabs = []
-        self.side = torch.cuda.Stream(device=dev, priority=-1)
-        # per-block preprocessing (float64 vector arithmetic) of batch k + 1 runs here, beside the LoG kernels of
-        # batch k (bound by memory requests) on the caller's stream
-        self.pre_stream = torch.cuda.Stream(device=dev)
-        self.rescore_stream = torch.cuda.Stream(device=dev, priority=0)
-        self.pack_stream = torch.cuda.Stream(device=dev)
-        self.native_events = []            # per candidate-table slot: (workspace read, batch done)
-        self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
-        self.graph_stream = None           # where they run when the caller is on the (uncapturable) default stream
-        self.plans = {}                    # batch plans + uploaded block tables of recent (block lists, volume layout)
-        self.plan_lists = {}               # (id(origins), id(shapes)) -> (the lists, their content key)
-        self.slots(2)
-
-    def slots(self, n: int):
-        """At least ``n`` candidate-table slots (one per batch in flight)."""
-        while len(self.cands) < n:
-            self.cands.append(None)
-            # [0]: entries in the table (candidates + probes, counts past the capacity); [1]: candidates among them
-            self.counts.append(torch.zeros(2, dtype=torch.int32, device=self.dev))
-            self.host_counts.append(torch.zeros(2, dtype=torch.int32).pin_memory())
-            self.host_tabs.append(None)
-            self.native_events.append(None)
-
-    def workspace(self, n_floats: int, which: int = 0):
-        """Workspace ``which`` (0: the only one of most paths; 1: the second of the two that batches of a raw volume
-        alternate between, so that the NMS and re-score of one batch run beside the LoG kernels of the next)."""
-        if which == 0:
-            if self.ws is None or self.ws.numel() < n_floats:
-                self.ws = None
-                self.ws = torch.empty(n_floats, dtype=torch.float32, device=self.dev)
-            return self.ws
-        if self.ws2 is None or self.ws2.numel() < n_floats:
-            self.ws2 = None
-            self.ws2 = torch.empty(n_floats, dtype=torch.float32, device=self.dev)
-        return self.ws2
-
-    def events(self, which: int):
-        """``(workspace read, batch done)`` events of slot ``which`` (made once, recorded again by every batch that takes
-        the slot -- which happens only after the previous holder has been waited for)."""
-        if self.native_events[which] is None:
-            self.native_events[which] = (_NativeEvent(), _NativeEvent())
-        return self.native_events[which]
-
-    def drop_graphs(self) -> None:
-        for hit in self.graphs.values():
-            if hit and hit != "plain":
-                nat.lib().mmx_graph_destroy(hit[0])
-        self.graphs = {}
-
-    def host_table(self, which: int):
-        """Pinned staging for the first ``_PREFIX_ENTRIES`` entries of slot ``which``'s candidate table."""
-        if self.host_tabs[which] is None:
-            self.host_tabs[which] = torch.empty(_PREFIX_ENTRIES * nat.CAND_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-        return self.host_tabs[which]
-
-    def cand_table(self, which: int, cap: int):
-        need = cap * nat.CAND_DTYPE.itemsize
-        if self.cands[which] is None or self.cands[which].numel() < need:
-            self.cands[which] = None
-            self.cands[which] = torch.empty(need, dtype=torch.uint8, device=self.dev)
-        return self.cands[which]
-
-
-_BUFFERS: Dict[str, _Buffers] = {}
-
-
-def _buffers_for(dev) -> _Buffers:
-    """The per-device scratch, created once: the side stream, the pinned count words and the workspace
-    cost ~25 ms to set up (pinned allocations, stream creation), a tenth of a whole benchmark volume."""
-    key = str(dev)
-    if key not in _BUFFERS:
-        if os.environ.get("MMX_SELF_TEST", "1") != "0":
-            self_test(dev)
-        _BUFFERS[key] = _Buffers(dev)
-    return _BUFFERS[key]
-
-
 _SELF_TESTED = set()
 
 
@@ -772,66 +356,6 @@ def self_test(dev) -> None:
                                        f"{int(space.radii[0])}, {np.dtype(dtype).name} voxels: off by {err:.3g}); "
                                        "this build of libmmx_hip.so must not be used")
     _SELF_TESTED.add(key)
-
-
-def release_buffers() -> None:
-    """Drop the cached device scratch (workspace, candidate tables, captured graphs) of every device."""
-    for b in _BUFFERS.values():
-        b.drop_graphs()
-    _BUFFERS.clear()
-    from . import preprocess
-    preprocess.release_retained()
-
-
-class _UploadRing:
-    """Small host -> device uploads (block tables, quantile classes, row offsets) that do not stall the host: a
-    pageable ``tensor.to(device)`` waits for everything queued on the stream before it -- with kernels of a few
-    milliseconds queued that is a few milliseconds per table, a dozen times per batch on the preprocessing and
-    co-localisation paths, and the GPU then idles while the host catches up.  Here the bytes go through a ring of
-    pinned slots and an asynchronous copy on the current stream; a slot is reused only after its copy has completed."""
-    SLOTS, SLOT_BYTES = 64, 1 << 17
-
-    def __init__(self):
-        self.stage = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
-        self.host = self.stage.numpy()
-        self.busy = [None] * self.SLOTS
-        self.at = 0
-
-    def put(self, raw: np.ndarray, dev) -> "torch.Tensor":
-        n = raw.size
-        k = self.at
-        self.at = (k + 1) % self.SLOTS
-        if self.busy[k] is not None:
-            self.busy[k].synchronize()
-        lo = k * self.SLOT_BYTES
-        self.host[lo:lo + n] = raw
-        out = torch.empty(n, dtype=torch.uint8, device=dev)
-        out.copy_(self.stage[lo:lo + n], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.busy[k] = ev
-        return out
-
-
-_UPLOAD: Optional[_UploadRing] = None
-
-
-def _to_device_bytes(arr: np.ndarray, dev) -> "torch.Tensor":
-    """``arr``'s bytes as a uint8 device tensor, uploaded on the current stream."""
-    global _UPLOAD
-    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
-    if 0 < raw.size <= _UploadRing.SLOT_BYTES and getattr(dev, "type", str(dev)[:4]) == "cuda":
-        if _UPLOAD is None:
-            _UPLOAD = _UploadRing()
-        return _UPLOAD.put(raw, dev)
-    return torch.from_numpy(raw).to(dev)
-
-
-def to_device(arr: np.ndarray, dev) -> "torch.Tensor":
-    """``torch.from_numpy(arr).to(dev)`` without the stall of a pageable copy (small arrays: :class:`_UploadRing`)."""
-    arr = np.ascontiguousarray(arr)
-    t = _to_device_bytes(arr, dev)
-    return t.view(getattr(torch, str(arr.dtype))).view(arr.shape) if arr.size else torch.from_numpy(arr).to(dev)
 
 
 def log_cube_blocks(dvol: DeviceVolume, channel: int, origins, shapes, space: ScaleSpace,
@@ -1417,400 +941,6 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
     redo["batch"] = job.get("batch")
     redo["retries"] = job.get("retries", 0) + 1
     return _finish_detect(redo, dvol, space, thr, wider, bufs, d_w0, d_w2, stats)
-
-
-class _BandTooNarrow(Exception):
-    """The float32 values of a batch deviate from the exact ones by more than a quarter of the nomination
-    band: the batch is nominated again with a wider band (``_finish_detect``)."""
-
-    def __init__(self, err: float):
-        super().__init__(err)
-        self.err = err
-
-
-def _check_f32_error(v32, v64, eps, stats):
-    """Every candidate the reference would find is nominated as long as |float32 - float64| < eps / 4 (a true
-    maximum then stays within eps of its float32 neighbours and of the threshold).  A larger deviation -- a float
-    image with a huge dynamic range, say -- is not fatal: the caller widens the band and nominates again."""
-    if len(v32):
-        err = float(np.max(np.abs(v32.astype(np.float64) - v64)))
-        if not np.isfinite(err):
-            raise nat.MmxError("non-finite LoG values: the image holds NaN or infinite voxels")
-        if not err < 0.25 * eps:
-            raise _BandTooNarrow(err)
-        stats.max_f32_error = max(stats.max_f32_error, err)
-
-
-def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_w0, d_w2,
-                   space, store_f32, stats, eps, exact):
-    """Exact peak membership + the reference's ordering, per block.
-
-    What the reference's float64 values decide: (i) whether a candidate within ``eps`` of the threshold or of
-    a neighbour is a peak -- the NMS kernel flags those CONTESTED; (ii) the order of the peaks of a block
-    (``argsort(-value)``, peak.py:17), which only two candidates whose float32 values lie within ``eps`` of
-    each other can swap.  Those candidates (and the neighbours of the contested ones) are re-scored in
-    float64 here; every other candidate keeps its float32 value as a stand-in, which leaves every comparison
-    the reference makes unchanged (|float32 - float64| < eps / 4 is checked on all re-scored values).
-    ``exact``: all candidates were re-scored by ``_enqueue_detect`` already.
-    """
-    L = nat.lib()
-    dev = dvol.tensor.device
-    nb = len(blocks)
-    keep = np.ones(len(cands), dtype=bool)
-    contested = np.nonzero(cands["flags"] & nat.MMX_CAND_CONTESTED)[0]
-    v32 = cands["v"].astype(np.float64)
-    if exact:
-        _check_f32_error(cands["v"], cands["v64"], eps, stats)      # (raises before any counter moves)
-        selves = np.zeros(0, dtype=np.int64)
-    stats.n_contested += len(contested)
-    if exact:
-        pass
-    else:
-        # candidates of one block whose float32 values are within eps of each other: their order is open
-        cslot = cands["slot"].astype(np.int64)
-        o = np.lexsort((-v32, cslot))
-        close = (cslot[o][1:] == cslot[o][:-1]) & ((v32[o][:-1] - v32[o][1:]) < eps)
-        need = np.zeros(len(cands), dtype=bool)
-        need[o[1:][close]] = True
-        need[o[:-1][close]] = True
-        need[contested] = True
-        selves = np.nonzero(need)[0]
-        stats.n_rescored += len(selves)
-        cands = cands.copy() if not cands.flags.writeable else cands
-        cands["v64"] = v32                      # stand-ins; the re-scored ones are overwritten below
-    if len(contested) or len(selves):
-        # exact values of the (up to) 80 neighbours of every contested candidate
-        offs = np.array([(ds, dz, dy, dx) for ds in (-1, 0, 1) for dz in (-1, 0, 1)
-                         for dy in (-1, 0, 1) for dx in (-1, 0, 1)
-                         if (ds, dz, dy, dx) != (0, 0, 0, 0)], dtype=np.int32)
-        c = cands[contested]
-        dims = np.array([shapes[i] for i in c["slot"]], dtype=np.int32).reshape(-1, 3)      # (m, 3)
-        ss = c["s"][:, None] + offs[None, :, 0]
-        zz = c["z"][:, None] + offs[None, :, 1]
-        yy = c["y"][:, None] + offs[None, :, 2]
-        xx = c["x"][:, None] + offs[None, :, 3]
-        inside = ((ss >= 0) & (ss < ns) & (zz >= 0) & (zz < dims[:, 0:1]) &
-                  (yy >= 0) & (yy < dims[:, 1:2]) & (xx >= 0) & (xx < dims[:, 2:3]))
-        probe = inside
-        if len(c) and np.all(c["flags"] & nat.MMX_CAND_BAND):
-            # the sparse NMS kernel recorded which neighbours have float32 values within eps below the candidate's
-            # (or above it): with |float32 - float64| < eps / 4 every other neighbour is below it in float64 too
-            bits = np.arange(64, dtype=np.uint64)
-            in_band = np.concatenate([(c["band"][:, None] >> bits[None, :]) & np.uint64(1),
-                                      ((c["flags"][:, None] >> np.arange(16, 32, dtype=np.uint32)[None, :]) & 1)
-                                      .astype(np.uint64)], axis=1).astype(bool)
-            probe = inside & in_band
-        owner, which = np.nonzero(probe)
-        n_nb = len(owner)
-        probes = np.zeros(n_nb + len(selves), dtype=nat.CAND_DTYPE)
-        probes["slot"][:n_nb] = c["slot"][owner]
-        probes["s"][:n_nb] = ss[owner, which]
-        probes["z"][:n_nb] = zz[owner, which]
-        probes["y"][:n_nb] = yy[owner, which]
-        probes["x"][:n_nb] = xx[owner, which]
-        for f in ("slot", "s", "z", "y", "x"):
-            probes[f][n_nb:] = cands[f][selves]
-        probes["v64"] = np.nan
-        stats.n_probes += n_nb
-        if len(probes):
-            d_probes = _to_device_bytes(probes, dev)
-            nat.check(L.mmx_rescore_f64(
-                ctypes.byref(vol_exact), d_blocks.data_ptr(), nb, d_probes.data_ptr(), len(probes),
-                None, d_w0.data_ptr(), d_w2.data_ptr(), nat.as_int32_ptr(space.radii),
-                nat.as_double_ptr(space.norms), ns, store_f32, _stream_ptr()), "mmx_rescore_f64")
-            vals = d_probes.cpu().numpy().view(nat.CAND_DTYPE)["v64"]
-        else:
-            vals = np.zeros(0)
-        if len(selves):
-            _check_f32_error(cands["v"][selves], vals[n_nb:], eps, stats)
-            cands["v64"][selves] = vals[n_nb:]
-            vals = vals[:n_nb]
-        nbr_max = np.full(len(contested), -np.inf)
-        np.maximum.at(nbr_max, owner, vals)
-        border = ~inside.all(axis=1)
-        nbr_max[border] = np.maximum(nbr_max[border], 0.0)   # mode='constant', cval=0
-        keep[contested] = cands["v64"][contested] >= nbr_max
-    keep &= cands["v64"] > thr
-    sel = np.nonzero(keep)[0]
-    # plain contiguous columns from here on (record-array field access walks 48-byte strides): the five leading
-    # int32 fields (slot, s, z, y, x) in one gather
-    ints = np.ascontiguousarray(cands).view(np.int32).reshape(-1, nat.CAND_DTYPE.itemsize // 4)[sel, :5].astype(np.int64)
-    slot, cs, cz, cy, cx = (ints[:, j] for j in range(5))
-    v64 = cands["v64"][sel]
-    # group by block; inside a block the C order of np.nonzero on the (z, y, x, sigma) cube: one sort on one key
-    # (a voxel of a block appears once, so the key is unique)
-    dims = np.asarray(shapes, dtype=np.int64)
-    lin = ((cz * dims[slot, 1] + cy) * dims[slot, 2] + cx) * ns + cs
-    span = int(np.max(dims[:, 0] * dims[:, 1] * dims[:, 2])) * ns
-    order = np.argsort(slot * span + lin, kind="stable") if span * len(shapes) < (1 << 62) else np.lexsort((lin, slot))
-    slot = slot[order]
-    coords_all = ints[order][:, [2, 3, 4, 1]]
-    vals_all = v64[order]
-    bounds = np.searchsorted(slot, np.arange(len(shapes) + 1))
-    out = []
-    for i in range(len(shapes)):
-        a, b = bounds[i], bounds[i + 1]
-        if a == b:
-            out.append((np.zeros((0, 4), dtype=np.int64), np.zeros(0)))
-            continue
-        cube_size = int(shapes[i][0]) * int(shapes[i][1]) * int(shapes[i][2]) * ns
-        if b - a == cube_size and cube_size > 1:
-            # every voxel equals its 3^4 maximum (a constant cube): "no peak for a trivial image"
-            # (skimage peak.py:41-43)
-            out.append((np.zeros((0, 4), dtype=np.int64), np.zeros(0)))
-            continue
-        vals = vals_all[a:b].copy()
-        rank = np.argsort(-vals)          # the reference's call on the reference's array (peak.py:17)
-        out.append((coords_all[a:b][rank], vals[rank]))
-        stats.n_peaks += b - a
-    return out
-
-
-class PeakBatch:
-    """The raw peaks of one batch as the native host code leaves them: ``coords[offsets[b]:offsets[b + 1]]`` are
-    block ``b``'s ``[z, y, x, sigma index]`` rows (int32) by descending float64 response ``vals`` -- the
-    reference's order (``argsort(-values)`` of the ``np.nonzero`` rows, peak.py:17).  After the overlap prune
-    ``alive`` marks the surviving rows and ``sigmas`` maps the last column to the blob's sigma."""
-    __slots__ = ("coords", "vals", "offsets", "alive", "sigmas")
-
-    def __init__(self, coords, vals, offsets):
-        self.coords, self.vals, self.offsets = coords, vals, offsets
-        self.alive = None
-        self.sigmas = None
-
-    def __len__(self):
-        return len(self.offsets) - 1
-
-    def block(self, b: int) -> Tuple[np.ndarray, np.ndarray]:
-        """``(coords int64 (n, 4), values float64 (n,))`` of block ``b``."""
-        lo, hi = self.offsets[b], self.offsets[b + 1]
-        return self.coords[lo:hi].astype(np.int64), self.vals[lo:hi]
-
-    def blobs(self, b: int) -> np.ndarray:
-        """Block ``b``'s pruned ``[z, y, x, sigma]`` rows (float64), ``np.empty((0, 3))`` without peaks."""
-        lo, hi = self.offsets[b], self.offsets[b + 1]
-        if lo == hi:
-            return np.empty((0, 3))
-        rows = self.coords[lo:hi][self.alive[lo:hi].view(bool)]
-        out = rows.astype(np.float64)
-        out[:, 3] = self.sigmas[rows[:, 3]]
-        return out
-
-
-def _resolve_peaks_native(cands, n_cands: int, blocks, ns: int, thr: float, stats: BatchStats, eps: float) -> PeakBatch:
-    """``mmx_host_resolve_peaks``: the decisions of ``_resolve_peaks`` for a table whose candidates AND probes
-    (``mmx_expand_probes``) were re-scored on the device; blocks whose peaks tie take their order from NumPy."""
-    L = nat.lib()
-    nb = len(blocks)
-    n_total = len(cands)
-    nz_coords = np.empty((max(n_cands, 1), 4), dtype=np.int32)
-    nz_vals = np.empty(max(n_cands, 1))
-    coords = np.empty_like(nz_coords)
-    vals = np.empty_like(nz_vals)
-    offsets = np.zeros(nb + 1, dtype=np.int32)
-    ties = np.zeros(nb, dtype=np.uint8)
-    st = np.zeros(4)
-    nat.check(L.mmx_host_resolve_peaks(cands.ctypes.data if n_total else None, n_cands, n_total, blocks.ctypes.data,
-                                       nb, ns, float(thr), nz_coords.ctypes.data, nz_vals.ctypes.data,
-                                       coords.ctypes.data, vals.ctypes.data, offsets.ctypes.data, ties.ctypes.data,
-                                       st.ctypes.data), "mmx_host_resolve_peaks")
-    err = float(st[2])
-    if n_cands:
-        if not np.isfinite(err):
-            raise nat.MmxError("non-finite LoG values: the image holds NaN or infinite voxels")
-        if not err < 0.25 * eps:
-            raise _BandTooNarrow(err)                      # (before any counter moves)
-        stats.max_f32_error = max(stats.max_f32_error, err)
-    stats.n_contested += int(st[0])
-    stats.n_probes += n_total - n_cands
-    stats.n_peaks += int(st[1])
-    for b in np.nonzero(ties)[0]:
-        # equal float64 responses inside one block: the reference's order is whatever np.argsort makes of them
-        lo, hi = offsets[b], offsets[b + 1]
-        rank = np.argsort(-nz_vals[lo:hi])                 # the reference's call on the reference's array (peak.py:17)
-        coords[lo:hi] = nz_coords[lo:hi][rank]
-        vals[lo:hi] = nz_vals[lo:hi][rank]
-    n = int(offsets[-1])
-    return PeakBatch(coords[:n], vals[:n], offsets)
-
-
-# ------------------------------------------------------------------------------ A5
-def _exact_overlap(b1: np.ndarray, b2: np.ndarray) -> float:
-    """``_blob_overlap`` with the reference's exact libm calls, for the knife-edge pairs
-    (skimage/feature/blob.py:84-143, 3-D branch :55-81)."""
-    root = math.sqrt(3)
-    if b1[-1] == b2[-1] == 0:
-        return 0.0
-    if b1[-1] > b2[-1]:
-        ms, r1, r2 = b1[-1:], 1, b2[-1] / b1[-1]
-    else:
-        ms, r2, r1 = b2[-1:], 1, b1[-1] / b2[-1]
-    p1 = b1[:3] / (ms * root)
-    p2 = b2[:3] / (ms * root)
-    d = np.sqrt(np.sum((p2 - p1) ** 2))
-    if d > r1 + r2:
-        return 0.0
-    if d <= abs(r1 - r2):
-        return 1.0
-    vol = (math.pi / (12 * d) * (r1 + r2 - d) ** 2 *
-           (d ** 2 + 2 * d * (r1 + r2) - 3 * (r1 ** 2 + r2 ** 2) + 6 * r1 * r2))
-    return vol / (4. / 3 * math.pi * min(r1, r2) ** 3)
-
-
-#: SciPy releases whose ``cKDTree.query_pairs`` + CPython set order are known to reproduce the real ``_prune_blobs`` on
-#: the chain-heavy fixture (tests/golden/overlap_prune.npz: made with 1.7.1; 1.15.3 is the reference's pin and this
-#: image's).  Any other release is used all the same -- it is the reference's own call -- with one warning.
-VERIFIED_SCIPY = ("1.7.1", "1.15.3")
-_warned_scipy = False
-
-
-def _reference_pair_order(lm: np.ndarray) -> np.ndarray:
-    """The visiting order ``_prune_blobs`` uses (blob.py:169-172): iteration order of the
-    Python ``set`` returned by SciPy's ``cKDTree.query_pairs``.  It is implementation
-    defined, so when the outcome depends on it the only faithful source is the same call."""
-    global _warned_scipy
-    if not _warned_scipy:
-        _warned_scipy = True
-        import scipy
-        if scipy.__version__ not in VERIFIED_SCIPY:
-            import warnings
-            warnings.warn(f"SciPy {scipy.__version__}: the pair order of cKDTree.query_pairs decides blocks with "
-                          f"pruning chains and was verified against the real _prune_blobs for {VERIFIED_SCIPY} only "
-                          "(tests/test_host_logic.py::test_overlap_prune_reproduces_scikit_image_on_every_fixture)")
-    sigma = lm[:, -1].max()
-    distance = 2 * sigma * math.sqrt(lm.shape[1] - 1)
-    tree = _scipy_spatial.cKDTree(lm[:, :-1])
-    return np.array(list(tree.query_pairs(distance)))
-
-
-def _apply_pairs(allb, sig, offsets, pairs, frac, overlap: float, stats: BatchStats, only_blocks=None) -> None:
-    """The sequential rule of ``_prune_blobs`` (blob.py:172-186) on the over-limit pairs: ``sig`` of the losers is
-    zeroed in place.  ``pairs`` are global rows (i < j) in any order, ``frac`` their overlap fractions; fractions
-    within ``OVERLAP_BAND`` of the limit are re-evaluated with the reference's exact libm calls first.
-    ``only_blocks``: leave every other block alone (its outcome is already known)."""
-    frac = frac.copy()
-    for k in np.nonzero(np.abs(frac - overlap) <= OVERLAP_BAND)[0]:   # knife edge: exact libm
-        frac[k] = _exact_overlap(allb[pairs[k, 0]], allb[pairs[k, 1]])
-    act = pairs[frac > overlap]
-    if not len(act):
-        return
-    i, j = act[:, 0], act[:, 1]
-    block_of_pair = np.searchsorted(offsets, i, side="right") - 1
-    if only_blocks is not None:
-        sel = np.isin(block_of_pair, only_blocks)
-        act, i, j, block_of_pair = act[sel], i[sel], j[sel], block_of_pair[sel]
-        if not len(act):
-            return
-    first_bigger = sig[i] > sig[j]
-    loser = np.where(first_bigger, j, i)
-    winner = np.where(first_bigger, i, j)
-    chained = np.intersect1d(loser, winner)
-    chain_blocks = np.unique(np.searchsorted(offsets, chained, side="right") - 1)
-    simple = ~np.isin(block_of_pair, chain_blocks)
-    sig[loser[simple]] = 0
-    for b in chain_blocks:
-        stats.n_order_fallbacks += 1
-        lo, hi = offsets[b], offsets[b + 1]
-        mine = block_of_pair == b
-        active = {(int(a_) - lo, int(b_) - lo) for a_, b_ in act[mine]}
-        bs = sig[lo:hi]
-        for a_, b_ in _reference_pair_order(allb[lo:hi]):
-            a_, b_ = int(a_), int(b_)
-            if (a_, b_) in active and bs[a_] > 0 and bs[b_] > 0:
-                if bs[a_] > bs[b_]:
-                    bs[b_] = 0
-                else:
-                    bs[a_] = 0
-
-
-def _prune_batch_native(pb: PeakBatch, space: ScaleSpace, overlap: float, stats: BatchStats) -> PeakBatch:
-    """``mmx_host_overlap_prune`` on the host's own peaks (no upload, no kernel, no wait): ``pb.alive`` per row.
-    Blocks whose outcome depends on the order scikit-image visits the pairs in, and batches with a fraction on the
-    knife edge, go through :func:`_apply_pairs` with the pairs the native search found."""
-    L = nat.lib()
-    nb = len(pb)
-    n = len(pb.coords)
-    pb.sigmas = np.ascontiguousarray(space.sigmas, dtype=np.float64)
-    pb.alive = np.ones(n, dtype=np.uint8)
-    if n == 0:
-        return pb
-    open_blocks = np.zeros(nb, dtype=np.uint8)
-    cap = max(1024, 4 * n)
-    n_pairs, n_knife = ctypes.c_int64(0), ctypes.c_int64(0)
-    while True:
-        pairs = np.empty((cap, 2), dtype=np.int32)
-        frac = np.empty(cap)
-        nat.check(L.mmx_host_overlap_prune(pb.coords.ctypes.data, pb.offsets.ctypes.data, nb, pb.sigmas.ctypes.data,
-                                           len(pb.sigmas), float(overlap), OVERLAP_BAND, pb.alive.ctypes.data,
-                                           open_blocks.ctypes.data, pairs.ctypes.data, frac.ctypes.data, cap,
-                                           ctypes.byref(n_pairs), ctypes.byref(n_knife)), "mmx_host_overlap_prune")
-        if n_pairs.value <= cap:
-            break
-        cap = n_pairs.value + 64
-    stats.n_overlap_pairs += n_pairs.value
-    todo = None if n_knife.value else np.nonzero(open_blocks)[0]
-    if todo is None or len(todo):
-        allb = pb.coords.astype(np.float64)
-        allb[:, 3] = pb.sigmas[pb.coords[:, 3]]
-        sig = allb[:, 3].copy()
-        if todo is not None:
-            sig[pb.alive == 0] = 0         # (the closed blocks' outcome stands)
-        _apply_pairs(allb, sig, pb.offsets, pairs[:n_pairs.value].astype(np.int64), frac[:n_pairs.value], overlap,
-                     stats, only_blocks=todo)
-        pb.alive = (sig > 0).astype(np.uint8)
-    stats.n_blobs += int(pb.alive.sum())
-    return pb
-
-
-def _prune_batch(peaks, space: ScaleSpace, overlap: float, dev, stats: BatchStats):
-    """Sphere-overlap prune of every block of the batch (skimage blob.py:146-187).
-
-    The device returns every pair whose overlap fraction exceeds the limit.  The reference
-    visits pairs one by one and zeroes the smaller sigma (first of the pair on ties); a dead
-    blob never kills another.  The outcome is independent of the visiting order unless some
-    blob loses one over-limit pair and wins another (a chain): only blocks with such a blob
-    take the reference's own order from ``cKDTree.query_pairs``.
-    """
-    L = nat.lib()
-    sizes = np.array([len(c) for c, _ in peaks], dtype=np.int32)
-    offsets = np.zeros(len(peaks) + 1, dtype=np.int32)
-    np.cumsum(sizes, out=offsets[1:])
-    total = int(offsets[-1])
-    if total == 0:
-        return [np.empty((0, 3)) for _ in peaks]
-    coords = np.concatenate([c for c, _ in peaks if len(c)])
-    allb = coords.astype(np.float64)
-    allb[:, 3] = space.sigmas[coords[:, 3]]
-    d_blobs = torch.from_numpy(allb).to(dev)
-    d_off = torch.from_numpy(offsets).to(dev)
-    cap = max(1024, 4 * total)
-    while True:
-        d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
-        d_frac = torch.empty(cap, dtype=torch.float64, device=dev)
-        d_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        nat.check(L.mmx_overlap_pairs(d_blobs.data_ptr(), d_off.data_ptr(), len(peaks), overlap,
-                                      OVERLAP_BAND, float(space.sigmas.max()), d_pairs.data_ptr(),
-                                      d_frac.data_ptr(), cap,
-                                      d_count.data_ptr(), _stream_ptr()), "mmx_overlap_pairs")
-        n = int(d_count.item()) & 0xFFFFFFFF
-        if n <= cap:
-            break
-        cap = n + 64
-    sig = allb[:, 3].copy()
-    stats.n_overlap_pairs += n
-    if n:
-        _apply_pairs(allb, sig, offsets, d_pairs[:n].cpu().numpy().astype(np.int64), d_frac[:n].cpu().numpy(),
-                     overlap, stats)
-    results = []
-    for b in range(len(peaks)):
-        lo, hi = offsets[b], offsets[b + 1]
-        if lo == hi:
-            results.append(np.empty((0, 3)))
-            continue
-        res = allb[lo:hi][sig[lo:hi] > 0]
-        results.append(res)
-        stats.n_blobs += len(res)
-    return results
 
 
 def blob_log(image, min_sigma=1, max_sigma=50, num_sigma=10, threshold=.2, overlap=.5):

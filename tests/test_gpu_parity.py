@@ -506,11 +506,11 @@ def test_detect_blobs_stack_from_the_on_disk_image(gpu, tmp_path, monkeypatch):
     detect_blobs_stack -> archive; equals detection on the in-memory array, and the metadata
     (resolutions, near_max) reaches the detection and the preprocessing."""
     import shutil
-    from magellanmapper_amd import blob_log as bl, config, detector, importer, stack_detect
+    from magellanmapper_amd import blob_log as bl, config, detector, importer, stack_detect, volume
     from oracle import magmap_oracle as mmo
     monkeypatch.chdir(tmp_path)
-    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 1 << 10)        # take the streamed-upload path
-    monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 40 << 10)     # ... in several chunks
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 1 << 10)    # take the streamed-upload path (slabs beside the detection)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 40 << 10)     # ... in several slabs
     for fn in ("sample_image5d.npy", "sample_meta.yml"):
         shutil.copy(os.path.join(GOLDEN, fn), tmp_path / fn)
     config.setup_roi_profiles(None)

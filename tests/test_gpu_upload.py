@@ -32,14 +32,14 @@ def test_streamed_upload_gives_the_resident_volumes_table(gpu, monkeypatch, tmp_
     """The same stack detected from a volume that is uploaded in one synchronous copy and from one that goes up in
     slabs of 9 planes while its first blocks are already being detected (raw and per-block preprocessing): identical
     tables, and the slab path was really taken."""
-    from magellanmapper_amd import blob_log as bl, config, synth
+    from magellanmapper_amd import blob_log as bl, config, synth, volume
     vol = synth.make_volume(17, (100, 72, 80), 60)
     try:
-        monkeypatch.setattr(bl, "STREAM_UPLOAD", False)
+        monkeypatch.setattr(volume, "STREAM_UPLOAD", False)
         want = _stack(vol, denoise)
-        monkeypatch.setattr(bl, "STREAM_UPLOAD", True)
-        monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
-        monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 9 * vol[0].nbytes)
+        monkeypatch.setattr(volume, "STREAM_UPLOAD", True)
+        monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+        monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 9 * vol[0].nbytes)
         made = []
         init = bl._SlabUpload.__init__
         monkeypatch.setattr(bl._SlabUpload, "__init__", lambda self, *a: (init(self, *a), made.append(self))[0])
@@ -62,10 +62,10 @@ def test_streamed_upload_gives_the_resident_volumes_table(gpu, monkeypatch, tmp_
 def test_pinned_source_is_copied_without_staging_and_partial_waits_work(gpu, monkeypatch):
     """A pinned tensor: every slab copy is queued at construction (no thread); `stream_wait(z)` orders a stream after the
     slabs below z only, `wait_all` after everything; the device copy equals the source."""
-    from magellanmapper_amd import blob_log as bl, synth
+    from magellanmapper_amd import blob_log as bl, synth, volume
     vol = synth.make_volume(3, (64, 48, 56), 10)
-    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
-    monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 8 * vol[0].nbytes)
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 8 * vol[0].nbytes)
     src = torch.from_numpy(vol.view(np.int16)).pin_memory() if not hasattr(torch, "uint16") else \
         torch.from_numpy(vol).pin_memory()
     dv = bl.DeviceVolume(src)
@@ -86,12 +86,12 @@ def test_pinned_source_is_copied_without_staging_and_partial_waits_work(gpu, mon
 
 def test_a_failing_source_is_reported_by_the_waiter(gpu, monkeypatch):
     """An exception in the staging thread surfaces where the detection waits for the slab (not as a hang)."""
-    from magellanmapper_amd import _native as nat, blob_log as bl
+    from magellanmapper_amd import _native as nat, blob_log as bl, volume
 
     class Bad(np.ndarray):
         def __getitem__(self, item):
             raise OSError("disk gone")
-    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
     src = np.zeros((8, 16, 16), dtype=np.uint16).view(Bad)
     dv = bl.DeviceVolume.__new__(bl.DeviceVolume)
     dv._upload = bl._SlabUpload(src, torch.device("cuda", 0))
@@ -104,10 +104,10 @@ def test_a_failing_source_is_reported_by_the_waiter(gpu, monkeypatch):
 def test_three_tiles_streamed_equal_the_oracle_per_tile(gpu, monkeypatch, tmp_path, denoise):
     """`stack_detect.detect_blobs_tiles`: three tiles of a stack as memory-mapped image5d files, tile k + 1 uploading
     (in slabs) while tile k is detected, device buffers reused -- every tile's table equals the oracle's for that tile."""
-    from magellanmapper_amd import blob_log as bl, config, stack_detect, synth
+    from magellanmapper_amd import blob_log as bl, config, stack_detect, synth, volume
     from oracle import magmap_oracle as mmo
-    monkeypatch.setattr(bl, "_STREAM_MIN_BYTES", 0)
-    monkeypatch.setattr(bl, "_STREAM_CHUNK_BYTES", 16 * 64 * 72 * 2)
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 16 * 64 * 72 * 2)
     config.setup_roi_profiles(None)
     config.roi_profile.update(dict(num_sigma=3, denoise_size=denoise, segment_size=40))
     config.resolutions = np.array([[1.0, 1.0, 1.0]])
