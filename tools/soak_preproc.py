@@ -7,7 +7,7 @@ against the oracle, bit for bit, on seeded random blocks, tile sizes and profile
 import argparse, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from magellanmapper_amd import config, preprocess, synth
+from magellanmapper_amd import _native as nat, config, preprocess, synth
 from oracle import preprocess_oracle as ppo
 
 ap = argparse.ArgumentParser()
@@ -46,12 +46,17 @@ for trial in range(a.trials):
     profs = [dict(p) for p in config.roi_profiles]
     nm = [float(rng.choice([-1.0, 5000.0, 30000.0]))] if vol.dtype.kind == "u" else [float(rng.choice([-1.0, 0.5, 2.0]))]
     want = ppo.preprocess_block(vol, dms, profs, nm)
+    # the kernel form of the LDS-resident tiles (integer voxels): one kernel per tile, the pipelined kernels whatever
+    # the tile size, or the library's choice; runs of 1 .. 8 tiles per workgroup of the blur kernel
+    preprocess.KERNEL_MODE = int(rng.choice([nat.MMX_PP_AUTO, nat.MMX_PP_SINGLE, nat.MMX_PP_PIPELINED]))
+    preprocess.TILES_PER_WG = int(rng.choice([0, 1, 2, 3, 5, 8]))
     got = preprocess.preprocess_roi(vol, dms, near_max=nm)
     vox += vol.size
     if got.shape != want.shape or not np.array_equal(got, want):
         bad += 1
         d = np.abs(got - want)
-        print("MISMATCH trial", trial, shape, vol.dtype, dms, over, nm, "max diff", d.max(), "at",
+        print("MISMATCH trial", trial, shape, vol.dtype, dms, over, nm, "mode", preprocess.KERNEL_MODE, "tpw",
+              preprocess.TILES_PER_WG, "max diff", d.max(), "at",
               np.unravel_index(d.argmax(), d.shape), flush=True)
 print(f"preproc soak seed {a.seed}: {a.trials} trials, {vox} voxels compared bit for bit, {bad} mismatching blocks, "
       f"{time.time() - t0:.0f} s")
