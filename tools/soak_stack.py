@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Randomised end-to-end soak: stack_detect.detect_blobs_blocks (blocks -> device detection -> gather ->
 native prune -> final table) against the oracle's whole-stack restatement, on seeded random volumes, block
-sizes, voxel sizes (anisotropy), 1-2 channels, preprocessing on/off, isotropic rescale, co-localisation.
+sizes, voxel sizes (anisotropy), 1-2 channels, preprocessing on/off, isotropic rescale, co-localisation; every third
+stack goes to the device in slabs of a few planes while its first blocks are detected (volume._SlabUpload), from an
+array, a read-only array or a memory-mapped file.
 
     python tools/soak_stack.py [--trials N] [--seed S]
 """
 import argparse, sys, os, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from magellanmapper_amd import config, preprocess, stack_detect, synth
+from magellanmapper_amd import config, preprocess, stack_detect, synth, volume
 from oracle import magmap_oracle as mmo
 
 ap = argparse.ArgumentParser()
@@ -81,7 +83,19 @@ for trial in range(a.trials):
             pass
         continue
     try:
-        img5d = stack_detect.Image5d(vol[None])
+        # the upload: one synchronous copy, or z-slabs of a few planes on the copy stream beside the detection
+        src, streamed = vol[None], rng.random() < 0.34
+        volume._STREAM_MIN_BYTES = 0 if streamed else (64 << 20)
+        volume._STREAM_CHUNK_BYTES = int(rng.integers(3, 40)) * vol[0].nbytes if streamed else (128 << 20)
+        if streamed:
+            how = rng.random()
+            if how < 0.33:
+                np.save("soak_vol.npy", vol[None])
+                src = np.load("soak_vol.npy", mmap_mode="r")
+            elif how < 0.66:
+                src = vol[None].copy()
+                src.flags.writeable = False
+        img5d = stack_detect.Image5d(src)
         _, _, blobs = stack_detect.detect_blobs_blocks("soak", img5d, None, None, None, False, False, True, coloc)
     except NotImplementedError as e:      # a combination this build states it does not cover
         print("skipped (not built):", e)
