@@ -433,6 +433,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         final, colocs, stats = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_timers = dict(timers)          # (the timed region's: the extra steps below keep adding to `timers`)
     n_replays = bl.GRAPH_REPLAYS - replays0
     pre_wait_ms = sum(a.elapsed_time(b) for a, b in bl.PRE_WAITS) / steps if bl.PRE_WAITS else None
     bl.PRE_WAITS.clear()
@@ -455,9 +456,10 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
-        mine = torch.tensor([sum(ms for ms, n in ktimes.values()) / steps, timers["detect_ms"] / steps,
-                             timers["gather_ms"] / steps, timers["prune_ms"] / steps, float(hi - lo),
-                             timers["tail_ms"] / steps, (timers["tail_ms"] - timers["tail_exchange_ms"]) / steps],
+        mine = torch.tensor([sum(ms for ms, n in ktimes.values()) / steps, step_timers["detect_ms"] / steps,
+                             step_timers["gather_ms"] / steps, step_timers["prune_ms"] / steps, float(hi - lo),
+                             step_timers["tail_ms"] / steps,
+                             (step_timers["tail_ms"] - step_timers["tail_exchange_ms"]) / steps],
                             dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         tdist.all_gather(allr, mine)
@@ -634,7 +636,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             "host_exposed_ms_per_step": round(elapsed / steps * 1e3 - main_ms, 2) if world == 1 else None,
             # rank 0: from the moment its last batch's kernels were seen done to the end of the step (the last batch's
             # host work, the pruning with its exchanges, the final columns); per rank in `ranks`
-            "tail_after_last_kernel_ms": round(timers["tail_ms"] / steps, 2),
+            "tail_after_last_kernel_ms": round(step_timers["tail_ms"] / steps, 2),
+            "host_step_parts_ms": {"detect_blobs_sub_rois": round(step_timers["detect_ms"] / steps, 3),
+                                   "prune_blobs_mp_and_final_columns": round(step_timers["prune_ms"] / steps, 3)},
             # of which: the LoG stream waiting for a batch's preprocessing on the other stream (HIP events around the waits)
             "pre_stream_wait_ms": None if pre_wait_ms is None else round(pre_wait_ms, 2),
             "overlapped_streams": list(overlapped) or None},

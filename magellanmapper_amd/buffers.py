@@ -3,11 +3,8 @@ host -> device copies and the event wrappers.  Split out of ``blob_log.py`` (rou
 from __future__ import annotations
 
 import ctypes
-import math
 import os
-import time
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -178,19 +175,27 @@ class _UploadRing:
         self.busy = [None] * self.SLOTS
         self.at = 0
 
+    #: largest upload taken (a quarter of the ring: the co-localisation's blob rows of a batch are ~0.7 MB)
+    MAX_BYTES = SLOTS // 4 * SLOT_BYTES
+
     def put(self, raw: np.ndarray, dev) -> "torch.Tensor":
         n = raw.size
+        need = -(-n // self.SLOT_BYTES)                 # consecutive slots
+        if self.at + need > self.SLOTS:
+            self.at = 0
         k = self.at
-        self.at = (k + 1) % self.SLOTS
-        if self.busy[k] is not None:
-            self.busy[k].synchronize()
+        self.at = (k + need) % self.SLOTS
+        for j in range(k, k + need):
+            if self.busy[j] is not None:
+                self.busy[j].synchronize()
         lo = k * self.SLOT_BYTES
         self.host[lo:lo + n] = raw
         out = torch.empty(n, dtype=torch.uint8, device=dev)
         out.copy_(self.stage[lo:lo + n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.busy[k] = ev
+        for j in range(k, k + need):
+            self.busy[j] = ev
         return out
 
 
@@ -201,7 +206,7 @@ def _to_device_bytes(arr: np.ndarray, dev) -> "torch.Tensor":
     """``arr``'s bytes as a uint8 device tensor, uploaded on the current stream."""
     global _UPLOAD
     raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
-    if 0 < raw.size <= _UploadRing.SLOT_BYTES and getattr(dev, "type", str(dev)[:4]) == "cuda":
+    if 0 < raw.size <= _UploadRing.MAX_BYTES and getattr(dev, "type", str(dev)[:4]) == "cuda":
         if _UPLOAD is None:
             _UPLOAD = _UploadRing()
         return _UPLOAD.put(raw, dev)

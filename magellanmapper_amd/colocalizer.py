@@ -62,13 +62,15 @@ def _flags_from_means(table: np.ndarray, means: np.ndarray, shape3, n_channels: 
     return colocs
 
 
-def colocalize_blocks_device(volumes: Dict[int, nat.Volume], blocks: np.ndarray, d_blocks,
+def colocalize_blocks_device(volumes: Dict[int, nat.Volume], blocks, d_blocks,
                              shapes, tables: List[Optional[np.ndarray]], n_channels: int,
                              dev, means_only: bool = False, percentile=None) -> List[Optional[np.ndarray]]:
     """Flags for the tables of one batch of blocks.
 
     ``volumes[c]`` is the device view of image channel ``c`` (raw voxels or a preprocessed slot
     buffer) addressed through ``blocks[i].src_off``; channels without a view cannot have blobs.
+    ``blocks`` / ``d_blocks``: one block table for every channel, or dicts of them per channel (preprocessed
+    channels live in slot buffers of their own).  The kernels of all channels are queued before the host waits once.
     ``tables[i]`` is block ``i``'s 11-column table with block-relative coordinates (or ``None``).
     ``means_only`` returns the ``(rows, n_channels)`` mean matrices (NaN where not computed) instead.
     ``percentile``: a channel's threshold is this percentile of its intensities over every voxel owned by one of
@@ -94,23 +96,29 @@ def colocalize_blocks_device(volumes: Dict[int, nat.Volume], blocks: np.ndarray,
     from . import blob_log as _bl
     d_rows = _bl.to_device(rows.reshape(-1), dev)
     d_off = _bl.to_device(offsets, dev)
-    d_mean = torch.empty(n, dtype=torch.float64, device=dev)
+    order = sorted(volumes)
+    d_mean = torch.empty((len(order), n), dtype=torch.float64, device=dev)
     d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
     means = np.full((n, n_channels), np.nan)
     stream = torch.cuda.current_stream().cuda_stream
     owned: Dict[int, Tuple[np.ndarray, np.ndarray]] = {}
     d_vox = torch.empty((n, nat.MMX_COLOC_BALL), dtype=torch.float64, device=dev) if percentile is not None else None
-    for c, vol in sorted(volumes.items()):
+    for k, c in enumerate(order):
+        vol = volumes[c]
+        blk = blocks[c] if isinstance(blocks, dict) else blocks
+        d_blk = d_blocks[c] if isinstance(d_blocks, dict) else d_blocks
         if d_vox is None:
-            nat.check(L.mmx_coloc_means(ctypes.byref(vol), d_blocks.data_ptr(), len(blocks), d_rows.data_ptr(),
-                                        d_off.data_ptr(), n, d_mean.data_ptr(), d_cnt.data_ptr(), stream),
+            nat.check(L.mmx_coloc_means(ctypes.byref(vol), d_blk.data_ptr(), len(blk), d_rows.data_ptr(),
+                                        d_off.data_ptr(), n, d_mean[k].data_ptr(), d_cnt.data_ptr(), stream),
                       "mmx_coloc_means")
         else:
-            nat.check(L.mmx_coloc_voxels(ctypes.byref(vol), d_blocks.data_ptr(), len(blocks), d_rows.data_ptr(),
-                                         d_off.data_ptr(), n, d_mean.data_ptr(), d_cnt.data_ptr(),
+            nat.check(L.mmx_coloc_voxels(ctypes.byref(vol), d_blk.data_ptr(), len(blk), d_rows.data_ptr(),
+                                         d_off.data_ptr(), n, d_mean[k].data_ptr(), d_cnt.data_ptr(),
                                          d_vox.data_ptr(), stream), "mmx_coloc_voxels")
             owned[c] = (d_vox.cpu().numpy(), d_cnt.cpu().numpy())
-        means[:, c] = d_mean.cpu().numpy()
+    h_mean = d_mean.cpu().numpy()           # (one wait for every channel's kernel)
+    for k, c in enumerate(order):
+        means[:, c] = h_mean[k]
     for i in live:
         a, b = offsets[i], offsets[i + 1]
         if means_only:

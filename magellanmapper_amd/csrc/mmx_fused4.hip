@@ -3,15 +3,15 @@
 //
 //   zx4_kernel :  I (u8 / u16, read once, x contiguous)  ->  P = G(z) G(x) I
 //                                                            Q = G(z) G''(x) I + G''(z) G(x) I
-// in three forms that share the arithmetic below:
-//   zx_mode 4  (TILED = false)  row-major voxels in, row-major P / Q out, feeding y2_kernel (mmx_fused.hip) exactly
-//                               as zx2_kernel (mmx_fused2.hip) does -- the experiment that showed the arithmetic at
-//                               1.8 ms and the kernel at 5.3: every access is "16 planes x 64 bytes";
+// in two forms that share the arithmetic below:
 //   zx_mode 6  (TILED)          voxels from the operand-ordered copy zx6_pack_kernel makes once per batch, P / Q out
 //                               as 16 x 16 tiles of float32 -- every access one contiguous KiB -- feeding y6_kernel;
 //   zx_mode 7  (TILED, Q16)     the same with the tiles as one dword per voxel (P unorm16, Q snorm16 of value /
-//                               bound): the default, whenever the caller's NMS band covers the stated rounding bound.
-// zx5_kernel (zx_mode 5) is the LDS-staged experiment in between.  DESIGN.md section 4b has the measurements.
+//                               bound): the default, whenever the stated rounding bound is inside MMX_LOG_ABS_TOL and
+//                               the caller's NMS band covers it.
+// Only TILED = true is instantiated.  The row-major form (TILED = false; zx_mode 4 until round 4: the arithmetic at
+// 1.8 ms, the kernel at 5.3 because every access was "16 planes x 64 bytes") stays in the template as the statement of
+// what the tiling replaced; DESIGN.md section 4b has the measurements.
 //
 // Why.  zx2_kernel needs 5R packed VALU instructions per voxel and a workgroup-wide LDS hand-off per 8 planes;
 // measured, neither its arithmetic nor its skeleton (loads, LDS, barriers: 3.5 of its 5.4 ms per 64 blocks at
@@ -78,7 +78,6 @@ struct mmx_zx4_cfg {
     float qp, qq;                          // Q16 tiles: P / bound(P) and Q / bound(Q) land in [0, 1] and [-1, 1]
     int staged;                            // 0: chunks clamped into the row (zx4); 1: at their natural position (zx5); 2: same, windows at 16 c - R8 (zx6)
     int ntw;                               // column tiles per wave (tiled form): 2 = tiles (2 p, 2 p + 1) share the window of tile 2 p
-    int keep_pad;                          // 1: store the planes of the last z tile past the block too (A/B switch)
 };
 
 namespace {
@@ -476,7 +475,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // Nothing reads them: the Y pass works within a plane and discards the planes past the block (ym_kernel: `real`).
     // (Second tile of a pair: the next ntz KiB, 0 records when the row has no such tile -- its stores are dropped.)
     const unsigned col_b = (unsigned)ntz * 1024u;                                        // bytes of one tile column
-    const unsigned live_b = TILED ? col_b - (cfg.keep_pad ? 0u : (unsigned)(16 * ntz - nz) * 64u) : 0x7fffffffu;
+    const unsigned live_b = TILED ? col_b - (unsigned)(16 * ntz - nz) * 64u : 0x7fffffffu;
     const int64_t wave_e = TILED ? (int64_t)((y * ntx + c) * ntz) * 256 : 0;             // elements before this wave's tiles
     const rsrc4_t rp = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems + wave_e, 0, (int)live_b, 0x00020000);
     const rsrc4_t rq = __builtin_amdgcn_make_buffer_rsrc(gq + (int64_t)bd.slot * slot_elems + wave_e, 0, (int)live_b, 0x00020000);
@@ -901,7 +900,6 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     // the block are not stored (the A/B runs of both: profiles/r04_zx_experiments.txt)
     const bool pair = NKX == 2 && LA == 1 && qp > 0.f && vol->dtype != MMX_F32;
     cfg.ntw = pair ? 2 : 1;
-    cfg.keep_pad = 0;
     int max_waves = 0;
     for (int i = 0; i < n_blocks; ++i) {
         const mmx_block& b = h_blocks[i];

@@ -12,9 +12,8 @@
 //     them (measured: three different loaders).  So the voxels are first copied, strip of x-adjacent tiles by strip
 //     (whole block rows: coalesced reads), into a TILE-MAJOR uint16 copy: every later read of a tile is one
 //     contiguous 31 KiB stream.  +2 B/voxel written, all reads coalesced.
-//   * pp_stats_kernel: a tile's voxels into registers (63 per lane) -> histogram of the high byte -> order
-//     statistics -> vmin / vmax / mean / flags per tile.  5 KiB of LDS and 256 lanes per tile, so four or five
-//     tiles per CU overlap their latencies.
+//   * pp_stats_kernel: histogram of the high byte -> order statistics -> vmin / vmax / mean / flags per tile.  5 KiB
+//     of LDS and 256 lanes per tile, so several tiles per CU overlap their latencies.
 //   * pp_blur_kernel: a workgroup walks a run of tiles.  The stretch is folded into the first line pass (its
 //     input is clip(stretch(voxel)) computed from the uint16 copy in LDS), the voxels of the NEXT tile are
 //     loaded while the unsharp stage of the current one runs and dropped into the LDS words that stage has
@@ -213,12 +212,12 @@ pp_retile_kernel(const InT* __restrict__ vol, int64_t sz, int64_t sy, int64_t sx
 }
 
 // ------------------------------------------------------------------------------------------------------
-// statistics: the order statistics np.percentile interpolates between -> vmin / vmax per tile.
-// pp_stats_kernel keeps a lane's voxels in registers (NV rows of one x: a 25^3 tile is 63 rows for 250 of the
-// 256 lanes) -- one pass over global memory, no voxel copy in LDS, 5 KiB of histograms per workgroup;
-// tiles with more rows per lane re-read their voxels from global memory (L2) for the second histogram.
-// The wave-aggregated increment with the leader's bin read by v_readlane (the ballot is an SGPR pair: the
-// leader is uniform) instead of a cross-lane LDS permute.
+// statistics: the order statistics np.percentile interpolates between -> vmin / vmax, and np.mean of the stretched
+// tile -> the erosion flag.  256 lanes and 5 KiB of histograms per tile, several tiles per CU; the tile is read from
+// the tile-major copy three times (high-byte histogram, low-byte histograms of the selected bins, the sums), in
+// chunks of 8 loads per lane: the second and third time from L2.  (Measured against holding a lane's 64 voxels in
+// registers: the fully unrolled passes then keep 128 compare masks alive in scalar registers and spill them lane by
+// lane -- 0.97 against 0.65 ms per 27 blocks.)
 // High-byte histogram of a lane's voxels.  A tile is mostly background, whose voxels share two high bytes: LDS
 // atomics of many lanes on ONE address serialise (measured: 50 cycles per wave-instruction), a loop over the
 // distinct bins of a wave costs a scalar round trip per bin.  So every wave picks the two bins its first 64 voxels
@@ -254,7 +253,6 @@ struct pp_hist2 {
     }
 };
 
-template <int NV>
 __global__ void __launch_bounds__(PPS_WG)
 pp_stats_kernel(const uint16_t* __restrict__ copy, const int64_t* __restrict__ copy_off,
                 const mmx_subblock* __restrict__ subs, int n_subs,
@@ -272,7 +270,7 @@ pp_stats_kernel(const uint16_t* __restrict__ copy, const int64_t* __restrict__ c
     if (sub_id >= n_subs) return;
     const mmx_subblock sb = subs[sub_id];
     const int nz = sb.nz, ny = sb.ny, nx = sb.nx, n = nz * ny * nx;
-    // the tile's voxels, contiguous; a load past its end returns 0 and is replaced by -1: no branch, 64 loads in flight
+    // the tile's voxels, contiguous; a load past its end returns 0 and is replaced by -1: no branch, the loads pipeline
     const pp_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(copy + copy_off[sub_id]), 0, n * 2, 0x00020000);
     auto vox = [&](int i) {
         const int r = (int)(unsigned)__builtin_amdgcn_raw_buffer_load_b16(src, (unsigned)i << 1, 0, 0);
@@ -283,26 +281,7 @@ pp_stats_kernel(const uint16_t* __restrict__ copy, const int64_t* __restrict__ c
     for (int i = tid; i < PP_HIST; i += PPS_WG) hist[i] = 0;
     __syncthreads();
 
-#ifdef PPS_REGS
-    const bool regs = n <= NV * PPS_WG;                // every lane's voxels fit its registers
-#else
-    // (measured: with 64 voxels in registers the fully unrolled passes keep 128 compare masks alive in scalar registers
-    //  and spill them lane by lane; re-reading the tile from L2 in chunks of 8 for each of the three passes is faster:
-    //  0.97 -> 0.65 ms per 27 blocks.  Also measured and dropped: a constant-line shortcut in the blur kernel's first
-    //  pass -- lines of background voxels all stretch to clip_min, their outputs are one chain -- which fired for a
-    //  quarter of the waves and still lost 9 % to its spills, ballots and second LDS read)
-    const bool regs = false;
-#endif
-    int v[NV];
-    if (regs) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) v[j] = vox(j * PPS_WG + tid);
-        pp_hist2 h;
-        h.pick(v[0]);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) h.add(hist, v[j]);
-        h.flush(hist);
-    } else {
+    {
         pp_hist2 h;
         bool picked = false;
         for (int i0 = 0; i0 < n; i0 += 8 * PPS_WG) {           // same trip count in every lane (ballots)
@@ -339,17 +318,12 @@ pp_stats_kernel(const uint16_t* __restrict__ copy, const int64_t* __restrict__ c
             if (u2 && hi == b2) atomicAdd(&hist[768 + lo], 1u);
             if (u3 && hi == b3) atomicAdd(&hist[1024 + lo], 1u);
         };
-        if (regs) {
+        for (int i0 = 0; i0 < n; i0 += 8 * PPS_WG) {
+            int w8[8];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) add2(v[j]);
-        } else {
-            for (int i0 = 0; i0 < n; i0 += 8 * PPS_WG) {
-                int w8[8];
+            for (int j = 0; j < 8; ++j) w8[j] = vox(i0 + j * PPS_WG + tid);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w8[j] = vox(i0 + j * PPS_WG + tid);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) add2(w8[j]);
-            }
+            for (int j = 0; j < 8; ++j) add2(w8[j]);
         }
     }
     __syncthreads();
@@ -365,7 +339,7 @@ pp_stats_kernel(const uint16_t* __restrict__ copy, const int64_t* __restrict__ c
     PP_TICK(0, 3);
     // np.mean(saturated) gates the erosion.  saturated = (clip(v, vmin, vmax) - vmin) / span, so its sum is
     // (sum over vmin <= v <= vmax of (v - floor(vmin)) - n_mid frac(vmin) + n_hi span) / span up to roundings of
-    // 1e-16 of itself: integer sums over the lane's registers.  Within 1e-9 of the threshold the blur kernel, which
+    // 1e-16 of itself: integer sums.  Within 1e-9 of the threshold the blur kernel, which
     // holds the voxels in LDS, re-sums in NumPy's pairwise order (MMX_PP_KNIFE: internal, cleared there).
     const double vmin = pp_lerp(s_val[0], s_val[1], qc.lo_gamma);
     double vmax = pp_lerp(s_val[2], s_val[3], qc.hi_gamma);
@@ -382,17 +356,12 @@ pp_stats_kernel(const uint16_t* __restrict__ copy, const int64_t* __restrict__ c
         n_hi += vv > ic_hi ? 1u : 0u;
         i_all += vv >= 0 ? (uint32_t)vv : 0u;
     };
-    if (regs) {
+    for (int i0 = 0; i0 < n; i0 += 8 * PPS_WG) {
+        int w8[8];
 #pragma unroll
-        for (int j = 0; j < NV; ++j) tally(v[j]);
-    } else {
-        for (int i0 = 0; i0 < n; i0 += 8 * PPS_WG) {
-            int w8[8];
+        for (int j = 0; j < 8; ++j) w8[j] = vox(i0 + j * PPS_WG + tid);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w8[j] = vox(i0 + j * PPS_WG + tid);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tally(w8[j]);
-        }
+        for (int j = 0; j < 8; ++j) tally(w8[j]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -862,7 +831,7 @@ int mmx_launch_pp_pipe(const mmx_volume* vol, const mmx_subblock* d_subs, const 
     else
         hipLaunchKernelGGL(pp_retile_kernel<uint8_t>, dim3(n_subs), dim3(PPR_WG), 0, s, (const uint8_t*)vol->d_data,
                            vol->stride_z, vol->stride_y, vol->stride_x, d_subs, n_subs, copy_off, is_head, copy);
-    hipLaunchKernelGGL(pp_stats_kernel<64>, dim3(grid_a), dim3(PPS_WG), 0, s, (const uint16_t*)copy,
+    hipLaunchKernelGGL(pp_stats_kernel, dim3(grid_a), dim3(PPS_WG), 0, s, (const uint16_t*)copy,
                        (const int64_t*)copy_off, d_subs, n_subs, d_qclasses, A, d_info);
     auto kb = pp_blur_kernel;
     if (hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tile_b + raw_b)) != hipSuccess)

@@ -542,21 +542,30 @@ def _append_colocs(dvol, channels, origins, shapes, tables, denoise_max_shape, k
         global _coloc_pre
         if _coloc_pre is None or _coloc_pre.dms != [int(v) for v in denoise_max_shape]:
             _coloc_pre = preprocess.Preprocessor(denoise_max_shape)
-        flags = None
-        for c in channels:
-            kept = None if keeper is None else keeper.retained_view(c, origins, shapes)
-            if kept is not None:           # what detection preprocessed is still there (Preprocessor.retain)
-                blocks, vol64 = kept
-            else:
-                blocks, _, _, vol64 = _coloc_pre.run(dvol, c, origins, shapes, 0)
-            d_blocks = bl._to_device_bytes(blocks, dev)
-            part = colocalizer.colocalize_blocks_device({c: vol64}, blocks, d_blocks, shapes, tables,
-                                                        dvol.n_channels, dev, means_only=True)
-            flags = part if flags is None else [None if a is None else np.where(np.isnan(a), b, a)
-                                                for a, b in zip(flags, part)]
-        flags = [None if (t is None or m is None) else
-                 colocalizer._flags_from_means(t, m, shp, dvol.n_channels)
-                 for t, m, shp in zip(tables, flags, shapes)]
+        kept = {c: (None if keeper is None else keeper.retained_view(c, origins, shapes)) for c in channels}
+        if all(v is not None for v in kept.values()):
+            # what detection preprocessed is still there for every channel (Preprocessor.retain): all kernels queued,
+            # one wait, flags per block
+            blocks_of = {c: kept[c][0] for c in channels}
+            volumes = {c: kept[c][1] for c in channels}
+            d_blocks_of = {c: bl._to_device_bytes(blocks_of[c], dev) for c in channels}
+            flags = colocalizer.colocalize_blocks_device(volumes, blocks_of, d_blocks_of, shapes, tables,
+                                                         dvol.n_channels, dev)
+        else:
+            flags = None
+            for c in channels:          # (one buffer set: a channel is read before the next one overwrites it)
+                if kept[c] is not None:
+                    blocks, vol64 = kept[c]
+                else:
+                    blocks, _, _, vol64 = _coloc_pre.run(dvol, c, origins, shapes, 0)
+                d_blocks = bl._to_device_bytes(blocks, dev)
+                part = colocalizer.colocalize_blocks_device({c: vol64}, blocks, d_blocks, shapes, tables,
+                                                            dvol.n_channels, dev, means_only=True)
+                flags = part if flags is None else [None if a is None else np.where(np.isnan(a), b, a)
+                                                    for a, b in zip(flags, part)]
+            flags = [None if (t is None or m is None) else
+                     colocalizer._flags_from_means(t, m, shp, dvol.n_channels)
+                     for t, m, shp in zip(tables, flags, shapes)]
     return [None if t is None else np.hstack((t, f)) for t, f in zip(tables, flags)]
 
 

@@ -24,6 +24,7 @@ switches the old behaviour on for the golden fixtures made with 0.18.3.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -146,8 +147,8 @@ class Preprocessor:
         self._weights = None
         self._tmpl_key = None
         self._tmpl, self._qc_rows, self._qc_index = {}, [], {}
-        self._stage = None
-        self._stage_free = None
+        self._stage = [None] * N_BUFFER_SETS              # pinned staging of the tile tables, one per buffer set
+        self._stage_free = [None] * N_BUFFER_SETS
         self._tiles: Dict[Tuple[int, int, int], Tuple[np.ndarray, np.ndarray]] = {}
         self.last_info: Optional[np.ndarray] = None
         self.last_subs: Optional[np.ndarray] = None
@@ -347,8 +348,12 @@ class Preprocessor:
         # blocks of one shape share a template: their tables are filled with two broadcast additions,
         # straight into a pinned staging buffer (a 25 um tile of anisotropic data is ~2 000 voxels, so a
         # batch easily has 1e6 tiles)
-        if self._stage_free is not None:
-            self._stage_free.synchronize()                   # the previous batch's copy out of the staging buffer
+        # (one staging buffer per buffer set: the copy out of it is queued behind the preprocessing of the batch
+        #  before, so with ONE buffer the host waited here until the GPU had reached this batch's predecessor --
+        #  never more than a batch ahead, tools/steptrace.py --denoise 25)
+        sset = int(which) % N_BUFFER_SETS
+        if self._stage_free[sset] is not None:
+            self._stage_free[sset].synchronize()             # this set's previous copy out of the staging buffer
         groups: Dict[Tuple[int, int, int], List[int]] = {}
         for i in range(nb):
             groups.setdefault(tuple(int(v) for v in shp[i]), []).append(i)
@@ -364,9 +369,10 @@ class Preprocessor:
         n_gen = counts[1] + counts[2]
         total = n_fast + n_gen
         item = nat.SUBBLOCK_DTYPE.itemsize
-        if self._stage is None or self._stage.numel() < max(1, total) * item:
-            self._stage = torch.empty(max(1, total) * item * 5 // 4, dtype=torch.uint8).pin_memory()
-        subs = self._stage.numpy()[:total * item].view(nat.SUBBLOCK_DTYPE)
+        if self._stage[sset] is None or self._stage[sset].numel() < max(1, total) * item:
+            self._stage[sset] = torch.empty(max(1, total) * item * 5 // 4, dtype=torch.uint8).pin_memory()
+        stage = self._stage[sset]
+        subs = stage.numpy()[:total * item].view(nat.SUBBLOCK_DTYPE)
         at = [0, n_fast, n_fast + n_mid]
         base_src_all = org[:, 0] * vsz + org[:, 1] * vsy + org[:, 2] * vsx
         for cls, tmpl, members in plan:
@@ -389,9 +395,9 @@ class Preprocessor:
             out32 = self._buffer("_out32", which, nb * slot_pre, torch.float32, dev)
             out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
         d_subs = torch.empty(max(1, total) * item, dtype=torch.uint8, device=dev)
-        d_subs[:total * item].copy_(self._stage[:total * item], non_blocking=True)
-        self._stage_free = torch.cuda.Event()
-        self._stage_free.record()
+        d_subs[:total * item].copy_(stage[:total * item], non_blocking=True)
+        self._stage_free[sset] = torch.cuda.Event()
+        self._stage_free[sset].record()
         from . import blob_log as _bl
         d_qc = _bl._to_device_bytes(qc, dev)
         # per-tile records: the statistics kernel hands them to the blur kernel (and `info()` reads them)

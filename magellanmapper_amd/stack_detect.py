@@ -627,14 +627,15 @@ class StackDetector:
             return cls._exclude_matrix(coords[mine[k]], last_coord, exclude_border)
 
         pruner = None
-        # (PRUNE_AHEAD "1" / "0" / "": always / never / for raw stacks of 64 blocks and more -- with per-block
-        #  preprocessing on it measured 218.9 against 216.6 ms per volume: nothing to gain.  On the benchmark volume it
+        # (PRUNE_AHEAD "1" / "0" / "": always / never / for stacks of 64 blocks and more.  On the benchmark volume it
         #  moves ~4 ms of pruning under the GPU's last batches and adds most of that in the merge: 0.8-1.0 ms per volume
-        #  in four alternating pairs of bench.py runs; it costs small stacks 0.6 ms: DESIGN.md)
+        #  in four alternating pairs of bench.py runs; it costs small stacks 0.6 ms: DESIGN.md.  With per-block
+        #  preprocessing on: tail after the last kernel 11.4 -> 6.3 ms, tools/steptrace.py --denoise 25 -- once the
+        #  host no longer waited for the tile tables' staging buffer, round 5; 218.9 against 216.6 ms before that)
         ahead = PRUNE_AHEAD
         make_pruner = None
         if regular and dist.world_size() == 1 and mine and (
-                ahead == "1" or (ahead != "0" and len(mine) >= 64 and denoise_max_shape is None)):
+                ahead == "1" or (ahead != "0" and len(mine) >= 64)):
             ov, tl, pad, prune_channels = hint
 
             def make_pruner():
@@ -1227,7 +1228,8 @@ class StackPruner:
             if chan is None:
                 cur = np.arange(len(zyx), dtype=np.int64)
             else:
-                cur = np.ascontiguousarray(np.nonzero(np.isin(chan, chl))[0], dtype=np.int64)  # row ids, table order
+                cur = np.flatnonzero(chan == chl).astype(np.int64, copy=False)      # row ids, table order (np.isin of a
+                #                                                              scalar: 4 ms per 4e5 rows)
             out_rows = np.empty(len(cur), dtype=np.int64)
             out_keys = None if whole else np.empty(len(cur), dtype=np.int64)
             out_n = ctypes.c_int64(0)

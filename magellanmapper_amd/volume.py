@@ -3,12 +3,10 @@ z-slab beside the detection: ``_SlabUpload``) and the host-side ``img_as_float``
 Split out of ``blob_log.py`` (round 5); ``blob_log`` re-exports the public names."""
 from __future__ import annotations
 
-import ctypes
-import math
-import os
-import time
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+import bisect
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -99,7 +97,7 @@ class DeviceVolume:
         up = self._upload
         if up is None:
             return
-        ev = up.event_for(self.shape[0] if z_hi is None else int(z_hi) - getattr(self, "z_off", 0))
+        ev = up.event_for(self.shape[0] if z_hi is None else int(z_hi))
         for st in (streams or [torch.cuda.current_stream()]):
             if st is not None:
                 st.wait_event(ev)
@@ -168,8 +166,7 @@ STREAM_UPLOAD = True
 _STAGE_THREADS = 4
 _UPLOAD_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
 _STAGING: Dict[Tuple[str, int], list] = {}          # (dtype, elements) -> free pairs of pinned staging buffers
-import threading as _threading          # noqa: E402
-_STAGING_LOCK = _threading.Lock()
+_STAGING_LOCK = threading.Lock()
 
 
 class _SlabUpload:
@@ -179,7 +176,6 @@ class _SlabUpload:
     a pageable or memory-mapped one goes through two pinned staging buffers filled by a few host threads."""
 
     def __init__(self, src, dev):
-        import threading
         if isinstance(src, torch.Tensor):
             shape, tdtype, itemsize = tuple(src.shape), src.dtype, src.element_size()
         else:
@@ -224,7 +220,6 @@ class _SlabUpload:
         return len(self.events) >= max(1, self.n_slabs)
 
     def _stage(self, arr, tdtype):
-        from concurrent.futures import ThreadPoolExecutor
         try:
             torch.cuda.set_device(self.dev)
             shape1 = (self.slab,) + tuple(arr.shape[1:])
@@ -271,7 +266,6 @@ class _SlabUpload:
 
     def event_for(self, z_hi: int):
         """The event after which planes ``[0, z_hi)`` are on the device (waits until its copy has been queued)."""
-        import bisect
         z_hi = max(0, min(int(z_hi), self.nz))
         with self.cv:
             while True:

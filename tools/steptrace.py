@@ -15,7 +15,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--budget-gb", type=float, default=16.0)
 ap.add_argument("--keep-heap", action="store_true", help="mallopt: big arrays from the heap, freed memory stays mapped")
 ap.add_argument("--profile", action="store_true", help="cProfile one more step: where the host time goes")
-ap.add_argument("--config", default="c3", choices=["c2", "c3"])
+ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"])
+ap.add_argument("--denoise", type=int, default=0, help="profile denoise_size (per-block preprocessing on)")
+ap.add_argument("--prune-ahead", default=None, choices=["0", "1"], help="stack_detect.PRUNE_AHEAD")
+ap.add_argument("--fine", action="store_true", help="also time the per-block pieces of the co-localisation path")
 ap.add_argument("--no-plan", action="store_true", help="no StackDetector.plan_pruning: the whole table is pruned after the detection")
 a = ap.parse_args()
 if a.keep_heap:
@@ -26,7 +29,20 @@ shape = cfg["shape"]
 dev = torch.device("cuda", 0)
 config.resolutions = bench.RESOLUTIONS; config.filename = "p"
 config.setup_roi_profiles(None); config.roi_profile.update(dict(bench._BASE_PROFILE, **cfg["profile"]))
+if a.prune_ahead is not None:
+    stack_detect.PRUNE_AHEAD = a.prune_ahead
+if a.denoise:
+    config.roi_profile["denoise_size"] = a.denoise
 vol = synth.make_volume_device(shape, cfg["seed"], dev)
+CHANNELS = list(range(cfg["channels"]))
+COLOC = bool(cfg["coloc"])
+if len(CHANNELS) > 1:      # (as bench.py builds it: channel 1 = its own blob field + 70 % of channel 0's)
+    c1 = synth.make_volume_device(shape, cfg["seed"] + 1, dev)
+    c1 = torch.maximum(c1.to(torch.int32), (vol.to(torch.int32) * 7) // 10).to(vol.dtype)
+    vol = torch.stack((vol, c1), dim=-1).contiguous()
+    del c1
+DENOISE = a.denoise or cfg["profile"].get("denoise_size") or 0
+config.near_max = [-1.0] * len(CHANNELS)
 dvol = bl.DeviceVolume(vol)
 blocks = stack_detect.setup_blocks(config.roi_profile, shape)
 bl.blob_log_blocks = functools.partial(bl.blob_log_blocks, budget_bytes=int(a.budget_gb * (1 << 30)))
@@ -68,18 +84,26 @@ wrap(bl, "_prune_batch_native", "per-block overlap prune (native)")
 wrap(stack_detect._ArenaSink, "__call__", "tables -> arena (native) + regions that became ready")
 wrap(stack_detect._RegionPruner, "__init__", "region pruner set-up")
 wrap(stack_detect._RegionPruner, "finish", "remaining regions + merge")
+if COLOC and a.fine:
+    from magellanmapper_amd import colocalizer
+    wrap(detector, "_append_colocs", "  co-localisation of a batch")
+    wrap(colocalizer, "colocalize_blocks_device", "    means of one channel (kernel + wait)")
+    wrap(colocalizer, "_flags_from_means", "    flags of a block")
+    wrap(stack_detect.StackDetector, "_finish_block", "  block table -> ROI coordinates")
+    wrap(stack_detect._TableArena, "add", "  table -> arena")
 orig_prune = stack_detect.StackPruner.prune_blobs_mp.__func__
 
 
 def step():
     if not a.no_plan:
-        stack_detect.StackDetector.plan_pruning(blocks.overlap, blocks.tol, blocks.overlap_padding, [0])
+        stack_detect.StackDetector.plan_pruning(blocks.overlap, blocks.tol, blocks.overlap_padding, CHANNELS)
     seg = stack_detect.StackDetector.detect_blobs_sub_rois(None, dvol, blocks.sub_roi_slices, blocks.sub_rois_offsets,
-                                                           None, None, False, [0])
+                                                           blocks.denoise_max_shape if DENOISE else None, None,
+                                                           COLOC, CHANNELS)
     t = time.perf_counter()
     pruned, _ = stack_detect.StackPruner.prune_blobs_mp(dvol, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
-                                                        blocks.sub_rois_offsets, [0], blocks.overlap_padding,
-                                                        final_form=True, untouched=True)
+                                                        blocks.sub_rois_offsets, CHANNELS, blocks.overlap_padding,
+                                                        final_form=not COLOC, untouched=True)
     log.append((t - T0[0], time.perf_counter() - T0[0], "StackPruner.prune_blobs_mp", ""))
     t = time.perf_counter()
     if isinstance(pruned, stack_detect._FinalTable):
