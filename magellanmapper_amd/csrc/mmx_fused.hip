@@ -201,7 +201,7 @@ int launch_y2(const mmx_block* d_blocks, int n_blocks, int max_cols, int64_t slo
 
 // ---------------------------------------------------------------- Y pass on tiled (P, Q)  (zx_mode 6)
 // Same arithmetic, other geometry: P and Q arrive as 16 z x 16 x tiles of 1 KiB in (y, c, U) order
-// (mmx_fused4.hip: zx4_kernel<.., TILED>).  A workgroup owns one (column tile c, z tile U); each of its four waves
+// (mmx_fused4.hip: zx4_kernel).  A workgroup owns one (column tile c, z tile U); each of its four waves
 // marches along y over 4 planes x 16 columns of it: one contiguous 256-byte piece per array and step, the next
 // one ntx ntz KiB further on -- at any time the workgroups of a block read inside the same few hundred KiB.  The LoG cube stays row-major (the NMS and re-scoring kernels
 // read single voxels from it): a wave stores four 64-byte row pieces, and only where something is above the

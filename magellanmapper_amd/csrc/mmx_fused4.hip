@@ -4,14 +4,13 @@
 //   zx4_kernel :  I (u8 / u16, read once, x contiguous)  ->  P = G(z) G(x) I
 //                                                            Q = G(z) G''(x) I + G''(z) G(x) I
 // in two forms that share the arithmetic below:
-//   zx_mode 6  (TILED)          voxels from the operand-ordered copy zx6_pack_kernel makes once per batch, P / Q out
+//   zx_mode 6                   voxels from the operand-ordered copy zx6_pack_kernel makes once per batch, P / Q out
 //                               as 16 x 16 tiles of float32 -- every access one contiguous KiB -- feeding y6_kernel;
-//   zx_mode 7  (TILED, Q16)     the same with the tiles as one dword per voxel (P unorm16, Q snorm16 of value /
+//   zx_mode 7  (Q16)            the same with the tiles as one dword per voxel (P unorm16, Q snorm16 of value /
 //                               bound): the default, whenever the stated rounding bound is inside MMX_LOG_ABS_TOL and
 //                               the caller's NMS band covers it.
-// Only TILED = true is instantiated.  The row-major form (TILED = false; zx_mode 4 until round 4: the arithmetic at
-// 1.8 ms, the kernel at 5.3 because every access was "16 planes x 64 bytes") stays in the template as the statement of
-// what the tiling replaced; DESIGN.md section 4b has the measurements.
+// (The row-major form of round 4 -- zx_mode 4: the same arithmetic at 1.8 ms in a kernel of 5.3, because every access
+// was "16 planes x 64 bytes" -- is what the tiling replaced; DESIGN.md section 4b has the measurements.)
 //
 // Why.  zx2_kernel needs 5R packed VALU instructions per voxel and a workgroup-wide LDS hand-off per 8 planes;
 // measured, neither its arithmetic nor its skeleton (loads, LDS, barriers: 3.5 of its 5.4 ms per 64 blocks at
@@ -282,7 +281,7 @@ template <> struct pieces4<uint8_t> {
     }
 };
 
-// float voxels (TILED only): zx6_pack_f32_kernel has split them already -- per unit of 8 columns x 16 planes the high
+// float voxels: zx6_pack_f32_kernel has split them already -- per unit of 8 columns x 16 planes the high
 // float16 pieces (256 bytes) then the low ones, v = hi + lo / 2048 -- two 16-byte loads per k-step, no unpacking
 struct presplit_t { u4_4 h, l; };
 template <> struct pieces4<float> {
@@ -309,14 +308,14 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_4, a), __builtin_bit_cast(h8_4, b), c, 0, 0, 0);
 }
 
-// TILED (zx_mode 6): the voxels come from the operand-ordered copy zx6_pack_kernel leaves (`vol` = that copy,
+// The voxels come from the operand-ordered copy zx6_pack_kernel leaves (`vol` = that copy,
 // stride_z = its elements per block) and P / Q leave as 16 x 16 tiles of 1 KiB (slot_elems = tile elements per
 // block) in (y, c, U) order, which y6_kernel (mmx_fused.hip) reads: every global access of a wave is then one
 // contiguous KiB.
 // Q16 (zx_mode 7): the tile holds one dword per voxel, P as unorm16 of P / bound(P) in the low half and Q as snorm16
 // of Q / bound(Q) in the high half (the bounds follow from the weights alone: mmx_tiled_q16_error_bound) -- half
 // the bytes for the Y pass to read and for this kernel to write, at a known error that the caller's band must cover.
-// NTW = 2 (TILED, Q16, 8 < radius <= 16): a wave owns TWO adjacent column tiles (2 p, 2 p + 1).  Their windows -- 48
+// NTW = 2 (Q16, 8 < radius <= 16): a wave owns TWO adjacent column tiles (2 p, 2 p + 1).  Their windows -- 48
 // of the 64 columns two k-steps load -- overlap by two thirds, and the 64 columns from 16 c - 16 on hold both: the
 // same two loads per z step now feed two output tiles (half the L2 read requests per tile: the counters had shown
 // 4.3 x as many bytes requested from L2 as read from HBM, neighbouring waves re-reading each other's windows), and
@@ -324,8 +323,8 @@ __device__ __forceinline__ f4_4 mfma16(const u4_4& a, const u4_4& b, const f4_4&
 // tile's X fragments and window are another 64 registers: two waves per SIMD instead of three, each with twice the
 // independent work per step.  An odd tile count leaves the last wave of a row one tile: it computes the second with
 // zero weights and its stores are dropped by a zero-length buffer descriptor (no branch in the march).
-template <int NKX, int LA, typename InT, bool TILED = false, bool Q16 = false, int NTW = 1>
-__global__ void __launch_bounds__(256, (NTW == 1 && TILED && (LA == 1 || Q16) && !is_f32_4<InT>::value) ? 3 : 2)   // (float32 tiles, LA == 2: 232 registers)
+template <int NKX, int LA, typename InT, bool Q16 = false, int NTW = 1>
+__global__ void __launch_bounds__(256, (NTW == 1 && (LA == 1 || Q16) && !is_f32_4<InT>::value) ? 3 : 2)   // (float32 tiles, LA == 2: 232 registers)
 zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
            const mmx_block* __restrict__ blocks, int64_t slot_elems,
            float* __restrict__ gp, float* __restrict__ gq,
@@ -336,23 +335,22 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     constexpr int NKZ = cg::NKZ, NT = cg::NT;
     constexpr int kUnit = std::is_same<InT, float>::value ? 512 : 256;      // bytes of a unit of the voxel copy
     constexpr bool LO_SCALED = lo_scaled4<InT>::value;
-    static_assert(TILED || !std::is_same<InT, float>::value, "float voxels: tiled form only");
-    static_assert(NTW == 1 || (NTW == 2 && TILED && Q16 && NKX == 2 && LA == 1), "two tiles per wave: 16-bit tiles, 8 < radius <= 16");
-    // TILED, radius <= 16: the Z fragments of the interior z tiles live in LDS, shared by the workgroup's waves, and
+    static_assert(NTW == 1 || (NTW == 2 && Q16 && NKX == 2 && LA == 1), "two tiles per wave: 16-bit tiles, 8 < radius <= 16");
+    // radius <= 16: the Z fragments of the interior z tiles live in LDS, shared by the workgroup's waves, and
     // two z tiles are in flight instead of three: 154 registers, three waves per SIMD.  (Radius > 16 has three
     // k-steps of Z fragments: with float32 tiles, which are bound by their stores, fetching them from LDS every step
     // costs more than the third wave gives -- 4.19 against 3.87 ms --; with 16-bit tiles, 168 registers, it pays:
     // 3.10 against 3.15 ms.)
-    constexpr bool ZLDS = TILED && (LA == 1 || Q16);
+    constexpr bool ZLDS = LA == 1 || Q16;
     constexpr int PF = ZLDS ? ZX6_PF : kPF4;         // z tiles of voxels in flight per wave
     const mmx_block bd = blocks[blockIdx.y];
-    const int W = bd.nx, nz = bd.nz, px = bd.px;
+    const int W = bd.nx, nz = bd.nz;
     const int ntx = (W + 15) >> 4;
     // (readfirstlane: the wave index is uniform, but only this tells the compiler -- otherwise every buffer
     //  descriptor below is built per lane and each load becomes a waterfall loop)
-    // TILED: workgroups are dealt to the 8 XCDs round robin; neighbours along x read overlapping windows, so the
+    // workgroups are dealt to the 8 XCDs round robin; neighbours along x read overlapping windows, so the
     // workgroups one XCD gets (every 8th) are made neighbours: its L2 then serves the overlap (gridDim.x % 8 == 0)
-    const int bx = TILED ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int bx = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     const int gw = bx * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave of this block: (y, column)
     const int ntp = (ntx + NTW - 1) / NTW;                      // waves per row: one per tile, or per pair of tiles
     const int y = gw / ntp;
@@ -396,7 +394,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     // The sums come from the matrix cores themselves: an A operand of ones.  Their float32 rounding (values of ~5
     // instead of <= 1: 5e-7) is inside what mmx_tiled_q16_error_bound states.
     // (radius > 16: the eight start registers would push the kernel past three waves per SIMD)
-    constexpr bool BIASED = TILED && Q16 && !is_f32_4<InT>::value && LA == 1;
+    constexpr bool BIASED = Q16 && !is_f32_4<InT>::value && LA == 1;
     constexpr bool MIXSPLIT = Q16;
     const f4_4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f4_4 a_start[NTW], b_start[NTW];
@@ -427,37 +425,20 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     int zset = -1;
 
     // voxel rows: plane z0 + li, chunk of 8 x at xl[m] (clamped into the block; the fragments know)
-    const InT* in = TILED ? vol + (int64_t)bd.slot * stride_z : vol + bd.src_off + (int64_t)y * stride_y;
-    const int nch8 = (W + 7) >> 3;                               // TILED: 256-byte units (8 columns x 16 planes) per row tile
+    const InT* in = vol + (int64_t)bd.slot * stride_z;
+    const int nch8 = (W + 7) >> 3;                               // 256-byte units (8 columns x 16 planes) per row tile
     unsigned xoff[NKX];
 #pragma unroll
     for (int m = 0; m < NKX; ++m) {
-        if constexpr (TILED) {
-            int j = 2 * c - cg::R8 / 8 + 4 * m + kq;             // unit of this lane; outside the row: any unit, zero weights
-            j = j < 0 ? 0 : (j > nch8 - 1 ? nch8 - 1 : j);
-            xoff[m] = (unsigned)(j * kUnit + li * 16);
-        } else {
-            int xl = cg::xstart(c) + 32 * m + 8 * kq;
-            xl = xl < 0 ? 0 : xl;
-            xl = xl > W - 8 ? W - 8 : xl;
-            xoff[m] = (unsigned)xl * (unsigned)sizeof(InT);
-        }
+        int j = 2 * c - cg::R8 / 8 + 4 * m + kq;                 // unit of this lane; outside the row: any unit, zero weights
+        j = j < 0 ? 0 : (j > nch8 - 1 ? nch8 - 1 : j);
+        xoff[m] = (unsigned)(j * kUnit + li * 16);
     }
     const rsrc4_t rin = make_rsrc4(in);
-    const unsigned zstride_b = (unsigned)(stride_z * (int64_t)sizeof(InT));
     auto load_tile = [&](int t, typename pc::raw_t (&raw)[NKX]) __attribute__((always_inline)) {
-        if constexpr (TILED) {
-            const unsigned so = (unsigned)((y * ntz + t) * nch8) * (unsigned)kUnit;      // wave-uniform: the row tile
+        const unsigned so = (unsigned)((y * ntz + t) * nch8) * (unsigned)kUnit;          // wave-uniform: the row tile
 #pragma unroll
-            for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rin, xoff[m], so);
-            return;
-        }
-        const rsrc4_t rs = make_rsrc4(in + (int64_t)(16 * t) * stride_z);
-        int zr = nz - 1 - 16 * t;                                // last real plane relative to the tile
-        zr = li < zr ? li : zr;
-        const unsigned zo = (unsigned)zr * zstride_b;
-#pragma unroll
-        for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rs, zo + xoff[m]);
+        for (int m = 0; m < NKX; ++m) raw[m] = pc::load(rin, xoff[m], so);
     };
 
     // window of X results as float16 pieces: [column tile][array: A hi, A lo, B hi, B lo][z tile][2 dwords]
@@ -469,27 +450,25 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #pragma unroll
             for (int i = 0; i < NT; ++i) { win[w][a][i][0] = 0u; win[w][a][i][1] = 0u; }
 
-    // TILED: one descriptor per wave, over the tile column (y, c, all U) it writes -- ntz KiB -- and ENDING where the
+    // One descriptor per wave, over the tile column (y, c, all U) it writes -- ntz KiB -- and ENDING where the
     // block's planes end: the rows of the last z tile past the block (11 of 16 at 261 planes) fall outside it and the
     // hardware drops their part of the store, 4 % of the kernel's write requests, without a branch or an exec mask.
     // Nothing reads them: the Y pass works within a plane and discards the planes past the block (ym_kernel: `real`).
     // (Second tile of a pair: the next ntz KiB, 0 records when the row has no such tile -- its stores are dropped.)
     const unsigned col_b = (unsigned)ntz * 1024u;                                        // bytes of one tile column
-    const unsigned live_b = TILED ? col_b - (unsigned)(16 * ntz - nz) * 64u : 0x7fffffffu;
-    const int64_t wave_e = TILED ? (int64_t)((y * ntx + c) * ntz) * 256 : 0;             // elements before this wave's tiles
+    const unsigned live_b = col_b - (unsigned)(16 * ntz - nz) * 64u;
+    const int64_t wave_e = (int64_t)((y * ntx + c) * ntz) * 256;                          // elements before this wave's tiles
     const rsrc4_t rp = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems + wave_e, 0, (int)live_b, 0x00020000);
     const rsrc4_t rq = __builtin_amdgcn_make_buffer_rsrc(gq + (int64_t)bd.slot * slot_elems + wave_e, 0, (int)live_b, 0x00020000);
     const rsrc4_t rp2 = __builtin_amdgcn_make_buffer_rsrc(gp + (int64_t)bd.slot * slot_elems + wave_e + (int64_t)ntz * 256, 0,
                                                           has2 ? (int)live_b : 0, 0x00020000);
-    const unsigned row_b = (unsigned)px * 4u;
-    // TILED: tile (y, c, U) of 16 z x 16 x floats, row-major, at ((y ntx + c) ntz + U) KiB: what a wave writes
+    // Tile (y, c, U) of 16 z x 16 x floats, row-major, at ((y ntx + c) ntz + U) KiB: what a wave writes
     // during its march is contiguous, the waves of a workgroup and the workgroups of a row follow each other --
     // the kernel's stores are one sequential stream -- and y6_kernel's workgroups, one per (c, U), all read inside
     // the same ntx ntz KiB at any time.  (Measured against the (c, U, y) order: no difference in either kernel; both
     // run at the request rate the memory system sustains)
-    const unsigned plane_b = TILED ? 64u : (unsigned)bd.ny * row_b;
-    unsigned obase = TILED ? (unsigned)((4 * li + kq) * 16)          // (relative to the wave's tile column)
-                           : (unsigned)li * plane_b + (unsigned)y * row_b + (unsigned)(16 * c + 4 * kq) * 4u;
+    const unsigned plane_b = 64u;
+    unsigned obase = (unsigned)((4 * li + kq) * 16);                  // (relative to the wave's tile column)
 
     // voxels of the next ZX4_PF z tiles, in flight.  vmcnt counts loads and stores together and in issue order:
     // a tile loaded only one step ahead could not be used before the stores of the step in between have been
@@ -628,6 +607,9 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                     const u4_4* zp = zt + ((size_t)(want * NKZ + ks) * 2) * 128;
                     z00 = zp[0]; z01 = zp[64]; z10 = zp[128]; z11 = zp[192];
                 }
+                // (The window's last tile, U + LA, stands alone in its k-step -- the fragments' other half is zero.  The
+                //  legacy v_mfma_f32_16x16x16_f16 on that half costs what the 16x16x32 form costs on gfx950 and, mixed
+                //  with it on one accumulator chain, gave run-dependent values: profiles/r05_experiments.txt, section 5.)
 #pragma unroll
                 for (int w = 0; w < NTW; ++w) {
                     const u4_4 ah = {win[w][0][2 * ks][0], win[w][0][2 * ks][1], win[w][0][2 * ks + 1][0], win[w][0][2 * ks + 1][1]};
@@ -656,7 +638,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 #pragma unroll
             for (int w = 0; w < NTW; ++w) asm volatile("" ::"v"(P[w]));     // the slot's previous results stayed in these registers until now
             asm volatile("" ::"v"(Q));
-            if (STEADY || TILED || 16 * U + li < nz) {     // (a tile is stored whole: its padding belongs to it)
+            {                                              // (a tile is stored whole: its padding belongs to it)
                 // the results reach the slot's registers through opaque moves: the stores then read registers
                 // that nothing else may be allocated to before the slot comes round again
                 if constexpr (Q16) {
@@ -747,7 +729,7 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
 // ------------------------------------------------------------------------------- tiled variant (zx_mode 6)
 // Operand-ordered copy of the blocks' voxels, made once per batch: for every block row y and z tile t the row
 // tile of 16 planes x nx voxels as units of 8 columns x 16 planes (256 bytes, plane-major inside), widened to
-// uint16 (uint8 voxels shifted into the high byte): the four units a lane group of zx4_kernel<.., TILED> needs for one
+// uint16 (uint8 voxels shifted into the high byte): the four units a lane group of zx4_kernel needs for one
 // k-step are one contiguous KiB
 // wherever the window starts.  Planes past the block and columns past the row read as zero.  Any strides, any
 // alignment: the copy is what lifts zx4's 16-byte alignment rules.
@@ -929,28 +911,28 @@ int launch_zx6(const mmx_volume* vol, const mmx_block* d_blocks, const mmx_block
     dim3 grid((((max_waves + 3) / 4) + 7) & ~7, n_blocks);        // (a multiple of 8: the XCD-aware order in the kernel)
     if (vol->dtype == MMX_F32) {
         if (qp > 0.f)          // (16-bit tiles: the caller's bounds cover the voxels' range, mmx_volume.value_range)
-            hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true, true>), grid, dim3(256), 0, s,
+            hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true>), grid, dim3(256), 0, s,
                                reinterpret_cast<const float*>(w + plan.pack_off), plan.pack_stride / 2, (int64_t)0, d_blocks,
                                plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
                                xtab, ztab, cfg);
         else
-            hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, true, false>), grid, dim3(256), 0, s,
+            hipLaunchKernelGGL((zx4_kernel<NKX, LA, float, false>), grid, dim3(256), 0, s,
                                reinterpret_cast<const float*>(w + plan.pack_off), plan.pack_stride / 2, (int64_t)0, d_blocks,
                                plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
                                xtab, ztab, cfg);
     } else if (pair) {
         if constexpr (NKX == 2 && LA == 1)
-            hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, true, 2>), grid, dim3(256), 0, s,
+            hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, 2>), grid, dim3(256), 0, s,
                                reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
                                plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
                                xtab, ztab, cfg);
     } else if (qp > 0.f)
-        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, true>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true>), grid, dim3(256), 0, s,
                            reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
                            plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
                            xtab, ztab, cfg);
     else
-        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, true, false>), grid, dim3(256), 0, s,
+        hipLaunchKernelGGL((zx4_kernel<NKX, LA, uint16_t, false>), grid, dim3(256), 0, s,
                            reinterpret_cast<const uint16_t*>(w + plan.pack_off), plan.pack_stride, (int64_t)0, d_blocks,
                            plan.tile_stride, reinterpret_cast<float*>(w), reinterpret_cast<float*>(w + plan.q_off),
                            xtab, ztab, cfg);
