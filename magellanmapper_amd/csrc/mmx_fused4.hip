@@ -366,11 +366,29 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const int u_hi = (nz - 16 - R) >> 4;                        // last U with 16 U + 15 + R <= nz - 1 (may be < u_lo)
     const u4_4* zt = ztab + ((size_t)cz * cfg.maxu * NKZ * 2) * 128 + lane;
     // (the steps at the ends of the block take their fragments straight from the table)
-    __shared__ u4_4 zl[ZLDS ? NKZ * 4 * 64 : 1];
+    // ROT: in the steady steps z tile t keeps the window slot t mod NT it was written to -- no shifting, the operand
+    // quads (slots 2 q, 2 q + 1) never move -- and the fragments rotate instead: by whole k-steps when the window
+    // starts on an even slot (the table as it is), and through a second table, shifted by one tile, when it starts on
+    // an odd one: F1[k] = [F0[k - 1] upper half | F0[k] lower half].  The slot outside the window holds the tile that
+    // left it (finite values) against zero fragments.  A third fewer register moves per step; built where it measured
+    // faster (tools/kbench.py, 16-bit tiles, ms per 22 blocks: radius 8 0.752 -> 0.70, radius 18 / 20 1.02 -> 0.975);
+    // two column tiles per wave spill with it (76 bytes: 0.75 -> 1.20), one tile per wave at radius 9..16 loses to
+    // the pair as before (0.845 against 0.74), float32 tiles read +6 %: profiles/r05_experiments.txt, section 6.
+    constexpr bool ROT = ZLDS && Q16 && NTW == 1 && !is_f32_4<InT>::value && (NKX == 1 || LA == 2);
+    constexpr int ZL1 = NKZ * 4 * 64;                          // entries of one table
+    __shared__ u4_4 zl[ZLDS ? (ROT ? 2 : 1) * ZL1 : 1];
     if constexpr (ZLDS) {
         const u4_4* zi = ztab + ((size_t)(cz * cfg.maxu + (u_lo < cfg.maxu ? u_lo : 0)) * NKZ * 2) * 128;
-        for (int e = threadIdx.x; e < NKZ * 4 * 64; e += 256) zl[e] = zi[e];
+        for (int e = threadIdx.x; e < ZL1; e += 256) zl[e] = zi[e];
         __syncthreads();
+        if constexpr (ROT) {
+            for (int e = threadIdx.x; e < ZL1; e += 256) {
+                const u4_4 cur = zl[e];
+                const u4_4 prev = e >= 256 ? zl[e - 256] : (u4_4){0u, 0u, 0u, 0u};  // (k-step before: 4 x 64 entries back)
+                zl[ZL1 + e] = (u4_4){prev.z, prev.w, cur.x, cur.y};
+            }
+            __syncthreads();
+        }
     }
     if (y >= bd.ny) return;                                   // whole wave (no barriers below)
 
@@ -493,15 +511,22 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         for (int w = 0; w < NTW; ++w) outP[u][w] = zero4;
         outQ[u] = zero4;
     }
-    auto step = [&](int t, auto steady_tag, typename pc::raw_t (&rw)[NKX], f4_4 (&P)[NTW], f4_4& Q) __attribute__((always_inline)) {
+    // (phase_tag: the window slot of z tile t in a steady step of the rotating form, -1 otherwise: the window is
+    //  shifted and t takes slot 2 LA -- the arrangement the rotating steps start from and return to every NT steps)
+    auto step = [&](int t, auto steady_tag, auto phase_tag, typename pc::raw_t (&rw)[NKX], f4_4 (&P)[NTW], f4_4& Q) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        // shift the window by one z tile
+        constexpr int PH = decltype(phase_tag)::value;
+        constexpr bool TURN = STEADY && ROT && PH >= 0;
+        constexpr int SLOT = TURN ? PH : 2 * LA;                 // where the X results of z tile t go
+        if constexpr (!TURN) {
+            // shift the window by one z tile
 #pragma unroll
-        for (int w = 0; w < NTW; ++w)
+            for (int w = 0; w < NTW; ++w)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int i = 0; i < 2 * LA; ++i) { win[w][a][i][0] = win[w][a][i + 1][0]; win[w][a][i][1] = win[w][a][i + 1][1]; }
+                    for (int i = 0; i < 2 * LA; ++i) { win[w][a][i][0] = win[w][a][i + 1][0]; win[w][a][i][1] = win[w][a][i + 1][1]; }
+        }
         if (STEADY || t < ntz) {
             // ---- X pass of z tile t
             u4_4 dh[NKX], dl[NKX];
@@ -556,25 +581,25 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                         //  whose register writes the compiler's hazard recogniser does not see: one landed right behind an
                         //  MFMA that still read the register as its C operand -- wrong results for radius <= 8.)
                         const f2_4 ar = {av0 - (float)ah.x, av1 - (float)ah.y}, br = {bv0 - (float)bh.x, bv1 - (float)bh.y};
-                        win[w][0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
-                        win[w][1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
-                        win[w][2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
-                        win[w][3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
+                        win[w][0][SLOT][r >> 1] = __builtin_bit_cast(unsigned, ah);
+                        win[w][1][SLOT][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
+                        win[w][2][SLOT][r >> 1] = __builtin_bit_cast(unsigned, bh);
+                        win[w][3][SLOT][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
                         continue;
                     }
                     const f2_4 ar = {__builtin_fmaf((float)ah.x, -kLoScale, av0 * kLoScale), __builtin_fmaf((float)ah.y, -kLoScale, av1 * kLoScale)};
                     const f2_4 br = {__builtin_fmaf((float)bh.x, -kLoScale, bv0 * kLoScale), __builtin_fmaf((float)bh.y, -kLoScale, bv1 * kLoScale)};
-                    win[w][0][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, ah);
-                    win[w][1][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
-                    win[w][2][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, bh);
-                    win[w][3][2 * LA][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
+                    win[w][0][SLOT][r >> 1] = __builtin_bit_cast(unsigned, ah);
+                    win[w][1][SLOT][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(ar, h2_4));
+                    win[w][2][SLOT][r >> 1] = __builtin_bit_cast(unsigned, bh);
+                    win[w][3][SLOT][r >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(br, h2_4));
                 }
             }
         } else {
 #pragma unroll
             for (int w = 0; w < NTW; ++w)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { win[w][a][2 * LA][0] = 0u; win[w][a][2 * LA][1] = 0u; }
+                for (int a = 0; a < 4; ++a) { win[w][a][SLOT][0] = 0u; win[w][a][SLOT][1] = 0u; }
         }
         const int U = t - LA;
         if (STEADY || U >= 0) {
@@ -601,8 +626,12 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
                 if constexpr (!ZLDS) {
                     z00 = zw[ks][0][0]; z01 = zw[ks][0][1]; z10 = zw[ks][1][0]; z11 = zw[ks][1][1];
                 } else if constexpr (STEADY) {
-                    z00 = zl[(ks * 4 + 0) * 64 + lane]; z01 = zl[(ks * 4 + 1) * 64 + lane];
-                    z10 = zl[(ks * 4 + 2) * 64 + lane]; z11 = zl[(ks * 4 + 3) * 64 + lane];
+                    // (rotating form: the window starts TR slots after slot 0; quad ks holds the window tiles of k-step
+                    //  ks - TR / 2, one tile later when TR is odd)
+                    constexpr int TR = TURN ? (PH - (NT - 2) + NT) % NT : 0;
+                    const int KF = ((TR & 1) ? ZL1 : 0) + ((ks - TR / 2 + NKZ) % NKZ) * 256;     // (a constant once unrolled)
+                    z00 = zl[KF + 0 * 64 + lane]; z01 = zl[KF + 1 * 64 + lane];
+                    z10 = zl[KF + 2 * 64 + lane]; z11 = zl[KF + 3 * 64 + lane];
                 } else {
                     const u4_4* zp = zt + ((size_t)(want * NKZ + ks) * 2) * 128;
                     z00 = zp[0]; z01 = zp[64]; z10 = zp[128]; z11 = zp[192];
@@ -686,14 +715,16 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
     const int t_end = ntz + LA;
     int tA = ((u_lo + LA + PF - 1) / PF) * PF;
     int nB = (u_hi + LA + 1 < ntz ? u_hi + LA + 1 : ntz) - tA;       // steady steps available
-    nB = nB > 0 ? (nB / PF) * PF : 0;
+    constexpr int GROUP = ROT ? NT : PF;                             // (rotating form: whole turns of the window)
+    static_assert(GROUP % PF == 0, "a turn of the window is a whole number of rings");
+    nB = nB > 0 ? (nB / GROUP) * GROUP : 0;
     if (tA > t_end) tA = ((t_end + PF - 1) / PF) * PF;
     const int tB = tA + nB;
 #pragma unroll 1
     for (int t0 = 0; t0 < tA; t0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            if (t0 + u < t_end) step(t0 + u, std::false_type{}, raw[u], outP[u], outQ[u]);
+            if (t0 + u < t_end) step(t0 + u, std::false_type{}, std::integral_constant<int, -1>{}, raw[u], outP[u], outQ[u]);
     }
     if (nB > 0) {
         // interior Z fragments (the generic steps may have left an edge set in the registers)
@@ -710,17 +741,35 @@ zx4_kernel(const InT* __restrict__ vol, int64_t stride_z, int64_t stride_y,
         // nothing may be pending at the loop head: a wait for the fragment loads above, placed inside the loop
         // at their first use, would be a static vmcnt(N) that in steady state waits for the previous step's stores
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        // (rotating form: step j of a turn writes slot NT - 1 + j (mod NT): the generic steps leave tile t in slot NT - 2)
+        auto turn = [&](int t0, auto... J) __attribute__((always_inline)) {
+            (step(t0 + decltype(J)::value, std::true_type{},
+                  std::integral_constant<int, ROT ? (NT - 1 + decltype(J)::value) % NT : -1>{},
+                  raw[decltype(J)::value % PF], outP[decltype(J)::value % PF], outQ[decltype(J)::value % PF]), ...);
+        };
+        if constexpr (!ROT) {
 #pragma unroll 1
-        for (int t0 = tA; t0 < tB; t0 += PF) {
+            for (int t0 = tA; t0 < tB; t0 += PF) {
 #pragma unroll
-            for (int u = 0; u < PF; ++u) step(t0 + u, std::true_type{}, raw[u], outP[u], outQ[u]);
+                for (int u = 0; u < PF; ++u) step(t0 + u, std::true_type{}, std::integral_constant<int, -1>{}, raw[u], outP[u], outQ[u]);
+            }
+        } else {
+#pragma unroll 1
+            for (int t0 = tA; t0 < tB; t0 += GROUP) {
+                using std::integral_constant;
+                if constexpr (GROUP == 4) turn(t0, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
+                                               integral_constant<int, 3>{});
+                else turn(t0, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{},
+                          integral_constant<int, 3>{}, integral_constant<int, 4>{}, integral_constant<int, 5>{});
+                static_assert(GROUP == 4 || GROUP == 6, "turn lengths built: 4 (radius <= 16), 6 (radius <= 24)");
+            }
         }
     }
 #pragma unroll 1
     for (int t0 = tB; t0 < t_end; t0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u)
-            if (t0 + u < t_end) step(t0 + u, std::false_type{}, raw[u], outP[u], outQ[u]);
+            if (t0 + u < t_end) step(t0 + u, std::false_type{}, std::integral_constant<int, -1>{}, raw[u], outP[u], outQ[u]);
     }
 }
 
