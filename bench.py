@@ -849,7 +849,7 @@ def main():
         # the oracle pools have just ended: a hundred-odd spawned interpreters are still being torn down and the cores
         # they loaded for a minute are hot.  Two runs of this command on two boxes read 104.3 / 104.9 ms with 10.8 / 11.9
         # ms of exposed host time when the GPU part followed at once (100.0 without the pools on the same box); with this
-        # pause (and the allocator set up first) 99.1 / 99.3 against 99.8 / 101.0 alternating (tools/exp/ab_baseline.sh)
+        # pause (and the allocator set up first) 99.1 / 99.3 against 99.8 / 101.0 alternating (round 4)
         time.sleep(float(os.environ.get("MMX_BENCH_SETTLE_S", 3)))
     # one rank per GPU; MMX_DIST_BACKEND=gloo + fewer GPUs than ranks is only for functional tests
     backend = os.environ.get("MMX_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
