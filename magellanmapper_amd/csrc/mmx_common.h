@@ -43,7 +43,7 @@ int mmx_launch_zx2(const mmx_volume* vol, const mmx_block* d_blocks, int n_block
                    int64_t slot_elems, const mmx_taps_f32& tz, const mmx_taps_f32& tx, int radius,
                    float* d_p, float* d_q, hipStream_t s);
 // Tiled fused path (zx_mode 6): where its pieces live inside the four intermediate arrays of d_work
-// (4 n_blocks slot_elems floats).  P and Q as 16 x 16 tiles (mmx_fused4.hip: zx4_kernel<.., TILED>), the Toeplitz
+// (4 n_blocks slot_elems floats).  P and Q as 16 x 16 tiles (mmx_fused4.hip: zx4_kernel), the Toeplitz
 // fragment tables of the current sigma, and the operand-ordered copy of the blocks' voxels (zx6_pack_kernel),
 // which survives from one sigma of a batch to the next.
 struct mmx_zx6_plan {

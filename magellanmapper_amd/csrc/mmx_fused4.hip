@@ -249,43 +249,13 @@ template <> struct pieces4<uint16_t> {
         }
     }
 };
-// 8 consecutive uint8 voxels (2 dwords) -> one exact piece: b / 256
-template <> struct pieces4<uint8_t> {
-    static constexpr int NP = 1;
-    using raw_t = u2_4;
-    static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off, unsigned soff = 0)
-    {
-        return __builtin_bit_cast(u2_4, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
-    }
-    static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo)
-    {
-        const h2_4 four = {(_Float16)4.0f, (_Float16)4.0f};
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned t0 = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07010500u);   // [44 b1 44 b0]
-            const unsigned t1 = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07030502u);   // [44 b3 44 b2]
-            hi[2 * i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2_4, t0) - four);
-            hi[2 * i + 1] = __builtin_bit_cast(unsigned, __builtin_bit_cast(h2_4, t1) - four);
-        }
-        lo = hi;
-    }
-    static constexpr float kBiasHi = 4.0f, kBiasLo = 0.0f;
-    static __device__ __forceinline__ void split_biased(const raw_t& d, u4_4& hi, u4_4& lo)
-    {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            hi[2 * i] = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07010500u);
-            hi[2 * i + 1] = __builtin_amdgcn_perm(0x44004400u, d[i], 0x07030502u);
-        }
-        lo = hi;
-    }
-};
+// (uint8 voxels: zx6_pack_kernel widens them to uint16, shifted into the high byte -- the uint16 pieces serve both)
 
 // float voxels: zx6_pack_f32_kernel has split them already -- per unit of 8 columns x 16 planes the high
 // float16 pieces (256 bytes) then the low ones, v = hi + lo / 2048 -- two 16-byte loads per k-step, no unpacking
 struct presplit_t { u4_4 h, l; };
 template <> struct pieces4<float> {
-    static constexpr int NP = 2;
+    [[maybe_unused]] static constexpr int NP = 2;
     using raw_t = presplit_t;
     static __device__ __forceinline__ raw_t load(rsrc4_t r, unsigned off, unsigned soff = 0)
     {
@@ -295,7 +265,7 @@ template <> struct pieces4<float> {
         return v;
     }
     static __device__ __forceinline__ void split(const raw_t& d, u4_4& hi, u4_4& lo) { hi = d.h; lo = d.l; }
-    static constexpr float kBiasHi = 0.f, kBiasLo = 0.f;
+    [[maybe_unused]] static constexpr float kBiasHi = 0.f, kBiasLo = 0.f;      // (never biased: read in discarded branches only)
     static __device__ __forceinline__ void split_biased(const raw_t& d, u4_4& hi, u4_4& lo) { hi = d.h; lo = d.l; }
 };
 template <typename InT> struct is_f32_4 { static constexpr bool value = false; };
