@@ -1,9 +1,8 @@
-import os
 #!/usr/bin/env python3
-"""Host timeline of one full-volume step (c3): when each batch is enqueued, when the host starts / ends finishing
+"""Host timeline of one full-volume step: when each batch is enqueued, when the host starts / ends finishing
 it, when the GPU goes idle, how long the tail after the last kernel is and what it consists of.
 
-    python tools/steptrace.py [--budget-gb 64]
+    python tools/steptrace.py [--config c2|c3|c5] [--denoise 25] [--prune-ahead 0|1] [--fine] [--budget-gb 64]
 """
 import argparse, functools, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
