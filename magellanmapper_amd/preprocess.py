@@ -24,7 +24,6 @@ switches the old behaviour on for the golden fixtures made with 0.18.3.
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
