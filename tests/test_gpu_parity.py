@@ -955,6 +955,34 @@ def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
     assert np.all(f7 & nat.MMX_CAND_BAND)
 
 
+def test_rotating_window_of_the_zx_march_against_the_float32_tiles(gpu):
+    """Deep blocks, radius 8 and radius 17 / 20 / 24 on 16-bit tiles: the steady steps of ``zx4_kernel`` there keep the
+    window's tiles in their slots and rotate the Z fragments (whole turns of 4 and 6 steps; 200 planes = 13 z tiles give
+    two turns and one).  The float32 tiles of the same path shift their window as ever: every candidate they nominate in
+    the narrow band is nominated from the 16-bit tiles too, with a value inside the bound the library states; and the
+    16-bit result is the same from the prepacked copy and on a second run."""
+    from magellanmapper_amd import _native as nat, synth, kernels1d as k1
+    vol = synth.make_volume(21, (215, 70, 100), 110)
+    origins = [(0, 0, 0), (9, 5, 33), (15, 20, 7)]
+    shapes = [(200, 64, 64), (206, 60, 67), (187, 50, 37)]
+    for sig in ([2.0], [4.25, 5.0, 6.0]):
+        p6, l6, k6, v6, f6 = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED, False)
+        p7, l7, k7, v7, f7 = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED_Q16, False, eps=2.5e-4)
+        p7b, l7b, k7b, v7b, f7b = _abi_batch(vol, origins, shapes, sig, nat.MMX_ZX_TILED_Q16, True, eps=2.5e-4)
+        assert (p6, l6) == (nat.MMX_ZX_TILED, nat.MMX_MASK_QUADS) and (p7, l7) == (p7b, l7b) == (nat.MMX_ZX_TILED_Q16, nat.MMX_MASK_QUADS)
+        assert np.array_equal(k7, k7b) and np.array_equal(v7, v7b) and np.array_equal(f7, f7b)
+        bound = max(nat.lib().mmx_tiled_q16_error_bound(
+            nat.as_double_ptr(k1.gaussian_half_kernel(s_, 0, k1.kernel_radius(s_))),
+            nat.as_double_ptr(k1.gaussian_half_kernel(s_, 2, k1.kernel_radius(s_))), k1.kernel_radius(s_), s_ * s_) for s_ in sig)
+        assert len(k6) >= 60
+        pos = {tuple(r): i for i, r in enumerate(k7)}
+        idx = [pos.get(tuple(r), -1) for r in k6]
+        assert min(idx) >= 0
+        assert np.max(np.abs(v7[idx] - v6)) < bound
+        # (both halves of every block's depth hold candidates: the steady steps' tiles are among those compared)
+        assert (k6[:, 2] < 60).any() and (k6[:, 2] > 120).any()
+
+
 def test_y_pass_on_the_matrix_cores_agrees_with_the_valu_kernel(gpu):
     """``MMX_ZX_TILED_Q16`` runs its Y pass on the matrix cores (``ym_kernel``); ``| MMX_ZX_Y_VALU`` asks for ``y6_kernel``
     on the same 16-bit tiles.  Both read the same tiles, so their values differ only by the float32 arithmetic and the low
