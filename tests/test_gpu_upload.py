@@ -134,3 +134,30 @@ def test_three_tiles_streamed_equal_the_oracle_per_tile(gpu, monkeypatch, tmp_pa
         assert seen == [0, 1, 2] and len(uploads) == 3 and all(t.device_volume is None for t in tiles)
     finally:
         config.setup_roi_profiles(None)
+
+
+def test_small_uploads_through_the_pinned_ring_arrive_intact(gpu):
+    """``buffers.to_device``: arrays of up to a quarter of the ring go through consecutive pinned slots and an asynchronous
+    copy (several slots for the co-localisation's blob rows of a batch), larger ones through the plain copy; the ring
+    wraps without a slot being overwritten before its copy has run -- kernels queued in between keep the copies pending
+    while the host moves on."""
+    import torch
+    from magellanmapper_amd import buffers
+    dev = torch.device("cuda", 0)
+    ring = buffers._UploadRing
+    rng = np.random.default_rng(5)
+    sizes = [1, 7, ring.SLOT_BYTES - 1, ring.SLOT_BYTES, ring.SLOT_BYTES + 1, 5 * ring.SLOT_BYTES + 3, ring.MAX_BYTES,
+             ring.MAX_BYTES + 1]
+    sent = []
+    busy = torch.zeros(1 << 24, device=dev)
+    for rep in range(40):                            # several times round the ring
+        for n in sizes:
+            a = rng.integers(0, 256, n, dtype=np.uint8)
+            busy.add_(1.0)                           # (something for the copies to queue behind)
+            sent.append((a, buffers._to_device_bytes(a, dev)))
+    torch.cuda.synchronize()
+    for a, t in sent:
+        assert t.device.type == "cuda" and np.array_equal(t.cpu().numpy(), a)
+    f = rng.standard_normal((300, 5))
+    assert np.array_equal(buffers.to_device(f, dev).cpu().numpy(), f)
+    assert buffers.to_device(np.zeros((0, 3)), dev).shape == (0, 3)
