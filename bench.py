@@ -305,7 +305,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     # A rank-local view that behaves like the full (z, y, x[, c]) ROI for block addressing.
     class SlabVolume(bl.DeviceVolume):
         def __init__(self, t, z_off, full_shape):
-            super().__init__(t, dev)
+            # (host sources -- `--from-host` -- go up beside the detection: this script leaves them alone meanwhile)
+            super().__init__(t, dev, streamed=True)
             self.z_off = z_off
             self.shape = tuple(full_shape) + tuple(t.shape[3:])
 

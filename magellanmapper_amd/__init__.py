@@ -20,4 +20,14 @@ __version__ = "0.1.0"
 # GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin: with the default the upload stream shares a queue with a
 # kernel stream, and the kernels queue behind 150 ms of copies (measured: 302 vs 254 ms per tile of a streamed stack).
 # Read when the HIP runtime starts, so it is set here, before anything touches the GPU; a caller's own value wins.
+# This only works while the runtime has NOT started: a host application that touched the GPU before importing this
+# package keeps the queues it started with (INTEGRATION.md section 4 says what to export instead), and the first
+# streamed upload warns once when that -- or a smaller value of the caller's -- is the case (volume._check_hw_queues).
+import sys as _sys
+
+_torch = _sys.modules.get("torch")
+#: True when torch had already initialised the GPU when this package was imported: the setting below came too late
+GPU_WAS_INITIALISED_AT_IMPORT = bool(_torch is not None and getattr(_torch, "cuda", None) is not None
+                                     and _torch.cuda.is_initialized())
+del _torch
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -157,8 +157,9 @@ def release_buffers() -> None:
     for b in _BUFFERS.values():
         b.drop_graphs()
     _BUFFERS.clear()
-    from . import preprocess
+    from . import preprocess, volume
     preprocess.release_retained()
+    volume.release_staging()        # (pinned staging buffers of host-volume uploads, the copy streams)
 
 
 class _UploadRing:

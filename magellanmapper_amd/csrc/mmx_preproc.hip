@@ -936,11 +936,16 @@ int mmx_preprocess_batch_mode(const mmx_volume* vol, const mmx_subblock* d_subs,
         void* work = d_work;
         if (!inf && hipMallocAsync((void**)&inf, (size_t)n_subs * sizeof(mmx_subblock_info), s) != hipSuccess)
             return MMX_ERR_HIP;
-        if (!work && hipMallocAsync(&work, (size_t)need, s) != hipSuccess) return MMX_ERR_HIP;
+        if (!work && hipMallocAsync(&work, (size_t)need, s) != hipSuccess) {
+            if (!d_info) (void)hipFreeAsync(inf, s);       // (the table just taken from the pool goes back)
+            return MMX_ERR_HIP;
+        }
         const int rc = mmx_launch_pp_pipe(vol, d_subs, h_subs, n_subs, d_qclasses, d_weights, A, d_out32, d_out64,
                                           inf, work, tiles_per_wg > 0 ? tiles_per_wg : MMX_PP_TILES_PER_WG, s);
-        if (!d_info && hipFreeAsync(inf, s) != hipSuccess) return MMX_ERR_HIP;
-        if (!d_work && hipFreeAsync(work, s) != hipSuccess) return MMX_ERR_HIP;
+        // (both are returned whatever the first one's status: a failed free must not strand the other block)
+        const bool freed_inf = d_info || hipFreeAsync(inf, s) == hipSuccess;
+        const bool freed_work = d_work || hipFreeAsync(work, s) == hipSuccess;
+        if (!freed_inf || !freed_work) return MMX_ERR_HIP;
         if (rc != MMX_ERR_UNSUPPORTED || mode == MMX_PP_PIPELINED) return rc;
     }
 #define PP_FAST_LAUNCH(T, W)                                                                              \

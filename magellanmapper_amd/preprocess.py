@@ -143,6 +143,7 @@ class Preprocessor:
         self._scratch = None
         self._info = [None] * N_BUFFER_SETS
         self._work = None
+        self._last_use = None           # (stream, event) of the most recent run: orders the reuse of `_work` / `_info`
         self._weights = None
         self._tmpl_key = None
         self._tmpl, self._qc_rows, self._qc_index = {}, [], {}
@@ -414,6 +415,11 @@ class Preprocessor:
         d_w = self._weights[1]
         vol = dvol.view(channel, False)
         stream = torch.cuda.current_stream().cuda_stream
+        # `_work` and the `_info` sets are reused in STREAM order: a run queued on another stream than the one before it
+        # (blob_log.PRE_STREAM toggled between calls, a caller's own stream) first waits for that run's kernels
+        last = self._last_use
+        if last is not None and last[0] != stream:
+            torch.cuda.current_stream().wait_event(last[1])
         item = nat.SUBBLOCK_DTYPE.itemsize
         info_ptr = d_info.data_ptr() if d_info is not None else None
         if n_fast:
@@ -435,6 +441,9 @@ class Preprocessor:
                     dst_sy, dst_sz, out32.data_ptr(), out64.data_ptr(),
                     (info_ptr + first * nat.SUBINFO_DTYPE.itemsize) if info_ptr else None,
                     scratch.data_ptr(), int(scratch.numel()), stream), "mmx_preprocess_batch_generic")
+        used = torch.cuda.Event()
+        used.record()
+        self._last_use = (stream, used)
         self.last_subs = subs.copy() if self.want_info else None
         self._keep = (d_subs, d_qc, d_info)
         if self.want_info:

@@ -66,11 +66,18 @@ class Image5d:
     def prefetch(self):
         """Start the upload of the first time point now (``blob_log.DeviceVolume``: z-slabs on a copy stream); a later
         whole-image ``detect_blobs_blocks`` / ``detect_blobs_stack`` of this image detects on it while the rest is still
-        in flight.  What `detect_blobs_tiles` calls for tile k + 1 before it detects tile k."""
+        in flight.  What `detect_blobs_tiles` calls for tile k + 1 before it detects tile k.  The image must stay as it is
+        until the detection has returned or :meth:`release` has been called (the upload reads it in the background)."""
         from . import blob_log as bl
         if self.device_volume is None and self.img is not None:
-            self.device_volume = bl.DeviceVolume(self.img[0])
+            self.device_volume = bl.DeviceVolume(self.img[0], streamed=True)
         return self
+
+    def release(self):
+        """Drop the prefetched device copy, cancelling whatever of its upload has not been queued yet."""
+        dv, self.device_volume = self.device_volume, None
+        if dv is not None:
+            dv.close()
 
 
 class _TableArena:
@@ -656,8 +663,14 @@ class StackDetector:
                     pruner.advance()
             return tbl
 
+        own_dvol = None
         if mine:
-            dvol = img if isinstance(img, bl.DeviceVolume) else bl.DeviceVolume(img)
+            if isinstance(img, bl.DeviceVolume):
+                dvol = img
+            else:
+                # a host image handed over for the length of this call: it goes up beside the detection of the blocks
+                # that have landed, and whatever of it this rank's blocks never touched is cancelled before returning
+                dvol = own_dvol = bl.DeviceVolume(img, streamed=True)
             sink = None
             if arena is not None and n_extra == 0:
                 flat_offsets = np.asarray(sub_rois_offsets, dtype=np.float64).reshape(-1, 3)    # (C order: coords' order)
@@ -684,6 +697,9 @@ class StackDetector:
                         except Exception:       # (the detection's own exception is the one to report)
                             pass
                 raise
+            finally:
+                if own_dvol is not None:
+                    own_dvol.close()
             if sink is not None and sink.pruner is not None:
                 pruner = sink.pruner
         cls.last_stats = stats
@@ -966,19 +982,27 @@ def detect_blobs_tiles(filename_bases, tiles, channels=None, coloc: bool = False
     file (stack_detect.py:338-517); placing the tables in a common frame is the caller's (the importer's) business."""
     it = iter(tiles)
     names = iter(filename_bases) if not isinstance(filename_bases, str) else None
-    cur = next(it, None)
-    if cur is not None:
-        cur.prefetch()
-    k = 0
-    while cur is not None:
-        nxt = next(it, None)
-        if nxt is not None:
-            nxt.prefetch()                          # (its copies are queued on its own stream before tile k's kernels)
-        base = f"{filename_bases}_{k}" if names is None else next(names)
-        _, _, blobs = detect_blobs_blocks(base, cur, None, None, channels, False, save_dfs, True, coloc)
-        cur.device_volume = None                    # (the tile's voxels leave the device with it)
-        yield k, blobs
-        cur, k = nxt, k + 1
+    cur = nxt = None
+    try:
+        cur = next(it, None)
+        if cur is not None:
+            cur.prefetch()
+        k = 0
+        while cur is not None:
+            nxt = next(it, None)
+            if nxt is not None:
+                nxt.prefetch()                      # (its copies are queued on its own stream before tile k's kernels)
+            base = f"{filename_bases}_{k}" if names is None else next(names)
+            _, _, blobs = detect_blobs_blocks(base, cur, None, None, channels, False, save_dfs, True, coloc)
+            cur.release()                           # (the tile's voxels leave the device with it)
+            yield k, blobs
+            cur, nxt, k = nxt, None, k + 1
+    finally:
+        # a failed detection, or a consumer that stops early (GeneratorExit): the uploads still in flight are cancelled
+        # and joined before their device blocks go back to the allocator
+        for tile in (cur, nxt):
+            if tile is not None:
+                tile.release()
 
 
 def _save_pruning_ratios(df):

@@ -3,8 +3,11 @@ z-slab beside the detection: ``_SlabUpload``) and the host-side ``img_as_float``
 Split out of ``blob_log.py`` (round 5); ``blob_log`` re-exports the public names."""
 from __future__ import annotations
 
+import atexit
 import bisect
+import os
 import threading
+import weakref
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Tuple
 
@@ -40,12 +43,22 @@ class DeviceVolume:
     Integer images other than uint8/uint16 and float16 are converted like
     ``skimage.img_as_float`` would (to float64) on the host first.  For a float64 image a
     float32 copy feeds the float32 passes; the exact re-score reads the float64 original.
+
+    ``streamed``: how a large host image gets there.  ``False``: one synchronous copy -- the constructor returns with
+    the voxels read.  ``True``: z-slab by z-slab on a copy stream beside the detection (:class:`_SlabUpload`); the
+    constructor returns BEFORE the source has been read, and the caller promises to leave the source untouched until
+    :meth:`wait_all` / :meth:`close` (``stack_detect`` opts in for the images it is handed for the length of one call,
+    ``Image5d.prefetch`` for the tile it announces).  ``None`` (default): streamed only where nobody can write behind
+    the copy -- read-only arrays and read-only memory maps (what the reference's importer hands over,
+    importer.py:794) -- and synchronous for ordinary writeable arrays and pinned tensors, which a caller may well
+    refill right after this returns (a double-buffered tile).
     """
 
     _upload = None          # the z-slab upload still in flight (`_SlabUpload`), if any
 
-    def __init__(self, image, device: Optional["torch.device"] = None):
+    def __init__(self, image, device: Optional["torch.device"] = None, streamed: Optional[bool] = None):
         dev = device or _require_gpu()
+        want_stream = STREAM_UPLOAD and streamed is not False
         if isinstance(image, torch.Tensor):
             t = image
             np_dtype = np.dtype(str(t.dtype).replace("torch.", ""))
@@ -58,7 +71,7 @@ class DeviceVolume:
                 raise TypeError(f"unsupported voxel type {np_dtype}")
             if arr.ndim not in (3, 4):
                 raise ValueError("image must be (z, y, x) or (z, y, x, c)")
-            if arr.nbytes > _STREAM_MIN_BYTES and STREAM_UPLOAD:
+            if arr.nbytes > _STREAM_MIN_BYTES and want_stream and (streamed or not arr.flags.writeable):
                 # large host images (the reference's callers hand a memory-mapped image5d.npy, importer.py:794) go up
                 # z-slab by z-slab on a copy stream; detection starts on the blocks whose slabs have landed
                 t = None
@@ -68,7 +81,7 @@ class DeviceVolume:
                 t = torch.from_numpy(np.array(arr) if not arr.flags.writeable else np.ascontiguousarray(arr))
         if np_dtype not in _NP_TO_MMX:
             raise TypeError(f"unsupported voxel type {np_dtype}")
-        if t is not None and t.device.type == "cpu" and t.is_pinned() and STREAM_UPLOAD and \
+        if t is not None and t.device.type == "cpu" and t.is_pinned() and want_stream and streamed and \
                 t.numel() * t.element_size() > _STREAM_MIN_BYTES and t.is_contiguous():
             self._upload = _SlabUpload(t, dev)          # (pinned source: DMA straight from it, no staging thread)
             self.tensor = self._upload.out
@@ -102,14 +115,34 @@ class DeviceVolume:
             if st is not None:
                 st.wait_event(ev)
         if up.all_queued() and up.events[-1].query():
+            up.finish()
             self._upload = None             # everything has landed: later calls cost nothing
 
     def wait_all(self) -> None:
-        """Host-side wait for the whole upload (readers of the voxels outside the batched detection)."""
+        """Host-side wait for the whole upload (readers of the voxels outside the batched detection); from here on the
+        source is no longer read."""
         up = self._upload
         if up is not None:
             up.event_for(self.shape[0]).synchronize()
+            up.finish()
             self._upload = None
+
+    def close(self) -> None:
+        """Done with this volume, whether or not its upload has finished (a share of the blocks that ends early, a
+        partial ROI, a failed detection, an abandoned tile): slabs not yet staged are dropped, the staging thread is
+        joined, and the copies already queued keep the device allocation alive until they have run (the allocation
+        is recorded on the copy stream), so that the block can go back to the allocator at once without a DMA still
+        writing into it.  The source is not read after this returns unless copies of a PINNED source were queued --
+        those are waited for here (the DMA reads the caller's buffer directly)."""
+        up, self._upload = self._upload, None
+        if up is not None:
+            up.cancel()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # (interpreter shutdown)
+            pass
 
     def value_scale(self) -> float:
         """Magnitude of the image values after ``img_as_float`` (1 for integer images)."""
@@ -156,26 +189,95 @@ class DeviceVolume:
         return nat.Volume(ptr, code, 0, int(sz), int(sy), int(sx))
 
 
-#: host images above this size go to the device z-slab by z-slab on a copy stream (`_SlabUpload`); 0 / False keeps
-#: the one synchronous copy (tests compare the two)
+#: host images above this size go to the device z-slab by z-slab on a copy stream (`_SlabUpload`) when the caller allows
+#: it (`DeviceVolume(streamed=...)`); 0 / False keeps the one synchronous copy (tests compare the two)
 _STREAM_MIN_BYTES = 64 << 20
 _STREAM_CHUNK_BYTES = 128 << 20
 STREAM_UPLOAD = True
-#: threads that fill a pinned staging buffer from a pageable / memory-mapped source (one memcpy stream reads ~10 GB/s,
-#: the link takes 57)
-_STAGE_THREADS = 4
+#: threads that fill the pinned staging buffers from a pageable / memory-mapped source.  One memcpy stream reads
+#: ~10 GB/s, the link takes 55-57: four threads (round 5) left a memory-mapped C3 volume staging-bound (8.6 GB / ~40
+#: GB/s = 215 ms against 150 ms of DMA); 0 = a quarter of the cores, between 4 and 16
+_STAGE_THREADS = 0
+#: pinned staging buffers of one upload in flight (each one slab): with three the threads fill slab k + 2 while the
+#: DMA reads slab k and slab k + 1 waits its turn
+_STAGE_DEPTH = 3
+#: page-locked staging memory kept between uploads (bytes); buffers beyond it are freed when their upload ends
+_STAGING_KEEP_BYTES = 1 << 30
 _UPLOAD_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
-_STAGING: Dict[Tuple[str, int], list] = {}          # (dtype, elements) -> free pairs of pinned staging buffers
+_STAGING: List["torch.Tensor"] = []                 # free pinned staging buffers (uint8), any size
 _STAGING_LOCK = threading.Lock()
+_LIVE_UPLOADS: "weakref.WeakSet" = weakref.WeakSet()
+_QUEUES_CHECKED = [False]
+
+
+def _stage_threads() -> int:
+    n = int(_STAGE_THREADS)
+    if n <= 0:
+        n = max(4, min(16, (os.cpu_count() or 8) // 4))
+    return n
+
+
+def _take_staging(nbytes: int) -> "torch.Tensor":
+    """A pinned uint8 buffer of at least ``nbytes``: the smallest free one that is large enough, else a new one
+    (pinning 128 MiB takes tens of ms, which is why they are kept)."""
+    with _STAGING_LOCK:
+        fit = [b for b in _STAGING if b.numel() >= nbytes]
+        if fit:
+            buf = min(fit, key=lambda b: b.numel())
+            _STAGING.remove(buf)
+            return buf
+    return torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+
+
+def _give_staging(bufs) -> None:
+    with _STAGING_LOCK:
+        for b in bufs:
+            if sum(x.numel() for x in _STAGING) + b.numel() <= _STAGING_KEEP_BYTES:
+                _STAGING.append(b)
+
+
+def release_staging() -> None:
+    """Drop the pinned staging buffers and the copy streams kept between uploads (``buffers.release_buffers``)."""
+    with _STAGING_LOCK:
+        _STAGING.clear()
+    _UPLOAD_STREAMS.clear()
+
+
+def _check_hw_queues() -> None:
+    """Once per process, at the first streamed upload: the copy stream needs a hardware queue of its own, which takes
+    ``GPU_MAX_HW_QUEUES`` >= 8 read WHEN THE HIP RUNTIME STARTS (magellanmapper_amd/__init__ sets it at import; a host
+    application that initialised the GPU before importing this package, or that set a smaller value itself, gets the
+    default 4 and kernels queue behind the copies: 302 against 254 ms per tile)."""
+    if _QUEUES_CHECKED[0]:
+        return
+    _QUEUES_CHECKED[0] = True
+    import warnings
+    from . import GPU_WAS_INITIALISED_AT_IMPORT
+    try:
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        queues = 4
+    if GPU_WAS_INITIALISED_AT_IMPORT or queues < 8:
+        warnings.warn(
+            "magellanmapper_amd: uploads that run beside the detection want GPU_MAX_HW_QUEUES >= 8 set before the HIP "
+            f"runtime starts (now: {queues}{', and the GPU was initialised before this package was imported' if GPU_WAS_INITIALISED_AT_IMPORT else ''}); "
+            "the copy stream may share a hardware queue with a kernel stream, which costs up to 20 % per streamed tile",
+            RuntimeWarning, stacklevel=3)
 
 
 class _SlabUpload:
     """A host ``(z, y, x[, c])`` image on its way to the device, z-slab by z-slab, on a stream of its own: one event
     per slab, so that the detection of the blocks a slab completes can start while the rest is still in flight (blocks
     are consumed in z-major order).  A pinned source is read by the DMA engine directly -- every copy is queued at once;
-    a pageable or memory-mapped one goes through two pinned staging buffers filled by a few host threads."""
+    a pageable or memory-mapped one goes through a small ring of pinned staging buffers filled by a few host threads.
+
+    Lifetime: the device allocation is recorded on the copy stream (``record_stream``), so dropping the volume while
+    copies are in flight cannot hand the block to another allocation before they have run; :meth:`cancel` drops the
+    slabs not yet staged and joins the staging thread; the source must stay untouched until the upload has finished or
+    been cancelled."""
 
     def __init__(self, src, dev):
+        _check_hw_queues()
         if isinstance(src, torch.Tensor):
             shape, tdtype, itemsize = tuple(src.shape), src.dtype, src.element_size()
         else:
@@ -190,12 +292,18 @@ class _SlabUpload:
         self.n_slabs = -(-self.nz // self.slab) if self.nz else 0
         self.cv = threading.Condition()
         self.error: Optional[BaseException] = None
+        self.cancelled = False
+        self.thread: Optional[threading.Thread] = None
+        self._keep = None
         # ONE copy stream per device for every upload: streams are dealt to the hardware queues round-robin as they are
         # made, so a stream per volume would sooner or later share a queue with a kernel stream (magellanmapper_amd/__init__)
         self.stream = _UPLOAD_STREAMS.get(str(dev))
         if self.stream is None:
             self.stream = _UPLOAD_STREAMS[str(dev)] = torch.cuda.Stream(dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))        # (the allocation above)
+        # the block is written from the copy stream: the allocator must not reuse it before that stream is through with it
+        self.out.record_stream(self.stream)
+        _LIVE_UPLOADS.add(self)
         if self.nz == 0:
             ev = torch.cuda.Event()
             ev.record(self.stream)
@@ -213,56 +321,86 @@ class _SlabUpload:
             self._keep = src                       # (the source must outlive the copies)
         else:
             arr = src.numpy() if isinstance(src, torch.Tensor) else src
-            self.thread = threading.Thread(target=self._stage, args=(arr, tdtype), daemon=True)
+            self.thread = threading.Thread(target=self._stage, args=(arr, tdtype, itemsize), daemon=True,
+                                           name="mmx-upload")
             self.thread.start()
 
     def all_queued(self) -> bool:
         return len(self.events) >= max(1, self.n_slabs)
 
-    def _stage(self, arr, tdtype):
+    def finish(self) -> None:
+        """Every copy has completed (the caller has seen the last event): the source is released, the thread gone."""
+        th, self.thread = self.thread, None
+        if th is not None and th is not threading.current_thread():
+            th.join()
+        self._keep = None
+
+    def cancel(self) -> None:
+        """Give the upload up: slabs not yet staged are dropped (waiters are told), the staging thread is joined; copies
+        of a pinned source that are already queued cannot be recalled and are waited for, because the DMA reads the
+        caller's buffer.  Safe to call more than once and after the upload has finished."""
+        with self.cv:
+            self.cancelled = True
+            self.cv.notify_all()
+        th, self.thread = self.thread, None
+        if th is not None and th is not threading.current_thread():
+            th.join()
+        if self._keep is not None:
+            if self.events:
+                self.events[-1].synchronize()
+            self._keep = None
+
+    def _stage(self, arr, tdtype, itemsize):
+        stage: List = []
+        done: List = []
         try:
             torch.cuda.set_device(self.dev)
-            shape1 = (self.slab,) + tuple(arr.shape[1:])
-            key = (str(tdtype), int(np.prod(shape1)))
-            # (pinning 128 MiB takes tens of ms: a pair of buffers is kept for the next volume; two uploads at once --
-            #  tile k + 1 behind tile k -- each take their own pair)
-            with _STAGING_LOCK:
-                free = _STAGING.setdefault(key, [])
-                stage = free.pop() if free else None
-            if stage is None:
-                stage = [torch.empty(key[1], dtype=tdtype).pin_memory() for _ in range(2)]
-            done = [None, None]
-            with ThreadPoolExecutor(_STAGE_THREADS) as pool:
+            inner = tuple(arr.shape[1:])
+            per_plane = int(np.prod(inner))
+            slab_bytes = self.slab * per_plane * itemsize
+            depth = max(2, min(int(_STAGE_DEPTH), self.n_slabs))
+            stage = [_take_staging(slab_bytes) for _ in range(depth)]
+            done = [None] * depth
+            n_thr = _stage_threads()
+            if isinstance(arr, np.memmap):
+                _advise_sequential(arr)
+            with ThreadPoolExecutor(n_thr, thread_name_prefix="mmx-stage") as pool:
                 for k, z0 in enumerate(range(0, self.nz, self.slab)):
+                    if self.cancelled:
+                        break
                     z1 = min(z0 + self.slab, self.nz)
-                    buf = stage[k & 1][:(z1 - z0) * int(np.prod(arr.shape[1:]))].view((z1 - z0,) + tuple(arr.shape[1:]))
-                    if done[k & 1] is not None:
-                        done[k & 1].synchronize()          # the DMA that last used this buffer
+                    which = k % depth
+                    n_el = (z1 - z0) * per_plane
+                    buf = stage[which][:n_el * itemsize].view(tdtype).view((z1 - z0,) + inner)
+                    if done[which] is not None:
+                        done[which].synchronize()          # the DMA that last used this buffer
                     host = buf.numpy()
-                    cuts = np.linspace(0, z1 - z0, min(_STAGE_THREADS, z1 - z0) + 1).astype(int)
+                    cuts = np.linspace(0, z1 - z0, min(n_thr, z1 - z0) + 1).astype(int)
                     list(pool.map(lambda ab: np.copyto(host[ab[0]:ab[1]], arr[z0 + ab[0]:z0 + ab[1]]),
                                   zip(cuts[:-1], cuts[1:])))
+                    if self.cancelled:
+                        break
                     with torch.cuda.stream(self.stream):
                         self.out[z0:z1].copy_(buf, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record()
-                    done[k & 1] = ev
+                    done[which] = ev
                     with self.cv:
                         self.bounds.append(z1)
                         self.events.append(ev)
                         self.cv.notify_all()
-            for ev in done:
-                if ev is not None:
-                    ev.synchronize()               # (the buffers go back only when the DMA has read them)
-            with _STAGING_LOCK:
-                if len(_STAGING) > 4:
-                    _STAGING.clear()
-                if len(_STAGING.setdefault(key, [])) < 2:
-                    _STAGING[key].append(stage)
         except BaseException as exc:               # (reported by whoever waits for a slab)
             with self.cv:
                 self.error = exc
                 self.cv.notify_all()
+        finally:
+            try:
+                for ev in done:
+                    if ev is not None:
+                        ev.synchronize()           # (the buffers go back only when the DMA has read them)
+                _give_staging(stage)
+            except BaseException:                  # (interpreter shutdown / a lost device: the buffers are dropped)
+                pass
 
     def event_for(self, z_hi: int):
         """The event after which planes ``[0, z_hi)`` are on the device (waits until its copy has been queued)."""
@@ -276,7 +414,35 @@ class _SlabUpload:
                     return self.events[i]
                 if self.all_queued():
                     return self.events[-1]
+                if self.cancelled:
+                    raise nat.MmxError("upload of the image was cancelled (DeviceVolume.close) before these planes went up")
                 self.cv.wait(0.5)
+
+
+def _advise_sequential(arr) -> None:
+    """Tell the kernel a memory map is about to be read front to back (read-ahead on a file-backed map; harmless on
+    tmpfs).  Best effort: a map this Python cannot advise is read as it is."""
+    try:
+        import mmap as _mmap
+        mm = getattr(arr, "_mmap", None)
+        if mm is not None and hasattr(mm, "madvise"):
+            mm.madvise(_mmap.MADV_SEQUENTIAL)
+            if hasattr(_mmap, "MADV_WILLNEED"):
+                mm.madvise(_mmap.MADV_WILLNEED)
+    except (OSError, ValueError, AttributeError):
+        pass
+
+
+def _cancel_live_uploads() -> None:
+    """At interpreter exit: no staging thread may still be inside HIP calls when the runtime is torn down."""
+    for up in list(_LIVE_UPLOADS):
+        try:
+            up.cancel()
+        except BaseException:
+            pass
+
+
+atexit.register(_cancel_live_uploads)
 
 
 def _img_as_float_host(arr: np.ndarray) -> np.ndarray:

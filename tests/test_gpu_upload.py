@@ -68,9 +68,10 @@ def test_pinned_source_is_copied_without_staging_and_partial_waits_work(gpu, mon
     monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 8 * vol[0].nbytes)
     src = torch.from_numpy(vol.view(np.int16)).pin_memory() if not hasattr(torch, "uint16") else \
         torch.from_numpy(vol).pin_memory()
-    dv = bl.DeviceVolume(src)
+    assert bl.DeviceVolume(src)._upload is None          # (a writeable buffer: copied before the constructor returns)
+    dv = bl.DeviceVolume(src, streamed=True)
     up = dv._upload
-    assert up is not None and not hasattr(up, "thread") and up.n_slabs == 8 and up.all_queued()
+    assert up is not None and up.thread is None and up.n_slabs == 8 and up.all_queued()
     assert up.event_for(1) is up.events[0] and up.event_for(8) is up.events[0] and up.event_for(9) is up.events[1]
     assert up.event_for(64) is up.events[-1]
     side = torch.cuda.Stream()
@@ -161,3 +162,88 @@ def test_small_uploads_through_the_pinned_ring_arrive_intact(gpu):
     f = rng.standard_normal((300, 5))
     assert np.array_equal(buffers.to_device(f, dev).cpu().numpy(), f)
     assert buffers.to_device(np.zeros((0, 3)), dev).shape == (0, 3)
+
+
+def test_writeable_sources_are_copied_before_the_constructor_returns(gpu, monkeypatch):
+    """The default: an ordinary array or a pinned tensor may be refilled right after ``DeviceVolume(...)`` returns (a
+    double-buffered tile), so it is copied synchronously; only sources nobody can write to -- read-only arrays, read-only
+    memory maps -- go up in the background without being asked."""
+    from magellanmapper_amd import blob_log as bl, synth, volume
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 4 * 48 * 56 * 2)
+    vol = synth.make_volume(8, (40, 48, 56), 10)
+    keep = vol.copy()
+    dv = bl.DeviceVolume(vol)
+    assert dv._upload is None
+    vol[:] = 0                                      # the caller reuses its buffer at once
+    np.testing.assert_array_equal(dv.tensor.cpu().numpy().view(keep.dtype), keep)
+    ro = keep.copy()
+    ro.flags.writeable = False
+    dv2 = bl.DeviceVolume(ro)
+    assert dv2._upload is not None and dv2._upload.n_slabs == 10
+    dv2.wait_all()
+    assert dv2._upload is None
+    np.testing.assert_array_equal(dv2.tensor.cpu().numpy().view(keep.dtype), keep)
+    assert bl.DeviceVolume(ro, streamed=False)._upload is None
+
+
+def test_close_cancels_what_has_not_been_staged_and_joins_the_thread(gpu, monkeypatch):
+    """``DeviceVolume.close`` in the middle of an upload (a share of blocks that ends early, a failed detection, an
+    abandoned tile): the staging thread stops at the next slab and is joined, waiters for later planes are told, the
+    slabs already queued still land, and the device block can go back to the allocator at once -- the copy stream holds
+    it (``record_stream``) until its copies have run."""
+    import time
+    from magellanmapper_amd import _native as nat, blob_log as bl, volume
+
+    class Slow(np.ndarray):
+        def __getitem__(self, item):
+            time.sleep(0.02)
+            return super().__getitem__(item)
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 2 * 32 * 32 * 2)
+    monkeypatch.setattr(volume, "_STAGE_THREADS", 2)
+    data = np.arange(64 * 32 * 32, dtype=np.uint16).reshape(64, 32, 32)
+    dv = bl.DeviceVolume.__new__(bl.DeviceVolume)
+    dv._upload = up = bl._SlabUpload(data.view(Slow), torch.device("cuda", 0))
+    dv.tensor, dv.shape = up.out, (64, 32, 32)
+    dv.stream_wait(2)                               # the first slab has been queued
+    dv.close()
+    assert dv._upload is None and up.thread is None and up.cancelled
+    n_done = len(up.events)
+    assert 1 <= n_done < up.n_slabs
+    with pytest.raises(nat.MmxError, match="cancelled"):
+        up.event_for(64)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(up.out[:up.bounds[n_done - 1]].cpu().numpy().view(np.uint16),
+                                  data[:up.bounds[n_done - 1]])
+    dv.close()                                      # (idempotent)
+    del dv, up
+    fresh = torch.zeros(64 * 32 * 32, dtype=torch.int16, device="cuda")     # may take the very block just freed
+    torch.cuda.synchronize()
+    assert int(fresh.abs().sum().item()) == 0
+
+
+def test_an_abandoned_tile_generator_releases_the_tile_it_prefetched(gpu, monkeypatch, tmp_path):
+    """A consumer that stops after the first tile: the generator's clean-up cancels the upload of the tile it had
+    announced and drops both device copies."""
+    from magellanmapper_amd import config, stack_detect, synth, volume
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 8 * 64 * 72 * 2)
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(dict(num_sigma=2, denoise_size=None, segment_size=40))
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "tiles"
+    tiles = []
+    for k in range(3):
+        np.save(tmp_path / f"a{k}.npy", synth.make_volume(50 + k, (48, 64, 72), 20)[None])
+        tiles.append(stack_detect.Image5d(np.load(tmp_path / f"a{k}.npy", mmap_mode="r")))
+    try:
+        gen = stack_detect.detect_blobs_tiles("tiles", tiles)
+        k, blobs = next(gen)
+        assert k == 0 and blobs.blobs is not None
+        ups = [t.device_volume._upload for t in tiles[1:] if t.device_volume is not None]
+        gen.close()
+        assert all(t.device_volume is None for t in tiles)
+        assert all(u is None or (u.thread is None and (u.cancelled or u.all_queued())) for u in ups)
+    finally:
+        config.setup_roi_profiles(None)
