@@ -285,10 +285,15 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
 
     # Each rank needs the z-range its blocks touch (blocks are z-major contiguous per rank).
     coords = list(np.ndindex(*grid))
-    lo, hi = dist.share_bounds(n_blocks, rank, world)
+    # --share k/N: this ONE process stands in for rank k of N (dist.Loopback: a recording in place of the wire)
+    share, wire = ctx.get("share"), ctx.get("wire")
+    eff_rank, eff_world = share if share else (rank, world)
+    lo, hi = dist.share_bounds(n_blocks, eff_rank, eff_world)
     zs = [blocks.sub_roi_slices[coords[i]][0] for i in range(lo, hi)]
     z0 = min(s.indices(shape[0])[0] for s in zs) if zs else 0
     z1 = max(s.indices(shape[0])[1] for s in zs) if zs else 1
+    if share:
+        z0, z1 = 0, shape[0]            # (the whole volume: the recording rounds play every rank once)
     t_gen = time.time()
     if use_vol is not None:
         slab = torch.from_numpy(np.ascontiguousarray(use_vol[z0:z1]).view(np.int16)).to(dev).view(torch.uint16)
@@ -316,7 +321,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             return v
 
     dvol = SlabVolume(slab, z0, shape)
-    timers = {"gather_ms": 0.0, "prune_ms": 0.0, "detect_ms": 0.0, "tail_ms": 0.0, "tail_exchange_ms": 0.0}
+    timers = {"gather_ms": 0.0, "prune_ms": 0.0, "detect_ms": 0.0, "tail_ms": 0.0, "tail_exchange_ms": 0.0,
+              "start_ms": 0.0, "last_batch_host_ms": 0.0}
 
     def finish(pruned):
         if pruned is None:
@@ -362,9 +368,14 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         # exchanges included) and the final columns
         timers["tail_ms"] += (t_c - bl.LAST_BATCH_DONE_T) * 1e3 if bl.LAST_BATCH_DONE_T >= t_a else 0.0
         timers["tail_exchange_ms"] += in_prune
+        # step begin -> first batch handed to the GPU; last batch seen done -> detect_blobs_sub_rois returns
+        timers["start_ms"] += (bl.FIRST_ENQUEUED_T - t_a) * 1e3 if bl.FIRST_ENQUEUED_T >= t_a else 0.0
+        timers["last_batch_host_ms"] += (t_b - bl.LAST_BATCH_DONE_T) * 1e3 if bl.LAST_BATCH_DONE_T >= t_a else 0.0
         return final, colocs, st
 
     def one_step():
+        if wire is not None:
+            wire.begin_step(eff_rank)
         return detect_and_prune(dvol, blocks)
 
     # workspace budget per batch: from the free HBM of this GPU unless given (ranks that share a GPU in the
@@ -402,6 +413,15 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             tdist.barrier()
         torch.cuda.synchronize()
 
+    if wire is not None:
+        # the recording: every rank of the N played twice by this process (the first round puts the rows near the seams
+        # on the tape, the second the survivors pruned with them), then rank k's steps replay it
+        wire.mode = "record"
+        for _ in range(2):
+            for q in range(eff_world):
+                wire.begin_step(q)
+                detect_and_prune(dvol, blocks)
+        wire.mode = "replay"
     nat.timing_enable(True)             # (the warm-up tells which kernel family dominates: the one the roofline is about)
     for _ in range(warmup):
         one_step()
@@ -526,7 +546,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                 pmc = json.load(f)
             fresh = pmc.get("source_digest") == source_digest()
             # (the counter passes ran the DEFAULT command: same volume, raw voxels, default batches, one rank)
-            usable = (fresh and name == "c3" and tuple(shape) == cfg["shape"] and world == 1 and
+            usable = (fresh and name == "c3" and tuple(shape) == cfg["shape"] and world == 1 and not share and
                       not PROFILE["denoise_size"] and use_vol is None and not args.budget_gb and
                       not args.segment_size and dom in pmc.get("per_launch_GB", {}))
             if usable:
@@ -583,8 +603,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     main_ms = sum(ms for k, (ms, n) in ktimes.items() if k in MAIN_STREAM and k not in overlapped) / steps
     b_alg = B_ALG_PER_SIGMA * ns * n_chl
     vol_bytes = nvox * n_chl * 2
-    frac_kernels = b_alg * (nvox / world) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    frac_wall = b_alg * nvox / (elapsed / steps) / 1e9 / HBM_PEAK_GBS / world
+    frac_kernels = b_alg * (nvox / eff_world) / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    frac_wall = b_alg * nvox / (elapsed / steps) / 1e9 / HBM_PEAK_GBS / eff_world
     for key, val in (("pipeline_roofline.frac_kernels", frac_kernels), ("pipeline_roofline.frac_wall", frac_wall),
                      ("roofline.frac", roof["frac"] if roof else 0)):
         if val > 1:
@@ -656,6 +676,20 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                     "volume pays this once per volume"},
         "kernels": per_kernel,
         "ranks": per_rank,
+        # --share k/N: a MODEL of rank k's step in an N-GPU run, measured on one GPU -- its blocks, its seam rows, the
+        # pruning of its rows between the recorded seam rows of its neighbours, the merge of every rank's recorded
+        # survivors: everything but the transfer (`value` = the whole volume / this step: what N such ranks would give)
+        "share": None if not share else {
+            "rank": eff_rank, "of": eff_world, "blocks": hi - lo, "batches": list(bl.LAST_BATCH_SIZES),
+            "step_ms": round(elapsed / steps * 1e3, 3),
+            "kernels_ms": round(gpu_ms, 3), "main_stream_kernels_ms": round(main_ms, 3),
+            "start_ms": round(step_timers["start_ms"] / steps, 3),
+            "last_batch_host_ms": round(step_timers["last_batch_host_ms"] / steps, 3),
+            "prune_and_merge_ms": round(step_timers["prune_ms"] / steps, 3),
+            "loopback_copy_ms": round(step_timers["gather_ms"] / steps, 3),
+            "tail_after_last_kernel_ms": round(step_timers["tail_ms"] / steps, 3),
+            "linear_ms": None if not ctx.get("full_step_ms") else round(ctx["full_step_ms"] / eff_world, 3),
+            "note": "MODEL, one GPU: no RCCL transfer in it; the merged table is the whole stack's (table_sha1)"},
         "detector_stats": {k: (round(float(v), 9) if isinstance(v, (float, np.floating)) else int(v))
                            for k, v in vars(stats).items()},
         # the analytic bound of the 16-bit intermediates' rounding error (mmx_tiled_q16_error_bound x value range) that
@@ -683,6 +717,201 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         np.savez(args.dump, final=np.zeros((0, 8)) if final is None else final,
                  colocs=np.zeros((0, n_chl), dtype=np.uint8) if colocs is None else colocs)
     return out
+
+
+def run_gpu_tiles(args, baseline, steps, warmup, ctx):
+    """configs[4] as what it is -- a TILED stack -- with the tiles sharded over the ranks (``--config c5 --tiles T
+    [--gpus N]``): every rank holds T tiles resident in HBM (tile g of the stack comes from seed + 2 g: tile 0 is the
+    volume the one-GPU c5 record detects) and one step detects each rank's tiles through
+    ``stack_detect.detect_blobs_tiles(shard="tiles")`` -- one whole-image detection per tile, as the reference makes one
+    call per file (stack_detect.py:338-517), no collective inside the timed region.  Per-GPU work is fixed as N grows:
+    ``"scaling": "weak"``; ``value`` = the voxels all ranks processed / the slowest rank's time."""
+    import torch
+    import torch.distributed as tdist
+    from magellanmapper_amd import _native as nat
+    from magellanmapper_amd import blob_log as bl
+    from magellanmapper_amd import config, dist, stack_detect, synth
+    rank, world, dev, backend = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"]
+    name = args.config
+    cfg, PROFILE, shape, n_chl, coloc = config_setup(name, args, None)
+    channels = list(range(n_chl))
+    config.resolutions = RESOLUTIONS
+    config.filename = "bench"
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(PROFILE)
+    for p in config.roi_profiles:
+        p.update(PROFILE)
+    config.near_max = [-1.0] * max(1, n_chl)
+    per_rank, total = int(args.tiles), int(args.tiles) * world
+    mine = dist.tile_share(total, rank, world)
+    t_gen = time.time()
+    resident = {}
+    for g in mine:
+        vol = synth.make_volume_device(shape, cfg["seed"] + 2 * g, dev)
+        if n_chl > 1:
+            c1 = synth.make_volume_device(shape, cfg["seed"] + 2 * g + 1, dev)
+            c1 = torch.maximum(c1.to(torch.int32), (vol.to(torch.int32) * 7) // 10).to(vol.dtype)
+            vol = torch.stack((vol, c1), dim=-1).contiguous()
+            del c1
+        resident[g] = bl.DeviceVolume(vol, dev)
+        del vol
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    # every tile of the stack as the image object the reference's callers hand over; a rank's own tiles are already on
+    # its device (`device_volume`), the others are never touched.  (`img`: the (t, z, y, x[, c]) geometry only -- a
+    # zero-stride view, no host copy of a resident benchmark tile exists)
+    geometry = np.broadcast_to(np.zeros(1, dtype=np.uint16), (1,) + tuple(shape) + ((n_chl,) if n_chl > 1 else ()))
+    tiles = [stack_detect.Image5d(geometry) for _ in range(total)]
+    if args.budget_gb > 0:
+        budget = int(args.budget_gb * (1 << 30))
+    else:
+        free_b, _ = torch.cuda.mem_get_info()
+        sharers = max(1, -(-world // max(1, torch.cuda.device_count()))) if backend != "nccl" else 1
+        budget = min(16 << 30, int(0.55 * free_b / sharers))
+    bl.blob_log_blocks = functools.partial(ctx["blob_log_blocks"], budget_bytes=budget)
+
+    parity = None
+    cpu = None
+    if baseline is not None and rank == 0:
+        cpu, cpu_final, sample = baseline["cpu"], baseline["final"], baseline["sample"]
+        with dist.solo():
+            _, _, got = stack_detect.detect_blobs_blocks("bench", stack_detect.Image5d(sample[None]), None, None,
+                                                         channels, False, False, True, coloc)
+        parity = bool(cpu_final is not None and got.blobs is not None and got.blobs.shape == cpu_final.shape and
+                      np.array_equal(canon(got.blobs), canon(cpu_final)))
+        if parity and baseline.get("colocs") is not None:
+            parity = bool(np.array_equal(got.blobs, cpu_final) and got.colocalizations is not None and
+                          np.array_equal(got.colocalizations, baseline["colocs"]))
+
+    tile_ms = {g: [] for g in mine}
+
+    def one_step():
+        for g in mine:
+            tiles[g].device_volume = resident[g]
+        out = []
+        t_prev = time.perf_counter()
+        for g, blobs in stack_detect.detect_blobs_tiles("bench", tiles, channels, coloc, shard="tiles"):
+            now = time.perf_counter()
+            tile_ms[g].append((now - t_prev) * 1e3)
+            t_prev = now
+            out.append((g, blobs))
+        return out
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    for g in mine:
+        tile_ms[g].clear()
+    nat.timing_read()
+    nat.timing_enable(args.kernel_events != "none")
+    barrier()
+    t0 = time.perf_counter()
+    results = []
+    for _ in range(steps):
+        results = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = nat.timing_read()
+    nat.timing_enable(False)
+    if args.kernel_events == "none":
+        nat.timing_enable(True)
+        one_step()
+        torch.cuda.synchronize()
+        ktimes = {k: (ms * steps, n * steps) for k, (ms, n) in nat.timing_read().items()}
+        nat.timing_enable(False)
+    # after the timed region: every rank's tables on every rank (two small all-gathers), timed apart
+    t_g = time.perf_counter()
+    everything = stack_detect.gather_tiles(results)
+    gather_ms = (time.perf_counter() - t_g) * 1e3
+
+    def sha(a):
+        return None if a is None else hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+    digests = [(g, sha(b.blobs), sha(b.colocalizations), 0 if b.blobs is None else int(len(b.blobs))) for g, b in everything]
+    per_rank_rec = None
+    if world > 1:
+        cdev = dev if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        own_ms = float(np.mean([np.mean(v) for v in tile_ms.values()])) if tile_ms else 0.0
+        mine_t = torch.tensor([elapsed / steps * 1e3, own_ms, sum(ms for ms, n in ktimes.values()) / steps, float(len(mine)),
+                               gather_ms], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine_t) for _ in range(world)]
+        tdist.all_gather(allr, mine_t)
+        per_rank_rec = [dict(zip(("step_ms", "ms_per_tile", "kernel_ms", "tiles", "gather_ms"),
+                                 (round(float(v), 2) for v in r.cpu()))) for r in allr]
+        elapsed = float(t.item())
+    resident.clear()
+    bl.release_buffers()
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    nvox = int(np.prod(shape))
+    ns = PROFILE["num_sigma"]
+    my_vox = nvox * n_chl * len(mine)
+    per_kernel = {}
+    for k, (ms, n) in ktimes.items():
+        if n:
+            per_kernel[k] = {"ms_per_step": round(ms / steps, 3), "launches_per_step": n // steps}
+            if k in ALG_BYTES:
+                per_kernel[k]["alg_GBps"] = round(ALG_BYTES[k] * my_vox * ns * steps / (ms * 1e-3) / 1e9, 1)
+    stream_k = {k: v for k, v in per_kernel.items() if k in ALG_BYTES}
+    dom = max(stream_k, key=lambda k: stream_k[k]["ms_per_step"]) if stream_k else None
+    roof = None
+    if dom:
+        launches = ktimes[dom][1]
+        roof = {"bound": "hbm", "kernel": dom, "achieved": stream_k[dom]["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(stream_k[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),
+                "alg_bytes_per_launch": int(ALG_BYTES[dom] * my_vox * ns * steps / max(1, launches)),
+                "avg_launch_ms": round(ktimes[dom][0] / max(1, launches), 4), "traffic": None,
+                "copy_GBps": ctx.get("copy_gbps"),
+                "note": "rank 0's launches of the dominant LoG kernel over the timed region (HIP events on its launch stream); "
+                        "achieved = SURVEY.md 8d's algorithmic bytes of this pass / that time; no counter pass was taken for "
+                        "this command (traffic null): the kernel is the one profiles/r06_pmc_counters.json describes, here on "
+                        "preprocessed float voxels"}
+    ms_tile = elapsed / steps * 1e3 / max(1, per_rank)
+    b_alg = B_ALG_PER_SIGMA * ns * n_chl
+    tile0 = next((d for d in digests if d[0] == 0), None)
+    return {
+        "metric": cfg["metric"] + f"; tiled stack, {per_rank} tile(s) per GPU sharded by tile",
+        "value": round(nvox * total * steps / elapsed / 1e6, 2), "unit": "Mvoxels/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64 preprocessing; " + ZX_DTYPES.get(bl.LAST_ZX_PATH, "f32; f64 re-score of every candidate")
+                 if PROFILE["denoise_size"] else ZX_DTYPES.get(bl.LAST_ZX_PATH, "f32; f64 re-score of every candidate"),
+        "data": "synthetic",
+        "config": {"workload": f"{name} tiled: {total} tiles of {shape[2]}x{shape[1]}x{shape[0]} (x,y,z) x {n_chl} channel(s) "
+                               f"uint16 (tile g: seeds {cfg['seed']} + 2 g [, + 1]), {cfg['what']}; one whole-image detection "
+                               "per tile (detect + prune + final table), tiles resident in HBM",
+                   "tiles_per_rank": per_rank, "tiles_total": total,
+                   "parallelism": f"tiles r, r + N, ... on rank r of {world}; no collective in the timed region",
+                   "batch_budget_GB": round(budget / (1 << 30), 1)},
+        "ms_per_tile": round(ms_tile, 2),
+        "Mvoxels_per_s_per_gpu": round(nvox * per_rank * steps / elapsed / 1e6, 2),
+        "ranks": per_rank_rec,
+        "tile_ms_rank0": {str(g): round(float(np.mean(v)), 2) for g, v in tile_ms.items() if v},
+        "tiles": [{"tile": g, "table_sha1": a, "colocs_sha1": c, "blobs": n} for g, a, c, n in digests],
+        "tile0_is_the_c5_record_volume": None if tile0 is None else {"table_sha1": tile0[1], "colocs_sha1": tile0[2],
+                                                                     "blobs": tile0[3]},
+        "blobs": int(sum(d[3] for d in digests)),
+        "blobs_per_s": round(sum(d[3] for d in digests) * steps / elapsed, 1),
+        "gather_tiles_ms_rank0": round(gather_ms, 2),
+        "roofline": roof,
+        "pipeline_roofline": {"alg_bytes_per_voxel": b_alg,
+                              "gpu_kernel_ms_per_step_rank0": round(sum(ms for ms, n in ktimes.values()) / steps, 2),
+                              "frac_wall": round(b_alg * nvox * per_rank / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+        "kernels": per_kernel,
+        "cpu_baseline": cpu, "parity_sample_identical": parity,
+        "parity_sample_source": None if baseline is None else (
+            "committed oracle table " + baseline["committed"] if baseline.get("committed") else
+            "the oracle, run in this process before the GPU was initialised"),
+        "scipy": ctx.get("scipy"), "volume_gen_s": round(t_gen, 2),
+    }
 
 
 def from_host_record(kind, slab, z0, shape, volume_cls, detect_and_prune, blocks, rec, n_steps, n_tiles=1):
@@ -803,7 +1032,18 @@ def main():
                     help="after the timed region: steps that start from a HOST copy of the volume (upload overlapped "
                          "with the detection), reported as `from_host`")
     ap.add_argument("--tiles", type=int, default=1,
-                    help="with --from-host: also run this many consecutive tiles, each uploading beside its predecessor's detection")
+                    help="with --from-host: also run this many consecutive tiles, each uploading beside its predecessor's "
+                         "detection.  Without --from-host (or with --shard tiles): the workload as a TILED stack, this many "
+                         "resident tiles PER GPU, sharded by tile over the ranks -- a weak-scaling line, no collective in "
+                         "the timed region (configs[4] across N GPUs)")
+    ap.add_argument("--share", default=None, metavar="K/N",
+                    help="ONE process stands in for rank K of an N-GPU run of the workload: its share of the blocks, its "
+                         "seam rows, the pruning of its rows, the merge of all ranks' survivors, with a recording in place "
+                         "of the wire (dist.Loopback) -- a model of the strong-scaling step measured on one GPU")
+    ap.add_argument("--full-step-ms", type=float, default=0.0, help="with --share: the one-GPU step to quote linear scaling against")
+    ap.add_argument("--shard", choices=("blocks", "tiles"), default=None,
+                    help="N > 1: blocks of ONE volume over the ranks (strong scaling, the default) or whole tiles of a "
+                         "tiled stack (weak scaling; implied by --tiles T without --from-host)")
     ap.add_argument("--parity-sample", default=None, metavar="NPZ",
                     help="check the parity sample against this committed oracle table (tests/golden/make_bench_samples.py) "
                          "instead of running the oracle: no cpu_baseline timing, seconds instead of minutes")
@@ -813,6 +1053,9 @@ def main():
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     explicit = args.config is not None
     args.config = args.config or "c3"
+    by_tile = args.shard == "tiles" or (args.shard is None and args.tiles > 1 and not args.from_host)
+    if by_tile and (args.volume or args.from_host or args.dump):
+        raise SystemExit("--shard tiles generates its resident tiles itself: not with --volume / --from-host / --dump")
     host_vol = np.load(args.volume, mmap_mode="r") if args.volume else None
 
     rank = int(os.environ.get("RANK", "0"))
@@ -823,7 +1066,7 @@ def main():
     # before anything touches the GPU runtime (the host driver only supports dmabuf IPC)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     subs = [] if (explicit or args.no_sub_records or world > 1 or args.volume or args.shape or args.denoise
-                  or args.segment_size or args.dump) else list(SUB_RECORDS)
+                  or args.segment_size or args.dump or by_tile or args.share) else list(SUB_RECORDS)
 
     import torch
     import torch.distributed as tdist
@@ -872,7 +1115,16 @@ def main():
     from magellanmapper_amd import blob_log as bl
 
     import scipy
+    share = wire = None
+    if args.share:
+        if world > 1 or by_tile:
+            raise SystemExit("--share models ONE rank in ONE process: not with --gpus N > 1 or --shard tiles")
+        from magellanmapper_amd import dist as _dist
+        k_, n_ = (int(v) for v in args.share.split("/"))
+        share, wire = (k_, n_), _dist.Loopback(k_, n_)
+        _dist.set_loopback(wire)
     ctx = dict(rank=rank, world=world, dev=dev, backend=backend, blob_log_blocks=bl.blob_log_blocks,
+               share=share, wire=wire, full_step_ms=args.full_step_ms,
                # the one third-party routine whose implementation-defined order reaches the result (chain blocks of the
                # overlap prune: blob_log._reference_pair_order); fixtures were made with 1.7.1, tests run with this one
                scipy=scipy.__version__)
@@ -903,7 +1155,10 @@ def main():
         del a, b, hbuf, dbuf
         torch.cuda.empty_cache()
 
-    out = run_gpu(args.config, args, host_vol, baselines.get(args.config), args.steps, args.warmup, ctx)
+    if by_tile:
+        out = run_gpu_tiles(args, baselines.get(args.config), args.steps, args.warmup, ctx)
+    else:
+        out = run_gpu(args.config, args, host_vol, baselines.get(args.config), args.steps, args.warmup, ctx)
     if subs and out is not None:
         out["sub_records"] = {}
         for name in subs:

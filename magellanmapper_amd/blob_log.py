@@ -78,6 +78,10 @@ LAST_Q16_BOUND = 0.0
 LAST_NMS_BAND = 0.0
 #: host clock (time.perf_counter) at which the most recent batch's last kernel was seen complete
 LAST_BATCH_DONE_T = 0.0
+#: host clock at which the first batch of the most recent ``blob_log_blocks`` call had been handed to the GPU (the
+#: "start" of a step: block lists, plans, tables -> first launch), and the batch sizes of that call (bench.py --share)
+FIRST_ENQUEUED_T = 0.0
+LAST_BATCH_SIZES: list = []
 #: ``mmx_zx_mode`` passed with every ``mmx_log_batch_f32`` call (``MMX_FUSE`` in the environment overrides the
 #: default for kernel experiments; tests set it to cross-check the kernels against each other)
 ZX_MODE = int(os.environ.get("MMX_FUSE", nat.MMX_ZX_AUTO))
@@ -554,6 +558,9 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                                         if pre is not None else False, parity=enq)
             done_events.append(jobs[enq]["done"])
             jobs[enq]["batch"] = batch
+            if enq == 0:
+                global FIRST_ENQUEUED_T, LAST_BATCH_SIZES
+                FIRST_ENQUEUED_T, LAST_BATCH_SIZES = time.perf_counter(), [len(b_) for b_ in batches]
             enq += 1
         pending, jobs[k] = jobs[k], None
         # host + side-stream work of batch k, the GPU busy with the batches behind it

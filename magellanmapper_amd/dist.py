@@ -31,11 +31,62 @@ _solo = 0
 
 
 def rank() -> int:
-    return tdist.get_rank() if _active() and not _solo else 0
+    if _solo:
+        return 0
+    if _loopback is not None:
+        return _loopback.me
+    return tdist.get_rank() if _active() else 0
 
 
 def world_size() -> int:
-    return tdist.get_world_size() if _active() and not _solo else 1
+    if _solo:
+        return 1
+    if _loopback is not None:
+        return _loopback.world
+    return tdist.get_world_size() if _active() else 1
+
+
+class Loopback:
+    """ONE process standing in for rank ``me`` of ``world`` with a recording in place of the wire (``bench.py --share
+    k/N``, tests): ``rank()`` / ``world_size()`` / ``my_share()`` answer as that rank's would, and every collective of a
+    step -- the i-th ``all_reduce_sum`` / row exchange since :meth:`begin_step` -- hands back what the OTHER ranks
+    contributed to their i-th collective when this same process played them (mode ``"record"``: the own contribution is
+    stored; ranks not played yet contribute nothing).  Playing every rank twice fills the tape with what a real run
+    would put on the wire (the first round records the rows near the seams, which the second round's pruning needs);
+    ``"replay"`` then measures one rank's step with everything a rank does except the transfer itself -- and its merged
+    table is the whole stack's.  Installed with :func:`set_loopback`; never active unless a caller installs it."""
+
+    def __init__(self, me: int, world: int):
+        if not 0 <= int(me) < int(world):
+            raise ValueError(f"rank {me} of {world}")
+        self.me, self.world, self.mode, self.at = int(me), int(world), "record", 0
+        self.tape = {q: [] for q in range(self.world)}
+
+    def begin_step(self, me: Optional[int] = None) -> None:
+        if me is not None:
+            self.me = int(me)
+        self.at = 0
+
+    def exchange(self, own: np.ndarray):
+        """The i-th collective of the step: every rank's contribution, in rank order (``None``: not recorded yet)."""
+        i, self.at = self.at, self.at + 1
+        if self.mode == "record":
+            mine = self.tape[self.me]
+            while len(mine) <= i:
+                mine.append(None)
+            mine[i] = np.array(own, copy=True)
+        return [own if q == self.me else (self.tape[q][i] if i < len(self.tape[q]) else None)
+                for q in range(self.world)]
+
+
+_loopback: Optional[Loopback] = None
+
+
+def set_loopback(wire: Optional[Loopback]) -> None:
+    global _loopback
+    if wire is not None and _active():
+        raise RuntimeError("a loop-back wire stands in for a process group: not with one initialised")
+    _loopback = wire
 
 
 class solo:
@@ -64,6 +115,18 @@ def share_bounds(n_items: int, r: int, n_ranks: int) -> Tuple[int, int]:
 def my_share(n_items: int) -> List[int]:
     lo, hi = share_bounds(n_items, rank(), world_size())
     return list(range(lo, hi))
+
+
+def tile_share(n_tiles: int, r: Optional[int] = None, n_ranks: Optional[int] = None) -> List[int]:
+    """Tiles of a tiled stack that rank ``r`` detects when the stack is sharded BY TILE (``stack_detect.
+    detect_blobs_tiles(shard="tiles")``, BASELINE.json configs[4]): tiles r, r + N, r + 2N, ... -- round robin, so that
+    the split needs no tile count up front (tiles may come from an iterator) and consecutive tiles of a rank are N
+    apart on the stage: while one rank detects tile k the next ranks upload and detect k + 1 ... k + N - 1 on their own
+    PCIe links.  Every tile is an image of its own (the reference makes one ``detect_blobs_blocks`` call per file,
+    stack_detect.py:338-517), so this split has no exchange step at all."""
+    r = rank() if r is None else int(r)
+    n_ranks = world_size() if n_ranks is None else int(n_ranks)
+    return list(range(r, int(n_tiles), max(1, n_ranks)))
 
 
 def _device_for_collectives():
@@ -121,6 +184,7 @@ def gather_tables(local: Sequence[Tuple[int, Optional[np.ndarray]]], n_items: in
     _last_gather_ms = 0.0
     if not _multi_rank():
         return sorted(local, key=lambda e: e[0])
+    _no_loopback("gather_tables")
     import time
     t_start = time.perf_counter()
     dev = _device_for_collectives()
@@ -207,7 +271,7 @@ def raise_together(failure: Optional[BaseException], what: str = "a rank") -> No
     """Agree on whether any rank failed before the next collective: re-raises ``failure`` on the rank that holds it
     and raises ``RuntimeError`` on all the others, instead of leaving them waiting in a collective the failed rank
     never enters (one tiny all_reduce; nothing without a process group beyond re-raising)."""
-    if _multi_rank():
+    if _multi_rank() and _loopback is None:
         flag = torch.tensor([0 if failure is None else 1], dtype=torch.int64, device=_device_for_collectives())
         tdist.all_reduce(flag, op=tdist.ReduceOp.MAX)
         if int(flag.item()) and failure is None:
@@ -216,11 +280,17 @@ def raise_together(failure: Optional[BaseException], what: str = "a rank") -> No
         raise failure
 
 
+def _no_loopback(what: str) -> None:
+    if _loopback is not None:
+        raise NotImplementedError(f"{what} has no loop-back form: a Loopback wire stands in for the distributed pruning "
+                                  "of a regular block geometry (row exchanges and all_reduce_sum) only")
+
+
 def _multi_rank() -> bool:
     """True when collectives have somebody to talk to.  ``_force_collectives`` (a test hook, never set by the
     product) sends a ONE-rank group through the collective code as well, so that a single GPU can execute the RCCL
     branches: pinned staging, ``all_gather_into_tensor`` on device tensors, the stream ordering around them."""
-    return _active() and (world_size() > 1 or _force_collectives)
+    return (_loopback is not None and not _solo) or (_active() and (world_size() > 1 or _force_collectives))
 
 
 _force_collectives = False
@@ -233,6 +303,20 @@ def _gather_rows(rows: np.ndarray, n_cols: Optional[int], failure: Optional[Base
     largest count (two collectives: the counts, then the rows).  ``failure``: what this rank's preparation of the
     rows raised, if anything -- it travels with the counts, so that every rank raises before the second collective
     instead of waiting in it for a rank that never comes."""
+    if _loopback is not None:
+        if failure is not None:
+            raise failure
+        parts = _loopback.exchange(rows)
+        counts = [0 if p is None else int(p.shape[0]) for p in parts]
+        width = max([int(n_cols or 0)] + [int(p.shape[1]) for p in parts if p is not None and p.shape[0]])
+        most = max(counts)
+        if most == 0 or width == 0:
+            return None, counts, width
+        bufs = np.zeros((len(parts), most, width))          # (what the receive buffer of a real exchange holds)
+        for r, p in enumerate(parts):
+            if counts[r]:
+                bufs[r, :counts[r], :p.shape[1]] = p
+        return bufs, counts, width
     dev = _device_for_collectives()
     n_ranks = world_size()
     meta = torch.tensor([rows.shape[0], rows.shape[1] if rows.shape[0] else int(n_cols or 0),
@@ -330,6 +414,60 @@ def all_gather_rows_padded(rows: Optional[np.ndarray], n_cols: Optional[int] = N
     return _gather_rows(rows, n_cols, failure, what)
 
 
+def gather_tile_tables(local: Sequence[Tuple], failure: Optional[BaseException] = None):
+    """Every rank's per-tile tables on every rank: ``local`` = this rank's ``(tile index, table | None[, tag])`` items
+    (float64 2-D tables of any number of rows, one common width among the tables that hold rows; ``tag``: one integer
+    per tile that travels with it, 0 if absent) -> the items of ALL ranks, sorted by tile index.  ``None`` stays
+    ``None`` and a table without rows keeps its width.  Two exchanges (one row of three numbers per tile, then the rows
+    prefixed with their tile index); without a process group: ``local``, sorted.  Collective -- every rank calls it, also
+    a rank that detected no tile (``local = []``); ``failure``: what this rank's detection raised, if anything -- it
+    travels with the first exchange, so that every rank raises instead of waiting for a rank that never comes."""
+    items = []
+    for it in local:
+        idx, tbl = int(it[0]), it[1]
+        tag = int(it[2]) if len(it) > 2 else 0
+        if tbl is not None:
+            tbl = np.ascontiguousarray(tbl, dtype=np.float64)
+            if tbl.ndim != 2:
+                raise ValueError(f"tile {idx}: a table must be 2-D, not {tbl.shape}")
+        items.append((idx, tbl, tag))
+    items.sort(key=lambda e: e[0])
+    if not _multi_rank():
+        if failure is not None:
+            raise failure
+        return items
+    meta = np.array([[i, -1 if t is None else len(t), 0 if t is None else t.shape[1], tag] for i, t, tag in items],
+                    dtype=np.float64).reshape(-1, 4)
+    metas = all_gather_rows(meta, 4, failure, "detection of a rank's tiles")
+    widths = sorted({int(m[2]) for part in metas for m in part if m[1] > 0})
+    if len(widths) > 1:         # (every rank sees the same metas: all raise, nobody waits in the second exchange)
+        raise ValueError(f"tile tables differ in width: {widths}")
+    width = widths[0] if widths else 0
+    rows = [np.concatenate((np.full((len(t), 1), float(i)), t), axis=1) for i, t, _ in items if t is not None and len(t)]
+    mine = np.concatenate(rows) if rows else np.zeros((0, 0))
+    parts = all_gather_rows(mine, width + 1)
+    out = []
+    for part_meta, rows_r in zip(metas, parts):
+        at = 0
+        for i, n, w, tag in part_meta:
+            i, n, w = int(i), int(n), int(w)
+            if n < 0:
+                out.append((i, None, int(tag)))
+            elif n == 0:
+                out.append((i, np.zeros((0, w)), int(tag)))
+            else:
+                block = rows_r[at:at + n]
+                if len(block) != n or not np.all(block[:, 0] == i):
+                    raise RuntimeError(f"tile {i}: the exchange delivered other rows than announced")
+                out.append((i, np.ascontiguousarray(block[:, 1:1 + w]), int(tag)))
+                at += n
+    out.sort(key=lambda e: e[0])
+    seen = [i for i, _, _ in out]
+    if len(set(seen)) != len(seen):
+        raise ValueError(f"tile indices held by more than one rank: {sorted(i for i in set(seen) if seen.count(i) > 1)}")
+    return out
+
+
 _pinned_bufs = {}
 
 
@@ -347,6 +485,8 @@ def all_reduce_sum(values: np.ndarray) -> np.ndarray:
     values = np.ascontiguousarray(values, dtype=np.int64)
     if not _multi_rank():
         return values
+    if _loopback is not None:
+        return np.sum([p for p in _loopback.exchange(values) if p is not None and p.shape == values.shape], axis=0)
     t = torch.from_numpy(values.copy()).to(_device_for_collectives())
     tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
     return t.cpu().numpy()
@@ -356,6 +496,7 @@ def broadcast_table(table: Optional[np.ndarray], src: int = 0) -> Optional[np.nd
     """``table`` of rank ``src`` (a float64 2-D array or ``None``) on every rank."""
     if not _multi_rank():
         return table
+    _no_loopback("broadcast_table")
     dev = _device_for_collectives()
     is_src = rank() == src
     meta = torch.tensor([-1, 0] if (not is_src or table is None) else list(table.shape), dtype=torch.int64, device=dev)

@@ -973,36 +973,109 @@ def detect_blobs_blocks(filename_base: str, img5d, offset=None, size=None, chann
     return None, None, blobs
 
 
-def detect_blobs_tiles(filename_bases, tiles, channels=None, coloc: bool = False, save_dfs: bool = False):
+def detect_blobs_tiles(filename_bases, tiles, channels=None, coloc: bool = False, save_dfs: bool = False,
+                       shard: Optional[str] = None):
     """Whole-image detection of consecutive tiles of a tiled stack (BASELINE.json configs[4]: a light-sheet stack as
     tiles), one ``detect_blobs_blocks`` each: the upload of tile k + 1 is queued before tile k is detected and runs
     beside it, the device buffers of the batched passes and of the per-block preprocessing are reused from tile to
     tile.  ``tiles``: an iterable of ``Image5d`` (host images: memory-mapped ``image5d.npy`` files, arrays, pinned
     tensors); yields ``(index, Blobs)`` in order.  Each tile is an image of its own, exactly as the reference treats a
-    file (stack_detect.py:338-517); placing the tables in a common frame is the caller's (the importer's) business."""
-    it = iter(tiles)
-    names = iter(filename_bases) if not isinstance(filename_bases, str) else None
+    file (stack_detect.py:338-517); placing the tables in a common frame is the caller's (the importer's) business.
+
+    Several ranks (``torch.distributed``), ``shard``:
+
+    * ``None`` / ``"blocks"``: every rank walks ALL tiles and the blocks of each tile are cut over the ranks, as
+      ``detect_blobs_blocks`` does for one image (two small exchanges per tile, every rank gets every table);
+    * ``"tiles"``: rank r detects tiles r, r + N, ... (``dist.tile_share``) as one process would -- no exchange at all,
+      the pruning local, each rank uploading over its own PCIe link -- and yields ``(index, Blobs)`` for ITS tiles only
+      (``index``: the tile's place in ``tiles``).  Tiles of other ranks are never touched (an iterator is advanced past
+      them).  :func:`gather_tiles` afterwards puts every rank's tables on every rank, for a caller that wants them."""
+    import itertools
+    from . import dist
+    if shard not in (None, "blocks", "tiles"):
+        raise ValueError(f"shard must be None, 'blocks' or 'tiles', not {shard!r}")
+    by_tile = shard == "tiles" and dist.world_size() > 1
+    step, first = (dist.world_size(), dist.rank()) if by_tile else (1, 0)
+    it = itertools.islice(enumerate(tiles), first, None, step)
+    named = None if isinstance(filename_bases, str) else iter(filename_bases)
+    names_at = [0]
+
+    def base_of(k):
+        if named is None:
+            return f"{filename_bases}_{k}"
+        name = None
+        while names_at[0] <= k:                     # (an iterator of names is advanced past the other ranks' tiles too)
+            name = next(named)
+            names_at[0] += 1
+        return name
+
+    def detect(base, tile):
+        if by_tile:
+            with dist.solo():                       # this tile is this rank's alone: all its blocks, no collective
+                return detect_blobs_blocks(base, tile, None, None, channels, False, save_dfs, True, coloc)
+        return detect_blobs_blocks(base, tile, None, None, channels, False, save_dfs, True, coloc)
+
     cur = nxt = None
     try:
-        cur = next(it, None)
+        k, cur = next(it, (0, None))
         if cur is not None:
             cur.prefetch()
-        k = 0
         while cur is not None:
-            nxt = next(it, None)
+            k_nxt, nxt = next(it, (0, None))
             if nxt is not None:
                 nxt.prefetch()                      # (its copies are queued on its own stream before tile k's kernels)
-            base = f"{filename_bases}_{k}" if names is None else next(names)
-            _, _, blobs = detect_blobs_blocks(base, cur, None, None, channels, False, save_dfs, True, coloc)
+            _, _, blobs = detect(base_of(k), cur)
             cur.release()                           # (the tile's voxels leave the device with it)
             yield k, blobs
-            cur, nxt, k = nxt, None, k + 1
+            cur, nxt, k = nxt, None, k_nxt
     finally:
         # a failed detection, or a consumer that stops early (GeneratorExit): the uploads still in flight are cancelled
         # and joined before their device blocks go back to the allocator
         for tile in (cur, nxt):
             if tile is not None:
                 tile.release()
+
+
+def gather_tiles(results, failure: Optional[BaseException] = None):
+    """After ``detect_blobs_tiles(..., shard="tiles")``: every rank's ``(index, Blobs)`` pairs on every rank, sorted by
+    tile index (collective; a rank without tiles passes ``[]``).  What travels is each tile's final table and its
+    co-localisation flags (``dist.gather_tile_tables``: two small all-gathers, RCCL on GPUs); the ``Blobs`` made for
+    another rank's tile carry those plus this process' resolutions -- paths and ROI metadata stay with the rank that
+    detected the tile.  Without a process group: ``results``, sorted.  ``failure``: what this rank's detection raised,
+    if anything (every rank then raises)."""
+    from . import dist
+    results = sorted(results, key=lambda e: e[0])
+    if dist.world_size() == 1:
+        if failure is not None:
+            raise failure
+        return results
+    own = {int(k): b for k, b in results}
+    local = []
+    for k, b in results:
+        tbl, n_cols = b.blobs, 0
+        if tbl is not None:
+            n_cols = tbl.shape[1]
+            if b.colocalizations is not None:
+                tbl = np.hstack((tbl, np.asarray(b.colocalizations, dtype=np.float64)))
+        local.append((int(k), tbl, n_cols))
+    out = []
+    # the columns of a final table (stack_detect.py:455-470: rel <- abs, abs dropped): this rank's own tiles say, a rank
+    # without tiles takes the registry's standard order
+    col_names = next((list(b.cols) for b in own.values() if b.blobs is not None and b.cols), None) or [
+        c.value for c in detector.Blobs.Cols if not c.name.startswith("ABS_")]
+    for k, tbl, n_cols in dist.gather_tile_tables(local, failure):
+        if k in own:
+            out.append((k, own[k]))
+            continue
+        blobs = detector.Blobs(None)
+        if tbl is not None:
+            blobs.cols = col_names[:n_cols] if n_cols <= len(col_names) else None
+            blobs.blobs = np.ascontiguousarray(tbl[:, :n_cols])
+            if tbl.shape[1] > n_cols:
+                blobs.colocalizations = tbl[:, n_cols:].astype(np.uint8)
+        blobs.resolutions = config.resolutions
+        out.append((k, blobs))
+    return out
 
 
 def _save_pruning_ratios(df):

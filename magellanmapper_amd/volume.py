@@ -224,7 +224,7 @@ def _take_staging(nbytes: int) -> "torch.Tensor":
         fit = [b for b in _STAGING if b.numel() >= nbytes]
         if fit:
             buf = min(fit, key=lambda b: b.numel())
-            _STAGING.remove(buf)
+            _STAGING[:] = [b for b in _STAGING if b is not buf]         # (by identity: `==` on tensors compares elements)
             return buf
     return torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
 

@@ -437,3 +437,172 @@ def test_a_failing_rank_makes_every_rank_raise(tmp_path, stage):
     verdicts = [open(tmp_path / f"verdict{r}").read() for r in range(world)]
     assert verdicts[1].startswith("own:") and "injected failure" in verdicts[1]
     assert verdicts[0].startswith("peer:") and verdicts[2].startswith("peer:")
+
+
+# ---------------------------------------------------------------- configs[4] sharded BY TILE (no exchange while detecting)
+def _tile_result(k):
+    """What the detection of tile ``k`` leaves: ``(final 8-column table | None, colocs | None)`` -- every fifth tile
+    without blobs, every seventh with an EMPTY table, the others with a seeded number of rows and two flag columns."""
+    rng = np.random.default_rng(900 + k)
+    if k % 5 == 3:
+        return None, None
+    n = 0 if k % 7 == 5 else int(rng.integers(1, 40))
+    table = rng.integers(0, 500, (n, 8)).astype(np.float64) + k
+    return table, rng.integers(0, 2, (n, 2)).astype(np.uint8)
+
+
+class _FakeTile:
+    """Stands in for ``stack_detect.Image5d`` where there is no GPU: records who prefetched / released it."""
+    def __init__(self, k, log):
+        self.k, self.log, self.device_volume = k, log, None
+
+    def prefetch(self):
+        self.log.append(("prefetch", self.k))
+        self.device_volume = object()
+        return self
+
+    def release(self):
+        self.log.append(("release", self.k))
+        self.device_volume = None
+
+
+def _worker_tiles(rank, world, port, n_tiles, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from magellanmapper_amd import config, detector, dist as d, stack_detect as sd
+        config.resolutions = np.array([[1.0, 1.0, 1.0]])
+        mine = list(range(rank, n_tiles, world))
+        assert d.tile_share(n_tiles) == mine
+        log = []
+        tiles = [_FakeTile(k, log) for k in range(n_tiles)]
+        seen_names = []
+
+        def fake_detect(base, tile, offset, size, channels, verify, save_dfs, full_roi, coloc):
+            # one process' path: inside the call this rank is alone (no collective can be entered by mistake)
+            assert d.world_size() == 1 and d.rank() == 0 and full_roi and tile.device_volume is not None
+            seen_names.append(base)
+            table, colocs = _tile_result(tile.k)
+            blobs = detector.Blobs(None)
+            if table is not None:
+                blobs.cols = [c.value for c in detector.Blobs.Cols if not c.name.startswith("ABS_")]
+                blobs.blobs, blobs.colocalizations = table, colocs
+            return None, None, blobs
+        sd.detect_blobs_blocks = fake_detect
+        names = (f"tile{k}" for k in range(n_tiles))                 # an ITERATOR of names: advanced past foreign tiles
+        got = list(sd.detect_blobs_tiles(names, iter(tiles), coloc=True, shard="tiles"))
+        assert d.world_size() == world                               # (solo has been left)
+        assert [k for k, _ in got] == mine and seen_names == [f"tile{k}" for k in mine]
+        # only this rank's tiles were touched, tile k + N announced before tile k was detected, each released once
+        assert {k for _, k in log} == set(mine)
+        assert [e for e in log if e[0] == "release"] == [("release", k) for k in mine]
+        for a, b in zip(mine, mine[1:]):
+            assert log.index(("prefetch", b)) < log.index(("release", a))
+        everything = sd.gather_tiles(got)
+        assert [k for k, _ in everything] == list(range(n_tiles))
+        for k, blobs in everything:
+            table, colocs = _tile_result(k)
+            if table is None:
+                assert blobs.blobs is None and blobs.colocalizations is None
+            else:
+                assert blobs.blobs.shape == table.shape and blobs.blobs.shape[1] == 8     # EMPTY tables keep their width
+                np.testing.assert_array_equal(blobs.blobs, table)
+                assert blobs.colocalizations.dtype == np.uint8
+                np.testing.assert_array_equal(blobs.colocalizations, colocs)
+                assert list(blobs.cols)[-1] == "region" and len(blobs.cols) == 8
+            if k in mine:
+                assert blobs is dict(got)[k]                         # own tiles come back as they are
+        # a rank whose detection failed: everybody raises at the gather instead of waiting for it
+        try:
+            sd.gather_tiles([], failure=ValueError("tile unreadable") if rank == 1 % world else None)
+            verdict = "returned"
+        except ValueError as exc:
+            verdict = f"own:{exc}"
+        except RuntimeError as exc:
+            verdict = f"peer:{exc}"
+        open(os.path.join(out_dir, f"tiles{rank}"), "w").write(f"{len(mine)} {verdict}")
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_tiles", [(8, 11), (8, 5), (3, 7), (2, 1)])
+def test_tiles_sharded_over_ranks_and_gathered(tmp_path, world, n_tiles):
+    """BASELINE.json configs[4] across the ranks BY TILE: ``detect_blobs_tiles(shard="tiles")`` gives rank r the tiles
+    r, r + N, ... (uneven counts, ranks without any tile at 5 tiles over 8 ranks), detects each as one process would
+    (inside the call the rank is alone), touches no other rank's tile, and ``gather_tiles`` puts every table and its
+    flags on every rank -- ``None`` and EMPTY tables included; a failing rank makes all ranks raise."""
+    tmp.spawn(_worker_tiles, args=(world, _free_port(), n_tiles, str(tmp_path)), nprocs=world, join=True)
+    notes = [open(tmp_path / f"tiles{r}").read().split(" ", 1) for r in range(world)]
+    assert sum(int(n) for n, _ in notes) == n_tiles
+    failing = 1 % world
+    for r, (_, verdict) in enumerate(notes):
+        assert verdict.startswith("own:tile unreadable" if r == failing else "peer:"), (r, verdict)
+
+
+def test_tile_gather_without_a_group_and_bad_arguments():
+    from magellanmapper_amd import detector, stack_detect as sd
+    assert dist.tile_share(5) == [0, 1, 2, 3, 4] and dist.tile_share(7, 2, 3) == [2, 5] and dist.tile_share(2, 5, 8) == []
+    a, b = detector.Blobs(None), detector.Blobs(None)
+    assert sd.gather_tiles([(3, a), (1, b)]) == [(1, b), (3, a)]
+    items = dist.gather_tile_tables([(2, np.ones((3, 4))), (0, None, 7)])
+    assert [i for i, _, _ in items] == [0, 2] and items[0][1] is None and items[0][2] == 7
+    with pytest.raises(ValueError, match="2-D"):
+        dist.gather_tile_tables([(0, np.ones(3))])
+    with pytest.raises(ValueError, match="shard"):
+        list(sd.detect_blobs_tiles("x", [], shard="rows"))
+
+
+@pytest.mark.parametrize("world,case", [(8, "c4_grid"), (3, "holes"), (4, "extra_columns_two_channels"), (2, "nothing")])
+def test_loopback_wire_replays_a_rank_with_the_whole_stacks_table(world, case):
+    """``dist.Loopback`` (what ``bench.py --share k/N`` measures a rank's step with): ONE process plays every rank of the
+    distributed pruning twice -- the first round records the rows near the seams, the second the survivors pruned with
+    them -- and then replays single ranks: every replay merges the WHOLE stack's table, equal to the one-process
+    passes, and the statistics sum up as over a real group."""
+    from magellanmapper_amd import stack_detect as sd
+    blocks, tables, shape, channels, n_extra = _dist_case(case)
+    grid = blocks.sub_roi_slices.shape
+    coords = list(np.ndindex(*grid))
+
+    class Img:
+        pass
+    Img.shape = shape
+    args = (blocks.overlap, blocks.tol, blocks.sub_roi_slices, blocks.sub_rois_offsets, channels, blocks.overlap_padding)
+    want, df = sd.StackPruner.prune_blobs_mp(Img, sd.StackDetector.assemble_seg_rois(list(enumerate(tables)), grid, n_extra),
+                                             *args)
+
+    def play(q):
+        wire.begin_step(q)
+        mine = dist.my_share(len(coords))
+        assert mine == list(range(*dist.share_bounds(len(coords), q, world)))
+        arena = sd._TableArena(11 + n_extra, len(mine))
+        local = []
+        for i in mine:
+            if tables[i] is not None and len(tables[i]):
+                arena.add(coords[i], tables[i])
+            arena.landed()
+            local.append((i, tables[i]))
+        seg = sd.StackDetector.assemble_seg_rois(local, grid, n_extra, arena, local_only=True)
+        return sd.StackPruner.prune_blobs_mp(Img, seg, *args)
+
+    wire = dist.Loopback(0, world)
+    dist.set_loopback(wire)
+    try:
+        assert dist.world_size() == world and dist._multi_rank()
+        for _ in range(2):
+            for q in range(world):
+                play(q)
+        wire.mode = "replay"
+        for q in sorted({0, world // 2, world - 1}):
+            got, df_q = play(q)
+            if want is None:
+                assert got is None
+                continue
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(df_q.to_numpy(), df.to_numpy())
+        with pytest.raises(NotImplementedError):
+            dist.broadcast_table(np.zeros((1, 1)))
+    finally:
+        dist.set_loopback(None)
+    assert dist.world_size() == 1 and not dist._multi_rank()

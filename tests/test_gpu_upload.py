@@ -247,3 +247,93 @@ def test_an_abandoned_tile_generator_releases_the_tile_it_prefetched(gpu, monkey
         assert all(u is None or (u.thread is None and (u.cancelled or u.all_queued())) for u in ups)
     finally:
         config.setup_roi_profiles(None)
+
+
+_TILE_RANK_SCRIPT = '''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as td
+from magellanmapper_amd import config, dist, stack_detect, volume
+from oracle import magmap_oracle as mmo
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                            # (both ranks share the one GPU of a test box)
+td.init_process_group("gloo")
+try:
+    c5 = {c5!r}
+    volume._STREAM_MIN_BYTES = 0
+    volume._STREAM_CHUNK_BYTES = 12 * 100 * 110 * (4 if c5 else 2)
+    config.setup_roi_profiles(None)
+    profile = dict(num_sigma=3, denoise_size=25 if c5 else None, segment_size=64)
+    config.roi_profile.update(profile)
+    for p in config.roi_profiles:
+        p.update(profile)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "tiles"
+    config.near_max = [-1.0, -1.0]
+    n_tiles = 4
+    tiles = [stack_detect.Image5d(np.load(os.path.join({tmp!r}, f"t{{k}}.npy"), mmap_mode="r")) for k in range(n_tiles)]
+    calls = []
+    real = dist.all_gather_rows
+    dist.all_gather_rows = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    got = list(stack_detect.detect_blobs_tiles("tiles", tiles, coloc=c5, shard="tiles"))
+    assert [k for k, _ in got] == dist.tile_share(n_tiles) == [rank, rank + 2]
+    assert not calls                                # no exchange while detecting: every tile was this rank's alone
+    everything = stack_detect.gather_tiles(got)
+    assert calls and [k for k, _ in everything] == list(range(n_tiles))
+    key = lambda t: np.lexsort(tuple(t[:, i] for i in range(t.shape[1] - 1, -1, -1)))
+    profiles = [dict(config.roi_profile)] * (2 if c5 else 1)
+    for k, blobs in (everything if rank == 0 else got):
+        vol = np.load(os.path.join({tmp!r}, f"t{{k}}.npy"))[0]
+        if c5:
+            want, stages = mmo.detect_blobs_blocks(vol, [0, 1], profiles, config.resolutions, near_max=[-1.0, -1.0],
+                                                   coloc=True)
+            np.testing.assert_array_equal(blobs.blobs, want)
+            np.testing.assert_array_equal(blobs.colocalizations, stages["colocs"])
+            assert set(np.unique(want[:, 6])) == {{0.0, 1.0}}
+        else:
+            want, _ = mmo.detect_blobs_blocks(vol, None, profiles, config.resolutions)
+            assert blobs.colocalizations is None
+            np.testing.assert_array_equal(blobs.blobs[key(blobs.blobs)], want[key(want)])
+        assert len(want) > 30
+    assert all(t.device_volume is None for t in tiles)
+    torch.cuda.synchronize()
+    print(f"TILE_RANK_OK {{rank}} {{[k for k, _ in got]}}", flush=True)
+finally:
+    td.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("c5", [False, True])
+def test_four_tiles_over_two_ranks_equal_the_oracle_per_tile(gpu, tmp_path, c5):
+    """BASELINE.json configs[4] sharded BY TILE, as far as one GPU goes: four memory-mapped tiles over two ranks (gloo,
+    sharing this GPU), ``detect_blobs_tiles(shard="tiles")`` -- rank r detects tiles r and r + 2 as one process would,
+    tile r + 2 uploading while tile r is detected, no collective entered -- then ``gather_tiles``: every tile's final
+    table (and, C5-shaped: two channels, per-block preprocessing, the co-localisation flags) equals the oracle's for
+    that tile, on the rank that detected it and, after the gather, on rank 0 for all four."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from magellanmapper_amd import synth
+    for k in range(4):
+        shape = (56, 100, 110)
+        c0 = synth.make_volume(60 + 2 * k, shape, 45)
+        if c5:
+            c1 = np.maximum(synth.make_volume(61 + 2 * k, shape, 45).astype(np.int32), (c0.astype(np.int32) * 7) // 10)
+            c0 = np.stack((c0, c1.astype(np.uint16)), axis=-1)
+        np.save(tmp_path / f"t{k}.npy", c0[None])
+    script = tmp_path / "tile_ranks.py"
+    script.write_text(_TILE_RANK_SCRIPT.format(root=ROOT, tmp=str(tmp_path), c5=c5))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    assert "TILE_RANK_OK 0 [0, 2]" in run.stdout and "TILE_RANK_OK 1 [1, 3]" in run.stdout
