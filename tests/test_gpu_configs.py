@@ -266,22 +266,17 @@ def test_tiled_stack_sharded_by_tile_is_a_weak_scaling_line(gpu, tmp_path):
     per tile (tile g is the same volume whoever detects it), distinct tiles differ, the line says ``weak`` and carries
     per-rank tile times, and the parity sample (rank 0, by itself) equals the oracle run in that process."""
     args = ("--config", "c5", "--shape", "56", "150", "160", "--segment-size", "64", "--cpu-cores", "4")
-    one = _run_bench(tmp_path, 1, *args, "--tiles", "4")
-    cmd_env = dict(os.environ, MMX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", *args, "--tiles", "2"],
-                         capture_output=True, text=True, timeout=900, env=cmd_env, cwd=str(tmp_path))
+    env = dict(os.environ, MMX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", *args, "--tiles", "4"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert run.returncode == 0, run.stderr[-3000:]
-    two = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    one = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert one["parity_sample_identical"] is True and one["cpu_baseline"]["kind"] == "port"
+    two = _run_bench(tmp_path, 2, *args, "--tiles", "2", "--steps", "2", "--warmup", "1")
     for line, n in ((one, 1), (two, 2)):
         assert line["scaling"] == "weak" and line["n_gpus"] == n and line["config"]["tiles_total"] == 4
         assert line["config"]["tiles_per_rank"] == 4 // n and [t["tile"] for t in line["tiles"]] == [0, 1, 2, 3]
         assert line["roofline"]["kernel"] in line["kernels"] and line["roofline"]["frac"] > 0
-        assert line["parity_sample_identical"] is True and line["cpu_baseline"]["kind"] == "port"
         assert all(t["blobs"] > 50 and t["colocs_sha1"] for t in line["tiles"])
     assert one["tiles"] == two["tiles"]
     assert len({t["table_sha1"] for t in one["tiles"]}) == 4
