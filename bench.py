@@ -329,7 +329,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             return None, None
         if isinstance(pruned, stack_detect._FinalTable):       # the pruning step wrote the final columns itself
             detector.Blobs(None).cols = list(pruned.col_names)
-            return pruned.view(np.ndarray), None
+            return pruned.view(np.ndarray), (None if pruned.coloc_cols is None else pruned.coloc_cols.astype(np.uint8))
         bb = detector.Blobs(pruned)              # the table's final form (reference stack_detect.py:458-467)
         bb.replace_rel_with_abs_blob_coords(pruned)
         colocs = pruned[:, 10:10 + n_chl].astype(np.uint8) if coloc else None
@@ -353,7 +353,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
             pruned, _ = stack_detect.StackPruner.prune_blobs_mp(
                 vol, seg, blk.overlap, blk.tol, blk.sub_roi_slices, blk.sub_rois_offsets,
                 channels, blk.overlap_padding, untouched=True,
-                final_form=not coloc and (dist.world_size() == 1 or getattr(seg, "local_only", False)))
+                final_form=dist.world_size() == 1 or getattr(seg, "local_only", False),
+                n_flag_cols=n_chl if coloc else 0)
             if rank == 0:
                 final, colocs = finish(pruned)
         t_c = time.perf_counter()
@@ -1041,6 +1042,9 @@ def main():
                          "seam rows, the pruning of its rows, the merge of all ranks' survivors, with a recording in place "
                          "of the wire (dist.Loopback) -- a model of the strong-scaling step measured on one GPU")
     ap.add_argument("--full-step-ms", type=float, default=0.0, help="with --share: the one-GPU step to quote linear scaling against")
+    ap.add_argument("--prune-prof", action="store_true", help="print the phases of every pruning step to stderr")
+    ap.add_argument("--prune-ahead", choices=("auto", "0", "1"), default="auto",
+                    help="prune finished regions while the GPU detects: auto = stacks of 64 blocks and more (stack_detect.PRUNE_AHEAD)")
     ap.add_argument("--shard", choices=("blocks", "tiles"), default=None,
                     help="N > 1: blocks of ONE volume over the ranks (strong scaling, the default) or whole tiles of a "
                          "tiled stack (weak scaling; implied by --tiles T without --from-host)")
@@ -1113,6 +1117,10 @@ def main():
             tdist.init_process_group(backend, timeout=wait)
 
     from magellanmapper_amd import blob_log as bl
+    from magellanmapper_amd import stack_detect as _sd
+    _sd.PRUNE_PROF = bool(args.prune_prof)
+    if args.prune_ahead != "auto":
+        _sd.PRUNE_AHEAD = args.prune_ahead
 
     import scipy
     share = wire = None

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MMX_ABI_VERSION 15
+#define MMX_ABI_VERSION 16
 
 typedef enum {
     MMX_OK = 0,
@@ -565,6 +565,19 @@ int mmx_host_gather_parts_by_key_final(const double* table, int64_t ld, int32_t 
                                        const int64_t* const* keys, const double* const* abs_rows,
                                        const int64_t* n_rows, int64_t n_keys, const int32_t* src_cols, int32_t n_out,
                                        int32_t abs_dst0, double* out, int64_t out_rows);
+/* ... with the output in TWO tables (ABI v16): columns [0, n_main) of the layout into `out` (row pitch n_main,
+ * abs_dst0 + 3 <= n_main), the other n_out - n_main into `out_rest` (row pitch n_out - n_main).  A stack detected with
+ * co-localisation ends as eight final columns plus the columns its flags are read from -- `segments_all[:, 10:10 + C]`,
+ * magmap/cv/stack_detect.py:463-464 -- and both leave the one pass that gathers the surviving rows.  out_rest NULL:
+ * the plain form above. */
+int mmx_host_take_rows_split(const double* table, int64_t ld, const int64_t* rows, int64_t n,
+                             const int32_t* src_cols, int32_t n_out, const double* abs_zyx, int32_t abs_dst0,
+                             double* out, int32_t n_main, double* out_rest);
+int mmx_host_gather_parts_by_key_split(const double* table, int64_t ld, int32_t n_parts, const int64_t* const* ids,
+                                       const int64_t* const* keys, const double* const* abs_rows,
+                                       const int64_t* n_rows, int64_t n_keys, const int32_t* src_cols, int32_t n_out,
+                                       int32_t abs_dst0, double* out, int64_t out_rows, int32_t n_main,
+                                       double* out_rest);
 
 /* All three axis passes of the pruning for one REGION of the stack (the whole stack, one rank's blocks, or a group
  * of blocks pruned while the GPU still works on later ones): a table holding the region's own rows (ids

@@ -696,9 +696,26 @@ extern "C" int mmx_host_gather_parts_by_key_final(const double* table, int64_t l
                                                   const int32_t* src_cols, int32_t n_out, int32_t abs_dst0,
                                                   double* out, int64_t out_rows)
 {
+    return mmx_host_gather_parts_by_key_split(table, ld, n_parts, ids, keys, abs_rows, n_rows, n_keys, src_cols, n_out,
+                                              abs_dst0, out, out_rows, n_out, nullptr);
+}
+
+// ... with the output in TWO tables: columns [0, n_main) of the layout into `out` (row pitch n_main), the remaining
+// n_out - n_main into `out_rest` (row pitch n_out - n_main) -- a stack detected with co-localisation: the eight final
+// columns as one contiguous table, the columns its flags are read from (magmap/cv/stack_detect.py:463-464: columns 10
+// .. 10 + C of the pruned table) beside it, in the one pass that gathers the rows.  out_rest NULL: n_main = n_out.
+extern "C" int mmx_host_gather_parts_by_key_split(const double* table, int64_t ld, int32_t n_parts,
+                                                  const int64_t* const* ids, const int64_t* const* keys,
+                                                  const double* const* abs_rows, const int64_t* n_rows, int64_t n_keys,
+                                                  const int32_t* src_cols, int32_t n_out, int32_t abs_dst0,
+                                                  double* out, int64_t out_rows, int32_t n_main, double* out_rest)
+{
     if (n_parts < 0 || n_keys < 1 || n_out < 3 || n_out > 64 || !src_cols || abs_dst0 < 0 || abs_dst0 + 3 > n_out ||
         (n_parts && (!ids || !keys || !abs_rows || !n_rows)))
         return MMX_ERR_ARG;
+    if (!out_rest) n_main = n_out;
+    if (n_main < abs_dst0 + 3 || n_main > n_out || (out_rest && n_main == n_out)) return MMX_ERR_ARG;
+    const int n_rest = n_out - n_main;
     if (n_keys > (int64_t(1) << 26)) return MMX_ERR_UNSUPPORTED;
     for (int j = 0; j < n_out; ++j)
         if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
@@ -750,10 +767,15 @@ extern "C" int mmx_host_gather_parts_by_key_final(const double* table, int64_t l
         int64_t* pos = at.data() + (size_t)t * (size_t)n_keys;
         for (int p = first[(size_t)t]; p < first[(size_t)t + 1]; ++p)
             for (int64_t i = 0; i < n_rows[p]; ++i) {
-                double* o = out + pos[keys[p][i]]++ * n_out;
+                const int64_t at_row = pos[keys[p][i]]++;
+                double* o = out + at_row * n_main;
                 const double* src = table + ids[p][i] * ld;
-                for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
+                for (int j = 0; j < n_main; ++j) o[j] = src[src_cols[j]];
                 for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_rows[p][3 * i + a];
+                if (n_rest) {
+                    double* o2 = out_rest + at_row * n_rest;
+                    for (int j = 0; j < n_rest; ++j) o2[j] = src[src_cols[n_main + j]];
+                }
             }
     });
     return MMX_OK;
@@ -980,19 +1002,34 @@ extern "C" int mmx_host_take_rows_final(const double* table, int64_t ld, const i
                                         const int32_t* src_cols, int32_t n_out, const double* abs_zyx,
                                         int32_t abs_dst0, double* out)
 {
+    return mmx_host_take_rows_split(table, ld, rows, n, src_cols, n_out, abs_zyx, abs_dst0, out, n_out, nullptr);
+}
+
+// ... with the output in two tables (see mmx_host_gather_parts_by_key_split).
+extern "C" int mmx_host_take_rows_split(const double* table, int64_t ld, const int64_t* rows, int64_t n,
+                                        const int32_t* src_cols, int32_t n_out, const double* abs_zyx,
+                                        int32_t abs_dst0, double* out, int32_t n_main, double* out_rest)
+{
     if (!table || (!rows && n) || !out || n < 0 || n_out < 3 || n_out > 64 || !src_cols || !abs_zyx || abs_dst0 < 0 ||
         abs_dst0 + 3 > n_out)
         return MMX_ERR_ARG;
+    if (!out_rest) n_main = n_out;
+    if (n_main < abs_dst0 + 3 || n_main > n_out || (out_rest && n_main == n_out)) return MMX_ERR_ARG;
+    const int n_rest = n_out - n_main;
     for (int j = 0; j < n_out; ++j)
         if (src_cols[j] < 0 || src_cols[j] >= ld) return MMX_ERR_ARG;
     parallel(host_threads(n), [&](int t, int nt) {
         const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
         for (int64_t i = lo; i < hi; ++i) {
             const int64_t r = rows[i];
-            double* o = out + i * n_out;
+            double* o = out + i * n_main;
             const double* src = table + r * ld;
-            for (int j = 0; j < n_out; ++j) o[j] = src[src_cols[j]];
+            for (int j = 0; j < n_main; ++j) o[j] = src[src_cols[j]];
             for (int a = 0; a < 3; ++a) o[abs_dst0 + a] = abs_zyx[3 * r + a];
+            if (n_rest) {
+                double* o2 = out_rest + i * n_rest;
+                for (int j = 0; j < n_rest; ++j) o2[j] = src[src_cols[n_main + j]];
+            }
         }
     });
     return MMX_OK;

@@ -443,16 +443,22 @@ class _RegionPruner:
         ncol = ar.store.shape[1] - 3
         if final is not None:
             # the regions' survivor lists go to the merge as they are (no concatenation: 12 MB of copies for 3e5 rows)
-            src, dst0 = final
+            src, dst0, n_main = final
             parts = [d for d in self.done if len(d[0])]
             n_rows = np.array([len(d[0]) for d in parts], dtype=np.int64)
             ptrs = [(ctypes.c_void_p * max(1, len(parts)))(*[d[c].ctypes.data for d in parts]) for c in range(3)]
-            out = np.empty((int(n_rows.sum()), len(src)))
-            nat.check(nat.lib().mmx_host_gather_parts_by_key_final(
+            total = int(n_rows.sum())
+            out = np.empty((total, n_main))
+            rest = np.empty((total, len(src) - n_main)) if n_main < len(src) else None
+            nat.check(nat.lib().mmx_host_gather_parts_by_key_split(
                 ar.store.ctypes.data, ar.store.strides[0] // 8, len(parts), ptrs[0], ptrs[1], ptrs[2],
                 n_rows.ctypes.data, self.plan["n_keys"] * len(self.channels), (ctypes.c_int32 * len(src))(*src),
-                len(src), dst0, out.ctypes.data, len(out)), "mmx_host_gather_parts_by_key_final")
+                len(src), dst0, out.ctypes.data, total, n_main, None if rest is None else rest.ctypes.data),
+                "mmx_host_gather_parts_by_key_split")
             _lap("  regions: merge by key, final columns")
+            if rest is not None:
+                out = out.view(_FinalTable)
+                out.coloc_cols = rest
             return out, counts
         ids = np.ascontiguousarray(np.concatenate([d[0] for d in self.done]), dtype=np.int64)
         keys = np.ascontiguousarray(np.concatenate([d[1] for d in self.done]), dtype=np.int64)
@@ -469,8 +475,11 @@ class _RegionPruner:
 
 class _FinalTable(np.ndarray):
     """A pruned table that left ``StackPruner.prune_blobs_mp(..., final_form=True)`` already in the reference's final
-    columns (rel <- abs, abs and unnamed columns dropped): ``col_names`` are the columns it holds."""
+    columns (rel <- abs, abs and unnamed columns dropped): ``col_names`` are the columns it holds.  ``coloc_cols``: for a
+    table with co-localisation columns, the columns the reference reads the flags from (``[:, 10:10 + C]`` of the pruned
+    table, stack_detect.py:463-464), row for row, as float64 -- ``None`` otherwise."""
     col_names = None
+    coloc_cols = None
 
 
 class _SegRois(np.ndarray):
@@ -879,7 +888,8 @@ class _StackRun:
         own = dist.world_size() == 1 or getattr(self.seg_rois, "local_only", False)
         return StackPruner.prune_blobs_mp(self.roi, self.seg_rois, bk.overlap, bk.tol, bk.sub_roi_slices,
                                           bk.sub_rois_offsets, self.channels, bk.overlap_padding,
-                                          final_form=not self.coloc and own, untouched=True)
+                                          final_form=own, untouched=True,
+                                          n_flag_cols=self.n_roi_channels if self.coloc else 0)
 
     def prune(self):
         """The merged, pruned table on every rank.  One rank: a plain call.  Several ranks: either the tables stayed
@@ -915,6 +925,8 @@ class _StackRun:
             # the pruning step wrote the final columns itself; the column registry ends as the two steps below leave it
             blobs = detector.Blobs(None, path=path)
             blobs.cols = list(final.col_names)
+            if final.coloc_cols is not None:        # (`segments_all[:, 10:10 + C].astype(np.uint8)`, :463-464)
+                flags = final.coloc_cols.astype(np.uint8)
             final = final.view(np.ndarray)
         else:
             blobs = detector.Blobs(final, path=path)
@@ -1366,18 +1378,21 @@ class StackPruner:
         return ratios_all
 
     @staticmethod
-    def _final_columns(merged, abs_inds):
-        """What the reference's last two steps on the pruned table (``replace_rel_with_abs_blob_coords``, then
-        ``remove_abs_blob_coords(True)``, :455-470) leave of the merged table's columns, for the gather to write
-        directly: ``(source columns, place of the abs coordinates among them, their names)`` -- or ``None`` where the
-        two steps do not reduce to that (co-localisation columns behind the named ones, an unusual registry, a table
-        the native gather does not take)."""
+    def _final_columns(merged, abs_inds, n_flag_cols: int = 0):
+        """What the reference's last steps on the pruned table (``replace_rel_with_abs_blob_coords``, [the flags read
+        from ``[:, 10:10 + C]``,] ``remove_abs_blob_coords(True)``, :455-470) leave of the merged table's columns, for
+        the gather to write directly: ``(source columns, place of the abs coordinates among them, names of the final
+        columns, how many of the source columns they are)`` -- with ``n_flag_cols`` = C co-localisation columns behind the
+        named ones the source columns end with the C columns the flags are read from -- or ``None`` where the steps do not
+        reduce to that (columns beyond the named ones that were not announced, an unusual registry, a table the native
+        gather does not take)."""
         if not (merged.dtype == np.float64 and merged.strides[1] == 8 and merged.strides[0] % 8 == 0):
             return None
         registry = detector.Blobs._col_inds
         named = [(c, i) for c, i in registry.items() if i is not None]
-        if merged.shape[1] - 3 != len(named) or sorted(i for _, i in named) != list(range(len(named))):
-            return None                 # (columns beyond the named ones: the co-localisation flags are read from them)
+        n_flag_cols = int(n_flag_cols)
+        if merged.shape[1] - 3 != len(named) + n_flag_cols or sorted(i for _, i in named) != list(range(len(named))):
+            return None                 # (columns beyond the named ones that nobody announced)
         rel = detector.Blobs._get_rel_inds()
         drop = set(abs_inds)
         keep = [(c, i) for c, i in named if i not in drop]
@@ -1387,7 +1402,10 @@ class StackPruner:
         dst0 = src.index(rel[0])
         if src[dst0:dst0 + 3] != list(rel):
             return None
-        return src, dst0, [c.value for c, _ in keep]
+        if n_flag_cols and len(named) != 11:
+            return None                 # (the reference's literal `10:10 + C` is only what it means with the 11 standard columns)
+        flag_src = list(range(10, 10 + n_flag_cols))        # (the literal columns of stack_detect.py:464, region first)
+        return src + flag_src, dst0, [c.value for c, _ in keep], len(src)
 
     @staticmethod
     def _take_rows(merged, rows, abs_cur, abs_inds, final=None):
@@ -1395,12 +1413,16 @@ class StackPruner:
         columns, place of the abs coordinates)`` the table in those columns instead (:meth:`_final_columns`)."""
         ncol = merged.shape[1]
         if final is not None:
-            src, dst0 = final
-            out = np.empty((len(rows), len(src)))
-            nat.check(nat.lib().mmx_host_take_rows_final(
+            src, dst0, n_main = final
+            out = np.empty((len(rows), n_main))
+            rest = np.empty((len(rows), len(src) - n_main)) if n_main < len(src) else None
+            nat.check(nat.lib().mmx_host_take_rows_split(
                 merged.ctypes.data, merged.strides[0] // 8, rows.ctypes.data, len(rows),
-                (ctypes.c_int32 * len(src))(*src), len(src), abs_cur.ctypes.data, dst0, out.ctypes.data),
-                "mmx_host_take_rows_final")
+                (ctypes.c_int32 * len(src))(*src), len(src), abs_cur.ctypes.data, dst0, out.ctypes.data, n_main,
+                None if rest is None else rest.ctypes.data), "mmx_host_take_rows_split")
+            if rest is not None:
+                out = out.view(_FinalTable)
+                out.coloc_cols = rest
             return out
         if merged.dtype == np.float64 and merged.strides[1] == 8 and merged.strides[0] % 8 == 0:
             out = np.empty((len(rows), ncol - 3))
@@ -1426,13 +1448,13 @@ class StackPruner:
         ar = seg_rois.arena
         world, me = dist.world_size(), dist.rank()
         from time import perf_counter
-        _prof = PRUNE_PROF and me == 0
+        _prof = PRUNE_PROF and (me == 0 or dist._loopback is not None)
         _t = [perf_counter()]
 
         def _lap(what):
             if _prof:
                 now = perf_counter()
-                print(f"distributed prune, rank 0: {what}: {(now - _t[0]) * 1e3:.2f} ms", file=sys.stderr)
+                print(f"distributed prune, rank {me}: {what}: {(now - _t[0]) * 1e3:.2f} ms", file=sys.stderr)
                 _t[0] = now
         # Every rank-local stage runs under try / except and its failure travels with the NEXT collective (a status
         # word in the all_reduce, in the row counts of the two exchanges): a rank that fails -- a native error, tables
@@ -1661,7 +1683,8 @@ class StackPruner:
 
     @classmethod
     def prune_blobs_mp(cls, img, seg_rois, overlap, tol, sub_roi_slices, sub_rois_offsets,
-                       channels, overlap_padding=None, final_form: bool = False, untouched: bool = False):
+                       channels, overlap_padding=None, final_form: bool = False, untouched: bool = False,
+                       n_flag_cols: int = 0):
         """Prune duplicates in the overlap slabs, per channel, axis by axis (:679-861).
 
         For every axis with more than one block, every block boundary ``j | j+1`` defines a
@@ -1670,7 +1693,9 @@ class StackPruner:
         everything else passes through, and the recombined table goes on to the next axis.
         Returns ``(table, DataFrame)`` or ``(None, None)``.  ``final_form`` (not in the reference; ``_StackRun`` asks
         for it): where possible the table comes back as a :class:`_FinalTable`, already in the columns the reference's
-        next two steps would leave (rel <- abs, abs dropped) -- two passes over the whole table less.  ``untouched``:
+        next two steps would leave (rel <- abs, abs dropped) -- two passes over the whole table less; ``n_flag_cols``
+        = C says the tables carry C co-localisation columns behind the 11 named ones, and the columns the reference reads
+        the flags from come back beside the table (``_FinalTable.coloc_cols``).  ``untouched``:
         the caller vouches that nobody has had the tables since ``detect_blobs_sub_rois`` returned them (``_StackRun``
         calls one right after the other), which spares the sampled comparison that looks for in-place edits -- 5000
         cache misses on a 3e5-row table, 0.3 ms.
@@ -1697,14 +1722,19 @@ class StackPruner:
             detector.Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry
             plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
             # (the same decision on every rank: it follows from the arena's width and the registry alone)
-            final = cls._final_columns(seg_rois.arena.store, detector.Blobs._get_abs_inds()) if final_form else None
+            final = (cls._final_columns(seg_rois.arena.store, detector.Blobs._get_abs_inds(), n_flag_cols)
+                     if final_form else None)
             out, counts = cls._prune_distributed(seg_rois, shape3, plan, sub_roi_slices, channels,
                                                  None if final is None else final[:2])
             if out is None:
                 return None, None
             if final is not None:
+                rest = None
+                if final[3] < len(final[0]):        # (the merge leaves one table: final columns | the flags' columns)
+                    rest = np.ascontiguousarray(out[:, final[3]:])
+                    out = np.ascontiguousarray(out[:, :final[3]])
                 out = out.view(_FinalTable)
-                out.col_names = final[2]
+                out.col_names, out.coloc_cols = final[2], rest
             return out, cls._ratio_frame(cls._ratios_from_counts(counts, plan))
         arena = getattr(seg_rois, "arena", None)
         if arena is not None and not arena.intact(seg_rois, sample_columns=not untouched):
@@ -1737,8 +1767,8 @@ class StackPruner:
         ncol = merged.shape[1]
         detector.Blobs(merged)      # bind the class-level column registry to the 11 standard columns
         abs_inds = detector.Blobs._get_abs_inds()
-        final = cls._final_columns(merged, abs_inds) if final_form else None
-        gather_as = None if final is None else final[:2]
+        final = cls._final_columns(merged, abs_inds, n_flag_cols) if final_form else None
+        gather_as = None if final is None else (final[0], final[1], final[3])
         # regions of this very call finished while the GPU was still detecting (StackDetector.plan_pruning)
         if early is not None and arena is not None and early.matches(arena, plan, channels):
             _lap("set-up (arena check, geometry, registry)")
@@ -1767,8 +1797,9 @@ class StackPruner:
             out = cls._take_rows(merged, rows, abs_cur, abs_inds, gather_as)
             _lap("gather of the output table")
         if final is not None:
+            rest = getattr(out, "coloc_cols", None)
             out = out.view(_FinalTable)
-            out.col_names = final[2]
+            out.col_names, out.coloc_cols = final[2], rest
         df = cls._ratio_frame(cls._ratios_from_counts(counts, plan))
         _lap("ratio frame")
         return out, df

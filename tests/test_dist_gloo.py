@@ -252,6 +252,13 @@ def _worker_dist_prune(rank, world, port, case, out_dir, regions=False):
         np.save(os.path.join(out_dir, f"final{rank}.npy"), np.zeros((0, 0)) if final is None else np.asarray(final))
         with open(os.path.join(out_dir, f"final{rank}.txt"), "w") as f:
             f.write(",".join(final.col_names) if is_final else "")
+        if n_extra:     # ... and with the co-localisation columns announced: final columns + the flags' columns beside them
+            fl, _ = sd.StackPruner.prune_blobs_mp(Img, seg, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                  blocks.sub_rois_offsets, channels, blocks.overlap_padding,
+                                                  final_form=True, untouched=True, n_flag_cols=n_extra)
+            assert fl is None or (isinstance(fl, sd._FinalTable) and fl.coloc_cols is not None)
+            if fl is not None:
+                np.save(os.path.join(out_dir, f"flagged{rank}.npy"), np.hstack((np.asarray(fl), fl.coloc_cols)))
         with open(os.path.join(out_dir, f"regions{rank}.txt"), "w") as f:
             f.write(" ".join(str(v) for v in region_runs))
     finally:
@@ -350,7 +357,7 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
     tmp.spawn(_worker_dist_prune, args=(world, _free_port(), case, str(tmp_path), bool(regions)), nprocs=world, join=True)
     runs = [(tmp_path / f"regions{r}.txt").read_text().split() for r in range(world)]
     if regions:         # (some rank did prune several regions side by side, in both collectives)
-        assert any(len(v) == 2 and int(v[0]) > 1 for v in runs), runs
+        assert any(len(v) == (3 if n_extra else 2) and int(v[0]) > 1 for v in runs), runs
     elif not case.startswith("c4_grid"):      # (tables of that size prune by regions on their own)
         assert not any(runs), runs
     for r in range(world):
@@ -368,6 +375,11 @@ def test_distributed_pruning_equals_one_process(tmp_path, world, case):
         if n_extra:
             assert names == ""
             np.testing.assert_array_equal(final, want)
+            flagged = np.load(tmp_path / f"flagged{r}.npy")
+            rel = want.copy()
+            rel[:, 0:3] = rel[:, 7:10]
+            np.testing.assert_array_equal(flagged[:, :8], rel[:, [0, 1, 2, 3, 4, 5, 6, 10]])
+            np.testing.assert_array_equal(flagged[:, 8:], want[:, 10:10 + n_extra])
         else:
             from magellanmapper_amd import detector
             bb = detector.Blobs(want.copy())

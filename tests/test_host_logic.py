@@ -1289,8 +1289,19 @@ def test_region_wise_pruning_equals_the_whole_table_passes(case, monkeypatch):
         if n_extra:
             assert not isinstance(got_f, sd._FinalTable)
             np.testing.assert_array_equal(got_f, want)
+            # ... unless they are announced: the eight final columns as one contiguous table and, beside it, the columns
+            # the reference reads its flags from (`segments_all[:, 10:10 + C]`, stack_detect.py:463-464)
+            seg_g, _ = build(with_pruner)
+            got_g, df_g = sd.StackPruner.prune_blobs_mp(Img, seg_g, blocks.overlap, blocks.tol, blocks.sub_roi_slices,
+                                                         blocks.sub_rois_offsets, channels, blocks.overlap_padding,
+                                                         final_form=True, untouched=with_pruner, n_flag_cols=n_extra)
+            assert isinstance(got_g, sd._FinalTable) and got_g.col_names == want_cols
+            assert got_g.view(np.ndarray).flags["C_CONTIGUOUS"] and got_g.shape[1] == 8
+            np.testing.assert_array_equal(got_g.view(np.ndarray), want_final)
+            np.testing.assert_array_equal(got_g.coloc_cols, want[:, 10:10 + n_extra])
+            np.testing.assert_array_equal(df_g.to_numpy(), df_want.to_numpy())
         else:
-            assert isinstance(got_f, sd._FinalTable) and got_f.col_names == want_cols
+            assert isinstance(got_f, sd._FinalTable) and got_f.col_names == want_cols and got_f.coloc_cols is None
             np.testing.assert_array_equal(got_f.view(np.ndarray), want_final)
     # other parameters than planned for: the regions are ignored, the whole table is pruned
     seg_c, pruner_c = build(True)
