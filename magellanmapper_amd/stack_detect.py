@@ -89,6 +89,9 @@ class _TableArena:
     def __init__(self, n_cols: int = 11, n_expected: int = 0):
         self.n_cols = n_cols
         self.n_expected = int(n_expected)      # blocks that will be added (0: unknown), for the growth estimate
+        #: room kept beyond the rows asked for (a rank's arena: the seam rows of the other ranks are appended behind its
+        #: own rows for the pruning -- growing for them would copy all four arrays inside the step's tail)
+        self.headroom = 0.0
         self.cap = 4096
         self.store = np.empty((self.cap, n_cols + 3))
         self.zyx = np.empty((self.cap, 3), dtype=np.int32)
@@ -108,6 +111,7 @@ class _TableArena:
             # blocks hold similar numbers of blobs: size for all of them at once (the last doublings would
             # otherwise copy a few hundred thousand rows while the GPU has nothing left to hide them)
             cap = max(cap, int(need * 1.15 * self.n_expected / (len(self.spans) + 1)) + 1024)
+        cap = int(cap * (1.0 + self.headroom))
         for name in ("store", "zyx", "tag", "abs"):
             old = getattr(self, name)
             new = np.empty((cap,) + old.shape[1:], dtype=old.dtype)
@@ -303,7 +307,7 @@ class _RegionPruner:
     Results equal the whole-table passes (``mmx_host_prune_region`` says why); ``StackPruner.prune_blobs_mp`` uses
     them when it is called with the very parameters they were made for, and prunes the whole table otherwise."""
 
-    def __init__(self, arena: _TableArena, plan, channels, sub_roi_slices, shape3, share, halo=None):
+    def __init__(self, arena: _TableArena, plan, channels, sub_roi_slices, shape3, share, halo=None, min_regions=1):
         self.arena, self.plan, self.channels = arena, plan, list(channels)
         # several ranks: the row ranges (behind the arena's own rows) of the seam rows received from the ranks before
         # and after this one -- every region sees them as the first and the last part of its local table
@@ -311,6 +315,10 @@ class _RegionPruner:
         grid = sub_roi_slices.shape
         coords = StackDetector._grid_coords(grid)
         run = max(1, int(grid[2]))
+        # (a rank's share pruned in one go after the exchange: 32 blocks are four x-rows -- half rows give every
+        #  region thread something to do)
+        while run > 1 and -(-len(share) // run) < min_regions:
+            run = -(-run // 2)
         reach = _region_reach(plan["tol"])
         self.regions = []
         for k0 in range(0, len(share), run):
@@ -637,6 +645,8 @@ class StackDetector:
         # own tables and the pruning itself is distributed; otherwise the tables are gathered on rank 0
         local_only = dist.world_size() > 1 and regular and DIST_PRUNE
         arena = _TableArena(11 + n_extra, len(mine)) if (dist.world_size() == 1 or local_only) else None
+        if local_only:
+            arena.headroom = 0.35       # (seam rows of the neighbouring ranks: ~10 % of a rank's rows per neighbour)
         pos = {i: k for k, i in enumerate(mine)}
 
         def exclude_of(k):
@@ -689,9 +699,11 @@ class StackDetector:
                 # (the pruner's set-up -- 0.7 ms for 256 blocks -- waits until the first batch has landed: by then every
                 #  batch is queued and the GPU busy)
                 sink.pruner_factory = make_pruner
-            elif make_pruner is not None and ahead == "1":
-                # (tables with co-localisation columns land block by block through finish(): pruning ahead there costs
-                #  the two-channel C5 run 35-55 ms per volume -- only on request)
+            elif make_pruner is not None:
+                # (tables with co-localisation columns land block by block through finish(), during the LAST channel's
+                #  pass.  Round 4 measured pruning ahead there at +35-55 ms per C5 volume -- the regions were pruned by
+                #  Python then; with the native region step (mmx_host_prune_parts) and the final columns written by the
+                #  merge it is 246.2 -> 240.5 ms, pruning + final columns 15.9 -> 5.8 ms: profiles/r06_experiments.txt)
                 pruner = make_pruner()
             try:
                 tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
@@ -1614,7 +1626,8 @@ class StackPruner:
         if geometry is not None and mine_box is not None and n >= cls.REGION_MIN_ROWS and \
                 len(ar.row_end) == len(geometry[2]) + 1 and ar.row_end[-1] == n:
             rp = _RegionPruner(ar, plan, channels, geometry[0], geometry[1], list(geometry[2]),
-                               halo=((edges[0], edges[1]), (edges[1], edges[2])))
+                               halo=((edges[0], edges[1]), (edges[1], edges[2])),
+                               min_regions=getattr(_region_workers(), "_max_workers", 8))
             if len(rp.regions) > 1:
                 rp.run_all()
                 _lap(f"three passes on own + halo rows ({len(rp.regions)} regions)")
@@ -1720,7 +1733,9 @@ class StackPruner:
         if getattr(seg_rois, "local_only", False):
             # several ranks, each with the tables of its own blocks: a collective (every rank calls this)
             detector.Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry
-            plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
+            plan = cls._geometry(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)[0]
+            if plan is None:            # (cannot be: the tables stay on their ranks only for a regular geometry)
+                plan = cls._axis_plan(shape3, overlap, tol, overlap_padding, sub_roi_slices, sub_rois_offsets)
             # (the same decision on every rank: it follows from the arena's width and the registry alone)
             final = (cls._final_columns(seg_rois.arena.store, detector.Blobs._get_abs_inds(), n_flag_cols)
                      if final_form else None)
