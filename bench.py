@@ -1042,6 +1042,10 @@ def main():
                          "seam rows, the pruning of its rows, the merge of all ranks' survivors, with a recording in place "
                          "of the wire (dist.Loopback) -- a model of the strong-scaling step measured on one GPU")
     ap.add_argument("--full-step-ms", type=float, default=0.0, help="with --share: the one-GPU step to quote linear scaling against")
+    ap.add_argument("--pre-stream", choices=("0", "1"), default="1",
+                    help="per-block preprocessing on a stream of its own beside the LoG kernels (1, the default) or on the "
+                         "LoG stream (0: the kernel families then run one after the other and their HIP-event times are "
+                         "each family's ALONE -- what tools/logfloat_profile.sh compares with the raw-voxel run)")
     ap.add_argument("--prune-prof", action="store_true", help="print the phases of every pruning step to stderr")
     ap.add_argument("--prune-ahead", choices=("auto", "0", "1"), default="auto",
                     help="prune finished regions while the GPU detects: auto = stacks of 64 blocks and more (stack_detect.PRUNE_AHEAD)")
@@ -1119,6 +1123,7 @@ def main():
     from magellanmapper_amd import blob_log as bl
     from magellanmapper_amd import stack_detect as _sd
     _sd.PRUNE_PROF = bool(args.prune_prof)
+    bl.PRE_STREAM = args.pre_stream == "1"
     if args.prune_ahead != "auto":
         _sd.PRUNE_AHEAD = args.prune_ahead
 

@@ -22,7 +22,7 @@ def short(name):
     if any(k in name for k in ("pp_fast_kernel", "pp_generic_kernel", "pp_mid_kernel", "pp_blur_kernel", "pp_stats_kernel",
                                "pp_retile_kernel", "pp_offsets")):
         return "preproc"
-    if "zx6_pack_kernel" in name:
+    if "zx6_pack" in name:              # (zx6_pack_kernel<T>, zx6_pack_f32_kernel)
         return "zxpack"
     if "zx2_kernel" in name or "zx_kernel" in name or "zx4_kernel" in name:
         return "zxpass"
