@@ -66,7 +66,8 @@ CONFIGS = {
                what="2 channels, denoise_size 25, sigma 3..5 x5, co-localisation"),
 }
 #: steps / warm-up of the compact sub-records the default command appends
-SUB_RECORDS = {"c2": (100, 20), "c5": (3, 1)}       # (c2: ~1.3 ms a step -- 20 warm-up steps let the clocks and the host pool settle)
+SUB_RECORDS = {"c2": (100, 20), "c5": (8, 2)}       # (c2: ~1.3 ms a step -- 20 warm-up steps let the clocks and the host pool settle;
+#                                                      c5: 0.25 s a step -- eight steps tell a 5 % change from noise, round 5's three did not)
 RESOLUTIONS = np.array([[1.0, 1.0, 1.0]])
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
 #: algorithmic HBM bytes per voxel per sigma of each kernel
