@@ -683,6 +683,25 @@ int mmx_host_emit_tables(const int32_t* coords, const uint8_t* alive, const int3
                          const int32_t* block_tags, const int32_t* interior, double* store, int64_t ld,
                          int32_t* zyx, int32_t* tag, double* abs_zyx, int64_t row0, int64_t capacity,
                          int64_t* rows_per_block);
+/* ... for blocks detected in SEVERAL channels (ABI v16; the reference's per-channel loop and `np.vstack` in
+ * detect_blobs, magmap/cv/detector.py:899-943): block b's table = channel 0's rows, then channel 1's ..., each channel
+ * from its own peak arrays over the same n_blocks blocks.  n_extra >= 0 columns behind the 11 named ones are zeroed
+ * (-1: untouched); any_before[b] (optional): a blob of block b existed before the border exclusion (None vs an EMPTY
+ * table, :941-942); coloc_rows (optional) [rows][5] int32: block, z, y, x (block-relative), channel per written row --
+ * mmx_coloc_means' d_blobs.
+ * mmx_host_coloc_flags: colocalizer.colocalize_blobs' thresholds and flags (magmap/cv/colocalizer.py:372-441, thresh
+ * "min") for a batch of such tables from the per-blob channel means -- per block, per channel present among its in-ROI
+ * blobs: threshold = smallest mean of that channel over the channel's own in-ROI blobs (NaN-poisoned like np.amin),
+ * flag 1 for every in-ROI blob whose mean reaches it -- written to flags[r * ld + channel] (the tables' extra columns). */
+int mmx_host_emit_tables_multi(int32_t n_channels, const int32_t* const* coords, const uint8_t* const* alive,
+                               const int32_t* const* offsets, int n_blocks, const double* const* sigmas,
+                               const int32_t* n_sigma, const double* channel_ids, const double* block_offsets,
+                               const int32_t* block_tags, const int32_t* interior, double* store, int64_t ld,
+                               int32_t n_extra, int32_t* zyx, int32_t* tag, double* abs_zyx, int64_t row0,
+                               int64_t capacity, int64_t* rows_per_block, uint8_t* any_before, int32_t* coloc_rows);
+int mmx_host_coloc_flags(const double* means, const int32_t* mean_channels, int32_t n_mean_channels, int64_t n,
+                         const int32_t* rows, const int64_t* row_offsets, int n_blocks, const int32_t* shapes,
+                         int32_t n_channels, double* flags, int64_t ld);
 
 /* ---- match-based co-localisation: the two third-party calls of the reference's
  * verifier.find_closest_blobs_cdist (magmap/cv/verifier.py:47-119).

@@ -568,7 +568,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         if isinstance(peaks, PeakBatch):
             pb = _prune_batch_native(peaks, space, float(overlap), stats)
             if sink is not None:        # the caller builds its tables from the arrays (native, no per-block lists)
-                sink(pending["batch"], pb)
+                with torch.cuda.stream(bufs.side):      # (whatever it launches -- co-localisation means -- beside the next batch)
+                    sink(pending["batch"], pb)
                 continue
             pruned = [pb.blobs(b) for b in range(len(pb))]
             peaks = [pb.block(b) for b in range(len(pb))] if return_peaks else [None] * len(pb)

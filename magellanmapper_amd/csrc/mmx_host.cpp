@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <limits>
 #include <vector>
 
 #include <unistd.h>
@@ -1464,11 +1465,39 @@ extern "C" int mmx_host_emit_tables(const int32_t* coords, const uint8_t* alive,
                                     double* store, int64_t ld, int32_t* zyx, int32_t* tag, double* abs_zyx,
                                     int64_t row0, int64_t capacity, int64_t* rows_per_block)
 {
-    if (!offsets || n_blocks < 1 || !sigmas || !block_offsets || !block_tags || !store || ld < 14 || !zyx || !tag ||
-        !abs_zyx || row0 < 0 || !rows_per_block)
+    const int32_t ns = n_sigma;
+    return mmx_host_emit_tables_multi(1, &coords, &alive, &offsets, n_blocks, &sigmas, &ns, &channel, block_offsets,
+                                      block_tags, interior, store, ld, -1, zyx, tag, abs_zyx, row0, capacity,
+                                      rows_per_block, nullptr, nullptr);
+}
+
+// The same for blocks detected in SEVERAL channels (the reference's per-channel loop in detect_blobs,
+// magmap/cv/detector.py:899-943: `blobs_all.append(...)`, `np.vstack(blobs_all)`): block b's table holds channel 0's rows,
+// then channel 1's ..., every channel from its own peak arrays (coords[c] / alive[c] / offsets[c] over the SAME n_blocks
+// blocks) and sigma table.  n_extra >= 0: that many columns behind the 11 named ones are zeroed (the co-localisation
+// flags land there: mmx_host_coloc_flags); -1: left untouched.  any_before[b] (optional): some channel held a blob of
+// block b before the border exclusion (detect_blobs returns None, not an EMPTY table, when none did, :941-942).
+// coloc_rows (optional): [rows][5] int32 per written row -- block, z, y, x (block-relative), channel: what
+// mmx_coloc_means takes as d_blobs.
+extern "C" int mmx_host_emit_tables_multi(int32_t n_channels, const int32_t* const* coords, const uint8_t* const* alive,
+                                          const int32_t* const* offsets, int n_blocks, const double* const* sigmas,
+                                          const int32_t* n_sigma, const double* channel_ids,
+                                          const double* block_offsets, const int32_t* block_tags,
+                                          const int32_t* interior, double* store, int64_t ld, int32_t n_extra,
+                                          int32_t* zyx, int32_t* tag, double* abs_zyx, int64_t row0, int64_t capacity,
+                                          int64_t* rows_per_block, uint8_t* any_before, int32_t* coloc_rows)
+{
+    if (n_channels < 1 || n_channels > 64 || !coords || !alive || !offsets || n_blocks < 1 || !sigmas || !n_sigma ||
+        !channel_ids || !block_offsets || !block_tags || !store || !zyx || !tag || !abs_zyx || row0 < 0 ||
+        !rows_per_block || n_extra < -1 || ld < 14 + (n_extra > 0 ? n_extra : 0))
         return MMX_ERR_ARG;
-    const int64_t n = offsets[n_blocks];
-    if (n && (!coords || !alive)) return MMX_ERR_ARG;
+    int64_t n = 0;
+    for (int c = 0; c < n_channels; ++c) {
+        if (!offsets[c] || !sigmas[c]) return MMX_ERR_ARG;
+        const int64_t nc = offsets[c][n_blocks];
+        if (nc && (!coords[c] || !alive[c])) return MMX_ERR_ARG;
+        n += nc;
+    }
     auto inside = [&](int b, const int32_t* c) {
         if (!interior) return true;
         const int32_t* q = interior + 6 * (int64_t)b;
@@ -1477,11 +1506,16 @@ extern "C" int mmx_host_emit_tables(const int32_t* coords, const uint8_t* alive,
     std::vector<int64_t> first((size_t)n_blocks + 1, row0);
     for (int b = 0; b < n_blocks; ++b) {
         int64_t k = 0;
-        for (int32_t r = offsets[b]; r < offsets[b + 1]; ++r) {
-            if (coords[4 * (int64_t)r + 3] < 0 || coords[4 * (int64_t)r + 3] >= n_sigma) return MMX_ERR_ARG;
-            k += alive[r] && inside(b, coords + 4 * (int64_t)r);
-        }
+        bool any = false;
+        for (int c = 0; c < n_channels; ++c)
+            for (int32_t r = offsets[c][b]; r < offsets[c][b + 1]; ++r) {
+                const int32_t* q = coords[c] + 4 * (int64_t)r;
+                if (q[3] < 0 || q[3] >= n_sigma[c]) return MMX_ERR_ARG;
+                any = any || alive[c][r];
+                k += alive[c][r] && inside(b, q);
+            }
         rows_per_block[b] = k;
+        if (any_before) any_before[b] = any ? 1 : 0;
         first[(size_t)b + 1] = first[(size_t)b] + k;
     }
     if (first[(size_t)n_blocks] > capacity) return MMX_ERR_WORKSPACE;
@@ -1493,23 +1527,95 @@ extern "C" int mmx_host_emit_tables(const int32_t* coords, const uint8_t* alive,
             int64_t at = first[(size_t)b];
             const double* off = block_offsets + 3 * (int64_t)b;
             const int32_t* tg = block_tags + 3 * (int64_t)b;
-            for (int32_t r = offsets[b]; r < offsets[b + 1]; ++r) {
-                const int32_t* c = coords + 4 * (int64_t)r;
-                if (!alive[r] || !inside(b, c)) continue;
-                double* o = store + at * ld;
-                for (int a = 0; a < 3; ++a) {
-                    const double p = (double)c[a] + off[a];
-                    o[a] = p; o[7 + a] = p;
-                    abs_zyx[3 * at + a] = p;
-                    zyx[3 * at + a] = (int32_t)p;
-                    tag[3 * at + a] = tg[a];
-                    o[ld - 3 + a] = (double)tg[a];
+            for (int ch = 0; ch < n_channels; ++ch)
+                for (int32_t r = offsets[ch][b]; r < offsets[ch][b + 1]; ++r) {
+                    const int32_t* c = coords[ch] + 4 * (int64_t)r;
+                    if (!alive[ch][r] || !inside(b, c)) continue;
+                    double* o = store + at * ld;
+                    for (int a = 0; a < 3; ++a) {
+                        const double p = (double)c[a] + off[a];
+                        o[a] = p; o[7 + a] = p;
+                        abs_zyx[3 * at + a] = p;
+                        zyx[3 * at + a] = (int32_t)p;
+                        tag[3 * at + a] = tg[a];
+                        o[ld - 3 + a] = (double)tg[a];
+                    }
+                    o[3] = sigmas[ch][c[3]] * root3;
+                    o[4] = -1.0; o[5] = -1.0; o[6] = channel_ids[ch]; o[10] = -1.0;
+                    for (int e = 0; e < n_extra; ++e) o[11 + e] = 0.0;
+                    if (coloc_rows) {
+                        int32_t* q = coloc_rows + 5 * (at - row0);
+                        q[0] = b; q[1] = c[0]; q[2] = c[1]; q[3] = c[2]; q[4] = (int32_t)channel_ids[ch];
+                    }
+                    ++at;
                 }
-                o[3] = sigmas[c[3]] * root3;
-                o[4] = -1.0; o[5] = -1.0; o[6] = channel; o[10] = -1.0;
-                ++at;
+        }
+    });
+    return MMX_OK;
+}
+
+// The co-localisation flags of a batch of block tables from the per-blob channel means (colocalizer.colocalize_blobs,
+// magmap/cv/colocalizer.py:372-441 with the default thresh "min"), written into the tables' extra columns:
+//   means[k][r]  : mean of image channel mean_channels[k] over the voxels blob r owns (mmx_coloc_means), NaN when it owns
+//                  none; channels without a means row count as NaN everywhere
+//   rows[r]      : block, z, y, x (block-relative), channel of blob r (mmx_host_emit_tables_multi's coloc_rows);
+//                  row_offsets[n_blocks + 1] delimits the blocks; shapes[b][3] the block extents
+//   per block: the channels PRESENT among its in-ROI blobs; for each, the threshold is the smallest mean of that channel
+//   over the channel's own in-ROI blobs (np.amin: a NaN among them poisons it -- then nothing reaches it) and every
+//   in-ROI blob whose mean of that channel reaches the threshold gets flag 1; blobs outside the ROI keep zeros.
+//   flags        : &store[row0][11]: row r's flags at flags[r * ld + c], c < n_channels (zeroed by the caller)
+// MMX_ERR_ARG when a blob's channel is not an image channel (the reference raises IndexError there).
+extern "C" int mmx_host_coloc_flags(const double* means, const int32_t* mean_channels, int32_t n_mean_channels, int64_t n,
+                                    const int32_t* rows, const int64_t* row_offsets, int n_blocks, const int32_t* shapes,
+                                    int32_t n_channels, double* flags, int64_t ld)
+{
+    if (n < 0 || n_blocks < 0 || n_channels < 1 || n_channels > 64 || n_mean_channels < 0 || ld < n_channels ||
+        (n && (!rows || !flags)) || (n_blocks && (!row_offsets || !shapes)) || (n_mean_channels && (!means || !mean_channels)))
+        return MMX_ERR_ARG;
+    int slot_of[64];
+    for (int c = 0; c < 64; ++c) slot_of[c] = -1;
+    for (int k = 0; k < n_mean_channels; ++k) {
+        if (mean_channels[k] < 0 || mean_channels[k] >= n_channels) return MMX_ERR_ARG;
+        slot_of[mean_channels[k]] = k;
+    }
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    auto mean_of = [&](int64_t r, int c) { return slot_of[c] < 0 ? nan : means[(int64_t)slot_of[c] * n + r]; };
+    std::vector<int> bad((size_t)std::max(1, n_blocks), 0);
+    const int T = n < 4000 ? 1 : std::min(pool::get().size(), 16);
+    parallel(std::max(1, std::min(T, n_blocks)), [&](int t, int nt) {
+        std::vector<uint8_t> in_roi;
+        for (int b = t; b < n_blocks; b += nt) {
+            const int64_t lo = row_offsets[b], hi = row_offsets[b + 1];
+            if (hi <= lo) continue;
+            const int32_t* shp = shapes + 3 * (int64_t)b;
+            in_roi.assign((size_t)(hi - lo), 0);
+            uint64_t present = 0;
+            for (int64_t r = lo; r < hi; ++r) {
+                const int32_t* q = rows + 5 * r;
+                const bool in = q[1] >= 0 && q[1] < shp[0] && q[2] >= 0 && q[2] < shp[1] && q[3] >= 0 && q[3] < shp[2];
+                in_roi[(size_t)(r - lo)] = in ? 1 : 0;
+                if (!in) continue;
+                if (q[4] < 0 || q[4] >= n_channels) { bad[(size_t)b] = 1; break; }
+                present |= uint64_t(1) << q[4];
+            }
+            if (bad[(size_t)b]) continue;
+            for (int other = 0; other < n_channels; ++other) {
+                if (!((present >> other) & 1)) continue;
+                double thr = std::numeric_limits<double>::infinity();
+                bool poisoned = false;
+                for (int64_t r = lo; r < hi && !poisoned; ++r) {
+                    if (!in_roi[(size_t)(r - lo)] || rows[5 * r + 4] != other) continue;
+                    const double m = mean_of(r, other);
+                    if (m != m) poisoned = true;
+                    else if (m < thr) thr = m;
+                }
+                if (poisoned) continue;         // (`means >= nan` is False everywhere)
+                for (int64_t r = lo; r < hi; ++r)
+                    if (in_roi[(size_t)(r - lo)] && mean_of(r, other) >= thr) flags[r * ld + other] = 1.0;
             }
         }
     });
+    for (int b = 0; b < n_blocks; ++b)
+        if (bad[(size_t)b]) return MMX_ERR_ARG;
     return MMX_OK;
 }

@@ -437,6 +437,15 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
         pre.set_blocks(origins, shapes, log_shapes)
     per_block: List[List[np.ndarray]] = [[] for _ in shapes]
     done: List[Optional[np.ndarray]] = [None] * len(shapes)
+    # Block tables of several channels straight from the native host path (``sink.emit``: stack_detect._ArenaSink): the
+    # plain per-channel detection -- no rescale, no unmixing -- and, with co-localisation, every channel's image at hand
+    # for the means (raw voxels, or the preprocessed blocks kept by ``Preprocessor.retain``)
+    multi_sink = bool(
+        sink is not None and hasattr(sink, "emit") and len(channels) > 1 and iso_factor is None and dvol.multichannel
+        and bl.HOST_PATH == "native"
+        and not any(getattr(config.get_roi_profile(c), "spectral_unmixing", None) for c in channels)
+        and (not coloc or denoise_max_shape is None or keeper is not None))
+    held: dict = {}
     Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry to the 11 columns
     for chl in channels:
         settings = config.get_roi_profile(chl)
@@ -504,6 +513,25 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
             def to_sink(indices, pb, chl=chl):
                 for i, tbl in zip(indices, sink(indices, pb, chl)):
                     done[i] = tbl
+        elif multi_sink:
+            # several channels: a batch's peak arrays wait (a few hundred KB each) until its LAST channel has been
+            # detected, then all of them go to the arena in one native call, the co-localisation flags with them
+            def to_sink(indices, pb, chl=chl):
+                key = tuple(indices)
+                held.setdefault(key, {})[chl] = pb
+                if chl != channels[-1]:
+                    return
+                pbs = held.pop(key)
+                if sorted(pbs) != sorted(channels):
+                    from . import _native as nat
+                    raise nat.MmxError("the channels of a stack were batched differently: cannot assemble block tables")
+                fn = None
+                if coloc:
+                    fn = lambda idx, rows5, row_offsets, flags_ptr, ld: _colocs_into(
+                        dvol, channels, [origins[i] for i in idx], [shapes[i] for i in idx], rows5, row_offsets,
+                        flags_ptr, ld, denoise_max_shape, keeper)
+                for i, tbl in zip(indices, sink.emit(indices, [pbs[c] for c in channels], channels, fn)):
+                    done[i] = tbl
 
         bl.blob_log_blocks(
             dvol, chl if multichannel else 0, origins, log_shapes,
@@ -567,6 +595,49 @@ def _append_colocs(dvol, channels, origins, shapes, tables, denoise_max_shape, k
                      colocalizer._flags_from_means(t, m, shp, dvol.n_channels)
                      for t, m, shp in zip(tables, flags, shapes)]
     return [None if t is None else np.hstack((t, f)) for t, f in zip(tables, flags)]
+
+
+def _colocs_into(dvol, channels, origins, shapes, rows5, row_offsets, flags_ptr, ld, denoise_max_shape, keeper):
+    """The co-localisation flags of one batch of block tables, written into the tables' extra columns where they lie
+    (``mmx_host_coloc_flags``): ``rows5`` -- block, z, y, x (block-relative), channel of every row, ``row_offsets`` the
+    blocks' row ranges -- go to the device once, every image channel's per-blob means come back behind ONE wait, thresholds
+    and flags are taken natively (``colocalizer._flags_from_means`` is the same rule block by block in NumPy)."""
+    import torch
+    from . import _native as nat
+    from . import blob_log as bl
+    L = nat.lib()
+    dev = dvol.tensor.device
+    n = len(rows5)
+    nb = len(shapes)
+    order = sorted(int(c) for c in channels)
+    if denoise_max_shape is None:
+        blocks, _ = bl._make_blocks(dvol, 0, origins, shapes)
+        d_blocks = bl._to_device_bytes(blocks, dev)
+        views = {c: (blocks, d_blocks, dvol.view(c, False)) for c in order}
+    else:
+        views = {}
+        for c in order:
+            blocks, vol64 = keeper.retained_view(c, origins, shapes)
+            views[c] = (blocks, bl._to_device_bytes(blocks, dev), vol64)
+    d_rows = bl.to_device(rows5.reshape(-1), dev)
+    d_off = bl.to_device(row_offsets.astype(np.int32), dev)
+    d_mean = torch.empty((len(order), n), dtype=torch.float64, device=dev)
+    d_cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    stream = bl._stream_ptr()
+    for k, c in enumerate(order):
+        blocks, d_blocks, vol = views[c]
+        nat.check(L.mmx_coloc_means(ctypes.byref(vol), d_blocks.data_ptr(), len(blocks), d_rows.data_ptr(),
+                                    d_off.data_ptr(), n, d_mean[k].data_ptr(), d_cnt.data_ptr(), stream),
+                  "mmx_coloc_means")
+    h_mean = np.ascontiguousarray(d_mean.cpu().numpy())         # (one wait for every channel's kernel)
+    shp = np.ascontiguousarray(shapes, dtype=np.int32).reshape(nb, 3)
+    chans = np.ascontiguousarray(order, dtype=np.int32)
+    offs = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    rc = L.mmx_host_coloc_flags(h_mean.ctypes.data, chans.ctypes.data, len(order), n, rows5.ctypes.data, offs.ctypes.data,
+                                nb, shp.ctypes.data, dvol.n_channels, flags_ptr, ld)
+    if rc == 1:
+        raise IndexError(f"a blob's channel is out of bounds for axis 0 with size {dvol.n_channels}")
+    nat.check(rc, "mmx_host_coloc_flags")
 
 
 _coloc_pre = None

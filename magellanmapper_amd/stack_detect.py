@@ -219,15 +219,29 @@ class _ArenaSink:
         self.pruner = None
         self.pruner_factory = None      # () -> _RegionPruner, called when the first batch lands
 
-    def __call__(self, indices, pb, chl):
+    def ensure_pruner(self):
+        """The regions' pruner, made when the first rows are about to land (by then every batch is queued)."""
         if self.pruner is None and self.pruner_factory is not None:
             self.pruner, self.pruner_factory = self.pruner_factory(), None
+        return self.pruner
+
+    def __call__(self, indices, pb, chl):
+        return self.emit(indices, [pb], [chl])
+
+    def emit(self, indices, pbs, chls, flags_fn=None):
+        """The tables of one batch of blocks from the peak arrays of every channel they were detected in (``pbs[c]``: a
+        ``PeakBatch`` over the same blocks, channel ``chls[c]``): a block's table holds channel 0's rows, then channel
+        1's ... (the reference's ``np.vstack`` in ``detect_blobs``, detector.py:943).  With extra columns in the arena
+        (co-localisation) ``flags_fn(indices, rows5, row_offsets, flags_ptr, ld)`` fills them for the rows just written
+        -- ``rows5``: block, z, y, x (block-relative), channel per row; ``flags_ptr``: address of the first row's first
+        extra column -- before the regions are told that the blocks have landed."""
+        self.ensure_pruner()
         ar = self.arena
         idx = np.asarray(indices, dtype=np.int64)
         nb = len(idx)
-        alive_before = np.concatenate(([0], np.cumsum(pb.alive, dtype=np.int64)))
-        per_block_before = alive_before[pb.offsets[1:]] - alive_before[pb.offsets[:-1]]
-        need = ar.n + int(alive_before[-1])
+        nch = len(pbs)
+        n_extra = ar.n_cols - 11
+        need = ar.n + int(sum(int(pb.alive.sum()) for pb in pbs))
         if need > ar.cap:
             ar._grow(need)
         interior = None
@@ -242,16 +256,26 @@ class _ArenaSink:
         offs = np.ascontiguousarray(self.block_offsets[idx])
         tags = np.ascontiguousarray(self.grid_coords[idx])
         rows = np.zeros(nb, dtype=np.int64)
-        nat.check(nat.lib().mmx_host_emit_tables(
-            pb.coords.ctypes.data, pb.alive.ctypes.data, pb.offsets.ctypes.data, nb, pb.sigmas.ctypes.data,
-            len(pb.sigmas), float(chl), offs.ctypes.data, tags.ctypes.data,
-            None if interior is None else interior.ctypes.data, ar.store.ctypes.data, ar.store.shape[1],
-            ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data, ar.n, ar.cap, rows.ctypes.data),
-            "mmx_host_emit_tables")
+        any_before = np.zeros(nb, dtype=np.uint8)
+        rows5 = np.empty((max(1, need - ar.n), 5), dtype=np.int32) if flags_fn is not None else None
+        ptrs = lambda arrs: (ctypes.c_void_p * nch)(*[a.ctypes.data for a in arrs])
+        sig = [np.ascontiguousarray(pb.sigmas, dtype=np.float64) for pb in pbs]
+        nat.check(nat.lib().mmx_host_emit_tables_multi(
+            nch, ptrs([pb.coords for pb in pbs]), ptrs([pb.alive for pb in pbs]), ptrs([pb.offsets for pb in pbs]), nb,
+            ptrs(sig), (ctypes.c_int32 * nch)(*[len(v) for v in sig]), (ctypes.c_double * nch)(*[float(c) for c in chls]),
+            offs.ctypes.data, tags.ctypes.data, None if interior is None else interior.ctypes.data,
+            ar.store.ctypes.data, ar.store.shape[1], n_extra if n_extra > 0 else -1,
+            ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data, ar.n, ar.cap, rows.ctypes.data,
+            any_before.ctypes.data, None if rows5 is None else rows5.ctypes.data), "mmx_host_emit_tables_multi")
+        total = int(rows.sum())
+        if flags_fn is not None and total:
+            row_offsets = np.concatenate(([0], np.cumsum(rows))).astype(np.int64)
+            flags_fn(indices, rows5[:total], row_offsets,
+                     ar.store.ctypes.data + (ar.n * ar.store.shape[1] + 11) * 8, ar.store.shape[1])
         out = []
         at = ar.n
         for k in range(nb):
-            if per_block_before[k] == 0:
+            if not any_before[k]:
                 out.append(None)                         # no blobs at all: detect_blobs returns None (:941-942)
             elif rows[k] == 0:
                 out.append(np.zeros((0, ar.n_cols)))     # all excluded: an EMPTY table
@@ -261,7 +285,7 @@ class _ArenaSink:
                 out.append(ar.store[at:at + int(rows[k]), :ar.n_cols])
                 at += int(rows[k])
         if at > ar.n:
-            ar.chan_lo, ar.chan_hi = min(ar.chan_lo, chl), max(ar.chan_hi, chl)
+            ar.chan_lo, ar.chan_hi = min(ar.chan_lo, *chls), max(ar.chan_hi, *chls)
         ar.n = at
         # (row_end per block of the batch: rows of the blocks before it)
         ends = ar.row_end[-1] + np.cumsum(rows)
@@ -669,17 +693,20 @@ class StackDetector:
                                                                    sub_roi_slices, sub_rois_offsets),
                                      prune_channels, sub_roi_slices, shape3, mine)
 
+        sink = None
+
         def finish(k, tbl):
             # shift to ROI coordinates as soon as the block's batch is done (border exclusion and
             # co-localisation have happened on the block-relative table, in the reference's order)
             coord = coords[mine[k]]
             tbl = cls._finish_block(tbl, shapes[k], None, sub_rois_offsets[coord])
             if arena is not None:
+                ahead_of_time = pruner if sink is None else sink.ensure_pruner()
                 if tbl is not None and len(tbl):
                     arena.add(coord, tbl)
                 arena.landed()
-                if pruner is not None:
-                    pruner.advance()
+                if ahead_of_time is not None:
+                    ahead_of_time.advance()
             return tbl
 
         own_dvol = None
@@ -690,8 +717,14 @@ class StackDetector:
                 # a host image handed over for the length of this call: it goes up beside the detection of the blocks
                 # that have landed, and whatever of it this rank's blocks never touched is cancelled before returning
                 dvol = own_dvol = bl.DeviceVolume(img, streamed=True)
-            sink = None
-            if arena is not None and n_extra == 0:
+            if arena is not None:
+                # finished tables go straight from the native host path into the arena where the detection can hand
+                # over peak arrays (one channel; several channels with co-localisation: the tables then land during the
+                # LAST channel's pass, flags included); tables it has to build itself come through finish() -- both ways
+                # the regions of the stack are pruned as their blocks land.  (Round 4 measured pruning ahead at +35-55 ms
+                # per C5 volume with tables landing block by block -- the regions were pruned by Python then; with the
+                # native region step and the final columns written by the merge it is 246.2 -> 240.5 ms, pruning + final
+                # columns 15.9 -> 5.8 ms: profiles/r06_experiments.txt)
                 flat_offsets = np.asarray(sub_rois_offsets, dtype=np.float64).reshape(-1, 3)    # (C order: coords' order)
                 sink = _ArenaSink(arena, np.asarray(coords, dtype=np.int32)[mine[0]:mine[-1] + 1],
                                   flat_offsets[mine[0]:mine[-1] + 1],
@@ -699,12 +732,6 @@ class StackDetector:
                 # (the pruner's set-up -- 0.7 ms for 256 blocks -- waits until the first batch has landed: by then every
                 #  batch is queued and the GPU busy)
                 sink.pruner_factory = make_pruner
-            elif make_pruner is not None:
-                # (tables with co-localisation columns land block by block through finish(), during the LAST channel's
-                #  pass.  Round 4 measured pruning ahead there at +35-55 ms per C5 volume -- the regions were pruned by
-                #  Python then; with the native region step (mmx_host_prune_parts) and the final columns written by the
-                #  merge it is 246.2 -> 240.5 ms, pruning + final columns 15.9 -> 5.8 ms: profiles/r06_experiments.txt)
-                pruner = make_pruner()
             try:
                 tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
                                                              denoise_max_shape=denoise_max_shape,

@@ -1530,3 +1530,89 @@ def test_geometry_memo_and_ratio_frame():
     ratios = {"blobs": [12, 7, 30], "ratio_pruning": [0.5, 1.0, 0.25], "ratio_adjacent": [1.5, 0.75, 2.0]}
     pd.testing.assert_frame_equal(sd.StackPruner._ratio_frame(ratios), pd.DataFrame(ratios))
     assert sd.StackPruner._ratio_frame({}).shape == pd.DataFrame({}).shape
+
+
+def test_multi_channel_tables_and_coloc_flags_native():
+    """``mmx_host_emit_tables_multi`` + ``mmx_host_coloc_flags`` (the co-localisation path's tables straight into the
+    arena): block tables of two channels -- channel 0's rows, then channel 1's, shifted, tagged, border rows dropped --
+    equal what ``detect_blobs`` / ``detect_sub_roi`` / ``merge_blobs`` build step by step, ``None`` vs EMPTY blocks are
+    told apart, and the flags written into the extra columns equal ``colocalizer._flags_from_means`` block by block
+    (NaN means poison a channel's threshold; blobs outside the ROI keep zeros)."""
+    from magellanmapper_amd import _native as nat, colocalizer, stack_detect as sd
+    from magellanmapper_amd.host_resolve import PeakBatch
+    rng = np.random.default_rng(77)
+    nb, shapes = 5, [(30, 40, 50)] * 5
+    sig = [np.array([3.0, 4.0, 5.0]), np.array([2.0, 6.0])]
+
+    def peaks(c, counts):
+        offsets = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+        n = int(offsets[-1])
+        coords = np.column_stack([rng.integers(0, 30, n), rng.integers(0, 40, n), rng.integers(0, 50, n),
+                                  rng.integers(0, len(sig[c]), n)]).astype(np.int32)
+        pb = PeakBatch(coords, rng.random(n), offsets)
+        pb.alive = (rng.random(n) < 0.8).astype(np.uint8)
+        pb.sigmas = sig[c]
+        return pb
+    pbs = [peaks(0, [12, 0, 7, 3, 9]), peaks(1, [5, 0, 0, 4, 11])]
+    pbs[0].alive[pbs[0].offsets[3]:pbs[0].offsets[4]] = 0            # block 3: channel 0's peaks all pruned away
+    grid_coords = np.array([[0, 0, k] for k in range(nb)], dtype=np.int32)
+    offsets3 = np.array([[0.0, 0.0, 45.0 * k] for k in range(nb)])
+    exclude = np.array([[2, 3, 4], [1, 2, 3]])
+    arena = sd._TableArena(13, nb)
+    sink = sd._ArenaSink(arena, grid_coords, offsets3, shapes, lambda i: exclude)
+    seen = {}
+
+    def flags_fn(idx, rows5, row_offsets, flags_ptr, ld):
+        seen["rows5"], seen["off"] = rows5.copy(), row_offsets.copy()
+        n = len(rows5)
+        means = rng.random((2, n)) * 3
+        means[0, rng.integers(0, n, 3)] = np.nan
+        seen["means"] = means
+        chans = np.array([0, 1], dtype=np.int32)
+        shp = np.ascontiguousarray(shapes, dtype=np.int32)
+        nat.check(nat.lib().mmx_host_coloc_flags(means.ctypes.data, chans.ctypes.data, 2, n, rows5.ctypes.data,
+                                                 row_offsets.ctypes.data, nb, shp.ctypes.data, 2, flags_ptr, ld), "flags")
+    out = sink.emit(list(range(nb)), pbs, [0, 1], flags_fn)
+    at = 0
+    for b in range(nb):
+        parts = []
+        for c in (0, 1):
+            lo, hi = pbs[c].offsets[b], pbs[c].offsets[b + 1]
+            rows = pbs[c].coords[lo:hi][pbs[c].alive[lo:hi].view(bool)]
+            t = np.zeros((len(rows), 11))
+            t[:, :3] = rows[:, :3]
+            t[:, 3] = sig[c][rows[:, 3]] * np.sqrt(3)
+            t[:, 4:6], t[:, 6], t[:, 7:10], t[:, 10] = -1, c, rows[:, :3], -1
+            parts.append(t)
+        tbl = np.vstack(parts)
+        if len(tbl) == 0:
+            assert out[b] is None
+            continue
+        tbl = detector.get_blobs_interior(tbl, shapes[b], *exclude)
+        if len(tbl) == 0:
+            assert out[b] is not None and out[b].shape == (0, 13)
+            continue
+        rel = tbl.copy()
+        tbl[:, :3] += offsets3[b]
+        tbl[:, 7:10] += offsets3[b]
+        got = out[b]
+        np.testing.assert_array_equal(got[:, :11], tbl)
+        n = len(tbl)
+        np.testing.assert_array_equal(arena.store[at:at + n, 13:], np.tile(grid_coords[b], (n, 1)))
+        np.testing.assert_array_equal(arena.zyx[at:at + n], tbl[:, :3].astype(np.int32))
+        np.testing.assert_array_equal(arena.abs[at:at + n], tbl[:, 7:10])
+        a, e = seen["off"][b], seen["off"][b + 1]
+        assert e - a == n
+        np.testing.assert_array_equal(seen["rows5"][a:e], np.column_stack([np.full(n, b), rel[:, :3], rel[:, 6]]).astype(np.int32))
+        want = colocalizer._flags_from_means(rel, seen["means"][:, a:e].T, shapes[b], 2)
+        np.testing.assert_array_equal(got[:, 11:], want)
+        at += n
+    assert arena.n == at and arena.row_end[-1] == at and (arena.chan_lo, arena.chan_hi) == (0, 1)
+    # a blob whose channel is no image channel: the reference raises IndexError, the native rule reports a bad argument
+    rows5 = np.array([[0, 1, 1, 1, 5]], dtype=np.int32)
+    off = np.array([0, 1], dtype=np.int64)
+    m = np.zeros((1, 1))
+    fl = np.zeros((1, 2))
+    assert nat.lib().mmx_host_coloc_flags(m.ctypes.data, np.zeros(1, np.int32).ctypes.data, 1, 1, rows5.ctypes.data,
+                                          off.ctypes.data, 1, np.array([[9, 9, 9]], np.int32).ctypes.data, 2,
+                                          fl.ctypes.data, 2) == 1
