@@ -452,10 +452,13 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     t0 = time.perf_counter()
     final = colocs = None
     stats = None
+    step_ends = []
     for _ in range(steps):
         final, colocs, stats = one_step()
+        step_ends.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    each = np.diff(np.concatenate(([t0], step_ends))) * 1e3
     step_timers = dict(timers)          # (the timed region's: the extra steps below keep adding to `timers`)
     n_replays = bl.GRAPH_REPLAYS - replays0
     pre_wait_ms = sum(a.elapsed_time(b) for a, b in bl.PRE_WAITS) / steps if bl.PRE_WAITS else None
@@ -617,6 +620,9 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         "value": round(nvox * steps / elapsed / 1e6, 2), "unit": "Mvoxels/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True,
+        # host clock after every step of the timed region (the last step's barrier is not in these): spread of a step
+        "step_ms_percentiles": {"min": round(float(each.min()), 3), "p50": round(float(np.percentile(each, 50)), 3),
+                                "p95": round(float(np.percentile(each, 95)), 3), "max": round(float(each.max()), 3)},
         "scaling": "strong", "vs_baseline": None,
         "dtype": ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate") if PROFILE["denoise_size"] is None
                  else "f64 preprocessing; " + ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate"),
@@ -991,7 +997,8 @@ def compact(rec):
     """The sub-record form of a full record."""
     pr, roof = rec["pipeline_roofline"], rec["roofline"] or {}
     return {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"],
-            "ms_per_step": rec["ms_per_step"], "blobs": rec["blobs"], "table_sha1": rec["table_sha1"],
+            "ms_per_step": rec["ms_per_step"], "step_ms_percentiles": rec.get("step_ms_percentiles"),
+            "blobs": rec["blobs"], "table_sha1": rec["table_sha1"],
             "frac_wall": pr["frac_wall"], "main_stream_kernel_ms_per_step": pr["main_stream_kernel_ms_per_step_rank0"],
             "host_exposed_ms_per_step": pr["host_exposed_ms_per_step"],
             "dominant_kernel": roof.get("kernel"), "dominant_kernel_frac": roof.get("frac"),
@@ -1047,6 +1054,9 @@ def main():
                     help="per-block preprocessing on a stream of its own beside the LoG kernels (1, the default) or on the "
                          "LoG stream (0: the kernel families then run one after the other and their HIP-event times are "
                          "each family's ALONE -- what tools/logfloat_profile.sh compares with the raw-voxel run)")
+    ap.add_argument("--stack-finisher", choices=("0", "1"), default="1",
+                    help="small one-batch stacks: the host chain behind the kernels as one native call (1, default) or the "
+                         "call-by-call form (0)")
     ap.add_argument("--prune-prof", action="store_true", help="print the phases of every pruning step to stderr")
     ap.add_argument("--prune-ahead", choices=("auto", "0", "1"), default="auto",
                     help="prune finished regions while the GPU detects: auto = stacks of 64 blocks and more (stack_detect.PRUNE_AHEAD)")
@@ -1124,6 +1134,7 @@ def main():
     from magellanmapper_amd import blob_log as bl
     from magellanmapper_amd import stack_detect as _sd
     _sd.PRUNE_PROF = bool(args.prune_prof)
+    _sd.STACK_FINISHER = args.stack_finisher == "1"
     bl.PRE_STREAM = args.pre_stream == "1"
     if args.prune_ahead != "auto":
         _sd.PRUNE_AHEAD = args.prune_ahead

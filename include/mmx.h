@@ -41,7 +41,8 @@ typedef enum {
     MMX_ERR_HIP = 2,        /* a HIP runtime call failed; see mmx_last_hip_error()      */
     MMX_ERR_NO_DEVICE = 3,  /* no gfx950 device visible                                 */
     MMX_ERR_WORKSPACE = 4,  /* workspace too small                                      */
-    MMX_ERR_UNSUPPORTED = 5 /* e.g. kernel radius above MMX_MAX_RADIUS_GENERIC          */
+    MMX_ERR_UNSUPPORTED = 5,/* e.g. kernel radius above MMX_MAX_RADIUS_GENERIC          */
+    MMX_DEFERRED = 6        /* not an error: mmx_host_finish_stack leaves a decision to the caller */
 } mmx_status;
 
 /* input voxel types (reference accepts any dtype through skimage.img_as_float,
@@ -702,6 +703,39 @@ int mmx_host_emit_tables_multi(int32_t n_channels, const int32_t* const* coords,
 int mmx_host_coloc_flags(const double* means, const int32_t* mean_channels, int32_t n_mean_channels, int64_t n,
                          const int32_t* rows, const int64_t* row_offsets, int n_blocks, const int32_t* shapes,
                          int32_t n_channels, double* flags, int64_t ld);
+
+/* A small stack -- all blocks in ONE batch: the GUI's ROI, a grid-search step (magmap/cv/detector.py:931-933 once per
+ * ROI; gui/visualizer.py:2758, io/cli.py:1111-1151) -- from the re-scored candidate table to the final table in one call
+ * (ABI v16): mmx_host_resolve_peaks -> mmx_host_overlap_prune -> mmx_host_emit_tables (rows from 0 on) ->
+ * mmx_host_prune_region over the whole table -> mmx_host_take_rows_final, each with the meaning of its own entry point.
+ *   cands .. n_sigma, thr : as for mmx_host_resolve_peaks; eps: the nomination band (max |f32 - f64| must stay < eps / 4)
+ *   sigmas, overlap, overlap_band : as for mmx_host_overlap_prune
+ *   channel .. any_before : as for mmx_host_emit_tables[_multi] (one channel; capacity rows in store / zyx / tag / abs)
+ *   n_sections .. stat_ld : as for mmx_host_prune_region (own rows = all rows)
+ *   src_cols, n_out, abs_dst0, out[out_capacity][n_out], *out_rows : as for mmx_host_take_rows_final
+ *   stats[8] : contested candidates, peaks, max |f32 - f64|, constant cubes, overlap pairs, blobs after the per-block
+ *              prune, and [6] = why the call returned MMX_DEFERRED: 1 equal peak values in a block (NumPy's argsort
+ *              order decides), 2 the band is too narrow (or a non-finite value), 3 a knife-edge overlap fraction or a
+ *              blob that wins one pair and loses another (the reference's libm calls / pair order), 4 more rows than
+ *              `capacity` / `out_capacity`.  MMX_DEFERRED leaves the merged table untouched: the caller takes the
+ *              call-by-call path on the same candidates. */
+typedef struct {
+    const mmx_cand* cands; uint32_t n_cands, n_total;
+    const mmx_block* blocks; int32_t n_blocks, n_sigma;
+    double thr, eps;
+    const double* sigmas; double overlap, overlap_band;
+    double channel;
+    const double* block_offsets; const int32_t* block_tags; const int32_t* interior;
+    double* store; int64_t ld; int32_t* zyx; int32_t* tag; double* abs_zyx; int64_t capacity;
+    int64_t* rows_per_block; uint8_t* any_before;
+    const int32_t* n_sections; const double* const* bounds; const double* last_end; const int32_t* tol;
+    const double* const* nxt_lo; const double* const* nxt_hi;
+    int64_t* n_slab; int64_t* n_after; int64_t* n_next; int64_t stat_ld;
+    const int32_t* src_cols; int32_t n_out, abs_dst0;
+    double* out; int64_t out_capacity; int64_t* out_rows;
+    double* stats;
+} mmx_finish_stack_args;
+int mmx_host_finish_stack(const mmx_finish_stack_args* a);
 
 /* ---- match-based co-localisation: the two third-party calls of the reference's
  * verifier.find_closest_blobs_cdist (magmap/cv/verifier.py:47-119).

@@ -78,6 +78,27 @@ class DetectArgs(Structure):
                 ("ev_work_free", c_void_p), ("ev_work_read", c_void_p), ("ev_done", c_void_p)]
 
 
+class FinishStackArgs(Structure):
+    """``mmx_finish_stack_args`` (a one-batch stack from the re-scored candidates to its final table: ``mmx_host_finish_stack``)."""
+    _fields_ = [("cands", c_void_p), ("n_cands", c_uint32), ("n_total", c_uint32),
+                ("blocks", c_void_p), ("n_blocks", c_int32), ("n_sigma", c_int32),
+                ("thr", c_double), ("eps", c_double),
+                ("sigmas", c_void_p), ("overlap", c_double), ("overlap_band", c_double),
+                ("channel", c_double),
+                ("block_offsets", c_void_p), ("block_tags", c_void_p), ("interior", c_void_p),
+                ("store", c_void_p), ("ld", c_int64), ("zyx", c_void_p), ("tag", c_void_p), ("abs_zyx", c_void_p),
+                ("capacity", c_int64), ("rows_per_block", c_void_p), ("any_before", c_void_p),
+                ("n_sections", c_void_p), ("bounds", c_void_p), ("last_end", c_void_p), ("tol", c_void_p),
+                ("nxt_lo", c_void_p), ("nxt_hi", c_void_p),
+                ("n_slab", c_void_p), ("n_after", c_void_p), ("n_next", c_void_p), ("stat_ld", c_int64),
+                ("src_cols", c_void_p), ("n_out", c_int32), ("abs_dst0", c_int32),
+                ("out", c_void_p), ("out_capacity", c_int64), ("out_rows", c_void_p),
+                ("stats", c_void_p)]
+
+
+MMX_DEFERRED = 6
+
+
 class DetectInfo(Structure):
     """``mmx_detect_info``."""
     _fields_ = [("zx_path", c_int32), ("mask_layout", c_int32), ("n_pass_rounds", c_int32), ("_pad", c_int32),
@@ -109,7 +130,7 @@ SYMBOLS = (
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_mode", "mmx_preprocess_work_bytes", "mmx_preprocess_batch_generic",
     "mmx_coloc_means", "mmx_coloc_voxels", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
     "mmx_cdist_f64", "mmx_host_lsap", "mmx_expand_probes", "mmx_host_resolve_peaks", "mmx_host_overlap_prune",
-    "mmx_host_emit_tables", "mmx_host_prune_region", "mmx_host_prune_parts", "mmx_host_rows_in_boxes", "mmx_host_append_rows", "mmx_host_emit_survivors", "mmx_host_merge_by_key", "mmx_host_merge_parts_by_key", "mmx_host_gather_by_key", "mmx_host_take_rows_final", "mmx_host_emit_survivors_final", "mmx_host_emit_parts_final", "mmx_host_gather_parts_by_key_final", "mmx_host_take_rows_split", "mmx_host_gather_parts_by_key_split", "mmx_host_emit_tables_multi", "mmx_host_coloc_flags",
+    "mmx_host_emit_tables", "mmx_host_prune_region", "mmx_host_prune_parts", "mmx_host_rows_in_boxes", "mmx_host_append_rows", "mmx_host_emit_survivors", "mmx_host_merge_by_key", "mmx_host_merge_parts_by_key", "mmx_host_gather_by_key", "mmx_host_take_rows_final", "mmx_host_emit_survivors_final", "mmx_host_emit_parts_final", "mmx_host_gather_parts_by_key_final", "mmx_host_take_rows_split", "mmx_host_gather_parts_by_key_split", "mmx_host_emit_tables_multi", "mmx_host_coloc_flags", "mmx_host_finish_stack",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass", "preproc", "coloc", "zxpack")
@@ -231,6 +252,7 @@ def lib() -> ctypes.CDLL:
     L.mmx_host_emit_tables_multi.argtypes = [c_int32, vp, vp, vp, c_int, vp, vp, vp, vp, vp, vp, vp, c_int64, c_int32, vp, vp,
                                              vp, c_int64, c_int64, vp, vp, vp]
     L.mmx_host_coloc_flags.argtypes = [vp, vp, c_int32, c_int64, vp, vp, c_int, vp, c_int32, vp, c_int64]
+    L.mmx_host_finish_stack.argtypes = [POINTER(FinishStackArgs)]
     L.mmx_host_take_rows_split.argtypes = [vp, c_int64, vp, c_int64, POINTER(c_int32), c_int32, vp, c_int32, vp, c_int32, vp]
     L.mmx_host_gather_parts_by_key_split.argtypes = [vp, c_int64, c_int32, vp, vp, vp, vp, c_int64, POINTER(c_int32), c_int32,
                                                      c_int32, vp, c_int64, c_int32, vp]

@@ -424,7 +424,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                     num_sigma: int, threshold: float, overlap: float, *,
                     budget_bytes: int = 24 << 30, stats: Optional[BatchStats] = None,
                     return_peaks: bool = False, on_batch=None, pre=None,
-                    exact_values: Optional[bool] = None, sink=None):
+                    exact_values: Optional[bool] = None, sink=None, finisher=None):
     """``blob_log`` of every block -> list of ``(n, 4)`` float64 ``[z, y, x, sigma]`` arrays.
 
     ``exact_values`` (default True): re-score EVERY candidate in float64 in the batch's own kernel queue, so
@@ -443,6 +443,10 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     float64 result exactly as the reference's ``blob_log`` does.
     ``sink(indices, peak_batch)`` (native host path only) takes each batch as a :class:`PeakBatch` -- rows, ``alive``
     flags, block offsets -- instead of per-block arrays; the call then returns ``None`` entries for those blocks.
+    ``finisher(indices, cands, n_cands, blocks, space, thr, eps, overlap, stats) -> bool`` (native host path, only when
+    ALL blocks are one batch): takes the batch's re-scored candidate table and does everything behind it itself
+    (``stack_detect._StackFinisher``: one native call up to the stack's final table); ``False``: it left the batch to
+    the usual steps.
     """
     _require_gpu()
     space = ScaleSpace.make(min_sigma, max_sigma, num_sigma)
@@ -564,7 +568,10 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             enq += 1
         pending, jobs[k] = jobs[k], None
         # host + side-stream work of batch k, the GPU busy with the batches behind it
-        peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats)
+        peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats,
+                               finisher=finisher if n_b == 1 else None, overlap=float(overlap))
+        if peaks is _FINISHED:
+            continue
         if isinstance(peaks, PeakBatch):
             pb = _prune_batch_native(peaks, space, float(overlap), stats)
             if sink is not None:        # the caller builds its tables from the arrays (native, no per-block lists)
@@ -886,8 +893,11 @@ def _launch_batch_graph(L, a, info, bufs: _Buffers, blocks, space, vol32, vol_ex
     return rc
 
 
+_FINISHED = object()        # what `_finish_detect` returns when a finisher has taken the whole batch
+
+
 def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _Buffers, d_w0, d_w2,
-                   stats: BatchStats):
+                   stats: BatchStats, finisher=None, overlap: float = 0.5):
     """Wait for one batch's candidates and turn them into ordered raw peaks
     ``(coords int64 (n, 4), values float64 (n,))`` per block."""
     job["done"].synchronize()
@@ -923,6 +933,12 @@ def _finish_detect(job, dvol, space: ScaleSpace, thr: float, eps: float, bufs: _
                     cands = bufs.host_table(which).numpy()[:count * nat.CAND_DTYPE.itemsize].view(nat.CAND_DTYPE)
                 else:
                     cands = table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)
+                if finisher is not None and not job.get("retries") and finisher(
+                        job.get("batch"), cands, n_cands, job["blocks"], space, thr, eps, overlap, stats):
+                    stats.n_blocks += job["nb"]
+                    stats.n_voxels += job["n_vox"]
+                    stats.n_candidates += n_cands
+                    return _FINISHED
                 out = _resolve_peaks_native(cands, n_cands, job["blocks"], ns, thr, stats, eps)
             else:
                 cands = (table[:count * nat.CAND_DTYPE.itemsize].cpu().numpy().view(nat.CAND_DTYPE)

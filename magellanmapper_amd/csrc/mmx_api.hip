@@ -129,6 +129,7 @@ const char* mmx_strerror(int status)
         case MMX_ERR_NO_DEVICE: return "no gfx950 device";
         case MMX_ERR_WORKSPACE: return "workspace too small";
         case MMX_ERR_UNSUPPORTED: return "unsupported configuration";
+        case MMX_DEFERRED: return "left to the caller";
         default: return "unknown status";
     }
 }

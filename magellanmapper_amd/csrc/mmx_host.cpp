@@ -1619,3 +1619,90 @@ extern "C" int mmx_host_coloc_flags(const double* means, const int32_t* mean_cha
         if (bad[(size_t)b]) return MMX_ERR_ARG;
     return MMX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// A SMALL stack -- all its blocks in one batch (the GUI's ROI, a grid-search step: magmap/cv/detector.py:931-933 called
+// once per ROI) -- from the re-scored candidate table to the final table in ONE call: peak decisions
+// (mmx_host_resolve_peaks), per-block overlap prune (mmx_host_overlap_prune), block tables into the merged table
+// (mmx_host_emit_tables), the three pruning passes over the whole table (mmx_host_prune_region) and the gather in the
+// final columns (mmx_host_take_rows_final).  Each piece is the entry point of its own name; what this saves is the
+// host language between them -- five calls' worth of array set-up, as long as the kernels of such a stack.
+// MMX_DEFERRED (not an error; stats[6] says why): a decision needs the caller -- two equal peak values in a block
+// (NumPy's argsort order: 1), float32 values further than eps / 4 from the exact ones (a wider band: 2), an overlap
+// fraction on the knife edge or a blob that both wins and loses a pair (the reference's libm calls and pair order: 3),
+// more rows than the tables take (4).  Nothing has been written to the merged table then: the caller takes the
+// call-by-call path on the same candidates.
+extern "C" int mmx_host_finish_stack(const mmx_finish_stack_args* a)
+{
+    if (!a || !a->blocks || a->n_blocks < 1 || a->n_sigma < 1 || !a->sigmas || !a->block_offsets || !a->block_tags ||
+        !a->store || !a->zyx || !a->tag || !a->abs_zyx || !a->rows_per_block || !a->n_sections || !a->bounds ||
+        !a->last_end || !a->tol || !a->nxt_lo || !a->nxt_hi || !a->n_slab || !a->n_after || !a->n_next || !a->src_cols ||
+        !a->out || !a->out_rows || !a->stats || (a->n_total && !a->cands) || a->n_cands > a->n_total)
+        return MMX_ERR_ARG;
+    double* st = a->stats;
+    for (int i = 0; i < 8; ++i) st[i] = 0.0;
+    *a->out_rows = 0;
+    const int nb = a->n_blocks;
+    const size_t nc = std::max<size_t>(1, a->n_cands);
+    std::vector<int32_t> nz_coords(4 * nc), coords(4 * nc), offsets((size_t)nb + 1, 0);
+    std::vector<double> nz_vals(nc), vals(nc);
+    std::vector<uint8_t> ties((size_t)nb, 0);
+    double rst[4] = {0, 0, 0, 0};
+    int rc = mmx_host_resolve_peaks(a->cands, a->n_cands, a->n_total, a->blocks, nb, a->n_sigma, a->thr, nz_coords.data(),
+                                    nz_vals.data(), coords.data(), vals.data(), offsets.data(), ties.data(), rst);
+    if (rc != MMX_OK) return rc;
+    st[0] = rst[0]; st[1] = rst[1]; st[2] = rst[2]; st[3] = rst[3];
+    if (a->n_cands && !(rst[2] < 0.25 * a->eps)) { st[6] = 2; return MMX_DEFERRED; }     // (also a non-finite value)
+    for (int b = 0; b < nb; ++b)
+        if (ties[(size_t)b]) { st[6] = 1; return MMX_DEFERRED; }
+    const int64_t n = offsets[(size_t)nb];
+    std::vector<uint8_t> alive((size_t)std::max<int64_t>(1, n), 1), open_blocks((size_t)nb, 0);
+    int64_t n_pairs = 0, n_knife = 0;
+    if (n) {
+        int64_t cap = std::max<int64_t>(1024, 4 * n);
+        for (;;) {
+            std::vector<int32_t> pairs((size_t)(2 * cap));
+            std::vector<double> frac((size_t)cap);
+            std::fill(alive.begin(), alive.end(), (uint8_t)1);
+            rc = mmx_host_overlap_prune(coords.data(), offsets.data(), nb, a->sigmas, a->n_sigma, a->overlap,
+                                        a->overlap_band, alive.data(), open_blocks.data(), pairs.data(), frac.data(), cap,
+                                        &n_pairs, &n_knife);
+            if (rc != MMX_OK) return rc;
+            if (n_pairs <= cap) break;
+            cap = n_pairs + 64;
+        }
+        st[4] = (double)n_pairs;
+        if (n_knife) { st[6] = 3; return MMX_DEFERRED; }
+        for (int b = 0; b < nb; ++b)
+            if (open_blocks[(size_t)b]) { st[6] = 3; return MMX_DEFERRED; }
+    }
+    int64_t n_alive = 0;
+    for (int64_t r = 0; r < n; ++r) n_alive += alive[(size_t)r];
+    st[5] = (double)n_alive;
+    if (n_alive > a->capacity || n_alive > a->out_capacity) { st[6] = 4; return MMX_DEFERRED; }
+    const int32_t* cp = coords.data();
+    const uint8_t* ap = alive.data();
+    const int32_t* op = offsets.data();
+    const int32_t ns = a->n_sigma;
+    rc = mmx_host_emit_tables_multi(1, &cp, &ap, &op, nb, &a->sigmas, &ns, &a->channel, a->block_offsets, a->block_tags,
+                                    a->interior, a->store, a->ld, -1, a->zyx, a->tag, a->abs_zyx, 0, a->capacity,
+                                    a->rows_per_block, a->any_before, nullptr);
+    if (rc != MMX_OK) return rc;
+    int64_t rows = 0;
+    for (int b = 0; b < nb; ++b) rows += a->rows_per_block[b];
+    if (rows == 0) return MMX_OK;
+    // the three passes work on a private copy of the absolute coordinates: the per-block tables stay as detected
+    std::vector<double> abs_cur(a->abs_zyx, a->abs_zyx + 3 * rows);
+    std::vector<int64_t> cur((size_t)rows), keep((size_t)rows);
+    for (int64_t r = 0; r < rows; ++r) cur[(size_t)r] = r;
+    int64_t kept = 0;
+    rc = mmx_host_prune_region(a->zyx, a->tag, abs_cur.data(), cur.data(), rows, INT64_MIN, INT64_MAX, a->n_sections,
+                               a->bounds, a->last_end, a->tol, a->nxt_lo, a->nxt_hi, keep.data(), nullptr, &kept,
+                               a->n_slab, a->n_after, a->n_next, a->stat_ld);
+    if (rc != MMX_OK) return rc;
+    rc = mmx_host_take_rows_final(a->store, a->ld, keep.data(), kept, a->src_cols, a->n_out, abs_cur.data(), a->abs_dst0,
+                                  a->out);
+    if (rc != MMX_OK) return rc;
+    *a->out_rows = kept;
+    return MMX_OK;
+}

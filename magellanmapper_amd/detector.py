@@ -394,7 +394,7 @@ def detect_blobs(roi, channel: Optional[Sequence[int]],
 
 def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                                on_block=None, denoise_max_shape=None, exclude=None,
-                               coloc: bool = False, sink=None) -> List[Optional[np.ndarray]]:
+                               coloc: bool = False, sink=None, stack_finisher=None) -> List[Optional[np.ndarray]]:
     """:func:`detect_blobs` for many blocks of one resident volume in one device pass.
 
     Returns one 11-column table (block-relative coordinates) or ``None`` per block, rows
@@ -409,6 +409,8 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
     ``sink(indices, peak_batch, channel) -> tables`` (optional) builds the finished tables of a batch itself from
     the native host path's arrays (``blob_log.PeakBatch``; ``stack_detect._ArenaSink`` writes them straight into the
     merged table): used for one channel without rescale / co-localisation, instead of ``exclude`` + ``on_block``.
+    ``stack_finisher`` (optional; ``stack_detect._StackFinisher``): for a stack whose blocks are ONE batch, everything
+    behind the kernels -- peaks, per-block prune, tables, the stack's pruning, final columns -- in one native call.
     """
     from . import blob_log as bl
     multichannel, channels = _channels_of(dvol.tensor.ndim, dvol.n_channels, channel)
@@ -533,12 +535,22 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                 for i, tbl in zip(indices, sink.emit(indices, [pbs[c] for c in channels], channels, fn)):
                     done[i] = tbl
 
+        fin = None
+        if stack_finisher is not None and to_sink is not None and not multi_sink and len(channels) == 1:
+            def fin(indices, cands, n_cands, blocks, space, thr, eps, overlap, stats_, chl=chl):
+                tables = stack_finisher.run(indices, cands, n_cands, blocks, space, thr, eps, overlap, stats_, chl)
+                if tables is None:
+                    return False
+                for i, tbl in zip(indices, tables):
+                    done[i] = tbl
+                return True
+
         bl.blob_log_blocks(
             dvol, chl if multichannel else 0, origins, log_shapes,
             min_sigma=settings["min_sigma_factor"] * scaling_factor,
             max_sigma=settings["max_sigma_factor"] * scaling_factor,
             num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
-            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=source, sink=to_sink)
+            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=source, sink=to_sink, finisher=fin)
     return done
 
 

@@ -44,6 +44,9 @@ DIST_PRUNE = True
 PRUNE_AHEAD = ""
 #: print the phases of the pruning step to stderr (tools/prune_prof.py)
 PRUNE_PROF = False
+#: small one-batch stacks: the host chain behind the kernels as ONE native call (``_StackFinisher``); False keeps the
+#: call-by-call form (what tests compare it with)
+STACK_FINISHER = True
 
 
 class Image5d:
@@ -244,15 +247,7 @@ class _ArenaSink:
         need = ar.n + int(sum(int(pb.alive.sum()) for pb in pbs))
         if need > ar.cap:
             ar._grow(need)
-        interior = None
-        if self.exclude_of is not None:
-            interior = np.empty((nb, 6), dtype=np.int32)
-            for k, i in enumerate(indices):
-                ex = self.exclude_of(i)
-                lo = np.zeros(3) if ex is None else np.asarray(ex[0], dtype=float)
-                hi = np.asarray(self.shapes[i], dtype=float) - (0 if ex is None else np.asarray(ex[1], dtype=float))
-                interior[k, :3] = np.ceil(lo)            # integer coordinates: z >= lo  <=>  z >= ceil(lo)
-                interior[k, 3:] = np.ceil(hi)            #                      z < hi   <=>  z < ceil(hi)
+        interior = self.interior_of(indices)
         offs = np.ascontiguousarray(self.block_offsets[idx])
         tags = np.ascontiguousarray(self.grid_coords[idx])
         rows = np.zeros(nb, dtype=np.int64)
@@ -272,9 +267,32 @@ class _ArenaSink:
             row_offsets = np.concatenate(([0], np.cumsum(rows))).astype(np.int64)
             flags_fn(indices, rows5[:total], row_offsets,
                      ar.store.ctypes.data + (ar.n * ar.store.shape[1] + 11) * 8, ar.store.shape[1])
+        out = self.landed(tags, rows, any_before, chls)
+        if self.pruner is not None:
+            self.pruner.advance()
+        return out
+
+    def interior_of(self, indices):
+        """``[lo z, y, x, hi z, y, x]`` per block of a batch: the block-relative bounds rows must lie in (border
+        exclusion, ``detector.get_blobs_interior``), ``None`` without exclusion."""
+        if self.exclude_of is None:
+            return None
+        interior = np.empty((len(indices), 6), dtype=np.int32)
+        for k, i in enumerate(indices):
+            ex = self.exclude_of(i)
+            lo = np.zeros(3) if ex is None else np.asarray(ex[0], dtype=float)
+            hi = np.asarray(self.shapes[i], dtype=float) - (0 if ex is None else np.asarray(ex[1], dtype=float))
+            interior[k, :3] = np.ceil(lo)            # integer coordinates: z >= lo  <=>  z >= ceil(lo)
+            interior[k, 3:] = np.ceil(hi)            #                      z < hi   <=>  z < ceil(hi)
+        return interior
+
+    def landed(self, tags, rows, any_before, chls):
+        """Book-keeping for rows a native call has just written behind the arena's last row: the per-block tables
+        (views of the store; ``None`` for a block without blobs, an EMPTY table where all were excluded)."""
+        ar = self.arena
         out = []
         at = ar.n
-        for k in range(nb):
+        for k in range(len(rows)):
             if not any_before[k]:
                 out.append(None)                         # no blobs at all: detect_blobs returns None (:941-942)
             elif rows[k] == 0:
@@ -290,9 +308,110 @@ class _ArenaSink:
         # (row_end per block of the batch: rows of the blocks before it)
         ends = ar.row_end[-1] + np.cumsum(rows)
         ar.row_end.extend(int(v) for v in ends)
-        if self.pruner is not None:
-            self.pruner.advance()
         return out
+
+
+class _StackFinisher:
+    """A SMALL stack -- all its blocks in one batch (the GUI's ROI, a grid-search step) -- from the re-scored candidates
+    to the final table in ONE native call (``mmx_host_finish_stack``: peak decisions, per-block overlap prune, block
+    tables into the arena, the three pruning passes, the gather in the final columns) instead of five calls with array
+    set-up in Python between them: those five are as long as the kernels of such a stack.
+
+    Plays the part of a :class:`_RegionPruner` towards ``StackPruner.prune_blobs_mp``: made by
+    ``detect_blobs_sub_rois`` from the planned pruning parameters, it hands its table over when ``prune_blobs_mp`` is
+    called with those very parameters and ``final_form`` -- otherwise the arena it filled is pruned as always.  Where a
+    decision needs the reference's own calls (equal peak values, a knife-edge overlap, a pruning chain, a band that
+    proved too narrow) the native call changes nothing and the batch takes the call-by-call path."""
+
+    def __init__(self, sink: "_ArenaSink", plan, channels):
+        self.sink, self.arena, self.plan, self.channels = sink, sink.arena, plan, list(channels)
+        self.layout = None          # (source columns, place of the abs coordinates, names, n_main) of the table made
+        self.result = None          # (final table, counts)
+        self.deferred = 0           # why the last run was left to the caller (mmx_host_finish_stack's stats[6])
+
+    def run(self, indices, cands, n_cands: int, blocks, space, thr: float, eps: float, overlap: float, stats, chl):
+        """The tables of the batch (as ``_ArenaSink.emit`` returns them), or ``None`` when the call was deferred."""
+        from .host_resolve import OVERLAP_BAND
+        ar = self.arena
+        if ar.n or self.result is not None or len(self.channels) != 1 or chl != self.channels[0]:
+            return None
+        layout = StackPruner._final_columns(ar.store, detector.Blobs._get_abs_inds())
+        if layout is None or layout[3] != len(layout[0]):
+            return None
+        nb = len(indices)
+        if max(n_cands, 1) > ar.cap:
+            ar._grow(n_cands)
+        idx = np.asarray(indices, dtype=np.int64)
+        offs = np.ascontiguousarray(self.sink.block_offsets[idx])
+        tags = np.ascontiguousarray(self.sink.grid_coords[idx])
+        interior = self.sink.interior_of(indices)
+        sig = np.ascontiguousarray(space.sigmas, dtype=np.float64)
+        rows = np.zeros(nb, dtype=np.int64)
+        any_before = np.zeros(nb, dtype=np.uint8)
+        ld = self.plan["max_slabs"]
+        stat = np.zeros((3, 3, ld), dtype=np.int64)           # [kind][axis][slab]
+        src = layout[0]
+        out = np.empty((max(n_cands, 1), len(src)))
+        out_rows = ctypes.c_int64(0)
+        st = np.zeros(8)
+        n_sec, bounds, last_end, tol3, nxt_lo, nxt_hi = self.plan["c_args"]
+        src_c = (ctypes.c_int32 * len(src))(*src)
+        a = nat.FinishStackArgs()
+        a.cands, a.n_cands, a.n_total = (cands.ctypes.data if len(cands) else None), int(n_cands), len(cands)
+        a.blocks, a.n_blocks, a.n_sigma = blocks.ctypes.data, nb, len(sig)
+        a.thr, a.eps = float(thr), float(eps)
+        a.sigmas, a.overlap, a.overlap_band = sig.ctypes.data, float(overlap), float(OVERLAP_BAND)
+        a.channel = float(chl)
+        a.block_offsets, a.block_tags = offs.ctypes.data, tags.ctypes.data
+        a.interior = None if interior is None else interior.ctypes.data
+        a.store, a.ld = ar.store.ctypes.data, ar.store.shape[1]
+        a.zyx, a.tag, a.abs_zyx, a.capacity = ar.zyx.ctypes.data, ar.tag.ctypes.data, ar.abs.ctypes.data, ar.cap
+        a.rows_per_block, a.any_before = rows.ctypes.data, any_before.ctypes.data
+        a.n_sections = ctypes.cast(n_sec, ctypes.c_void_p)
+        a.bounds, a.last_end = ctypes.cast(bounds, ctypes.c_void_p), ctypes.cast(last_end, ctypes.c_void_p)
+        a.tol = ctypes.cast(tol3, ctypes.c_void_p)
+        a.nxt_lo, a.nxt_hi = ctypes.cast(nxt_lo, ctypes.c_void_p), ctypes.cast(nxt_hi, ctypes.c_void_p)
+        a.n_slab, a.n_after, a.n_next, a.stat_ld = stat[0].ctypes.data, stat[1].ctypes.data, stat[2].ctypes.data, ld
+        a.src_cols, a.n_out, a.abs_dst0 = ctypes.cast(src_c, ctypes.c_void_p), len(src), layout[1]
+        a.out, a.out_capacity = out.ctypes.data, len(out)
+        a.out_rows = ctypes.cast(ctypes.pointer(out_rows), ctypes.c_void_p)
+        a.stats = st.ctypes.data
+        rc = nat.lib().mmx_host_finish_stack(ctypes.byref(a))
+        if rc == nat.MMX_DEFERRED:
+            self.deferred = int(st[6])
+            return None
+        nat.check(rc, "mmx_host_finish_stack")
+        err = float(st[2])
+        stats.max_f32_error = max(stats.max_f32_error, err) if n_cands else stats.max_f32_error
+        stats.n_contested += int(st[0])
+        stats.n_probes += len(cands) - int(n_cands)
+        stats.n_peaks += int(st[1])
+        stats.n_overlap_pairs += int(st[4])
+        stats.n_blobs += int(st[5])
+        tables = self.sink.landed(tags, rows, any_before, [chl])
+        counts = np.zeros((1, 3, ld, 3), dtype=np.int64)
+        counts[0] = np.moveaxis(stat, 0, -1)
+        self.layout = layout
+        self.result = (out[:out_rows.value], counts)
+        return tables
+
+    # ---- towards prune_blobs_mp: the part of a _RegionPruner
+    def matches(self, arena, plan, channels) -> bool:
+        return self.result is not None and _RegionPruner.matches(self, arena, plan, channels)
+
+    def serves(self, gather_as) -> bool:
+        lay = self.layout
+        return (gather_as is not None and lay is not None and list(gather_as[0]) == list(lay[0])
+                and gather_as[1] == lay[1] and gather_as[2] == lay[3])
+
+    def finish(self, abs_inds, final=None, _lap=lambda what: None):
+        return self.result
+
+    def advance(self) -> None:
+        pass
+
+    def cancel(self) -> None:
+        pass
 
 
 def _region_reach(tol3) -> np.ndarray:
@@ -694,6 +813,7 @@ class StackDetector:
                                      prune_channels, sub_roi_slices, shape3, mine)
 
         sink = None
+        finisher = None
 
         def finish(k, tbl):
             # shift to ROI coordinates as soon as the block's batch is done (border exclusion and
@@ -732,10 +852,21 @@ class StackDetector:
                 # (the pruner's set-up -- 0.7 ms for 256 blocks -- waits until the first batch has landed: by then every
                 #  batch is queued and the GPU busy)
                 sink.pruner_factory = make_pruner
+                # a small stack of one channel (all blocks in one batch: the GUI's ROI, a grid-search step): the whole
+                # host chain behind its kernels as one native call
+                if (regular and dist.world_size() == 1 and make_pruner is None and n_extra == 0 and STACK_FINISHER
+                        and len(list(channel or [0])) == 1 and len(mine) <= bl.GRAPH_BLOCKS
+                        and denoise_max_shape is None and list(hint[3]) == list(channel or [0])):
+                    ov, tl, pad, _ = hint
+                    plan_ = StackPruner._geometry(shape3, ov, tl, tl if pad is None else pad, sub_roi_slices,
+                                                  sub_rois_offsets)[0]
+                    if plan_ is not None:
+                        finisher = _StackFinisher(sink, plan_, hint[3])
             try:
                 tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
                                                              denoise_max_shape=denoise_max_shape,
-                                                             exclude=exclude_of, coloc=coloc, sink=sink)
+                                                             exclude=exclude_of, coloc=coloc, sink=sink,
+                                                             stack_finisher=finisher)
             except BaseException:
                 # the detection failed: the regions pruned ahead have nobody to collect them
                 for p_ in (pruner, None if sink is None else sink.pruner):
@@ -750,6 +881,8 @@ class StackDetector:
                     own_dvol.close()
             if sink is not None and sink.pruner is not None:
                 pruner = sink.pruner
+            if finisher is not None and finisher.result is not None:
+                pruner = finisher           # (its table is what prune_blobs_mp hands out, asked the planned way)
         cls.last_stats = stats
         local = [(i, tbl) for i, tbl in zip(mine, tables)]
         seg_rois = cls.assemble_seg_rois(local, grid, n_extra, arena, local_only=local_only)
@@ -1812,7 +1945,8 @@ class StackPruner:
         final = cls._final_columns(merged, abs_inds, n_flag_cols) if final_form else None
         gather_as = None if final is None else (final[0], final[1], final[3])
         # regions of this very call finished while the GPU was still detecting (StackDetector.plan_pruning)
-        if early is not None and arena is not None and early.matches(arena, plan, channels):
+        if early is not None and arena is not None and early.matches(arena, plan, channels) and \
+                getattr(early, "serves", lambda g: True)(gather_as):
             _lap("set-up (arena check, geometry, registry)")
             out, counts = early.finish(abs_inds, gather_as, _lap)
             _lap("regions pruned during detection: the rest + merge")

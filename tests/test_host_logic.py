@@ -1616,3 +1616,103 @@ def test_multi_channel_tables_and_coloc_flags_native():
     assert nat.lib().mmx_host_coloc_flags(m.ctypes.data, np.zeros(1, np.int32).ctypes.data, 1, 1, rows5.ctypes.data,
                                           off.ctypes.data, 1, np.array([[9, 9, 9]], np.int32).ctypes.data, 2,
                                           fl.ctypes.data, 2) == 1
+
+
+def test_one_native_call_for_a_small_stack_equals_the_call_by_call_chain():
+    """``mmx_host_finish_stack`` through ``stack_detect._StackFinisher``: a one-batch stack from its re-scored candidate
+    table to the final table in one native call gives what the five calls give one after the other
+    (``_resolve_peaks_native`` -> ``_prune_batch_native`` -> ``_ArenaSink`` -> ``prune_blobs_mp(final_form=True)``) --
+    per-block tables, the final table, the pruning ratios, the counters -- hands its table out only when
+    ``prune_blobs_mp`` is asked the planned way, and defers (changing nothing) when a block holds two equal peak values
+    or the float32 values strayed beyond the band."""
+    from magellanmapper_amd import _native as nat, blob_log as bl, stack_detect as sd
+    config.setup_roi_profiles(None)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.roi_profile.update(segment_size=20, denoise_size=None)
+    shape = (38, 40, 36)
+    blocks_g = sd.setup_blocks(config.roi_profile, shape)
+    grid = blocks_g.sub_roi_slices.shape
+    coords = list(np.ndindex(*grid))
+    shapes = [tuple(len(range(*s.indices(n))) for s, n in zip(blocks_g.sub_roi_slices[c], shape)) for c in coords]
+    nb, ns = len(coords), 3
+    assert nb == 8
+    rng = np.random.default_rng(5)
+    space = bl.ScaleSpace.make(3.0, 5.0, ns)
+    blocks = np.zeros(nb, dtype=nat.BLOCK_DTYPE)
+    for k, shp in enumerate(shapes):
+        blocks[k] = (0, shp[0], shp[1], shp[2], k, 32, 0)
+    offsets3 = np.array([blocks_g.sub_rois_offsets[c] for c in coords], dtype=np.float64)
+
+    class Img:
+        pass
+    Img.shape = shape
+    args = (blocks_g.overlap, blocks_g.tol, blocks_g.sub_roi_slices, blocks_g.sub_rois_offsets, [0],
+            blocks_g.overlap_padding)
+    plan = sd.StackPruner._geometry(shape, blocks_g.overlap, blocks_g.tol, blocks_g.overlap_padding,
+                                    blocks_g.sub_roi_slices, blocks_g.sub_rois_offsets)[0]
+
+    def sink_for(arena):
+        return sd._ArenaSink(arena, np.asarray(coords, dtype=np.int32), offsets3, shapes, None)
+
+    def chain(table, n_c):
+        stats = bl.BatchStats()
+        pb = bl._prune_batch_native(bl._resolve_peaks_native(table, n_c, blocks, ns, 0.1, stats, 1e-3), space, 0.5, stats)
+        arena = sd._TableArena(11, nb)
+        tables = sink_for(arena)(list(range(nb)), pb, 0)
+        seg = np.zeros(grid, dtype=object).view(sd._SegRois)
+        for c, t in zip(coords, tables):
+            seg[c] = t
+        seg.arena = arena
+        final, df = sd.StackPruner.prune_blobs_mp(Img, seg, *args, final_form=True, untouched=True)
+        return tables, final, df, stats
+
+    def one_call(table, n_c):
+        stats = bl.BatchStats()
+        arena = sd._TableArena(11, nb)
+        fin = sd._StackFinisher(sink_for(arena), plan, [0])
+        detector.Blobs(np.ones((1, 4))).format_blobs()
+        tables = fin.run(list(range(nb)), table, n_c, blocks, space, 0.1, 1e-3, 0.5, stats, 0)
+        return fin, arena, tables, stats
+
+    done = 0
+    for trial in range(10):
+        table, n_c = _random_candidates(rng, shapes, ns, 60 if trial == 0 else 9)      # (dense blocks chain: deferred)
+        want_tables, want_final, want_df, want_stats = chain(table, n_c)
+        fin, arena, tables, stats = one_call(table, n_c)
+        if tables is None:
+            assert fin.deferred == 3 and arena.n == 0 and want_stats.n_order_fallbacks > 0       # a chain block: left alone
+            continue
+        done += 1
+        for got, want in zip(tables, want_tables):
+            assert (got is None) == (want is None)
+            if want is not None:
+                np.testing.assert_array_equal(got, want)
+        seg = np.zeros(grid, dtype=object).view(sd._SegRois)
+        for c, t in zip(coords, tables):
+            seg[c] = t
+        seg.arena, seg.pruner = arena, fin
+        got_final, got_df = sd.StackPruner.prune_blobs_mp(Img, seg, *args, final_form=True, untouched=True)
+        assert isinstance(got_final, sd._FinalTable) and got_final.col_names == want_final.col_names
+        assert got_final.base is not None and np.shares_memory(got_final, fin.result[0])       # (its table, not a recomputation)
+        np.testing.assert_array_equal(np.asarray(got_final), np.asarray(want_final))
+        np.testing.assert_array_equal(got_df.to_numpy(), want_df.to_numpy())
+        for f in ("n_peaks", "n_contested", "n_probes", "n_overlap_pairs", "n_blobs"):
+            assert getattr(stats, f) == getattr(want_stats, f), f
+        assert stats.max_f32_error == want_stats.max_f32_error
+        # asked another way (not the final columns; another tolerance): the arena it filled is pruned as always
+        seg.pruner = fin
+        plain, _ = sd.StackPruner.prune_blobs_mp(Img, seg, *args)
+        assert not isinstance(plain, sd._FinalTable) and plain.shape[1] == 11 and len(plain) == len(want_final)
+        np.testing.assert_array_equal(plain[:, 7:10], np.asarray(want_final)[:, :3])
+    assert 3 <= done < 10
+    # equal peak values inside a block, a band that proved too narrow: deferred, nothing written
+    table, n_c = _random_candidates(rng, shapes, ns, 40, tie_every=5)
+    fin, arena, tables, _ = one_call(table, n_c)
+    assert tables is None and fin.deferred == 1 and arena.n == 0 and fin.result is None
+    table, n_c = _random_candidates(rng, shapes, ns, 40)
+    table["v"][0] += np.float32(0.01)
+    fin, arena, tables, _ = one_call(table, n_c)
+    assert tables is None and fin.deferred == 2 and arena.n == 0
+    # no candidates at all
+    fin, arena, tables, _ = one_call(table[:0], 0)
+    assert tables == [None] * nb and len(fin.result[0]) == 0
