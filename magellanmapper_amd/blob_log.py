@@ -47,13 +47,14 @@ except Exception as exc:  # pragma: no cover
 #: half-width of the float32 "contested" band, relative to the input's value scale
 EPS_REL = float(os.environ.get("MMX_EPS_REL", 2e-5))
 #: the band for raw integer volumes, whose default kernels hand the Z+X results to the Y pass as 16-bit fixed point
-#: (``MMX_ZX_TILED_Q16``: error <= 5.2e-5, ``mmx_tiled_q16_error_bound``); 0 keeps float32 intermediates
+#: (``MMX_ZX_TILED_Q16``: error <= 3.0e-5 of the value range from radius 4 on, ``mmx_tiled_q16_error_bound``); 0 keeps
+#: float32 intermediates
 EPS_REL_Q16 = float(os.environ.get("MMX_EPS_REL_Q16", 2.5e-4))
 #: the rounding error of the 16-bit intermediates, relative to the value range, for kernel radii >= 4 (sigma >= 0.875;
-#: largest at radius 6: 5.28e-5 -- swept over sigma in tests/test_host_logic.py).  Per call the library states the bound
-#: of the sigmas at hand (``mmx_tiled_q16_error_bound``); the kernels of radius 1..3 carry up to 7.5e-5, and their
-#: batches then keep float32 intermediates under ``MMX_ZX_AUTO`` (4 x 7.5e-5 exceeds the band).
-Q16_BOUND_ANY_SIGMA = 5.3e-5
+#: largest at radius 5: 2.97e-5 -- swept over sigma in tests/test_host_logic.py; rounds 3-5 carried 5.3e-5: Q was
+#: quantised over twice the range it can take, see ``q16_bounds`` in csrc/mmx_api.hip).  Per call the library states the
+#: bound of the sigmas at hand (``mmx_tiled_q16_error_bound``); the kernels of radius 1..3 carry up to 5.4e-5.
+Q16_BOUND_ANY_SIGMA = 3.0e-5
 #: ``MMX_LOG_ABS_TOL`` of include/mmx.h: the LoG contract in value units (BASELINE.json: "LoG response within 1e-4")
 LOG_ABS_TOL = 1e-4
 if 0.0 < EPS_REL_Q16 < 4.0 * Q16_BOUND_ANY_SIGMA:

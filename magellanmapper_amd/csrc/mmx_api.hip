@@ -151,21 +151,34 @@ int mmx_device_count(void)
 }
 
 // Q16 tiles (MMX_ZX_TILED_Q16): P in [0, BP] as unorm16, Q in [-BQ, BQ] as snorm16.  For voxels in [0, 1] (integer
-// types after img_as_float) the bounds follow from the weights alone -- |P| <= (sum w0)^2, |Q| <= 2 sum|w2| sum w0,
-// folding reflected taps only merges weights -- and so does the error the rounding leaves in the LoG value:
+// types after img_as_float) the bounds follow from the weights alone.  |P| <= (sum w0)^2.  Q = sum K I with the 2-D
+// kernel K(i, j) = w2(i) w0(j) + w0(i) w2(j) and every voxel I in [0, 1], so Q lies in [-sum of K's negative taps, sum of
+// its positive taps] -- about HALF of sum|K| <= 2 sum|w2| sum w0 either way, a second-derivative kernel summing to ~0
+// (round 6: BQ is that, the larger of the two one-sided sums; rounds 3-5 quantised Q over the two-sided 2 sum|w2| sum w0
+// and carried twice the rounding error for it).  Folding reflected taps at a block face only merges weights, which
+// can only shrink both one-sided sums.  The error the rounding leaves in the LoG value follows likewise:
 //   norm (sum|w2| BP / 65535 + sum w0 BQ / 32767) / 2,
-// i.e. 3.7e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7, the product
+// i.e. 2.2e-5 whatever sigma (sum|w2| ~ 0.97 / sigma^2), plus the float32 arithmetic's own few 1e-7, the product
 // term the 16-bit kernel leaves out (0.55e-5) and the rounding of its X accumulators, which run with the voxel
-// pieces' exponent offsets still in them (values up to 8 instead of 1: four roundings of 2^-22 each, 0.3e-5):
-// 4.6e-5; the Y pass on the matrix cores (mmx_ymfma.hip) leaves out its own low x low product -- low byte of a count x
+// pieces' exponent offsets still in them (values up to 8 instead of 1: four roundings of 2^-22 each, 0.2e-5):
+// 3.0e-5; the Y pass on the matrix cores (mmx_ymfma.hip) leaves out its own low x low product -- low byte of a count x
 // (weight - float16(weight)): 255 x 2^-12 = 0.062 counts per unit of weight against the 0.5 of the rounding -- which adds an
-// eighth: 5.1e-5 in all.
+// eighth: 3.3e-5 in all (5.1e-5 with the two-sided BQ).
 static void q16_bounds(const double* w0, const double* w2, int radius, double norm, double* bp, double* bq, double* err)
 {
     double s0 = w0[0], s2 = fabs(w2[0]);
     for (int k = 1; k <= radius; ++k) { s0 += 2.0 * w0[k]; s2 += 2.0 * fabs(w2[k]); }
     *bp = s0 * s0 * (1.0 + 1e-6);
-    *bq = 2.0 * s2 * s0 * (1.0 + 1e-6);
+    // one-sided sums of K over its (2 R + 1)^2 taps (K is symmetric in both indices: a quadrant, weighted)
+    double pos = 0.0, neg = 0.0;
+    for (int i = 0; i <= radius; ++i)
+        for (int j = 0; j <= radius; ++j) {
+            const double k = (w2[i] * w0[j] + w0[i] * w2[j]) * ((i ? 2.0 : 1.0) * (j ? 2.0 : 1.0));
+            if (k > 0.0) pos += k; else neg -= k;
+        }
+    // (1e-4 of slack: the kernel's own float32 / split-float16 arithmetic may land a hair beyond the exact extreme, and
+    //  a value beyond BQ would clamp)
+    *bq = (pos > neg ? pos : neg) * (1.0 + 1e-4);
     // ... plus what the 16-bit kernel drops in the X pass (low voxel byte x low weight piece: 255 / 65536 x 2^-11 per
     // unit of weight): P off by 1.9e-6 s0^2, Q by 1.9e-6 x 2 s2 s0
     const double drop = 255.0 / 65536.0 / 2048.0;
