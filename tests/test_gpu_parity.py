@@ -103,7 +103,7 @@ def test_fused_zx_path_gives_the_same_cube(gpu, case):
             # the fused kernels really ran (wherever the geometry lets any register-resident pass run)
             assert kinds["zxpass"][1] > 0 or kinds["generic"][1] > 0 or kinds["zpass"][1] > 0
             assert np.max(np.abs(fused - st["cube"].astype(np.float64))) < LOG_TOL, (mode, bl.LAST_ZX_PATH)
-            # (mode 7 hands 16-bit intermediates to the Y pass: error <= 5.1e-5 of the value scale)
+            # (mode 7 hands 16-bit intermediates to the Y pass: error <= 3.0e-5 of the value scale)
             assert np.max(np.abs(fused - sep)) < (4.5e-5 if bl.LAST_ZX_PATH == 7 else 2e-6) * max(1.0, float(np.abs(sep).max()))
     finally:
         bl.ZX_MODE = default
@@ -131,7 +131,7 @@ def test_blob_log_identical_to_reference(gpu, case, host_path):
     np.testing.assert_array_equal(res[0], res_o)
     if stats.n_candidates:
         # a quarter of the nomination band: 5e-6 for the float32 paths, 5e-5 where the default path hands 16-bit
-        # intermediates to the Y pass (raw integer volumes, radii <= 24; their bound is 5.1e-5)
+        # intermediates to the Y pass (raw integer volumes, radii <= 24; their bound is 3.0e-5)
         q16 = bl.LAST_ZX_PATH == 7
         assert stats.max_f32_error < (4.4e-5 if q16 else 5e-6) * max(1.0, float(np.abs(g["volume"]).max())
                                                                      if g["volume"].dtype.kind == "f" else 1.0)
@@ -559,7 +559,7 @@ def test_every_kernel_radius_matches_oracle(gpu, fused, monkeypatch):
             if fused == 7:      # 16-bit intermediates: the bound the library states for these weights
                 tol = nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(space.w0[0]), nat.as_double_ptr(space.w2[0]),
                                                           R, float(space.norms[0]))
-                assert 3.5e-5 < tol < 8e-5
+                assert 2.5e-5 < tol < 5.5e-5
             assert np.abs(got - want).max() < tol, R
             # the kernel asked for is the kernel that ran (its geometry conditions hold for this volume)
             if fused in (2, 3) and 1 <= R <= 24:
@@ -607,11 +607,10 @@ def test_q16_error_bound_holds_across_value_ranges(gpu, case, monkeypatch):
                                                     R, float(space.norms[0]))
         err = np.abs(got - want).max()
         assert err < bound * vmax, (case, R, err, bound * vmax)
-        # what the band of 2.5e-4 covers fourfold (the few-tap kernels of sigma < 1 carry a little more, and AUTO then
-        # keeps float32 intermediates for them)
-        assert bound <= (bl.Q16_BOUND_ANY_SIGMA if R >= 4 else 7.6e-5), (R, bound)
+        # what the band of 2.5e-4 covers fourfold (the few-tap kernels of sigma < 1 carry a little more)
+        assert bound <= (bl.Q16_BOUND_ANY_SIGMA if R >= 4 else 5.4e-5), (R, bound)
         worst = max(worst, err / vmax)
-    assert worst < 7.6e-5              # the north star's LoG tolerance of 1e-4, relative to the value scale, with room
+    assert worst < 5.4e-5              # the north star's LoG tolerance of 1e-4, relative to the value scale, with room
 
 
 @pytest.mark.parametrize("unsharp,clip_max,expect_q16", [(0.3, 1.0, True), (0.9, 1.0, False), (0.3, 1.6, False)])
@@ -859,7 +858,7 @@ def test_a_band_narrower_than_the_float32_error_widens_itself(gpu, monkeypatch):
                              int(g["num_sigma"]), float(g["threshold"]), float(g["overlap"]), stats=stats)[0]
     assert stats.n_band_retries >= 1 and stats.n_blocks == 1
     np.testing.assert_array_equal(got, g["pruned"])
-    # the 16-bit intermediates forced under a band their error (<= 5.1e-5) does not fit: same way out
+    # the 16-bit intermediates forced under a band their error (<= 3.0e-5) does not fit: same way out
     monkeypatch.setattr(bl, "EPS_REL_Q16", 2e-5)
     monkeypatch.setattr(bl, "ZX_MODE", nat.MMX_ZX_TILED_Q16)
     stats = bl.BatchStats()
@@ -947,7 +946,7 @@ def test_tiled_path_entries_and_prepacked_copy_through_the_abi(gpu):
     bound = max(nat.lib().mmx_tiled_q16_error_bound(nat.as_double_ptr(k1.gaussian_half_kernel(s_, 0, k1.kernel_radius(s_))),
                                                     nat.as_double_ptr(k1.gaussian_half_kernel(s_, 2, k1.kernel_radius(s_))),
                                                     k1.kernel_radius(s_), s_ * s_) for s_ in sig)
-    assert 4e-5 < bound < 5.3e-5
+    assert 2.5e-5 < bound < 3.0e-5
     pos = {tuple(r): i for i, r in enumerate(k7)}
     idx = [pos.get(tuple(r), -1) for r in k2]
     assert min(idx) >= 0
@@ -1272,7 +1271,7 @@ def test_detect_batch_through_the_abi(gpu):
     nat.check(L.mmx_detect_batch(ctypes.byref(args(cap)), ctypes.byref(info)), "mmx_detect_batch")
     ev.synchronize()
     assert info.zx_path == nat.MMX_ZX_TILED_Q16 and info.mask_layout == nat.MMX_MASK_QUADS and info.n_pass_rounds == 1
-    assert 0 < info.q16_bound <= 5.2e-5
+    assert 0 < info.q16_bound <= 3.0e-5
     n_all, n_cands = (int(v) for v in h_count.numpy().view(np.uint32))
     assert 0 < n_cands <= n_all <= cap
     cands = h_table.numpy()[:n_all * nat.CAND_DTYPE.itemsize].view(nat.CAND_DTYPE)
