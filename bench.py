@@ -312,7 +312,8 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     class SlabVolume(bl.DeviceVolume):
         def __init__(self, t, z_off, full_shape):
             # (host sources -- `--from-host` -- go up beside the detection: this script leaves them alone meanwhile)
-            super().__init__(t, dev, streamed=True)
+            super().__init__(t, dev, streamed=True,
+                             cells=None if args.upload_order == "slabs" else stack_detect._upload_cells(blocks.sub_roi_slices, full_shape))
             self.z_off = z_off
             self.shape = tuple(full_shape) + tuple(t.shape[3:])
 
@@ -1040,6 +1041,8 @@ def main():
     ap.add_argument("--from-host", choices=("pinned", "pageable", "mmap"), default=None,
                     help="after the timed region: steps that start from a HOST copy of the volume (upload overlapped "
                          "with the detection), reported as `from_host`")
+    ap.add_argument("--upload-order", choices=("cells", "slabs"), default="cells",
+                    help="--from-host: the volume goes up block row by block row (cells, default) or in z-slabs")
     ap.add_argument("--tiles", type=int, default=1,
                     help="with --from-host: also run this many consecutive tiles, each uploading beside its predecessor's "
                          "detection.  Without --from-host (or with --shard tiles): the workload as a TILED stack, this many "

@@ -526,6 +526,11 @@ int mmx_gauss_axis_batch(const mmx_volume* vol, const mmx_block* d_blocks, const
 int mmx_timing_enable(int on);
 int mmx_timing_read(double* ms, int64_t* launches, int n);
 
+/* A rectangle of a host image into its place in the device copy (ABI v16): `height` rows of `width` bytes, rows
+ * spitch / dpitch bytes apart, host -> device on `stream` (asynchronous for pinned host memory).  The upload of a host
+ * volume block row by block row: a y-band of a z-range is one such rectangle (rows = planes). */
+int mmx_copy_rect_h2d(void* d_dst, size_t dpitch, const void* h_src, size_t spitch, size_t width, size_t height,
+                      void* stream);
 int mmx_event_create(void** ev);
 int mmx_event_destroy(void* ev);
 int mmx_event_record(void* ev, void* stream);

@@ -606,10 +606,11 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
     d_blocks = None
     # a volume still on its way up (`DeviceVolume.stream_wait`): this batch waits for the slabs its blocks touch, on
     # every stream that reads voxels (the passes, the voxel copy of the tiled path, the exact re-score)
-    z_hi = max((int(o[0]) + int(s_[0]) for o, s_ in zip(origins, shapes)), default=0) if dvol._upload is not None else 0
+    boxes = ([(int(o[0]), int(o[0]) + int(s_[0]), int(o[1]), int(o[1]) + int(s_[1])) for o, s_ in zip(origins, shapes)]
+             if dvol._upload is not None else None)
     if pre is None:
         if dvol._upload is not None:
-            dvol.stream_wait(z_hi, [torch.cuda.current_stream(), bufs.pack_stream, bufs.rescore_stream, bufs.side])
+            dvol.stream_wait(None, [torch.cuda.current_stream(), bufs.pack_stream, bufs.rescore_stream, bufs.side], boxes)
         if prepared is not None:
             blocks, slot, d_blocks = prepared
         else:
@@ -627,7 +628,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
             main = torch.cuda.current_stream()
             bufs.pre_stream.wait_stream(main) if buffer_free is None else bufs.pre_stream.wait_event(buffer_free)
             with torch.cuda.stream(bufs.pre_stream):
-                dvol.stream_wait(z_hi, [torch.cuda.current_stream(), bufs.side])     # (side: co-localisation means)
+                dvol.stream_wait(None, [torch.cuda.current_stream(), bufs.side], boxes)     # (side: co-localisation means)
                 blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
                 ready = torch.cuda.Event()
                 ready.record()
@@ -641,7 +642,7 @@ def _enqueue_detect(dvol, channel, origins, shapes, space: ScaleSpace, thr: floa
                 after.record()
                 PRE_WAITS.append((before, after))
         else:
-            dvol.stream_wait(z_hi, [torch.cuda.current_stream(), bufs.side])
+            dvol.stream_wait(None, [torch.cuda.current_stream(), bufs.side], boxes)
             blocks, slot, vol32, vol_exact = pre.run(dvol, channel, origins, shapes, which)
         store_f32 = int(getattr(pre, "store_f32", 0))
     nb, ns = len(blocks), len(space.sigmas)

@@ -466,6 +466,19 @@ int mmx_peaks_batch(const float* d_log, const uint64_t* d_nms_mask, int mask_lay
     return rc == MMX_ERR_HIP ? hip_fail(hipGetLastError(), "peaks") : rc;
 }
 
+// A rectangle of a host image into its place in the device copy: `height` rows of `width` bytes, the rows spitch /
+// dpitch bytes apart (hipMemcpy2DAsync, host -> device, on `stream`; the host side pinned for the copy to be
+// asynchronous).  What lets a host volume go up block row by block row -- the y-band of a z-range is `planes` rows of
+// (band rows x row bytes) bytes, one plane pitch apart -- instead of whole z-slabs (volume._SlabUpload).
+int mmx_copy_rect_h2d(void* d_dst, size_t dpitch, const void* h_src, size_t spitch, size_t width, size_t height,
+                      void* stream)
+{
+    if (!d_dst || !h_src || width > dpitch || width > spitch) return MMX_ERR_ARG;
+    if (!width || !height) return MMX_OK;
+    hipError_t r = hipMemcpy2DAsync(d_dst, dpitch, h_src, spitch, width, height, hipMemcpyHostToDevice, (hipStream_t)stream);
+    return r == hipSuccess ? MMX_OK : hip_fail(r, "hipMemcpy2DAsync");
+}
+
 int mmx_event_create(void** ev)
 {
     if (!ev) return MMX_ERR_ARG;

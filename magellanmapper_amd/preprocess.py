@@ -55,7 +55,8 @@ def _wait_upload(dvol, origins, shapes) -> None:
     """A volume still on its way to the device (``DeviceVolume.stream_wait``): the current stream waits for the slabs
     these blocks touch."""
     if getattr(dvol, "_upload", None) is not None:
-        dvol.stream_wait(max((int(o[0]) + int(s_[0]) for o, s_ in zip(origins, shapes)), default=0))
+        dvol.stream_wait(None, None, [(int(o[0]), int(o[0]) + int(s_[0]), int(o[1]), int(o[1]) + int(s_[1]))
+                                      for o, s_ in zip(origins, shapes)])
 
 
 def gauss_weights() -> np.ndarray:

@@ -67,13 +67,20 @@ class Image5d:
         self.device_volume = None
 
     def prefetch(self):
-        """Start the upload of the first time point now (``blob_log.DeviceVolume``: z-slabs on a copy stream); a later
-        whole-image ``detect_blobs_blocks`` / ``detect_blobs_stack`` of this image detects on it while the rest is still
-        in flight.  What `detect_blobs_tiles` calls for tile k + 1 before it detects tile k.  The image must stay as it is
-        until the detection has returned or :meth:`release` has been called (the upload reads it in the background)."""
+        """Start the upload of the first time point now (``blob_log.DeviceVolume``: block row by block row on a copy
+        stream); a later whole-image ``detect_blobs_blocks`` / ``detect_blobs_stack`` of this image detects on it while
+        the rest is still in flight.  What `detect_blobs_tiles` calls for tile k + 1 before it detects tile k.  The image
+        must stay as it is until the detection has returned or :meth:`release` has been called (the upload reads it in
+        the background)."""
         from . import blob_log as bl
         if self.device_volume is None and self.img is not None:
-            self.device_volume = bl.DeviceVolume(self.img[0], streamed=True)
+            cells = None
+            try:        # (where the first channel's profile puts the block rows: only the upload ORDER depends on it)
+                blocks = setup_blocks(config.get_roi_profile(0), self.img.shape[1:4])
+                cells = _upload_cells(blocks.sub_roi_slices, self.img.shape[1:4])
+            except Exception:
+                pass
+            self.device_volume = bl.DeviceVolume(self.img[0], streamed=True, cells=cells)
         return self
 
     def release(self):
@@ -81,6 +88,15 @@ class Image5d:
         dv, self.device_volume = self.device_volume, None
         if dv is not None:
             dv.close()
+
+
+def _upload_cells(sub_roi_slices, shape3):
+    """``(z ends, y ends)`` of the block grid's layers and rows: where a host image on its way to the device is cut so
+    that a block can start once the cells it touches have landed (``volume._SlabUpload``)."""
+    gz, gy = sub_roi_slices.shape[:2]
+    z_ends = [int(sub_roi_slices[(l, 0, 0)][0].indices(int(shape3[0]))[1]) for l in range(gz)]
+    y_ends = [int(sub_roi_slices[(0, j, 0)][1].indices(int(shape3[1]))[1]) for j in range(gy)]
+    return z_ends, y_ends
 
 
 class _TableArena:
@@ -836,7 +852,7 @@ class StackDetector:
             else:
                 # a host image handed over for the length of this call: it goes up beside the detection of the blocks
                 # that have landed, and whatever of it this rank's blocks never touched is cancelled before returning
-                dvol = own_dvol = bl.DeviceVolume(img, streamed=True)
+                dvol = own_dvol = bl.DeviceVolume(img, streamed=True, cells=_upload_cells(sub_roi_slices, shape3))
             if arena is not None:
                 # finished tables go straight from the native host path into the arena where the detection can hand
                 # over peak arrays (one channel; several channels with co-localisation: the tables then land during the

@@ -51,12 +51,14 @@ class DeviceVolume:
     ``Image5d.prefetch`` for the tile it announces).  ``None`` (default): streamed only where nobody can write behind
     the copy -- read-only arrays and read-only memory maps (what the reference's importer hands over,
     importer.py:794) -- and synchronous for ordinary writeable arrays and pinned tensors, which a caller may well
-    refill right after this returns (a double-buffered tile).
+    refill right after this returns (a double-buffered tile).  ``cells = (z ends, y ends)`` of the caller's block rows
+    (optional, streamed uploads only): the image then goes up y-band by y-band within each z-layer of blocks instead of
+    in whole z-slabs, and a block can start once the bands it touches have landed.
     """
 
     _upload = None          # the z-slab upload still in flight (`_SlabUpload`), if any
 
-    def __init__(self, image, device: Optional["torch.device"] = None, streamed: Optional[bool] = None):
+    def __init__(self, image, device: Optional["torch.device"] = None, streamed: Optional[bool] = None, cells=None):
         dev = device or _require_gpu()
         want_stream = STREAM_UPLOAD and streamed is not False
         if isinstance(image, torch.Tensor):
@@ -75,7 +77,7 @@ class DeviceVolume:
                 # large host images (the reference's callers hand a memory-mapped image5d.npy, importer.py:794) go up
                 # z-slab by z-slab on a copy stream; detection starts on the blocks whose slabs have landed
                 t = None
-                self._upload = _SlabUpload(arr, dev)
+                self._upload = _SlabUpload(arr, dev, cells)
                 self.tensor = self._upload.out
             else:
                 t = torch.from_numpy(np.array(arr) if not arr.flags.writeable else np.ascontiguousarray(arr))
@@ -83,7 +85,7 @@ class DeviceVolume:
             raise TypeError(f"unsupported voxel type {np_dtype}")
         if t is not None and t.device.type == "cpu" and t.is_pinned() and want_stream and streamed and \
                 t.numel() * t.element_size() > _STREAM_MIN_BYTES and t.is_contiguous():
-            self._upload = _SlabUpload(t, dev)          # (pinned source: DMA straight from it, no staging thread)
+            self._upload = _SlabUpload(t, dev, cells)   # (pinned source: DMA straight from it, no staging thread)
             self.tensor = self._upload.out
             t = None
         if t is not None:
@@ -103,14 +105,15 @@ class DeviceVolume:
     def multichannel(self) -> bool:
         return self.tensor.ndim == 4
 
-    def stream_wait(self, z_hi: Optional[int] = None, streams=None) -> None:
+    def stream_wait(self, z_hi: Optional[int] = None, streams=None, boxes=None) -> None:
         """Order ``streams`` (default: the current one) after the upload of planes ``[0, z_hi)`` (all planes when
-        ``None``).  Nothing to do for a resident volume.  With a staging thread behind the upload the host waits until
-        that slab's copy has been QUEUED (its event recorded), never for the copy itself."""
+        ``None``) or, with ``boxes`` = ``(z_lo, z_hi, y_lo, y_hi)`` extents of blocks, of the regions holding those.
+        Nothing to do for a resident volume.  With a staging thread behind the upload the host waits until that
+        region's copy has been QUEUED (its event recorded), never for the copy itself."""
         up = self._upload
         if up is None:
             return
-        ev = up.event_for(self.shape[0] if z_hi is None else int(z_hi))
+        ev = up.event_for_boxes(boxes) if boxes is not None else up.event_for(self.shape[0] if z_hi is None else int(z_hi))
         for st in (streams or [torch.cuda.current_stream()]):
             if st is not None:
                 st.wait_event(ev)
@@ -266,17 +269,21 @@ def _check_hw_queues() -> None:
 
 
 class _SlabUpload:
-    """A host ``(z, y, x[, c])`` image on its way to the device, z-slab by z-slab, on a stream of its own: one event
-    per slab, so that the detection of the blocks a slab completes can start while the rest is still in flight (blocks
-    are consumed in z-major order).  A pinned source is read by the DMA engine directly -- every copy is queued at once;
-    a pageable or memory-mapped one goes through a small ring of pinned staging buffers filled by a few host threads.
+    """A host ``(z, y, x[, c])`` image on its way to the device region by region, on a stream of its own: one event per
+    region, so that the detection of the blocks a region completes can start while the rest is still in flight.
+    Regions are z-slabs (blocks are consumed in z-major order) or, when the caller says where its block rows end
+    (``cells = (z ends, y ends)``), y-bands of z-layers in (z, y) order -- block row j of layer l can then start once
+    band j of that layer has landed instead of the whole layer, and behind the LAST band only one row of blocks is left
+    to detect instead of a whole layer (a quarter of the benchmark volume).  A pinned source is read by the DMA engine
+    directly -- every copy is queued at once; a pageable or memory-mapped one goes through a small ring of pinned
+    staging buffers filled by a few host threads.
 
     Lifetime: the device allocation is recorded on the copy stream (``record_stream``), so dropping the volume while
     copies are in flight cannot hand the block to another allocation before they have run; :meth:`cancel` drops the
-    slabs not yet staged and joins the staging thread; the source must stay untouched until the upload has finished or
-    been cancelled."""
+    regions not yet staged and joins the staging thread; the source must stay untouched until the upload has finished
+    or been cancelled."""
 
-    def __init__(self, src, dev):
+    def __init__(self, src, dev, cells=None):
         _check_hw_queues()
         if isinstance(src, torch.Tensor):
             shape, tdtype, itemsize = tuple(src.shape), src.dtype, src.element_size()
@@ -285,11 +292,16 @@ class _SlabUpload:
         self.out = torch.empty(shape, dtype=tdtype, device=dev)
         self.dev = dev
         self.nz = shape[0]
-        plane = max(1, int(np.prod(shape[1:])) * itemsize)
+        self.ny = shape[1] if len(shape) > 1 else 1
+        self.itemsize = itemsize
+        self.row_bytes = max(1, int(np.prod(shape[2:])) * itemsize)
+        plane = max(1, self.ny * self.row_bytes)
         self.slab = max(1, min(self.nz, _STREAM_CHUNK_BYTES // plane))
-        self.bounds: List[int] = []          # z end of every queued slab
+        self.regions = self._plan(cells)      # (z0, z1, y0, y1) in upload order
+        self._boxes = np.asarray(self.regions, dtype=np.int64).reshape(-1, 4)
+        self.bounds: List[int] = []          # z end of every queued region
         self.events: List = []
-        self.n_slabs = -(-self.nz // self.slab) if self.nz else 0
+        self.n_slabs = len(self.regions)
         self.cv = threading.Condition()
         self.error: Optional[BaseException] = None
         self.cancelled = False
@@ -304,26 +316,75 @@ class _SlabUpload:
         # the block is written from the copy stream: the allocator must not reuse it before that stream is through with it
         self.out.record_stream(self.stream)
         _LIVE_UPLOADS.add(self)
-        if self.nz == 0:
+        if self.nz == 0 or not self.regions:
             ev = torch.cuda.Event()
             ev.record(self.stream)
             self.bounds.append(0)
             self.events.append(ev)
+            self.regions, self.n_slabs = [(0, 0, 0, self.ny)], 1
+            self._boxes = np.asarray(self.regions, dtype=np.int64).reshape(-1, 4)
         elif isinstance(src, torch.Tensor) and src.is_pinned():
-            with torch.cuda.stream(self.stream):
-                for z0 in range(0, self.nz, self.slab):
-                    z1 = min(z0 + self.slab, self.nz)
-                    self.out[z0:z1].copy_(src[z0:z1], non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    self.bounds.append(z1)
-                    self.events.append(ev)
+            base = src.data_ptr()
+            for z0, z1, y0, y1 in self.regions:
+                self._queue(z0, z1, y0, y1, src, base)
             self._keep = src                       # (the source must outlive the copies)
         else:
             arr = src.numpy() if isinstance(src, torch.Tensor) else src
-            self.thread = threading.Thread(target=self._stage, args=(arr, tdtype, itemsize), daemon=True,
-                                           name="mmx-upload")
+            self.thread = threading.Thread(target=self._stage, args=(arr, tdtype), daemon=True, name="mmx-upload")
             self.thread.start()
+
+    def _plan(self, cells):
+        """Upload order: z-slabs of at most ``_STREAM_CHUNK_BYTES``; with ``cells = (z ends, y ends)`` (ascending, the
+        last ones the image's extent) the y-bands of every z-layer in turn, a band cut along z where it exceeds that."""
+        nz, ny = self.nz, self.ny
+        if nz == 0:
+            return []
+        banded = None
+        if cells is not None:
+            z_ends = sorted({int(v) for v in cells[0] if 0 < int(v) < nz} | {nz})
+            y_ends = sorted({int(v) for v in cells[1] if 0 < int(v) < ny} | {ny})
+            if len(y_ends) > 1:
+                banded = (z_ends, y_ends)
+        if banded is None:
+            return [(z0, min(z0 + self.slab, nz), 0, ny) for z0 in range(0, nz, self.slab)]
+        regions = []
+        za = 0
+        for zb in banded[0]:
+            ya = 0
+            for yb in banded[1]:
+                step = max(1, _STREAM_CHUNK_BYTES // max(1, (yb - ya) * self.row_bytes))
+                for z0 in range(za, zb, step):
+                    regions.append((z0, min(z0 + step, zb), ya, yb))
+                ya = yb
+            za = zb
+        return regions
+
+    def _queue(self, z0, z1, y0, y1, src, src_base, src_pitch=None):
+        """One region's copy on the copy stream + its event.  ``src``: a pinned tensor holding the whole image
+        (``src_pitch`` None: the image's own plane pitch) or the region alone, packed (``src_pitch`` = its plane bytes)."""
+        full_rows = y0 == 0 and y1 == self.ny
+        with torch.cuda.stream(self.stream):
+            if full_rows and src_pitch is None:
+                self.out[z0:z1].copy_(src[z0:z1], non_blocking=True)
+            elif full_rows:
+                self.out[z0:z1].copy_(src, non_blocking=True)
+            else:
+                plane = self.ny * self.row_bytes
+                width = (y1 - y0) * self.row_bytes
+                dst = self.out.data_ptr() + z0 * plane + y0 * self.row_bytes
+                if src_pitch is None:
+                    ptr, pitch = src_base + z0 * plane + y0 * self.row_bytes, plane
+                else:
+                    ptr, pitch = src_base, src_pitch
+                nat.check(nat.lib().mmx_copy_rect_h2d(dst, plane, ptr, pitch, width, z1 - z0, self.stream.cuda_stream),
+                          "mmx_copy_rect_h2d")
+            ev = torch.cuda.Event()
+            ev.record()
+        with self.cv:
+            self.bounds.append(z1)
+            self.events.append(ev)
+            self.cv.notify_all()
+        return ev
 
     def all_queued(self) -> bool:
         return len(self.events) >= max(1, self.n_slabs)
@@ -336,9 +397,9 @@ class _SlabUpload:
         self._keep = None
 
     def cancel(self) -> None:
-        """Give the upload up: slabs not yet staged are dropped (waiters are told), the staging thread is joined; copies
-        of a pinned source that are already queued cannot be recalled and are waited for, because the DMA reads the
-        caller's buffer.  Safe to call more than once and after the upload has finished."""
+        """Give the upload up: regions not yet staged are dropped (waiters are told), the staging thread is joined;
+        copies of a pinned source that are already queued cannot be recalled and are waited for, because the DMA reads
+        the caller's buffer.  Safe to call more than once and after the upload has finished."""
         with self.cv:
             self.cancelled = True
             self.cv.notify_all()
@@ -350,46 +411,37 @@ class _SlabUpload:
                 self.events[-1].synchronize()
             self._keep = None
 
-    def _stage(self, arr, tdtype, itemsize):
+    def _stage(self, arr, tdtype):
         stage: List = []
         done: List = []
         try:
             torch.cuda.set_device(self.dev)
-            inner = tuple(arr.shape[1:])
-            per_plane = int(np.prod(inner))
-            slab_bytes = self.slab * per_plane * itemsize
-            depth = max(2, min(int(_STAGE_DEPTH), self.n_slabs))
-            stage = [_take_staging(slab_bytes) for _ in range(depth)]
+            inner = tuple(arr.shape[2:])
+            itemsize = self.itemsize
+            need = max((z1 - z0) * (y1 - y0) for z0, z1, y0, y1 in self.regions) * self.row_bytes
+            depth = max(2, min(int(_STAGE_DEPTH), len(self.regions)))
+            stage = [_take_staging(need) for _ in range(depth)]
             done = [None] * depth
             n_thr = _stage_threads()
             if isinstance(arr, np.memmap):
                 _advise_sequential(arr)
             with ThreadPoolExecutor(n_thr, thread_name_prefix="mmx-stage") as pool:
-                for k, z0 in enumerate(range(0, self.nz, self.slab)):
+                for k, (z0, z1, y0, y1) in enumerate(self.regions):
                     if self.cancelled:
                         break
-                    z1 = min(z0 + self.slab, self.nz)
                     which = k % depth
-                    n_el = (z1 - z0) * per_plane
-                    buf = stage[which][:n_el * itemsize].view(tdtype).view((z1 - z0,) + inner)
+                    n_el = (z1 - z0) * (y1 - y0) * int(np.prod(inner, dtype=np.int64))
+                    buf = stage[which][:n_el * itemsize].view(tdtype).view((z1 - z0, y1 - y0) + inner)
                     if done[which] is not None:
                         done[which].synchronize()          # the DMA that last used this buffer
                     host = buf.numpy()
                     cuts = np.linspace(0, z1 - z0, min(n_thr, z1 - z0) + 1).astype(int)
-                    list(pool.map(lambda ab: np.copyto(host[ab[0]:ab[1]], arr[z0 + ab[0]:z0 + ab[1]]),
+                    list(pool.map(lambda ab: np.copyto(host[ab[0]:ab[1]], arr[z0 + ab[0]:z0 + ab[1], y0:y1]),
                                   zip(cuts[:-1], cuts[1:])))
                     if self.cancelled:
                         break
-                    with torch.cuda.stream(self.stream):
-                        self.out[z0:z1].copy_(buf, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                    done[which] = ev
-                    with self.cv:
-                        self.bounds.append(z1)
-                        self.events.append(ev)
-                        self.cv.notify_all()
-        except BaseException as exc:               # (reported by whoever waits for a slab)
+                    done[which] = self._queue(z0, z1, y0, y1, buf, buf.data_ptr(), (y1 - y0) * self.row_bytes)
+        except BaseException as exc:               # (reported by whoever waits for a region)
             with self.cv:
                 self.error = exc
                 self.cv.notify_all()
@@ -404,14 +456,28 @@ class _SlabUpload:
 
     def event_for(self, z_hi: int):
         """The event after which planes ``[0, z_hi)`` are on the device (waits until its copy has been queued)."""
-        z_hi = max(0, min(int(z_hi), self.nz))
+        return self.event_for_boxes([(0, int(z_hi), 0, self.ny)])
+
+    def event_for_boxes(self, boxes):
+        """The event after which every voxel of the ``(z_lo, z_hi, y_lo, y_hi)`` boxes (all x) is on the device: that
+        of the last region, in upload order, that holds any of them (the copy stream runs the regions in order).  Waits
+        until that region's copy has been QUEUED, never for the copy itself."""
+        last = 0
+        rg = self._boxes
+        for z_lo, z_hi, y_lo, y_hi in boxes:
+            z_lo, z_hi = max(0, int(z_lo)), min(int(z_hi), self.nz)
+            y_lo, y_hi = max(0, int(y_lo)), min(int(y_hi), self.ny)
+            if z_hi <= z_lo or y_hi <= y_lo:
+                continue
+            hit = np.flatnonzero((rg[:, 0] < z_hi) & (rg[:, 1] > z_lo) & (rg[:, 2] < y_hi) & (rg[:, 3] > y_lo))
+            if len(hit):
+                last = max(last, int(hit[-1]))
         with self.cv:
             while True:
                 if self.error is not None:
                     raise nat.MmxError(f"upload of the image failed: {self.error!r}") from self.error
-                i = bisect.bisect_left(self.bounds, z_hi)
-                if i < len(self.events):
-                    return self.events[i]
+                if last < len(self.events):
+                    return self.events[last]
                 if self.all_queued():
                     return self.events[-1]
                 if self.cancelled:

@@ -52,7 +52,10 @@ def test_streamed_upload_gives_the_resident_volumes_table(gpu, monkeypatch, tmp_
         else:
             src = vol
         got = _stack(src, denoise)
-        assert made and made[0].n_slabs == 12 and made[0].all_queued()
+        # (block rows of 45 / 27 voxels along y, layers of 45 / 45 / 10 planes: the volume went up y-band by y-band within
+        #  each layer of blocks, every band in pieces of at most 9 planes' worth of bytes)
+        assert made and made[0].n_slabs >= 12 and made[0].all_queued()
+        assert {r[2:] for r in made[0].regions} == {(0, 45), (45, 72)} and {r[0] for r in made[0].regions} >= {0, 45, 90}
         assert want is not None and got is not None
         np.testing.assert_array_equal(got, want)
     finally:
@@ -337,3 +340,47 @@ def test_four_tiles_over_two_ranks_equal_the_oracle_per_tile(gpu, tmp_path, c5):
                          capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
     assert "TILE_RANK_OK 0 [0, 2]" in run.stdout and "TILE_RANK_OK 1 [1, 3]" in run.stdout
+
+
+@pytest.mark.parametrize("source", ["pinned", "readonly"])
+def test_block_row_by_block_row_upload_lands_every_voxel_and_orders_the_waits(gpu, monkeypatch, source):
+    """``cells = (z ends, y ends)``: the image goes up y-band by y-band within each z-layer (``mmx_copy_rect_h2d``: a band
+    is one rectangle per piece, strided on the device, strided in a pinned source or packed in the staging buffer); the
+    device copy equals the source -- 3-D and (z, y, x, c) -- and a block's wait is the event of the LAST region, in upload
+    order, that holds any of its voxels."""
+    from magellanmapper_amd import blob_log as bl, volume
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    rng = np.random.default_rng(3)
+    for shape in ((50, 60, 72), (33, 40, 24, 2)):
+        data = rng.integers(0, 65535, shape).astype(np.uint16)
+        plane_bytes = int(np.prod(shape[1:])) * 2
+        monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 3 * plane_bytes)
+        cells = ([20, 45, shape[0]], [16, 30, shape[1]])
+        if source == "pinned":
+            src = torch.from_numpy(data).pin_memory()
+        else:
+            src = data.copy()
+            src.flags.writeable = False
+        dv = bl.DeviceVolume(src, streamed=True, cells=cells)
+        up = dv._upload
+        assert up is not None and (up.thread is None) == (source == "pinned")
+        regions = up.regions
+        # (z, y) order: all bands of layer [0, 20) before any of [20, 45); a band wider than the chunk is cut along z
+        assert regions[0][:1] + regions[0][2:] == (0, 0, 16) and regions[-1][1] == shape[0] and regions[-1][3] == shape[1]
+        firsts = [i for i, r in enumerate(regions) if r[0] == 0]
+        assert firsts == sorted(firsts) and max(firsts) < min(i for i, r in enumerate(regions) if r[0] >= 20)
+        assert sum((r[1] - r[0]) * (r[3] - r[2]) for r in regions) == shape[0] * shape[1]       # a partition
+        # a block in layer 1, row 0: waits for the last piece of band 0 of layer [20, 45) -- not for band 1 or layer 2
+        want = max(i for i, r in enumerate(regions) if r[0] < 40 and r[1] > 18 and r[2] < 14 and r[3] > 0)
+        assert regions[want][2:] == (0, 16) and regions[want][1] <= 45
+        ev = up.event_for_boxes([(18, 40, 0, 14)])
+        side = torch.cuda.Stream()
+        dv.stream_wait(None, [side], [(18, 40, 0, 14)])
+        with torch.cuda.stream(side):
+            part = dv.tensor[18:40, 0:14].clone()
+        assert ev is up.events[want]
+        dv.wait_all()
+        side.synchronize()
+        np.testing.assert_array_equal(part.cpu().numpy().view(np.uint16), data[18:40, 0:14])
+        np.testing.assert_array_equal(dv.tensor.cpu().numpy().view(np.uint16), data)
+        assert dv._upload is None

@@ -3,21 +3,22 @@
 # CPU only -- the GPU pool offers no sanitizers.  Builds libmmx_asan.so / libmmx_tsan.so (the stock device objects +
 # an instrumented mmx_host.o), preloads the matching runtime into Python and runs the CPU tests that drive the host
 # entry points (tests/test_host_logic.py, tests/test_dist_gloo.py) through MMX_LIB_PATH.
-#   tools/host_sanitize.sh [asan|tsan|both] [log directory]     (default: both, profiles/)
-# Logs: <dir>/r04_host_asan.log, <dir>/r04_host_tsan.log; exit status 0 only when pytest passed and no report
+#   tools/host_sanitize.sh [asan|tsan|both] [log directory] [round tag]     (default: both, profiles/, r06)
+# Logs: <dir>/<tag>_host_asan.log, <dir>/<tag>_host_tsan.log; exit status 0 only when pytest passed and no report
 # mentions mmx_host.cpp / libmmx (reports from inside CPython / NumPy / torch, which are not instrumented, are
 # counted separately and listed).
 set -u
 cd "$(dirname "$0")/.."
 which=${1:-both}
 out=${2:-profiles}
+tag=${3:-r06}
 mkdir -p "$out"
 make -s -C magellanmapper_amd/csrc -j8 all || exit 1
 status=0
 run() {   # name, runtime libraries, environment, tests
     local name=$1 libs=$2 envs=$3 tests=$4
     make -s -C magellanmapper_amd/csrc host-$name || exit 1
-    local log="$out/r04_host_$name.log"
+    local log="$out/${tag}_host_$name.log"
     echo "# tools/host_sanitize.sh $name: $(date -u +%FT%TZ), $(gcc --version | head -1)" > "$log"
     echo "# LD_PRELOAD=$libs $envs MMX_LIB_PATH=magellanmapper_amd/libmmx_$name.so python -m pytest $tests -q -m 'not gpu' -p no:cacheprovider" >> "$log"
     timeout 1800 env LD_PRELOAD="$libs" $envs MMX_LIB_PATH="$PWD/magellanmapper_amd/libmmx_$name.so" \

@@ -74,8 +74,9 @@ for trial in range(n_trials):
         continue
     want, df_want = sd.StackPruner.prune_blobs_mp(Img, build(False), *args)
     seg_b = build(True)
+    pruner_b = seg_b.pruner                 # (prune_blobs_mp takes it off the tables: one shot)
     got, df_got = sd.StackPruner.prune_blobs_mp(Img, seg_b, *args)
-    assert all(d is not None for d in seg_b.pruner.done), "the regions were not merged"
+    assert all(d is not None for d in pruner_b.done), "the regions were not merged"
     ok = np.array_equal(got, want) and np.array_equal(df_got.to_numpy(), df_want.to_numpy())
     done += 1
     if not ok:
