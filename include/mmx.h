@@ -531,6 +531,17 @@ int mmx_timing_read(double* ms, int64_t* launches, int n);
  * volume block row by block row: a y-band of a z-range is one such rectangle (rows = planes). */
 int mmx_copy_rect_h2d(void* d_dst, size_t dpitch, const void* h_src, size_t spitch, size_t width, size_t height,
                       void* stream);
+/* The staged upload of a pageable / memory-mapped host image as ONE call (ABI v16; no interpreter lock needed while
+ * it runs): for each of the n_regions (z0, z1, y0, y1) of the (nz, ny, row_bytes) image in turn -- wait for
+ * events[k - depth] (the DMA that last read staging buffer k % depth), copy the region into that buffer with n_threads
+ * threads (planes packed: (y1 - y0) * row_bytes each), queue mmx_copy_rect_h2d's rectangle on `stream`, record
+ * events[k], store k + 1 to *n_queued.  *cancel != 0 (written by another thread) ends the loop at the next region.
+ * h_staging[depth]: pinned buffers of staging_bytes each; events[n_regions]: created by the caller. */
+int mmx_host_stage_upload(const void* h_src, void* d_dst, const int64_t* regions, int32_t n_regions, int64_t nz,
+                          int64_t ny, int64_t row_bytes, void* const* h_staging, int64_t staging_bytes, int32_t depth,
+                          void* const* events, void* stream, int32_t device, int64_t* n_queued, const int32_t* cancel,
+                          int32_t n_threads);
+int mmx_event_query(void* ev);      /* 0: completed, 1: not yet, else an mmx_status */
 int mmx_event_create(void** ev);
 int mmx_event_destroy(void* ev);
 int mmx_event_record(void* ev, void* stream);

@@ -130,7 +130,7 @@ SYMBOLS = (
     "mmx_preprocess_fast_lds", "mmx_preprocess_batch", "mmx_preprocess_batch_mode", "mmx_preprocess_work_bytes", "mmx_preprocess_batch_generic",
     "mmx_coloc_means", "mmx_coloc_voxels", "mmx_host_take_rows", "mmx_host_map_columns", "mmx_resize_batch_as", "mmx_gauss_axis_batch", "mmx_unmix_batch", "mmx_minmax_batch", "mmx_resize_batch",
     "mmx_cdist_f64", "mmx_host_lsap", "mmx_expand_probes", "mmx_host_resolve_peaks", "mmx_host_overlap_prune",
-    "mmx_host_emit_tables", "mmx_host_prune_region", "mmx_host_prune_parts", "mmx_host_rows_in_boxes", "mmx_host_append_rows", "mmx_host_emit_survivors", "mmx_host_merge_by_key", "mmx_host_merge_parts_by_key", "mmx_host_gather_by_key", "mmx_host_take_rows_final", "mmx_host_emit_survivors_final", "mmx_host_emit_parts_final", "mmx_host_gather_parts_by_key_final", "mmx_host_take_rows_split", "mmx_host_gather_parts_by_key_split", "mmx_host_emit_tables_multi", "mmx_host_coloc_flags", "mmx_host_finish_stack", "mmx_copy_rect_h2d",
+    "mmx_host_emit_tables", "mmx_host_prune_region", "mmx_host_prune_parts", "mmx_host_rows_in_boxes", "mmx_host_append_rows", "mmx_host_emit_survivors", "mmx_host_merge_by_key", "mmx_host_merge_parts_by_key", "mmx_host_gather_by_key", "mmx_host_take_rows_final", "mmx_host_emit_survivors_final", "mmx_host_emit_parts_final", "mmx_host_gather_parts_by_key_final", "mmx_host_take_rows_split", "mmx_host_gather_parts_by_key_split", "mmx_host_emit_tables_multi", "mmx_host_coloc_flags", "mmx_host_finish_stack", "mmx_copy_rect_h2d", "mmx_host_stage_upload", "mmx_event_query",
 )
 KERNEL_KINDS = ("zpass", "ypass", "xpass", "generic", "peaks", "rescore", "overlap_pairs",
                 "close_pairs", "zxpass", "y2pass", "preproc", "coloc", "zxpack")
@@ -253,6 +253,9 @@ def lib() -> ctypes.CDLL:
                                              vp, c_int64, c_int64, vp, vp, vp]
     L.mmx_host_coloc_flags.argtypes = [vp, vp, c_int32, c_int64, vp, vp, c_int, vp, c_int32, vp, c_int64]
     L.mmx_host_finish_stack.argtypes = [POINTER(FinishStackArgs)]
+    L.mmx_host_stage_upload.argtypes = [vp, vp, vp, c_int32, c_int64, c_int64, c_int64, vp, c_int64, c_int32, vp, vp, c_int32,
+                                        vp, vp, c_int32]
+    L.mmx_event_query.argtypes = [vp]
     L.mmx_copy_rect_h2d.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.mmx_host_take_rows_split.argtypes = [vp, c_int64, vp, c_int64, POINTER(c_int32), c_int32, vp, c_int32, vp, c_int32, vp]
     L.mmx_host_gather_parts_by_key_split.argtypes = [vp, c_int64, c_int32, vp, vp, vp, vp, c_int64, POINTER(c_int32), c_int32,

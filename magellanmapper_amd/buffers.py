@@ -39,6 +39,12 @@ class _NativeEvent:
     def synchronize(self) -> None:
         nat.check(nat.lib().mmx_event_synchronize(self.handle), "mmx_event_synchronize")
 
+    def query(self) -> bool:
+        rc = nat.lib().mmx_event_query(self.handle)
+        if rc > 1:
+            nat.check(rc, "mmx_event_query")
+        return rc == 0
+
     def __del__(self):
         try:
             if self.handle:

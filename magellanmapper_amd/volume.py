@@ -114,9 +114,10 @@ class DeviceVolume:
         if up is None:
             return
         ev = up.event_for_boxes(boxes) if boxes is not None else up.event_for(self.shape[0] if z_hi is None else int(z_hi))
+        from .buffers import _stream_wait
         for st in (streams or [torch.cuda.current_stream()]):
             if st is not None:
-                st.wait_event(ev)
+                _stream_wait(st, ev)
         if up.all_queued() and up.events[-1].query():
             up.finish()
             self._upload = None             # everything has landed: later calls cost nothing
@@ -201,6 +202,9 @@ STREAM_UPLOAD = True
 #: ~10 GB/s, the link takes 55-57: four threads (round 5) left a memory-mapped C3 volume staging-bound (8.6 GB / ~40
 #: GB/s = 215 ms against 150 ms of DMA); 0 = a quarter of the cores, between 4 and 16
 _STAGE_THREADS = 0
+#: the staging loop of plain arrays and memory maps as one native call (False: the Python loop, which array subclasses
+#: and non-contiguous sources always take)
+NATIVE_STAGING = True
 #: pinned staging buffers of one upload in flight (each one slab): with three the threads fill slab k + 2 while the
 #: DMA reads slab k and slab k + 1 waits its turn
 _STAGE_DEPTH = 3
@@ -301,8 +305,9 @@ class _SlabUpload:
         self.slab = max(1, min(self.nz, _STREAM_CHUNK_BYTES // plane))
         self.regions = self._plan(cells)      # (z0, z1, y0, y1) in upload order
         self._boxes = np.asarray(self.regions, dtype=np.int64).reshape(-1, 4)
-        self.bounds: List[int] = []          # z end of every queued region
-        self.events: List = []
+        self._events: List = []              # one per region: appended as queued, or all made up front (native staging)
+        self._nq = None                      # native staging: [regions queued so far], written by the staging call
+        self._cancel = np.zeros(1, dtype=np.int32)
         self.n_slabs = len(self.regions)
         self.cv = threading.Condition()
         self.error: Optional[BaseException] = None
@@ -321,8 +326,7 @@ class _SlabUpload:
         if self.nz == 0 or not self.regions:
             ev = torch.cuda.Event()
             ev.record(self.stream)
-            self.bounds.append(0)
-            self.events.append(ev)
+            self._events.append(ev)
             self.regions, self.n_slabs = [(0, 0, 0, self.ny)], 1
             self._boxes = np.asarray(self.regions, dtype=np.int64).reshape(-1, 4)
         elif isinstance(src, torch.Tensor) and src.is_pinned():
@@ -389,13 +393,26 @@ class _SlabUpload:
             ev = torch.cuda.Event()
             ev.record()
         with self.cv:
-            self.bounds.append(z1)
-            self.events.append(ev)
+            self._events.append(ev)
             self.cv.notify_all()
         return ev
 
+    @property
+    def n_queued(self) -> int:
+        return len(self._events) if self._nq is None else int(self._nq[0])
+
+    @property
+    def events(self) -> List:
+        """The events of the regions queued so far, in upload order."""
+        return self._events[:self.n_queued]
+
+    @property
+    def bounds(self) -> List[int]:
+        """z end of every region queued so far."""
+        return [r[1] for r in self.regions[:self.n_queued]]
+
     def all_queued(self) -> bool:
-        return len(self.events) >= max(1, self.n_slabs)
+        return self.n_queued >= max(1, self.n_slabs)
 
     def finish(self) -> None:
         """Every copy has completed (the caller has seen the last event): the source is released, the thread gone."""
@@ -410,20 +427,22 @@ class _SlabUpload:
         the caller's buffer.  Safe to call more than once and after the upload has finished."""
         with self.cv:
             self.cancelled = True
+            self._cancel[0] = 1
             self.cv.notify_all()
         th, self.thread = self.thread, None
         if th is not None and th is not threading.current_thread():
             th.join()
         if self._keep is not None:
-            if self.events:
-                self.events[-1].synchronize()
+            queued = self.events
+            if queued:
+                queued[-1].synchronize()
             self._keep = None
 
     def _wait_queued(self, waiter) -> None:
         """Block until this upload has queued its last region (or gave up); ``waiter`` stops waiting when cancelled."""
         with self.cv:
             while not (self.all_queued() or self.cancelled or self.error is not None or waiter.cancelled):
-                self.cv.wait(0.05)
+                self.cv.wait(0.002)
 
     def _stage(self, arr, tdtype, prev=None):
         stage: List = []
@@ -432,6 +451,8 @@ class _SlabUpload:
             if prev is not None:
                 prev._wait_queued(self)
             torch.cuda.set_device(self.dev)
+            if NATIVE_STAGING and type(arr) in (np.ndarray, np.memmap) and arr.flags.c_contiguous:
+                return self._stage_native(arr)
             inner = tuple(arr.shape[2:])
             itemsize = self.itemsize
             need = max((z1 - z0) * (y1 - y0) for z0, z1, y0, y1 in self.regions) * self.row_bytes
@@ -470,6 +491,40 @@ class _SlabUpload:
             except BaseException:                  # (interpreter shutdown / a lost device: the buffers are dropped)
                 pass
 
+    def _stage_native(self, arr) -> None:
+        """The whole staging loop in ONE native call (``mmx_host_stage_upload``): nothing in it needs the interpreter lock,
+        which a busy detection holds most of the time -- the Python loop above waited for it between every two regions
+        (a two-channel tile from a memory map: 413 against 289 ms from pinned memory)."""
+        from .buffers import _NativeEvent
+        need = max((z1 - z0) * (y1 - y0) for z0, z1, y0, y1 in self.regions) * self.row_bytes
+        depth = max(2, min(int(_STAGE_DEPTH), len(self.regions)))
+        stage = [_take_staging(need) for _ in range(depth)]
+        try:
+            events = [_NativeEvent() for _ in self.regions]
+            nq = np.zeros(1, dtype=np.int64)
+            with self.cv:
+                self._events, self._nq = events, nq
+            if isinstance(arr, np.memmap):
+                _advise_sequential(arr)
+            import ctypes
+            regions = np.ascontiguousarray(self.regions, dtype=np.int64)
+            rc = nat.lib().mmx_host_stage_upload(
+                arr.ctypes.data, self.out.data_ptr(), regions.ctypes.data, len(regions), self.nz, self.ny, self.row_bytes,
+                (ctypes.c_void_p * depth)(*[b.data_ptr() for b in stage]), need, depth,
+                (ctypes.c_void_p * len(events))(*[e.handle for e in events]), self.stream.cuda_stream,
+                self.dev.index if self.dev.index is not None else torch.cuda.current_device(),
+                nq.ctypes.data, self._cancel.ctypes.data, _stage_threads())
+            nat.check(rc, "mmx_host_stage_upload")
+        finally:
+            try:
+                for ev in self.events[-depth:]:
+                    ev.synchronize()               # (the buffers go back only when the DMA has read them)
+                _give_staging(stage)
+            except BaseException:
+                pass
+            with self.cv:
+                self.cv.notify_all()
+
     def event_for(self, z_hi: int):
         """The event after which planes ``[0, z_hi)`` are on the device (waits until its copy has been queued)."""
         return self.event_for_boxes([(0, int(z_hi), 0, self.ny)])
@@ -492,13 +547,15 @@ class _SlabUpload:
             while True:
                 if self.error is not None:
                     raise nat.MmxError(f"upload of the image failed: {self.error!r}") from self.error
-                if last < len(self.events):
-                    return self.events[last]
-                if self.all_queued():
-                    return self.events[-1]
+                n = self.n_queued
+                if last < n:
+                    return self._events[last]
+                if n >= max(1, self.n_slabs):
+                    return self._events[n - 1]
                 if self.cancelled:
                     raise nat.MmxError("upload of the image was cancelled (DeviceVolume.close) before these planes went up")
-                self.cv.wait(0.5)
+                # (the native staging loop publishes its progress in a counter, not through this condition: polled)
+                self.cv.wait(0.5 if self._nq is None else 0.0003)
 
 
 def _advise_sequential(arr) -> None:

@@ -384,3 +384,50 @@ def test_block_row_by_block_row_upload_lands_every_voxel_and_orders_the_waits(gp
         np.testing.assert_array_equal(part.cpu().numpy().view(np.uint16), data[18:40, 0:14])
         np.testing.assert_array_equal(dv.tensor.cpu().numpy().view(np.uint16), data)
         assert dv._upload is None
+
+
+def test_native_staging_loop_equals_the_python_loop_and_can_be_cancelled(gpu, monkeypatch):
+    """Plain arrays and memory maps are staged by ONE native call (``mmx_host_stage_upload``: no interpreter lock between
+    regions); array subclasses take the Python loop.  Both land the same bytes, z-slabs and block-row cells alike, the
+    waits see the native call's progress counter, and ``close()`` in the middle ends the call at the next region."""
+    from magellanmapper_amd import _native as nat, blob_log as bl, volume
+    from magellanmapper_amd.buffers import _NativeEvent
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    rng = np.random.default_rng(9)
+    data = rng.integers(0, 65535, (70, 96, 64)).astype(np.uint16)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", 5 * data[0].nbytes)
+    ro = data.copy()
+    ro.flags.writeable = False
+    for cells in (None, ([30, 70], [40, 96])):
+        got = {}
+        for native in (True, False):
+            monkeypatch.setattr(volume, "NATIVE_STAGING", native)
+            dv = bl.DeviceVolume(ro, streamed=True, cells=cells)
+            up = dv._upload
+            side = torch.cuda.Stream()
+            dv.stream_wait(None, [side], [(0, 12, 0, 30)])          # (a wait while the staging is still running)
+            with torch.cuda.stream(side):
+                head = dv.tensor[:12, :30].clone()
+            dv.wait_all()
+            side.synchronize()
+            assert up.all_queued() and up.thread is None and isinstance(up._events[0], _NativeEvent) == native
+            np.testing.assert_array_equal(head.cpu().numpy().view(np.uint16), data[:12, :30])
+            got[native] = dv.tensor.cpu().numpy().view(np.uint16)
+        np.testing.assert_array_equal(got[True], data)
+        np.testing.assert_array_equal(got[False], data)
+    # cancelled in flight: the call returns, whatever was queued has landed intact, later planes are refused
+    monkeypatch.setattr(volume, "NATIVE_STAGING", True)
+    monkeypatch.setattr(volume, "_STREAM_CHUNK_BYTES", data[0].nbytes)
+    big = np.ascontiguousarray(np.broadcast_to(data, (6,) + data.shape).reshape(-1, 96, 64))
+    big.flags.writeable = False
+    dv = bl.DeviceVolume(big, streamed=True)
+    up = dv._upload
+    dv.stream_wait(3)
+    dv.close()
+    assert up.thread is None and up.cancelled and 3 <= up.n_queued <= up.n_slabs
+    torch.cuda.synchronize()
+    n = up.bounds[up.n_queued - 1]
+    np.testing.assert_array_equal(up.out[:n].cpu().numpy().view(np.uint16), big[:n])
+    if not up.all_queued():
+        with pytest.raises(nat.MmxError, match="cancelled"):
+            up.event_for(len(big))
