@@ -1042,6 +1042,7 @@ def main():
                     help="after the timed region: steps that start from a HOST copy of the volume (upload overlapped "
                          "with the detection), reported as `from_host`")
     ap.add_argument("--stage-threads", type=int, default=0, help="--from-host pageable / mmap: host threads that fill the pinned staging buffers (0: volume._stage_threads)")
+    ap.add_argument("--native-staging", choices=("0", "1"), default="1", help="--from-host pageable / mmap: the staging loop as one native call (1) or the Python loop (0)")
     ap.add_argument("--upload-order", choices=("cells", "slabs"), default="cells",
                     help="--from-host: the volume goes up block row by block row (cells, default) or in z-slabs")
     ap.add_argument("--tiles", type=int, default=1,
@@ -1140,9 +1141,10 @@ def main():
     _sd.PRUNE_PROF = bool(args.prune_prof)
     _sd.STACK_FINISHER = args.stack_finisher == "1"
     bl.PRE_STREAM = args.pre_stream == "1"
+    from magellanmapper_amd import volume as _volume
     if args.stage_threads:
-        from magellanmapper_amd import volume as _volume
         _volume._STAGE_THREADS = args.stage_threads
+    _volume.NATIVE_STAGING = args.native_staging == "1"
     if args.prune_ahead != "auto":
         _sd.PRUNE_AHEAD = args.prune_ahead
 

@@ -552,9 +552,16 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     jobs: List[Optional[dict]] = [None] * n_b
     done_events: List = []
     enq = 0
+    uploading = dvol._upload is not None
     for k in range(n_b):
         while enq < min(n_b, k + 1 + ahead):           # batch k itself and `ahead` batches behind it
             batch = batches[enq]
+            if uploading and enq > k and not dvol.upload_ready(
+                    [(origins[i][0], origins[i][0] + shapes[i][0], origins[i][1], origins[i][1] + shapes[i][1]) for i in batch]):
+                # a volume still on its way up: this batch's voxels have not been queued for copying yet.  Enqueueing it
+                # would block the host until they are -- with finished batches waiting for their host work (all of it
+                # then piled up behind the upload's last region: 30 ms at the end of a from-host step).  Batch k first.
+                break
             jobs[enq] = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
                                         space, float(threshold), eps, bufs, enq % (ahead + 1), d_w0, d_w2, pre=pre,
                                         exact=exact, prepared=None if prepared is None else prepared[enq],

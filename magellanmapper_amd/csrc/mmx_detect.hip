@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -357,16 +359,23 @@ int mmx_host_stage_upload(const void* h_src, void* d_dst, const int64_t* regions
     std::atomic<int> stop{0};
     spin_barrier go, filled;
     go.n = filled.n = T;
+    const bool prof = getenv("MMX_STAGE_PROF") != nullptr;
+    double t_wait = 0, t_fill = 0, t_queue = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     auto work = [&](int t) {
         for (int k = 0; k < n_regions; ++k) {
             const int64_t* r = regions + 4 * (int64_t)k;
             const int which = k % depth;
+            double t0 = 0;
             if (t == 0) {
+                if (prof) t0 = now();
                 // the leader: the DMA that last read this staging buffer must be through with it
                 if (*(volatile const int32_t*)cancel) stop.store(1);
                 else if (k >= depth && hipEventSynchronize((hipEvent_t)events[k - depth]) != hipSuccess) {
                     status.store(fail(hipGetLastError(), "hipEventSynchronize")); stop.store(1);
                 }
+                if (prof) { const double t1 = now(); t_wait += t1 - t0; t0 = t1; }
             }
             go.wait();
             if (stop.load()) return;
@@ -377,12 +386,14 @@ int mmx_host_stage_upload(const void* h_src, void* d_dst, const int64_t* regions
             for (int64_t z = a; z < b; ++z) std::memcpy(dst + z * width, src + z * plane, (size_t)width);
             filled.wait();
             if (t == 0) {
+                if (prof) { const double t1 = now(); t_fill += t1 - t0; t0 = t1; }
                 hipError_t e = hipMemcpy2DAsync((char*)d_dst + r[0] * plane + r[2] * row_bytes, (size_t)plane,
                                                 h_staging[which], (size_t)width, (size_t)width, (size_t)planes,
                                                 hipMemcpyHostToDevice, (hipStream_t)stream);
                 if (e == hipSuccess) e = hipEventRecord((hipEvent_t)events[k], (hipStream_t)stream);
                 if (e != hipSuccess) { status.store(fail(e, "staged upload")); stop.store(1); }
                 else __atomic_store_n(n_queued, (int64_t)k + 1, __ATOMIC_RELEASE);
+                if (prof) t_queue += now() - t0;
             }
         }
     };
@@ -391,5 +402,8 @@ int mmx_host_stage_upload(const void* h_src, void* d_dst, const int64_t* regions
     work(0);
     // (every thread, the leader included, passes go.wait() before it looks at `stop`: nobody is left in a barrier)
     for (auto& h : helpers) h.join();
+    if (prof)
+        fprintf(stderr, "mmx_host_stage_upload: %d regions, %d threads, %.1f ms: waiting for staging buffers %.1f, filling %.1f, "
+                "queueing copies %.1f\n", n_regions, T, now() - t_begin, t_wait, t_fill, t_queue);
     return status.load();
 }

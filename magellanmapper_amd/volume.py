@@ -122,6 +122,12 @@ class DeviceVolume:
             up.finish()
             self._upload = None             # everything has landed: later calls cost nothing
 
+    def upload_ready(self, boxes) -> bool:
+        """True when the copies of every region holding voxels of ``boxes`` have been QUEUED (a ``stream_wait`` for
+        them would not block the host); always True for a resident volume."""
+        up = self._upload
+        return up is None or up.queued_for_boxes(boxes)
+
     def wait_all(self) -> None:
         """Host-side wait for the whole upload (readers of the voxels outside the batched detection); from here on the
         source is no longer read."""
@@ -295,6 +301,8 @@ class _SlabUpload:
             shape, tdtype, itemsize = tuple(src.shape), src.dtype, src.element_size()
         else:
             shape, tdtype, itemsize = tuple(src.shape), getattr(torch, str(src.dtype)), src.dtype.itemsize
+        import time
+        self._t0 = time.perf_counter()
         self.out = torch.empty(shape, dtype=tdtype, device=dev)
         self.dev = dev
         self.nz = shape[0]
@@ -504,10 +512,15 @@ class _SlabUpload:
             nq = np.zeros(1, dtype=np.int64)
             with self.cv:
                 self._events, self._nq = events, nq
+                self.cv.notify_all()
             if isinstance(arr, np.memmap):
                 _advise_sequential(arr)
             import ctypes
             regions = np.ascontiguousarray(self.regions, dtype=np.int64)
+            if os.environ.get("MMX_STAGE_PROF"):
+                import sys, time
+                print(f"_SlabUpload: {(time.perf_counter() - self._t0) * 1e3:.2f} ms from the constructor to the staging call",
+                      file=sys.stderr)
             rc = nat.lib().mmx_host_stage_upload(
                 arr.ctypes.data, self.out.data_ptr(), regions.ctypes.data, len(regions), self.nz, self.ny, self.row_bytes,
                 (ctypes.c_void_p * depth)(*[b.data_ptr() for b in stage]), need, depth,
@@ -529,10 +542,7 @@ class _SlabUpload:
         """The event after which planes ``[0, z_hi)`` are on the device (waits until its copy has been queued)."""
         return self.event_for_boxes([(0, int(z_hi), 0, self.ny)])
 
-    def event_for_boxes(self, boxes):
-        """The event after which every voxel of the ``(z_lo, z_hi, y_lo, y_hi)`` boxes (all x) is on the device: that
-        of the last region, in upload order, that holds any of them (the copy stream runs the regions in order).  Waits
-        until that region's copy has been QUEUED, never for the copy itself."""
+    def _last_region(self, boxes) -> int:
         last = 0
         rg = self._boxes
         for z_lo, z_hi, y_lo, y_hi in boxes:
@@ -543,6 +553,21 @@ class _SlabUpload:
             hit = np.flatnonzero((rg[:, 0] < z_hi) & (rg[:, 1] > z_lo) & (rg[:, 2] < y_hi) & (rg[:, 3] > y_lo))
             if len(hit):
                 last = max(last, int(hit[-1]))
+        return last
+
+    def queued_for_boxes(self, boxes) -> bool:
+        """Whether ``event_for_boxes(boxes)`` would return without waiting (errors and a cancelled upload count as
+        ready: the wait itself reports them)."""
+        if self.error is not None or self.cancelled:
+            return True
+        n = self.n_queued
+        return self._last_region(boxes) < n or n >= max(1, self.n_slabs)
+
+    def event_for_boxes(self, boxes):
+        """The event after which every voxel of the ``(z_lo, z_hi, y_lo, y_hi)`` boxes (all x) is on the device: that
+        of the last region, in upload order, that holds any of them (the copy stream runs the regions in order).  Waits
+        until that region's copy has been QUEUED, never for the copy itself."""
+        last = self._last_region(boxes)
         with self.cv:
             while True:
                 if self.error is not None:
@@ -555,7 +580,7 @@ class _SlabUpload:
                 if self.cancelled:
                     raise nat.MmxError("upload of the image was cancelled (DeviceVolume.close) before these planes went up")
                 # (the native staging loop publishes its progress in a counter, not through this condition: polled)
-                self.cv.wait(0.5 if self._nq is None else 0.0003)
+                self.cv.wait(0.5 if (self._nq is None and self.thread is None) else 0.0003)
 
 
 def _advise_sequential(arr) -> None:
