@@ -330,9 +330,11 @@ struct spin_barrier {
             count.store(0, std::memory_order_relaxed);
             phase.store(p + 1, std::memory_order_release);
         } else {
+            // (a few microseconds of polling for the common case -- the threads arrive together -- then sleep: the leader
+            //  may be waiting two milliseconds for a DMA, and polling helpers take cores from the detection's host side)
             int spins = 0;
             while (phase.load(std::memory_order_acquire) == p)
-                if (++spins > 2000) std::this_thread::yield();
+                if (++spins > 4000) std::this_thread::sleep_for(std::chrono::microseconds(40));
         }
     }
 };

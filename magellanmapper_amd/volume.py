@@ -206,7 +206,9 @@ _STREAM_CHUNK_BYTES = 128 << 20
 STREAM_UPLOAD = True
 #: threads that fill the pinned staging buffers from a pageable / memory-mapped source.  One memcpy stream reads
 #: ~10 GB/s, the link takes 55-57: four threads (round 5) left a memory-mapped C3 volume staging-bound (8.6 GB / ~40
-#: GB/s = 215 ms against 150 ms of DMA); 0 = a quarter of the cores, between 4 and 16
+#: GB/s = 215 ms against 150 ms of DMA), sixteen take memory bandwidth and cores from the detection's own host side
+#: (a preprocessed tile from a memory map: 292 ms against 206 with six; raw C3: 176 with eight, 174 with six); 0 = six
+#: where the machine has them
 _STAGE_THREADS = 0
 #: the staging loop of plain arrays and memory maps as one native call (False: the Python loop, which array subclasses
 #: and non-contiguous sources always take)
@@ -227,7 +229,7 @@ _QUEUES_CHECKED = [False]
 def _stage_threads() -> int:
     n = int(_STAGE_THREADS)
     if n <= 0:
-        n = max(4, min(16, (os.cpu_count() or 8) // 4))
+        n = max(2, min(6, (os.cpu_count() or 8) // 4))
     return n
 
 
