@@ -984,14 +984,21 @@ def from_host_record(kind, slab, z0, shape, volume_cls, detect_and_prune, blocks
     ms = float(np.median(times))
     h2d = (rec.get("h2d") or {}).get("ms_for_volume")
     floor = max(h2d or 0.0, rec["ms_per_step"])
+    nvox_all = int(np.prod(shape))
     return {"source": kind, "ms_per_step": round(ms, 2), "steps": len(times),
+            "Mvoxels_per_s": round(nvox_all / (ms * 1e-3) / 1e6, 1),
+            # what the host -> device link alone allows for a volume that starts on the host (measured copy rate of this
+            # run; uint16 voxels, every channel): no overlap scheme can beat it
+            "pcie_ceiling_Mvoxels_per_s": None if h2d is None else round(nvox_all / (h2d * 1e-3) / 1e6, 1),
+            "fraction_of_pcie_ceiling": None if h2d is None else round(h2d / ms, 3),
             "resident_ms_per_step": rec["ms_per_step"], "h2d_ms_for_volume": h2d,
             "ratio_to_max_of_both": round(ms / floor, 3) if floor else None,
             "serial_ms": None if h2d is None else round(h2d + rec["ms_per_step"], 2),
             "blobs": n, "table_sha1": digest, "same_table_as_resident": digest == rec.get("table_sha1"),
             "tiled": tiled,
-            "note": "every step: upload of the host volume (z-slabs on a copy stream, one event per slab) + detection of "
-                    "the blocks whose slabs have landed + pruning; `serial_ms` = whole upload, then the resident step"}
+            "note": "every step: upload of the host volume (block row by block row on a copy stream, one event per piece; "
+                    "--upload-order slabs: whole z-slabs) + detection of the blocks whose pieces have landed + pruning; "
+                    "`serial_ms` = whole upload, then the resident step"}
 
 
 def compact(rec):

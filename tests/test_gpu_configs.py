@@ -282,3 +282,23 @@ def test_tiled_stack_sharded_by_tile_is_a_weak_scaling_line(gpu, tmp_path):
     assert len({t["table_sha1"] for t in one["tiles"]}) == 4
     assert [r["tiles"] for r in two["ranks"]] == [2.0, 2.0] and all(r["ms_per_tile"] > 0 for r in two["ranks"])
     assert one["value"] > 0 and two["value"] > 0 and two["ms_per_tile"] > 0
+
+
+def test_share_run_models_a_rank_and_merges_the_whole_stacks_table(gpu, tmp_path):
+    """``bench.py --share k/N`` (the strong-scaling MODEL measured on one GPU): one process plays every rank of N twice to
+    record what a real run puts on the wire (``dist.Loopback``), then replays rank k -- its share of the blocks, its seam
+    rows, the pruning of its rows, the merge of every rank's survivors.  The merged table is the whole stack's: the same
+    digest as the plain one-process run, for a middle and an edge rank of 3 and of 8."""
+    shape = (96, 200, 210)
+    np.save(tmp_path / "sh.npy", _host_volume(shape, 5))
+    common = ("--config", "c3", "--segment-size", "48", "--volume", str(tmp_path / "sh.npy"), "--steps", "2", "--warmup", "1")
+    plain = _run_bench(tmp_path, 1, *common)
+    assert plain["share"] is None and plain["blobs"] > 500
+    for spec in ("1/3", "0/8", "5/8"):
+        line = _run_bench(tmp_path, 1, *common, "--share", spec)
+        k, n = (int(v) for v in spec.split("/"))
+        sh = line["share"]
+        assert sh["rank"] == k and sh["of"] == n and sh["blocks"] > 0 and sum(sh["batches"]) == sh["blocks"]
+        assert line["table_sha1"] == plain["table_sha1"] and line["blobs"] == plain["blobs"], spec
+        assert line["n_gpus"] == 1 and sh["step_ms"] > 0 and sh["prune_and_merge_ms"] > 0
+        assert line["config"]["blocks_per_rank"] == sh["blocks"] < plain["config"]["blocks_per_rank"]
