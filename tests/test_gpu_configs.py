@@ -289,7 +289,7 @@ def test_share_run_models_a_rank_and_merges_the_whole_stacks_table(gpu, tmp_path
     record what a real run puts on the wire (``dist.Loopback``), then replays rank k -- its share of the blocks, its seam
     rows, the pruning of its rows, the merge of every rank's survivors.  The merged table is the whole stack's: the same
     digest as the plain one-process run, for a middle and an edge rank of 3 and of 8."""
-    shape = (96, 200, 210)
+    shape = (96, 192, 240)             # (whole blocks of 48: a regular geometry -- the distributed pruning's domain)
     np.save(tmp_path / "sh.npy", _host_volume(shape, 5))
     common = ("--config", "c3", "--segment-size", "48", "--volume", str(tmp_path / "sh.npy"), "--steps", "2", "--warmup", "1")
     plain = _run_bench(tmp_path, 1, *common)
