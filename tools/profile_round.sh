@@ -3,7 +3,7 @@
 # rocprofv3 kernel trace + stats of the headline command, and two separate PMC passes (FETCH_SIZE / WRITE_SIZE)
 # for the bench and for the known-byte calibration streams.  Outputs under gpurun_out/prof_<tag>/.
 set -u
-tag=${1:-r03}
+tag=${1:-r06}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -12,6 +12,7 @@ timeout 900 python bench.py --steps 10 --warmup 3 > $out/bench_default.json 2> $
 timeout 300 python bench.py --config c2 --steps 40 --warmup 5 --no-cpu-baseline > $out/bench_c2.json 2> $out/bench_c2.err
 timeout 600 python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_c5.json 2> $out/bench_c5.err
 timeout 600 python bench.py --denoise 25 --steps 4 --warmup 1 --no-cpu-baseline > $out/bench_denoise25.json 2> $out/bench_denoise25.err
+timeout 600 python bench.py --config c5 --tiles 2 --steps 4 --warmup 1 --parity-sample tests/golden/bench_sample_c5.npz > $out/bench_c5_tiles2.json 2> $out/bench_c5_tiles2.err
 B="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sub-records"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $B > $out/trace.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $B > $out/pmc_fetch.log 2>&1
