@@ -78,7 +78,7 @@ B_ALG_PER_SIGMA = 50                # SURVEY.md section 8d contract figure
 #: kernel families enqueued on the stream the LoG passes run on (everything but the side-stream table kernels)
 MAIN_STREAM = ("zpass", "ypass", "xpass", "generic", "peaks", "zxpass", "y2pass", "preproc", "zxpack", "rescore")
 #: committed counter passes of this command (tools/profile_round.sh): HBM bytes per launch, VALU / MFMA busy
-PMC_FILE = "profiles/r05_pmc_counters.json"
+PMC_FILE = "profiles/r06_pmc_counters.json"
 ZX_DTYPES = {7: "f16x2 MFMA (f32 accumulate) + 16-bit fixed-point intermediates; f64 re-score of every candidate",
              6: "f16x2 MFMA (f32 accumulate), f32 intermediates; f64 re-score of every candidate",
              2: "f32 (packed VALU); f64 re-score of every candidate",
