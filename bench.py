@@ -390,6 +390,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         sharers = max(1, -(-world // max(1, torch.cuda.device_count()))) if backend != "nccl" else 1
         budget = min(16 << 30, int(0.55 * free_b / sharers))
     bl.blob_log_blocks = functools.partial(ctx["blob_log_blocks"], budget_bytes=budget)
+    bl.BUDGET_BYTES = budget               # (calls that do not name a budget: the multi-channel pipeline)
 
     # ---------------- the HIP path on the CPU-baseline sample must give the identical table
     parity = None
@@ -778,6 +779,7 @@ def run_gpu_tiles(args, baseline, steps, warmup, ctx):
         sharers = max(1, -(-world // max(1, torch.cuda.device_count()))) if backend != "nccl" else 1
         budget = min(16 << 30, int(0.55 * free_b / sharers))
     bl.blob_log_blocks = functools.partial(ctx["blob_log_blocks"], budget_bytes=budget)
+    bl.BUDGET_BYTES = budget               # (calls that do not name a budget: the multi-channel pipeline)
 
     parity = None
     cpu = None
@@ -1066,6 +1068,9 @@ def main():
                     help="per-block preprocessing on a stream of its own beside the LoG kernels (1, the default) or on the "
                          "LoG stream (0: the kernel families then run one after the other and their HIP-event times are "
                          "each family's ALONE -- what tools/logfloat_profile.sh compares with the raw-voxel run)")
+    ap.add_argument("--batch-major", choices=("0", "1"), default="1",
+                    help="several channels: one pipeline, both channels of a batch of blocks before the next batch (1, default) "
+                         "or channel after channel (0)")
     ap.add_argument("--stack-finisher", choices=("0", "1"), default="1",
                     help="small one-batch stacks: the host chain behind the kernels as one native call (1, default) or the "
                          "call-by-call form (0)")
@@ -1147,6 +1152,7 @@ def main():
     from magellanmapper_amd import stack_detect as _sd
     _sd.PRUNE_PROF = bool(args.prune_prof)
     _sd.STACK_FINISHER = args.stack_finisher == "1"
+    bl.BATCH_MAJOR = args.batch_major == "1"
     bl.PRE_STREAM = args.pre_stream == "1"
     from magellanmapper_amd import volume as _volume
     if args.stage_threads:

@@ -423,7 +423,7 @@ def _make_blocks(dvol: DeviceVolume, channel: int, origins, shapes):
 def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence[int]],
                     shapes: Sequence[Sequence[int]], min_sigma: float, max_sigma: float,
                     num_sigma: int, threshold: float, overlap: float, *,
-                    budget_bytes: int = 24 << 30, stats: Optional[BatchStats] = None,
+                    budget_bytes: Optional[int] = None, stats: Optional[BatchStats] = None,
                     return_peaks: bool = False, on_batch=None, pre=None,
                     exact_values: Optional[bool] = None, sink=None, finisher=None):
     """``blob_log`` of every block -> list of ``(n, 4)`` float64 ``[z, y, x, sigma]`` arrays.
@@ -449,8 +449,75 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     (``stack_detect._StackFinisher``: one native call up to the stack's final table); ``False``: it left the batch to
     the usual steps.
     """
+    lane = Lane(channel, min_sigma, max_sigma, num_sigma, threshold, overlap, stats=stats, on_batch=on_batch, pre=pre,
+                exact_values=exact_values, sink=sink, finisher=finisher)
+    out = blob_log_lanes(dvol, [lane], origins, shapes, budget_bytes=budget_bytes, return_peaks=return_peaks)
+    return (out[0][0], out[1][0]) if return_peaks else out[0]
+
+
+class Lane:
+    """One detection over the blocks of a volume -- a channel with its scales, threshold, preprocessing and the callbacks
+    that take its batches (the arguments of :func:`blob_log_blocks`); :func:`blob_log_lanes` runs several of them over the
+    same blocks in ONE pipeline."""
+
+    def __init__(self, channel: int, min_sigma: float, max_sigma: float, num_sigma: int, threshold: float, overlap: float,
+                 *, stats: Optional[BatchStats] = None, on_batch=None, pre=None, exact_values: Optional[bool] = None,
+                 sink=None, finisher=None):
+        self.channel, self.threshold, self.overlap = channel, float(threshold), float(overlap)
+        self.space = ScaleSpace.make(min_sigma, max_sigma, num_sigma)
+        self.stats = stats if stats is not None else BatchStats()
+        self.on_batch, self.pre, self.sink, self.finisher = on_batch, pre, sink, finisher
+        self.exact = bool(True if exact_values is None else exact_values)
+        self.results: list = []
+        self.peaks_out: list = []
+
+    def bind(self, dvol: DeviceVolume, n_blocks: int) -> None:
+        """What follows from the volume: value scale, nomination band, value range, the weight tables on its device."""
+        space, pre, channel = self.space, self.pre, self.channel
+        self.results = [None] * n_blocks
+        self.peaks_out = [None] * n_blocks
+        self.vscale = float(dvol.value_scale() if pre is None else pre.value_scale([channel]))
+        eps = EPS_REL * self.vscale
+        # what is known about the voxels the passes will read: raw integer images [0, 1]; float images their measured
+        # range; preprocessed / unmixed / rescaled blocks the bounds their arithmetic implies
+        self.vrange = vrange = dvol.value_range(channel) if pre is None else pre.value_range([channel])
+        integer_voxels = pre is None and dvol.np_dtype in (np.dtype(np.uint8), np.dtype(np.uint16))
+        # volumes whose voxels are known to be non-negative and of ordinary magnitude take 16-bit intermediates: the
+        # band must cover their rounding error fourfold
+        # -- and their error in value units must stay inside the LoG contract (a profile whose unsharp / clip settings
+        # stretch the preprocessed range past ~3.4 keeps float32 intermediates and the narrow band)
+        if (vrange is not None and vrange[0] >= 0.0 and vrange[1] <= FLOAT_TILED_RANGE[1] and EPS_REL_Q16 > EPS_REL
+                and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)
+                and (ZX_MODE == nat.MMX_ZX_TILED_Q16 or space.q16_bound() * (vrange[1] if not integer_voxels else 1.0)
+                     <= LOG_ABS_TOL)):
+            eps = EPS_REL_Q16 * self.vscale
+        self.eps = eps
+        self.d_w0, self.d_w2 = space.device_tables(dvol.tensor.device)
+
+
+#: workspace budget per batch of a call that does not say (``budget_bytes=None``); bench.py sets it from the free HBM
+BUDGET_BYTES = 24 << 30
+#: several channels of a stack in one pipeline, batch-major (both channels of a batch of blocks before the next batch):
+#: False runs the channels one after the other, each through all its batches (``detector.detect_blobs_blocks_device``)
+BATCH_MAJOR = True
+
+
+def blob_log_lanes(dvol: DeviceVolume, lanes: Sequence[Lane], origins: Sequence[Sequence[int]],
+                   shapes: Sequence[Sequence[int]], *, budget_bytes: Optional[int] = None, return_peaks: bool = False):
+    """:func:`blob_log_blocks` for several lanes (channels) over the SAME blocks in one pipeline, batch-major: the
+    batches are planned once, and batch b goes through lane 0, lane 1, ... before batch b + 1 -- one queue of launches
+    for the whole call (no drain between channels), a block's tables of every channel complete together (so that a stack's
+    rows land, and its regions are pruned, from the first batches on), and a host tile still on its way up is needed
+    layer by layer by ALL channels instead of whole by the first.  All lanes preprocess or none does.
+    Returns ``[lane results]`` (and ``[lane peaks]`` with ``return_peaks``)."""
     _require_gpu()
-    space = ScaleSpace.make(min_sigma, max_sigma, num_sigma)
+    budget_bytes = int(BUDGET_BYTES if budget_bytes is None else budget_bytes)
+    lanes = list(lanes)
+    if not lanes:
+        return ([], []) if return_peaks else []
+    if len({lane.pre is None for lane in lanes}) > 1:
+        raise ValueError("lanes of one pipeline either all preprocess their blocks or none does")
+    any_pre = lanes[0].pre is not None
     bufs = _buffers_for(dvol.tensor.device)
     # The very same tuple objects step after step (stack_detect hands over its cached block lists): their checked copies
     # and their content key are remembered -- converting and hashing 256 blocks is 0.3 ms before the first launch.
@@ -468,59 +535,46 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
             if len(bufs.plan_lists) >= 8:
                 bufs.plan_lists.clear()
             bufs.plan_lists[(id(given[0]), id(given[1]))] = (given[0], given[1], lists_key, origins, shapes)   # (kept alive: ids stay theirs)
-    stats = stats if stats is not None else BatchStats()
-    results: List[Optional[np.ndarray]] = [None] * len(shapes)
-    peaks_out: List[Optional[Tuple[np.ndarray, np.ndarray]]] = [None] * len(shapes)
-    vscale = float(dvol.value_scale() if pre is None else pre.value_scale([channel]))
-    eps = EPS_REL * vscale
-    # what is known about the voxels the passes will read: raw integer images [0, 1]; float images their measured
-    # range; preprocessed / unmixed / rescaled blocks the bounds their arithmetic implies
-    vrange = dvol.value_range(channel) if pre is None else pre.value_range([channel])
-    integer_voxels = pre is None and dvol.np_dtype in (np.dtype(np.uint8), np.dtype(np.uint16))
-    # volumes whose voxels are known to be non-negative and of ordinary magnitude take 16-bit intermediates: the
-    # band must cover their rounding error fourfold
-    # -- and their error in value units must stay inside the LoG contract (a profile whose unsharp / clip settings
-    # stretch the preprocessed range past ~1.9 keeps float32 intermediates and the narrow band)
-    if (vrange is not None and vrange[0] >= 0.0 and vrange[1] <= FLOAT_TILED_RANGE[1] and EPS_REL_Q16 > EPS_REL
-            and ZX_MODE in (nat.MMX_ZX_AUTO, nat.MMX_ZX_TILED_Q16)
-            and (ZX_MODE == nat.MMX_ZX_TILED_Q16 or space.q16_bound() * (vrange[1] if not integer_voxels else 1.0)
-                 <= LOG_ABS_TOL)):
-        eps = EPS_REL_Q16 * vscale
-    d_w0, d_w2 = space.device_tables(dvol.tensor.device)
+    for lane in lanes:
+        lane.bind(dvol, len(shapes))
+    n_sig = [len(lane.space.sigmas) for lane in lanes]
+    ns_max = max(n_sig)
     # the batches and their block tables on the device: remembered for the same block lists, volume layout and budget (a
     # stack detected step after step) -- a millisecond of planning, record building and upload per step otherwise, before
     # the first kernel can start
     plan_key = None
     planned = None
-    if pre is None:
+    if not any_pre:
         t_ = dvol.tensor
         # (block records hold element offsets, not addresses: any volume of this layout can use them; the block lists
         #  are compared by content -- `lists_key` above -- so that a caller who builds them afresh finds the same device
         #  tables, which is also what lets a small batch's captured graph be found again)
-        plan_key = (lists_key, tuple(t_.stride()), tuple(t_.shape), str(t_.dtype), len(space.sigmas),
+        plan_key = (lists_key, tuple(t_.stride()), tuple(t_.shape), str(t_.dtype), ns_max,
                     int(budget_bytes), _MAX_BATCH, RAMP, TAPER)
         planned = bufs.plans.get(plan_key)
     if planned is not None:
         batches = planned[0]
     else:
-        batches = plan_batches(shapes, len(space.sigmas), budget_bytes,
-                               0 if pre is None else pre.bytes_per_voxel())
-    exact = bool(True if exact_values is None else exact_values)
+        batches = plan_batches(shapes, ns_max, budget_bytes,
+                               0 if not any_pre else max(lane.pre.bytes_per_voxel() for lane in lanes))
     n_b = len(batches)
+    n_l = len(lanes)
+    items = [(b, l) for b in range(n_b) for l in range(n_l)]       # batch-major
+    n_items = len(items)
     # How far the GPU queue runs ahead of the host.  Raw volumes: EVERY batch is enqueued before the host looks at
     # the first result, so the GPU runs the batches back to back whatever the host is doing (measured: enqueueing
     # batch k + 1 only after the host work of batch k - 1 left the GPU idle ~4 ms per batch once the host work of
     # a batch outlasted the kernels of the next).  Each batch in flight owns a candidate table; the workspace is
     # shared (stream order).  With preprocessing the float64 tiles are double-buffered, so one batch ahead.
-    ahead = n_b if pre is None else PRE_AHEAD
+    ahead = n_items if not any_pre else PRE_AHEAD
     bufs.slots(ahead + 1)
     prepared = None
     if planned is not None:
         prepared = planned[1]
-    elif pre is None:
+    elif not any_pre:
         # block tables of every batch go to the device BEFORE the first kernel: a pageable host -> device copy
         # waits for everything queued on the stream before it
-        prepared = [_make_blocks(dvol, channel, [origins[i] for i in b], [shapes[i] for i in b]) for b in batches]
+        prepared = [_make_blocks(dvol, lanes[0].channel, [origins[i] for i in b], [shapes[i] for i in b]) for b in batches]
         if prepared:        # (one upload for all of them: fourteen small copies were 0.4 ms of idle GPU at the start of a step)
             sizes = [blk.nbytes for blk, _ in prepared]
             allrec = _to_device_bytes(np.concatenate([blk.view(np.uint8).reshape(-1) for blk, _ in prepared]),
@@ -530,44 +584,45 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
         if len(bufs.plans) >= 8:
             bufs.plans.clear()
         bufs.plans[plan_key] = (batches, prepared)
-    if pre is not None and PRE_SIDE_TAIL and RESCORE_STREAM and exact and n_b > 1:
+    if any_pre and PRE_SIDE_TAIL and RESCORE_STREAM and all(lane.exact for lane in lanes) and n_items > 1:
         # preprocessed batches alternate between two workspaces as well (the tail of a batch on the second stream beside
         # the next batch's passes): both at their final size before anything is queued on them
         need = 0
         for b in batches:
             slot_b = max(int(shapes[i][0]) * int(shapes[i][1]) * (-(-int(shapes[i][2]) // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
                          for i in b)
-            need = max(need, -(-int(nat.lib().mmx_workspace_bytes(len(b), slot_b, len(space.sigmas), 1)) // 4))
+            need = max(need, -(-int(nat.lib().mmx_workspace_bytes(len(b), slot_b, ns_max, 1)) // 4))
         bufs.workspace(need)
         bufs.workspace(need, 1)
         bufs.ws_free = [None, None]
-    if pre is None:        # ... and the shared workspace has its final size before anything is queued on it
+    if not any_pre:        # ... and the shared workspace has its final size before anything is queued on it
         if prepared:
-            need = max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, len(space.sigmas), 1)) // 4)
+            need = max(-(-int(nat.lib().mmx_workspace_bytes(len(blk), slot, ns_max, 1)) // 4)
                        for blk, slot, _ in prepared)
             bufs.workspace(need)
-            if RESCORE_STREAM and len(prepared) > 1:
+            if RESCORE_STREAM and n_items > 1:
                 bufs.workspace(need, 1)
             bufs.ws_free = [None, None]
-    jobs: List[Optional[dict]] = [None] * n_b
+    jobs: List[Optional[dict]] = [None] * n_items
     done_events: List = []
     enq = 0
     uploading = dvol._upload is not None
-    for k in range(n_b):
-        while enq < min(n_b, k + 1 + ahead):           # batch k itself and `ahead` batches behind it
-            batch = batches[enq]
+    for k, (b_k, l_k) in enumerate(items):
+        while enq < min(n_items, k + 1 + ahead):       # item k itself and `ahead` items behind it
+            b_e, l_e = items[enq]
+            batch, ln = batches[b_e], lanes[l_e]
             if uploading and enq > k and not dvol.upload_ready(
                     [(origins[i][0], origins[i][0] + shapes[i][0], origins[i][1], origins[i][1] + shapes[i][1]) for i in batch]):
                 # a volume still on its way up: this batch's voxels have not been queued for copying yet.  Enqueueing it
                 # would block the host until they are -- with finished batches waiting for their host work (all of it
-                # then piled up behind the upload's last region: 30 ms at the end of a from-host step).  Batch k first.
+                # then piled up behind the upload's last region: 30 ms at the end of a from-host step).  Item k first.
                 break
-            jobs[enq] = _enqueue_detect(dvol, channel, [origins[i] for i in batch], [shapes[i] for i in batch],
-                                        space, float(threshold), eps, bufs, enq % (ahead + 1), d_w0, d_w2, pre=pre,
-                                        exact=exact, prepared=None if prepared is None else prepared[enq],
-                                        vscale=vscale, vrange=vrange,
+            jobs[enq] = _enqueue_detect(dvol, ln.channel, [origins[i] for i in batch], [shapes[i] for i in batch],
+                                        ln.space, ln.threshold, ln.eps, bufs, enq % (ahead + 1), ln.d_w0, ln.d_w2,
+                                        pre=ln.pre, exact=ln.exact, prepared=None if prepared is None else prepared[b_e],
+                                        vscale=ln.vscale, vrange=ln.vrange,
                                         buffer_free=(None if enq < ahead + 1 else done_events[enq - (ahead + 1)])
-                                        if pre is not None else False, parity=enq)
+                                        if ln.pre is not None else False, parity=enq)
             done_events.append(jobs[enq]["done"])
             jobs[enq]["batch"] = batch
             if enq == 0:
@@ -575,29 +630,31 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                 FIRST_ENQUEUED_T, LAST_BATCH_SIZES = time.perf_counter(), [len(b_) for b_ in batches]
             enq += 1
         pending, jobs[k] = jobs[k], None
-        # host + side-stream work of batch k, the GPU busy with the batches behind it
-        peaks = _finish_detect(pending, dvol, space, float(threshold), eps, bufs, d_w0, d_w2, stats,
-                               finisher=finisher if n_b == 1 else None, overlap=float(overlap))
+        ln = lanes[l_k]
+        # host + side-stream work of item k, the GPU busy with the items behind it
+        peaks = _finish_detect(pending, dvol, ln.space, ln.threshold, ln.eps, bufs, ln.d_w0, ln.d_w2, ln.stats,
+                               finisher=ln.finisher if n_items == 1 else None, overlap=ln.overlap)
         if peaks is _FINISHED:
             continue
         if isinstance(peaks, PeakBatch):
-            pb = _prune_batch_native(peaks, space, float(overlap), stats)
-            if sink is not None:        # the caller builds its tables from the arrays (native, no per-block lists)
+            pb = _prune_batch_native(peaks, ln.space, ln.overlap, ln.stats)
+            if ln.sink is not None:        # the caller builds its tables from the arrays (native, no per-block lists)
                 with torch.cuda.stream(bufs.side):      # (whatever it launches -- co-localisation means -- beside the next batch)
-                    sink(pending["batch"], pb)
+                    ln.sink(pending["batch"], pb)
                 continue
             pruned = [pb.blobs(b) for b in range(len(pb))]
             peaks = [pb.block(b) for b in range(len(pb))] if return_peaks else [None] * len(pb)
         else:
             with torch.cuda.stream(bufs.side):
-                pruned = _prune_batch(peaks, space, float(overlap), dvol.tensor.device, stats)
+                pruned = _prune_batch(peaks, ln.space, ln.overlap, dvol.tensor.device, ln.stats)
         for i, pk, res in zip(pending["batch"], peaks, pruned):
-            results[i] = res
-            peaks_out[i] = pk
-        if on_batch is not None:    # caller's per-block post-processing, still overlapped: whatever it launches
+            ln.results[i] = res
+            ln.peaks_out[i] = pk
+        if ln.on_batch is not None:    # caller's per-block post-processing, still overlapped: whatever it launches
             with torch.cuda.stream(bufs.side):           # (co-localisation means) runs beside the next batch's kernels
-                on_batch(pending["batch"], pruned)
-    return (results, peaks_out) if return_peaks else results
+                ln.on_batch(pending["batch"], pruned)
+    results = [ln.results for ln in lanes]
+    return (results, [ln.peaks_out for ln in lanes]) if return_peaks else results
 
 
 # --------------------------------------------------------------------------- A0-A4

@@ -448,7 +448,9 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
         and not any(getattr(config.get_roi_profile(c), "spectral_unmixing", None) for c in channels)
         and (not coloc or denoise_max_shape is None or keeper is not None))
     held: dict = {}
+    batch_major = bool(bl.BATCH_MAJOR and len(channels) > 1)
     Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry to the 11 columns
+    lanes = []
     for chl in channels:
         settings = config.get_roi_profile(chl)
         source = pre
@@ -545,12 +547,23 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
                     done[i] = tbl
                 return True
 
-        bl.blob_log_blocks(
-            dvol, chl if multichannel else 0, origins, log_shapes,
-            min_sigma=settings["min_sigma_factor"] * scaling_factor,
-            max_sigma=settings["max_sigma_factor"] * scaling_factor,
-            num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
-            overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=source, sink=to_sink, finisher=fin)
+        kwargs = dict(min_sigma=settings["min_sigma_factor"] * scaling_factor,
+                      max_sigma=settings["max_sigma_factor"] * scaling_factor,
+                      num_sigma=settings["num_sigma"], threshold=settings["detection_threshold"],
+                      overlap=settings["overlap"], stats=stats, on_batch=to_tables, pre=source, sink=to_sink, finisher=fin)
+        if batch_major:
+            # every channel a lane of ONE pipeline: both channels of a batch of blocks before the next batch
+            # (blob_log.blob_log_lanes; the closures above take the batches as they finish, the last channel's completes
+            # the block tables)
+            lanes.append(bl.Lane(chl if multichannel else 0, **kwargs))
+        else:
+            bl.blob_log_blocks(dvol, chl if multichannel else 0, origins, log_shapes, **kwargs)
+    if lanes:
+        if len({ln.pre is None for ln in lanes}) > 1:       # (some channels preprocess, some do not: one after the other)
+            for ln in lanes:
+                bl.blob_log_lanes(dvol, [ln], origins, log_shapes)
+        else:
+            bl.blob_log_lanes(dvol, lanes, origins, log_shapes)
     return done
 
 
