@@ -160,7 +160,7 @@ class Preprocessor:
         instead of recycling two batch-sized buffers: the intensity co-localisation, which the reference runs on the
         image detection saw (stack_detect.py:159-162), then reads them instead of preprocessing every channel a
         second time.  MI355X's 288 GB make that affordable for whole tiles (2 channels x 128 blocks of 261^3:
-        40 GB + 10 GB of float32); returns False -- nothing kept, callers preprocess again -- when the free HBM does not."""
+        40 GB + 20 GB of float32); returns False -- nothing kept, callers preprocess again -- when the free HBM does not."""
         nb = len(shapes)
         if nb == 0:
             return False
@@ -168,7 +168,7 @@ class Preprocessor:
         sx = int(-(-shp[:, 2].max() // nat.MMX_ROW_ALIGN) * nat.MMX_ROW_ALIGN)
         sy_rows = int(shp[:, 1].max())
         slot = sx * sy_rows * int(shp[:, 0].max())
-        need = nb * slot * (8 * len(channels) + 4)
+        need = nb * slot * (8 + 4) * len(channels)
         free_b, _ = torch.cuda.mem_get_info(dvol.tensor.device)
         dev = dvol.tensor.device
         held = sum(t.numel() * t.element_size() for t in _RETAINED.get(str(dev), {}).values() if t is not None)
@@ -186,13 +186,17 @@ class Preprocessor:
                 pool[name] = None
                 t = pool[name] = torch.empty(nb * slot, dtype=dtype, device=dev)
             return t[:nb * slot]
-        for name in [k for k in pool if k != "f32" and k not in {f"f64_{int(c)}" for c in channels}]:
+        wanted = {f"f64_{int(c)}" for c in channels} | {f"f32_{int(c)}" for c in channels}
+        for name in [k for k in pool if k not in wanted]:
             del pool[name]                  # (channels of an earlier call that this one does not keep)
+        # (a float32 copy per channel too: with the channels of a batch detected back to back -- blob_log.blob_log_lanes
+        #  -- channel 1's preprocessing runs ahead, beside channel 0's LoG passes, and one shared copy would be overwritten
+        #  under them)
         self._retain = dict(
             gid={(tuple(int(v) for v in o), tuple(int(v) for v in s_)): i for i, (o, s_) in enumerate(zip(origins, shapes))},
             sx=sx, sy_rows=sy_rows, slot=slot, nb=nb,
             out64={int(c): take(f"f64_{int(c)}", torch.float64) for c in channels},
-            out32=take("f32", torch.float32))
+            out32={int(c): take(f"f32_{int(c)}", torch.float32) for c in channels})
         return True
 
     def retained_view(self, channel: int, origins, shapes):
@@ -391,7 +395,7 @@ class Preprocessor:
             subs["scratch_off"][n_fast:] = offs[:-1]
             scratch = self._buffer("_scratch", None, int(offs[-1]), torch.float64, dev)
         if kept is not None:
-            out32, out64 = kept["out32"], kept["out64"][int(channel)]
+            out32, out64 = kept["out32"][int(channel)], kept["out64"][int(channel)]
         else:
             out32 = self._buffer("_out32", which, nb * slot_pre, torch.float32, dev)
             out64 = self._buffer("_out64", which, nb * slot_pre, torch.float64, dev)
