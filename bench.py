@@ -956,16 +956,20 @@ def from_host_record(kind, slab, z0, shape, volume_cls, detect_and_prune, blocks
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             hv, same = volume_cls(src, z0, shape), True
+            each_tile, t_prev = [], t0
             for k in range(n_tiles):
                 nxt = volume_cls(src, z0, shape) if k + 1 < n_tiles else None
                 final_k, _, _ = detect_and_prune(hv, blocks)
+                each_tile.append(round((time.perf_counter() - t_prev) * 1e3, 1))
+                t_prev = time.perf_counter()
                 d_k = None if final_k is None else hashlib.sha1(np.ascontiguousarray(final_k).tobytes()).hexdigest()
                 same = same and d_k == rec.get("table_sha1")
                 hv = nxt
             torch.cuda.synchronize()
             ms_tile = (time.perf_counter() - t0) * 1e3 / n_tiles
             h2d_t = (rec.get("h2d") or {}).get("ms_for_volume")
-            tiled = {"tiles": n_tiles, "ms_per_tile": round(ms_tile, 2), "every_tile_same_table_as_resident": same,
+            tiled = {"tiles": n_tiles, "ms_per_tile": round(ms_tile, 2), "ms_each_tile": each_tile,
+                     "every_tile_same_table_as_resident": same,
                      "serial_ms_per_tile": None if h2d_t is None else round(h2d_t + rec["ms_per_step"], 2),
                      "ratio_to_max_of_both": None if h2d_t is None else round(ms_tile / max(h2d_t, rec["ms_per_step"]), 3)}
         for i in range(n_steps + 1):               # (the first step also pins the staging buffers: not counted)
