@@ -194,3 +194,52 @@ def test_stack_colocalizer_matches_reference(gpu, name):
             assert got[key].get_mean_coords().shape == (len(got[key].df), 3)
     finally:
         detector.Blobs(np.ones((1, 4))).format_blobs()
+
+
+def test_channels_as_lanes_of_one_pipeline_equal_channel_after_channel(gpu, monkeypatch):
+    """``blob_log.blob_log_lanes`` (every channel a lane of ONE pipeline, batch b through all channels before batch b + 1)
+    against the channels detected one after the other: a two-channel stack whose channels detect with DIFFERENT profiles
+    (scales, threshold, overlap), with per-block preprocessing and co-localisation, small batches (several per channel) --
+    identical final tables and flags, both equal to the oracle."""
+    from magellanmapper_amd import blob_log as bl, config, stack_detect, synth
+    from oracle import magmap_oracle as mmo
+    shape = (60, 130, 140)
+    c0 = synth.make_volume(21, shape, 90)
+    c1 = np.maximum(synth.make_volume(22, shape, 70).astype(np.int32), (c0.astype(np.int32) * 6) // 10).astype(np.uint16)
+    vol = np.stack((c0, c1), axis=-1)
+    config.setup_roi_profiles(["default"] * 2)
+    base = dict(segment_size=44, denoise_size=25, num_sigma=3)
+    for p in config.roi_profiles:
+        p.update(base)
+    config.roi_profile.update(base)
+    config.roi_profiles[1].update(num_sigma=4, min_sigma_factor=2.5, max_sigma_factor=4.5, detection_threshold=0.2, overlap=0.3)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "lanes"
+    config.near_max = [-1.0, -1.0]
+    monkeypatch.setattr(bl, "BUDGET_BYTES", 40 << 20)          # (a few blocks per batch: several batches per channel)
+    try:
+        got = {}
+        for batch_major in (True, False):
+            monkeypatch.setattr(bl, "BATCH_MAJOR", batch_major)
+            sizes = []
+            real = bl._enqueue_detect
+            monkeypatch.setattr(bl, "_enqueue_detect", lambda *a, **k: (sizes.append((a[1], len(a[2]))), real(*a, **k))[1])
+            _, _, blobs = stack_detect.detect_blobs_blocks("lanes", stack_detect.Image5d(vol[None]), None, None, None,
+                                                           False, False, True, True)
+            monkeypatch.setattr(bl, "_enqueue_detect", real)
+            chans = [c for c, _ in sizes]
+            assert len(sizes) >= 6 and set(chans) == {0, 1}
+            if batch_major:
+                assert chans[:4] == [0, 1, 0, 1]                # batch 0 in both channels, then batch 1 ...
+            else:
+                assert chans == sorted(chans)                   # all of channel 0, then all of channel 1
+            got[batch_major] = (blobs.blobs, blobs.colocalizations)
+        np.testing.assert_array_equal(got[True][0], got[False][0])
+        np.testing.assert_array_equal(got[True][1], got[False][1])
+        profiles = [dict(p) for p in config.roi_profiles]
+        want, stages = mmo.detect_blobs_blocks(vol, [0, 1], profiles, config.resolutions, near_max=[-1.0, -1.0], coloc=True)
+        assert len(want) > 100 and set(np.unique(want[:, 6])) == {0.0, 1.0}
+        np.testing.assert_array_equal(got[True][0], want)
+        np.testing.assert_array_equal(got[True][1], stages["colocs"])
+    finally:
+        config.setup_roi_profiles(None)
