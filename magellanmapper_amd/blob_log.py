@@ -425,7 +425,7 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
                     num_sigma: int, threshold: float, overlap: float, *,
                     budget_bytes: Optional[int] = None, stats: Optional[BatchStats] = None,
                     return_peaks: bool = False, on_batch=None, pre=None,
-                    exact_values: Optional[bool] = None, sink=None, finisher=None):
+                    exact_values: Optional[bool] = None, sink=None, finisher=None, plan_num_sigma: Optional[int] = None):
     """``blob_log`` of every block -> list of ``(n, 4)`` float64 ``[z, y, x, sigma]`` arrays.
 
     ``exact_values`` (default True): re-score EVERY candidate in float64 in the batch's own kernel queue, so
@@ -451,7 +451,8 @@ def blob_log_blocks(dvol: DeviceVolume, channel: int, origins: Sequence[Sequence
     """
     lane = Lane(channel, min_sigma, max_sigma, num_sigma, threshold, overlap, stats=stats, on_batch=on_batch, pre=pre,
                 exact_values=exact_values, sink=sink, finisher=finisher)
-    out = blob_log_lanes(dvol, [lane], origins, shapes, budget_bytes=budget_bytes, return_peaks=return_peaks)
+    out = blob_log_lanes(dvol, [lane], origins, shapes, budget_bytes=budget_bytes, return_peaks=return_peaks,
+                         plan_num_sigma=plan_num_sigma)
     return (out[0][0], out[1][0]) if return_peaks else out[0]
 
 
@@ -503,12 +504,15 @@ BATCH_MAJOR = True
 
 
 def blob_log_lanes(dvol: DeviceVolume, lanes: Sequence[Lane], origins: Sequence[Sequence[int]],
-                   shapes: Sequence[Sequence[int]], *, budget_bytes: Optional[int] = None, return_peaks: bool = False):
+                   shapes: Sequence[Sequence[int]], *, budget_bytes: Optional[int] = None, return_peaks: bool = False,
+                   plan_num_sigma: Optional[int] = None):
     """:func:`blob_log_blocks` for several lanes (channels) over the SAME blocks in one pipeline, batch-major: the
     batches are planned once, and batch b goes through lane 0, lane 1, ... before batch b + 1 -- one queue of launches
     for the whole call (no drain between channels), a block's tables of every channel complete together (so that a stack's
     rows land, and its regions are pruned, from the first batches on), and a host tile still on its way up is needed
     layer by layer by ALL channels instead of whole by the first.  All lanes preprocess or none does.
+    ``plan_num_sigma``: plan the batches as for this many scales (calls for the channels of one stack made one after
+    the other cut the blocks into the SAME batches that way, whatever each channel's own number of scales).
     Returns ``[lane results]`` (and ``[lane peaks]`` with ``return_peaks``)."""
     _require_gpu()
     budget_bytes = int(BUDGET_BYTES if budget_bytes is None else budget_bytes)
@@ -538,7 +542,7 @@ def blob_log_lanes(dvol: DeviceVolume, lanes: Sequence[Lane], origins: Sequence[
     for lane in lanes:
         lane.bind(dvol, len(shapes))
     n_sig = [len(lane.space.sigmas) for lane in lanes]
-    ns_max = max(n_sig)
+    ns_max = max(n_sig + [int(plan_num_sigma or 0)])
     # the batches and their block tables on the device: remembered for the same block lists, volume layout and budget (a
     # stack detected step after step) -- a millisecond of planning, record building and upload per step otherwise, before
     # the first kernel can start

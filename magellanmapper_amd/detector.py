@@ -557,7 +557,10 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
             # the block tables)
             lanes.append(bl.Lane(chl if multichannel else 0, **kwargs))
         else:
-            bl.blob_log_blocks(dvol, chl if multichannel else 0, origins, log_shapes, **kwargs)
+            # (one channel after the other: every channel's call cuts the blocks into the same batches -- the
+            #  multi-channel sink assembles a batch's tables from all channels' peak arrays)
+            bl.blob_log_blocks(dvol, chl if multichannel else 0, origins, log_shapes, **kwargs,
+                               plan_num_sigma=max(int(config.get_roi_profile(c)["num_sigma"]) for c in channels))
     if lanes:
         if len({ln.pre is None for ln in lanes}) > 1:       # (some channels preprocess, some do not: one after the other)
             for ln in lanes:
