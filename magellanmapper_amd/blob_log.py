@@ -221,6 +221,8 @@ _MAX_BATCH = 1 << 30
 #: last batches), the first batch into a ramp that starts at this many blocks (nothing hides its GPU time from the host)
 TAPER = 4
 RAMP = 16
+#: experiments only: cut the block list into batches of exactly these sizes (when they add up to the number of blocks)
+FORCED_BATCH_SIZES: list = []
 
 
 def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
@@ -234,6 +236,9 @@ def plan_batches(shapes: Sequence[Tuple[int, int, int]], num_sigma: int,
     per_vox = (4 + num_sigma) * 4 + (num_sigma + 1) // 2 + extra_bytes_per_voxel     # + the NMS bit masks
     if not len(shapes):
         return []
+    if FORCED_BATCH_SIZES and sum(FORCED_BATCH_SIZES) == len(shapes):       # (experiments: bench.py --batches)
+        cuts = np.concatenate(([0], np.cumsum(FORCED_BATCH_SIZES)))
+        return [list(range(int(a), int(b))) for a, b in zip(cuts[:-1], cuts[1:])]
     batches: List[List[int]] = []
     cur: List[int] = []
     cur_slot = 0
