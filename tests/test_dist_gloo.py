@@ -566,16 +566,27 @@ def test_tile_gather_without_a_group_and_bad_arguments():
         list(sd.detect_blobs_tiles("x", [], shard="rows"))
 
 
-@pytest.mark.parametrize("world,case", [(8, "c4_grid"), (3, "holes"), (4, "extra_columns_two_channels"), (2, "nothing")])
-def test_loopback_wire_replays_a_rank_with_the_whole_stacks_table(world, case):
+@pytest.mark.parametrize("world,case", [(8, "c4_grid"), (8, "c4_grid+16 region threads"), (3, "holes"),
+                                        (4, "extra_columns_two_channels"), (2, "nothing")])
+def test_loopback_wire_replays_a_rank_with_the_whole_stacks_table(world, case, monkeypatch):
     """``dist.Loopback`` (what ``bench.py --share k/N`` measures a rank's step with): ONE process plays every rank of the
     distributed pruning twice -- the first round records the rows near the seams, the second the survivors pruned with
     them -- and then replays single ranks: every replay merges the WHOLE stack's table, equal to the one-process
     passes, and the statistics sum up as over a real group."""
     from magellanmapper_amd import stack_detect as sd
+    case, _, wide = case.partition("+")
     blocks, tables, shape, channels, n_extra = _dist_case(case)
     grid = blocks.sub_roi_slices.shape
     coords = list(np.ndindex(*grid))
+    if wide:
+        # a machine with many cores: a rank's 32 blocks are pruned in as many regions as there are region threads --
+        # quarter rows of the block grid (2 blocks each) instead of whole x-rows
+        from concurrent.futures import ThreadPoolExecutor
+        monkeypatch.setattr(sd, "_REGION_POOL", [ThreadPoolExecutor(max_workers=16), os.getpid()])
+        monkeypatch.setattr(sd.StackPruner, "REGION_MIN_ROWS", 0)
+        seen = []
+        init = sd._RegionPruner.__init__
+        monkeypatch.setattr(sd._RegionPruner, "__init__", lambda self, *a, **k: (init(self, *a, **k), seen.append(len(self.regions)))[0])
 
     class Img:
         pass
@@ -615,6 +626,8 @@ def test_loopback_wire_replays_a_rank_with_the_whole_stacks_table(world, case):
             np.testing.assert_array_equal(df_q.to_numpy(), df.to_numpy())
         with pytest.raises(NotImplementedError):
             dist.broadcast_table(np.zeros((1, 1)))
+        if wide:
+            assert seen and max(seen) == 16            # 32 blocks in 16 regions of two blocks
     finally:
         dist.set_loopback(None)
     assert dist.world_size() == 1 and not dist._multi_rank()
