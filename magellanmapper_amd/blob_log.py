@@ -470,6 +470,10 @@ class Lane:
                  *, stats: Optional[BatchStats] = None, on_batch=None, pre=None, exact_values: Optional[bool] = None,
                  sink=None, finisher=None):
         self.channel, self.threshold, self.overlap = channel, float(threshold), float(overlap)
+        from . import host_resolve as _hr
+        if _hr.PEAK_ORDER == "0.19+" and self.threshold < 0:
+            raise NotImplementedError("PEAK_ORDER '0.19+' pads the peak mask with 'nearest': identical to the zero padding "
+                                      "of this path for thresholds >= 0 only")
         self.space = ScaleSpace.make(min_sigma, max_sigma, num_sigma)
         self.stats = stats if stats is not None else BatchStats()
         self.on_batch, self.pre, self.sink, self.finisher = on_batch, pre, sink, finisher

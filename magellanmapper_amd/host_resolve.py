@@ -32,6 +32,14 @@ from .buffers import _to_device_bytes
 
 #: band around the overlap limit inside which the host re-evaluates the fraction exactly
 OVERLAP_BAND = 1e-9
+#: which scikit-image the order of EXACTLY EQUAL peak values follows: "0.18" (default; what every fixture of this
+#: repository was made with: `argsort(-values)`, NumPy's default sort -- its order of equal keys is its own) or "0.19+"
+#: (`argsort(..., kind="stable")`, scikit-image >= 0.19, incl. the reference's pinned 0.25.2, envs/requirements.txt:46:
+#: equal values keep np.nonzero order; its peak mask pads with 'nearest' instead of zeros, which is the same mask for the
+#: non-negative thresholds of this path and is refused for negative ones).  PARITY UNPINNED for "0.19+": no fixture of
+#: the pinned release can be made in this image; it differs from the default only in blocks that
+#: hold two bit-equal float64 responses.
+PEAK_ORDER = "0.18"
 
 
 def _pipeline():
@@ -180,7 +188,8 @@ def _resolve_peaks(cands, blocks, shapes, ns, thr, dvol, vol_exact, d_blocks, d_
             out.append((np.zeros((0, 4), dtype=np.int64), np.zeros(0)))
             continue
         vals = vals_all[a:b].copy()
-        rank = np.argsort(-vals)          # the reference's call on the reference's array (peak.py:17)
+        # the reference's call on the reference's array (peak.py:17; scikit-image >= 0.19: kind="stable")
+        rank = np.argsort(-vals, kind="stable") if PEAK_ORDER == "0.19+" else np.argsort(-vals)
         out.append((coords_all[a:b][rank], vals[rank]))
         stats.n_peaks += b - a
     return out
@@ -244,6 +253,8 @@ def _resolve_peaks_native(cands, n_cands: int, blocks, ns: int, thr: float, stat
     stats.n_contested += int(st[0])
     stats.n_probes += n_total - n_cands
     stats.n_peaks += int(st[1])
+    if PEAK_ORDER == "0.19+":
+        ties = ties[:0]                 # (stable order = descending value, equal values in np.nonzero order: what the native step left)
     for b in np.nonzero(ties)[0]:
         # equal float64 responses inside one block: the reference's order is whatever np.argsort makes of them
         lo, hi = offsets[b], offsets[b + 1]

@@ -1720,3 +1720,42 @@ def test_one_native_call_for_a_small_stack_equals_the_call_by_call_chain():
     # no candidates at all
     fin, arena, tables, _ = one_call(table[:0], 0)
     assert tables == [None] * nb and len(fin.result[0]) == 0
+
+
+def test_stable_peak_order_switch_on_constructed_ties(monkeypatch):
+    """``host_resolve.PEAK_ORDER = "0.19+"`` (PARITY UNPINNED: scikit-image >= 0.19 sorts peaks with a stable argsort; no
+    fixture of the reference's pinned 0.25.2 can be made in this image): in a block that holds bit-equal float64
+    responses the equal peaks keep np.nonzero order, everything else -- membership, values, blocks without ties -- is the
+    default's; the default itself is untouched (NumPy's own order of equal keys), and negative thresholds are refused in
+    the new mode (its 'nearest' peak mask equals this path's zero padding for thresholds >= 0 only)."""
+    from magellanmapper_amd import _native as nat, blob_log as bl, host_resolve as hr
+    rng = np.random.default_rng(23)
+    shapes = [(6, 7, 8), (5, 5, 5), (4, 9, 6)]
+    ns = 3
+    table, n_c = _random_candidates(rng, shapes, ns, 60, tie_every=4)      # every fourth candidate: exactly 0.3125
+    blocks = np.zeros(len(shapes), dtype=nat.BLOCK_DTYPE)
+    for k, shp in enumerate(shapes):
+        blocks[k] = (0, shp[0], shp[1], shp[2], k, 32, 0)
+    assert hr.PEAK_ORDER == "0.18"
+    default = bl._resolve_peaks_native(table, n_c, blocks, ns, 0.1, bl.BatchStats(), 1e-3)
+    want_default = _resolve_with_numpy(table, n_c, shapes, ns, 0.1)
+    monkeypatch.setattr(hr, "PEAK_ORDER", "0.19+")
+    stable = bl._resolve_peaks_native(table, n_c, blocks, ns, 0.1, bl.BatchStats(), 1e-3)
+    differs = 0
+    for b, shp in enumerate(shapes):
+        c_d, v_d = default.block(b)
+        c_s, v_s = stable.block(b)
+        np.testing.assert_array_equal(c_d, want_default[b][0])                 # (the default: np.argsort's own order)
+        np.testing.assert_array_equal(v_s, v_d)                                # same values in the same (descending) order
+        assert sorted(map(tuple, c_s)) == sorted(map(tuple, c_d))              # same peaks
+        # stable: descending value, equal values by their place in the (z, y, x, sigma) cube
+        lin = ((c_s[:, 0] * shp[1] + c_s[:, 1]) * shp[2] + c_s[:, 2]) * ns + c_s[:, 3]
+        order = np.lexsort((lin, -v_s))
+        np.testing.assert_array_equal(order, np.arange(len(v_s)))
+        differs += int(not np.array_equal(c_s, c_d))
+        assert np.count_nonzero(v_s == 0.3125) >= 2
+    assert differs >= 1                 # (NumPy's default order of a dozen equal keys is not the stable one)
+    with pytest.raises(NotImplementedError, match="nearest"):
+        bl.Lane(0, 3.0, 3.0, 1, -0.5, 0.5)
+    monkeypatch.setattr(hr, "PEAK_ORDER", "0.18")
+    bl.Lane(0, 3.0, 3.0, 1, -0.5, 0.5)          # (the default takes any threshold)
