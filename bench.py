@@ -1072,6 +1072,7 @@ def main():
                     help="per-block preprocessing on a stream of its own beside the LoG kernels (1, the default) or on the "
                          "LoG stream (0: the kernel families then run one after the other and their HIP-event times are "
                          "each family's ALONE -- what tools/logfloat_profile.sh compares with the raw-voxel run)")
+    ap.add_argument("--pre-ahead-retained", type=int, default=-1, help="experiments: blob_log.PRE_AHEAD_RETAINED")
     ap.add_argument("--batches", default=None, metavar="N,N,...", help="experiments: batches of exactly these sizes (blob_log.FORCED_BATCH_SIZES)")
     ap.add_argument("--taper", type=int, default=-1, help="blob_log.TAPER: size of the last batch of a step (experiments)")
     ap.add_argument("--batch-major", choices=("0", "1"), default="1",
@@ -1161,6 +1162,8 @@ def main():
     bl.BATCH_MAJOR = args.batch_major == "1"
     if args.taper >= 0:
         bl.TAPER = args.taper
+    if args.pre_ahead_retained >= 0:
+        bl.PRE_AHEAD_RETAINED = args.pre_ahead_retained
     if args.batches:
         bl.FORCED_BATCH_SIZES = [int(v) for v in args.batches.split(",")]
     bl.PRE_STREAM = args.pre_stream == "1"

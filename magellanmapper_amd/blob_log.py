@@ -107,6 +107,8 @@ PRE_SIDE_TAIL = False
 #: ... and this many batches ahead of the one the host is finishing (``preprocess.N_BUFFER_SETS`` - 1 buffer sets allow
 #: it): the first batch is then the only one whose LoG passes wait for their preprocessing
 PRE_AHEAD = 2
+#: ... and this many BATCHES (x the number of lanes) when the preprocessed blocks are retained per block
+PRE_AHEAD_RETAINED = 2
 #: raw volumes: everything after a batch's last LoG kernel -- NMS, probe expansion, exact re-score, the copies of the
 #: results to the host -- on a stream of its own, beside the LoG kernels of the next batch, which then work in a second
 #: workspace (``_Buffers.workspace(n, 1)``: +16 GiB with the default budget).  Measured on the benchmark volume,
@@ -580,6 +582,11 @@ def blob_log_lanes(dvol: DeviceVolume, lanes: Sequence[Lane], origins: Sequence[
     # a batch outlasted the kernels of the next).  Each batch in flight owns a candidate table; the workspace is
     # shared (stream order).  With preprocessing the float64 tiles are double-buffered, so one batch ahead.
     ahead = n_items if not any_pre else PRE_AHEAD
+    if any_pre and all(getattr(lane.pre, "retains", lambda c: False)(lane.channel) for lane in lanes):
+        # every lane's preprocessed blocks have slots of their own (Preprocessor.retain: the co-localisation's): no buffer
+        # set limits how far the queue may run ahead -- and with several lanes PRE_AHEAD items are less than PRE_AHEAD
+        # batches
+        ahead = max(ahead, min(n_items, PRE_AHEAD_RETAINED * n_l))
     bufs.slots(ahead + 1)
     prepared = None
     if planned is not None:

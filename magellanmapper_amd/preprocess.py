@@ -199,6 +199,10 @@ class Preprocessor:
             out32={int(c): take(f"f32_{int(c)}", torch.float32) for c in channels})
         return True
 
+    def retains(self, channel: int) -> bool:
+        """Whether the preprocessed blocks of ``channel`` go to slots of their own (``retain``) instead of the buffer sets."""
+        return self._retain is not None and int(channel) in self._retain["out64"]
+
     def retained_view(self, channel: int, origins, shapes):
         """``(blocks, vol64)`` of already preprocessed blocks of ``channel`` (``None`` when nothing is retained)."""
         r = self._retain
