@@ -1075,9 +1075,9 @@ def main():
     ap.add_argument("--pre-ahead-retained", type=int, default=-1, help="experiments: blob_log.PRE_AHEAD_RETAINED")
     ap.add_argument("--batches", default=None, metavar="N,N,...", help="experiments: batches of exactly these sizes (blob_log.FORCED_BATCH_SIZES)")
     ap.add_argument("--taper", type=int, default=-1, help="blob_log.TAPER: size of the last batch of a step (experiments)")
-    ap.add_argument("--batch-major", choices=("0", "1"), default="1",
-                    help="several channels: one pipeline, both channels of a batch of blocks before the next batch (1, default) "
-                         "or channel after channel (0)")
+    ap.add_argument("--batch-major", choices=("auto", "0", "1"), default="auto",
+                    help="several channels: one pipeline, both channels of a batch of blocks before the next batch (1), "
+                         "channel after channel (0), or batch-major only while the volume is still uploading (auto, default)")
     ap.add_argument("--stack-finisher", choices=("0", "1"), default="1",
                     help="small one-batch stacks: the host chain behind the kernels as one native call (1, default) or the "
                          "call-by-call form (0)")
@@ -1159,7 +1159,8 @@ def main():
     from magellanmapper_amd import stack_detect as _sd
     _sd.PRUNE_PROF = bool(args.prune_prof)
     _sd.STACK_FINISHER = args.stack_finisher == "1"
-    bl.BATCH_MAJOR = args.batch_major == "1"
+    if args.batch_major != "auto":
+        bl.BATCH_MAJOR = args.batch_major == "1"
     if args.taper >= 0:
         bl.TAPER = args.taper
     if args.pre_ahead_retained >= 0:

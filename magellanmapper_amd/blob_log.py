@@ -510,8 +510,12 @@ class Lane:
 #: workspace budget per batch of a call that does not say (``budget_bytes=None``); bench.py sets it from the free HBM
 BUDGET_BYTES = 24 << 30
 #: several channels of a stack in one pipeline, batch-major (both channels of a batch of blocks before the next batch):
-#: False runs the channels one after the other, each through all its batches (``detector.detect_blobs_blocks_device``)
-BATCH_MAJOR = True
+#: "uploading" (default) = while the volume is still on its way to the device -- a host tile is then needed layer by
+#: layer by all channels instead of whole by the first (one C5 tile from the host: 240 against 285 ms); True = always;
+#: False = never: the channels one after the other, each through all its batches.  For a RESIDENT volume the two orders
+#: cost the same on average (213-217 ms per C5 step) but batch-major scatters more (p95 / p50 1.08 against 1.02; as a
+#: sub-record behind other workloads 232-254 against 223-225): profiles/r06_experiments.txt section 7
+BATCH_MAJOR = "uploading"
 
 
 def blob_log_lanes(dvol: DeviceVolume, lanes: Sequence[Lane], origins: Sequence[Sequence[int]],

@@ -448,7 +448,8 @@ def detect_blobs_blocks_device(dvol, channel, origins, shapes, stats=None,
         and not any(getattr(config.get_roi_profile(c), "spectral_unmixing", None) for c in channels)
         and (not coloc or denoise_max_shape is None or keeper is not None))
     held: dict = {}
-    batch_major = bool(bl.BATCH_MAJOR and len(channels) > 1)
+    batch_major = bool(len(channels) > 1 and (bl.BATCH_MAJOR is True or (
+        bl.BATCH_MAJOR == "uploading" and getattr(dvol, "_upload", None) is not None)))
     Blobs(np.ones((1, 4))).format_blobs()      # bind the class-level column registry to the 11 columns
     lanes = []
     for chl in channels:
