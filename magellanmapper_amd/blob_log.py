@@ -937,8 +937,7 @@ def _launch_batch(L, a, info, bufs: _Buffers, nb: int, blocks, space, vol32, vol
         # instead, ordered after what the caller has queued and before what it queues next
         caller = torch.cuda.current_stream()
         if bufs.graph_stream is None:
-            from .buffers import _STREAMS
-            bufs.graph_stream = _STREAMS[str(bufs.dev)].setdefault("graph", torch.cuda.Stream(device=bufs.dev))
+            bufs.graph_stream = torch.cuda.Stream(device=bufs.dev)
         gs = bufs.graph_stream
         origin = a.stream
         for name in ("stream", "tail_stream", "pack_stream"):

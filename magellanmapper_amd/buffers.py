@@ -80,24 +80,15 @@ class _Buffers:
         self.counts = []
         self.host_counts = []
         self.host_tabs = []
-        # The streams are made ONCE per process and device and survive `release_buffers()`: ROCm deals streams to its
-        # hardware queues (GPU_MAX_HW_QUEUES) as they are made, and a second set made later -- another workload of the
-        # same process: bench.py's sub-records -- came to share queues with each other (the preprocessing stream behind
-        # the LoG stream: the C5 sub-record read 236-252 ms after C3 and C2 had run in the process, 207-217 alone)
-        st = _STREAMS.get(str(dev))
-        if st is None:
-            st = _STREAMS[str(dev)] = dict(
-                side=torch.cuda.Stream(device=dev, priority=-1),
-                # per-block preprocessing (float64 vector arithmetic) of batch k + 1 runs here, beside the LoG kernels
-                # of batch k (bound by memory requests) on the caller's stream
-                pre=torch.cuda.Stream(device=dev),
-                rescore=torch.cuda.Stream(device=dev, priority=0),
-                pack=torch.cuda.Stream(device=dev))
-        self.side, self.pre_stream = st["side"], st["pre"]
-        self.rescore_stream, self.pack_stream = st["rescore"], st["pack"]
+        self.side = torch.cuda.Stream(device=dev, priority=-1)
+        # per-block preprocessing (float64 vector arithmetic) of batch k + 1 runs here, beside the LoG kernels of
+        # batch k (bound by memory requests) on the caller's stream
+        self.pre_stream = torch.cuda.Stream(device=dev)
+        self.rescore_stream = torch.cuda.Stream(device=dev, priority=0)
+        self.pack_stream = torch.cuda.Stream(device=dev)
         self.native_events = []            # per candidate-table slot: (workspace read, batch done)
         self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
-        self.graph_stream = _STREAMS[str(dev)].get("graph")    # where they run when the caller is on the (uncapturable) default stream
+        self.graph_stream = None           # where they run when the caller is on the (uncapturable) default stream
         self.plans = {}                    # batch plans + uploaded block tables of recent (block lists, volume layout)
         self.plan_lists = {}               # (id(origins), id(shapes)) -> (the lists, their content key)
         self.slots(2)
@@ -153,7 +144,6 @@ class _Buffers:
 
 
 _BUFFERS: Dict[str, _Buffers] = {}
-_STREAMS: Dict[str, dict] = {}          # per device: the pipeline's streams, made once per process
 
 
 def _buffers_for(dev) -> _Buffers:

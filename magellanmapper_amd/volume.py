@@ -253,10 +253,11 @@ def _give_staging(bufs) -> None:
 
 
 def release_staging() -> None:
-    """Drop the pinned staging buffers kept between uploads (``buffers.release_buffers``)."""
+    """Drop the pinned staging buffers and the copy streams kept between uploads (``buffers.release_buffers``)."""
     with _STAGING_LOCK:
         _STAGING.clear()
-    _LAST_STAGED.clear()            # (the copy streams stay: streams are dealt to the hardware queues as they are made)
+    _UPLOAD_STREAMS.clear()
+    _LAST_STAGED.clear()
 
 
 def _check_hw_queues() -> None:
