@@ -624,8 +624,7 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
         "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True,
         # host clock after every step of the timed region (the last step's barrier is not in these): spread of a step
         "step_ms_percentiles": {"min": round(float(each.min()), 3), "p50": round(float(np.percentile(each, 50)), 3),
-                                "p95": round(float(np.percentile(each, 95)), 3), "max": round(float(each.max()), 3),
-                                "slowest_step": int(each.argmax())},
+                                "p95": round(float(np.percentile(each, 95)), 3), "max": round(float(each.max()), 3)},
         "scaling": "strong", "vs_baseline": None,
         "dtype": ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate") if PROFILE["denoise_size"] is None
                  else "f64 preprocessing; " + ZX_DTYPES.get(zx_path, "f32; f64 re-score of every candidate"),

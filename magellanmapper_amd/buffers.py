@@ -88,12 +88,7 @@ class _Buffers:
         self.pack_stream = torch.cuda.Stream(device=dev)
         self.native_events = []            # per candidate-table slot: (workspace read, batch done)
         self.graphs = {}                   # captured small batches: key -> (graph handle, mmx_detect_info, keep-alives)
-        # where captured batches run when the caller is on the (uncapturable) default stream.  Made -- and used once --
-        # here: ROCm takes a hardware queue for a stream at its FIRST submission, 12-17 ms that used to fall into the
-        # first step that replayed a graph (bench.py's c2 sub-record: its slowest step was always step 0)
-        self.graph_stream = torch.cuda.Stream(device=dev)
-        for st in (self.graph_stream, self.side, self.pre_stream, self.rescore_stream, self.pack_stream):
-            torch.cuda.Event().record(st)
+        self.graph_stream = None           # where they run when the caller is on the (uncapturable) default stream
         self.plans = {}                    # batch plans + uploaded block tables of recent (block lists, volume layout)
         self.plan_lists = {}               # (id(origins), id(shapes)) -> (the lists, their content key)
         self.slots(2)
