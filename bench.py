@@ -427,10 +427,22 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
                 detect_and_prune(dvol, blocks)
         wire.mode = "replay"
     nat.timing_enable(True)             # (the warm-up tells which kernel family dominates: the one the roofline is about)
-    for _ in range(warmup):
+    # Volumes of a few blocks (c2) run their timed region as replays of a captured hipGraph (below), which the per-kernel
+    # timing prevents: their last two warm-up steps run without it -- the first sighting of the batch and its capture,
+    # with the stream the graph runs on taking its hardware queue (12-17 ms once) -- so that the timed region is what a
+    # caller's steady state is: replays.
+    early_replay = (world == 1 and 0 < n_blocks <= bl.GRAPH_BLOCKS and bl.NATIVE_BATCH and not PROFILE["denoise_size"]
+                    and warmup >= 3)
+    warm = {}
+    for w in range(warmup):
+        if early_replay and w == warmup - 2:
+            torch.cuda.synchronize()
+            warm = {k: ms for k, (ms, n) in nat.timing_read().items() if n and k in ALG_BYTES}
+            nat.timing_enable(False)
         one_step()
     torch.cuda.synchronize()
-    warm = {k: ms for k, (ms, n) in nat.timing_read().items() if n and k in ALG_BYTES}
+    if not early_replay:
+        warm = {k: ms for k, (ms, n) in nat.timing_read().items() if n and k in ALG_BYTES}
     nat.timing_enable(False)
     for k in timers:
         timers[k] = 0.0
