@@ -206,6 +206,14 @@ def run_cpu_baseline(name, args, host_vol):
     cfg, profile, shape, n_chl, coloc = config_setup(name, args, host_vol)
     phys = physical_cores()
     cores = args.cpu_cores or phys
+    pool_note = None
+    if n_chl > 1 and not args.cpu_cores and not (args.cpu_full and name == args.config) and cores > 16:
+        # the preprocessed two-channel sample: the pool's throughput on this pool's 128-core boxes is FLAT from 16
+        # processes on (tools/exp/cpu_sample_scaling.py: 2.74 / 2.42 / 2.57 Mvoxel/s with 16 / 32 / 64 blocks and
+        # processes -- detection 37 / 94 / 157 s), so the larger sample only made the default command 2.4 minutes longer
+        cores = 16
+        pool_note = ("16 blocks over 16 processes: the pool's throughput on this box does not grow beyond that "
+                     "(measured flat for 16 / 32 / 64 processes with one block each, profiles/r06_experiments.txt section 10)")
     # a bounded sample (10-30 s of CPU work): about one block per core, at least two z-layers of blocks where
     # the volume has them so that the sample prunes seams along all three axes
     want_blocks = max(2, cores)
@@ -233,6 +241,8 @@ def run_cpu_baseline(name, args, host_vol):
                      f"{n_jobs} blocks over a pool of {min(cores, n_jobs)} processes "
                      f"(reference strategy, stack_detect.py:222-257)",
            "blobs": 0 if cpu_final is None else int(len(cpu_final))}
+    if pool_note:
+        cpu["pool_note"] = pool_note
     return dict(cpu=cpu, final=cpu_final, sample=sample, colocs=cpu_colocs)
 
 
