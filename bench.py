@@ -1186,7 +1186,8 @@ def main():
 
     from magellanmapper_amd import blob_log as bl
     from magellanmapper_amd import stack_detect as _sd
-    _sd.PRUNE_PROF = bool(args.prune_prof)
+    from magellanmapper_amd import stack_prune as _sp
+    _sp.PRUNE_PROF = bool(args.prune_prof)
     _sd.STACK_FINISHER = args.stack_finisher == "1"
     if args.batch_major != "auto":
         bl.BATCH_MAJOR = args.batch_major == "1"

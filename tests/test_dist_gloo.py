@@ -582,7 +582,7 @@ def test_loopback_wire_replays_a_rank_with_the_whole_stacks_table(world, case, m
         # a machine with many cores: a rank's 32 blocks are pruned in as many regions as there are region threads --
         # quarter rows of the block grid (2 blocks each) instead of whole x-rows
         from concurrent.futures import ThreadPoolExecutor
-        monkeypatch.setattr(sd, "_REGION_POOL", [ThreadPoolExecutor(max_workers=16), os.getpid()])
+        monkeypatch.setattr(sd.stack_prune, "_REGION_POOL", [ThreadPoolExecutor(max_workers=16), os.getpid()])
         monkeypatch.setattr(sd.StackPruner, "REGION_MIN_ROWS", 0)
         seen = []
         init = sd._RegionPruner.__init__
