@@ -1041,7 +1041,7 @@ def compact(rec):
             "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in rec["kernels"].items()},
             "parity_sample_identical": rec["parity_sample_identical"],
             "cpu_baseline": None if rec["cpu_baseline"] is None else
-            {k: rec["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample")},
+            {k: rec["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample", "pool_note") if k in rec["cpu_baseline"]},
             "config": rec["config"]["workload"], "dtype": rec["dtype"], "graph_replay": rec.get("graph_replay")}
 
 
