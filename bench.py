@@ -1109,6 +1109,8 @@ def main():
     ap.add_argument("--shard", choices=("blocks", "tiles"), default=None,
                     help="N > 1: blocks of ONE volume over the ranks (strong scaling, the default) or whole tiles of a "
                          "tiled stack (weak scaling; implied by --tiles T without --from-host)")
+    ap.add_argument("--region-split", type=int, default=0,
+                    help="regions of the pruning ahead per x-row of blocks (stack_detect.REGION_SPLIT; 0 = one per channel)")
     ap.add_argument("--parity-sample", default=None, metavar="NPZ",
                     help="check the parity sample against this committed oracle table (tests/golden/make_bench_samples.py) "
                          "instead of running the oracle: no cpu_baseline timing, seconds instead of minutes")
@@ -1204,6 +1206,8 @@ def main():
     _volume.NATIVE_STAGING = args.native_staging == "1"
     if args.prune_ahead != "auto":
         _sd.PRUNE_AHEAD = args.prune_ahead
+    if args.region_split:
+        _sd.REGION_SPLIT = args.region_split
 
     import scipy
     share = wire = None

@@ -48,6 +48,9 @@ DIST_PRUNE = True
 #: "0" = always / never (what tests and tools set; DESIGN.md section 4b has the measurements)
 PRUNE_AHEAD = ""
 #: (the phases of the pruning step on stderr: ``stack_prune.PRUNE_PROF``)
+#: regions of the pruning ahead per x-row of blocks: 0 = one per channel of the table (a two-channel stack has twice the
+#: rows per block: its last regions, pruned after the last kernel, are halved -- bench.py --region-split has the A/B)
+REGION_SPLIT = 0
 #: small one-batch stacks: the host chain behind the kernels as ONE native call (``_StackFinisher``); False keeps the
 #: call-by-call form (what tests compare it with)
 STACK_FINISHER = True
@@ -269,7 +272,9 @@ class StackDetector:
             def make_pruner():
                 return _RegionPruner(arena, StackPruner._axis_plan(shape3, ov, tl, tl if pad is None else pad,
                                                                    sub_roi_slices, sub_rois_offsets),
-                                     prune_channels, sub_roi_slices, shape3, mine)
+                                     prune_channels, sub_roi_slices, shape3, mine,
+                                     min_regions=-(-len(mine) // max(1, int(grid[2]))) * int(
+                                         REGION_SPLIT or max(1, len(prune_channels))))
 
         sink = None
         finisher = None
