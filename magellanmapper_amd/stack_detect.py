@@ -81,6 +81,8 @@ class Image5d:
         the background)."""
         from . import blob_log as bl
         if self.device_volume is None and self.img is not None:
+            if _image_bytes(self.img[0]) > _resident_limit():
+                return self             # (too large to be resident: detected z-chunk by z-chunk from the host)
             cells = None
             try:        # (where the first channel's profile puts the block rows: only the upload ORDER depends on it)
                 blocks = setup_blocks(config.get_roi_profile(0), self.img.shape[1:4])
@@ -95,6 +97,50 @@ class Image5d:
         dv, self.device_volume = self.device_volume, None
         if dv is not None:
             dv.close()
+
+
+#: a HOST image larger than this many bytes is detected z-chunk by z-chunk -- whole layers of blocks, each chunk a device
+#: volume of its own with the next one on its way up meanwhile -- instead of going to the device whole (the reference
+#: reads any size through its memory map, importer.py:794); the tables land in the one arena and are pruned once, as
+#: always.  ``None``: a third of the device memory that is free when the call starts.
+MAX_RESIDENT_BYTES = None
+
+
+def _resident_limit() -> int:
+    if MAX_RESIDENT_BYTES is not None:
+        return int(MAX_RESIDENT_BYTES)
+    import torch
+    return int(torch.cuda.mem_get_info()[0] // 3)
+
+
+def _image_bytes(img) -> int:
+    n = 1
+    for v in img.shape:
+        n *= int(v)
+    item = img.element_size() if hasattr(img, "element_size") else np.dtype(img.dtype).itemsize
+    return n * int(item)
+
+
+def _z_chunks(coords, mine, origins, shapes, plane_bytes: int, limit: int):
+    """This rank's blocks (z-major, ``mine[k]`` -> ``coords``) cut into runs of whole block LAYERS whose planes take at
+    most ``limit / 2`` bytes (two chunks are on the device while one is detected and the next goes up; a single layer
+    may exceed it): ``[(k_lo, k_hi, z_lo, z_hi)]``."""
+    layers = []                       # (k_lo, k_hi, z_lo, z_hi) per layer of the block grid
+    for k, i in enumerate(mine):
+        z0, z1 = int(origins[k][0]), int(origins[k][0]) + int(shapes[k][0])
+        if layers and coords[i][0] == layers[-1][4]:
+            a = layers[-1]
+            layers[-1] = (a[0], k + 1, min(a[2], z0), max(a[3], z1), a[4])
+        else:
+            layers.append((k, k + 1, z0, z1, coords[i][0]))
+    chunks = []
+    for k_lo, k_hi, z_lo, z_hi, _ in layers:
+        if chunks and (max(chunks[-1][3], z_hi) - chunks[-1][2]) * plane_bytes <= limit // 2:
+            c = chunks[-1]
+            chunks[-1] = (c[0], k_hi, c[2], max(c[3], z_hi))
+        else:
+            chunks.append((k_lo, k_hi, z_lo, z_hi))
+    return chunks
 
 
 def _upload_cells(sub_roi_slices, shape3):
@@ -295,8 +341,14 @@ class StackDetector:
 
         own_dvol = None
         if mine:
+            chunks = None
             if isinstance(img, bl.DeviceVolume):
                 dvol = img
+            elif _image_bytes(img) > _resident_limit() and len({coords[i][0] for i in mine}) > 1:
+                # too large to be resident: whole layers of blocks at a time, each from a device volume of its own
+                plane = _image_bytes(img) // max(1, int(img.shape[0]))
+                chunks = _z_chunks(coords, mine, origins, shapes, plane, _resident_limit())
+                dvol = None
             else:
                 # a host image handed over for the length of this call: it goes up beside the detection of the blocks
                 # that have landed, and whatever of it this rank's blocks never touched is cancelled before returning
@@ -319,7 +371,7 @@ class StackDetector:
                 # a small stack of one channel (all blocks in one batch: the GUI's ROI, a grid-search step): the whole
                 # host chain behind its kernels as one native call
                 if (regular and dist.world_size() == 1 and make_pruner is None and n_extra == 0 and STACK_FINISHER
-                        and len(list(channel or [0])) == 1 and len(mine) <= bl.GRAPH_BLOCKS
+                        and chunks is None and len(list(channel or [0])) == 1 and len(mine) <= bl.GRAPH_BLOCKS
                         and denoise_max_shape is None and list(hint[3]) == list(channel or [0])):
                     ov, tl, pad, _ = hint
                     plan_ = StackPruner._geometry(shape3, ov, tl, tl if pad is None else pad, sub_roi_slices,
@@ -327,10 +379,14 @@ class StackDetector:
                     if plan_ is not None:
                         finisher = _StackFinisher(sink, plan_, hint[3])
             try:
-                tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
-                                                             denoise_max_shape=denoise_max_shape,
-                                                             exclude=exclude_of, coloc=coloc, sink=sink,
-                                                             stack_finisher=finisher)
+                if chunks is None:
+                    tables = detector.detect_blobs_blocks_device(dvol, channel, origins, shapes, stats, finish,
+                                                                 denoise_max_shape=denoise_max_shape,
+                                                                 exclude=exclude_of, coloc=coloc, sink=sink,
+                                                                 stack_finisher=finisher)
+                else:
+                    tables = cls._detect_chunks(img, chunks, sub_roi_slices, shape3, channel, origins, shapes, stats,
+                                                finish, denoise_max_shape, exclude_of, coloc, sink)
             except BaseException:
                 # the detection failed: the regions pruned ahead have nobody to collect them
                 for p_ in (pruner, None if sink is None else sink.pruner):
@@ -353,6 +409,54 @@ class StackDetector:
         if pruner is not None and seg_rois.arena is arena:
             seg_rois.pruner = pruner
         return seg_rois
+
+    @classmethod
+    def _detect_chunks(cls, img, chunks, sub_roi_slices, shape3, channel, origins, shapes, stats, finish,
+                       denoise_max_shape, exclude_of, coloc, sink):
+        """The blocks of this rank's share chunk by chunk (``_z_chunks``): planes ``[z_lo, z_hi)`` of the host image as
+        a device volume that answers for the whole image (``DeviceVolume(z_off=...)``), the next chunk's upload started
+        before this one is detected, the tables through per-chunk sinks into the ONE arena (same pruner, same order of
+        landing as the resident path).  Returns the tables of all blocks, in order."""
+        from . import blob_log as bl
+        z_ends_all, y_ends = _upload_cells(sub_roi_slices, shape3)
+
+        def volume(c):
+            k_lo, k_hi, z_lo, z_hi = c
+            cells = ([z - z_lo for z in z_ends_all if z_lo < z < z_hi] + [z_hi - z_lo], y_ends)
+            return bl.DeviceVolume(img[z_lo:z_hi], streamed=True, cells=cells, z_off=z_lo, full_shape=shape3)
+
+        tables = []
+        pruner = None if sink is None else sink.pruner
+        factory = None if sink is None else sink.pruner_factory
+        nxt = volume(chunks[0])
+        cur = None
+        try:
+            for ci, (k_lo, k_hi, z_lo, z_hi) in enumerate(chunks):
+                cur, nxt = nxt, None
+                if ci + 1 < len(chunks):
+                    nxt = volume(chunks[ci + 1])     # (its staging starts once this chunk has queued its last region)
+                part = None
+                if sink is not None:
+                    part = _ArenaSink(sink.arena, sink.grid_coords[k_lo:k_hi], sink.block_offsets[k_lo:k_hi],
+                                      shapes[k_lo:k_hi],
+                                      None if sink.exclude_of is None else (lambda j, k0=k_lo: sink.exclude_of(k0 + j)))
+                    part.pruner, part.pruner_factory = pruner, (factory if pruner is None else None)
+                tables.extend(detector.detect_blobs_blocks_device(
+                    cur, channel, origins[k_lo:k_hi], shapes[k_lo:k_hi], stats,
+                    lambda j, tbl, k0=k_lo: finish(k0 + j, tbl), denoise_max_shape=denoise_max_shape,
+                    exclude=None if exclude_of is None else (lambda j, k0=k_lo: exclude_of(k0 + j)),
+                    coloc=coloc, sink=part, stack_finisher=None))
+                if part is not None and part.pruner is not None:
+                    pruner = part.pruner
+                cur.close()
+                cur = None
+        finally:
+            for v in (cur, nxt):
+                if v is not None:
+                    v.close()
+            if sink is not None:
+                sink.pruner, sink.pruner_factory = pruner, (factory if pruner is None else None)
+        return tables
 
     @staticmethod
     def assemble_seg_rois(local, grid, n_extra: int = 0, arena=None, local_only: bool = False):

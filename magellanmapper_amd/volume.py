@@ -54,11 +54,19 @@ class DeviceVolume:
     refill right after this returns (a double-buffered tile).  ``cells = (z ends, y ends)`` of the caller's block rows
     (optional, streamed uploads only): the image then goes up y-band by y-band within each z-layer of blocks instead of
     in whole z-slabs, and a block can start once the bands it touches have landed.
+
+    ``z_off`` / ``full_shape``: ``image`` holds planes ``[z_off, z_off + nz)`` of a larger ``full_shape = (Z, Y, X)``
+    volume and the object answers for the WHOLE volume -- ``shape`` is the full one, blocks are addressed by their
+    coordinates in it (the views' base pointers are shifted back by ``z_off`` planes), and touching a plane it does not
+    hold is the caller's error.  What a rank's share of a stack (``bench.py``) and a z-chunk of an image too large for
+    the device (``stack_detect``) are.  ``cells`` are then relative to ``image``.
     """
 
     _upload = None          # the z-slab upload still in flight (`_SlabUpload`), if any
+    z_off = 0
 
-    def __init__(self, image, device: Optional["torch.device"] = None, streamed: Optional[bool] = None, cells=None):
+    def __init__(self, image, device: Optional["torch.device"] = None, streamed: Optional[bool] = None, cells=None,
+                 z_off: int = 0, full_shape=None):
         dev = device or _require_gpu()
         want_stream = STREAM_UPLOAD and streamed is not False
         if isinstance(image, torch.Tensor):
@@ -96,6 +104,13 @@ class DeviceVolume:
             raise ValueError("image must be (z, y, x) or (z, y, x, c)")
         self.np_dtype = np_dtype
         self.shape = tuple(self.tensor.shape)
+        if z_off or full_shape is not None:
+            full = tuple(int(v) for v in (full_shape if full_shape is not None else self.shape[:3]))
+            if len(full) != 3 or full[1:] != self.shape[1:3] or z_off < 0 or z_off + self.shape[0] > full[0]:
+                raise ValueError(f"planes [{z_off}, {z_off + self.shape[0]}) of shape {self.shape[:3]} do not lie in a "
+                                 f"volume of shape {full}")
+            self.z_off = int(z_off)
+            self.shape = full + self.shape[3:]
         self.n_channels = self.shape[3] if self.tensor.ndim == 4 else 1
         self._f32 = None
         self._scale = None
@@ -113,7 +128,10 @@ class DeviceVolume:
         up = self._upload
         if up is None:
             return
-        ev = up.event_for_boxes(boxes) if boxes is not None else up.event_for(self.shape[0] if z_hi is None else int(z_hi))
+        if boxes is not None:
+            ev = up.event_for_boxes(self._local_boxes(boxes))
+        else:
+            ev = up.event_for(self.tensor.shape[0] if z_hi is None else int(z_hi) - self.z_off)
         from .buffers import _stream_wait
         for st in (streams or [torch.cuda.current_stream()]):
             if st is not None:
@@ -126,14 +144,20 @@ class DeviceVolume:
         """True when the copies of every region holding voxels of ``boxes`` have been QUEUED (a ``stream_wait`` for
         them would not block the host); always True for a resident volume."""
         up = self._upload
-        return up is None or up.queued_for_boxes(boxes)
+        return up is None or up.queued_for_boxes(self._local_boxes(boxes))
+
+    def _local_boxes(self, boxes):
+        """``(z_lo, z_hi, y_lo, y_hi)`` extents in the whole volume -> in the planes this object holds."""
+        if not self.z_off:
+            return boxes
+        return [(b[0] - self.z_off, b[1] - self.z_off, b[2], b[3]) for b in boxes]
 
     def wait_all(self) -> None:
         """Host-side wait for the whole upload (readers of the voxels outside the batched detection); from here on the
         source is no longer read."""
         up = self._upload
         if up is not None:
-            up.event_for(self.shape[0]).synchronize()
+            up.event_for(self.tensor.shape[0]).synchronize()
             up.finish()
             self._upload = None
 
@@ -196,6 +220,7 @@ class DeviceVolume:
             code = _NP_TO_MMX[self.np_dtype]
         sz, sy, sx = self._strides(t)
         ptr = int(t.data_ptr()) + (int(channel) if self.multichannel else 0) * t.element_size()
+        ptr -= self.z_off * int(sz) * t.element_size()        # (plane z of the whole volume is plane z - z_off here)
         return nat.Volume(ptr, code, 0, int(sz), int(sy), int(sx))
 
 

@@ -431,3 +431,67 @@ def test_native_staging_loop_equals_the_python_loop_and_can_be_cancelled(gpu, mo
     if not up.all_queued():
         with pytest.raises(nat.MmxError, match="cancelled"):
             up.event_for(len(big))
+
+
+@pytest.mark.parametrize("ahead", ["1", "0"])
+@pytest.mark.parametrize("channels,denoise", [(1, None), (1, 25), (2, 25), (2, None)])
+def test_an_image_too_large_to_be_resident_is_detected_z_chunk_by_z_chunk(gpu, monkeypatch, tmp_path, channels, denoise, ahead):
+    """``stack_detect.MAX_RESIDENT_BYTES``: a memory-mapped image larger than the device may hold goes up in chunks of
+    whole block layers, each a device volume of its own that answers for the whole image (``DeviceVolume(z_off=...)``), the
+    next chunk uploading while this one is detected; the tables land in the one arena and are pruned once (ahead, region by
+    region, or at the end).  Same final table -- and co-localisation flags -- as the resident image, row for row; the
+    single-channel raw case also against the oracle."""
+    from magellanmapper_amd import blob_log as bl, config, stack_detect, synth, volume
+    monkeypatch.setattr(volume, "_STREAM_MIN_BYTES", 0)
+    monkeypatch.setattr(stack_detect, "PRUNE_AHEAD", ahead)
+    shape = (230, 72, 80)
+    vol = synth.make_volume(71, shape, 140)
+    if channels == 2:
+        other = synth.make_volume(72, shape, 90)
+        vol = np.stack((vol, np.maximum(other, (vol.astype(np.int32) * 7 // 10).astype(vol.dtype))), axis=-1)
+    np.save(tmp_path / "big.npy", vol[None])
+    config.setup_roi_profiles(None)
+    config.roi_profile.update(dict(num_sigma=3, denoise_size=denoise, segment_size=40))
+    for p in config.roi_profiles:
+        p.update(config.roi_profile)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "big"
+    monkeypatch.setattr(config, "near_max", [-1.0] * channels)
+    chans = list(range(channels))
+
+    def run():
+        img5d = stack_detect.Image5d(np.load(tmp_path / "big.npy", mmap_mode="r"))
+        _, _, blobs = stack_detect.detect_blobs_blocks("big", img5d, None, None, chans, False, False, True, channels > 1)
+        return blobs
+
+    made = []
+    init = bl.DeviceVolume.__init__
+
+    def spy(self, *a, **k):
+        init(self, *a, **k)
+        made.append((self.z_off, self.tensor.shape[0]))
+    monkeypatch.setattr(bl.DeviceVolume, "__init__", spy)
+    try:
+        monkeypatch.setattr(stack_detect, "MAX_RESIDENT_BYTES", 1 << 40)
+        whole = run()
+        # (blocks whose overlap prune falls back to SciPy's pair order make small volumes of their own)
+        assert all(m[0] == 0 for m in made) and made[0][1] == shape[0]
+        del made[:]
+        plane = int(np.prod(vol.shape[1:])) * 2
+        monkeypatch.setattr(stack_detect, "MAX_RESIDENT_BYTES", 200 * plane)     # (230 planes: two block layers per chunk)
+        parts = run()
+        chunks = [m for m in made if m[0] > 0]
+        assert made[0][0] == 0 and made[0][1] < shape[0] and len(chunks) >= 2
+        assert all(b[0] > a[0] for a, b in zip(chunks, chunks[1:])) and chunks[-1][0] + chunks[-1][1] == shape[0]
+        assert max(n for _, n in made) < shape[0]
+        assert whole.blobs is not None and len(whole.blobs) > 100
+        np.testing.assert_array_equal(parts.blobs, whole.blobs)
+        if channels > 1:
+            np.testing.assert_array_equal(parts.colocalizations, whole.colocalizations)
+        if channels == 1 and denoise is None:
+            from oracle import magmap_oracle as mmo
+            want, _ = mmo.detect_blobs_blocks(vol, None, [dict(config.roi_profile)], config.resolutions)
+            key = lambda t: t[np.lexsort(tuple(t[:, i] for i in range(t.shape[1] - 1, -1, -1)))]
+            np.testing.assert_array_equal(key(parts.blobs), key(want))
+    finally:
+        config.setup_roi_profiles(None)

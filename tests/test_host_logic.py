@@ -1759,3 +1759,32 @@ def test_stable_peak_order_switch_on_constructed_ties(monkeypatch):
         bl.Lane(0, 3.0, 3.0, 1, -0.5, 0.5)
     monkeypatch.setattr(hr, "PEAK_ORDER", "0.18")
     bl.Lane(0, 3.0, 3.0, 1, -0.5, 0.5)          # (the default takes any threshold)
+
+
+def test_z_chunks_are_whole_block_layers_within_the_byte_limit():
+    """``stack_detect._z_chunks``: the blocks of a share (z-major) cut into runs of whole layers whose planes fit half the
+    limit; a layer that does not fit stands alone; every block is in exactly one chunk and the chunk's planes cover it."""
+    from magellanmapper_amd import config, roi_prof, stack_detect as sd
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    shape = (230, 90, 100)
+    bl_ = sd.setup_blocks(roi_prof.ROIProfile(segment_size=50, denoise_size=None), shape)
+    coords = sd.StackDetector._grid_coords(bl_.sub_roi_slices.shape)
+    for mine in (list(range(len(coords))), list(range(5, len(coords) - 3))):
+        origins, shapes = sd.StackDetector._block_extents(bl_.sub_roi_slices, shape, mine)
+        plane = 90 * 100 * 2
+        for planes in (10, 70, 130, 10 ** 6):
+            chunks = sd._z_chunks(coords, mine, origins, shapes, plane, 2 * planes * plane)
+            assert chunks[0][0] == 0 and chunks[-1][1] == len(mine)
+            assert all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
+            for k_lo, k_hi, z_lo, z_hi in chunks:
+                layers = {coords[mine[k]][0] for k in range(k_lo, k_hi)}
+                assert layers == set(range(min(layers), max(layers) + 1))
+                # whole layers: no layer is shared with a neighbouring chunk
+                assert not any(coords[mine[k]][0] in layers for k in list(range(0, k_lo)) + list(range(k_hi, len(mine))))
+                for k in range(k_lo, k_hi):
+                    assert z_lo <= origins[k][0] and origins[k][0] + shapes[k][0] <= z_hi
+                assert len(layers) == 1 or (z_hi - z_lo) <= planes
+            if planes == 10 ** 6:
+                assert len(chunks) == 1
+            if planes == 10:
+                assert len(chunks) == len({coords[i][0] for i in mine})
