@@ -319,18 +319,13 @@ def run_gpu(name, args, host_vol, baseline, steps, warmup, ctx):
     t_gen = time.time() - t_gen
 
     # A rank-local view that behaves like the full (z, y, x[, c]) ROI for block addressing.
+    # (DeviceVolume(z_off=, full_shape=): the planes a rank holds, addressed by their coordinates in the whole volume)
     class SlabVolume(bl.DeviceVolume):
         def __init__(self, t, z_off, full_shape):
             # (host sources -- `--from-host` -- go up beside the detection: this script leaves them alone meanwhile)
             super().__init__(t, dev, streamed=True,
-                             cells=None if args.upload_order == "slabs" else stack_detect._upload_cells(blocks.sub_roi_slices, full_shape))
-            self.z_off = z_off
-            self.shape = tuple(full_shape) + tuple(t.shape[3:])
-
-        def view(self, channel, for_f32_passes):
-            v = super().view(channel, for_f32_passes)
-            v.d_data = v.d_data - self.z_off * self.tensor.stride()[0] * self.tensor.element_size()
-            return v
+                             cells=None if args.upload_order == "slabs" else stack_detect._upload_cells(blocks.sub_roi_slices, full_shape),
+                             z_off=z_off, full_shape=tuple(full_shape)[:3])
 
     dvol = SlabVolume(slab, z0, shape)
     timers = {"gather_ms": 0.0, "prune_ms": 0.0, "detect_ms": 0.0, "tail_ms": 0.0, "tail_exchange_ms": 0.0,
