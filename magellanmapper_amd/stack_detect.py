@@ -344,12 +344,22 @@ class StackDetector:
             chunks = None
             if isinstance(img, bl.DeviceVolume):
                 dvol = img
-            elif _image_bytes(img) > _resident_limit() and len({coords[i][0] for i in mine}) > 1:
-                # too large to be resident: whole layers of blocks at a time, each from a device volume of its own
-                plane = _image_bytes(img) // max(1, int(img.shape[0]))
-                chunks = _z_chunks(coords, mine, origins, shapes, plane, _resident_limit())
-                dvol = None
             else:
+                # the planes this rank's blocks touch (all of them without torch.distributed)
+                z_lo = min(int(o[0]) for o in origins)
+                z_hi = max(int(o[0]) + int(s_[0]) for o, s_ in zip(origins, shapes))
+                plane = _image_bytes(img) // max(1, int(img.shape[0]))
+                dvol = None
+                on_host = getattr(getattr(img, "device", None), "type", "cpu") == "cpu"     # (not a tensor on a device)
+                if not on_host:
+                    pass
+                elif (z_hi - z_lo) * plane > _resident_limit() and len({coords[i][0] for i in mine}) > 1:
+                    # too large to be resident: whole layers of blocks at a time, each from a device volume of its own
+                    chunks = _z_chunks(coords, mine, origins, shapes, plane, _resident_limit())
+                elif z_lo > 0 or z_hi < int(shape3[0]):
+                    # a rank's share of a host image: only its planes go up (over this rank's own link)
+                    chunks = [(0, len(mine), z_lo, z_hi)]
+            if chunks is None and dvol is None:
                 # a host image handed over for the length of this call: it goes up beside the detection of the blocks
                 # that have landed, and whatever of it this rank's blocks never touched is cancelled before returning
                 dvol = own_dvol = bl.DeviceVolume(img, streamed=True, cells=_upload_cells(sub_roi_slices, shape3))

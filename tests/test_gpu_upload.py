@@ -495,3 +495,88 @@ def test_an_image_too_large_to_be_resident_is_detected_z_chunk_by_z_chunk(gpu, m
             np.testing.assert_array_equal(key(parts.blobs), key(want))
     finally:
         config.setup_roi_profiles(None)
+
+
+_SLAB_RANK_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+import torch.distributed as td
+from magellanmapper_amd import blob_log as bl, config, dist, stack_detect, volume
+from oracle import magmap_oracle as mmo
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                            # (both ranks share the one GPU of a test box)
+td.init_process_group("gloo")
+try:
+    c5 = {c5!r}
+    volume._STREAM_MIN_BYTES = 0
+    config.setup_roi_profiles(None)
+    profile = dict(num_sigma=3, denoise_size=25 if c5 else None, segment_size=40)
+    config.roi_profile.update(profile)
+    for p in config.roi_profiles:
+        p.update(profile)
+    config.resolutions = np.array([[1.0, 1.0, 1.0]])
+    config.filename = "slab"
+    config.near_max = [-1.0, -1.0]
+    made = []
+    init = bl.DeviceVolume.__init__
+    def spy(self, *a, **k):
+        init(self, *a, **k)
+        made.append((self.z_off, self.tensor.shape[0], self.shape[0]))
+    bl.DeviceVolume.__init__ = spy
+    img5d = stack_detect.Image5d(np.load(os.path.join({tmp!r}, "whole.npy"), mmap_mode="r"))
+    chans = [0, 1] if c5 else [0]
+    _, _, blobs = stack_detect.detect_blobs_blocks("slab", img5d, None, None, chans, False, False, True, c5)
+    # this rank's planes only: rank 0 from plane 0, rank 1 from further up, neither the whole image
+    z_off, planes, full = made[0]
+    assert full == 160 and planes < 160 and (z_off == 0) == (rank == 0), made[0]
+    vol = np.load(os.path.join({tmp!r}, "whole.npy"))[0]
+    profiles = [dict(config.roi_profile)] * len(chans)
+    if rank == 0:
+        if c5:
+            want, stages = mmo.detect_blobs_blocks(vol, [0, 1], profiles, config.resolutions, near_max=[-1.0, -1.0],
+                                                   coloc=True)
+            np.testing.assert_array_equal(blobs.blobs, want)
+            np.testing.assert_array_equal(blobs.colocalizations, stages["colocs"])
+        else:
+            want, _ = mmo.detect_blobs_blocks(vol, None, profiles, config.resolutions)
+            key = lambda t: np.lexsort(tuple(t[:, i] for i in range(t.shape[1] - 1, -1, -1)))
+            np.testing.assert_array_equal(blobs.blobs[key(blobs.blobs)], want[key(want)])
+        assert len(want) > 30
+    torch.cuda.synchronize()
+    print(f"SLAB_RANK_OK {{rank}} {{z_off}} {{planes}}", flush=True)
+finally:
+    td.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("c5", [False, True])
+def test_two_ranks_upload_only_their_own_planes_of_a_memory_mapped_image(gpu, tmp_path, c5):
+    """The BLOCK split of one host image over two ranks (gloo, sharing this GPU): every rank's device volume holds the
+    planes its own blocks touch and answers for the whole image (``DeviceVolume(z_off=...)``) -- a rank of N uploads a
+    N-th of the image over its own link, not the image up to its share's end -- and rank 0's final table (C5-shaped: with
+    the co-localisation flags) equals the oracle's for the whole image."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from magellanmapper_amd import synth
+    shape = (160, 72, 80)
+    c0 = synth.make_volume(91, shape, 110)
+    if c5:
+        c1 = np.maximum(synth.make_volume(92, shape, 80).astype(np.int32), (c0.astype(np.int32) * 7) // 10)
+        c0 = np.stack((c0, c1.astype(np.uint16)), axis=-1)
+    np.save(tmp_path / "whole.npy", c0[None])
+    script = tmp_path / "slab_ranks.py"
+    script.write_text(_SLAB_RANK_SCRIPT.format(root=ROOT, tmp=str(tmp_path), c5=c5))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    assert "SLAB_RANK_OK 0 0 " in run.stdout and "SLAB_RANK_OK 1 " in run.stdout
