@@ -24,6 +24,7 @@ rng = np.random.default_rng(a.seed)
 os.chdir(tempfile.mkdtemp())
 bad = 0
 rows = 0
+n_chunked = 0
 t0 = time.time()
 
 
@@ -95,6 +96,10 @@ for trial in range(a.trials):
             elif how < 0.66:
                 src = vol[None].copy()
                 src.flags.writeable = False
+        # ... or z-chunk by z-chunk, as an image too large to be resident would go (whole block layers, a device volume each)
+        chunked = rng.random() < 0.3
+        stack_detect.MAX_RESIDENT_BYTES = int(rng.integers(12, 60)) * vol[0].nbytes if chunked else None
+        n_chunked += chunked
         img5d = stack_detect.Image5d(src)
         _, _, blobs = stack_detect.detect_blobs_blocks("soak", img5d, None, None, None, False, False, True, coloc)
     except NotImplementedError as e:      # a combination this build states it does not cover
@@ -113,6 +118,6 @@ for trial in range(a.trials):
         if a.dump:
             np.savez_compressed(f"{a.dump}_{a.seed}_{trial}.npz", vol=vol, res=res, got=np.zeros(0) if got is None else got,
                                 want=np.zeros(0) if want is None else want, over=repr(over), coloc=coloc, unmix=repr(unmix))
-print(f"stack soak seed {a.seed}: {a.trials} trials, {rows} final blob rows compared, {bad} mismatching stacks, "
+print(f"stack soak seed {a.seed}: {a.trials} trials ({n_chunked} of them z-chunk by z-chunk), {rows} final blob rows compared, {bad} mismatching stacks, "
       f"{time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
