@@ -73,23 +73,38 @@ class Image5d:
         #: the first time point already on its way to the device (`prefetch`): what a whole-image detection then reads
         self.device_volume = None
 
-    def prefetch(self):
+    def prefetch(self, own_planes: bool = False):
         """Start the upload of the first time point now (``blob_log.DeviceVolume``: block row by block row on a copy
         stream); a later whole-image ``detect_blobs_blocks`` / ``detect_blobs_stack`` of this image detects on it while
         the rest is still in flight.  What `detect_blobs_tiles` calls for tile k + 1 before it detects tile k.  The image
         must stay as it is until the detection has returned or :meth:`release` has been called (the upload reads it in
-        the background)."""
+        the background).  ``own_planes``: with a process group, only the planes the blocks of THIS rank's share touch
+        (the block split of a whole-image detection; not for a tile a rank detects alone)."""
         from . import blob_log as bl
+        from . import dist
         if self.device_volume is None and self.img is not None:
             if _image_bytes(self.img[0]) > _resident_limit():
                 return self             # (too large to be resident: detected z-chunk by z-chunk from the host)
-            cells = None
+            shape3 = tuple(int(v) for v in self.img.shape[1:4])
+            cells = blocks = None
             try:        # (where the first channel's profile puts the block rows: only the upload ORDER depends on it)
-                blocks = setup_blocks(config.get_roi_profile(0), self.img.shape[1:4])
-                cells = _upload_cells(blocks.sub_roi_slices, self.img.shape[1:4])
+                blocks = setup_blocks(config.get_roi_profile(0), shape3)
+                cells = _upload_cells(blocks.sub_roi_slices, shape3)
             except Exception:
                 pass
-            self.device_volume = bl.DeviceVolume(self.img[0], streamed=True, cells=cells)
+            if own_planes and blocks is not None and dist.world_size() > 1:
+                grid = blocks.sub_roi_slices.shape
+                coords = grid_coords(grid)
+                mine = dist.my_share(len(coords))
+                if not mine:
+                    return self
+                ext = [blocks.sub_roi_slices[coords[i]][0].indices(shape3[0])[:2] for i in mine]
+                z_lo, z_hi = min(e[0] for e in ext), max(e[1] for e in ext)
+                cells = ([z - z_lo for z in cells[0] if z_lo < z < z_hi] + [z_hi - z_lo], cells[1])
+                self.device_volume = bl.DeviceVolume(self.img[0][z_lo:z_hi], streamed=True, cells=cells, z_off=z_lo,
+                                                     full_shape=shape3)
+            else:
+                self.device_volume = bl.DeviceVolume(self.img[0], streamed=True, cells=cells)
         return self
 
     def release(self):
@@ -344,6 +359,15 @@ class StackDetector:
             chunks = None
             if isinstance(img, bl.DeviceVolume):
                 dvol = img
+                held = (int(dvol.z_off), int(dvol.z_off) + int(dvol.tensor.shape[0]))
+                if held != (0, int(shape3[0])):
+                    # a volume that holds some planes only (Image5d.prefetch(own_planes=True), a rank's slab): they
+                    # must be the ones this rank's blocks touch
+                    z_lo = min(int(o[0]) for o in origins)
+                    z_hi = max(int(o[0]) + int(s_[0]) for o, s_ in zip(origins, shapes))
+                    if z_lo < held[0] or z_hi > held[1]:
+                        raise nat.MmxError(f"the device volume holds planes [{held[0]}, {held[1]}) but this rank's blocks "
+                                           f"touch [{z_lo}, {z_hi})")
             else:
                 # the planes this rank's blocks touch (all of them without torch.distributed)
                 z_lo = min(int(o[0]) for o in origins)
@@ -779,13 +803,15 @@ def detect_blobs_tiles(filename_bases, tiles, channels=None, coloc: bool = False
 
     cur = nxt = None
     try:
+        own = not by_tile and dist.world_size() > 1      # (every tile's BLOCKS over all ranks: a rank's planes only)
         k, cur = next(it, (0, None))
+        prefetch = (lambda t: t.prefetch(own_planes=True)) if own else (lambda t: t.prefetch())
         if cur is not None:
-            cur.prefetch()
+            prefetch(cur)
         while cur is not None:
             k_nxt, nxt = next(it, (0, None))
             if nxt is not None:
-                nxt.prefetch()                      # (its copies are queued on its own stream before tile k's kernels)
+                prefetch(nxt)                       # (its copies are queued on its own stream before tile k's kernels)
             _, _, blobs = detect(base_of(k), cur)
             cur.release()                           # (the tile's voxels leave the device with it)
             yield k, blobs

@@ -468,7 +468,7 @@ class _FakeTile:
     def __init__(self, k, log):
         self.k, self.log, self.device_volume = k, log, None
 
-    def prefetch(self):
+    def prefetch(self, own_planes=False):
         self.log.append(("prefetch", self.k))
         self.device_volume = object()
         return self

@@ -544,6 +544,20 @@ try:
             key = lambda t: np.lexsort(tuple(t[:, i] for i in range(t.shape[1] - 1, -1, -1)))
             np.testing.assert_array_equal(blobs.blobs[key(blobs.blobs)], want[key(want)])
         assert len(want) > 30
+    # the same image twice as the tiles of a stack, every tile's BLOCKS over both ranks: the prefetch of a tile takes this
+    # rank's planes only as well, the next tile's while this one is detected
+    del made[:]
+    tiles = [stack_detect.Image5d(np.load(os.path.join({tmp!r}, "whole.npy"), mmap_mode="r")) for _ in range(2)]
+    n_seen = 0
+    for k, tb in stack_detect.detect_blobs_tiles("slabtiles", tiles, chans, c5, False, shard=None):
+        if rank == 0:
+            np.testing.assert_array_equal(tb.blobs, blobs.blobs)
+            if c5:
+                np.testing.assert_array_equal(tb.colocalizations, blobs.colocalizations)
+        n_seen += 1
+    slabs = [m for m in made if m[2] == 160 and m[1] < 160]
+    assert n_seen == 2 and len(slabs) == 2 and all((m[0] == 0) == (rank == 0) for m in slabs), made
+    assert not any(m[1] == 160 for m in made)               # nobody uploaded a whole tile
     torch.cuda.synchronize()
     print(f"SLAB_RANK_OK {{rank}} {{z_off}} {{planes}}", flush=True)
 finally:
