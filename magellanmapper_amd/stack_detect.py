@@ -31,7 +31,7 @@ from . import chunking, config, detector, roi_prof
 from . import stack_prune
 # (the reference keeps the pruner in this module, magmap/cv/stack_detect.py:618-861: same import path here)
 from .stack_prune import StackPruner, _FinalTable, _RegionPruner, _region_reach, _region_workers, _rows_within, grid_coords
-from .stack_tables import _ArenaSink, _StackFinisher, _TableArena
+from .stack_tables import _ArenaSink, _ArenaSinkPart, _StackFinisher, _TableArena
 
 _logger = config.logger.getChild(__name__)
 
@@ -460,8 +460,6 @@ class StackDetector:
             return bl.DeviceVolume(img[z_lo:z_hi], streamed=True, cells=cells, z_off=z_lo, full_shape=shape3)
 
         tables = []
-        pruner = None if sink is None else sink.pruner
-        factory = None if sink is None else sink.pruner_factory
         nxt = volume(chunks[0])
         cur = None
         try:
@@ -469,27 +467,18 @@ class StackDetector:
                 cur, nxt = nxt, None
                 if ci + 1 < len(chunks):
                     nxt = volume(chunks[ci + 1])     # (its staging starts once this chunk has queued its last region)
-                part = None
-                if sink is not None:
-                    part = _ArenaSink(sink.arena, sink.grid_coords[k_lo:k_hi], sink.block_offsets[k_lo:k_hi],
-                                      shapes[k_lo:k_hi],
-                                      None if sink.exclude_of is None else (lambda j, k0=k_lo: sink.exclude_of(k0 + j)))
-                    part.pruner, part.pruner_factory = pruner, (factory if pruner is None else None)
+                part = None if sink is None else _ArenaSinkPart(sink, k_lo, k_hi)
                 tables.extend(detector.detect_blobs_blocks_device(
                     cur, channel, origins[k_lo:k_hi], shapes[k_lo:k_hi], stats,
                     lambda j, tbl, k0=k_lo: finish(k0 + j, tbl), denoise_max_shape=denoise_max_shape,
                     exclude=None if exclude_of is None else (lambda j, k0=k_lo: exclude_of(k0 + j)),
                     coloc=coloc, sink=part, stack_finisher=None))
-                if part is not None and part.pruner is not None:
-                    pruner = part.pruner
                 cur.close()
                 cur = None
         finally:
             for v in (cur, nxt):
                 if v is not None:
                     v.close()
-            if sink is not None:
-                sink.pruner, sink.pruner_factory = pruner, (factory if pruner is None else None)
         return tables
 
     @staticmethod

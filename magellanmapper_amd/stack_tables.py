@@ -246,6 +246,24 @@ class _ArenaSink:
         return out
 
 
+class _ArenaSinkPart(_ArenaSink):
+    """Blocks ``[k_lo, k_hi)`` of a sink's share as a sink of their own (block indices start at 0 again): the same arena,
+    and ONE pruner whoever makes it first -- a chunk's native tables, or the parent through ``finish()`` for tables built
+    in Python (what a stack detected z-chunk by z-chunk hands each chunk's detection, ``stack_detect._detect_chunks``)."""
+
+    def __init__(self, parent: _ArenaSink, k_lo: int, k_hi: int):
+        self.parent = parent
+        self.arena = parent.arena
+        self.grid_coords = parent.grid_coords[k_lo:k_hi]
+        self.block_offsets = parent.block_offsets[k_lo:k_hi]
+        self.shapes = parent.shapes[k_lo:k_hi]
+        self.exclude_of = None if parent.exclude_of is None else (lambda j: parent.exclude_of(k_lo + j))
+
+    pruner = property(lambda self: self.parent.pruner, lambda self, v: setattr(self.parent, "pruner", v))
+    pruner_factory = property(lambda self: self.parent.pruner_factory,
+                              lambda self, v: setattr(self.parent, "pruner_factory", v))
+
+
 class _StackFinisher:
     """A SMALL stack -- all its blocks in one batch (the GUI's ROI, a grid-search step) -- from the re-scored candidates
     to the final table in ONE native call (``mmx_host_finish_stack``: peak decisions, per-block overlap prune, block
